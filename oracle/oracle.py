@@ -1,0 +1,271 @@
+"""ctypes front-end for the CPU oracle (oracle/libdeftet_oracle.so) and oracle/_ref.
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  Nothing in deftet_amd/ imports this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libdeftet_oracle.so")
+REF_DIR = os.path.join(HERE, "_ref")
+
+_f32p = C.POINTER(C.c_float)
+_i32p = C.POINTER(C.c_int32)
+_i64p = C.POINTER(C.c_int64)
+_f64p = C.POINTER(C.c_double)
+
+
+def build(force: bool = False) -> None:
+    """Compile the restatement and (when /root/reference is present) oracle/_ref."""
+    src = [os.path.join(HERE, f) for f in ("deftet_oracle.c", "deftet_oracle_surface.c", "Makefile")]
+    stale = (not os.path.exists(LIB_PATH) or
+             any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in src))
+    need_ref = os.path.isdir("/root/reference/utils/lib") and not all(
+        os.path.exists(os.path.join(REF_DIR, n + "_run.so"))
+        for n in ("tet_adj_share", "tet_face_adj", "tet_point_adj", "colaps_v"))
+    if force or stale or need_ref:
+        subprocess.check_call(["make", "-s", "-C", HERE, "all"])
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(LIB_PATH)
+        _lib.oracle_point_in_tet_f32_omp.restype = C.c_int
+    return _lib
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+def _c(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+# --------------------------------------------------------------------------- A1 / A1b
+def point_in_tet(tet_bxtx4x3, pts_bxqx3, omp=False, return_executed=False):
+    tet = _c(tet_bxtx4x3, np.float32)
+    pts = _c(pts_bxqx3, np.float32)
+    B, T = tet.shape[0], tet.shape[1]
+    Q = pts.shape[1]
+    out = np.empty((B, Q, 1), np.float32)
+    if omp:
+        n = lib().oracle_point_in_tet_f32_omp(_p(tet, _f32p), _p(pts, _f32p), _p(out, _f32p), B, T, Q)
+        return (out, n) if return_executed else out
+    ex = C.c_longlong(0)
+    lib().oracle_point_in_tet_f32(_p(tet, _f32p), _p(pts, _f32p), _p(out, _f32p), B, T, Q, C.byref(ex))
+    return (out, ex.value) if return_executed else out
+
+
+def point_in_tet_margin(tet_tx4x3, pts_qx3):
+    tet = _c(tet_tx4x3, np.float32)
+    pts = _c(pts_qx3, np.float32)
+    out = np.empty(pts.shape[0], np.float64)
+    lib().oracle_point_in_tet_margin_f32(_p(tet, _f32p), _p(pts, _f32p), _p(out, _f64p),
+                                         tet.shape[0], pts.shape[0])
+    return out
+
+
+def bary(tet_bxtx4x3, pts_bxqx3, cond_bxq):
+    tet = _c(tet_bxtx4x3, np.float32)
+    pts = _c(pts_bxqx3, np.float32)
+    cond = _c(cond_bxq, np.float32).reshape(pts.shape[0], pts.shape[1])
+    out = np.empty(pts.shape[:2] + (4,), np.float32)
+    lib().oracle_bary_f32(_p(tet, _f32p), _p(pts, _f32p), _p(cond, _f32p), _p(out, _f32p),
+                          tet.shape[0], tet.shape[1], pts.shape[1])
+    return out
+
+
+def bary_torch(a, b, c, d, p):
+    """Restatement of /root/reference/utils/tet_utils.py:25-45 on torch tensors
+    (any dtype) — the autograd oracle for A1b."""
+    import torch
+
+    def triple(x, y, z):
+        return torch.sum(x * torch.cross(y, z, dim=-1), dim=-1)
+
+    vap, vbp = p - a, p - b
+    vab, vac, vad = b - a, c - a, d - a
+    vbc, vbd = c - b, d - b
+    va6 = triple(vbp, vbd, vbc)
+    vb6 = triple(vap, vac, vad)
+    vc6 = triple(vap, vad, vab)
+    vd6 = triple(vap, vab, vac)
+    v6 = 1 / triple(vab, vac, vad)
+    return va6 * v6, vb6 * v6, vc6 * v6, vd6 * v6
+
+
+def point_in_tet_bwd_torch(tet_bxtx4x3, pts_bxqx3, cond_bxq, grad_w_bxqx4, dtype=None):
+    """dL/dtet [B,T,4,3] by torch autograd through bary_torch + gather.
+    Misses (cond < 0) contribute nothing."""
+    import torch
+    dtype = dtype or torch.float64
+    tet = torch.as_tensor(np.asarray(tet_bxtx4x3)).to(dtype).clone().requires_grad_(True)
+    pts = torch.as_tensor(np.asarray(pts_bxqx3)).to(dtype)
+    cond = torch.as_tensor(np.asarray(cond_bxq)).reshape(pts.shape[0], pts.shape[1])
+    gw = torch.as_tensor(np.asarray(grad_w_bxqx4)).to(dtype)
+    hit = cond >= 0
+    idx = cond.clamp(min=0).long()
+    g = torch.gather(tet, 1, idx[:, :, None, None].expand(-1, -1, 4, 3))
+    w = torch.stack(bary_torch(g[:, :, 0], g[:, :, 1], g[:, :, 2], g[:, :, 3], pts), -1)
+    loss = (w * gw * hit[..., None].to(dtype)).sum()
+    loss.backward()
+    return w.detach().numpy(), tet.grad.numpy()
+
+
+# --------------------------------------------------------------------------- builders
+def tet_adj_share(tet_list, n_point):
+    tet = _c(tet_list, np.int32)
+    T = tet.shape[0]
+    out = np.zeros((T * 8, 3), np.int32)
+    n = np.zeros(1, np.int32)
+    lib().oracle_tet_adj_share(_p(tet, _i32p), _p(out, _i32p), _p(n, _i32p), int(n_point), T)
+    return out[: n[0] * 2]
+
+
+def tet_face_adj(tet_list, n_point, wrap32=True):
+    tet = _c(tet_list, np.int32)
+    T = tet.shape[0]
+    cnt = C.c_longlong(0)
+    lib().oracle_tet_face_adj(_p(tet, _i32p), None, C.byref(cnt), int(n_point), T, int(wrap32))
+    out = np.zeros((max(cnt.value, 1), 2), np.int32)
+    lib().oracle_tet_face_adj(_p(tet, _i32p), _p(out, _i32p), C.byref(cnt), int(n_point), T, int(wrap32))
+    return out[: cnt.value]
+
+
+def tet_point_adj(tet_list, n_point):
+    tet = _c(tet_list, np.int32)
+    T = tet.shape[0]
+    out = np.zeros((max(T * 12, 1), 2), np.int32)
+    n = np.zeros(1, np.int32)
+    lib().oracle_tet_point_adj(_p(tet, _i32p), _p(out, _i32p), _p(n, _i32p), int(n_point), T)
+    return out[: n[0]]
+
+
+def colaps_v(points_nx3):
+    pts = _c(points_nx3, np.float32)
+    N = pts.shape[0]
+    m = np.zeros(N, np.int32)
+    inv = np.zeros(N, np.int32)
+    n = np.zeros(1, np.int32)
+    lib().oracle_colaps_v(_p(pts, _f32p), _p(m, _i32p), _p(inv, _i32p), _p(n, _i32p), N)
+    return m, inv[: n[0]]
+
+
+def tet_to_face(tet_list, n_point, with_boundary=False):
+    tet = _c(tet_list, np.int32)
+    T = tet.shape[0]
+    f3 = np.zeros((T * 4, 3), np.int64)
+    t2 = np.zeros((T * 4, 2), np.int64)
+    tf2 = np.zeros((T * 4, 2), np.int64)
+    b3 = np.zeros((T * 4, 3), np.int64)
+    nf, nb, nm = (np.zeros(1, np.int32) for _ in range(3))
+    lib().oracle_tet_to_face(_p(tet, _i32p), int(n_point), T, int(with_boundary), _p(f3, _i64p), _p(t2, _i64p),
+                             _p(tf2, _i64p), _p(b3, _i64p), _p(nf, _i32p), _p(nb, _i32p), _p(nm, _i32p))
+    return f3[: nf[0]], t2[: nf[0]], tf2[: nf[0]], b3[: nb[0]], int(nm[0])
+
+
+# --------------------------------------------------------------------------- surface ops
+def face_edge_adj(face_fx3x3, n_max_nei=30):
+    face = _c(face_fx3x3, np.float32)
+    F = face.shape[0]
+    adj = -np.ones((F, n_max_nei), np.float32)
+    lib().oracle_face_edge_adj_f32(_p(face, _f32p), _p(adj, _f32p), F, n_max_nei)
+    return adj
+
+
+def tri_dist_fwd(pts_bxpx3, face_bxfx3x3, n_face_b):
+    pts = _c(pts_bxpx3, np.float32)
+    face = _c(face_bxfx3x3, np.float32)
+    nfb = _c(n_face_b, np.float32)
+    B, P = pts.shape[:2]
+    d = np.zeros((B, P, 1), np.float32)
+    f = np.zeros((B, P, 1), np.float32)
+    lib().oracle_tri_dist_fwd_f32(_p(pts, _f32p), _p(face, _f32p), _p(nfb, _f32p), _p(d, _f32p), _p(f, _f32p),
+                                  B, P, face.shape[1])
+    return d, f
+
+
+def tri_dist_bwd(pts_bxpx3, face_bxfx3x3, closest_f, dl_dd):
+    pts = _c(pts_bxpx3, np.float32)
+    face = _c(face_bxfx3x3, np.float32)
+    cf = _c(closest_f, np.float32)
+    g = _c(dl_dd, np.float32)
+    B, P = pts.shape[:2]
+    out = np.zeros(face.shape, np.float32)
+    lib().oracle_tri_dist_bwd_f32(_p(pts, _f32p), _p(face, _f32p), _p(cf, _f32p), _p(g, _f32p), _p(out, _f32p),
+                                  B, P, face.shape[1])
+    return out
+
+
+def nn_index(queries_bxnx3, points_bxmx3):
+    q = _c(queries_bxnx3, np.float32)
+    p = _c(points_bxmx3, np.float32)
+    B, N = q.shape[:2]
+    out = np.zeros((B, N), np.int32)
+    lib().oracle_nn_index_f32(_p(q, _f32p), _p(p, _f32p), _p(out, _i32p), B, N, p.shape[1])
+    return out
+
+
+# --------------------------------------------------------------------------- oracle/_ref
+class RefBuilders:
+    """The reference's own native builders (utils/lib/*/run.cpp) compiled by
+    oracle/Makefile into oracle/_ref/.  Same buffer sizing as the reference's
+    interface.py files."""
+
+    def __init__(self):
+        def load(n):
+            path = os.path.join(REF_DIR, n + "_run.so")
+            if not os.path.exists(path):
+                raise FileNotFoundError(path)
+            return C.CDLL(path)
+        self.adj_share = load("tet_adj_share")
+        self.face_adj = load("tet_face_adj")
+        self.point_adj = load("tet_point_adj")
+        self.colaps = load("colaps_v")
+
+    @staticmethod
+    def available():
+        return all(os.path.exists(os.path.join(REF_DIR, n + "_run.so"))
+                   for n in ("tet_adj_share", "tet_face_adj", "tet_point_adj", "colaps_v"))
+
+    def tet_adj_share(self, tet_list, n_point):           # utils/lib/tet_adj_share/interface.py:19-37
+        tet = _c(tet_list, np.int32)
+        out = np.zeros((tet.shape[0] * 8, 3), np.int32)
+        n = np.zeros(1, np.int32)
+        self.adj_share.run(_p(tet, _i32p), _p(out, _i32p), _p(n, _i32p), C.c_int(int(n_point)), C.c_int(tet.shape[0]))
+        return out[: n[0] * 2]
+
+    def tet_face_adj(self, tet_list, n_point):            # utils/lib/tet_face_adj/interface.py:20-32
+        tet = _c(tet_list, np.int32)
+        out = np.zeros((tet.shape[0] * 4 * 50, 2), np.int32)
+        n = np.zeros(1, np.int32)
+        self.face_adj.run(_p(tet, _i32p), _p(out, _i32p), _p(n, _i32p), C.c_int(int(n_point)), C.c_int(tet.shape[0]))
+        return out[: n[0]]
+
+    def tet_point_adj(self, tet_list, n_point):           # utils/lib/tet_point_adj/interface.py:20-39
+        tet = _c(tet_list, np.int32)
+        out = np.zeros((tet.shape[0] * 12, 2), np.int32)
+        n = np.zeros(1, np.int32)
+        self.point_adj.run(_p(tet, _i32p), _p(out, _i32p), _p(n, _i32p), C.c_int(int(n_point)), C.c_int(tet.shape[0]))
+        return out[: n[0]]
+
+    def colaps_v(self, points_nx3):                       # utils/lib/colaps_v/interface.py:20-35
+        pts = _c(points_nx3, np.float32)
+        N = pts.shape[0]
+        m = np.zeros(N, np.int32)
+        inv = np.zeros(N, np.int32)
+        n = np.zeros(1, np.int32)
+        self.colaps.run(_p(pts, _f32p), _p(m, _i32p), _p(inv, _i32p), _p(n, _i32p), C.c_int(N))
+        return m, inv[: n[0]]
