@@ -1,0 +1,177 @@
+#!/usr/bin/env python
+"""bench.py — headline benchmark of the DefTet per-tetrahedron hot path on MI355X.
+
+Metric (BASELINE.json): M tet-point tests/s (fwd+bwd) at res=70, 100k queries.
+One "step" = one pass of the hot path over one batch of B=8 synthetic shapes per GPU:
+    fwd : point-in-tet index (A1) + barycentric weights of the hit tet + paste_occ gather
+    bwd : dL/dtet scatter (A1b) + dL/dpred scatter (paste_occ backward)
+`value` counts NOMINAL tet-point pairs B*T*Q per step (what the reference's brute-force
+kernel enumerates), inputs resident in HBM, acceleration-structure build included.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+RES, N_QUERY, BATCH = 70, 100_000, 8          # BASELINE.json configs[2]
+HBM_PEAK_GBS = 8000.0                         # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def make_inputs(rank, device, res=RES, n_query=N_QUERY, batch=BATCH):
+    from deftet_amd import grids
+    verts, tets = grids.kuhn_grid(res)
+    pos = grids.jittered_positions(verts, res, batch, 0.1, seed0=1000 + rank * batch)
+    tet = grids.gather_tets(pos, tets)
+    pts = grids.random_queries(batch, n_query, seed0=2000 + rank * batch)
+    gw = np.stack([np.random.default_rng(4000 + rank * batch + b).standard_normal((n_query, 4)).astype(np.float32)
+                   for b in range(batch)])
+    pred = np.stack([np.random.default_rng(5000 + rank * batch + b).random(tet.shape[1]).astype(np.float32)
+                     for b in range(batch)])
+    gout = np.stack([np.random.default_rng(6000 + rank * batch + b).standard_normal(n_query).astype(np.float32)
+                     for b in range(batch)])
+    host = dict(tet=tet, pts=pts)
+    dev = {k: torch.from_numpy(v).to(device) for k, v in dict(tet=tet, pts=pts, gw=gw, pred=pred, gout=gout).items()}
+    return host, dev
+
+
+def step(d, world, gather_buf):
+    from deftet_amd import hip_ops
+    cond, w = hip_ops.point_in_tet(d["tet"], d["pts"], want_bary=True)
+    cond_c = cond.clone()                       # train_multigpu.py:383 pastes into a clone
+    occ = hip_ops.paste_occ_fwd(d["pred"], cond_c)
+    g_tet, _ = hip_ops.point_in_tet_bwd(d["tet"], d["pts"], cond, d["gw"])
+    g_pred = hip_ops.paste_occ_bwd(cond_c, d["gout"], d["tet"].shape[1])
+    loss = (w * d["gw"]).sum(dim=(1, 2)) + (occ * d["gout"]).sum(dim=1)       # [B] per-shape scalars
+    if world > 1:
+        torch.distributed.all_gather_into_tensor(gather_buf, loss)            # the only collective
+    return cond, w, g_tet, g_pred, loss
+
+
+def cpu_baseline(host):
+    """Oracle (CPU restatement, kind="port") on a bounded sample of the same workload."""
+    from oracle import oracle as O
+    tet = host["tet"][:1]
+    ncpu = os.cpu_count() or 1
+    q1 = 1500
+    t0 = time.perf_counter()
+    O.point_in_tet(tet, host["pts"][:1, :q1])
+    t1 = time.perf_counter() - t0
+    qn = min(N_QUERY, max(2000, 1200 * ncpu))
+    t0 = time.perf_counter()
+    _, nthreads = O.point_in_tet(tet, host["pts"][:1, :qn], omp=True, return_executed=True)
+    tn = time.perf_counter() - t0
+    T = tet.shape[1]
+    return {
+        "value": round(T * qn / tn / 1e6, 2), "unit": "M tet-point tests/s (fwd only)", "cores": int(nthreads),
+        "kind": "port",
+        "sample": "oracle/deftet_oracle.c brute-force scan, 1 shape res=%d (T=%d), first %d queries, OpenMP over "
+                  "queries; single-core on %d queries: %.2f M/s" % (RES, T, qn, q1, T * q1 / t1 / 1e6),
+        "value_1core": round(T * q1 / t1 / 1e6, 2),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from deftet_amd import _lib
+    lib = _lib.load()
+    host, d = make_inputs(rank, device)
+    B, T, Q = d["tet"].shape[0], d["tet"].shape[1], d["pts"].shape[1]
+    gather_buf = torch.empty(world * B, device=device) if world > 1 else None
+
+    for _ in range(args.warmup):
+        step(d, world, gather_buf)
+    torch.cuda.synchronize()
+
+    dominant = b"k_tet_scan"
+    lib.deftet_profile_select(dominant)
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step(d, world, gather_buf)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    elapsed = time.perf_counter() - t0
+    tot_ms, cnt = ctypes.c_double(0), ctypes.c_longlong(0)
+    lib.deftet_profile_read(ctypes.byref(tot_ms), ctypes.byref(cnt))
+    lib.deftet_profile_select(b"")
+
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        pairs = float(world) * B * T * Q * args.steps
+        kern_ms = tot_ms.value / max(cnt.value, 1)
+        algo_bytes = B * (48.0 * T + 16.0 * Q)          # k_tet_scan reads every tet record and sorted query once
+        achieved = algo_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("k_tet_scan_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "M tet-point tests/s (fwd+bwd) at res=70, 100k queries",
+            "value": round(pairs / elapsed / 1e6, 1),
+            "unit": "M tet-point tests/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: res=70 Kuhn tet grid (T=%d), %d uniform queries, batch=%d shapes "
+                                   "per GPU, point-in-tet index + weights + paste_occ, fwd+bwd, grid build included" % (T, Q, B),
+                       "res": RES, "n_tet": T, "n_query": Q, "batch_per_gpu": B,
+                       "sharding": "shapes sharded by rank; all-gather of %d loss scalars" % (world * B)},
+            "roofline": {"bound": "hbm", "kernel": dominant.decode(), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": round(kern_ms, 5),
+                         "launches_timed": int(cnt.value)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(host)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,117 @@
+"""ctypes binding of libdeftet_hip.so (the C ABI declared in include/deftet_hip.h).
+
+The product path has NO CPU fallback: if the shared object is missing, or an op is handed
+a non-GPU tensor, it raises.  Build the library with `python -m deftet_amd.build`
+(or `__graft_entry__.build()`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libdeftet_hip.so")
+
+_vp, _i, _sz, _ll, _f = C.c_void_p, C.c_int, C.c_size_t, C.c_longlong, C.c_float
+
+# name -> (restype, argtypes); must list every symbol of include/deftet_hip.h
+SIGNATURES = {
+    "deftet_version": (_i, []),
+    "deftet_last_error": (C.c_char_p, []),
+    "deftet_device_count": (_i, []),
+    "deftet_profile_select": (_i, [C.c_char_p]),
+    "deftet_profile_read": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
+    "deftet_point_in_tet_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "deftet_point_in_tet_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "deftet_point_in_tet_bwd_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "deftet_paste_occ_fwd_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "deftet_paste_occ_bwd_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "deftet_builder_workspace_bytes": (_sz, [_i, _i]),
+    "deftet_tet_adj_share_i32": (_i, [_vp, _vp, _vp, _i, _i, _vp, _sz, _vp]),
+    "deftet_tet_adj_share_host": (_i, [_vp, _vp, _vp, _i, _i]),
+    "deftet_tet_face_adj_i32": (_i, [_vp, _vp, _ll, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "deftet_tet_face_adj_host": (_i, [_vp, _vp, _vp, _i, _i]),
+    "deftet_tet_point_adj_i32": (_i, [_vp, _vp, _vp, _i, _i, _vp, _sz, _vp]),
+    "deftet_tet_point_adj_host": (_i, [_vp, _vp, _vp, _i, _i]),
+    "deftet_colaps_v_f32": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
+    "deftet_colaps_v_host": (_i, [_vp, _vp, _vp, _vp, _i]),
+    "deftet_tet_to_face_i32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "deftet_face_edge_adj_workspace_bytes": (_sz, [_i]),
+    "deftet_face_edge_adj_f32": (_i, [_vp, _vp, _i, _i, _vp, _sz, _vp]),
+    "deftet_tri_dist_fwd_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "deftet_tri_dist_bwd_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "deftet_nn_index_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "deftet_sparse_render_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "deftet_sparse_render_fwd_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _sz, _vp]),
+    "deftet_sparse_render_bwd_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp]),
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+class DefTetHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Returns the loaded library; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise DefTetHipError(
+                    "libdeftet_hip.so is missing (%s). Build it with `python -m deftet_amd.build`; "
+                    "there is no CPU fallback." % LIB_PATH)
+            lib = C.CDLL(LIB_PATH)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(lib, name)          # AttributeError = symbol not exported
+                fn.restype = res
+                fn.argtypes = args
+            _lib = lib
+    return _lib
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        msg = load().deftet_last_error()
+        raise DefTetHipError("%s failed (%d): %s" % (what, status, msg.decode() if msg else "?"))
+
+
+# ------------------------------------------------------------------------------------
+# torch plumbing: device pointers, current HIP stream, grow-only workspace per (device, stream)
+# ------------------------------------------------------------------------------------
+_ws = {}
+_ws_lock = threading.Lock()
+
+
+def require_gpu(*tensors) -> None:
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise DefTetHipError("deftet_amd operators need GPU tensors (got device %s); "
+                                 "there is no CPU fallback" % t.device)
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def current_stream(device):
+    import torch
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def workspace(device, nbytes: int):
+    """uint8 tensor of at least nbytes on `device`, cached per (device, stream)."""
+    import torch
+    key = (device.index if device.index is not None else torch.cuda.current_device(),
+           torch.cuda.current_stream(device).cuda_stream)
+    with _ws_lock:
+        buf = _ws.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(max(int(nbytes * 1.25), 1 << 20), dtype=torch.uint8, device=device)
+            _ws[key] = buf
+    return buf

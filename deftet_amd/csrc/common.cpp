@@ -1,0 +1,101 @@
+// common.cpp — error channel and misc entry points of libdeftet_hip.so
+#include "common.hpp"
+
+#include <string.h>
+
+#include <mutex>
+#include <vector>
+
+namespace deftet {
+
+char *err_buf()
+{
+    static thread_local char buf[512] = {0};
+    return buf;
+}
+
+int set_error(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(err_buf(), 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+// ---- per-kernel event timing -------------------------------------------------------
+namespace {
+struct Prof {
+    char name[64] = {0};
+    bool on = false;
+    std::vector<hipEvent_t> ev;   // pairs
+    size_t used = 0;
+} g_prof;
+std::mutex g_prof_mu;
+}  // namespace
+
+bool prof_match(const char *name) { return g_prof.on && strcmp(name, g_prof.name) == 0; }
+
+void prof_begin(hipStream_t st)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (g_prof.used + 2 > g_prof.ev.size()) {
+        for (int i = 0; i < 2; ++i) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return;
+            g_prof.ev.push_back(e);
+        }
+    }
+    hipEventRecord(g_prof.ev[g_prof.used], st);
+}
+
+void prof_end(hipStream_t st)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (g_prof.used + 2 > g_prof.ev.size()) return;
+    hipEventRecord(g_prof.ev[g_prof.used + 1], st);
+    g_prof.used += 2;
+}
+
+}  // namespace deftet
+
+// select the kernel to time ("" or NULL switches timing off); resets the accumulated samples
+extern "C" int deftet_profile_select(const char *kernel_name)
+{
+    std::lock_guard<std::mutex> lk(deftet::g_prof_mu);
+    deftet::g_prof.used = 0;
+    deftet::g_prof.on = kernel_name && kernel_name[0];
+    snprintf(deftet::g_prof.name, sizeof(deftet::g_prof.name), "%s", kernel_name ? kernel_name : "");
+    return DEFTET_OK;
+}
+
+// synchronises the recorded events; total_ms = sum of launch durations, count = launches
+extern "C" int deftet_profile_read(double *total_ms, long long *count)
+{
+    std::lock_guard<std::mutex> lk(deftet::g_prof_mu);
+    double tot = 0;
+    long long n = 0;
+    for (size_t i = 0; i + 1 < deftet::g_prof.used; i += 2) {
+        float ms = 0;
+        if (hipEventSynchronize(deftet::g_prof.ev[i + 1]) != hipSuccess) continue;
+        if (hipEventElapsedTime(&ms, deftet::g_prof.ev[i], deftet::g_prof.ev[i + 1]) != hipSuccess) continue;
+        tot += ms;
+        ++n;
+    }
+    deftet::g_prof.used = 0;
+    if (total_ms) *total_ms = tot;
+    if (count) *count = n;
+    return DEFTET_OK;
+}
+
+extern "C" int deftet_version(void) { return 100; }
+
+extern "C" const char *deftet_last_error(void) { return deftet::err_buf(); }
+
+extern "C" int deftet_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return deftet::set_error(DEFTET_ENODEV, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    return n;
+}

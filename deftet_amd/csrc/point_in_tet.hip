@@ -1,0 +1,742 @@
+// point_in_tet.hip — A1 point-in-tet occupancy query (+ A1b weights/backward, paste_occ)
+// for CDNA4 / gfx950.  See DESIGN.md section "A1" for the algorithm and its error analysis.
+//
+// Semantics follow /root/reference/layers/DefTet/check_condition_tetrahedron_base/
+// check_condition_tet_for.cu:105-189: for every query the LOWEST tet index t whose four
+// same-side tests agree (all true or all false), evaluated in fp32 in the source's
+// operation order WITHOUT fused multiply-add; else -1.
+//
+// Design (tet-centric, not a translation of the one-thread-per-query scan):
+//   1. queries are counting-sorted into a uniform G^3 grid spanning their own bounding box;
+//   2. one lane per tet: the lane computes the tet's four face planes once, visits the
+//      grid cells overlapped by its (slightly enlarged) bounding box and runs the exact
+//      predicate on the queries stored there; hits are combined with atomicMin, which
+//      makes the result independent of evaluation order;
+//   3. tets that fail a conditioning test ("irregular": tiny/flat/inverted-inconsistent,
+//      non-finite, huge) are tested against ALL queries, and queries that are
+//      non-finite/huge are tested against ALL tets, by two brute-force side kernels, so
+//      the result equals the reference scan for every input, not just for nice meshes.
+//
+// The whole file is compiled with -ffp-contract=off; the pragma below repeats that.
+#pragma clang fp contract(off)
+
+#include "common.hpp"
+
+namespace deftet {
+namespace pit {
+
+constexpr float kBig = 1048576.0f;           // 2^20: coordinates beyond this go to the brute side paths
+constexpr float kTau = 1.0f / 128.0f;        // regular tet: min |6V| >= tau * w^3
+constexpr float kMargin = 1.0f / 64.0f;      // bounding-box enlargement, in units of w
+constexpr float kWMin = 9.3132257e-10f;      // 2^-30
+constexpr int kMiss = 0x7F7F7F7F;            // result sentinel (> any tet index)
+constexpr int kChunk = 2048;                 // cells per scan chunk
+constexpr int kMaxG = 96;
+
+// ------------------------------------------------------------------------------------
+// exact predicate pieces (check_condition_tet_for.cu:105-121, :172-176)
+// ------------------------------------------------------------------------------------
+struct Planes {
+    float n[4][3];   // (b-a) x (c-a) for the four vertex orderings
+    float a[4][3];   // base vertex of each ordering (= vertex i)
+    unsigned sv;     // bit i: dotv4_i > 0
+    float dv[4];     // dotv4_i
+};
+
+__device__ __forceinline__ void make_planes(const float *v /*12*/, Planes &P)
+{
+    // orderings (a,b,c,d),(b,a,d,c),(c,d,a,b),(d,c,b,a): check_condition_tet_for.cu:172-175
+    constexpr int ord[4][4] = {{0, 1, 2, 3}, {1, 0, 3, 2}, {2, 3, 0, 1}, {3, 2, 1, 0}};
+    P.sv = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float *a = v + 3 * ord[i][0], *b = v + 3 * ord[i][1], *c = v + 3 * ord[i][2], *d = v + 3 * ord[i][3];
+        float r1x = b[0] - a[0], r1y = b[1] - a[1], r1z = b[2] - a[2];        // :111
+        float r2x = c[0] - a[0], r2y = c[1] - a[1], r2z = c[2] - a[2];        // :112
+        float nx = r1y * r2z - r1z * r2y;                                       // :63
+        float ny = r1z * r2x - r1x * r2z;                                       // :64
+        float nz = r1x * r2y - r1y * r2x;                                       // :65
+        float dx = d[0] - a[0], dy = d[1] - a[1], dz = d[2] - a[2];            // :114
+        float dotv4 = nx * dx + ny * dy + nz * dz;                              // :115
+        P.n[i][0] = nx; P.n[i][1] = ny; P.n[i][2] = nz;
+        P.a[i][0] = a[0]; P.a[i][1] = a[1]; P.a[i][2] = a[2];
+        P.dv[i] = dotv4;
+        P.sv |= (dotv4 > 0 ? 1u : 0u) << i;                                     // :119
+    }
+}
+
+__device__ __forceinline__ bool accept(const Planes &P, float px, float py, float pz)
+{
+    unsigned m = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float rx = px - P.a[i][0], ry = py - P.a[i][1], rz = pz - P.a[i][2];   // :116
+        float dotp = P.n[i][0] * rx + P.n[i][1] * ry + P.n[i][2] * rz;          // :117
+        m |= (dotp > 0 ? 1u : 0u) << i;                                          // :118
+    }
+    unsigned x = m ^ P.sv;          // bit i set <=> sign_p != sign_v  (:120)
+    return x == 0u || x == 15u;     // all four equal (:176)
+}
+
+// ------------------------------------------------------------------------------------
+// grid helpers
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ int f2ord(float f)
+{
+    int b = __float_as_int(f);
+    return b >= 0 ? b : b ^ 0x7FFFFFFF;
+}
+__device__ __forceinline__ float ord2f(int k) { return __int_as_float(k >= 0 ? k : k ^ 0x7FFFFFFF); }
+
+struct Grid {
+    float o[3], inv[3], lo[3], hi[3];
+};
+
+// one thread per shape: decode the query bounding box into grid parameters (12 floats)
+__global__ void k_grid_params(const int *__restrict__ bbox, int G, int nB, float *gparam)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nB) return;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float lo = ord2f(bbox[b * 6 + k]), hi = ord2f(bbox[b * 6 + 3 + k]);
+        bool ok = hi >= lo;                       // false when no regular query was seen
+        float ext = hi - lo;
+        lo = ok ? lo : 0.f;
+        hi = ok ? hi : 0.f;
+        gparam[b * 12 + k] = lo;                                              // origin
+        gparam[b * 12 + 3 + k] = (ok && ext > 1e-30f) ? (float)G / ext : 0.f;  // cells per unit
+        gparam[b * 12 + 6 + k] = lo;
+        gparam[b * 12 + 9 + k] = hi;
+    }
+}
+
+__device__ __forceinline__ Grid load_grid(const float *__restrict__ gp)
+{
+    Grid g;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        g.o[k] = gp[k];
+        g.inv[k] = gp[3 + k];
+        g.lo[k] = gp[6 + k];
+        g.hi[k] = gp[9 + k];
+    }
+    return g;
+}
+
+// monotone non-decreasing in x for fixed (o, inv >= 0): rounding, floor and clamp are monotone
+__device__ __forceinline__ int cell_of(float x, float o, float inv, int G)
+{
+    float f = floorf((x - o) * inv);
+    f = fminf(fmaxf(f, 0.f), (float)(G - 1));
+    return (int)f;
+}
+
+__device__ __forceinline__ bool query_regular(float x, float y, float z)
+{
+    return fabsf(x) <= kBig && fabsf(y) <= kBig && fabsf(z) <= kBig;   // NaN fails
+}
+
+// ------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------
+__global__ void k_init(int *bbox, int *counters, int *cells, int *result, int nB, long long nCells, long long nQ)
+{
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long stride = (long long)gridDim.x * blockDim.x;
+    if (i < nB * 6) bbox[i] = (i % 6) < 3 ? 0x7FFFFFFF : (int)0x80000000;
+    if (i < nB * 4) counters[i] = 0;
+    for (long long j = i; j < nCells; j += stride) cells[j] = 0;
+    for (long long j = i; j < nQ; j += stride) result[j] = kMiss;
+}
+
+// query bounding box per shape + list of irregular queries
+__global__ __launch_bounds__(256) void k_query_bbox(const float *__restrict__ pts, int Q, int *bbox, int *counters,
+                                                    int *irregQ)
+{
+    const int b = blockIdx.y;
+    const float *p = pts + (size_t)b * Q * 3;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    bool any = false;
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < Q; q += gridDim.x * blockDim.x) {
+        float x = p[q * 3], y = p[q * 3 + 1], z = p[q * 3 + 2];
+        if (query_regular(x, y, z)) {
+            any = true;
+            lo[0] = fminf(lo[0], x); lo[1] = fminf(lo[1], y); lo[2] = fminf(lo[2], z);
+            hi[0] = fmaxf(hi[0], x); hi[1] = fmaxf(hi[1], y); hi[2] = fmaxf(hi[2], z);
+        } else {
+            int k = atomicAdd(&counters[b * 4 + 1], 1);
+            irregQ[(size_t)b * Q + k] = q;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = fminf(lo[k], __shfl_xor(lo[k], off));
+            hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off));
+        }
+    }
+    unsigned long long anyw = __ballot(any);
+    if ((threadIdx.x & 63) == 0 && anyw) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            atomicMin(&bbox[b * 6 + k], f2ord(lo[k]));
+            atomicMax(&bbox[b * 6 + 3 + k], f2ord(hi[k]));
+        }
+    }
+}
+
+// cell id + rank inside the cell for every regular query
+__global__ __launch_bounds__(256) void k_query_bin(const float *__restrict__ pts, int Q, const float *__restrict__ gparam,
+                                                   int G, long long cellStride, int *cells, int2 *qcell)
+{
+    const int b = blockIdx.y;
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= Q) return;
+    const Grid g = load_grid(gparam + b * 12);
+    const float *p = pts + ((size_t)b * Q + q) * 3;
+    float x = p[0], y = p[1], z = p[2];
+    int2 r = make_int2(-1, 0);
+    if (query_regular(x, y, z)) {
+        int cx = cell_of(x, g.o[0], g.inv[0], G), cy = cell_of(y, g.o[1], g.inv[1], G), cz = cell_of(z, g.o[2], g.inv[2], G);
+        int c = (cz * G + cy) * G + cx;
+        r.x = c;
+        r.y = atomicAdd(&cells[(size_t)b * cellStride + c], 1);
+    }
+    qcell[(size_t)b * Q + q] = r;
+}
+
+// exclusive scan inside chunks of kChunk cells; chunk totals to chunkTot
+__global__ __launch_bounds__(256) void k_scan_chunks(int *cells, long long cellStride, int nChunk, int *chunkTot)
+{
+    __shared__ int wsum[4];
+    const int b = blockIdx.y, c = blockIdx.x;
+    int4 *base = reinterpret_cast<int4 *>(cells + (size_t)b * cellStride + (size_t)c * kChunk);
+    int4 v0 = base[threadIdx.x * 2], v1 = base[threadIdx.x * 2 + 1];
+    int s = v0.x + v0.y + v0.z + v0.w + v1.x + v1.y + v1.z + v1.w;
+    int incl = s;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        int t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    int wbase = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (k < w) wbase += wsum[k];
+    int run = wbase + incl - s;
+    int4 o0, o1;
+    o0.x = run; run += v0.x; o0.y = run; run += v0.y; o0.z = run; run += v0.z; o0.w = run; run += v0.w;
+    o1.x = run; run += v1.x; o1.y = run; run += v1.y; o1.z = run; run += v1.z; o1.w = run;
+    base[threadIdx.x * 2] = o0;
+    base[threadIdx.x * 2 + 1] = o1;
+    if (threadIdx.x == 255) chunkTot[b * nChunk + c] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// exclusive scan of the chunk totals of one shape (nChunk <= 512)
+__global__ __launch_bounds__(512) void k_scan_totals(int *chunkTot, int nChunk)
+{
+    __shared__ int sh[512];
+    const int b = blockIdx.x, i = threadIdx.x;
+    int v = i < nChunk ? chunkTot[b * nChunk + i] : 0;
+    sh[i] = v;
+    __syncthreads();
+    for (int off = 1; off < 512; off <<= 1) {
+        int t = i >= off ? sh[i - off] : 0;
+        __syncthreads();
+        sh[i] += t;
+        __syncthreads();
+    }
+    if (i < nChunk) chunkTot[b * nChunk + i] = sh[i] - v;
+}
+
+__device__ __forceinline__ int cell_start(const int *__restrict__ cells, const int *__restrict__ chunkBase, int c)
+{
+    return cells[c] + chunkBase[c / kChunk];
+}
+
+__global__ __launch_bounds__(256) void k_query_scatter(const float *__restrict__ pts, int Q, const int2 *__restrict__ qcell,
+                                                       const int *__restrict__ cells, long long cellStride,
+                                                       const int *__restrict__ chunkBase, int nChunk, float4 *sortedQ)
+{
+    const int b = blockIdx.y;
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= Q) return;
+    int2 r = qcell[(size_t)b * Q + q];
+    if (r.x < 0) return;
+    const float *p = pts + ((size_t)b * Q + q) * 3;
+    int pos = cell_start(cells + (size_t)b * cellStride, chunkBase + b * nChunk, r.x) + r.y;
+    sortedQ[(size_t)b * Q + pos] = make_float4(p[0], p[1], p[2], __int_as_float(q));
+}
+
+// the main kernel: one lane per tet
+__global__ __launch_bounds__(256) void k_tet_scan(const float *__restrict__ tet, int T, int Q,
+                                                  const float *__restrict__ gparam, int G, const int *__restrict__ cells,
+                                                  long long cellStride, const int *__restrict__ chunkBase, int nChunk,
+                                                  const float4 *__restrict__ sortedQ, int *result, int *counters,
+                                                  int *irregT)
+{
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    float v[12];
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(tet + ((size_t)b * T + t) * 12);
+        float4 a = src[0], bq = src[1], c = src[2];
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+        v[4] = bq.x; v[5] = bq.y; v[6] = bq.z; v[7] = bq.w;
+        v[8] = c.x; v[9] = c.y; v[10] = c.z; v[11] = c.w;
+    }
+    Planes P;
+    make_planes(v, P);
+    float lo[3], hi[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        lo[k] = fminf(fminf(v[k], v[3 + k]), fminf(v[6 + k], v[9 + k]));
+        hi[k] = fmaxf(fmaxf(v[k], v[3 + k]), fmaxf(v[6 + k], v[9 + k]));
+    }
+    float w = fmaxf(fmaxf(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]);
+    // conditioning test; every comparison is written so that NaN yields "irregular"
+    bool finite = true;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) finite = finite && (fabsf(v[k]) <= kBig);
+    float mn = fminf(fminf(fabsf(P.dv[0]), fabsf(P.dv[1])), fminf(fabsf(P.dv[2]), fabsf(P.dv[3])));
+    bool regular = finite && (P.sv == 0u || P.sv == 15u) && (w >= kWMin) && (mn >= kTau * ((w * w) * w));
+    // sv==0 with a zero dotv4 is excluded by mn >= tau*w^3 > 0
+    if (!regular) {
+        int k = atomicAdd(&counters[b * 4 + 0], 1);
+        irregT[(size_t)b * T + k] = t;
+        return;
+    }
+    const Grid g = load_grid(gparam + b * 12);
+    const float m = w * kMargin;
+    float elo[3], ehi[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        elo[k] = lo[k] - m;
+        ehi[k] = hi[k] + m;
+    }
+    // no regular query can lie in the enlarged box -> nothing to do
+    if (ehi[0] < g.lo[0] || elo[0] > g.hi[0] || ehi[1] < g.lo[1] || elo[1] > g.hi[1] || ehi[2] < g.lo[2] || elo[2] > g.hi[2])
+        return;
+    const int cx0 = cell_of(elo[0], g.o[0], g.inv[0], G), cx1 = cell_of(ehi[0], g.o[0], g.inv[0], G);
+    const int cy0 = cell_of(elo[1], g.o[1], g.inv[1], G), cy1 = cell_of(ehi[1], g.o[1], g.inv[1], G);
+    const int cz0 = cell_of(elo[2], g.o[2], g.inv[2], G), cz1 = cell_of(ehi[2], g.o[2], g.inv[2], G);
+    const int *cb = cells + (size_t)b * cellStride;
+    const int *kb = chunkBase + b * nChunk;
+    const float4 *sq = sortedQ + (size_t)b * Q;
+    int *res = result + (size_t)b * Q;
+    for (int cz = cz0; cz <= cz1; ++cz)
+        for (int cy = cy0; cy <= cy1; ++cy) {
+            const int row = (cz * G + cy) * G;
+            const int s = cell_start(cb, kb, row + cx0);
+            const int e = cell_start(cb, kb, row + cx1 + 1);   // cells has G^3+1 valid entries
+            for (int j = s; j < e; ++j) {
+                const float4 q = sq[j];
+                if (q.x >= elo[0] && q.x <= ehi[0] && q.y >= elo[1] && q.y <= ehi[1] && q.z >= elo[2] && q.z <= ehi[2]) {
+                    if (accept(P, q.x, q.y, q.z)) atomicMin(&res[__float_as_int(q.w)], t);
+                }
+            }
+        }
+}
+
+// irregular tets x all queries
+__global__ __launch_bounds__(256) void k_irreg_tets(const float *__restrict__ tet, const float *__restrict__ pts, int T,
+                                                    int Q, const int *__restrict__ counters,
+                                                    const int *__restrict__ irregT, int *result)
+{
+    const int b = blockIdx.y;
+    const int n = counters[b * 4 + 0];
+    if (n == 0) return;
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < Q; q += gridDim.x * blockDim.x) {
+        const float *p = pts + ((size_t)b * Q + q) * 3;
+        const float x = p[0], y = p[1], z = p[2];
+        int best = kMiss;
+        for (int k = 0; k < n; ++k) {
+            const int t = irregT[(size_t)b * T + k];
+            float v[12];
+            const float *src = tet + ((size_t)b * T + t) * 12;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) v[i] = src[i];
+            Planes P;
+            make_planes(v, P);
+            if (accept(P, x, y, z)) best = min(best, t);
+        }
+        if (best != kMiss) atomicMin(&result[(size_t)b * Q + q], best);
+    }
+}
+
+// irregular queries x all tets
+__global__ __launch_bounds__(256) void k_irreg_queries(const float *__restrict__ tet, const float *__restrict__ pts,
+                                                       int T, int Q, const int *__restrict__ counters,
+                                                       const int *__restrict__ irregQ, int *result)
+{
+    const int b = blockIdx.y;
+    const int n = counters[b * 4 + 1];
+    if (n == 0) return;
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < T; t += gridDim.x * blockDim.x) {
+        float v[12];
+        const float *src = tet + ((size_t)b * T + t) * 12;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) v[i] = src[i];
+        Planes P;
+        make_planes(v, P);
+        for (int k = 0; k < n; ++k) {
+            const int q = irregQ[(size_t)b * Q + k];
+            const float *p = pts + ((size_t)b * Q + q) * 3;
+            if (accept(P, p[0], p[1], p[2])) atomicMin(&result[(size_t)b * Q + q], t);
+        }
+    }
+}
+
+// barycentric weights, utils/tet_utils.py:25-45 (same association as the torch expression)
+__device__ __forceinline__ float triple(const float *a, const float *b, const float *c)
+{
+    float x0 = b[1] * c[2] - b[2] * c[1];
+    float x1 = b[2] * c[0] - b[0] * c[2];
+    float x2 = b[0] * c[1] - b[1] * c[0];
+    return (a[0] * x0 + a[1] * x1) + a[2] * x2;
+}
+
+__global__ __launch_bounds__(256) void k_finalize(const float *__restrict__ tet, const float *__restrict__ pts, int T,
+                                                  int Q, const int *__restrict__ result, float *cond, float *bary)
+{
+    const int b = blockIdx.y;
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= Q) return;
+    const size_t i = (size_t)b * Q + q;
+    const int r = result[i];
+    const bool hit = r != kMiss;
+    cond[i] = hit ? (float)r : -1.0f;                               // :177, :149
+    if (!bary) return;
+    float4 wq = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (hit) {
+        const float4 *src = reinterpret_cast<const float4 *>(tet + ((size_t)b * T + r) * 12);
+        float4 t0 = src[0], t1 = src[1], t2 = src[2];
+        const float A[3] = {t0.x, t0.y, t0.z}, Bv[3] = {t0.w, t1.x, t1.y}, Cv[3] = {t1.z, t1.w, t2.x}, D[3] = {t2.y, t2.z, t2.w};
+        const float *pp = pts + i * 3;
+        float vap[3], vbp[3], vab[3], vac[3], vad[3], vbc[3], vbd[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            vap[k] = pp[k] - A[k]; vbp[k] = pp[k] - Bv[k];
+            vab[k] = Bv[k] - A[k]; vac[k] = Cv[k] - A[k]; vad[k] = D[k] - A[k];
+            vbc[k] = Cv[k] - Bv[k]; vbd[k] = D[k] - Bv[k];
+        }
+        float v6 = 1.0f / triple(vab, vac, vad);
+        wq.x = triple(vbp, vbd, vbc) * v6;
+        wq.y = triple(vap, vac, vad) * v6;
+        wq.z = triple(vap, vad, vab) * v6;
+        wq.w = triple(vap, vab, vac) * v6;
+    }
+    reinterpret_cast<float4 *>(bary)[i] = wq;
+}
+
+// ------------------------------------------------------------------------------------
+// brute force (DEFTET_PIT_BRUTE): the algorithmic equivalent of the reference kernel —
+// every query meets every tet in index order — restructured for CDNA4: plane records are
+// computed once per tet, read through the scalar cache as wave-uniform operands, one
+// query per lane, wave-wide early exit once all 64 lanes have their first hit.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_prep_records(const float *__restrict__ tet, long long n, float *rec)
+{
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float v[12];
+    const float4 *src = reinterpret_cast<const float4 *>(tet + i * 12);
+    float4 a = src[0], bq = src[1], c = src[2];
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = bq.x; v[5] = bq.y; v[6] = bq.z; v[7] = bq.w;
+    v[8] = c.x; v[9] = c.y; v[10] = c.z; v[11] = c.w;
+    Planes P;
+    make_planes(v, P);
+    float4 *dst = reinterpret_cast<float4 *>(rec + i * 32);
+    dst[0] = make_float4(P.n[0][0], P.n[0][1], P.n[0][2], P.a[0][0]);
+    dst[1] = make_float4(P.a[0][1], P.a[0][2], P.n[1][0], P.n[1][1]);
+    dst[2] = make_float4(P.n[1][2], P.a[1][0], P.a[1][1], P.a[1][2]);
+    dst[3] = make_float4(P.n[2][0], P.n[2][1], P.n[2][2], P.a[2][0]);
+    dst[4] = make_float4(P.a[2][1], P.a[2][2], P.n[3][0], P.n[3][1]);
+    dst[5] = make_float4(P.n[3][2], P.a[3][0], P.a[3][1], P.a[3][2]);
+    dst[6] = make_float4(__int_as_float((int)P.sv), 0.f, 0.f, 0.f);
+    dst[7] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+__global__ __launch_bounds__(256) void k_brute(const float *__restrict__ rec, const float *__restrict__ pts, int T, int Q,
+                                               int *result)
+{
+    const int b = blockIdx.y;
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = q < Q;
+    const float *p = pts + ((size_t)b * Q + (live ? q : 0)) * 3;
+    const float px = p[0], py = p[1], pz = p[2];
+    const float *__restrict__ r = rec + (size_t)b * T * 32;
+    int found = live ? kMiss : 0;
+    for (int t = 0; t < T; ++t) {
+        const float *__restrict__ s = r + (size_t)t * 32;      // wave-uniform address -> scalar loads
+        unsigned m = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float nx = s[i * 6 + 0], ny = s[i * 6 + 1], nz = s[i * 6 + 2];
+            const float ax = s[i * 6 + 3], ay = s[i * 6 + 4], az = s[i * 6 + 5];
+            float rx = px - ax, ry = py - ay, rz = pz - az;
+            float dotp = nx * rx + ny * ry + nz * rz;
+            m |= (dotp > 0 ? 1u : 0u) << i;
+        }
+        const unsigned x = m ^ (unsigned)__float_as_int(s[24]);
+        if ((x == 0u || x == 15u) && found == kMiss) found = t;
+        if ((t & 7) == 7 && __ballot(found == kMiss) == 0ull) break;   // whole wave done
+    }
+    if (live) result[(size_t)b * Q + q] = found;
+}
+
+// ------------------------------------------------------------------------------------
+// A1b backward: dL/dtet = -w_k * G,  G = sum_i g_i * grad_p(w_i)   
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ void cross3(const float *a, const float *b, float *o)
+{
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+__global__ __launch_bounds__(256) void k_bary_bwd(const float *__restrict__ tet, const float *__restrict__ pts,
+                                                  const float *__restrict__ cond, const float *__restrict__ grad_w, int T,
+                                                  int Q, float *grad_tet, float *grad_pts)
+{
+    const int b = blockIdx.y;
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= Q) return;
+    const size_t i = (size_t)b * Q + q;
+    const float cf = cond[i];
+    const bool hit = cf >= 0.f;
+    float G3[3] = {0.f, 0.f, 0.f};
+    if (hit) {
+        const int t = (int)cf;
+        const float4 *src = reinterpret_cast<const float4 *>(tet + ((size_t)b * T + t) * 12);
+        float4 t0 = src[0], t1 = src[1], t2 = src[2];
+        const float A[3] = {t0.x, t0.y, t0.z}, Bv[3] = {t0.w, t1.x, t1.y}, Cv[3] = {t1.z, t1.w, t2.x}, D[3] = {t2.y, t2.z, t2.w};
+        const float *pp = pts + i * 3;
+        float vap[3], vbp[3], vab[3], vac[3], vad[3], vbc[3], vbd[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            vap[k] = pp[k] - A[k]; vbp[k] = pp[k] - Bv[k];
+            vab[k] = Bv[k] - A[k]; vac[k] = Cv[k] - A[k]; vad[k] = D[k] - A[k];
+            vbc[k] = Cv[k] - Bv[k]; vbd[k] = D[k] - Bv[k];
+        }
+        float na[3], nb[3], nc[3], nd[3];
+        cross3(vbd, vbc, na);    // grad_p va6
+        cross3(vac, vad, nb);    // grad_p vb6
+        cross3(vad, vab, nc);    // grad_p vc6
+        cross3(vab, vac, nd);    // grad_p vd6
+        const float v6 = 1.0f / (vab[0] * nb[0] + vab[1] * nb[1] + vab[2] * nb[2]);
+        float w[4];
+        w[0] = (vbp[0] * na[0] + vbp[1] * na[1] + vbp[2] * na[2]) * v6;
+        w[1] = (vap[0] * nb[0] + vap[1] * nb[1] + vap[2] * nb[2]) * v6;
+        w[2] = (vap[0] * nc[0] + vap[1] * nc[1] + vap[2] * nc[2]) * v6;
+        w[3] = (vap[0] * nd[0] + vap[1] * nd[1] + vap[2] * nd[2]) * v6;
+        const float4 g = reinterpret_cast<const float4 *>(grad_w)[i];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) G3[k] = (g.x * na[k] + g.y * nb[k] + g.z * nc[k] + g.w * nd[k]) * v6;
+        float *gt = grad_tet + ((size_t)b * T + t) * 12;
+#pragma unroll
+        for (int vtx = 0; vtx < 4; ++vtx)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) atomicAdd(gt + vtx * 3 + k, -w[vtx] * G3[k]);
+    }
+    if (grad_pts) {
+        grad_pts[i * 3 + 0] = G3[0];
+        grad_pts[i * 3 + 1] = G3[1];
+        grad_pts[i * 3 + 2] = G3[2];
+    }
+}
+
+// paste_occ, layers/DefTet/deftet.py:132-136
+__global__ __launch_bounds__(256) void k_paste_fwd(const float *__restrict__ pred, float *cond, float *out, int T, int Q,
+                                                   int clamp_inplace)
+{
+    const int b = blockIdx.y;
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= Q) return;
+    const size_t i = (size_t)b * Q + q;
+    float c = cond[i];
+    if (c < 0) {                                   // condition[condition < 0] = 0
+        c = 0.f;
+        if (clamp_inplace) cond[i] = 0.f;
+    }
+    out[i] = pred[(size_t)b * T + (long long)c];   // torch.gather(..., index=condition.long())
+}
+
+__global__ __launch_bounds__(256) void k_paste_bwd(const float *__restrict__ cond, const float *__restrict__ gout,
+                                                   float *gpred, int T, int Q)
+{
+    const int b = blockIdx.y;
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= Q) return;
+    const size_t i = (size_t)b * Q + q;
+    float c = cond[i];
+    if (c < 0) c = 0.f;
+    atomicAdd(&gpred[(size_t)b * T + (long long)c], gout[i]);
+}
+
+// ------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------
+static int pick_G(int T, int Q)
+{
+    double a = T / 6.0, bq = (Q > 0 ? Q : 1) / 2.0;
+    double m = a < bq ? a : bq;
+    int G = (int)llround(cbrt(m < 1 ? 1 : m));
+    if (G < 1) G = 1;
+    if (G > kMaxG) G = kMaxG;
+    return G;
+}
+
+struct Layout {
+    int G, nChunk;
+    long long cellStride;   // padded cells per shape (multiple of kChunk, >= G^3+1)
+    size_t bytes;
+    int *bbox, *counters, *cells, *chunkTot, *result, *irregT, *irregQ;
+    int2 *qcell;
+    float4 *sortedQ;
+    float *rec, *gparam;
+};
+
+static Layout make_layout(int B, int T, int Q, int algo, void *ws, size_t wsBytes)
+{
+    Layout L{};
+    Arena A(ws, wsBytes);
+    L.result = A.take<int>((size_t)B * Q);
+    if (algo == DEFTET_PIT_BRUTE) {
+        L.rec = A.take<float>((size_t)B * T * 32);
+    } else {
+        L.G = pick_G(T, Q);
+        long long n = (long long)L.G * L.G * L.G + 1;
+        L.nChunk = (int)((n + kChunk - 1) / kChunk);
+        L.cellStride = (long long)L.nChunk * kChunk;
+        L.bbox = A.take<int>((size_t)B * 6);
+        L.counters = A.take<int>((size_t)B * 4);
+        L.gparam = A.take<float>((size_t)B * 12);
+        L.cells = A.take<int>((size_t)B * L.cellStride);
+        L.chunkTot = A.take<int>((size_t)B * L.nChunk);
+        L.qcell = A.take<int2>((size_t)B * Q);
+        L.sortedQ = A.take<float4>((size_t)B * Q);
+        L.irregT = A.take<int>((size_t)B * T);
+        L.irregQ = A.take<int>((size_t)B * Q);
+    }
+    L.bytes = align_up(A.off, 256);
+    return L;
+}
+
+}  // namespace pit
+}  // namespace deftet
+
+using namespace deftet;
+using namespace deftet::pit;
+
+extern "C" size_t deftet_point_in_tet_workspace_bytes(int B, int T, int Q, int algo)
+{
+    if (B <= 0 || T < 0 || Q < 0) return 0;
+    return make_layout(B, T, Q, algo, nullptr, 0).bytes;
+}
+
+extern "C" int deftet_point_in_tet_f32(const float *tet, const float *pts, float *cond, float *bary, int B, int T, int Q,
+                                       int algo, void *workspace, size_t workspace_bytes, void *stream_)
+{
+    DEFTET_CHECK_ARG(B >= 0 && T >= 0 && Q >= 0, "negative size (B=%d T=%d Q=%d)", B, T, Q);
+    DEFTET_CHECK_ARG(algo == DEFTET_PIT_AUTO || algo == DEFTET_PIT_BRUTE, "unknown algo %d", algo);
+    if (T >= (1 << 24)) return set_error(DEFTET_ELIMIT, "n_tet=%d does not fit a float-encoded index (2^24)", T);
+    DEFTET_CHECK_ARG(B <= 65535, "n_batch=%d exceeds the grid-y limit 65535", B);
+    if (B == 0 || Q == 0) return DEFTET_OK;
+    DEFTET_CHECK_ARG(pts && cond, "null pts/cond pointer");
+    DEFTET_CHECK_ARG(T == 0 || tet, "null tet pointer");
+    DEFTET_CHECK_ARG(((uintptr_t)tet & 15) == 0, "tet must be 16-byte aligned");
+    DEFTET_CHECK_ARG(!bary || ((uintptr_t)bary & 15) == 0, "bary must be 16-byte aligned");
+    DEFTET_CHECK_ARG(workspace && ((uintptr_t)workspace & 255) == 0, "workspace null or not 256-byte aligned");
+    Layout L = make_layout(B, T, Q, algo, workspace, workspace_bytes);
+    DEFTET_CHECK_ARG(L.bytes <= workspace_bytes, "workspace too small: need %zu bytes, got %zu", L.bytes, workspace_bytes);
+    hipStream_t st = as_stream(stream_);
+    const dim3 blk(256);
+    const dim3 gq((Q + 255) / 256, B), gt((T + 255) / 256, B);
+
+    if (algo == DEFTET_PIT_BRUTE) {
+        if (T > 0) {
+            long long n = (long long)B * T;
+            DEFTET_LAUNCH(k_prep_records, dim3((unsigned)((n + 255) / 256)), blk, st, tet, n, L.rec);
+        }
+        DEFTET_LAUNCH(k_brute, gq, blk, st, L.rec, pts, T, Q, L.result);
+    } else {
+        const long long nCells = (long long)B * L.cellStride, nQ = (long long)B * Q;
+        long long mx = nCells > nQ ? nCells : nQ;
+        int ib = (int)((mx + 255) / 256);
+        if (ib > 4096) ib = 4096;
+        DEFTET_LAUNCH(k_init, dim3(ib), blk, st, L.bbox, L.counters, L.cells, L.result, B, nCells, nQ);
+        int nb = (Q + 255) / 256;
+        if (nb > 256) nb = 256;
+        DEFTET_LAUNCH(k_query_bbox, dim3(nb, B), blk, st, pts, Q, L.bbox, L.counters, L.irregQ);
+        DEFTET_LAUNCH(k_grid_params, dim3((B + 63) / 64), dim3(64), st, L.bbox, L.G, B, L.gparam);
+        DEFTET_LAUNCH(k_query_bin, gq, blk, st, pts, Q, L.gparam, L.G, L.cellStride, L.cells, L.qcell);
+        DEFTET_LAUNCH(k_scan_chunks, dim3(L.nChunk, B), blk, st, L.cells, L.cellStride, L.nChunk, L.chunkTot);
+        DEFTET_LAUNCH(k_scan_totals, dim3(B), dim3(512), st, L.chunkTot, L.nChunk);
+        DEFTET_LAUNCH(k_query_scatter, gq, blk, st, pts, Q, L.qcell, L.cells, L.cellStride, L.chunkTot, L.nChunk,
+                           L.sortedQ);
+        if (T > 0) {
+            DEFTET_LAUNCH(k_tet_scan, gt, blk, st, tet, T, Q, L.gparam, L.G, L.cells, L.cellStride, L.chunkTot,
+                               L.nChunk, L.sortedQ, L.result, L.counters, L.irregT);
+            int qb = (Q + 255) / 256, tb = (T + 255) / 256;
+            if (qb > 1024) qb = 1024;
+            if (tb > 1024) tb = 1024;
+            DEFTET_LAUNCH(k_irreg_tets, dim3(qb, B), blk, st, tet, pts, T, Q, L.counters, L.irregT, L.result);
+            DEFTET_LAUNCH(k_irreg_queries, dim3(tb, B), blk, st, tet, pts, T, Q, L.counters, L.irregQ, L.result);
+        }
+    }
+    DEFTET_LAUNCH(k_finalize, gq, blk, st, tet, pts, T, Q, L.result, cond, bary);
+    return DEFTET_OK;
+}
+
+extern "C" int deftet_point_in_tet_bwd_f32(const float *tet, const float *pts, const float *cond, const float *grad_w,
+                                           float *grad_tet, float *grad_pts, int B, int T, int Q, int zero_grad_tet,
+                                           void *stream_)
+{
+    DEFTET_CHECK_ARG(B >= 0 && T >= 0 && Q >= 0, "negative size");
+    DEFTET_CHECK_ARG(B <= 65535, "n_batch=%d exceeds 65535", B);
+    hipStream_t st = as_stream(stream_);
+    if (zero_grad_tet && B > 0 && T > 0) {
+        DEFTET_CHECK_ARG(grad_tet, "null grad_tet");
+        DEFTET_HIP(hipMemsetAsync(grad_tet, 0, (size_t)B * T * 48, st));
+    }
+    if (B == 0 || Q == 0 || T == 0) return DEFTET_OK;
+    DEFTET_CHECK_ARG(tet && pts && cond && grad_w && grad_tet, "null pointer");
+    DEFTET_CHECK_ARG(((uintptr_t)tet & 15) == 0 && ((uintptr_t)grad_w & 15) == 0, "tet/grad_w must be 16-byte aligned");
+    DEFTET_LAUNCH(k_bary_bwd, dim3((Q + 255) / 256, B), dim3(256), st, tet, pts, cond, grad_w, T, Q, grad_tet,
+                       grad_pts);
+    return DEFTET_OK;
+}
+
+extern "C" int deftet_paste_occ_fwd_f32(const float *pred, float *cond, float *out, int B, int T, int Q,
+                                        int clamp_cond_inplace, void *stream_)
+{
+    DEFTET_CHECK_ARG(B >= 0 && T >= 0 && Q >= 0 && B <= 65535, "bad size");
+    if (B == 0 || Q == 0) return DEFTET_OK;
+    DEFTET_CHECK_ARG(T > 0, "paste_occ needs at least one tet");
+    DEFTET_CHECK_ARG(pred && cond && out, "null pointer");
+    DEFTET_LAUNCH(k_paste_fwd, dim3((Q + 255) / 256, B), dim3(256), as_stream(stream_), pred, cond, out, T, Q,
+                       clamp_cond_inplace);
+    return DEFTET_OK;
+}
+
+extern "C" int deftet_paste_occ_bwd_f32(const float *cond, const float *grad_out, float *grad_pred, int B, int T, int Q,
+                                        int zero_grad_pred, void *stream_)
+{
+    DEFTET_CHECK_ARG(B >= 0 && T >= 0 && Q >= 0 && B <= 65535, "bad size");
+    hipStream_t st = as_stream(stream_);
+    if (zero_grad_pred && B > 0 && T > 0) {
+        DEFTET_CHECK_ARG(grad_pred, "null grad_pred");
+        DEFTET_HIP(hipMemsetAsync(grad_pred, 0, (size_t)B * T * 4, st));
+    }
+    if (B == 0 || Q == 0) return DEFTET_OK;
+    DEFTET_CHECK_ARG(T > 0 && cond && grad_out && grad_pred, "null pointer / empty tet set");
+    DEFTET_LAUNCH(k_paste_bwd, dim3((Q + 255) / 256, B), dim3(256), st, cond, grad_out, grad_pred, T, Q);
+    return DEFTET_OK;
+}

@@ -1,0 +1,75 @@
+"""Point-in-tet occupancy query with the reference's operator surface.
+
+Mirrors /root/reference/layers/DefTet/check_condition_tetrahedron_base/utils.py:38-62:
+`check_condition_f_base(tet_bxfx4x3, point_pos_bxnx3) -> condition_bxnx1` (float32 tensor
+holding the lowest containing tet index or -1), a torch.autograd.Function whose backward
+returns (None, None) exactly like the reference (utils.py:55-58).
+
+The arithmetic runs in libdeftet_hip.so (deftet_amd/csrc/point_in_tet.hip); there is no
+CPU fallback.  `point_in_tet_bary` is the build-defined differentiable extension
+(SURVEY.md section 8 row A1b): index + barycentric weights with a backward to the tet
+vertex positions (and optionally the query points).
+"""
+import torch
+from torch.autograd import Function
+
+from deftet_amd import hip_ops
+
+
+class TriRender2D(Function):
+    @staticmethod
+    def forward(ctx, tet_bxfx4x3, point_pos_bxnx3):
+        # the reference also builds an (unused) [B,T,6] bbox tensor here (utils.py:47);
+        # the kernel never read it (check_condition_tet_for.cu:154-164), so it is dropped.
+        return hip_ops.point_in_tet(tet_bxfx4x3, point_pos_bxnx3)
+
+    @staticmethod
+    def backward(ctx, condition_bxnx1):
+        return None, None
+
+
+check_condition_f_base = TriRender2D.apply
+
+
+class PointInTetBary(Function):
+    """(tet [B,T,4,3], pts [B,Q,3]) -> (condition [B,Q,1], weights [B,Q,4]).
+
+    weights follow utils/tet_utils.py:28-45 (bary_centric_tet) for the hit tet, zeros for
+    misses; gradients flow to tet (atomic scatter over the hit tets) and to pts."""
+
+    @staticmethod
+    def forward(ctx, tet_bxfx4x3, point_pos_bxnx3):
+        cond, w = hip_ops.point_in_tet(tet_bxfx4x3, point_pos_bxnx3, want_bary=True)
+        ctx.save_for_backward(tet_bxfx4x3, point_pos_bxnx3, cond)
+        ctx.mark_non_differentiable(cond)
+        return cond, w
+
+    @staticmethod
+    def backward(ctx, _grad_cond, grad_w):
+        tet, pts, cond = ctx.saved_tensors
+        need_pts = ctx.needs_input_grad[1]
+        g_tet, g_pts = hip_ops.point_in_tet_bwd(tet, pts, cond, grad_w, want_grad_pts=need_pts)
+        return (g_tet if ctx.needs_input_grad[0] else None), g_pts
+
+
+point_in_tet_bary = PointInTetBary.apply
+
+
+class PasteOcc(Function):
+    """DefTet.paste_occ (layers/DefTet/deftet.py:132-136) as one fused gather with its
+    scatter-add backward; `condition` is clamped in place like the reference does."""
+
+    @staticmethod
+    def forward(ctx, pred_tet_occ, condition):
+        out = hip_ops.paste_occ_fwd(pred_tet_occ, condition)
+        ctx.save_for_backward(condition)
+        ctx.n_tet = pred_tet_occ.shape[1]
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (condition,) = ctx.saved_tensors
+        return hip_ops.paste_occ_bwd(condition, grad_out, ctx.n_tet), None
+
+
+paste_occ = PasteOcc.apply

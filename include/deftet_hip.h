@@ -1,0 +1,178 @@
+/*
+ * deftet_hip.h — C ABI of libdeftet_hip.so, the MI355X (gfx950) implementation of
+ * DefTet's per-tetrahedron hot path.
+ *
+ * Conventions (mirroring the reference's bindings):
+ *   - plain pointers + sizes, no torch types; `stream` is a hipStream_t passed as void*
+ *     (NULL = the legacy default stream);
+ *   - device-pointer entry points: the CALLER allocates every input, output and
+ *     workspace buffer ("caller allocates, callee fills", as check_condition_tet.cpp:31-48
+ *     and the utils/lib run(...) functions do); nothing is allocated behind the caller's back;
+ *   - every entry point returns 0 on success or a negative DEFTET_E* code; the message
+ *     is available from deftet_last_error() (thread-local).  The reference's AT_ASSERTM
+ *     shape/device checks (check_condition_tet.cpp:19-25) become DEFTET_EINVAL;
+ *   - kernels are enqueued on `stream` and NOT synchronised (the reference launches on
+ *     the default stream and does not synchronise either); the `_host` builder variants
+ *     are synchronous because they return data in host memory, exactly like run.so.
+ *
+ * Paths in comments are relative to the reference checkout.
+ */
+#ifndef DEFTET_HIP_H_
+#define DEFTET_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DEFTET_OK 0
+#define DEFTET_EINVAL (-1)   /* bad argument (null pointer, negative size, misaligned, workspace too small) */
+#define DEFTET_ELAUNCH (-2)  /* HIP runtime / kernel launch failure */
+#define DEFTET_ENODEV (-3)   /* no usable gfx950 device */
+#define DEFTET_ELIMIT (-4)   /* size exceeds what the float-encoded index outputs can represent (2^24) */
+
+/* point-in-tet algorithm selector */
+#define DEFTET_PIT_AUTO 0    /* uniform-grid binned, tet-centric (default) */
+#define DEFTET_PIT_BRUTE 1   /* LDS/scalar-tiled brute force: the algorithmic equivalent of the reference kernel */
+
+int deftet_version(void);
+const char *deftet_last_error(void);
+/* number of HIP devices visible; negative code on failure */
+int deftet_device_count(void);
+/* Measurement hook (no reference counterpart; used by bench.py for the roofline figure):
+ * select ONE kernel by name (e.g. "k_tet_scan"; ""/NULL = off); every launch of it is then
+ * bracketed by hipEvents recorded on the launch stream.  deftet_profile_read synchronises
+ * them and returns the summed duration in ms and the number of launches, then resets. */
+int deftet_profile_select(const char *kernel_name);
+int deftet_profile_read(double *total_ms, long long *count);
+
+/* ---------------------------------------------------------------------------------
+ * A1  point-in-tet occupancy query
+ * replaces: layers/DefTet/check_condition_tetrahedron_base/check_condition_tet.cpp:31-48
+ *           (dr_forward_batch) -> check_condition_tet_for.cu:124-216
+ * tet  f32 [B,T,4,3] contiguous, 16-byte aligned;  pts f32 [B,Q,3];
+ * cond f32 [B,Q] (= [B,Q,1]) receives the LOWEST tet index whose four same-side tests
+ *      agree (check_condition_tet_for.cu:172-178), else -1;  fully overwritten.
+ * bary f32 [B,Q,4] or NULL: barycentric weights of the hit tet by the formula of
+ *      utils/tet_utils.py:28-45 (zeros for misses).
+ * ------------------------------------------------------------------------------- */
+size_t deftet_point_in_tet_workspace_bytes(int n_batch, int n_tet, int n_query, int algo);
+int deftet_point_in_tet_f32(const float *tet, const float *pts, float *cond, float *bary,
+                            int n_batch, int n_tet, int n_query, int algo,
+                            void *workspace, size_t workspace_bytes, void *stream);
+
+/* A1b  backward of the weights (the reference's own backward,
+ * check_condition_tetrahedron_base/utils.py:55-58, returns None).
+ * grad_w f32 [B,Q,4] -> grad_tet f32 [B,T,4,3] += d(sum grad_w*w)/d tet   (atomic scatter);
+ * grad_pts f32 [B,Q,3] or NULL receives d/d pts.  zero_grad_tet != 0: the library clears
+ * grad_tet first (hipMemsetAsync on `stream`); otherwise it accumulates into it like the
+ * reference's backward kernels accumulate into wrapper-zeroed buffers
+ * (tet_analytic_distance_batch/utils.py:65). */
+int deftet_point_in_tet_bwd_f32(const float *tet, const float *pts, const float *cond,
+                                const float *grad_w, float *grad_tet, float *grad_pts,
+                                int n_batch, int n_tet, int n_query, int zero_grad_tet, void *stream);
+
+/* DefTet.paste_occ (layers/DefTet/deftet.py:132-136): out[b,q] = pred[b, max(cond[b,q],0)];
+ * cond itself is clamped in place like the reference does (condition[condition<0]=0) when
+ * clamp_cond_inplace != 0.  Backward: grad_pred[b,t] += sum_q grad_out[b,q]. */
+int deftet_paste_occ_fwd_f32(const float *pred_bxt, float *cond_bxq, float *out_bxq,
+                             int n_batch, int n_tet, int n_query, int clamp_cond_inplace, void *stream);
+int deftet_paste_occ_bwd_f32(const float *cond_bxq, const float *grad_out_bxq, float *grad_pred_bxt,
+                             int n_batch, int n_tet, int n_query, int zero_grad_pred, void *stream);
+
+/* ---------------------------------------------------------------------------------
+ * A2-A6  adjacency builders.  Device variants take device pointers and a caller
+ * workspace; `_host` variants keep the EXACT signature of the reference's
+ * `extern "C" void run(...)` (plus an int status) so utils/lib/<lib>/interface.py can be
+ * pointed at this library unchanged.
+ * ------------------------------------------------------------------------------- */
+size_t deftet_builder_workspace_bytes(int n_point, int n_tet);
+
+/* replaces utils/lib/tet_adj_share/run.cpp:40-97.  out int32 [8*n_tet,3] rows
+ * [t0,t1,f0],[t1,t0,f1] in ascending face-key order; *n_out = shared faces (rows/2). */
+int deftet_tet_adj_share_i32(const int32_t *tet_list, int32_t *out_rows, int32_t *n_out_dev,
+                             int n_point, int n_tet, void *workspace, size_t workspace_bytes, void *stream);
+int deftet_tet_adj_share_host(int *tet_list, int *face_edge_p, int *n_face_edge_p, int n_point, int n_tet);
+
+/* replaces utils/lib/tet_face_adj/run.cpp:18-92.  rows [fa,fb]; capacity in rows
+ * (the reference sizes it 4*n_tet*50, interface.py:27-28).  wrap32 != 0 reproduces the
+ * native 32-bit edge key (run.cpp:39); 0 follows the Python twin utils/tet_utils.py:155-201. */
+int deftet_tet_face_adj_i32(const int32_t *tet_list, int32_t *out_rows, long long capacity_rows,
+                            long long *n_out_dev, int n_point, int n_tet, int wrap32,
+                            void *workspace, size_t workspace_bytes, void *stream);
+int deftet_tet_face_adj_host(int *tet_list, int *face_edge_p, int *n_face_edge_p, int n_point, int n_tet);
+
+/* replaces utils/lib/tet_point_adj/run.cpp:20-56.  out int32 [12*n_tet,2], unique directed
+ * vertex pairs sorted by (a,b) (the reference order is libstdc++ hash order — unspecified). */
+int deftet_tet_point_adj_i32(const int32_t *tet_list, int32_t *out_edges, int32_t *n_out_dev,
+                             int n_point, int n_tet, void *workspace, size_t workspace_bytes, void *stream);
+int deftet_tet_point_adj_host(int *tet_list, int *edge_p, int *n_edge, int n_point, int n_tet);
+
+/* replaces utils/lib/colaps_v/run.cpp:39-59 ("%.5f" decimal-string keys, first occurrence wins). */
+int deftet_colaps_v_f32(const float *point_nx3, int32_t *map_array, int32_t *inverse_idx,
+                        int32_t *n_colaps_dev, int n_point, void *workspace, size_t workspace_bytes, void *stream);
+int deftet_colaps_v_host(float *point_p, int *map_array_p, int *inverse_idx_p, int *n_colaps_v_p, int n_point);
+
+/* replaces the pure-Python utils/tet_utils.py:208-256 (with_boundary=0) and
+ * diff_render/diftet_6_subdiv/3_model/prepare_for_wz.py:49-104 (with_boundary=1).
+ * Outputs int64, capacity 4*n_tet rows each, first-seen order; counts[3] (device int32) =
+ * {n_face, n_boundary, n_multi}. */
+int deftet_tet_to_face_i32(const int32_t *tet_list, int64_t *face_fx3, int64_t *tetidx_fx2,
+                           int64_t *tetfaceidx_fx2, int64_t *boundary_fx3, int32_t *counts_dev,
+                           int n_point, int n_tet, int with_boundary,
+                           void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------
+ * A8  surface-face edge adjacency by position
+ * replaces layers/DefTet/tet_face_adj_m_idx/tet_face_adj_m.cpp (forward) ->
+ *          tet_face_adj_m_for.cu:72-130.  adj f32 [F,n_max_nei] pre-filled with -1 by the
+ * caller (utils.py:47); neighbour g ascending, first n_max_nei kept. */
+size_t deftet_face_edge_adj_workspace_bytes(int n_face);
+int deftet_face_edge_adj_f32(const float *face_fx3x3, float *adj_fxm, int n_face, int n_max_nei,
+                             void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------
+ * A9  point -> triangle-soup squared distance
+ * replaces layers/DefTet/tet_analytic_distance_batch/tet_analytic_distance.cpp ->
+ *          tet_analytic_distance_for.cu:256-334 / tet_analytic_distance_back.cu:591-715 */
+int deftet_tri_dist_fwd_f32(const float *pts_bxpx3, const float *face_bxfx3x3, const float *n_face_b,
+                            float *closest_d, float *closest_f, int n_batch, int n_point, int n_max_face,
+                            void *stream);
+/* dldface f32 [B,F,3,3] accumulates (zeroed by the wrapper, utils.py:65).  deterministic != 0:
+ * contributions are reduced in point order per face instead of by floating-point atomics. */
+int deftet_tri_dist_bwd_f32(const float *pts_bxpx3, const float *face_bxfx3x3, const float *closest_f,
+                            const float *dl_dclosest_d, float *dldface, int n_batch, int n_point, int n_face,
+                            int deterministic, void *stream);
+
+/* ---------------------------------------------------------------------------------
+ * A10 brute-force nearest-neighbour index
+ * replaces layers/nearest_neighbor/nearest_neighbor.cpp -> nearest_neighbor_cuda.cu:17-80
+ * result int32 [B,N]: index of the first point with the strictly smallest fp32 distance. */
+int deftet_nn_index_f32(const float *queries_bxnx3, const float *points_bxmx3, int32_t *result_bxn,
+                        int n_batch, int n_query, int n_point, void *stream);
+
+/* ---------------------------------------------------------------------------------
+ * A12 differentiable tet rasterizer with the contract of
+ * kaolin.render.mesh.deftet_sparse_render as called at
+ * diff_render/diftet_6_subdiv/5_rendereq/deftetrneder.py:97-100 (Kaolin itself is not part
+ * of the reference tree: parity unpinned). */
+size_t deftet_sparse_render_workspace_bytes(int n_batch, int n_pixel, int n_face, int knum);
+int deftet_sparse_render_fwd_f32(const float *pixel_bxpx2, const float *range_bxpx2,
+                                 const float *face_z_bxfx3, const float *face_xy_bxfx3x2,
+                                 const float *face_feat_bxfx3xd, float *out_feat_bxpxkxd,
+                                 int64_t *out_face_bxpxk, float *out_w_bxpxkx3,
+                                 int n_batch, int n_pixel, int n_face, int n_feat, int knum, float eps,
+                                 void *workspace, size_t workspace_bytes, void *stream);
+int deftet_sparse_render_bwd_f32(const float *pixel_bxpx2, const float *face_xy_bxfx3x2,
+                                 const float *face_feat_bxfx3xd, const int64_t *face_bxpxk,
+                                 const float *w_bxpxkx3, const float *grad_out_bxpxkxd,
+                                 float *grad_face_xy, float *grad_face_feat,
+                                 int n_batch, int n_pixel, int n_face, int n_feat, int knum, float eps,
+                                 void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEFTET_HIP_H_ */
