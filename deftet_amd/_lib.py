@@ -66,6 +66,10 @@ def load():
                 raise DefTetHipError(
                     "libdeftet_hip.so is missing (%s). Build it with `python -m deftet_amd.build`; "
                     "there is no CPU fallback." % LIB_PATH)
+            # torch bundles its own HIP runtime under the same SONAME (libamdhip64.so.7); it must
+            # be the one already mapped when our library resolves its dependency, otherwise the
+            # process ends up with two runtimes and ours sees no device.
+            import torch  # noqa: F401
             lib = C.CDLL(LIB_PATH)
             for name, (res, args) in SIGNATURES.items():
                 fn = getattr(lib, name)          # AttributeError = symbol not exported

@@ -92,22 +92,39 @@ struct Grid {
     float o[3], inv[3], lo[3], hi[3];
 };
 
-// one thread per shape: decode the query bounding box into grid parameters (12 floats)
-__global__ void k_grid_params(const int *__restrict__ bbox, int G, int nB, float *gparam)
+// one wave per shape: reduce the per-block query boxes into grid parameters (12 floats)
+__global__ __launch_bounds__(64) void k_grid_params(const float *__restrict__ part, int nPart, int G, float *gparam)
 {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nB) return;
+    const int b = blockIdx.x, lane = threadIdx.x;
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = lane; i < nPart; i += 64) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = fminf(lo[k], part[((size_t)b * nPart + i) * 6 + k]);
+            hi[k] = fmaxf(hi[k], part[((size_t)b * nPart + i) * 6 + 3 + k]);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = fminf(lo[k], __shfl_xor(lo[k], off));
+            hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off));
+        }
+    }
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        float lo = ord2f(bbox[b * 6 + k]), hi = ord2f(bbox[b * 6 + 3 + k]);
-        bool ok = hi >= lo;                       // false when no regular query was seen
-        float ext = hi - lo;
-        lo = ok ? lo : 0.f;
-        hi = ok ? hi : 0.f;
-        gparam[b * 12 + k] = lo;                                              // origin
-        gparam[b * 12 + 3 + k] = (ok && ext > 1e-30f) ? (float)G / ext : 0.f;  // cells per unit
-        gparam[b * 12 + 6 + k] = lo;
-        gparam[b * 12 + 9 + k] = hi;
+        float l = lo[k], h = hi[k];
+        bool ok = h >= l;                         // false when no regular query was seen
+        float ext = h - l;
+        l = ok ? l : 0.f;
+        h = ok ? h : 0.f;
+        if (lane == 0) {
+            gparam[b * 12 + k] = l;                                               // origin
+            gparam[b * 12 + 3 + k] = (ok && ext > 1e-30f) ? (float)G / ext : 0.f;  // cells per unit
+            gparam[b * 12 + 6 + k] = l;
+            gparam[b * 12 + 9 + k] = h;
+        }
     }
 }
 
@@ -140,28 +157,30 @@ __device__ __forceinline__ bool query_regular(float x, float y, float z)
 // ------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------
-__global__ void k_init(int *bbox, int *counters, int *cells, int *result, int nB, long long nCells, long long nQ)
+__global__ void k_init(int *counters, int *cells, int *result, int nB, long long nCells, long long nQ)
 {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     long long stride = (long long)gridDim.x * blockDim.x;
-    if (i < nB * 6) bbox[i] = (i % 6) < 3 ? 0x7FFFFFFF : (int)0x80000000;
     if (i < nB * 4) counters[i] = 0;
     for (long long j = i; j < nCells; j += stride) cells[j] = 0;
     for (long long j = i; j < nQ; j += stride) result[j] = kMiss;
 }
 
-// query bounding box per shape + list of irregular queries
-__global__ __launch_bounds__(256) void k_query_bbox(const float *__restrict__ pts, int Q, int *bbox, int *counters,
+// query bounding box per shape (per-block partials, no contended atomics) + list of
+// irregular queries.  part layout: [B][kBoxBlocks][6] floats (lo xyz, hi xyz); a block that
+// saw no regular query writes (+inf, -inf).
+constexpr int kBoxBlocks = 64;
+
+__global__ __launch_bounds__(256) void k_query_bbox(const float *__restrict__ pts, int Q, float *part, int *counters,
                                                     int *irregQ)
 {
+    __shared__ float sh[4][6];
     const int b = blockIdx.y;
     const float *p = pts + (size_t)b * Q * 3;
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    bool any = false;
     for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < Q; q += gridDim.x * blockDim.x) {
         float x = p[q * 3], y = p[q * 3 + 1], z = p[q * 3 + 2];
         if (query_regular(x, y, z)) {
-            any = true;
             lo[0] = fminf(lo[0], x); lo[1] = fminf(lo[1], y); lo[2] = fminf(lo[2], z);
             hi[0] = fmaxf(hi[0], x); hi[1] = fmaxf(hi[1], y); hi[2] = fmaxf(hi[2], z);
         } else {
@@ -177,13 +196,17 @@ __global__ __launch_bounds__(256) void k_query_bbox(const float *__restrict__ pt
             hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off));
         }
     }
-    unsigned long long anyw = __ballot(any);
-    if ((threadIdx.x & 63) == 0 && anyw) {
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            atomicMin(&bbox[b * 6 + k], f2ord(lo[k]));
-            atomicMax(&bbox[b * 6 + 3 + k], f2ord(hi[k]));
-        }
+        for (int k = 0; k < 3; ++k) { sh[w][k] = lo[k]; sh[w][3 + k] = hi[k]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int k = threadIdx.x;
+        float v = sh[0][k];
+        for (int i = 1; i < 4; ++i) v = k < 3 ? fminf(v, sh[i][k]) : fmaxf(v, sh[i][k]);
+        part[((size_t)b * kBoxBlocks + blockIdx.x) * 6 + k] = v;
     }
 }
 
@@ -237,31 +260,31 @@ __global__ __launch_bounds__(256) void k_scan_chunks(int *cells, long long cellS
     if (threadIdx.x == 255) chunkTot[b * nChunk + c] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
-// exclusive scan of the chunk totals of one shape (nChunk <= 512)
-__global__ __launch_bounds__(512) void k_scan_totals(int *chunkTot, int nChunk)
+// add the exclusive prefix of the chunk totals to every cell of the chunk (nChunk <= 512)
+__global__ __launch_bounds__(256) void k_scan_apply(int *cells, long long cellStride, int nChunk,
+                                                    const int *__restrict__ chunkTot)
 {
-    __shared__ int sh[512];
-    const int b = blockIdx.x, i = threadIdx.x;
-    int v = i < nChunk ? chunkTot[b * nChunk + i] : 0;
-    sh[i] = v;
+    __shared__ int wsum[4];
+    const int b = blockIdx.y, c = blockIdx.x;
+    int v = 0;
+    for (int i = threadIdx.x; i < c; i += 256) v += chunkTot[b * nChunk + i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = v;
     __syncthreads();
-    for (int off = 1; off < 512; off <<= 1) {
-        int t = i >= off ? sh[i - off] : 0;
-        __syncthreads();
-        sh[i] += t;
-        __syncthreads();
+    const int base = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (c == 0) return;
+    int4 *p = reinterpret_cast<int4 *>(cells + (size_t)b * cellStride + (size_t)c * kChunk);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        int4 x = p[threadIdx.x * 2 + k];
+        x.x += base; x.y += base; x.z += base; x.w += base;
+        p[threadIdx.x * 2 + k] = x;
     }
-    if (i < nChunk) chunkTot[b * nChunk + i] = sh[i] - v;
-}
-
-__device__ __forceinline__ int cell_start(const int *__restrict__ cells, const int *__restrict__ chunkBase, int c)
-{
-    return cells[c] + chunkBase[c / kChunk];
 }
 
 __global__ __launch_bounds__(256) void k_query_scatter(const float *__restrict__ pts, int Q, const int2 *__restrict__ qcell,
-                                                       const int *__restrict__ cells, long long cellStride,
-                                                       const int *__restrict__ chunkBase, int nChunk, float4 *sortedQ)
+                                                       const int *__restrict__ cells, long long cellStride, float4 *sortedQ)
 {
     const int b = blockIdx.y;
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
@@ -269,15 +292,14 @@ __global__ __launch_bounds__(256) void k_query_scatter(const float *__restrict__
     int2 r = qcell[(size_t)b * Q + q];
     if (r.x < 0) return;
     const float *p = pts + ((size_t)b * Q + q) * 3;
-    int pos = cell_start(cells + (size_t)b * cellStride, chunkBase + b * nChunk, r.x) + r.y;
+    int pos = cells[(size_t)b * cellStride + r.x] + r.y;
     sortedQ[(size_t)b * Q + pos] = make_float4(p[0], p[1], p[2], __int_as_float(q));
 }
 
 // the main kernel: one lane per tet
 __global__ __launch_bounds__(256) void k_tet_scan(const float *__restrict__ tet, int T, int Q,
                                                   const float *__restrict__ gparam, int G, const int *__restrict__ cells,
-                                                  long long cellStride, const int *__restrict__ chunkBase, int nChunk,
-                                                  const float4 *__restrict__ sortedQ, int *result, int *counters,
+                                                  long long cellStride, const float4 *__restrict__ sortedQ, int *result, int *counters,
                                                   int *irregT)
 {
     const int b = blockIdx.y;
@@ -327,21 +349,43 @@ __global__ __launch_bounds__(256) void k_tet_scan(const float *__restrict__ tet,
     const int cy0 = cell_of(elo[1], g.o[1], g.inv[1], G), cy1 = cell_of(ehi[1], g.o[1], g.inv[1], G);
     const int cz0 = cell_of(elo[2], g.o[2], g.inv[2], G), cz1 = cell_of(ehi[2], g.o[2], g.inv[2], G);
     const int *cb = cells + (size_t)b * cellStride;
-    const int *kb = chunkBase + b * nChunk;
     const float4 *sq = sortedQ + (size_t)b * Q;
     int *res = result + (size_t)b * Q;
-    for (int cz = cz0; cz <= cz1; ++cz)
-        for (int cy = cy0; cy <= cy1; ++cy) {
-            const int row = (cz * G + cy) * G;
-            const int s = cell_start(cb, kb, row + cx0);
-            const int e = cell_start(cb, kb, row + cx1 + 1);   // cells has G^3+1 valid entries
-            for (int j = s; j < e; ++j) {
-                const float4 q = sq[j];
-                if (q.x >= elo[0] && q.x <= ehi[0] && q.y >= elo[1] && q.y <= ehi[1] && q.z >= elo[2] && q.z <= ehi[2]) {
-                    if (accept(P, q.x, q.y, q.z)) atomicMin(&res[__float_as_int(q.w)], t);
-                }
-            }
+    // Walk the (cz, cy) rows of the cell range; the x-run of a row is contiguous in sortedQ.
+    // Latency hiding per lane: the next row's [start,end) is fetched before the current
+    // row's queries are tested, and queries are fetched four at a time.
+    auto test = [&](const float4 &q) {
+        if (q.x >= elo[0] && q.x <= ehi[0] && q.y >= elo[1] && q.y <= ehi[1] && q.z >= elo[2] && q.z <= ehi[2]) {
+            if (accept(P, q.x, q.y, q.z)) atomicMin(&res[__float_as_int(q.w)], t);
         }
+    };
+    int cy = cy0, cz = cz0;
+    int s = cb[(cz * G + cy) * G + cx0];
+    int e = cb[(cz * G + cy) * G + cx1 + 1];           // cells has G^3+1 valid entries
+    for (;;) {
+        int ny = cy + 1, nz = cz;
+        if (ny > cy1) { ny = cy0; nz = cz + 1; }
+        const bool more = nz <= cz1;
+        int s2 = 0, e2 = 0;
+        if (more) {
+            const int row2 = (nz * G + ny) * G;
+            s2 = cb[row2 + cx0];
+            e2 = cb[row2 + cx1 + 1];
+        }
+        for (int j = s; j < e; j += 4) {
+            const int last = e - 1;
+            const float4 q0 = sq[j];
+            const float4 q1 = sq[min(j + 1, last)];
+            const float4 q2 = sq[min(j + 2, last)];
+            const float4 q3 = sq[min(j + 3, last)];
+            test(q0);
+            if (j + 1 < e) test(q1);
+            if (j + 2 < e) test(q2);
+            if (j + 3 < e) test(q3);
+        }
+        if (!more) break;
+        s = s2; e = e2; cy = ny; cz = nz;
+    }
 }
 
 // irregular tets x all queries
@@ -543,7 +587,7 @@ __global__ __launch_bounds__(256) void k_bary_bwd(const float *__restrict__ tet,
 #pragma unroll
         for (int vtx = 0; vtx < 4; ++vtx)
 #pragma unroll
-            for (int k = 0; k < 3; ++k) atomicAdd(gt + vtx * 3 + k, -w[vtx] * G3[k]);
+            for (int k = 0; k < 3; ++k) unsafeAtomicAdd(gt + vtx * 3 + k, -w[vtx] * G3[k]);
     }
     if (grad_pts) {
         grad_pts[i * 3 + 0] = G3[0];
@@ -573,11 +617,18 @@ __global__ __launch_bounds__(256) void k_paste_bwd(const float *__restrict__ con
 {
     const int b = blockIdx.y;
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= Q) return;
-    const size_t i = (size_t)b * Q + q;
-    float c = cond[i];
-    if (c < 0) c = 0.f;
-    atomicAdd(&gpred[(size_t)b * T + (long long)c], gout[i]);
+    const bool live = q < Q;
+    const size_t i = (size_t)b * Q + (live ? q : 0);
+    const float c = live ? cond[i] : 0.f;
+    const float g = live ? gout[i] : 0.f;
+    // misses alias tet 0 (deftet.py:133): thousands of queries per shape hit one address, so
+    // their gradients are summed across the wave first and sent as one atomic
+    const bool miss = live && c < 0;
+    float gm = miss ? g : 0.f;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) gm += __shfl_xor(gm, off);
+    if ((threadIdx.x & 63) == 0 && gm != 0.f) unsafeAtomicAdd(&gpred[(size_t)b * T], gm);
+    if (live && !miss) unsafeAtomicAdd(&gpred[(size_t)b * T + (long long)c], g);
 }
 
 // ------------------------------------------------------------------------------------
@@ -597,7 +648,8 @@ struct Layout {
     int G, nChunk;
     long long cellStride;   // padded cells per shape (multiple of kChunk, >= G^3+1)
     size_t bytes;
-    int *bbox, *counters, *cells, *chunkTot, *result, *irregT, *irregQ;
+    float *bboxPart;
+    int *counters, *cells, *chunkTot, *result, *irregT, *irregQ;
     int2 *qcell;
     float4 *sortedQ;
     float *rec, *gparam;
@@ -615,7 +667,7 @@ static Layout make_layout(int B, int T, int Q, int algo, void *ws, size_t wsByte
         long long n = (long long)L.G * L.G * L.G + 1;
         L.nChunk = (int)((n + kChunk - 1) / kChunk);
         L.cellStride = (long long)L.nChunk * kChunk;
-        L.bbox = A.take<int>((size_t)B * 6);
+        L.bboxPart = A.take<float>((size_t)B * kBoxBlocks * 6);
         L.counters = A.take<int>((size_t)B * 4);
         L.gparam = A.take<float>((size_t)B * 12);
         L.cells = A.take<int>((size_t)B * L.cellStride);
@@ -671,19 +723,16 @@ extern "C" int deftet_point_in_tet_f32(const float *tet, const float *pts, float
         long long mx = nCells > nQ ? nCells : nQ;
         int ib = (int)((mx + 255) / 256);
         if (ib > 4096) ib = 4096;
-        DEFTET_LAUNCH(k_init, dim3(ib), blk, st, L.bbox, L.counters, L.cells, L.result, B, nCells, nQ);
-        int nb = (Q + 255) / 256;
-        if (nb > 256) nb = 256;
-        DEFTET_LAUNCH(k_query_bbox, dim3(nb, B), blk, st, pts, Q, L.bbox, L.counters, L.irregQ);
-        DEFTET_LAUNCH(k_grid_params, dim3((B + 63) / 64), dim3(64), st, L.bbox, L.G, B, L.gparam);
+        DEFTET_LAUNCH(k_init, dim3(ib), blk, st, L.counters, L.cells, L.result, B, nCells, nQ);
+        DEFTET_LAUNCH(k_query_bbox, dim3(kBoxBlocks, B), blk, st, pts, Q, L.bboxPart, L.counters, L.irregQ);
+        DEFTET_LAUNCH(k_grid_params, dim3(B), dim3(64), st, L.bboxPart, kBoxBlocks, L.G, L.gparam);
         DEFTET_LAUNCH(k_query_bin, gq, blk, st, pts, Q, L.gparam, L.G, L.cellStride, L.cells, L.qcell);
         DEFTET_LAUNCH(k_scan_chunks, dim3(L.nChunk, B), blk, st, L.cells, L.cellStride, L.nChunk, L.chunkTot);
-        DEFTET_LAUNCH(k_scan_totals, dim3(B), dim3(512), st, L.chunkTot, L.nChunk);
-        DEFTET_LAUNCH(k_query_scatter, gq, blk, st, pts, Q, L.qcell, L.cells, L.cellStride, L.chunkTot, L.nChunk,
-                           L.sortedQ);
+        DEFTET_LAUNCH(k_scan_apply, dim3(L.nChunk, B), blk, st, L.cells, L.cellStride, L.nChunk, L.chunkTot);
+        DEFTET_LAUNCH(k_query_scatter, gq, blk, st, pts, Q, L.qcell, L.cells, L.cellStride, L.sortedQ);
         if (T > 0) {
-            DEFTET_LAUNCH(k_tet_scan, gt, blk, st, tet, T, Q, L.gparam, L.G, L.cells, L.cellStride, L.chunkTot,
-                               L.nChunk, L.sortedQ, L.result, L.counters, L.irregT);
+            DEFTET_LAUNCH(k_tet_scan, gt, blk, st, tet, T, Q, L.gparam, L.G, L.cells, L.cellStride, L.sortedQ, L.result,
+                          L.counters, L.irregT);
             int qb = (Q + 255) / 256, tb = (T + 255) / 256;
             if (qb > 1024) qb = 1024;
             if (tb > 1024) tb = 1024;
