@@ -596,6 +596,86 @@ __global__ __launch_bounds__(256) void k_bary_bwd(const float *__restrict__ tet,
     }
 }
 
+// --- atomic-free backward -----------------------------------------------------------------
+// Device-scope fp32 atomics are fabric transactions on MI355X (~20 G/s measured); 12 per hit
+// made the scatter above the slowest kernel of the step.  Instead: thread the hits of every
+// tet into a linked list (ONE returning atomicExch per hit), then one lane per tet walks its
+// list, accumulates the 12 partials in registers and stores its 48-byte gradient record
+// once, coalesced.  No memset of grad_tet is needed: every tet is written.
+__global__ __launch_bounds__(256) void k_hit_link(const float *__restrict__ cond, int T, int Q, int *head, int *next)
+{
+    const int b = blockIdx.y;
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= Q) return;
+    const size_t i = (size_t)b * Q + q;
+    const float c = cond[i];
+    if (c >= 0.f) next[i] = atomicExch(&head[(size_t)b * T + (int)c], q);
+}
+
+__global__ __launch_bounds__(256) void k_bary_bwd_gather(const float *__restrict__ tet, const float *__restrict__ pts,
+                                                         const float *__restrict__ grad_w, const int *__restrict__ head,
+                                                         const int *__restrict__ next, int T, int Q, float *grad_tet,
+                                                         float *grad_pts, int accumulate)
+{
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    float acc[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) acc[k] = 0.f;
+    int q = head[(size_t)b * T + t];
+    if (q >= 0) {
+        const float4 *src = reinterpret_cast<const float4 *>(tet + ((size_t)b * T + t) * 12);
+        float4 t0 = src[0], t1 = src[1], t2 = src[2];
+        const float A[3] = {t0.x, t0.y, t0.z}, Bv[3] = {t0.w, t1.x, t1.y}, Cv[3] = {t1.z, t1.w, t2.x}, D[3] = {t2.y, t2.z, t2.w};
+        float vab[3], vac[3], vad[3], vbc[3], vbd[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            vab[k] = Bv[k] - A[k]; vac[k] = Cv[k] - A[k]; vad[k] = D[k] - A[k];
+            vbc[k] = Cv[k] - Bv[k]; vbd[k] = D[k] - Bv[k];
+        }
+        float na[3], nb[3], nc[3], nd[3];
+        cross3(vbd, vbc, na);
+        cross3(vac, vad, nb);
+        cross3(vad, vab, nc);
+        cross3(vab, vac, nd);
+        const float v6 = 1.0f / (vab[0] * nb[0] + vab[1] * nb[1] + vab[2] * nb[2]);
+        while (q >= 0) {
+            const size_t i = (size_t)b * Q + q;
+            const float *pp = pts + i * 3;
+            const float4 g = reinterpret_cast<const float4 *>(grad_w)[i];
+            const int qn = next[i];
+            float vap[3], vbp[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { vap[k] = pp[k] - A[k]; vbp[k] = pp[k] - Bv[k]; }
+            float w[4];
+            w[0] = (vbp[0] * na[0] + vbp[1] * na[1] + vbp[2] * na[2]) * v6;
+            w[1] = (vap[0] * nb[0] + vap[1] * nb[1] + vap[2] * nb[2]) * v6;
+            w[2] = (vap[0] * nc[0] + vap[1] * nc[1] + vap[2] * nc[2]) * v6;
+            w[3] = (vap[0] * nd[0] + vap[1] * nd[1] + vap[2] * nd[2]) * v6;
+            float G3[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) G3[k] = (g.x * na[k] + g.y * nb[k] + g.z * nc[k] + g.w * nd[k]) * v6;
+#pragma unroll
+            for (int vtx = 0; vtx < 4; ++vtx)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) acc[vtx * 3 + k] += -w[vtx] * G3[k];
+            if (grad_pts) { grad_pts[i * 3] = G3[0]; grad_pts[i * 3 + 1] = G3[1]; grad_pts[i * 3 + 2] = G3[2]; }
+            q = qn;
+        }
+    }
+    float4 *dst = reinterpret_cast<float4 *>(grad_tet + ((size_t)b * T + t) * 12);
+    float4 o0 = make_float4(acc[0], acc[1], acc[2], acc[3]), o1 = make_float4(acc[4], acc[5], acc[6], acc[7]),
+           o2 = make_float4(acc[8], acc[9], acc[10], acc[11]);
+    if (accumulate) {
+        float4 p0 = dst[0], p1 = dst[1], p2 = dst[2];
+        o0.x += p0.x; o0.y += p0.y; o0.z += p0.z; o0.w += p0.w;
+        o1.x += p1.x; o1.y += p1.y; o1.z += p1.z; o1.w += p1.w;
+        o2.x += p2.x; o2.y += p2.y; o2.z += p2.z; o2.w += p2.w;
+    }
+    dst[0] = o0; dst[1] = o1; dst[2] = o2;
+}
+
 // paste_occ, layers/DefTet/deftet.py:132-136
 __global__ __launch_bounds__(256) void k_paste_fwd(const float *__restrict__ pred, float *cond, float *out, int T, int Q,
                                                    int clamp_inplace)
@@ -621,9 +701,10 @@ __global__ __launch_bounds__(256) void k_paste_bwd(const float *__restrict__ con
     const size_t i = (size_t)b * Q + (live ? q : 0);
     const float c = live ? cond[i] : 0.f;
     const float g = live ? gout[i] : 0.f;
-    // misses alias tet 0 (deftet.py:133): thousands of queries per shape hit one address, so
-    // their gradients are summed across the wave first and sent as one atomic
-    const bool miss = live && c < 0;
+    // misses alias tet 0 (deftet.py:133; the caller may already have clamped them to 0.0):
+    // thousands of queries per shape hit one address, so everything destined for tet 0 is
+    // summed across the wave first and sent as one atomic
+    const bool miss = live && c < 1.0f;
     float gm = miss ? g : 0.f;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) gm += __shfl_xor(gm, off);
@@ -744,22 +825,44 @@ extern "C" int deftet_point_in_tet_f32(const float *tet, const float *pts, float
     return DEFTET_OK;
 }
 
+extern "C" size_t deftet_point_in_tet_bwd_workspace_bytes(int B, int T, int Q)
+{
+    if (B <= 0 || T < 0 || Q < 0) return 0;
+    return align_up((size_t)B * T * 4, 256) + align_up((size_t)B * Q * 4, 256);
+}
+
 extern "C" int deftet_point_in_tet_bwd_f32(const float *tet, const float *pts, const float *cond, const float *grad_w,
-                                           float *grad_tet, float *grad_pts, int B, int T, int Q, int zero_grad_tet,
-                                           void *stream_)
+                                           float *grad_tet, float *grad_pts, int B, int T, int Q, int accumulate,
+                                           void *workspace, size_t workspace_bytes, void *stream_)
 {
     DEFTET_CHECK_ARG(B >= 0 && T >= 0 && Q >= 0, "negative size");
     DEFTET_CHECK_ARG(B <= 65535, "n_batch=%d exceeds 65535", B);
     hipStream_t st = as_stream(stream_);
-    if (zero_grad_tet && B > 0 && T > 0) {
-        DEFTET_CHECK_ARG(grad_tet, "null grad_tet");
-        DEFTET_HIP(hipMemsetAsync(grad_tet, 0, (size_t)B * T * 48, st));
+    if (B == 0 || T == 0) return DEFTET_OK;
+    DEFTET_CHECK_ARG(grad_tet && ((uintptr_t)grad_tet & 15) == 0, "grad_tet null or not 16-byte aligned");
+    if (grad_pts && Q > 0) DEFTET_HIP(hipMemsetAsync(grad_pts, 0, (size_t)B * Q * 12, st));
+    if (Q == 0) {
+        if (!accumulate) DEFTET_HIP(hipMemsetAsync(grad_tet, 0, (size_t)B * T * 48, st));
+        return DEFTET_OK;
     }
-    if (B == 0 || Q == 0 || T == 0) return DEFTET_OK;
-    DEFTET_CHECK_ARG(tet && pts && cond && grad_w && grad_tet, "null pointer");
+    DEFTET_CHECK_ARG(tet && pts && cond && grad_w, "null pointer");
     DEFTET_CHECK_ARG(((uintptr_t)tet & 15) == 0 && ((uintptr_t)grad_w & 15) == 0, "tet/grad_w must be 16-byte aligned");
-    DEFTET_LAUNCH(k_bary_bwd, dim3((Q + 255) / 256, B), dim3(256), st, tet, pts, cond, grad_w, T, Q, grad_tet,
-                       grad_pts);
+    if (workspace) {
+        const size_t need = deftet_point_in_tet_bwd_workspace_bytes(B, T, Q);
+        DEFTET_CHECK_ARG(workspace_bytes >= need && ((uintptr_t)workspace & 255) == 0,
+                         "backward workspace too small (%zu < %zu) or misaligned", workspace_bytes, need);
+        int *head = static_cast<int *>(workspace);
+        int *next = reinterpret_cast<int *>(static_cast<char *>(workspace) + align_up((size_t)B * T * 4, 256));
+        DEFTET_HIP(hipMemsetAsync(head, 0xFF, (size_t)B * T * 4, st));      // -1 = empty list
+        DEFTET_LAUNCH(k_hit_link, dim3((Q + 255) / 256, B), dim3(256), st, cond, T, Q, head, next);
+        DEFTET_LAUNCH(k_bary_bwd_gather, dim3((T + 255) / 256, B), dim3(256), st, tet, pts, grad_w, head, next, T, Q,
+                      grad_tet, grad_pts, accumulate);
+    } else {
+        // no workspace: atomic scatter (slow on this chip; kept for callers that cannot provide one)
+        if (!accumulate) DEFTET_HIP(hipMemsetAsync(grad_tet, 0, (size_t)B * T * 48, st));
+        DEFTET_LAUNCH(k_bary_bwd, dim3((Q + 255) / 256, B), dim3(256), st, tet, pts, cond, grad_w, T, Q, grad_tet,
+                      grad_pts);
+    }
     return DEFTET_OK;
 }
 

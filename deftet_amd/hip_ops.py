@@ -50,9 +50,11 @@ def point_in_tet_bwd(tet_bxtx4x3, pts_bxqx3, cond, grad_w, want_grad_pts=False):
     grad_tet = torch.empty_like(tet)
     grad_pts = torch.empty_like(pts) if want_grad_pts else None
     with torch.cuda.device(dev):
+        ws = _lib.workspace(dev, lib.deftet_point_in_tet_bwd_workspace_bytes(B, T, Q))
         _lib.check(lib.deftet_point_in_tet_bwd_f32(_lib.ptr(tet), _lib.ptr(pts), _lib.ptr(cond), _lib.ptr(gw),
-                                                   _lib.ptr(grad_tet), _lib.ptr(grad_pts), B, T, Q, 1,
-                                                   _lib.current_stream(dev)), "deftet_point_in_tet_bwd_f32")
+                                                   _lib.ptr(grad_tet), _lib.ptr(grad_pts), B, T, Q, 0,
+                                                   _lib.ptr(ws), ws.numel(), _lib.current_stream(dev)),
+                   "deftet_point_in_tet_bwd_f32")
     return grad_tet, grad_pts
 
 

@@ -65,14 +65,17 @@ int deftet_point_in_tet_f32(const float *tet, const float *pts, float *cond, flo
 
 /* A1b  backward of the weights (the reference's own backward,
  * check_condition_tetrahedron_base/utils.py:55-58, returns None).
- * grad_w f32 [B,Q,4] -> grad_tet f32 [B,T,4,3] += d(sum grad_w*w)/d tet   (atomic scatter);
- * grad_pts f32 [B,Q,3] or NULL receives d/d pts.  zero_grad_tet != 0: the library clears
- * grad_tet first (hipMemsetAsync on `stream`); otherwise it accumulates into it like the
- * reference's backward kernels accumulate into wrapper-zeroed buffers
- * (tet_analytic_distance_batch/utils.py:65). */
+ * grad_w f32 [B,Q,4] -> grad_tet f32 [B,T,4,3] = d(sum grad_w*w)/d tet; grad_pts f32 [B,Q,3]
+ * or NULL receives d/d pts.  accumulate == 0: grad_tet is fully overwritten (no pre-zeroing
+ * needed); != 0: the result is added to its current content, like the reference's backward
+ * kernels add into wrapper-zeroed buffers (tet_analytic_distance_batch/utils.py:65).
+ * workspace (deftet_point_in_tet_bwd_workspace_bytes) enables the atomic-free gather path;
+ * NULL selects a float-atomic scatter. */
+size_t deftet_point_in_tet_bwd_workspace_bytes(int n_batch, int n_tet, int n_query);
 int deftet_point_in_tet_bwd_f32(const float *tet, const float *pts, const float *cond,
                                 const float *grad_w, float *grad_tet, float *grad_pts,
-                                int n_batch, int n_tet, int n_query, int zero_grad_tet, void *stream);
+                                int n_batch, int n_tet, int n_query, int accumulate,
+                                void *workspace, size_t workspace_bytes, void *stream);
 
 /* DefTet.paste_occ (layers/DefTet/deftet.py:132-136): out[b,q] = pred[b, max(cond[b,q],0)];
  * cond itself is clamped in place like the reference does (condition[condition<0]=0) when

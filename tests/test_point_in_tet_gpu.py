@@ -111,3 +111,32 @@ def test_rejects_cpu_tensors():
     from deftet_amd import hip_ops, _lib
     with pytest.raises(_lib.DefTetHipError):
         hip_ops.point_in_tet(torch.zeros(1, 1, 4, 3), torch.zeros(1, 1, 3))
+
+
+def test_backward_atomic_fallback_matches_gather(cuda, oracle):
+    """deftet_point_in_tet_bwd_f32 with workspace=NULL (float-atomic scatter) and with a
+    workspace (linked-list gather) must agree; accumulate=1 adds to the existing content."""
+    import ctypes as C
+    from deftet_amd import _lib, hip_ops
+    lib = _lib.load()
+    tet, pts = cases.jittered(8, 3000, 2)
+    t = torch.from_numpy(tet).to(cuda)
+    p = torch.from_numpy(pts).to(cuda)
+    cond = hip_ops.point_in_tet(t, p)
+    gw = torch.randn(2, 3000, 4, device=cuda, generator=torch.Generator(device=cuda).manual_seed(1))
+    g_gather, gp = hip_ops.point_in_tet_bwd(t, p, cond, gw, want_grad_pts=True)
+    g_atomic = torch.full_like(t, 7.0)          # must be overwritten when accumulate == 0
+    st = _lib.current_stream(cuda)
+    _lib.check(lib.deftet_point_in_tet_bwd_f32(_lib.ptr(t), _lib.ptr(p), _lib.ptr(cond), _lib.ptr(gw), _lib.ptr(g_atomic),
+                                               None, 2, t.shape[1], 3000, 0, None, 0, st), "bwd atomic")
+    torch.cuda.synchronize()
+    scale = g_gather.abs().max().item()
+    assert (g_gather - g_atomic).abs().max().item() <= 1e-5 * scale
+    acc = torch.ones_like(t)
+    ws = _lib.workspace(cuda, lib.deftet_point_in_tet_bwd_workspace_bytes(2, t.shape[1], 3000))
+    _lib.check(lib.deftet_point_in_tet_bwd_f32(_lib.ptr(t), _lib.ptr(p), _lib.ptr(cond), _lib.ptr(gw), _lib.ptr(acc),
+                                               None, 2, t.shape[1], 3000, 1, _lib.ptr(ws), ws.numel(), st), "bwd acc")
+    torch.cuda.synchronize()
+    assert (acc - 1.0 - g_gather).abs().max().item() <= 1e-5 * scale
+    miss = cond[..., 0] < 0
+    assert (gp[miss] == 0).all() and gp[~miss].abs().sum() > 0
