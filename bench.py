@@ -55,7 +55,8 @@ def step(d, world, gather_buf):
     occ = hip_ops.paste_occ_fwd(d["pred"], cond_c)
     g_tet, _ = hip_ops.point_in_tet_bwd(d["tet"], d["pts"], cond, d["gw"])
     g_pred = hip_ops.paste_occ_bwd(cond_c, d["gout"], d["tet"].shape[1])
-    loss = (w * d["gw"]).sum(dim=(1, 2)) + (occ * d["gout"]).sum(dim=1)       # [B] per-shape scalars
+    B = w.shape[0]                                                            # [B] per-shape loss scalars
+    loss = (torch.bmm(w.view(B, 1, -1), d["gw"].view(B, -1, 1)) + torch.bmm(occ.view(B, 1, -1), d["gout"].view(B, -1, 1))).view(B)
     if world > 1:
         torch.distributed.all_gather_into_tensor(gather_buf, loss)            # the only collective
     return cond, w, g_tet, g_pred, loss

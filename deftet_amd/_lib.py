@@ -11,7 +11,7 @@ import os
 import threading
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libdeftet_hip.so")
+LIB_PATH = os.environ.get("DEFTET_HIP_LIB") or os.path.join(HERE, "libdeftet_hip.so")   # env override: experiments only
 
 _vp, _i, _sz, _ll, _f = C.c_void_p, C.c_int, C.c_size_t, C.c_longlong, C.c_float
 

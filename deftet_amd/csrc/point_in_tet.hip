@@ -356,7 +356,13 @@ __global__ __launch_bounds__(256) void k_tet_scan(const float *__restrict__ tet,
     // row's queries are tested, and queries are fetched four at a time.
     auto test = [&](const float4 &q) {
         if (q.x >= elo[0] && q.x <= ehi[0] && q.y >= elo[1] && q.y <= ehi[1] && q.z >= elo[2] && q.z <= ehi[2]) {
+#if defined(PIT_EXP_PLAIN_STORE)      // timing experiment only (wrong results on ties)
+            if (accept(P, q.x, q.y, q.z)) res[__float_as_int(q.w)] = t;
+#elif defined(PIT_EXP_NO_STORE)
+            if (accept(P, q.x, q.y, q.z)) asm volatile("" ::"v"(t));
+#else
             if (accept(P, q.x, q.y, q.z)) atomicMin(&res[__float_as_int(q.w)], t);
+#endif
         }
     };
     int cy = cy0, cz = cz0;
@@ -708,7 +714,13 @@ __global__ __launch_bounds__(256) void k_paste_bwd(const float *__restrict__ con
     float gm = miss ? g : 0.f;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) gm += __shfl_xor(gm, off);
-    if ((threadIdx.x & 63) == 0 && gm != 0.f) unsafeAtomicAdd(&gpred[(size_t)b * T], gm);
+    __shared__ float wsum[4];
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = gm;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float tot = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+        if (tot != 0.f) unsafeAtomicAdd(&gpred[(size_t)b * T], tot);
+    }
     if (live && !miss) unsafeAtomicAdd(&gpred[(size_t)b * T + (long long)c], g);
 }
 

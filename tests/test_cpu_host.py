@@ -1,0 +1,126 @@
+"""CPU tests of the host side: the C-ABI library exports what include/deftet_hip.h declares,
+the ctypes table covers it, synthetic grids / .tet IO, shape sharding over gloo (world 2)."""
+import ctypes
+import os
+import re
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from deftet_amd import grids, sharding
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "deftet_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(deftet_\w+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from deftet_amd import _lib, build
+    build.build()
+    syms = header_symbols()
+    assert len(syms) >= 25
+    assert sorted(_lib.SIGNATURES) == syms, "ctypes table and header disagree"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for s in syms:
+        assert hasattr(lib, s), "libdeftet_hip.so does not export %s" % s
+    loaded = _lib.load()
+    assert loaded.deftet_version() >= 100
+    # argument errors are reported through the status code + deftet_last_error, no GPU needed
+    assert loaded.deftet_point_in_tet_workspace_bytes(8, 257250, 100000, 0) > 0
+    st = loaded.deftet_point_in_tet_f32(None, None, None, None, -1, 1, 1, 0, None, 0, None)
+    assert st == -1 and b"negative" in loaded.deftet_last_error()
+    st = loaded.deftet_point_in_tet_f32(None, None, None, None, 1, 1 << 24, 1, 0, None, 0, None)
+    assert st == -4
+
+
+def test_ops_fail_loudly_without_gpu_tensors():
+    from deftet_amd import _lib
+    from deftet_amd.layers.DefTet.check_condition_tetrahedron_base.utils import check_condition_f_base
+    with pytest.raises(_lib.DefTetHipError):
+        check_condition_f_base(torch.zeros(1, 2, 4, 3), torch.zeros(1, 3, 3))
+
+
+@pytest.mark.parametrize("res", [2, 4, 20])
+def test_kuhn_grid_counts_and_orientation(res):
+    verts, tets = grids.kuhn_grid(res)
+    assert tets.shape == (6 * (res // 2) ** 3, 4) and verts.shape == ((res // 2 + 1) ** 3, 3)
+    assert tets.shape[0] == round(0.75 * res ** 3)
+    pos = grids.jittered_positions(verts, res, 2)
+    tp = grids.gather_tets(pos, tets)
+    vol = grids.tet_orientation(tp)
+    assert (vol > 0).all()
+    # the six tets of every cube tile it: volumes add up to the cube volume
+    assert np.isclose(grids.tet_orientation(grids.gather_tets((verts - 0.5)[None].astype(np.float32), tets)).sum() / 6, 1.0)
+    # boundary vertices are not jittered
+    on_bnd = ((verts == 0) | (verts == 1))
+    assert np.array_equal(pos[0][on_bnd], (verts - 0.5).astype(np.float32)[on_bnd])
+    q = grids.random_queries(2, 1000)
+    assert q.dtype == np.float32 and q.min() >= -0.525 and q.max() < 0.525
+    assert np.array_equal(q, grids.random_queries(2, 1000))       # seeded
+
+
+def test_tet_file_roundtrip(tmp_path):
+    verts, tets = grids.kuhn_grid(4)
+    p = str(tmp_path / "cube_0.250000_tet.tet")
+    grids.write_tet(p, verts, tets)
+    assert open(p).readline().strip() == "tet %d %d" % (verts.shape[0], tets.shape[0])
+    v2, t2 = grids.read_tet(p)
+    assert np.allclose(v2, verts) and np.array_equal(t2, tets)
+
+
+def test_shard_ranges():
+    for n, w in [(64, 8), (8, 1), (10, 4), (3, 8), (0, 2)]:
+        spans = [sharding.shard_range(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        sizes = [b - a for a, b in spans]
+        assert max(sizes) - min(sizes) <= 1 and sizes == sharding.shard_sizes(n, w)
+    with pytest.raises(ValueError):
+        sharding.shard_range(4, 4, 4)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, n_items, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lo, hi = sharding.shard_range(n_items, rank, world)
+        # every rank computes the per-shape "losses" of the shapes it owns
+        local = torch.stack([torch.tensor([float(i), float(i) * 0.5 + 1.0]) for i in range(lo, hi)]) if hi > lo \
+            else torch.zeros(0, 2)
+        full = sharding.all_gather_losses(local, n_items)
+        q.put((rank, full.numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_items", [8, 5])
+def test_all_gather_losses_gloo_world2(n_items):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_items, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = np.stack([[float(i), float(i) * 0.5 + 1.0] for i in range(n_items)]).astype(np.float32)
+    assert np.array_equal(got[0], want) and np.array_equal(got[1], want)

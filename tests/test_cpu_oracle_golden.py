@@ -1,0 +1,188 @@
+"""CPU tests (no GPU): the oracle against the golden vectors generated from the reference's
+Python code (tests/golden/gen_golden.py) and against the reference's native builders
+compiled into oracle/_ref."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from deftet_amd import grids
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+SMALL = ["one", "two", "kuhn2", "kuhn4", "kuhn4perm", "kuhn8"]
+
+
+def load(name):
+    return np.load(os.path.join(GOLD, name))
+
+
+def lexsorted(rows):
+    rows = np.asarray(rows)
+    if rows.size == 0:
+        return rows.reshape(0, rows.shape[-1] if rows.ndim > 1 else 2)
+    return rows[np.lexsort(tuple(rows[:, k] for k in range(rows.shape[1] - 1, -1, -1)))]
+
+
+def split_share(rows, i):
+    sel = rows[rows[:, 2] == i][:, :2].astype(np.int64)
+    return lexsorted(sel)
+
+
+@pytest.mark.parametrize("name", SMALL)
+def test_builders_match_python_twins(oracle, name):
+    g = load("builders_%s.npz" % name)
+    tets, n_point = g["tets"], g["verts"].shape[0]
+    # A4 vertex adjacency (set semantics; reference order is hash order)
+    assert np.array_equal(oracle.tet_point_adj(tets, n_point).astype(np.int64), lexsorted(g["point_adj_idx"]))
+    # A3 face adjacency, compared as the canonical CSR the reference consumes
+    for wrap in (True, False):
+        assert np.array_equal(lexsorted(oracle.tet_face_adj(tets, n_point, wrap32=wrap)).astype(np.int64), g["face_adj_rows"])
+    assert (g["face_adj_vals"] == 1).all()
+    # A2 tet adjacency through shared faces
+    rows = oracle.tet_adj_share(tets, n_point)
+    if g["adj_share_raises"][0]:
+        assert rows.shape[0] == 0
+    else:
+        for i in range(4):
+            assert np.array_equal(split_share(rows, i), g["adj_share_%d" % i])
+    # A6 face tables: bit-exact including row order and winding
+    f3, t2, tf2, b3, nm = oracle.tet_to_face(tets, n_point, with_boundary=False)
+    assert nm == 0
+    assert np.array_equal(f3, g["face_fx3"].reshape(-1, 3)) and np.array_equal(t2, g["face_tetidx_fx2"].reshape(-1, 2))
+    assert np.array_equal(tf2, g["face_tetfaceidx_fx2"].reshape(-1, 2)) and np.array_equal(b3, g["boundary_fx3"])
+    f3, t2, tf2, _, _ = oracle.tet_to_face(tets, n_point, with_boundary=True)
+    assert np.array_equal(f3, g["facewb_fx3"]) and np.array_equal(t2, g["facewb_tetidx_fx2"])
+    assert np.array_equal(tf2, g["facewb_tetfaceidx_fx2"])
+
+
+def test_builders_cube40_hashes(oracle):
+    """the shipped QuarTet grid (data fixture cube40_grid.npz) against sha256 of the reference outputs"""
+    g = load("cube40_grid.npz")
+    h = load("cube40_hashes.npz")
+    tets, n_point = g["tets"], g["verts"].shape[0]
+
+    def sha(a):
+        return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), np.uint8)
+
+    pa = oracle.tet_point_adj(tets, n_point).astype(np.int64)
+    assert pa.shape[0] == 118566 and np.array_equal(sha(pa), h["point_adj_idx"])
+    f3, t2, tf2, b3, _ = oracle.tet_to_face(tets, n_point)
+    assert np.array_equal(sha(f3), h["face_fx3"]) and np.array_equal(sha(t2), h["face_tetidx_fx2"])
+    assert np.array_equal(sha(tf2), h["face_tetfaceidx_fx2"]) and np.array_equal(sha(b3), h["boundary_fx3"])
+    assert f3.shape[0] == 92604 and b3.shape[0] == 4680
+    rows = oracle.tet_adj_share(tets, n_point)
+    for i in range(4):
+        assert np.array_equal(sha(split_share(rows, i)), h["adj_share_%d" % i])
+    fa = lexsorted(oracle.tet_face_adj(tets, n_point, wrap32=True)).astype(np.int64)
+    assert fa.shape[0] == 4543344 and np.array_equal(sha(fa), h["face_adj_rows"])
+    f3, t2, tf2, _, _ = oracle.tet_to_face(tets, n_point, with_boundary=True)
+    assert np.array_equal(sha(f3), h["facewb_fx3"]) and np.array_equal(sha(t2), h["facewb_tetidx_fx2"])
+
+
+def _random_mesh(rng, res):
+    verts, tets = grids.kuhn_grid(res)
+    tets = tets[rng.permutation(tets.shape[0])]
+    relabel = rng.permutation(verts.shape[0]).astype(np.int32)
+    tets = relabel[tets]
+    for t in tets:                      # random local re-orderings (orientation is irrelevant to the builders)
+        rng.shuffle(t)
+    keep = rng.random(tets.shape[0]) > 0.2
+    return tets[keep].astype(np.int32), verts.shape[0]
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_builders_match_reference_native(oracle, seed):
+    """row-for-row equality with the reference's run.cpp compiled into oracle/_ref"""
+    if not oracle.RefBuilders.available():
+        pytest.skip("oracle/_ref not built (reference tree absent)")
+    ref = oracle.RefBuilders()
+    rng = np.random.default_rng(seed)
+    tets, n_point = _random_mesh(rng, 4 + 2 * (seed % 3))
+    assert np.array_equal(oracle.tet_adj_share(tets, n_point), ref.tet_adj_share(tets, n_point))
+    assert np.array_equal(oracle.tet_face_adj(tets, n_point, wrap32=True), ref.tet_face_adj(tets, n_point))
+    assert np.array_equal(oracle.tet_point_adj(tets, n_point), lexsorted(ref.tet_point_adj(tets, n_point)))
+    pts = rng.uniform(-1, 1, (500, 3)).astype(np.float32)
+    pts[100:200] = pts[:100] + rng.choice([0, 1e-7, 4e-6, 1e-5], (100, 3)).astype(np.float32)
+    pts[200:220] = np.round(pts[200:220], 5) + np.float32(5e-6)        # rounding ties of %.5f
+    pts[220] = 0.0
+    pts[221] = -0.0                                                     # "-0.00000" != "0.00000"
+    pts[222] = -1e-7
+    a, b = oracle.colaps_v(pts), ref.colaps_v(pts)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_face_adj_int32_wrap_matches_native(oracle):
+    """the native tet_face_adj keys edges with a 32-bit int (run.cpp:39): with n_point > 46340
+    the key wraps; the oracle's wrap32 mode must still equal the native output row for row"""
+    if not oracle.RefBuilders.available():
+        pytest.skip("oracle/_ref not built")
+    ref = oracle.RefBuilders()
+    rng = np.random.default_rng(3)
+    tets, n_small = _random_mesh(rng, 4)
+    n_point = 70000
+    remap = np.sort(rng.choice(n_point, n_small, replace=False)).astype(np.int32)
+    tets = remap[tets]
+    assert np.array_equal(oracle.tet_face_adj(tets, n_point, wrap32=True), ref.tet_face_adj(tets, n_point))
+    # and the Python-twin mode (exact keys) gives the same adjacency as on the un-remapped mesh
+    a = lexsorted(oracle.tet_face_adj(tets, n_point, wrap32=False))
+    b = lexsorted(oracle.tet_face_adj(tets, n_point, wrap32=True))
+    assert a.shape == b.shape          # no collision below 2^32
+
+
+@pytest.mark.parametrize("name", ["kuhn4", "kuhn8"])
+def test_bary_matches_reference_python(oracle, name):
+    g = load("bary_%s.npz" % name)
+    n = g["pts"].shape[0]
+    tet = g["tet"][None]                       # treat each (tet_i, p_i) pair as tet i of one shape
+    cond = np.arange(n, dtype=np.float32)[None]
+    w = oracle.bary(tet, g["pts"][None], cond)[0]
+    assert np.abs(w - g["w_f32"]).max() <= 1e-5 * np.abs(g["w_f64"]).max()
+    w64, gt64 = oracle.point_in_tet_bwd_torch(tet, g["pts"][None], cond, g["grad_w"][None])
+    assert np.allclose(w64[0], g["w_f64"], rtol=1e-12, atol=1e-12)
+    assert np.allclose(gt64[0], g["grad_tet_f64"], rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.parametrize("res,jit", [(4, 0.1), (8, 0.15)])
+def test_point_in_tet_semantics_vs_reference_barycentrics(oracle, res, jit):
+    """Semantic pin of the (otherwise unpinned) point-in-tet restatement: on a valid mesh the
+    tet it returns must contain the query according to the reference's own barycentric
+    formula, and a query it rejects must not be strictly inside any tet."""
+    tet, pts, _, _ = grids.make_case(res, 3000, 2, jit)
+    cond = oracle.point_in_tet(tet, pts)
+    tol = 1e-5
+    for b in range(tet.shape[0]):
+        import torch
+        t64 = torch.from_numpy(tet[b]).double()
+        p64 = torch.from_numpy(pts[b]).double()
+        W = torch.stack(oracle.bary_torch(t64[None, :, 0], t64[None, :, 1], t64[None, :, 2], t64[None, :, 3],
+                                          p64[:, None, :]), -1).numpy()          # [Q,T,4]
+        inside = (W > tol).all(-1)                                             # strictly inside
+        near = (W > -tol).all(-1)                                              # inside or within tol of the boundary
+        c = cond[b, :, 0].astype(int)
+        hit = c >= 0
+        assert near[np.arange(len(c))[hit], c[hit]].all()
+        assert not inside[~hit].any()
+        first_inside = np.where(inside.any(1), inside.argmax(1), -1)
+        strict = inside.any(1)
+        # where some tet strictly contains the query, the answer is that tet unless a
+        # lower-index tet touches the query within tol
+        lower_ok = (c[strict] == first_inside[strict]) | (c[strict] < first_inside[strict])
+        assert lower_ok.all()
+    m = oracle.point_in_tet_margin(tet[0], pts[0][:200])
+    assert (m >= 0).all()
+
+
+def test_deftet_module_fixture_is_selfconsistent():
+    """deftet_module.npz pins the reference's own outputs for A7 / paste_occ / A11; here only
+    shapes and invariants are checked on CPU (the HIP counterparts are tested with -m gpu)."""
+    g = load("deftet_module.npz")
+    occ = g["occ"]
+    for i in range(occ.shape[0]):
+        o2 = occ[i][g["tetidx_fx2"]]
+        assert g["boundary_%d" % i].shape[0] == int((o2.sum(-1) == 1).sum())
+        assert g["internal_%d" % i].shape[0] == int((o2.sum(-1) == 2).sum())
+    c = g["cond"].copy()
+    c[c < 0] = 0
+    assert np.array_equal(g["cond_after"], c)
+    assert np.array_equal(g["pasted"], np.take_along_axis(g["pred"], c[..., 0].astype(int), 1))
