@@ -3,16 +3,6 @@
 #include "common.hpp"
 #define NYI(name) return deftet::set_error(DEFTET_EINVAL, name ": not implemented yet")
 extern "C" {
-size_t deftet_builder_workspace_bytes(int, int) { return 0; }
-int deftet_tet_adj_share_i32(const int32_t *, int32_t *, int32_t *, int, int, void *, size_t, void *) { NYI("deftet_tet_adj_share_i32"); }
-int deftet_tet_adj_share_host(int *, int *, int *, int, int) { NYI("deftet_tet_adj_share_host"); }
-int deftet_tet_face_adj_i32(const int32_t *, int32_t *, long long, long long *, int, int, int, void *, size_t, void *) { NYI("deftet_tet_face_adj_i32"); }
-int deftet_tet_face_adj_host(int *, int *, int *, int, int) { NYI("deftet_tet_face_adj_host"); }
-int deftet_tet_point_adj_i32(const int32_t *, int32_t *, int32_t *, int, int, void *, size_t, void *) { NYI("deftet_tet_point_adj_i32"); }
-int deftet_tet_point_adj_host(int *, int *, int *, int, int) { NYI("deftet_tet_point_adj_host"); }
-int deftet_colaps_v_f32(const float *, int32_t *, int32_t *, int32_t *, int, void *, size_t, void *) { NYI("deftet_colaps_v_f32"); }
-int deftet_colaps_v_host(float *, int *, int *, int *, int) { NYI("deftet_colaps_v_host"); }
-int deftet_tet_to_face_i32(const int32_t *, int64_t *, int64_t *, int64_t *, int64_t *, int32_t *, int, int, int, void *, size_t, void *) { NYI("deftet_tet_to_face_i32"); }
 size_t deftet_face_edge_adj_workspace_bytes(int) { return 0; }
 int deftet_face_edge_adj_f32(const float *, float *, int, int, void *, size_t, void *) { NYI("deftet_face_edge_adj_f32"); }
 int deftet_tri_dist_fwd_f32(const float *, const float *, const float *, float *, float *, int, int, int, void *) { NYI("deftet_tri_dist_fwd_f32"); }

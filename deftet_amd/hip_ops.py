@@ -84,3 +84,108 @@ def paste_occ_bwd(cond_bxqx1, grad_out_bxq, n_tet):
         _lib.check(lib.deftet_paste_occ_bwd_f32(_lib.ptr(cond), _lib.ptr(go), _lib.ptr(gp), B, n_tet, Q, 1,
                                                 _lib.current_stream(go.device)), "deftet_paste_occ_bwd_f32")
     return gp
+
+
+# --------------------------------------------------------------------------------- A2-A6 builders
+def _i32_tets(tet_list, device):
+    t = torch.as_tensor(tet_list)
+    if t.dim() != 2 or t.shape[1] != 4:
+        raise RuntimeError("tet_list must be [T,4], got %s" % (tuple(t.shape),))
+    return t.to(device=device, dtype=torch.int32).contiguous()
+
+
+def _builder_ws(lib, dev, n_point, n_tet):
+    return _lib.workspace(dev, lib.deftet_builder_workspace_bytes(int(n_point), int(n_tet)))
+
+
+def tet_adj_share(tet_list, n_point, device):
+    """int32 rows [2*n_shared, 3] = [t0,t1,f0],[t1,t0,f1] in ascending face-key order
+    (utils/lib/tet_adj_share/run.cpp:40-97)."""
+    lib = _lib.load()
+    dev = torch.device(device)
+    tet = _i32_tets(tet_list, dev)
+    _lib.require_gpu(tet)
+    T = tet.shape[0]
+    out = torch.empty(max(T * 8, 1), 3, dtype=torch.int32, device=dev)
+    n = torch.zeros(1, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        ws = _builder_ws(lib, dev, n_point, T)
+        _lib.check(lib.deftet_tet_adj_share_i32(_lib.ptr(tet), _lib.ptr(out), _lib.ptr(n), int(n_point), T, _lib.ptr(ws),
+                                                ws.numel(), _lib.current_stream(dev)), "deftet_tet_adj_share_i32")
+    return out[: int(n.item()) * 2]
+
+
+def tet_face_adj(tet_list, n_point, device, wrap32=True):
+    """int32 rows [n,2] = [fa,fb] (utils/lib/tet_face_adj/run.cpp:18-92); two-phase: count, then fill."""
+    lib = _lib.load()
+    dev = torch.device(device)
+    tet = _i32_tets(tet_list, dev)
+    _lib.require_gpu(tet)
+    T = tet.shape[0]
+    n = torch.zeros(1, dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        ws = _builder_ws(lib, dev, n_point, T)
+        st = _lib.current_stream(dev)
+        _lib.check(lib.deftet_tet_face_adj_i32(_lib.ptr(tet), None, 0, _lib.ptr(n), int(n_point), T, int(wrap32),
+                                               _lib.ptr(ws), ws.numel(), st), "deftet_tet_face_adj_i32(count)")
+        cnt = int(n.item())
+        out = torch.empty(max(cnt, 1), 2, dtype=torch.int32, device=dev)
+        _lib.check(lib.deftet_tet_face_adj_i32(_lib.ptr(tet), _lib.ptr(out), cnt, _lib.ptr(n), int(n_point), T, int(wrap32),
+                                               _lib.ptr(ws), ws.numel(), st), "deftet_tet_face_adj_i32(fill)")
+    return out[:cnt]
+
+
+def tet_point_adj(tet_list, n_point, device):
+    """int32 [n,2] unique directed vertex pairs sorted by (a,b) (utils/lib/tet_point_adj/run.cpp:20-56)."""
+    lib = _lib.load()
+    dev = torch.device(device)
+    tet = _i32_tets(tet_list, dev)
+    _lib.require_gpu(tet)
+    T = tet.shape[0]
+    out = torch.empty(max(T * 12, 1), 2, dtype=torch.int32, device=dev)
+    n = torch.zeros(1, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        ws = _builder_ws(lib, dev, n_point, T)
+        _lib.check(lib.deftet_tet_point_adj_i32(_lib.ptr(tet), _lib.ptr(out), _lib.ptr(n), int(n_point), T, _lib.ptr(ws),
+                                                ws.numel(), _lib.current_stream(dev)), "deftet_tet_point_adj_i32")
+    return out[: int(n.item())]
+
+
+def colaps_v(points_nx3):
+    """(map_array int32 [N], inverse_idx int32 [k]) — utils/lib/colaps_v/run.cpp:39-59."""
+    _lib.require_gpu(points_nx3)
+    lib = _lib.load()
+    pts = _f32c(points_nx3)
+    N = pts.shape[0]
+    dev = pts.device
+    m = torch.empty(max(N, 1), dtype=torch.int32, device=dev)
+    inv = torch.empty(max(N, 1), dtype=torch.int32, device=dev)
+    n = torch.zeros(1, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        ws = _builder_ws(lib, dev, N, 0)
+        _lib.check(lib.deftet_colaps_v_f32(_lib.ptr(pts), _lib.ptr(m), _lib.ptr(inv), _lib.ptr(n), N, _lib.ptr(ws), ws.numel(),
+                                           _lib.current_stream(dev)), "deftet_colaps_v_f32")
+    return m[:N], inv[: int(n.item())]
+
+
+def tet_to_face(tet_list, n_point, device, with_boundary=False):
+    """(face_fx3, tetidx_fx2, tetfaceidx_fx2, boundary_fx3) int64, first-seen order —
+    utils/tet_utils.py:208-256 / prepare_for_wz.py:49-104; raises on non-manifold input."""
+    lib = _lib.load()
+    dev = torch.device(device)
+    tet = _i32_tets(tet_list, dev)
+    _lib.require_gpu(tet)
+    T = tet.shape[0]
+    cap = max(T * 4, 1)
+    f3 = torch.empty(cap, 3, dtype=torch.int64, device=dev)
+    t2 = torch.empty(cap, 2, dtype=torch.int64, device=dev)
+    tf2 = torch.empty(cap, 2, dtype=torch.int64, device=dev)
+    b3 = torch.empty(cap, 3, dtype=torch.int64, device=dev)
+    counts = torch.zeros(3, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        ws = _builder_ws(lib, dev, n_point, T)
+        _lib.check(lib.deftet_tet_to_face_i32(_lib.ptr(tet), _lib.ptr(f3), _lib.ptr(t2), _lib.ptr(tf2), _lib.ptr(b3),
+                                              _lib.ptr(counts), int(n_point), T, int(with_boundary), _lib.ptr(ws), ws.numel(),
+                                              _lib.current_stream(dev)), "deftet_tet_to_face_i32")
+    nf, nb, nm = (int(x) for x in counts.tolist())
+    return f3[:nf], t2[:nf], tf2[:nf], b3[:nb], nm
