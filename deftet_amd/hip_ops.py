@@ -189,3 +189,54 @@ def tet_to_face(tet_list, n_point, device, with_boundary=False):
                                               _lib.current_stream(dev)), "deftet_tet_to_face_i32")
     nf, nb, nm = (int(x) for x in counts.tolist())
     return f3[:nf], t2[:nf], tf2[:nf], b3[:nb], nm
+
+
+# --------------------------------------------------------------------------------- A8 / A9 / A10 surface ops
+def face_edge_adj(face_fx3x3, n_max_nei=30):
+    """f32 [F, n_max_nei] neighbour table (-1 padded): tet_face_adj_m_for.cu:72-108."""
+    _lib.require_gpu(face_fx3x3)
+    lib = _lib.load()
+    face = _f32c(face_fx3x3)
+    F = face.shape[0]
+    adj = torch.full((F, n_max_nei), -1.0, device=face.device, dtype=torch.float32)    # utils.py:47
+    with torch.cuda.device(face.device):
+        _lib.check(lib.deftet_face_edge_adj_f32(_lib.ptr(face), _lib.ptr(adj), F, n_max_nei, None, 0,
+                                                _lib.current_stream(face.device)), "deftet_face_edge_adj_f32")
+    return adj
+
+
+def tri_dist_fwd(pts_bxpx3, face_bxfx3x3, n_face_b):
+    _lib.require_gpu(pts_bxpx3, face_bxfx3x3, n_face_b)
+    lib = _lib.load()
+    pts, face, nfb = _f32c(pts_bxpx3), _f32c(face_bxfx3x3), _f32c(n_face_b)
+    B, P = pts.shape[0], pts.shape[1]
+    d = torch.zeros(B, P, 1, device=pts.device, dtype=torch.float32)                    # utils.py:44-45
+    f = torch.zeros(B, P, 1, device=pts.device, dtype=torch.float32)
+    with torch.cuda.device(pts.device):
+        _lib.check(lib.deftet_tri_dist_fwd_f32(_lib.ptr(pts), _lib.ptr(face), _lib.ptr(nfb), _lib.ptr(d), _lib.ptr(f), B, P,
+                                               face.shape[1], _lib.current_stream(pts.device)), "deftet_tri_dist_fwd_f32")
+    return d, f
+
+
+def tri_dist_bwd(pts_bxpx3, face_bxfx3x3, closest_f, dl_dd, deterministic=False):
+    _lib.require_gpu(pts_bxpx3, face_bxfx3x3, closest_f, dl_dd)
+    lib = _lib.load()
+    pts, face, cf, g = _f32c(pts_bxpx3), _f32c(face_bxfx3x3), _f32c(closest_f), _f32c(dl_dd)
+    B, P, F = pts.shape[0], pts.shape[1], face.shape[1]
+    out = torch.zeros(B, F, 3, 3, device=pts.device, dtype=torch.float32)               # utils.py:65
+    with torch.cuda.device(pts.device):
+        _lib.check(lib.deftet_tri_dist_bwd_f32(_lib.ptr(pts), _lib.ptr(face), _lib.ptr(cf), _lib.ptr(g), _lib.ptr(out), B, P, F,
+                                               int(deterministic), _lib.current_stream(pts.device)), "deftet_tri_dist_bwd_f32")
+    return out
+
+
+def nn_index(queries_bxnx3, points_bxmx3):
+    _lib.require_gpu(queries_bxnx3, points_bxmx3)
+    lib = _lib.load()
+    q, p = _f32c(queries_bxnx3), _f32c(points_bxmx3)
+    B, N = q.shape[0], q.shape[1]
+    out = torch.zeros(B, N, device=q.device, dtype=torch.int32)                         # nearest_neighbor.py:32-33
+    with torch.cuda.device(q.device):
+        _lib.check(lib.deftet_nn_index_f32(_lib.ptr(q), _lib.ptr(p), _lib.ptr(out), B, N, p.shape[1],
+                                           _lib.current_stream(q.device)), "deftet_nn_index_f32")
+    return out
