@@ -63,13 +63,13 @@ def test_nn_index_properties_full_size(cuda):
     assert torch.equal(idx2[0].long(), torch.arange(5000, device=cuda))
 
 
-@pytest.mark.parametrize("res", [6, 10])
+@pytest.mark.parametrize("res", [12, 20])
 def test_face_edge_adj_bit_exact(cuda, oracle, res):
     from deftet_amd import hip_ops
     from deftet_amd.layers.DefTet.tet_face_adj_m_idx.utils import tet_face_adj_m_f_idx
     face = sphere_surface(res)
     F = face.shape[0]
-    assert F > 50
+    assert F > 100
     want = oracle.face_edge_adj(face, 30)
     got = hip_ops.face_edge_adj(torch.from_numpy(face).to(cuda), 30).cpu().numpy()
     assert np.array_equal(got, want)
@@ -89,7 +89,7 @@ def test_face_edge_adj_bit_exact(cuda, oracle, res):
     assert empty.numel() == 0 and empty.is_floating_point()
 
 
-def _tri_case(seed, P=3000, res=8):
+def _tri_case(seed, P=3000, res=16):
     rng = np.random.default_rng(seed)
     face = sphere_surface(res)
     F = face.shape[0]
