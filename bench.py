@@ -48,17 +48,16 @@ def make_inputs(rank, device, res=RES, n_query=N_QUERY, batch=BATCH):
     return host, dev
 
 
-def step(d, world, gather_buf):
-    from deftet_amd import hip_ops
+def step(d, world):
+    from deftet_amd import hip_ops, sharding
     cond, w = hip_ops.point_in_tet(d["tet"], d["pts"], want_bary=True)
     cond_c = cond.clone()                       # train_multigpu.py:383 pastes into a clone
     occ = hip_ops.paste_occ_fwd(d["pred"], cond_c)
     g_tet, _ = hip_ops.point_in_tet_bwd(d["tet"], d["pts"], cond, d["gw"])
     g_pred = hip_ops.paste_occ_bwd(cond_c, d["gout"], d["tet"].shape[1])
-    B = w.shape[0]                                                            # [B] per-shape loss scalars
-    loss = (torch.bmm(w.view(B, 1, -1), d["gw"].view(B, -1, 1)) + torch.bmm(occ.view(B, 1, -1), d["gout"].view(B, -1, 1))).view(B)
+    loss = hip_ops.rowdot(w, d["gw"]) + hip_ops.rowdot(occ, d["gout"])         # [B] per-shape loss scalars
     if world > 1:
-        torch.distributed.all_gather_into_tensor(gather_buf, loss)            # the only collective
+        loss = sharding.all_gather_losses(loss, world * loss.shape[0])        # the only collective (RCCL)
     return cond, w, g_tet, g_pred, loss
 
 
@@ -111,10 +110,9 @@ def main():
     lib = _lib.load()
     host, d = make_inputs(rank, device)
     B, T, Q = d["tet"].shape[0], d["tet"].shape[1], d["pts"].shape[1]
-    gather_buf = torch.empty(world * B, device=device) if world > 1 else None
 
     for _ in range(args.warmup):
-        step(d, world, gather_buf)
+        step(d, world)
     torch.cuda.synchronize()
 
     dominant = b"k_tet_scan"
@@ -124,7 +122,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = step(d, world, gather_buf)
+        out = step(d, world)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()

@@ -32,6 +32,7 @@ constexpr float kWMin = 9.3132257e-10f;      // 2^-30
 constexpr int kMiss = 0x7F7F7F7F;            // result sentinel (> any tet index)
 constexpr int kChunk = 2048;                 // cells per scan chunk
 constexpr int kMaxG = 96;
+constexpr int kXFine = 4;                   // cells are kXFine times finer along x (the run direction)
 
 // ------------------------------------------------------------------------------------
 // exact predicate pieces (check_condition_tet_for.cu:105-121, :172-176)
@@ -93,7 +94,7 @@ struct Grid {
 };
 
 // one wave per shape: reduce the per-block query boxes into grid parameters (12 floats)
-__global__ __launch_bounds__(64) void k_grid_params(const float *__restrict__ part, int nPart, int G, float *gparam)
+__global__ __launch_bounds__(64) void k_grid_params(const float *__restrict__ part, int nPart, int G, int Gx, float *gparam)
 {
     const int b = blockIdx.x, lane = threadIdx.x;
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(64) void k_grid_params(const float *__restrict__ pa
         h = ok ? h : 0.f;
         if (lane == 0) {
             gparam[b * 12 + k] = l;                                               // origin
-            gparam[b * 12 + 3 + k] = (ok && ext > 1e-30f) ? (float)G / ext : 0.f;  // cells per unit
+            gparam[b * 12 + 3 + k] = (ok && ext > 1e-30f) ? (float)(k == 0 ? Gx : G) / ext : 0.f;  // cells per unit
             gparam[b * 12 + 6 + k] = l;
             gparam[b * 12 + 9 + k] = h;
         }
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(256) void k_query_bbox(const float *__restrict__ pt
 
 // cell id + rank inside the cell for every regular query
 __global__ __launch_bounds__(256) void k_query_bin(const float *__restrict__ pts, int Q, const float *__restrict__ gparam,
-                                                   int G, long long cellStride, int *cells, int2 *qcell)
+                                                   int G, int Gx, long long cellStride, int *cells, int2 *qcell)
 {
     const int b = blockIdx.y;
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
@@ -222,8 +223,8 @@ __global__ __launch_bounds__(256) void k_query_bin(const float *__restrict__ pts
     float x = p[0], y = p[1], z = p[2];
     int2 r = make_int2(-1, 0);
     if (query_regular(x, y, z)) {
-        int cx = cell_of(x, g.o[0], g.inv[0], G), cy = cell_of(y, g.o[1], g.inv[1], G), cz = cell_of(z, g.o[2], g.inv[2], G);
-        int c = (cz * G + cy) * G + cx;
+        int cx = cell_of(x, g.o[0], g.inv[0], Gx), cy = cell_of(y, g.o[1], g.inv[1], G), cz = cell_of(z, g.o[2], g.inv[2], G);
+        int c = (cz * G + cy) * Gx + cx;
         r.x = c;
         r.y = atomicAdd(&cells[(size_t)b * cellStride + c], 1);
     }
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(256) void k_scan_chunks(int *cells, long long cellS
     if (threadIdx.x == 255) chunkTot[b * nChunk + c] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
-// add the exclusive prefix of the chunk totals to every cell of the chunk (nChunk <= 512)
+// add the exclusive prefix of the chunk totals to every cell of the chunk
 __global__ __launch_bounds__(256) void k_scan_apply(int *cells, long long cellStride, int nChunk,
                                                     const int *__restrict__ chunkTot)
 {
@@ -298,13 +299,21 @@ __global__ __launch_bounds__(256) void k_query_scatter(const float *__restrict__
 
 // the main kernel: one lane per tet
 __global__ __launch_bounds__(256) void k_tet_scan(const float *__restrict__ tet, int T, int Q,
-                                                  const float *__restrict__ gparam, int G, const int *__restrict__ cells,
+                                                  const float *__restrict__ gparam, int G, int Gx, const int *__restrict__ cells,
                                                   long long cellStride, const float4 *__restrict__ sortedQ, int *result, int *counters,
                                                   int *irregT)
 {
     const int b = blockIdx.y;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= T) return;
+    // XCD-aware mapping (workgroup i is observed to run on XCD i % 8, each XCD has a private
+    // L2): give every XCD one CONTIGUOUS eighth of the tet range, so a mesh whose tet order is
+    // spatially coherent makes each L2 pull only its own part of the sorted queries instead of
+    // all eight pulling all of it (measured: 201 MB -> see profiles/).  Speed only; any
+    // placement is correct.
+    const int nblk = gridDim.x;
+    const int per = (nblk + 7) >> 3;
+    const int vb = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    const int t = vb * blockDim.x + threadIdx.x;
+    if (vb >= nblk || t >= T) return;
     float v[12];
     {
         const float4 *src = reinterpret_cast<const float4 *>(tet + ((size_t)b * T + t) * 12);
@@ -345,7 +354,7 @@ __global__ __launch_bounds__(256) void k_tet_scan(const float *__restrict__ tet,
     // no regular query can lie in the enlarged box -> nothing to do
     if (ehi[0] < g.lo[0] || elo[0] > g.hi[0] || ehi[1] < g.lo[1] || elo[1] > g.hi[1] || ehi[2] < g.lo[2] || elo[2] > g.hi[2])
         return;
-    const int cx0 = cell_of(elo[0], g.o[0], g.inv[0], G), cx1 = cell_of(ehi[0], g.o[0], g.inv[0], G);
+    const int cx0 = cell_of(elo[0], g.o[0], g.inv[0], Gx), cx1 = cell_of(ehi[0], g.o[0], g.inv[0], Gx);
     const int cy0 = cell_of(elo[1], g.o[1], g.inv[1], G), cy1 = cell_of(ehi[1], g.o[1], g.inv[1], G);
     const int cz0 = cell_of(elo[2], g.o[2], g.inv[2], G), cz1 = cell_of(ehi[2], g.o[2], g.inv[2], G);
     const int *cb = cells + (size_t)b * cellStride;
@@ -366,15 +375,15 @@ __global__ __launch_bounds__(256) void k_tet_scan(const float *__restrict__ tet,
         }
     };
     int cy = cy0, cz = cz0;
-    int s = cb[(cz * G + cy) * G + cx0];
-    int e = cb[(cz * G + cy) * G + cx1 + 1];           // cells has G^3+1 valid entries
+    int s = cb[(cz * G + cy) * Gx + cx0];
+    int e = cb[(cz * G + cy) * Gx + cx1 + 1];          // cells has Gx*G*G+1 valid entries
     for (;;) {
         int ny = cy + 1, nz = cz;
         if (ny > cy1) { ny = cy0; nz = cz + 1; }
         const bool more = nz <= cz1;
         int s2 = 0, e2 = 0;
         if (more) {
-            const int row2 = (nz * G + ny) * G;
+            const int row2 = (nz * G + ny) * Gx;
             s2 = cb[row2 + cx0];
             e2 = cb[row2 + cx1 + 1];
         }
@@ -738,7 +747,7 @@ static int pick_G(int T, int Q)
 }
 
 struct Layout {
-    int G, nChunk;
+    int G, Gx, nChunk;
     long long cellStride;   // padded cells per shape (multiple of kChunk, >= G^3+1)
     size_t bytes;
     float *bboxPart;
@@ -757,7 +766,8 @@ static Layout make_layout(int B, int T, int Q, int algo, void *ws, size_t wsByte
         L.rec = A.take<float>((size_t)B * T * 32);
     } else {
         L.G = pick_G(T, Q);
-        long long n = (long long)L.G * L.G * L.G + 1;
+        L.Gx = L.G * kXFine;
+        long long n = (long long)L.Gx * L.G * L.G + 1;
         L.nChunk = (int)((n + kChunk - 1) / kChunk);
         L.cellStride = (long long)L.nChunk * kChunk;
         L.bboxPart = A.take<float>((size_t)B * kBoxBlocks * 6);
@@ -803,7 +813,7 @@ extern "C" int deftet_point_in_tet_f32(const float *tet, const float *pts, float
     DEFTET_CHECK_ARG(L.bytes <= workspace_bytes, "workspace too small: need %zu bytes, got %zu", L.bytes, workspace_bytes);
     hipStream_t st = as_stream(stream_);
     const dim3 blk(256);
-    const dim3 gq((Q + 255) / 256, B), gt((T + 255) / 256, B);
+    const dim3 gq((Q + 255) / 256, B), gt((((T + 255) / 256 + 7) / 8) * 8, B);   // gt: multiple of 8 for the XCD mapping
 
     if (algo == DEFTET_PIT_BRUTE) {
         if (T > 0) {
@@ -818,13 +828,13 @@ extern "C" int deftet_point_in_tet_f32(const float *tet, const float *pts, float
         if (ib > 4096) ib = 4096;
         DEFTET_LAUNCH(k_init, dim3(ib), blk, st, L.counters, L.cells, L.result, B, nCells, nQ);
         DEFTET_LAUNCH(k_query_bbox, dim3(kBoxBlocks, B), blk, st, pts, Q, L.bboxPart, L.counters, L.irregQ);
-        DEFTET_LAUNCH(k_grid_params, dim3(B), dim3(64), st, L.bboxPart, kBoxBlocks, L.G, L.gparam);
-        DEFTET_LAUNCH(k_query_bin, gq, blk, st, pts, Q, L.gparam, L.G, L.cellStride, L.cells, L.qcell);
+        DEFTET_LAUNCH(k_grid_params, dim3(B), dim3(64), st, L.bboxPart, kBoxBlocks, L.G, L.Gx, L.gparam);
+        DEFTET_LAUNCH(k_query_bin, gq, blk, st, pts, Q, L.gparam, L.G, L.Gx, L.cellStride, L.cells, L.qcell);
         DEFTET_LAUNCH(k_scan_chunks, dim3(L.nChunk, B), blk, st, L.cells, L.cellStride, L.nChunk, L.chunkTot);
         DEFTET_LAUNCH(k_scan_apply, dim3(L.nChunk, B), blk, st, L.cells, L.cellStride, L.nChunk, L.chunkTot);
         DEFTET_LAUNCH(k_query_scatter, gq, blk, st, pts, Q, L.qcell, L.cells, L.cellStride, L.sortedQ);
         if (T > 0) {
-            DEFTET_LAUNCH(k_tet_scan, gt, blk, st, tet, T, Q, L.gparam, L.G, L.cells, L.cellStride, L.sortedQ, L.result,
+            DEFTET_LAUNCH(k_tet_scan, gt, blk, st, tet, T, Q, L.gparam, L.G, L.Gx, L.cells, L.cellStride, L.sortedQ, L.result,
                           L.counters, L.irregT);
             int qb = (Q + 255) / 256, tb = (T + 255) / 256;
             if (qb > 1024) qb = 1024;

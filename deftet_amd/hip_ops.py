@@ -86,6 +86,22 @@ def paste_occ_bwd(cond_bxqx1, grad_out_bxq, n_tet):
     return gp
 
 
+def rowdot(a, b=None):
+    """out[r] = sum over the trailing dims of a[r]*b[r] (row sums when b is None); f32 [R]."""
+    _lib.require_gpu(a, b)
+    lib = _lib.load()
+    a = _f32c(a)
+    b = _f32c(b) if b is not None else None
+    if b is not None and b.shape != a.shape:
+        raise RuntimeError("rowdot: shape mismatch %s vs %s" % (tuple(a.shape), tuple(b.shape)))
+    R = a.shape[0]
+    out = torch.empty(R, device=a.device, dtype=torch.float32)
+    with torch.cuda.device(a.device):
+        _lib.check(lib.deftet_rowdot_f32(_lib.ptr(a), _lib.ptr(b), _lib.ptr(out), R, a.numel() // max(R, 1),
+                                         _lib.current_stream(a.device)), "deftet_rowdot_f32")
+    return out
+
+
 # --------------------------------------------------------------------------------- A2-A6 builders
 def _i32_tets(tet_list, device):
     t = torch.as_tensor(tet_list)

@@ -85,6 +85,10 @@ int deftet_paste_occ_fwd_f32(const float *pred_bxt, float *cond_bxq, float *out_
 int deftet_paste_occ_bwd_f32(const float *cond_bxq, const float *grad_out_bxq, float *grad_pred_bxt,
                              int n_batch, int n_tet, int n_query, int zero_grad_pred, void *stream);
 
+/* Per-shape loss scalars: out[r] = sum_c a[r,c]*b[r,c] (b == NULL: row sums).  Deterministic
+ * reduction; the values every rank all-gathers in the multi-GPU harness. */
+int deftet_rowdot_f32(const float *a, const float *b, float *out, int n_rows, long long n_cols, void *stream);
+
 /* ---------------------------------------------------------------------------------
  * A2-A6  adjacency builders.  Device variants take device pointers and a caller
  * workspace; `_host` variants keep the EXACT signature of the reference's

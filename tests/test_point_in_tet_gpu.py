@@ -140,3 +140,16 @@ def test_backward_atomic_fallback_matches_gather(cuda, oracle):
     assert (acc - 1.0 - g_gather).abs().max().item() <= 1e-5 * scale
     miss = cond[..., 0] < 0
     assert (gp[miss] == 0).all() and gp[~miss].abs().sum() > 0
+
+
+def test_rowdot(cuda):
+    from deftet_amd import hip_ops
+    g = torch.Generator(device=cuda).manual_seed(3)
+    for shape in [(8, 100000, 4), (3, 1001), (2, 7, 3)]:
+        a = torch.randn(*shape, device=cuda, generator=g)
+        b = torch.randn(*shape, device=cuda, generator=g)
+        want = (a.double() * b.double()).flatten(1).sum(1)
+        got = hip_ops.rowdot(a, b)
+        assert torch.allclose(got.double(), want, rtol=1e-5, atol=1e-3)
+        assert torch.equal(got, hip_ops.rowdot(a, b))            # deterministic
+        assert torch.allclose(hip_ops.rowdot(a).double(), a.double().flatten(1).sum(1), rtol=1e-5, atol=1e-3)
