@@ -1,22 +1,26 @@
 // reduce.hip — per-shape loss scalars: out[r] = sum_c a[r,c] * b[r,c]  (b may be NULL: plain row sum).
-// Deterministic (fixed reduction tree, no atomics): one 1024-thread workgroup per row.
+// Deterministic (fixed reduction tree, no atomics): kParts workgroups per row write partial
+// sums into the caller's workspace, one wave per row adds them up.
 #include "common.hpp"
 
 namespace deftet {
 namespace red {
 
-__global__ __launch_bounds__(1024) void k_rowdot(const float *__restrict__ a, const float *__restrict__ b, float *out,
-                                                 long long n_cols)
+constexpr int kParts = 128;
+
+__global__ __launch_bounds__(256) void k_rowdot_partial(const float *__restrict__ a, const float *__restrict__ b,
+                                                        float *part, long long n_cols)
 {
-    __shared__ float wsum[16];
-    const long long r = blockIdx.x;
+    __shared__ float wsum[4];
+    const long long r = blockIdx.y;
     const float *pa = a + r * n_cols;
     const float *pb = b ? b + r * n_cols : nullptr;
     float acc = 0.f;
     const bool vec = (n_cols % 4 == 0) && (((uintptr_t)pa & 15) == 0) && (!pb || ((uintptr_t)pb & 15) == 0);
+    const long long tid = (long long)blockIdx.x * 256 + threadIdx.x, stride = (long long)kParts * 256;
     if (vec) {
         const long long n4 = n_cols / 4;
-        for (long long i = threadIdx.x; i < n4; i += 1024) {
+        for (long long i = tid; i < n4; i += stride) {
             const float4 x = reinterpret_cast<const float4 *>(pa)[i];
             if (pb) {
                 const float4 y = reinterpret_cast<const float4 *>(pb)[i];
@@ -26,28 +30,39 @@ __global__ __launch_bounds__(1024) void k_rowdot(const float *__restrict__ a, co
             }
         }
     } else {
-        for (long long i = threadIdx.x; i < n_cols; i += 1024) acc += pb ? pa[i] * pb[i] : pa[i];
+        for (long long i = tid; i < n_cols; i += stride) acc += pb ? pa[i] * pb[i] : pa[i];
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x < 64) {
-        float v = threadIdx.x < 16 ? wsum[threadIdx.x] : 0.f;
+    if (threadIdx.x == 0) part[r * kParts + blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+
+__global__ __launch_bounds__(64) void k_rowdot_final(const float *__restrict__ part, float *out)
+{
+    const long long r = blockIdx.x;
+    float v = part[r * kParts + threadIdx.x] + part[r * kParts + 64 + threadIdx.x];
 #pragma unroll
-        for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off);
-        if (threadIdx.x == 0) out[r] = v;
-    }
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if (threadIdx.x == 0) out[r] = v;
 }
 
 }  // namespace red
 }  // namespace deftet
 
-extern "C" int deftet_rowdot_f32(const float *a, const float *b, float *out, int n_rows, long long n_cols, void *stream_)
+extern "C" size_t deftet_rowdot_workspace_bytes(int n_rows) { return (size_t)(n_rows > 0 ? n_rows : 0) * deftet::red::kParts * 4; }
+
+extern "C" int deftet_rowdot_f32(const float *a, const float *b, float *out, int n_rows, long long n_cols, void *workspace,
+                                 size_t workspace_bytes, void *stream_)
 {
-    DEFTET_CHECK_ARG(n_rows >= 0 && n_cols >= 0, "negative size");
+    DEFTET_CHECK_ARG(n_rows >= 0 && n_cols >= 0 && n_rows <= 65535, "bad size");
     if (n_rows == 0) return DEFTET_OK;
     DEFTET_CHECK_ARG(a && out, "null pointer");
-    DEFTET_LAUNCH(deftet::red::k_rowdot, dim3(n_rows), dim3(1024), deftet::as_stream(stream_), a, b, out, n_cols);
+    DEFTET_CHECK_ARG(workspace && workspace_bytes >= deftet_rowdot_workspace_bytes(n_rows), "workspace null or too small");
+    hipStream_t st = deftet::as_stream(stream_);
+    float *part = static_cast<float *>(workspace);
+    DEFTET_LAUNCH(deftet::red::k_rowdot_partial, dim3(deftet::red::kParts, n_rows), dim3(256), st, a, b, part, n_cols);
+    DEFTET_LAUNCH(deftet::red::k_rowdot_final, dim3(n_rows), dim3(64), st, part, out);
     return DEFTET_OK;
 }

@@ -97,8 +97,9 @@ def rowdot(a, b=None):
     R = a.shape[0]
     out = torch.empty(R, device=a.device, dtype=torch.float32)
     with torch.cuda.device(a.device):
+        ws = _lib.workspace(a.device, lib.deftet_rowdot_workspace_bytes(R))
         _lib.check(lib.deftet_rowdot_f32(_lib.ptr(a), _lib.ptr(b), _lib.ptr(out), R, a.numel() // max(R, 1),
-                                         _lib.current_stream(a.device)), "deftet_rowdot_f32")
+                                         _lib.ptr(ws), ws.numel(), _lib.current_stream(a.device)), "deftet_rowdot_f32")
     return out
 
 

@@ -87,7 +87,9 @@ int deftet_paste_occ_bwd_f32(const float *cond_bxq, const float *grad_out_bxq, f
 
 /* Per-shape loss scalars: out[r] = sum_c a[r,c]*b[r,c] (b == NULL: row sums).  Deterministic
  * reduction; the values every rank all-gathers in the multi-GPU harness. */
-int deftet_rowdot_f32(const float *a, const float *b, float *out, int n_rows, long long n_cols, void *stream);
+size_t deftet_rowdot_workspace_bytes(int n_rows);
+int deftet_rowdot_f32(const float *a, const float *b, float *out, int n_rows, long long n_cols,
+                      void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------
  * A2-A6  adjacency builders.  Device variants take device pointers and a caller
