@@ -299,9 +299,18 @@ __global__ __launch_bounds__(256) void k_query_scatter(const float *__restrict__
     sortedQ[(size_t)b * Q + pos] = make_float4(p[0], p[1], p[2], __int_as_float(q));
 }
 
-// simple variant of the main kernel (one lane per tet, exact test inline); used when the
-// query count does not fit the packed queue entries of k_tet_scan, and for A/B timing
-__global__ __launch_bounds__(256) void k_tet_scan_simple(const float *__restrict__ tet, int T, int Q,
+// The main kernel: one lane per tet, exact test inline.
+// (A two-phase variant — ballot-compacted candidate ring in LDS + dense exact test — was built
+// and measured in round 1: 14 % fewer VALU instructions but 1.5x slower, because the kernel is
+// bound by vector-memory issue/latency, not by VALU: SQ_WAIT_ANY = 66 % of SQ_WAVE_CYCLES,
+// ~55 gather instructions per wave.  See DESIGN.md "A1 kernel anatomy" and profiles/.)
+#ifndef PIT_WAVES
+#define PIT_WAVES 6
+#endif
+#ifndef PIT_BATCH
+#define PIT_BATCH 4
+#endif
+__global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan(const float *__restrict__ tet, int T, int Q,
                                                   const float *__restrict__ gparam, int G, int Gx, const int *__restrict__ cells,
                                                   long long cellStride, const float4 *__restrict__ sortedQ, int *result, int *counters,
                                                   int *irregT)
@@ -390,191 +399,18 @@ __global__ __launch_bounds__(256) void k_tet_scan_simple(const float *__restrict
             s2 = cb[row2 + cx0];
             e2 = cb[row2 + cx1 + 1];
         }
-        for (int j = s; j < e; j += 4) {
+        for (int j = s; j < e; j += PIT_BATCH) {
             const int last = e - 1;
-            const float4 q0 = sq[j];
-            const float4 q1 = sq[min(j + 1, last)];
-            const float4 q2 = sq[min(j + 2, last)];
-            const float4 q3 = sq[min(j + 3, last)];
-            test(q0);
-            if (j + 1 < e) test(q1);
-            if (j + 2 < e) test(q2);
-            if (j + 3 < e) test(q3);
+            float4 qq[PIT_BATCH];
+#pragma unroll
+            for (int k = 0; k < PIT_BATCH; ++k) qq[k] = sq[min(j + k, last)];
+#pragma unroll
+            for (int k = 0; k < PIT_BATCH; ++k)
+                if (k == 0 || j + k < e) test(qq[k]);
         }
         if (!more) break;
         s = s2; e = e2; cy = ny; cz = nz;
     }
-}
-
-// ------------------------------------------------------------------------------------
-// The main kernel.  One lane per tet as above, but the work is split into two phases so the
-// expensive exact predicate runs on DENSE wavefronts:
-//   phase A (enumerate): every lane walks the (cz,cy) rows of its cell range in lock-step with
-//     the rest of its wave (wave-uniform loop bounds via __any), fetches four sorted queries
-//     per row visit, applies the cheap enlarged-bounding-box filter (passes ~30 %) and appends
-//     the survivors as packed (tet lane, query slot) entries to a per-wave ring in LDS; the
-//     slot of each survivor comes from a ballot prefix (no LDS atomics);
-//   phase B (drain): whenever the ring holds >= 64 entries, all 64 lanes pop one entry each,
-//     fetch that tet's plane record from LDS and the query from L1/L2, evaluate the exact
-//     predicate and atomicMin the tet index.
-// The inline variant above spent ~70 % of its issue slots running the 50-instruction exact
-// test with ~15 of 64 lanes enabled (profiles/, DESIGN.md "A1 kernel anatomy").
-// ------------------------------------------------------------------------------------
-constexpr int kRing = 512;              // entries per wave (>= 63 carried + 4*64 appended per step)
-constexpr int kSlotBits = 26;           // entry = tet lane << 26 | query slot  (Q < 2^26, else k_tet_scan_simple)
-
-__device__ __forceinline__ void wave_lds_fence()
-{
-    // LDS traffic of one wave is executed in order by the hardware; this only stops the
-    // compiler from moving one lane's loads across another lane's stores
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-__global__ __launch_bounds__(256) void k_tet_scan(const float *__restrict__ tet, int T, int Q,
-                                                  const float *__restrict__ gparam, int G, int Gx, const int *__restrict__ cells,
-                                                  long long cellStride, const float4 *__restrict__ sortedQ, int *result, int *counters,
-                                                  int *irregT)
-{
-    __shared__ float4 s_planes[4][64][7];
-    __shared__ unsigned s_ring[4][kRing];
-    const int b = blockIdx.y;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int nblk = gridDim.x, per = (nblk + 7) >> 3;
-    const int vb = (blockIdx.x & 7) * per + (blockIdx.x >> 3);       // XCD-aware mapping, see k_tet_scan_simple
-    const int t = vb * blockDim.x + threadIdx.x;
-    const int tw0 = t - lane;                                        // first tet of this wave
-    if (tw0 >= T) return;                                            // whole wave out of range
-    const bool intet = t < T;
-
-    float elo[3] = {0.f, 0.f, 0.f}, ehi[3] = {0.f, 0.f, 0.f};
-    int cx0 = 0, cx1 = 0, cy0 = 0, cy1 = -1, cz0 = 0, cz1 = -1;      // empty range by default
-    {
-        float v[12];
-        const float4 *src = reinterpret_cast<const float4 *>(tet + ((size_t)b * T + (intet ? t : tw0)) * 12);
-        float4 a = src[0], bq = src[1], c = src[2];
-        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
-        v[4] = bq.x; v[5] = bq.y; v[6] = bq.z; v[7] = bq.w;
-        v[8] = c.x; v[9] = c.y; v[10] = c.z; v[11] = c.w;
-        Planes P;
-        make_planes(v, P);
-        float lo[3], hi[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            lo[k] = fminf(fminf(v[k], v[3 + k]), fminf(v[6 + k], v[9 + k]));
-            hi[k] = fmaxf(fmaxf(v[k], v[3 + k]), fmaxf(v[6 + k], v[9 + k]));
-        }
-        const float w = fmaxf(fmaxf(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]);
-        bool finite = true;
-#pragma unroll
-        for (int k = 0; k < 12; ++k) finite = finite && (fabsf(v[k]) <= kBig);
-        const float mn = fminf(fminf(fabsf(P.dv[0]), fabsf(P.dv[1])), fminf(fabsf(P.dv[2]), fabsf(P.dv[3])));
-        const bool regular = finite && (P.sv == 0u || P.sv == 15u) && (w >= kWMin) && (mn >= kTau * ((w * w) * w));
-        if (intet && !regular) {
-            const int k = atomicAdd(&counters[b * 4 + 0], 1);
-            irregT[(size_t)b * T + k] = t;
-        }
-        // plane record of this lane's tet -> LDS (same packing as k_prep_records)
-        float4 *pl = s_planes[wv][lane];
-        pl[0] = make_float4(P.n[0][0], P.n[0][1], P.n[0][2], P.a[0][0]);
-        pl[1] = make_float4(P.a[0][1], P.a[0][2], P.n[1][0], P.n[1][1]);
-        pl[2] = make_float4(P.n[1][2], P.a[1][0], P.a[1][1], P.a[1][2]);
-        pl[3] = make_float4(P.n[2][0], P.n[2][1], P.n[2][2], P.a[2][0]);
-        pl[4] = make_float4(P.a[2][1], P.a[2][2], P.n[3][0], P.n[3][1]);
-        pl[5] = make_float4(P.n[3][2], P.a[3][0], P.a[3][1], P.a[3][2]);
-        pl[6] = make_float4(__int_as_float((int)P.sv), 0.f, 0.f, 0.f);
-        if (intet && regular) {
-            const Grid g = load_grid(gparam + b * 12);
-            const float m = w * kMargin;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) { elo[k] = lo[k] - m; ehi[k] = hi[k] + m; }
-            const bool outside = ehi[0] < g.lo[0] || elo[0] > g.hi[0] || ehi[1] < g.lo[1] || elo[1] > g.hi[1] ||
-                                 ehi[2] < g.lo[2] || elo[2] > g.hi[2];
-            if (!outside) {
-                cx0 = cell_of(elo[0], g.o[0], g.inv[0], Gx); cx1 = cell_of(ehi[0], g.o[0], g.inv[0], Gx);
-                cy0 = cell_of(elo[1], g.o[1], g.inv[1], G);  cy1 = cell_of(ehi[1], g.o[1], g.inv[1], G);
-                cz0 = cell_of(elo[2], g.o[2], g.inv[2], G);  cz1 = cell_of(ehi[2], g.o[2], g.inv[2], G);
-            }
-        }
-    }
-    wave_lds_fence();
-
-    const int *cb = cells + (size_t)b * cellStride;
-    const float4 *sq = sortedQ + (size_t)b * Q;
-    int *res = result + (size_t)b * Q;
-    unsigned *ring = s_ring[wv];
-    int head = 0, tail = 0;                                          // wave-uniform ring cursors
-
-    auto drain = [&](int n) {                                        // n <= 64 entries starting at head
-        wave_lds_fence();
-        if (lane < n) {
-            const unsigned e = ring[(head + lane) & (kRing - 1)];
-            const int tl = (int)(e >> kSlotBits), j = (int)(e & ((1u << kSlotBits) - 1u));
-            const float4 q = sq[j];
-            const float4 *pl = s_planes[wv][tl];
-            const float4 p0 = pl[0], p1 = pl[1], p2 = pl[2], p3 = pl[3], p4 = pl[4], p5 = pl[5];
-            const unsigned sv = (unsigned)__float_as_int(pl[6].x);
-            unsigned mk = 0;
-            {
-                float rx = q.x - p0.w, ry = q.y - p1.x, rz = q.z - p1.y;          // ordering 0: a = vertex 0
-                float d = p0.x * rx + p0.y * ry + p0.z * rz;
-                mk |= (d > 0 ? 1u : 0u);
-                rx = q.x - p2.y; ry = q.y - p2.z; rz = q.z - p2.w;                // ordering 1
-                d = p1.z * rx + p1.w * ry + p2.x * rz;
-                mk |= (d > 0 ? 2u : 0u);
-                rx = q.x - p3.w; ry = q.y - p4.x; rz = q.z - p4.y;                // ordering 2
-                d = p3.x * rx + p3.y * ry + p3.z * rz;
-                mk |= (d > 0 ? 4u : 0u);
-                rx = q.x - p5.y; ry = q.y - p5.z; rz = q.z - p5.w;                // ordering 3
-                d = p4.z * rx + p4.w * ry + p5.x * rz;
-                mk |= (d > 0 ? 8u : 0u);
-            }
-            const unsigned x = mk ^ sv;
-            if (x == 0u || x == 15u) atomicMin(&res[__float_as_int(q.w)], tw0 + tl);
-        }
-        head += n;
-    };
-
-    int cy = cy0, cz = cz0;                                          // this lane's current row
-    bool has = cz <= cz1 && cy <= cy1;
-    while (__any(has)) {
-        int s = 0, e = 0;
-        if (has) {
-            const int row = (cz * G + cy) * Gx;
-            s = cb[row + cx0];
-            e = cb[row + cx1 + 1];                                   // cells has Gx*G*G+1 valid entries
-        }
-        const int n = e - s;
-        for (int j0 = 0; __any(j0 < n); j0 += 4) {
-            float4 q[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                int idx = s + j0 + k;
-                idx = idx < e ? idx : (e > 0 ? e - 1 : 0);           // clamped: always a valid slot (Q > 0)
-                q[k] = sq[idx];
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const bool pass = (j0 + k < n) && q[k].x >= elo[0] && q[k].x <= ehi[0] && q[k].y >= elo[1] && q[k].y <= ehi[1] &&
-                                  q[k].z >= elo[2] && q[k].z <= ehi[2];
-                const unsigned long long mask = __ballot(pass);
-                if (pass) {
-                    const int off = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                    ring[(tail + off) & (kRing - 1)] = ((unsigned)lane << kSlotBits) | (unsigned)(s + j0 + k);
-                }
-                tail += __popcll(mask);
-            }
-            while (tail - head >= 64) drain(64);
-        }
-        // next row of this lane
-        if (has) {
-            ++cy;
-            if (cy > cy1) { cy = cy0; ++cz; }
-            has = cz <= cz1;
-        }
-    }
-    while (tail - head > 0) drain(min(64, tail - head));
 }
 
 // irregular tets x all queries
@@ -1008,14 +844,8 @@ extern "C" int deftet_point_in_tet_f32(const float *tet, const float *pts, float
         DEFTET_LAUNCH(k_scan_apply, dim3(L.nChunk, B), blk, st, L.cells, L.cellStride, L.nChunk, L.chunkTot);
         DEFTET_LAUNCH(k_query_scatter, gq, blk, st, pts, Q, L.qcell, L.cells, L.cellStride, L.sortedQ);
         if (T > 0) {
-            static const bool force_simple = getenv("DEFTET_PIT_SIMPLE") && atoi(getenv("DEFTET_PIT_SIMPLE")) != 0;   // A/B switch
-            if (force_simple || Q >= (1 << kSlotBits)) {
-                DEFTET_LAUNCH(k_tet_scan_simple, gt, blk, st, tet, T, Q, L.gparam, L.G, L.Gx, L.cells, L.cellStride, L.sortedQ,
-                              L.result, L.counters, L.irregT);
-            } else {
-                DEFTET_LAUNCH(k_tet_scan, gt, blk, st, tet, T, Q, L.gparam, L.G, L.Gx, L.cells, L.cellStride, L.sortedQ, L.result,
-                              L.counters, L.irregT);
-            }
+            DEFTET_LAUNCH(k_tet_scan, gt, blk, st, tet, T, Q, L.gparam, L.G, L.Gx, L.cells, L.cellStride, L.sortedQ, L.result,
+                          L.counters, L.irregT);
             int qb = (Q + 255) / 256, tb = (T + 255) / 256;
             if (qb > 1024) qb = 1024;
             if (tb > 1024) tb = 1024;
