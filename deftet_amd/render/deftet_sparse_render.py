@@ -1,0 +1,113 @@
+"""Differentiable tet-face rasterizer with the call signature of
+`kaolin.render.mesh.deftet_sparse_render` as the reference uses it
+(/root/reference/diff_render/diftet_6_subdiv/5_rendereq/deftetrneder.py:97-100), plus the
+in-tree host pieces around it restated exactly: `peel2mask` (deftetrneder.py:31-64),
+`vertex2face` (4_render/vertex2face.py:12-28), `perspective` (3_model/cameraop.py:19-33).
+
+PARITY UNPINNED for the rasterizer itself: Kaolin is not part of the reference tree and the
+reference does not pin a version (README.md:30); see deftet_amd/csrc/raster.hip for the exact
+arithmetic this build implements.
+"""
+import torch
+from torch.autograd import Function
+
+from deftet_amd import _lib
+
+
+def _f32c(t):
+    return t.contiguous().float()
+
+
+class _SparseRender(Function):
+    @staticmethod
+    def forward(ctx, pixel_coords, render_ranges, face_vertices_z, face_vertices_image, face_features, knum, eps):
+        _lib.require_gpu(pixel_coords, render_ranges, face_vertices_z, face_vertices_image, face_features)
+        lib = _lib.load()
+        pix, rng = _f32c(pixel_coords), _f32c(render_ranges)
+        fz, fxy, ff = _f32c(face_vertices_z), _f32c(face_vertices_image), _f32c(face_features)
+        B, P = pix.shape[0], pix.shape[1]
+        F, D = fz.shape[1], ff.shape[3]
+        if fxy.shape != (B, F, 3, 2) or ff.shape[:3] != (B, F, 3) or rng.shape != (B, P, 2):
+            raise RuntimeError("deftet_sparse_render: inconsistent shapes")
+        dev = pix.device
+        feat = torch.empty(B, P, knum, D, device=dev, dtype=torch.float32)
+        face = torch.empty(B, P, knum, device=dev, dtype=torch.int64)
+        w = torch.empty(B, P, knum, 3, device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            ws = _lib.workspace(dev, lib.deftet_sparse_render_workspace_bytes(B, P, F, knum))
+            _lib.check(lib.deftet_sparse_render_fwd_f32(_lib.ptr(pix), _lib.ptr(rng), _lib.ptr(fz), _lib.ptr(fxy), _lib.ptr(ff),
+                                                        _lib.ptr(feat), _lib.ptr(face), _lib.ptr(w), B, P, F, D, knum, eps,
+                                                        _lib.ptr(ws), ws.numel(), _lib.current_stream(dev)),
+                       "deftet_sparse_render_fwd_f32")
+        ctx.save_for_backward(pix, fxy, ff, face, w)
+        ctx.eps = eps
+        ctx.mark_non_differentiable(face)
+        return feat, face
+
+    @staticmethod
+    def backward(ctx, grad_feat, _grad_face):
+        pix, fxy, ff, face, w = ctx.saved_tensors
+        lib = _lib.load()
+        B, P, knum = face.shape
+        F, D = fxy.shape[1], ff.shape[3]
+        g = _f32c(grad_feat)
+        gxy = torch.empty_like(fxy)
+        gff = torch.empty_like(ff)
+        dev = pix.device
+        with torch.cuda.device(dev):
+            ws = _lib.workspace(dev, lib.deftet_sparse_render_bwd_workspace_bytes(B, P, F, knum))
+            _lib.check(lib.deftet_sparse_render_bwd_f32(_lib.ptr(pix), _lib.ptr(fxy), _lib.ptr(ff), _lib.ptr(face), _lib.ptr(w),
+                                                        _lib.ptr(g), _lib.ptr(gxy), _lib.ptr(gff), B, P, F, D, knum, ctx.eps,
+                                                        _lib.ptr(ws), ws.numel(), _lib.current_stream(dev)),
+                       "deftet_sparse_render_bwd_f32")
+        return None, None, None, gxy, gff, None, None
+
+
+def deftet_sparse_render(pixel_coords, render_ranges, face_vertices_z, face_vertices_image, face_features,
+                         knum=300, eps=1e-8):
+    """(pixel_coords [B,P,2], render_ranges [B,P,2] (min,max depth), face_vertices_z [B,F,3],
+    face_vertices_image [B,F,3,2], face_features [B,F,3,D]) ->
+    (features [B,P,knum,D] sorted nearest-first, face_idx int64 [B,P,knum], -1 = empty)."""
+    return _SparseRender.apply(pixel_coords, render_ranges, face_vertices_z, face_vertices_image, face_features,
+                               int(knum), float(eps))
+
+
+def vertex2face(vertex_features_bxpxk, faces_fx3):
+    """4_render/vertex2face.py:12-28"""
+    vertex_features_bxf3xk = vertex_features_bxpxk[:, faces_fx3.view(-1)]
+    bnum = vertex_features_bxpxk.shape[0]
+    knum = vertex_features_bxpxk.shape[2]
+    return vertex_features_bxf3xk.view(bnum, -1, knum * 3)
+
+
+def perspective(points_bxpx3, cameras):
+    """3_model/cameraop.py:19-33"""
+    camera_rot_bx3x3, camera_pos_bx3, camera_proj_3x1 = cameras
+    cameratrans_rot_bx3x3 = camera_rot_bx3x3.permute(0, 2, 1)
+    points_bxpx3 = points_bxpx3 - camera_pos_bx3.view(-1, 1, 3)
+    points_bxpx3 = torch.matmul(points_bxpx3, cameratrans_rot_bx3x3)
+    camera_proj_bx1x3 = camera_proj_3x1.view(-1, 1, 3)
+    xy_bxpx3 = points_bxpx3 * camera_proj_bx1x3
+    xy_bxpx2 = xy_bxpx3[:, :, :2] / xy_bxpx3[:, :, 2:3]
+    return points_bxpx3, xy_bxpx2
+
+
+def peel2mask(ims_bxpxkxd, imdepth_bxpxkx1=None):
+    """5_rendereq/deftetrneder.py:31-64: front-to-back alpha compositing over the k sorted hits."""
+    immask_bxpxkx1 = ims_bxpxkxd[:, :, :, :1]
+    imcolor_bxpxkxc = ims_bxpxkxd[:, :, :, 1:]
+    eps = 1e-10
+    immask_bxpxkx1 = torch.clamp(immask_bxpxkx1, eps, 1.0 - eps)
+    xprob_shift = torch.nn.functional.pad(1 - immask_bxpxkx1[:, :, :-1, :], pad=(0, 0, 1, 0), mode='constant', value=1)
+    xprob_shiftsum = torch.cumprod(xprob_shift, dim=2)
+    xvis = immask_bxpxkx1 * xprob_shiftsum
+    xcolor = (imcolor_bxpxkxc * xvis).sum(dim=2)
+    if imdepth_bxpxkx1 is not None:
+        imdepth_bxpx1 = (imdepth_bxpxkx1 * xvis).sum(dim=2)
+    else:
+        imdepth_bxpx1 = None
+    xvis = xvis.sum(2)
+    xcolor = xcolor + (1. - xvis)                       # white background
+    if imdepth_bxpx1 is not None:
+        imdepth_bxpx1 = imdepth_bxpx1 + -6.0 * (1.0 - xvis)
+    return xcolor, xvis, imdepth_bxpx1

@@ -174,12 +174,15 @@ int deftet_sparse_render_fwd_f32(const float *pixel_bxpx2, const float *range_bx
                                  int64_t *out_face_bxpxk, float *out_w_bxpxkx3,
                                  int n_batch, int n_pixel, int n_face, int n_feat, int knum, float eps,
                                  void *workspace, size_t workspace_bytes, void *stream);
+/* backward: gradients to face_vertices_image [B,F,3,2] and face_features [B,F,3,D] (both fully
+ * overwritten), none to z / pixels — as Kaolin documents.  Atomic-free (per-face hit lists). */
+size_t deftet_sparse_render_bwd_workspace_bytes(int n_batch, int n_pixel, int n_face, int knum);
 int deftet_sparse_render_bwd_f32(const float *pixel_bxpx2, const float *face_xy_bxfx3x2,
                                  const float *face_feat_bxfx3xd, const int64_t *face_bxpxk,
                                  const float *w_bxpxkx3, const float *grad_out_bxpxkxd,
                                  float *grad_face_xy, float *grad_face_feat,
                                  int n_batch, int n_pixel, int n_face, int n_feat, int knum, float eps,
-                                 void *stream);
+                                 void *workspace, size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

@@ -23,7 +23,7 @@ _f64p = C.POINTER(C.c_double)
 
 def build(force: bool = False) -> None:
     """Compile the restatement and (when /root/reference is present) oracle/_ref."""
-    src = [os.path.join(HERE, f) for f in ("deftet_oracle.c", "deftet_oracle_surface.c", "Makefile")]
+    src = [os.path.join(HERE, f) for f in ("deftet_oracle.c", "deftet_oracle_surface.c", "deftet_oracle_render.c", "Makefile")]
     stale = (not os.path.exists(LIB_PATH) or
              any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in src))
     need_ref = os.path.isdir("/root/reference/utils/lib") and not all(
@@ -216,6 +216,39 @@ def nn_index(queries_bxnx3, points_bxmx3):
     out = np.zeros((B, N), np.int32)
     lib().oracle_nn_index_f32(_p(q, _f32p), _p(p, _f32p), _p(out, _i32p), B, N, p.shape[1])
     return out
+
+
+# --------------------------------------------------------------------------- rasterizer (parity unpinned)
+def sparse_render_fwd(pixel_bxpx2, range_bxpx2, face_z_bxfx3, face_xy_bxfx3x2, face_feat_bxfx3xd, knum=300, eps=1e-8):
+    pix, rng = _c(pixel_bxpx2, np.float32), _c(range_bxpx2, np.float32)
+    fz, fxy, ff = _c(face_z_bxfx3, np.float32), _c(face_xy_bxfx3x2, np.float32), _c(face_feat_bxfx3xd, np.float32)
+    B, P = pix.shape[:2]
+    F, D = fz.shape[1], ff.shape[3]
+    feat = np.zeros((B, P, knum, D), np.float32)
+    face = np.zeros((B, P, knum), np.int64)
+    w = np.zeros((B, P, knum, 3), np.float32)
+    lib().oracle_sparse_render_fwd_f32(_p(pix, _f32p), _p(rng, _f32p), _p(fz, _f32p), _p(fxy, _f32p), _p(ff, _f32p),
+                                       _p(feat, _f32p), _p(face, _i64p), _p(w, _f32p), B, P, F, D, int(knum), C.c_float(eps))
+    return feat, face, w
+
+
+def sparse_render_torch(pixel, face_xy, face_feat, face_idx, eps=1e-8):
+    """Differentiable (torch, any dtype) re-evaluation of the interpolated features for GIVEN
+    face indices — the autograd oracle for the rasterizer backward."""
+    import torch
+    B, P, K = face_idx.shape
+    valid = face_idx >= 0
+    fi = face_idx.clamp(min=0)
+    xy = torch.gather(face_xy, 1, fi.reshape(B, P * K, 1, 1).expand(-1, -1, 3, 2)).reshape(B, P, K, 3, 2)
+    ft = torch.gather(face_feat, 1, fi.reshape(B, P * K, 1, 1).expand(-1, -1, 3, face_feat.shape[-1])).reshape(B, P, K, 3, -1)
+    ax, ay, bx, by, cx, cy = xy[..., 0, 0], xy[..., 0, 1], xy[..., 1, 0], xy[..., 1, 1], xy[..., 2, 0], xy[..., 2, 1]
+    px, py = pixel[..., 0:1], pixel[..., 1:2]
+    m, pp, n, q, s, t = bx - ax, by - ay, cx - ax, cy - ay, px - ax, py - ay
+    k1, k2, k3 = s * q - n * t, m * t - s * pp, m * q - n * pp
+    w1, w2 = k1 / (k3 + eps), k2 / (k3 + eps)
+    w0 = 1 - w1 - w2
+    feat = w0[..., None] * ft[..., 0, :] + w1[..., None] * ft[..., 1, :] + w2[..., None] * ft[..., 2, :]
+    return feat * valid[..., None].to(feat.dtype)
 
 
 # --------------------------------------------------------------------------- oracle/_ref

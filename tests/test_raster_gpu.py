@@ -1,0 +1,162 @@
+"""GPU tests of the tet-face rasterizer (A12).  PARITY UNPINNED w.r.t. Kaolin (not in the
+reference tree); these tests pin the HIP implementation to this repo's statement of the
+contract (oracle/deftet_oracle_render.c), to fp64 autograd for the backward, and to
+size-independent properties at the BASELINE configs[4] size."""
+import numpy as np
+import pytest
+import torch
+
+from deftet_amd import grids
+
+pytestmark = pytest.mark.gpu
+
+
+def projected_grid(res, rot=(0.35, 0.5), cam_z=4.0, focal=1111.0 / 800.0 * 2.0, mult=1000.0, coef=2.5, seed=0):
+    """Unique faces (incl. boundary) of a res=R Kuhn grid scaled by `coef`, rotated, projected by
+    the reference's perspective() (3_model/cameraop.py:19-33) and multiplied by 1000
+    (3_model/deftet.py:459-468).  Returns face_z [1,F,3], face_xy [1,F,3,2], feat [1,F,3,4]."""
+    from oracle import oracle as O
+    verts, tets = grids.kuhn_grid(res)
+    f3, _, _, _, _ = O.tet_to_face(tets, verts.shape[0], with_boundary=True)
+    p = (verts - 0.5) * coef
+    ax, ay = rot
+    Rx = np.array([[1, 0, 0], [0, np.cos(ax), -np.sin(ax)], [0, np.sin(ax), np.cos(ax)]])
+    Ry = np.array([[np.cos(ay), 0, np.sin(ay)], [0, 1, 0], [-np.sin(ay), 0, np.cos(ay)]])
+    p = p @ (Rx @ Ry).T
+    pc = p - np.array([0, 0, cam_z])
+    proj = np.array([focal, focal, -1.0])
+    xy3 = pc * proj
+    xy = xy3[:, :2] / xy3[:, 2:3] * mult
+    rng = np.random.default_rng(seed)
+    feat_v = rng.random((verts.shape[0], 4))
+    return (pc[f3][:, :, 2][None].astype(np.float32), xy[f3][None].astype(np.float32), feat_v[f3][None].astype(np.float32))
+
+
+def pixel_grid(n, mult=1000.0):
+    a = (np.arange(n) + 0.5) / n * 2 - 1
+    X, Y = np.meshgrid(a, a, indexing="xy")
+    pix = np.stack([X, Y], -1).reshape(1, -1, 2) * mult
+    rngs = np.zeros_like(pix)
+    rngs[..., 0] = -1000.0
+    return pix.astype(np.float32), rngs.astype(np.float32)
+
+
+def run(pix, rngs, fz, fxy, ff, knum, dev, eps=1e-8):
+    from deftet_amd.render import deftet_sparse_render
+    t = [torch.from_numpy(x).to(dev) for x in (pix, rngs, fz, fxy, ff)]
+    feat, face = deftet_sparse_render(*t, knum=knum, eps=eps)
+    torch.cuda.synchronize()
+    return feat, face
+
+
+@pytest.mark.parametrize("knum", [4, 64])
+def test_forward_matches_oracle_projected_grid(cuda, oracle, knum):
+    fz, fxy, ff = projected_grid(8)
+    pix, rngs = pixel_grid(40)
+    pix = pix * 0.7
+    wf, wface, ww = oracle.sparse_render_fwd(pix, rngs, fz, fxy, ff, knum=knum)
+    feat, face = run(pix, rngs, fz, fxy, ff, knum, cuda)
+    assert np.array_equal(face.cpu().numpy(), wface)
+    assert np.array_equal(feat.cpu().numpy(), wf)
+    nh = (wface >= 0).sum(-1)
+    assert nh.max() == knum if knum == 4 else nh.max() > 20      # knum=4 overflows (first-k-by-face-index rule)
+
+
+def test_forward_matches_oracle_adversarial(cuda, oracle):
+    rng = np.random.default_rng(3)
+    F = 400
+    fxy = rng.uniform(-1, 1, (1, F, 3, 2)).astype(np.float32)
+    fxy[0, :150] = fxy[0, :150] * 0.1 + rng.uniform(-0.9, 0.9, (150, 1, 2)).astype(np.float32)     # small faces (tiles)
+    fxy[0, 150:160, 2] = fxy[0, 150:160, 0]                                                          # zero area
+    fxy[0, 160:165, 2] = (fxy[0, 160:165, 0] + fxy[0, 160:165, 1]) / 2                               # collinear
+    fxy[0, 165, 0, 0] = np.nan
+    fxy[0, 166, 1] = np.inf
+    fxy[0, 167] *= 1e7
+    fxy[0, 168] = fxy[0, 3]                                                                          # duplicate face
+    fxy[0, 169] = fxy[0, 5][::-1]                                                                    # reversed winding
+    fz = rng.uniform(-5, -1, (1, F, 3)).astype(np.float32)
+    fz[0, 170:175] = 5.0                                                                             # outside the depth range
+    ff = rng.random((1, F, 3, 5)).astype(np.float32)
+    P = 1500
+    pix = rng.uniform(-1.1, 1.1, (1, P, 2)).astype(np.float32)
+    pix[0, :100] = fxy[0, rng.integers(0, 150, 100), rng.integers(0, 3, 100)]                        # on vertices
+    pix[0, 100] = np.nan
+    pix[0, 101, 0] = np.inf
+    pix[0, 102] = 3e6
+    rngs = np.tile(np.array([-1000.0, 0.0], np.float32), (1, P, 1))
+    rngs[0, 200:300] = [-3.0, -2.0]                                                                  # narrow depth window
+    for knum in (8, 300):
+        wf, wface, ww = oracle.sparse_render_fwd(pix, rngs, fz, fxy, ff, knum=knum)
+        feat, face = run(pix, rngs, fz, fxy, ff, knum, cuda)
+        assert np.array_equal(face.cpu().numpy(), wface)
+        assert np.array_equal(feat.cpu().numpy(), wf, equal_nan=True)
+
+
+def test_backward_matches_fp64_autograd(cuda, oracle):
+    from deftet_amd.render import deftet_sparse_render, peel2mask
+    fz, fxy, ff = projected_grid(6)
+    pix, rngs = pixel_grid(24)
+    pix = pix * 0.6
+    tp, tr, tz = (torch.from_numpy(x).to(cuda) for x in (pix, rngs, fz))
+    txy = torch.from_numpy(fxy).to(cuda).requires_grad_(True)
+    tff = torch.from_numpy(ff).to(cuda).requires_grad_(True)
+    feat, face = deftet_sparse_render(tp, tr, tz, txy, tff, knum=48)
+    color, vis, _ = peel2mask(feat)                        # the reference's compositing on top
+    g = torch.Generator(device=cuda).manual_seed(0)
+    loss = (color * torch.rand(color.shape, device=cuda, generator=g)).sum() + (vis ** 2).sum()
+    loss.backward()
+    # fp64 reference: same face indices, differentiable interpolation, same compositing
+    xy64 = torch.from_numpy(fxy).double().requires_grad_(True)
+    ff64 = torch.from_numpy(ff).double().requires_grad_(True)
+    feat64 = oracle.sparse_render_torch(torch.from_numpy(pix).double(), xy64, ff64, face.cpu())
+    assert torch.allclose(feat64.float(), feat.detach().cpu(), rtol=1e-4, atol=1e-5)
+    c64, v64, _ = peel2mask(feat64)
+    g = torch.Generator(device=cuda).manual_seed(0)
+    wts = torch.rand(color.shape, device=cuda, generator=g).cpu().double()
+    ((c64 * wts).sum() + (v64 ** 2).sum()).backward()
+    for got, want in ((txy.grad.cpu().double(), xy64.grad), (tff.grad.cpu().double(), ff64.grad)):
+        scale = want.abs().max().item()
+        assert scale > 0
+        assert (got - want).abs().max().item() <= 2e-4 * scale
+    # faces that no pixel hit get exactly zero gradient
+    hit = torch.zeros(fxy.shape[1], dtype=torch.bool)
+    hit[face.cpu()[face.cpu() >= 0]] = True
+    assert (txy.grad.cpu()[0][~hit] == 0).all() and (tff.grad.cpu()[0][~hit] == 0).all()
+
+
+def test_baseline_config_properties(cuda):
+    """BASELINE configs[4]: 512x512 rays, k=64, unique faces of the res=70 grid."""
+    fz, fxy, ff = projected_grid(70)
+    pix, rngs = pixel_grid(512)
+    feat, face = run(pix, rngs, fz, fxy, ff, 64, cuda)
+    F = fxy.shape[1]
+    assert F > 500000
+    assert face.shape == (1, 512 * 512, 64) and feat.shape == (1, 512 * 512, 64, 4)
+    valid = face >= 0
+    assert ((face >= -1) & (face < F)).all()
+    n = valid.sum(-1)
+    assert n.max().item() == 64 and (n == 0).float().mean().item() > 0.2          # rays through the grid saturate, corners miss
+    # valid slots form a prefix
+    assert (valid[..., 1:] <= valid[..., :-1]).all()
+    assert (feat[~valid] == 0).all()
+    fv = feat[valid]
+    assert fv.min().item() >= -1e-5 and fv.max().item() <= 1 + 1e-5             # convex combinations of features in [0,1)
+    # recompute depth of every recorded hit from the face and the pixel; must be sorted nearest-first
+    sub = slice(0, 512 * 512, 7)
+    fsub = face[0, sub]
+    vs = fsub >= 0
+    fi = fsub.clamp(min=0)
+    txy = torch.from_numpy(fxy).to(cuda)[0][fi]
+    tz = torch.from_numpy(fz).to(cuda)[0][fi]
+    p = torch.from_numpy(pix).to(cuda)[0, sub][:, None, :]
+    a, b, c = txy[..., 0, :], txy[..., 1, :], txy[..., 2, :]
+    m, pp, nn, q = b[..., 0] - a[..., 0], b[..., 1] - a[..., 1], c[..., 0] - a[..., 0], c[..., 1] - a[..., 1]
+    s, t = p[..., 0] - a[..., 0], p[..., 1] - a[..., 1]
+    den = (m * q - nn * pp) + 1e-8
+    w1, w2 = (s * q - nn * t) / den, (m * t - s * pp) / den
+    w0 = 1 - w1 - w2
+    assert (torch.stack([w0, w1, w2], -1)[vs] >= 0).all()
+    z = (w0 * tz[..., 0] + w1 * tz[..., 1]) + w2 * tz[..., 2]
+    z = torch.where(vs, z, torch.full_like(z, -1e30))
+    assert (z[:, 1:] <= z[:, :-1]).all()
+    assert (z[vs] <= 0).all() and (z[vs] >= -1000).all()
