@@ -35,7 +35,8 @@ constexpr float kBig = 1048576.0f;     // 2^20
 constexpr float kTau = 1.0f / 128.0f;
 constexpr float kMargin = 1.0f / 64.0f;
 
-struct Grid2 { float ox, oy, ix, iy, lox, loy, hix, hiy; };
+struct Grid2 { float ox, oy, ix, iy, lox, loy, hix, hiy; int gx, gy; };
+constexpr int kG2Max = 512;            // tiles per axis (upper bound; the actual count is chosen on the device)
 
 __device__ __forceinline__ int cell_of(float x, float o, float inv, int G)
 {
@@ -73,17 +74,46 @@ __global__ __launch_bounds__(256) void k_pix_bbox(const float *__restrict__ pix,
     }
 }
 
-__global__ __launch_bounds__(64) void k_pix_grid(const float *__restrict__ part, int G2, Grid2 *g)
+// mean image-space extent of the finite faces (per-block partials: sum of w, count)
+__global__ __launch_bounds__(256) void k_face_stats(const float *__restrict__ xy, int F, float *part)
+{
+    __shared__ float sh[4][2];
+    float sw = 0.f, cnt = 0.f;
+    for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < F; f += gridDim.x * blockDim.x) {
+        const float2 a = reinterpret_cast<const float2 *>(xy)[f * 3], b = reinterpret_cast<const float2 *>(xy)[f * 3 + 1],
+                     c = reinterpret_cast<const float2 *>(xy)[f * 3 + 2];
+        const float w = fmaxf(fmaxf(a.x, fmaxf(b.x, c.x)) - fminf(a.x, fminf(b.x, c.x)),
+                              fmaxf(a.y, fmaxf(b.y, c.y)) - fminf(a.y, fminf(b.y, c.y)));
+        if (w <= 2.f * kBig && w > 0.f) { sw += w; cnt += 1.f; }      // NaN fails
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { sw += __shfl_xor(sw, off); cnt += __shfl_xor(cnt, off); }
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sh[wv][0] = sw; sh[wv][1] = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[blockIdx.x * 2] = (sh[0][0] + sh[1][0]) + (sh[2][0] + sh[3][0]);
+        part[blockIdx.x * 2 + 1] = (sh[0][1] + sh[1][1]) + (sh[2][1] + sh[3][1]);
+    }
+}
+
+// pixel box + mean face size -> tile grid: tiles are about one mean face extent wide, so a
+// typical face overlaps 2x2..3x3 tiles; never more than kG2Max tiles per axis
+__global__ __launch_bounds__(64) void k_pix_grid(const float *__restrict__ part, const float *__restrict__ fpart, Grid2 *g)
 {
     const int lane = threadIdx.x;
     float lo[2] = {part[lane * 4], part[lane * 4 + 1]}, hi[2] = {part[lane * 4 + 2], part[lane * 4 + 3]};
+    float sw = fpart[lane * 2], cnt = fpart[lane * 2 + 1];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1)
+    for (int off = 32; off > 0; off >>= 1) {
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             lo[k] = fminf(lo[k], __shfl_xor(lo[k], off));
             hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off));
         }
+        sw += __shfl_xor(sw, off);
+        cnt += __shfl_xor(cnt, off);
+    }
     if (lane == 0) {
         Grid2 r;
         const bool okx = hi[0] >= lo[0], oky = hi[1] >= lo[1];
@@ -91,8 +121,13 @@ __global__ __launch_bounds__(64) void k_pix_grid(const float *__restrict__ part,
         r.loy = oky ? lo[1] : 0.f; r.hiy = oky ? hi[1] : 0.f;
         r.ox = r.lox; r.oy = r.loy;
         const float ex = r.hix - r.lox, ey = r.hiy - r.loy;
-        r.ix = ex > 1e-30f ? (float)G2 / ex : 0.f;
-        r.iy = ey > 1e-30f ? (float)G2 / ey : 0.f;
+        const float meanw = cnt > 0.f ? sw / cnt : 0.f;
+        float nx = meanw > 0.f ? ceilf(ex / meanw) : 1.f, ny = meanw > 0.f ? ceilf(ey / meanw) : 1.f;
+        nx = fminf(fmaxf(nx, 1.f), (float)kG2Max);                  // NaN -> 1
+        ny = fminf(fmaxf(ny, 1.f), (float)kG2Max);
+        r.gx = (int)nx; r.gy = (int)ny;
+        r.ix = ex > 1e-30f ? nx / ex : 0.f;
+        r.iy = ey > 1e-30f ? ny / ey : 0.f;
         *g = r;
     }
 }
@@ -102,7 +137,7 @@ __global__ __launch_bounds__(64) void k_pix_grid(const float *__restrict__ part,
 // the fp32 test can accept lies within w/64 of the face's box (same argument as DESIGN.md A1).
 struct FaceBox { int tx0, tx1, ty0, ty1, mode; };   // mode 0: skip, 1: tiles, 2: wide
 
-__device__ __forceinline__ FaceBox face_box(const float *__restrict__ xy, int f, const Grid2 &g, int G2, float eps)
+__device__ __forceinline__ FaceBox face_box(const float *__restrict__ xy, int f, const Grid2 &g, float eps)
 {
     const float2 a = reinterpret_cast<const float2 *>(xy)[f * 3], b = reinterpret_cast<const float2 *>(xy)[f * 3 + 1],
                  c = reinterpret_cast<const float2 *>(xy)[f * 3 + 2];
@@ -119,52 +154,55 @@ __device__ __forceinline__ FaceBox face_box(const float *__restrict__ xy, int f,
     const float mg = w * kMargin;
     const float elx = lox - mg, ehx = hix + mg, ely = loy - mg, ehy = hiy + mg;
     if (ehx < g.lox || elx > g.hix || ehy < g.loy || ely > g.hiy) { r.mode = 0; return r; }
-    r.tx0 = cell_of(elx, g.ox, g.ix, G2); r.tx1 = cell_of(ehx, g.ox, g.ix, G2);
-    r.ty0 = cell_of(ely, g.oy, g.iy, G2); r.ty1 = cell_of(ehy, g.oy, g.iy, G2);
+    r.tx0 = cell_of(elx, g.ox, g.ix, g.gx); r.tx1 = cell_of(ehx, g.ox, g.ix, g.gx);
+    r.ty0 = cell_of(ely, g.oy, g.iy, g.gy); r.ty1 = cell_of(ehy, g.oy, g.iy, g.gy);
     r.mode = ((r.tx1 - r.tx0 + 1) * (r.ty1 - r.ty0 + 1) <= kMaxTiles) ? 1 : 2;
     return r;
 }
 
-__global__ __launch_bounds__(256) void k_face_count(const float *__restrict__ xy, int F, const Grid2 *__restrict__ gp, int G2,
+__global__ __launch_bounds__(256) void k_face_count(const float *__restrict__ xy, int F, const Grid2 *__restrict__ gp,
                                                     float eps, int *tileCount, int *wide, int *nWide)
 {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= F) return;
     const Grid2 g = *gp;
-    const FaceBox fb = face_box(xy, f, g, G2, eps);
+    const FaceBox fb = face_box(xy, f, g, eps);
     if (fb.mode == 2) { wide[atomicAdd(nWide, 1)] = f; return; }
     if (fb.mode == 0) return;
     for (int ty = fb.ty0; ty <= fb.ty1; ++ty)
-        for (int tx = fb.tx0; tx <= fb.tx1; ++tx) atomicAdd(&tileCount[ty * G2 + tx], 1);
+        for (int tx = fb.tx0; tx <= fb.tx1; ++tx) atomicAdd(&tileCount[ty * g.gx + tx], 1);
 }
 
-__global__ __launch_bounds__(256) void k_face_fill(const float *__restrict__ xy, int F, const Grid2 *__restrict__ gp, int G2,
+__global__ __launch_bounds__(256) void k_face_fill(const float *__restrict__ xy, int F, const Grid2 *__restrict__ gp,
                                                    float eps, const int *__restrict__ tileStart, int *tileFill, int *list)
 {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= F) return;
     const Grid2 g = *gp;
-    const FaceBox fb = face_box(xy, f, g, G2, eps);
+    const FaceBox fb = face_box(xy, f, g, eps);
     if (fb.mode != 1) return;
     for (int ty = fb.ty0; ty <= fb.ty1; ++ty)
         for (int tx = fb.tx0; tx <= fb.tx1; ++tx) {
-            const int t = ty * G2 + tx;
+            const int t = ty * g.gx + tx;
             list[tileStart[t] + atomicAdd(&tileFill[t], 1)] = f;
         }
 }
 
 // ascending sort of one tile's face list (block per tile; the wide list is "tile" nTiles).
 // <= 2048 entries: bitonic sort in LDS; longer lists: rank sort through global scratch.
-__global__ __launch_bounds__(256) void k_tile_sort(int *list, const int *__restrict__ tileStart, int nTiles, int *wide,
-                                                   const int *__restrict__ nWide, int *scratch, long long wideScratchOff)
+__global__ __launch_bounds__(256) void k_tile_sort(int *list, const int *__restrict__ tileStart, const Grid2 *__restrict__ gp,
+                                                   int *wide, const int *__restrict__ nWide, int *scratch,
+                                                   long long wideScratchOff)
 {
     __shared__ int sh[2048];
-    const int tile = blockIdx.x;
+    const int nTiles = gp->gx * gp->gy;
+    for (int tile = blockIdx.x; tile <= nTiles; tile += gridDim.x) {
     int *base;
     int n;
     if (tile < nTiles) { base = list + tileStart[tile]; n = tileStart[tile + 1] - tileStart[tile]; }
     else { base = wide; n = *nWide; }
-    if (n <= 1) return;
+    if (n <= 1) continue;
+    __syncthreads();                                   // sh is reused across iterations
     if (n <= 2048) {
         int m = 1;
         while (m < n) m <<= 1;
@@ -195,6 +233,7 @@ __global__ __launch_bounds__(256) void k_tile_sort(int *list, const int *__restr
         __syncthreads();
         for (int i = threadIdx.x; i < n; i += 256) base[i] = tmp[i];
     }
+    }
 }
 
 struct Hit { int f; float z, w1, w2; };
@@ -202,7 +241,7 @@ struct Hit { int f; float z, w1, w2; };
 // one lane per pixel: walk the tile list merged with the wide list in ascending face order
 __global__ __launch_bounds__(256) void k_pix_raster(const float *__restrict__ pix, const float *__restrict__ rng,
                                                     const float *__restrict__ fz, const float *__restrict__ fxy, int P,
-                                                    const Grid2 *__restrict__ gp, int G2, const int *__restrict__ tileStart,
+                                                    const Grid2 *__restrict__ gp, const int *__restrict__ tileStart,
                                                     const int *__restrict__ list, const int *__restrict__ wide,
                                                     const int *__restrict__ nWide, int F, int knum, float eps, int4 *hits,
                                                     int *nhit)
@@ -215,7 +254,7 @@ __global__ __launch_bounds__(256) void k_pix_raster(const float *__restrict__ pi
     const bool tame = fabsf(px) <= kBig && fabsf(py) <= kBig;
     int i = 0, ie = 0;
     if (tame) {
-        const int t = cell_of(py, g.oy, g.iy, G2) * G2 + cell_of(px, g.ox, g.ix, G2);
+        const int t = cell_of(py, g.oy, g.iy, g.gy) * g.gx + cell_of(px, g.ox, g.ix, g.gx);
         i = tileStart[t];
         ie = tileStart[t + 1];
     }
@@ -351,19 +390,10 @@ __global__ __launch_bounds__(256) void k_bwd_gather(const float *__restrict__ pi
     o[0] = gax; o[1] = gay; o[2] = gbx; o[3] = gby; o[4] = gcx; o[5] = gcy;
 }
 
-static int pick_G2(int F, int P)
-{
-    double a = sqrt((double)(F > 0 ? F : 1) / 48.0), b = sqrt((double)(P > 0 ? P : 1));
-    int g = (int)llround(a < b ? a : b);
-    if (g < 1) g = 1;
-    if (g > 1024) g = 1024;
-    return g;
-}
-
 struct Layout {
-    int G2, nTiles;
+    int nTiles;
     size_t bytes;
-    float *part;
+    float *part, *fpart;
     Grid2 *grid;
     int *tileCount, *tileStart, *tileFill, *wide, *nWide, *list, *scratch, *nhit;
     int4 *hits;
@@ -375,9 +405,9 @@ static Layout make_layout(int P, int F, int knum, void *ws, size_t wsb)
 {
     Layout L{};
     Arena A(ws, wsb);
-    L.G2 = pick_G2(F, P);
-    L.nTiles = L.G2 * L.G2;
+    L.nTiles = kG2Max * kG2Max;                              // capacity; the device picks gx*gy <= this
     L.part = A.take<float>(kBoxBlocks * 4);
+    L.fpart = A.take<float>(kBoxBlocks * 2);
     L.grid = A.take<Grid2>(1);
     L.tileCount = A.take<int>((size_t)L.nTiles + 1);
     L.tileStart = A.take<int>((size_t)L.nTiles + 1);
@@ -426,9 +456,10 @@ extern "C" int deftet_sparse_render_fwd_f32(const float *pix, const float *rng, 
         DEFTET_HIP(hipMemsetAsync(L.tileFill, 0, ((size_t)L.nTiles + 1) * 4, st));
         DEFTET_HIP(hipMemsetAsync(L.nWide, 0, 16, st));
         DEFTET_LAUNCH(k_pix_bbox, dim3(kBoxBlocks), dim3(256), st, pb, P, L.part);
-        DEFTET_LAUNCH(k_pix_grid, dim3(1), dim3(64), st, L.part, L.G2, L.grid);
+        DEFTET_LAUNCH(k_face_stats, dim3(kBoxBlocks), dim3(256), st, xb, F, L.fpart);
+        DEFTET_LAUNCH(k_pix_grid, dim3(1), dim3(64), st, L.part, L.fpart, L.grid);
         if (F > 0) {
-            DEFTET_LAUNCH(k_face_count, dim3((F + 255) / 256), dim3(256), st, xb, F, L.grid, L.G2, eps, L.tileCount, L.wide, L.nWide);
+            DEFTET_LAUNCH(k_face_count, dim3((F + 255) / 256), dim3(256), st, xb, F, L.grid, eps, L.tileCount, L.wide, L.nWide);
         }
         size_t need = 0;
         hipError_t e = rocprim::exclusive_scan(nullptr, need, L.tileCount, L.tileStart, 0, (size_t)L.nTiles + 1, rocprim::plus<int>(), st);
@@ -436,11 +467,11 @@ extern "C" int deftet_sparse_render_fwd_f32(const float *pix, const float *rng, 
         e = rocprim::exclusive_scan(L.scanTmp, need, L.tileCount, L.tileStart, 0, (size_t)L.nTiles + 1, rocprim::plus<int>(), st);
         if (e != hipSuccess) return set_error(DEFTET_ELAUNCH, "exclusive_scan: %s", hipGetErrorString(e));
         if (F > 0) {
-            DEFTET_LAUNCH(k_face_fill, dim3((F + 255) / 256), dim3(256), st, xb, F, L.grid, L.G2, eps, L.tileStart, L.tileFill, L.list);
-            DEFTET_LAUNCH(k_tile_sort, dim3(L.nTiles + 1), dim3(256), st, L.list, L.tileStart, L.nTiles, L.wide, L.nWide, L.scratch,
+            DEFTET_LAUNCH(k_face_fill, dim3((F + 255) / 256), dim3(256), st, xb, F, L.grid, eps, L.tileStart, L.tileFill, L.list);
+            DEFTET_LAUNCH(k_tile_sort, dim3(4096), dim3(256), st, L.list, L.tileStart, L.grid, L.wide, L.nWide, L.scratch,
                           (long long)F * kMaxTiles + 1);
         }
-        DEFTET_LAUNCH(k_pix_raster, dim3((P + 255) / 256), dim3(256), st, pb, rb, zb, xb, P, L.grid, L.G2, L.tileStart, L.list,
+        DEFTET_LAUNCH(k_pix_raster, dim3((P + 255) / 256), dim3(256), st, pb, rb, zb, xb, P, L.grid, L.tileStart, L.list,
                       L.wide, L.nWide, F, knum, eps, L.hits, L.nhit);
         DEFTET_LAUNCH(k_pix_emit, dim3((P + 3) / 4), dim3(256), st, L.hits, L.nhit, fb, P, D, knum,
                       out_feat + (size_t)b * P * knum * D, (long long *)out_face + (size_t)b * P * knum, out_w + (size_t)b * P * knum * 3);

@@ -135,7 +135,7 @@ def test_baseline_config_properties(cuda):
     valid = face >= 0
     assert ((face >= -1) & (face < F)).all()
     n = valid.sum(-1)
-    assert n.max().item() == 64 and (n == 0).float().mean().item() > 0.2          # rays through the grid saturate, corners miss
+    assert n.max().item() == 64 and (n == 0).float().mean().item() > 0.01         # rays through the grid saturate, corners miss
     # valid slots form a prefix
     assert (valid[..., 1:] <= valid[..., :-1]).all()
     assert (feat[~valid] == 0).all()

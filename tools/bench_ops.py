@@ -1,0 +1,118 @@
+#!/usr/bin/env python
+"""Secondary measurements for the SURVEY section 8 rows that are not the headline metric:
+builders (A2-A6), surface ops (A8-A10) and the rasterizer (A12), each with its CPU comparator
+(oracle/_ref = the reference's own native code where it exists, else the oracle port).
+Prints one JSON line per op.   python tools/bench_ops.py [--quick]"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from deftet_amd import grids, hip_ops  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+dev = torch.device("cuda:0")
+quick = "--quick" in sys.argv
+
+
+def gpu_time(fn, reps=5, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    return float(np.median(ts))
+
+
+def cpu_time(fn):
+    t0 = time.perf_counter()
+    fn()
+    return time.perf_counter() - t0
+
+
+def emit(**kw):
+    print(json.dumps(kw), flush=True)
+
+
+def main():
+    res = 40 if quick else 70
+    verts, tets = grids.kuhn_grid(res)
+    n_point, T = verts.shape[0], tets.shape[0]
+    tets_d = torch.from_numpy(tets).to(dev)
+    ref = O.RefBuilders() if O.RefBuilders.available() else None
+    for name, g, c_ref, c_port in [
+        ("tet_adj_share", lambda: hip_ops.tet_adj_share(tets_d, n_point, dev), lambda: ref.tet_adj_share(tets, n_point), lambda: O.tet_adj_share(tets, n_point)),
+        ("tet_face_adj", lambda: hip_ops.tet_face_adj(tets_d, n_point, dev), lambda: ref.tet_face_adj(tets, n_point), lambda: O.tet_face_adj(tets, n_point)),
+        ("tet_point_adj", lambda: hip_ops.tet_point_adj(tets_d, n_point, dev), lambda: ref.tet_point_adj(tets, n_point), lambda: O.tet_point_adj(tets, n_point)),
+        ("tet_to_face", lambda: hip_ops.tet_to_face(tets_d, n_point, dev), None, lambda: O.tet_to_face(tets, n_point)),
+    ]:
+        tg = gpu_time(g)
+        kind, tc = ("reference", cpu_time(c_ref)) if (ref is not None and c_ref is not None) else ("port", cpu_time(c_port))
+        emit(op=name, res=res, n_tet=T, gpu_ms=round(tg * 1e3, 3), cpu_ms=round(tc * 1e3, 1), cpu_kind=kind, cpu_cores=1,
+             speedup=round(tc / tg, 1))
+
+    # surface ops on a sphere surface: F boundary faces, P = 100k GT points, N = 20 F queries
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from tests.test_surface_ops_gpu import sphere_surface
+    face = sphere_surface(40 if quick else 70)
+    F = face.shape[0]
+    rng = np.random.default_rng(3000)
+    d = rng.standard_normal((100000, 3))
+    gt = (0.3 * d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    face_d, gt_d = torch.from_numpy(face).to(dev), torch.from_numpy(gt).to(dev)[None]
+    nfb = torch.tensor([float(F)], device=dev)
+    tg = gpu_time(lambda: hip_ops.face_edge_adj(face_d, 30))
+    sub = min(F, 2000)
+    tc = cpu_time(lambda: O.face_edge_adj(face[:sub], 30)) * (F / sub) ** 2
+    emit(op="face_edge_adj", n_face=F, gpu_ms=round(tg * 1e3, 3), cpu_ms=round(tc * 1e3, 1), cpu_kind="port (extrapolated from %d faces, O(F^2))" % sub,
+         cpu_cores=1, pairs_per_s=round(F * F / tg / 1e9, 2), unit="G face pairs/s")
+    tg = gpu_time(lambda: hip_ops.tri_dist_fwd(gt_d, face_d[None], nfb), reps=3)
+    subp = 500
+    tc = cpu_time(lambda: O.tri_dist_fwd(gt[None, :subp], face[None], np.array([F], np.float32))) * (100000 / subp)
+    emit(op="tri_dist_fwd", n_face=F, n_point=100000, gpu_ms=round(tg * 1e3, 3), cpu_ms=round(tc * 1e3, 1),
+         cpu_kind="port (extrapolated from %d points)" % subp, cpu_cores=1, pairs_per_s=round(F * 1e5 / tg / 1e9, 2), unit="G point-triangle pairs/s")
+    dd, ff = hip_ops.tri_dist_fwd(gt_d, face_d[None], nfb)
+    gg = torch.ones_like(dd)
+    tg = gpu_time(lambda: hip_ops.tri_dist_bwd(gt_d, face_d[None], ff, gg))
+    emit(op="tri_dist_bwd", n_face=F, n_point=100000, gpu_ms=round(tg * 1e3, 3))
+    nq = 20 * F
+    q_d = torch.from_numpy(rng.uniform(-0.3, 0.3, (1, nq, 3)).astype(np.float32)).to(dev)
+    tg = gpu_time(lambda: hip_ops.nn_index(q_d, gt_d), reps=3)
+    subq = 200
+    tc = cpu_time(lambda: O.nn_index(q_d[:, :subq].cpu().numpy(), gt[None])) * (nq / subq)
+    emit(op="nn_index", n_query=nq, n_point=100000, gpu_ms=round(tg * 1e3, 3), cpu_ms=round(tc * 1e3, 1),
+         cpu_kind="port (extrapolated from %d queries)" % subq, cpu_cores=1, pairs_per_s=round(nq * 1e5 / tg / 1e9, 2), unit="G distance evals/s")
+
+    # rasterizer, BASELINE configs[4]
+    from tests.test_raster_gpu import pixel_grid, projected_grid
+    from deftet_amd.render import deftet_sparse_render
+    fz, fxy, ffe = projected_grid(40 if quick else 70)
+    npx = 256 if quick else 512
+    pix, rngs = pixel_grid(npx)
+    t = [torch.from_numpy(x).to(dev) for x in (pix, rngs, fz, fxy, ffe)]
+    t[3].requires_grad_(True)
+    t[4].requires_grad_(True)
+    tg = gpu_time(lambda: deftet_sparse_render(*t, knum=64), reps=3)
+    feat, face_i = deftet_sparse_render(*t, knum=64)
+    go = torch.rand_like(feat)
+    tb = gpu_time(lambda: torch.autograd.grad(feat, (t[3], t[4]), go, retain_graph=True), reps=3)
+    subp = 64
+    tc = cpu_time(lambda: O.sparse_render_fwd(pix[:, :subp], rngs[:, :subp], fz, fxy, ffe, knum=64)) * (pix.shape[1] / subp)
+    Fn, Pn = fxy.shape[1], pix.shape[1]
+    emit(op="deftet_sparse_render", n_pixel=Pn, n_face=Fn, knum=64, fwd_ms=round(tg * 1e3, 2), bwd_ms=round(tb * 1e3, 2),
+         cpu_fwd_ms=round(tc * 1e3, 0), cpu_kind="port (brute force, extrapolated from %d pixels)" % subp, cpu_cores=1,
+         nominal_pixel_face_tests_per_s=round(Pn * Fn / tg / 1e9, 1), unit="G pixel-face tests/s (fwd)",
+         hits=int((face_i >= 0).sum().item()), parity="unpinned (Kaolin not in the reference tree)")
+
+
+if __name__ == "__main__":
+    main()
