@@ -257,3 +257,66 @@ def nn_index(queries_bxnx3, points_bxmx3):
         _lib.check(lib.deftet_nn_index_f32(_lib.ptr(q), _lib.ptr(p), _lib.ptr(out), B, N, p.shape[1],
                                            _lib.current_stream(q.device)), "deftet_nn_index_f32")
     return out
+
+
+# --------------------------------------------------------------------------------- A7 / A11
+def boundary_index(tet_face_fx3, tet_idx_fx2, occ_bxn, mode=1):
+    """list of B int64 [Fb_i,3] tensors — DefTet.get_boundary_index (mode 1) /
+    get_internal_index (mode 2), layers/DefTet/deftet.py:186-203."""
+    _lib.require_gpu(tet_face_fx3, tet_idx_fx2, occ_bxn)
+    lib = _lib.load()
+    face = tet_face_fx3.contiguous().long()
+    tidx = tet_idx_fx2.contiguous().long()
+    occ = _f32c(occ_bxn)
+    B, T = occ.shape
+    Fi = face.shape[0]
+    dev = occ.device
+    out = torch.empty(max(B * Fi, 1), 3, dtype=torch.int64, device=dev)
+    offs = torch.zeros(B + 1, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        ws = _lib.workspace(dev, lib.deftet_boundary_index_workspace_bytes(B, Fi))
+        _lib.check(lib.deftet_boundary_index_i64(_lib.ptr(face), _lib.ptr(tidx), _lib.ptr(occ), _lib.ptr(out), _lib.ptr(offs),
+                                                 B, T, Fi, mode, _lib.ptr(ws), ws.numel(), _lib.current_stream(dev)),
+                   "deftet_boundary_index_i64")
+    o = offs.tolist()                                   # one sync (the reference syncs once per shape)
+    return [out[o[b]:o[b + 1]] for b in range(B)]
+
+
+class _TetEnergies(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tet_bxfx4x3, inverse_v, pow_v, pow_e, scale):
+        _lib.require_gpu(tet_bxfx4x3, inverse_v)
+        lib = _lib.load()
+        tet = _f32c(tet_bxfx4x3)
+        inv = _f32c(inverse_v) if inverse_v is not None else None
+        B, T = tet.shape[0], tet.shape[1]
+        dev = tet.device
+        out = torch.empty(B, 3, device=dev, dtype=torch.float32)
+        stats = torch.empty(B, 8, device=dev, dtype=torch.float64)
+        with torch.cuda.device(dev):
+            ws = _lib.workspace(dev, lib.deftet_tet_energies_workspace_bytes(B))
+            _lib.check(lib.deftet_tet_energies_fwd_f32(_lib.ptr(tet), _lib.ptr(inv), _lib.ptr(out), _lib.ptr(stats), B, T,
+                                                       int(pow_v), int(pow_e), float(scale), _lib.ptr(ws), ws.numel(),
+                                                       _lib.current_stream(dev)), "deftet_tet_energies_fwd_f32")
+        ctx.save_for_backward(tet, inv if inv is not None else tet.new_empty(0), stats)
+        ctx.cfg = (int(pow_v), int(pow_e), float(scale), inv is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        tet, inv, stats = ctx.saved_tensors
+        pow_v, pow_e, scale, has_inv = ctx.cfg
+        lib = _lib.load()
+        g = _f32c(grad_out)
+        B, T = tet.shape[0], tet.shape[1]
+        grad_tet = torch.empty_like(tet)
+        with torch.cuda.device(tet.device):
+            _lib.check(lib.deftet_tet_energies_bwd_f32(_lib.ptr(tet), _lib.ptr(inv) if has_inv else None, _lib.ptr(stats),
+                                                       _lib.ptr(g), _lib.ptr(grad_tet), B, T, pow_v, pow_e, scale,
+                                                       _lib.current_stream(tet.device)), "deftet_tet_energies_bwd_f32")
+        return grad_tet, None, None, None, None
+
+
+def tet_energies(tet_bxfx4x3, inverse_v=None, pow_v=4, pow_e=4, scale=20.0):
+    """f32 [B,3] = (volume_variance, amips_energy, edge_length) — differentiable w.r.t. tet."""
+    return _TetEnergies.apply(tet_bxfx4x3, inverse_v, pow_v, pow_e, scale)

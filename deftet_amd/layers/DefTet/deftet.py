@@ -1,0 +1,78 @@
+"""`DefTet` geometry module with the reference's method names and signatures
+(/root/reference/layers/DefTet/deftet.py), HIP-backed for the per-tetrahedron pieces:
+
+    get_boundary_index / get_internal_index   (:186-203)  -> deftet_boundary_index_i64
+    paste_occ                                 (:132-136)  -> deftet_paste_occ_*_f32
+    volume_variance / amips_energy / edge_length (:239-338) -> deftet_tet_energies_*_f32
+    tet_inverse_v / my_inverse                (:205-233,:300-318)  torch (init-time, T 3x3 inverses)
+    point queries                             (:110-112)  -> check_condition_f_base
+
+`forward_surface_align` itself is not provided: it needs the ground-truth occupancy of tet
+centroids from kaolin.ops.mesh.check_sign (:33-49), which is third-party and outside this
+build's scope; the pieces it composes are all here or in
+deftet_amd.layers / deftet_amd.utils.
+"""
+import torch
+import torch.nn as nn
+
+from deftet_amd import hip_ops
+from deftet_amd.layers.DefTet.check_condition_tetrahedron_base.utils import check_condition_f_base, paste_occ
+
+EPS = 1e-10
+
+
+class DefTet(nn.Module):
+    def __init__(self, device=None):
+        super(DefTet, self).__init__()
+        self.pow = 4
+        self.device = device
+        self.features_fixed = False
+        self.z_window_radius = 0.025
+        self.inverse_v = None
+
+    # --- A7
+    def get_boundary_index(self, tet_face_fx3, tet_idx_fx2, occ_bxn):
+        return hip_ops.boundary_index(tet_face_fx3, tet_idx_fx2, occ_bxn, mode=1)
+
+    def get_internal_index(self, tet_face_fx3, tet_idx_fx2, occ_bxn):
+        return hip_ops.boundary_index(tet_face_fx3, tet_idx_fx2, occ_bxn, mode=2)
+
+    # --- A1 / A1b
+    def check_condition(self, tet_bxfx4x3, point_pos_bxpx3):
+        return check_condition_f_base(tet_bxfx4x3, point_pos_bxpx3)
+
+    def paste_occ(self, pred_tet_occ, condition):
+        return paste_occ(pred_tet_occ, condition)
+
+    # --- A11 (each call evaluates the fused kernel and returns its own component)
+    def volume_variance(self, tet_bxfx4x3, base_area_mask=None, area_normalize=(20, 20), pow=2, center_occ=None):
+        return hip_ops.tet_energies(tet_bxfx4x3, None, pow_v=pow, pow_e=self.pow)[:, 0]
+
+    def amips_energy(self, tet_bxfx4x3, inverse_v, scale=20, center_occ=None, square=False):
+        e = hip_ops.tet_energies(tet_bxfx4x3, inverse_v, pow_v=self.pow, pow_e=self.pow, scale=scale)[:, 1]
+        if square:
+            raise NotImplementedError("square=True is never used by the reference (deftet.py:286-287)")
+        return e
+
+    def edge_length(self, tet_bxfx4x3, pow=2):
+        return hip_ops.tet_energies(tet_bxfx4x3, None, pow_v=self.pow, pow_e=pow, scale=20)[:, 2]
+
+    def energies(self, tet_bxfx4x3, inverse_v):
+        """(volume_variance, amips_energy, edge_length) from ONE fused evaluation — what
+        forward_surface_align (:82-83,:105) needs per step."""
+        out = hip_ops.tet_energies(tet_bxfx4x3, inverse_v, pow_v=self.pow, pow_e=self.pow, scale=20.0)
+        return out[:, 0], out[:, 1], out[:, 2]
+
+    # --- init-time helpers (pure torch, as in the reference)
+    def my_inverse(self, T):
+        det_m = (torch.abs(torch.det(T)) < 1e-10).float()                     # :215
+        iden_m = torch.eye(T.shape[-1], dtype=torch.float, device=T.device).unsqueeze(0).expand(T.shape[0], -1, -1)
+        tmp_m = T * (1 - det_m.unsqueeze(-1).unsqueeze(-1)) + iden_m * det_m.unsqueeze(-1).unsqueeze(-1)
+        return torch.inverse(tmp_m), 1 - det_m
+
+    def tet_inverse_v(self, init_tet_pos, init_tet_fx4, scale=20):
+        vertice_pos = init_tet_pos.float()
+        tet = vertice_pos[init_tet_fx4.long()]                                 # [T,4,3]
+        A, B, C, D = (tet[:, i:i + 1, :] * scale for i in range(4))
+        offset_vec = torch.cat([B - A, C - A, D - A], dim=1)                   # :316
+        return self.my_inverse(offset_vec)[0]

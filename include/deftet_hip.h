@@ -134,6 +134,26 @@ int deftet_tet_to_face_i32(const int32_t *tet_list, int64_t *face_fx3, int64_t *
                            void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------
+ * A7  DefTet.get_boundary_index (mode 1) / get_internal_index (mode 2), layers/DefTet/deftet.py:186-203.
+ * face_fx3, tetidx_fx2 int64 (tet_to_face outputs), occ f32 [B,T].  out_rows int64 [B*F,3] receives
+ * the selected faces of all shapes back to back in row-major mask order (boundary faces flipped
+ * when the first tet is the occupied one); offsets int32 [B+1] (device) = start row of every shape. */
+size_t deftet_boundary_index_workspace_bytes(int n_batch, int n_face);
+int deftet_boundary_index_i64(const int64_t *face_fx3, const int64_t *tetidx_fx2, const float *occ_bxt,
+                              int64_t *out_rows, int32_t *offsets, int n_batch, int n_tet, int n_face, int mode,
+                              void *workspace, size_t workspace_bytes, void *stream);
+
+/* A11 fused per-tet energies, layers/DefTet/deftet.py:239-338: out f32 [B,3] =
+ * {volume_variance(pow_v), amips_energy(inv_v f32 [T,3,3]; 0 when NULL), edge_length(pow_e)};
+ * stats f64 [B,8] is produced by the forward and consumed by the backward, which writes
+ * grad_tet f32 [B,T,4,3] = sum_k grad_out[b,k] * d out[b,k] / d tet (fully overwritten). */
+size_t deftet_tet_energies_workspace_bytes(int n_batch);
+int deftet_tet_energies_fwd_f32(const float *tet, const float *inv_v, float *out, double *stats, int n_batch, int n_tet,
+                                int pow_v, int pow_e, float scale, void *workspace, size_t workspace_bytes, void *stream);
+int deftet_tet_energies_bwd_f32(const float *tet, const float *inv_v, const double *stats, const float *grad_out,
+                                float *grad_tet, int n_batch, int n_tet, int pow_v, int pow_e, float scale, void *stream);
+
+/* ---------------------------------------------------------------------------------
  * A8  surface-face edge adjacency by position
  * replaces layers/DefTet/tet_face_adj_m_idx/tet_face_adj_m.cpp (forward) ->
  *          tet_face_adj_m_for.cu:72-130.  adj f32 [F,n_max_nei] pre-filled with -1 by the
