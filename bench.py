@@ -49,12 +49,11 @@ def make_inputs(rank, device, res=RES, n_query=N_QUERY, batch=BATCH):
 
 
 def step(d, world):
+    """fwd: index + weights + fused paste_occ gather; bwd: dL/dtet and dL/dpred from one
+    per-tet gather pass; then the per-shape loss scalars (all-gathered when world > 1)."""
     from deftet_amd import hip_ops, sharding
-    cond, w = hip_ops.point_in_tet(d["tet"], d["pts"], want_bary=True)
-    cond_c = cond.clone()                       # train_multigpu.py:383 pastes into a clone
-    occ = hip_ops.paste_occ_fwd(d["pred"], cond_c)
-    g_tet, _ = hip_ops.point_in_tet_bwd(d["tet"], d["pts"], cond, d["gw"])
-    g_pred = hip_ops.paste_occ_bwd(cond_c, d["gout"], d["tet"].shape[1])
+    cond, w, occ = hip_ops.point_in_tet(d["tet"], d["pts"], want_bary=True, pred_bxt=d["pred"])
+    g_tet, _, g_pred = hip_ops.point_in_tet_bwd(d["tet"], d["pts"], cond, d["gw"], grad_occ=d["gout"])
     loss = hip_ops.rowdot(w, d["gw"]) + hip_ops.rowdot(occ, d["gout"])         # [B] per-shape loss scalars
     if world > 1:
         loss = sharding.all_gather_losses(loss, world * loss.shape[0])        # the only collective (RCCL)

@@ -214,23 +214,37 @@ __global__ __launch_bounds__(256) void k_query_bbox(const float *__restrict__ pt
 }
 
 // cell id + rank inside the cell for every regular query
+constexpr int kBinPer = 4;     // queries per thread: returning atomics are latency-bound, keep 4 in flight per lane
+
 __global__ __launch_bounds__(256) void k_query_bin(const float *__restrict__ pts, int Q, const float *__restrict__ gparam,
                                                    int G, int Gx, long long cellStride, int *cells, int2 *qcell)
 {
     const int b = blockIdx.y;
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= Q) return;
     const Grid g = load_grid(gparam + b * 12);
-    const float *p = pts + ((size_t)b * Q + q) * 3;
-    float x = p[0], y = p[1], z = p[2];
-    int2 r = make_int2(-1, 0);
-    if (query_regular(x, y, z)) {
-        int cx = cell_of(x, g.o[0], g.inv[0], Gx), cy = cell_of(y, g.o[1], g.inv[1], G), cz = cell_of(z, g.o[2], g.inv[2], G);
-        int c = (cz * G + cy) * Gx + cx;
-        r.x = c;
-        r.y = atomicAdd(&cells[(size_t)b * cellStride + c], 1);
+    const int q0 = blockIdx.x * (256 * kBinPer) + threadIdx.x;
+    int cell[kBinPer];
+#pragma unroll
+    for (int k = 0; k < kBinPer; ++k) {
+        const int q = q0 + k * 256;
+        cell[k] = -1;
+        if (q < Q) {
+            const float *p = pts + ((size_t)b * Q + q) * 3;
+            const float x = p[0], y = p[1], z = p[2];
+            if (query_regular(x, y, z)) {
+                const int cx = cell_of(x, g.o[0], g.inv[0], Gx), cy = cell_of(y, g.o[1], g.inv[1], G),
+                          cz = cell_of(z, g.o[2], g.inv[2], G);
+                cell[k] = (cz * G + cy) * Gx + cx;
+            }
+        }
     }
-    qcell[(size_t)b * Q + q] = r;
+    int rank[kBinPer];
+#pragma unroll
+    for (int k = 0; k < kBinPer; ++k) rank[k] = cell[k] >= 0 ? atomicAdd(&cells[(size_t)b * cellStride + cell[k]], 1) : 0;
+#pragma unroll
+    for (int k = 0; k < kBinPer; ++k) {
+        const int q = q0 + k * 256;
+        if (q < Q) qcell[(size_t)b * Q + q] = make_int2(cell[k], rank[k]);
+    }
 }
 
 // exclusive scan inside chunks of kChunk cells; chunk totals to chunkTot
@@ -414,7 +428,7 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan(const float *__rest
 }
 
 // irregular tets x all queries
-__global__ __launch_bounds__(256) void k_irreg_tets(const float *__restrict__ tet, const float *__restrict__ pts, int T,
+__device__ __forceinline__ void irreg_tets_body(const float *__restrict__ tet, const float *__restrict__ pts, int T,
                                                     int Q, const int *__restrict__ counters,
                                                     const int *__restrict__ irregT, int *result)
 {
@@ -440,7 +454,7 @@ __global__ __launch_bounds__(256) void k_irreg_tets(const float *__restrict__ te
 }
 
 // irregular queries x all tets
-__global__ __launch_bounds__(256) void k_irreg_queries(const float *__restrict__ tet, const float *__restrict__ pts,
+__device__ __forceinline__ void irreg_queries_body(const float *__restrict__ tet, const float *__restrict__ pts,
                                                        int T, int Q, const int *__restrict__ counters,
                                                        const int *__restrict__ irregQ, int *result)
 {
@@ -462,6 +476,16 @@ __global__ __launch_bounds__(256) void k_irreg_queries(const float *__restrict__
     }
 }
 
+// both irregular side paths in one launch: blockIdx.z == 0 -> irregular tets x all queries,
+// blockIdx.z == 1 -> irregular queries x all tets (both return at once when their list is empty)
+__global__ __launch_bounds__(256) void k_irreg(const float *__restrict__ tet, const float *__restrict__ pts, int T, int Q,
+                                               const int *__restrict__ counters, const int *__restrict__ irregT,
+                                               const int *__restrict__ irregQ, int *result)
+{
+    if (blockIdx.z == 0) irreg_tets_body(tet, pts, T, Q, counters, irregT, result);
+    else irreg_queries_body(tet, pts, T, Q, counters, irregQ, result);
+}
+
 // barycentric weights, utils/tet_utils.py:25-45 (same association as the torch expression)
 __device__ __forceinline__ float triple(const float *a, const float *b, const float *c)
 {
@@ -472,7 +496,8 @@ __device__ __forceinline__ float triple(const float *a, const float *b, const fl
 }
 
 __global__ __launch_bounds__(256) void k_finalize(const float *__restrict__ tet, const float *__restrict__ pts, int T,
-                                                  int Q, const int *__restrict__ result, float *cond, float *bary)
+                                                  int Q, const int *__restrict__ result, float *cond, float *bary,
+                                                  const float *__restrict__ pred, float *occ)
 {
     const int b = blockIdx.y;
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
@@ -481,6 +506,7 @@ __global__ __launch_bounds__(256) void k_finalize(const float *__restrict__ tet,
     const int r = result[i];
     const bool hit = r != kMiss;
     cond[i] = hit ? (float)r : -1.0f;                               // :177, :149
+    if (occ) occ[i] = pred[(size_t)b * T + (hit ? r : 0)];          // paste_occ: misses alias tet 0 (deftet.py:133-135)
     if (!bary) return;
     float4 wq = make_float4(0.f, 0.f, 0.f, 0.f);
     if (hit) {
@@ -627,20 +653,51 @@ __global__ __launch_bounds__(256) void k_bary_bwd(const float *__restrict__ tet,
 // tet into a linked list (ONE returning atomicExch per hit), then one lane per tet walks its
 // list, accumulates the 12 partials in registers and stores its 48-byte gradient record
 // once, coalesced.  No memset of grad_tet is needed: every tet is written.
-__global__ __launch_bounds__(256) void k_hit_link(const float *__restrict__ cond, int T, int Q, int *head, int *next)
+constexpr int kLinkPer = 4;    // queries per thread (returning atomicExch: keep 4 in flight per lane)
+
+// gocc != NULL: additionally sum the paste_occ gradient of the MISSES (they alias tet 0,
+// deftet.py:133) per shape into missSum[b] — one atomic per workgroup.
+__global__ __launch_bounds__(256) void k_hit_link(const float *__restrict__ cond, int T, int Q, int *head, int *next,
+                                                  const float *__restrict__ gocc, float *missSum)
 {
+    __shared__ float wsum[4];
     const int b = blockIdx.y;
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= Q) return;
-    const size_t i = (size_t)b * Q + q;
-    const float c = cond[i];
-    if (c >= 0.f) next[i] = atomicExch(&head[(size_t)b * T + (int)c], q);
+    const int q0 = blockIdx.x * (256 * kLinkPer) + threadIdx.x;
+    int tgt[kLinkPer];
+    float gm = 0.f;
+#pragma unroll
+    for (int k = 0; k < kLinkPer; ++k) {
+        const int q = q0 + k * 256;
+        tgt[k] = -1;
+        if (q < Q) {
+            const float c = cond[(size_t)b * Q + q];
+            if (c >= 0.f) tgt[k] = (int)c;
+            else if (gocc) gm += gocc[(size_t)b * Q + q];
+        }
+    }
+    int prev[kLinkPer];
+#pragma unroll
+    for (int k = 0; k < kLinkPer; ++k) prev[k] = tgt[k] >= 0 ? atomicExch(&head[(size_t)b * T + tgt[k]], q0 + k * 256) : -1;
+#pragma unroll
+    for (int k = 0; k < kLinkPer; ++k)
+        if (tgt[k] >= 0) next[(size_t)b * Q + q0 + k * 256] = prev[k];
+    if (gocc) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) gm += __shfl_xor(gm, off);
+        if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = gm;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float tot = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+            if (tot != 0.f) unsafeAtomicAdd(&missSum[b], tot);
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void k_bary_bwd_gather(const float *__restrict__ tet, const float *__restrict__ pts,
                                                          const float *__restrict__ grad_w, const int *__restrict__ head,
                                                          const int *__restrict__ next, int T, int Q, float *grad_tet,
-                                                         float *grad_pts, int accumulate)
+                                                         float *grad_pts, int accumulate, const float *__restrict__ gocc,
+                                                         const float *__restrict__ missSum, float *grad_pred)
 {
     const int b = blockIdx.y;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -649,6 +706,7 @@ __global__ __launch_bounds__(256) void k_bary_bwd_gather(const float *__restrict
 #pragma unroll
     for (int k = 0; k < 12; ++k) acc[k] = 0.f;
     int q = head[(size_t)b * T + t];
+    float gp = (grad_pred && t == 0) ? missSum[b] : 0.f;             // clamped misses paste from tet 0
     if (q >= 0) {
         const float4 *src = reinterpret_cast<const float4 *>(tet + ((size_t)b * T + t) * 12);
         float4 t0 = src[0], t1 = src[1], t2 = src[2];
@@ -686,9 +744,11 @@ __global__ __launch_bounds__(256) void k_bary_bwd_gather(const float *__restrict
 #pragma unroll
                 for (int k = 0; k < 3; ++k) acc[vtx * 3 + k] += -w[vtx] * G3[k];
             if (grad_pts) { grad_pts[i * 3] = G3[0]; grad_pts[i * 3 + 1] = G3[1]; grad_pts[i * 3 + 2] = G3[2]; }
+            if (grad_pred) gp += gocc[i];
             q = qn;
         }
     }
+    if (grad_pred) grad_pred[(size_t)b * T + t] = accumulate ? grad_pred[(size_t)b * T + t] + gp : gp;
     float4 *dst = reinterpret_cast<float4 *>(grad_tet + ((size_t)b * T + t) * 12);
     float4 o0 = make_float4(acc[0], acc[1], acc[2], acc[3]), o1 = make_float4(acc[4], acc[5], acc[6], acc[7]),
            o2 = make_float4(acc[8], acc[9], acc[10], acc[11]);
@@ -806,9 +866,12 @@ extern "C" size_t deftet_point_in_tet_workspace_bytes(int B, int T, int Q, int a
     return make_layout(B, T, Q, algo, nullptr, 0).bytes;
 }
 
-extern "C" int deftet_point_in_tet_f32(const float *tet, const float *pts, float *cond, float *bary, int B, int T, int Q,
-                                       int algo, void *workspace, size_t workspace_bytes, void *stream_)
+extern "C" int deftet_point_in_tet_f32(const float *tet, const float *pts, float *cond, float *bary, const float *pred,
+                                       float *occ, int B, int T, int Q, int algo, void *workspace, size_t workspace_bytes,
+                                       void *stream_)
 {
+    DEFTET_CHECK_ARG((pred == nullptr) == (occ == nullptr), "pred and occ must be given together");
+    DEFTET_CHECK_ARG(!occ || T > 0, "paste_occ needs at least one tet");
     DEFTET_CHECK_ARG(B >= 0 && T >= 0 && Q >= 0, "negative size (B=%d T=%d Q=%d)", B, T, Q);
     DEFTET_CHECK_ARG(algo == DEFTET_PIT_AUTO || algo == DEFTET_PIT_BRUTE, "unknown algo %d", algo);
     if (T >= (1 << 24)) return set_error(DEFTET_ELIMIT, "n_tet=%d does not fit a float-encoded index (2^24)", T);
@@ -839,7 +902,7 @@ extern "C" int deftet_point_in_tet_f32(const float *tet, const float *pts, float
         DEFTET_LAUNCH(k_init, dim3(ib), blk, st, L.counters, L.cells, L.result, B, nCells, nQ);
         DEFTET_LAUNCH(k_query_bbox, dim3(kBoxBlocks, B), blk, st, pts, Q, L.bboxPart, L.counters, L.irregQ);
         DEFTET_LAUNCH(k_grid_params, dim3(B), dim3(64), st, L.bboxPart, kBoxBlocks, L.G, L.Gx, L.gparam);
-        DEFTET_LAUNCH(k_query_bin, gq, blk, st, pts, Q, L.gparam, L.G, L.Gx, L.cellStride, L.cells, L.qcell);
+        DEFTET_LAUNCH(k_query_bin, dim3((Q + 256 * kBinPer - 1) / (256 * kBinPer), B), blk, st, pts, Q, L.gparam, L.G, L.Gx, L.cellStride, L.cells, L.qcell);
         DEFTET_LAUNCH(k_scan_chunks, dim3(L.nChunk, B), blk, st, L.cells, L.cellStride, L.nChunk, L.chunkTot);
         DEFTET_LAUNCH(k_scan_apply, dim3(L.nChunk, B), blk, st, L.cells, L.cellStride, L.nChunk, L.chunkTot);
         DEFTET_LAUNCH(k_query_scatter, gq, blk, st, pts, Q, L.qcell, L.cells, L.cellStride, L.sortedQ);
@@ -849,32 +912,35 @@ extern "C" int deftet_point_in_tet_f32(const float *tet, const float *pts, float
             int qb = (Q + 255) / 256, tb = (T + 255) / 256;
             if (qb > 1024) qb = 1024;
             if (tb > 1024) tb = 1024;
-            DEFTET_LAUNCH(k_irreg_tets, dim3(qb, B), blk, st, tet, pts, T, Q, L.counters, L.irregT, L.result);
-            DEFTET_LAUNCH(k_irreg_queries, dim3(tb, B), blk, st, tet, pts, T, Q, L.counters, L.irregQ, L.result);
+            DEFTET_LAUNCH(k_irreg, dim3(qb > tb ? qb : tb, B, 2), blk, st, tet, pts, T, Q, L.counters, L.irregT, L.irregQ, L.result);
         }
     }
-    DEFTET_LAUNCH(k_finalize, gq, blk, st, tet, pts, T, Q, L.result, cond, bary);
+    DEFTET_LAUNCH(k_finalize, gq, blk, st, tet, pts, T, Q, L.result, cond, bary, pred, occ);
     return DEFTET_OK;
 }
 
 extern "C" size_t deftet_point_in_tet_bwd_workspace_bytes(int B, int T, int Q)
 {
     if (B <= 0 || T < 0 || Q < 0) return 0;
-    return align_up((size_t)B * T * 4, 256) + align_up((size_t)B * Q * 4, 256);
+    return align_up((size_t)B * T * 4, 256) + align_up((size_t)B * Q * 4, 256) + align_up((size_t)B * 4, 256);
 }
 
 extern "C" int deftet_point_in_tet_bwd_f32(const float *tet, const float *pts, const float *cond, const float *grad_w,
-                                           float *grad_tet, float *grad_pts, int B, int T, int Q, int accumulate,
-                                           void *workspace, size_t workspace_bytes, void *stream_)
+                                           float *grad_tet, float *grad_pts, const float *grad_occ, float *grad_pred, int B,
+                                           int T, int Q, int accumulate, void *workspace, size_t workspace_bytes, void *stream_)
 {
     DEFTET_CHECK_ARG(B >= 0 && T >= 0 && Q >= 0, "negative size");
     DEFTET_CHECK_ARG(B <= 65535, "n_batch=%d exceeds 65535", B);
+    DEFTET_CHECK_ARG((grad_occ == nullptr) == (grad_pred == nullptr), "grad_occ and grad_pred must be given together");
     hipStream_t st = as_stream(stream_);
     if (B == 0 || T == 0) return DEFTET_OK;
     DEFTET_CHECK_ARG(grad_tet && ((uintptr_t)grad_tet & 15) == 0, "grad_tet null or not 16-byte aligned");
     if (grad_pts && Q > 0) DEFTET_HIP(hipMemsetAsync(grad_pts, 0, (size_t)B * Q * 12, st));
     if (Q == 0) {
-        if (!accumulate) DEFTET_HIP(hipMemsetAsync(grad_tet, 0, (size_t)B * T * 48, st));
+        if (!accumulate) {
+            DEFTET_HIP(hipMemsetAsync(grad_tet, 0, (size_t)B * T * 48, st));
+            if (grad_pred) DEFTET_HIP(hipMemsetAsync(grad_pred, 0, (size_t)B * T * 4, st));
+        }
         return DEFTET_OK;
     }
     DEFTET_CHECK_ARG(tet && pts && cond && grad_w, "null pointer");
@@ -883,17 +949,25 @@ extern "C" int deftet_point_in_tet_bwd_f32(const float *tet, const float *pts, c
         const size_t need = deftet_point_in_tet_bwd_workspace_bytes(B, T, Q);
         DEFTET_CHECK_ARG(workspace_bytes >= need && ((uintptr_t)workspace & 255) == 0,
                          "backward workspace too small (%zu < %zu) or misaligned", workspace_bytes, need);
-        int *head = static_cast<int *>(workspace);
-        int *next = reinterpret_cast<int *>(static_cast<char *>(workspace) + align_up((size_t)B * T * 4, 256));
+        char *w = static_cast<char *>(workspace);
+        int *head = reinterpret_cast<int *>(w);
+        int *next = reinterpret_cast<int *>(w + align_up((size_t)B * T * 4, 256));
+        float *missSum = reinterpret_cast<float *>(w + align_up((size_t)B * T * 4, 256) + align_up((size_t)B * Q * 4, 256));
         DEFTET_HIP(hipMemsetAsync(head, 0xFF, (size_t)B * T * 4, st));      // -1 = empty list
-        DEFTET_LAUNCH(k_hit_link, dim3((Q + 255) / 256, B), dim3(256), st, cond, T, Q, head, next);
+        if (grad_pred) DEFTET_HIP(hipMemsetAsync(missSum, 0, (size_t)B * 4, st));
+        DEFTET_LAUNCH(k_hit_link, dim3((Q + 256 * kLinkPer - 1) / (256 * kLinkPer), B), dim3(256), st, cond, T, Q, head, next,
+                      grad_occ, missSum);
         DEFTET_LAUNCH(k_bary_bwd_gather, dim3((T + 255) / 256, B), dim3(256), st, tet, pts, grad_w, head, next, T, Q,
-                      grad_tet, grad_pts, accumulate);
+                      grad_tet, grad_pts, accumulate, grad_occ, missSum, grad_pred);
     } else {
         // no workspace: atomic scatter (slow on this chip; kept for callers that cannot provide one)
         if (!accumulate) DEFTET_HIP(hipMemsetAsync(grad_tet, 0, (size_t)B * T * 48, st));
         DEFTET_LAUNCH(k_bary_bwd, dim3((Q + 255) / 256, B), dim3(256), st, tet, pts, cond, grad_w, T, Q, grad_tet,
                       grad_pts);
+        if (grad_pred) {
+            if (!accumulate) DEFTET_HIP(hipMemsetAsync(grad_pred, 0, (size_t)B * T * 4, st));
+            DEFTET_LAUNCH(k_paste_bwd, dim3((Q + 255) / 256, B), dim3(256), st, cond, grad_occ, grad_pred, T, Q);
+        }
     }
     return DEFTET_OK;
 }

@@ -18,10 +18,12 @@ def _f32c(t):
 
 
 # --------------------------------------------------------------------------------- A1
-def point_in_tet(tet_bxtx4x3, pts_bxqx3, want_bary=False, algo=PIT_AUTO):
-    """cond f32 [B,Q,1] (lowest containing tet index or -1) and optionally the
-    barycentric weights f32 [B,Q,4] of the hit tet."""
-    _lib.require_gpu(tet_bxtx4x3, pts_bxqx3)
+def point_in_tet(tet_bxtx4x3, pts_bxqx3, want_bary=False, algo=PIT_AUTO, pred_bxt=None):
+    """cond f32 [B,Q,1] (lowest containing tet index or -1); with want_bary also the barycentric
+    weights f32 [B,Q,4] of the hit tet; with pred_bxt also occ f32 [B,Q] = the fused
+    DefTet.paste_occ gather pred[b, max(index, 0)].  Returns cond | (cond, bary) | (cond, bary, occ)
+    | (cond, occ) depending on what was asked for."""
+    _lib.require_gpu(tet_bxtx4x3, pts_bxqx3, pred_bxt)
     lib = _lib.load()
     tet, pts = _f32c(tet_bxtx4x3), _f32c(pts_bxqx3)
     if tet.dim() != 4 or tet.shape[2:] != (4, 3):
@@ -32,29 +34,40 @@ def point_in_tet(tet_bxtx4x3, pts_bxqx3, want_bary=False, algo=PIT_AUTO):
     dev = pts.device
     cond = torch.empty(B, Q, 1, device=dev, dtype=torch.float32)
     bary = torch.empty(B, Q, 4, device=dev, dtype=torch.float32) if want_bary else None
+    pred = _f32c(pred_bxt) if pred_bxt is not None else None
+    if pred is not None and pred.shape != (B, T):
+        raise RuntimeError("pred_tet_occ must be [B,T], got %s" % (tuple(pred.shape),))
+    occ = torch.empty(B, Q, device=dev, dtype=torch.float32) if pred is not None else None
     with torch.cuda.device(dev):
         nbytes = lib.deftet_point_in_tet_workspace_bytes(B, T, Q, algo)
         ws = _lib.workspace(dev, nbytes)
-        _lib.check(lib.deftet_point_in_tet_f32(_lib.ptr(tet), _lib.ptr(pts), _lib.ptr(cond), _lib.ptr(bary), B, T, Q,
-                                               algo, _lib.ptr(ws), ws.numel(), _lib.current_stream(dev)),
-                   "deftet_point_in_tet_f32")
-    return (cond, bary) if want_bary else cond
+        _lib.check(lib.deftet_point_in_tet_f32(_lib.ptr(tet), _lib.ptr(pts), _lib.ptr(cond), _lib.ptr(bary), _lib.ptr(pred),
+                                               _lib.ptr(occ), B, T, Q, algo, _lib.ptr(ws), ws.numel(),
+                                               _lib.current_stream(dev)), "deftet_point_in_tet_f32")
+    out = (cond,) + ((bary,) if want_bary else ()) + ((occ,) if pred is not None else ())
+    return out if len(out) > 1 else cond
 
 
-def point_in_tet_bwd(tet_bxtx4x3, pts_bxqx3, cond, grad_w, want_grad_pts=False):
-    _lib.require_gpu(tet_bxtx4x3, pts_bxqx3, cond, grad_w)
+def point_in_tet_bwd(tet_bxtx4x3, pts_bxqx3, cond, grad_w, want_grad_pts=False, grad_occ=None):
+    """(grad_tet [B,T,4,3], grad_pts [B,Q,3] | None) and, when grad_occ [B,Q] is given, also
+    grad_pred [B,T] (fused paste_occ backward)."""
+    _lib.require_gpu(tet_bxtx4x3, pts_bxqx3, cond, grad_w, grad_occ)
     lib = _lib.load()
     tet, pts, cond, gw = _f32c(tet_bxtx4x3), _f32c(pts_bxqx3), _f32c(cond), _f32c(grad_w)
     B, T, Q = tet.shape[0], tet.shape[1], pts.shape[1]
     dev = pts.device
     grad_tet = torch.empty_like(tet)
     grad_pts = torch.empty_like(pts) if want_grad_pts else None
+    go = _f32c(grad_occ) if grad_occ is not None else None
+    grad_pred = torch.empty(B, T, device=dev, dtype=torch.float32) if go is not None else None
     with torch.cuda.device(dev):
         ws = _lib.workspace(dev, lib.deftet_point_in_tet_bwd_workspace_bytes(B, T, Q))
         _lib.check(lib.deftet_point_in_tet_bwd_f32(_lib.ptr(tet), _lib.ptr(pts), _lib.ptr(cond), _lib.ptr(gw),
-                                                   _lib.ptr(grad_tet), _lib.ptr(grad_pts), B, T, Q, 0,
-                                                   _lib.ptr(ws), ws.numel(), _lib.current_stream(dev)),
+                                                   _lib.ptr(grad_tet), _lib.ptr(grad_pts), _lib.ptr(go), _lib.ptr(grad_pred),
+                                                   B, T, Q, 0, _lib.ptr(ws), ws.numel(), _lib.current_stream(dev)),
                    "deftet_point_in_tet_bwd_f32")
+    if go is not None:
+        return grad_tet, grad_pts, grad_pred
     return grad_tet, grad_pts
 
 

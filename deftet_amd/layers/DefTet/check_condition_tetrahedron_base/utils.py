@@ -55,6 +55,30 @@ class PointInTetBary(Function):
 point_in_tet_bary = PointInTetBary.apply
 
 
+class PointInTetOcc(Function):
+    """Fused A1 + A1b + paste_occ: (tet [B,T,4,3], pts [B,Q,3], pred_tet_occ [B,T]) ->
+    (condition [B,Q,1], weights [B,Q,4], occ [B,Q]).  One forward (the paste gather rides in
+    the finalize kernel) and one backward (grad_tet and grad_pred come out of the same per-tet
+    gather pass, no floating-point atomics).  `condition` keeps its -1 entries."""
+
+    @staticmethod
+    def forward(ctx, tet_bxfx4x3, point_pos_bxnx3, pred_tet_occ):
+        cond, w, occ = hip_ops.point_in_tet(tet_bxfx4x3, point_pos_bxnx3, want_bary=True, pred_bxt=pred_tet_occ)
+        ctx.save_for_backward(tet_bxfx4x3, point_pos_bxnx3, cond)
+        ctx.mark_non_differentiable(cond)
+        return cond, w, occ
+
+    @staticmethod
+    def backward(ctx, _grad_cond, grad_w, grad_occ):
+        tet, pts, cond = ctx.saved_tensors
+        g_tet, g_pts, g_pred = hip_ops.point_in_tet_bwd(tet, pts, cond, grad_w, want_grad_pts=ctx.needs_input_grad[1],
+                                                        grad_occ=grad_occ)
+        return (g_tet if ctx.needs_input_grad[0] else None), g_pts, (g_pred if ctx.needs_input_grad[2] else None)
+
+
+point_in_tet_occ = PointInTetOcc.apply
+
+
 class PasteOcc(Function):
     """DefTet.paste_occ (layers/DefTet/deftet.py:132-136) as one fused gather with its
     scatter-add backward; `condition` is clamped in place like the reference does."""

@@ -57,9 +57,12 @@ int deftet_profile_read(double *total_ms, long long *count);
  *      agree (check_condition_tet_for.cu:172-178), else -1;  fully overwritten.
  * bary f32 [B,Q,4] or NULL: barycentric weights of the hit tet by the formula of
  *      utils/tet_utils.py:28-45 (zeros for misses).
+ * pred f32 [B,T] + occ f32 [B,Q] (both or neither): fused DefTet.paste_occ gather
+ *      occ[b,q] = pred[b, max(index,0)] (layers/DefTet/deftet.py:132-136); cond keeps its -1s.
  * ------------------------------------------------------------------------------- */
 size_t deftet_point_in_tet_workspace_bytes(int n_batch, int n_tet, int n_query, int algo);
 int deftet_point_in_tet_f32(const float *tet, const float *pts, float *cond, float *bary,
+                            const float *pred, float *occ,
                             int n_batch, int n_tet, int n_query, int algo,
                             void *workspace, size_t workspace_bytes, void *stream);
 
@@ -69,11 +72,14 @@ int deftet_point_in_tet_f32(const float *tet, const float *pts, float *cond, flo
  * or NULL receives d/d pts.  accumulate == 0: grad_tet is fully overwritten (no pre-zeroing
  * needed); != 0: the result is added to its current content, like the reference's backward
  * kernels add into wrapper-zeroed buffers (tet_analytic_distance_batch/utils.py:65).
+ * grad_occ f32 [B,Q] + grad_pred f32 [B,T] (both or neither): fused backward of the paste_occ
+ * gather, grad_pred[b,t] = sum of grad_occ over the queries that pasted from t (misses -> tet 0).
  * workspace (deftet_point_in_tet_bwd_workspace_bytes) enables the atomic-free gather path;
  * NULL selects a float-atomic scatter. */
 size_t deftet_point_in_tet_bwd_workspace_bytes(int n_batch, int n_tet, int n_query);
 int deftet_point_in_tet_bwd_f32(const float *tet, const float *pts, const float *cond,
                                 const float *grad_w, float *grad_tet, float *grad_pts,
+                                const float *grad_occ, float *grad_pred,
                                 int n_batch, int n_tet, int n_query, int accumulate,
                                 void *workspace, size_t workspace_bytes, void *stream);
 

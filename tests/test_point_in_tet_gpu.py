@@ -128,14 +128,14 @@ def test_backward_atomic_fallback_matches_gather(cuda, oracle):
     g_atomic = torch.full_like(t, 7.0)          # must be overwritten when accumulate == 0
     st = _lib.current_stream(cuda)
     _lib.check(lib.deftet_point_in_tet_bwd_f32(_lib.ptr(t), _lib.ptr(p), _lib.ptr(cond), _lib.ptr(gw), _lib.ptr(g_atomic),
-                                               None, 2, t.shape[1], 3000, 0, None, 0, st), "bwd atomic")
+                                               None, None, None, 2, t.shape[1], 3000, 0, None, 0, st), "bwd atomic")
     torch.cuda.synchronize()
     scale = g_gather.abs().max().item()
     assert (g_gather - g_atomic).abs().max().item() <= 1e-5 * scale
     acc = torch.ones_like(t)
     ws = _lib.workspace(cuda, lib.deftet_point_in_tet_bwd_workspace_bytes(2, t.shape[1], 3000))
     _lib.check(lib.deftet_point_in_tet_bwd_f32(_lib.ptr(t), _lib.ptr(p), _lib.ptr(cond), _lib.ptr(gw), _lib.ptr(acc),
-                                               None, 2, t.shape[1], 3000, 1, _lib.ptr(ws), ws.numel(), st), "bwd acc")
+                                               None, None, None, 2, t.shape[1], 3000, 1, _lib.ptr(ws), ws.numel(), st), "bwd acc")
     torch.cuda.synchronize()
     assert (acc - 1.0 - g_gather).abs().max().item() <= 1e-5 * scale
     miss = cond[..., 0] < 0
@@ -153,3 +153,48 @@ def test_rowdot(cuda):
         assert torch.allclose(got.double(), want, rtol=1e-5, atol=1e-3)
         assert torch.equal(got, hip_ops.rowdot(a, b))            # deterministic
         assert torch.allclose(hip_ops.rowdot(a).double(), a.double().flatten(1).sum(1), rtol=1e-5, atol=1e-3)
+
+
+def test_fused_occ_op_matches_separate_ops(cuda, oracle):
+    """point_in_tet_occ == check_condition + bary + paste_occ (values and both gradients), with
+    the atomic fallback of the fused backward checked too."""
+    from deftet_amd import _lib, hip_ops
+    from deftet_amd.layers.DefTet.check_condition_tetrahedron_base.utils import (paste_occ, point_in_tet_bary,
+                                                                                point_in_tet_occ)
+    tet, pts = cases.jittered(8, 5000, 3)
+    gen = torch.Generator(device=cuda).manual_seed(7)
+    T = tet.shape[1]
+    pred0 = torch.rand(3, T, device=cuda, generator=gen)
+    gw = torch.randn(3, 5000, 4, device=cuda, generator=gen)
+    go = torch.randn(3, 5000, device=cuda, generator=gen)
+
+    t1 = torch.from_numpy(tet).to(cuda).requires_grad_(True)
+    p1 = pred0.clone().requires_grad_(True)
+    cond, w, occ = point_in_tet_occ(t1, torch.from_numpy(pts).to(cuda), p1)
+    ((w * gw).sum() + (occ * go).sum()).backward()
+
+    t2 = torch.from_numpy(tet).to(cuda).requires_grad_(True)
+    p2 = pred0.clone().requires_grad_(True)
+    cond2, w2 = point_in_tet_bary(t2, torch.from_numpy(pts).to(cuda))
+    occ2 = paste_occ(p2, cond2.clone())
+    ((w2 * gw).sum() + (occ2 * go).sum()).backward()
+
+    assert torch.equal(cond, cond2) and (cond < 0).any()                 # fused op keeps the -1s
+    assert np.array_equal(cond.cpu().numpy(), oracle.point_in_tet(tet, pts))
+    assert torch.equal(w, w2) and torch.equal(occ, occ2)
+    assert (t1.grad - t2.grad).abs().max() <= 1e-5 * t2.grad.abs().max()
+    assert (p1.grad - p2.grad).abs().max() <= 1e-5 * p2.grad.abs().max()
+    # misses paste from (and send their gradient to) tet 0
+    miss = cond[..., 0] < 0
+    assert torch.equal(occ[miss], pred0[:, 0:1].expand(-1, 5000)[miss])
+    # atomic fallback (no workspace) of the fused backward
+    lib = _lib.load()
+    g_tet = torch.empty_like(t1)
+    g_pred = torch.empty(3, T, device=cuda)
+    tt, pp = t1.detach().contiguous(), torch.from_numpy(pts).to(cuda)
+    _lib.check(lib.deftet_point_in_tet_bwd_f32(_lib.ptr(tt), _lib.ptr(pp), _lib.ptr(cond), _lib.ptr(gw), _lib.ptr(g_tet), None,
+                                               _lib.ptr(go), _lib.ptr(g_pred), 3, T, 5000, 0, None, 0, _lib.current_stream(cuda)),
+               "fused bwd atomic")
+    torch.cuda.synchronize()
+    assert (g_pred - p1.grad).abs().max() <= 1e-5 * p1.grad.abs().max()
+    assert (g_tet - t1.grad).abs().max() <= 1e-5 * t1.grad.abs().max()
