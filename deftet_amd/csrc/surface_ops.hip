@@ -58,6 +58,184 @@ __global__ __launch_bounds__(256) void k_nn(const float *__restrict__ queries, c
     if (live) result[(size_t)b * N + q] = besti;
 }
 
+// --- A10, grid-accelerated (exact) -------------------------------------------------------------------
+// Points are counting-sorted into a uniform G^3 grid over their bounding box; a query walks the
+// cell shells around its own (virtual) cell in increasing Chebyshev radius r and stops as soon as
+// the best distance found is smaller than a certified lower bound for everything outside the
+// shell box.  Distances are evaluated exactly as the reference does, and candidates are combined
+// lexicographically (distance, index), which equals "first strict minimum of an ascending scan".
+constexpr int kNNBlocks = 64;
+
+struct NNGrid { float o[3], inv[3], cs[3], slack[3]; int G; };
+
+__global__ __launch_bounds__(256) void k_nn_bbox(const float *__restrict__ pts, int M, float *part)
+{
+    __shared__ float sh[4][6];
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += gridDim.x * blockDim.x) {
+        const float x = pts[i * 3], y = pts[i * 3 + 1], z = pts[i * 3 + 2];
+        if (fabsf(x) < INFINITY && fabsf(y) < INFINITY && fabsf(z) < INFINITY) {     // finite (NaN fails)
+            lo[0] = fminf(lo[0], x); lo[1] = fminf(lo[1], y); lo[2] = fminf(lo[2], z);
+            hi[0] = fmaxf(hi[0], x); hi[1] = fmaxf(hi[1], y); hi[2] = fmaxf(hi[2], z);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = fminf(lo[k], __shfl_xor(lo[k], off));
+            hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off));
+        }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { sh[w][k] = lo[k]; sh[w][3 + k] = hi[k]; }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int k = threadIdx.x;
+        float v = sh[0][k];
+        for (int i = 1; i < 4; ++i) v = k < 3 ? fminf(v, sh[i][k]) : fmaxf(v, sh[i][k]);
+        part[blockIdx.x * 6 + k] = v;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_nn_grid(const float *__restrict__ part, int G, NNGrid *g)
+{
+    const int lane = threadIdx.x;
+    float lo[3], hi[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { lo[k] = part[lane * 6 + k]; hi[k] = part[lane * 6 + 3 + k]; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = fminf(lo[k], __shfl_xor(lo[k], off));
+            hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off));
+        }
+    if (lane == 0) {
+        NNGrid r;
+        r.G = G;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const bool ok = hi[k] >= lo[k];
+            const float l = ok ? lo[k] : 0.f, h = ok ? hi[k] : 0.f;
+            const float ext = h - l;
+            r.o[k] = l;
+            const bool flat = !(ext > 1e-30f) || !(ext < 1e30f);
+            r.inv[k] = flat ? 0.f : (float)G / ext;
+            r.cs[k] = flat ? INFINITY : ext / (float)G;          // cell size (inf: one slab, no bound on this axis)
+            // absolute uncertainty of a cell boundary position as seen through the fp32 cell assignment
+            r.slack[k] = 8e-6f * (fabsf(l) + fabsf(h)) + 1e-30f;
+        }
+        *g = r;
+    }
+}
+
+__device__ __forceinline__ int nn_cell(float x, float o, float inv, int G)
+{
+    float f = floorf((x - o) * inv);
+    f = fminf(fmaxf(f, 0.f), (float)(G - 1));
+    return (int)f;
+}
+
+__global__ __launch_bounds__(256) void k_nn_bin(const float *__restrict__ pts, int M, const NNGrid *__restrict__ gp, int *cells,
+                                                int2 *pcell)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    const NNGrid g = *gp;
+    const float x = pts[i * 3], y = pts[i * 3 + 1], z = pts[i * 3 + 2];
+    int2 r = make_int2(-1, 0);
+    if (fabsf(x) < INFINITY && fabsf(y) < INFINITY && fabsf(z) < INFINITY) {
+        const int c = (nn_cell(z, g.o[2], g.inv[2], g.G) * g.G + nn_cell(y, g.o[1], g.inv[1], g.G)) * g.G + nn_cell(x, g.o[0], g.inv[0], g.G);
+        r.x = c;
+        r.y = atomicAdd(&cells[c], 1);
+    }
+    pcell[i] = r;                                                  // non-finite points can never be nearest (d is inf/NaN)
+}
+
+__global__ __launch_bounds__(256) void k_nn_scatter(const float *__restrict__ pts, int M, const int2 *__restrict__ pcell,
+                                                    const int *__restrict__ start, float4 *sorted)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    const int2 r = pcell[i];
+    if (r.x < 0) return;
+    sorted[start[r.x] + r.y] = make_float4(pts[i * 3], pts[i * 3 + 1], pts[i * 3 + 2], __int_as_float(i));
+}
+
+__global__ __launch_bounds__(256) void k_nn_query(const float *__restrict__ queries, int N, const NNGrid *__restrict__ gp,
+                                                  const int *__restrict__ start, const float4 *__restrict__ sorted, int *result)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= N) return;
+    const NNGrid g = *gp;
+    const int G = g.G;
+    const float qx = queries[q * 3], qy = queries[q * 3 + 1], qz = queries[q * 3 + 2];
+    float best = 1e20f;                                            // nearest_neighbor_cuda.cu:28
+    int besti = 0;
+    const float qq[3] = {qx, qy, qz};
+    if (!(fabsf(qx) < INFINITY && fabsf(qy) < INFINITY && fabsf(qz) < INFINITY)) { result[q] = 0; return; }   // every d is inf/NaN
+    int c[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float f = floorf((qq[k] - g.o[k]) * g.inv[k]);
+        f = fminf(fmaxf(f, -1.f), (float)G);                       // virtual cell: -1 / G = outside the grid on that side
+        c[k] = (int)f;
+    }
+    auto visit = [&](int s, int e) {
+        for (int j = s; j < e; ++j) {
+            const float4 p = sorted[j];
+            const float dx = p.x - qx, dy = p.y - qy, dz = p.z - qz;
+            float d = 0.f;
+            d += dx * dx;                                           // :42
+            d += dy * dy;                                           // :44
+            d += dz * dz;                                           // :46
+            const int idx = __float_as_int(p.w);
+            if (d < best || (d == best && idx < besti && best < 1e20f)) { best = d; besti = idx; }
+        }
+    };
+    for (int r = 0;; ++r) {
+        const int x0 = max(c[0] - r, 0), x1 = min(c[0] + r, G - 1);
+        for (int dz = -r; dz <= r; ++dz) {
+            const int cz = c[2] + dz;
+            if (cz < 0 || cz >= G) continue;
+            for (int dy = -r; dy <= r; ++dy) {
+                const int cy = c[1] + dy;
+                if (cy < 0 || cy >= G) continue;
+                const int row = (cz * G + cy) * G;
+                if (max(abs(dz), abs(dy)) == r) {                  // a face of the shell: the whole x-run
+                    if (x0 <= x1) visit(start[row + x0], start[row + x1 + 1]);
+                } else {                                           // interior rows: only the two end cells
+                    const int xa = c[0] - r, xb = c[0] + r;
+                    if (xa >= 0 && xa < G) visit(start[row + xa], start[row + xa + 1]);
+                    if (xb >= 0 && xb < G && xb != xa) visit(start[row + xb], start[row + xb + 1]);
+                }
+            }
+        }
+        // certified lower bound on the distance to any point outside the box of cells [c-r, c+r]
+        float m = INFINITY;
+        bool more = false;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (c[k] - r > 0) {                                    // cells below exist on this axis
+                more = true;
+                const float edge = g.o[k] + (float)(c[k] - r) * g.cs[k];
+                m = fminf(m, fmaxf(qq[k] - edge - g.slack[k], 0.f));
+            }
+            if (c[k] + r < G - 1) {                                // cells above exist
+                more = true;
+                const float edge = g.o[k] + (float)(c[k] + r + 1) * g.cs[k];
+                m = fminf(m, fmaxf(edge - qq[k] - g.slack[k], 0.f));
+            }
+        }
+        if (!more) break;                                          // the box covers the whole grid
+        const float bound = (m * m) * 0.99999f;                    // fp32 distance of an unseen point >= this
+        if (best < bound) break;
+    }
+    result[q] = besti;
+}
+
 // ---------------------------------------------------------------------------- A8 face edge adjacency
 __device__ __forceinline__ bool pos_equal(const float *a, const float *b)
 {   // equal(), tet_face_adj_m_for.cu:26-35
@@ -104,6 +282,137 @@ __global__ __launch_bounds__(256) void k_face_edge_adj(const float *__restrict__
             ++found;
         }
     }
+}
+
+// --- A8, sort-based (exact): O(F log F) instead of O(F^2) ------------------------------------------
+// equal(a,b) (L1 distance <= 1e-15 in fp32) can only hold if, coordinate by coordinate, the two
+// floats are bitwise identical or both "tiny" (|x| < 2^-24: one ulp there is still > 1e-15 above
+// that magnitude, so distinct non-tiny floats differ by >= 7e-15).  NaN/Inf coordinates never
+// compare equal (the difference is NaN).  So a NECESSARY condition for two faces to share an edge
+// is equality of a 192-bit edge key built from per-coordinate keys (float bits, or one tag for
+// all tiny values, or a unique tag for non-finite ones).  Edge records are radix-sorted by that key
+// (three stable 64-bit passes), and every face runs the EXACT check_share() only on the faces in
+// the key groups of its three edges, keeping the 30 smallest neighbour ids in ascending order.
+using u64 = unsigned long long;
+using u32 = unsigned int;
+
+struct VKey { u32 x, y, z; };
+
+__device__ __forceinline__ u32 coord_key(float v, u32 unique, bool &bad)
+{
+    const u32 b = __float_as_uint(v);
+    if ((b & 0x7F800000u) == 0x7F800000u) { bad = true; return unique; }   // NaN / Inf: never equal to anything
+    if (fabsf(v) < 5.9604645e-08f) return 0u;                                // tiny (|x| < 2^-24), includes +-0
+    return b;
+}
+__device__ __forceinline__ VKey vertex_key(const float *v, u32 unique)
+{
+    bool bad = false;
+    VKey k{coord_key(v[0], unique, bad), coord_key(v[1], unique, bad), coord_key(v[2], unique, bad)};
+    if (bad) { k.x = 0xFFFFFFFFu; k.y = unique; k.z = 0u; }                 // 0xFFFFFFFF is itself a NaN pattern: no finite float has it
+    return k;
+}
+__device__ __forceinline__ bool vkey_less(const VKey &a, const VKey &b)
+{
+    if (a.x != b.x) return a.x < b.x;
+    if (a.y != b.y) return a.y < b.y;
+    return a.z < b.z;
+}
+
+__global__ __launch_bounds__(256) void k_edge_records(const float *__restrict__ face, int F, u64 *K0, u64 *K1, u64 *K2, u32 *idx)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;             // r = f*3 + e
+    if (r >= F * 3) return;
+    const int f = r / 3, e = r % 3;
+    const float *fa = face + (size_t)f * 9;
+    VKey a = vertex_key(fa + 3 * e, (u32)(f * 3 + e)), b = vertex_key(fa + 3 * ((e + 1) % 3), (u32)(f * 3 + (e + 1) % 3));
+    if (vkey_less(b, a)) { const VKey t = a; a = b; b = t; }
+    K0[r] = ((u64)a.x << 32) | a.y;
+    K1[r] = ((u64)a.z << 32) | b.x;
+    K2[r] = ((u64)b.y << 32) | b.z;
+    idx[r] = (u32)r;
+}
+
+__global__ __launch_bounds__(256) void k_gather64(const u64 *__restrict__ src, const u32 *__restrict__ idx, int n, u64 *dst)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[idx[i]];
+}
+
+// head position of each key group (max-scanned afterwards) and the inverse permutation
+__global__ __launch_bounds__(256) void k_edge_heads(const u64 *__restrict__ K0, const u64 *__restrict__ K1,
+                                                    const u64 *__restrict__ K2, const u32 *__restrict__ idx, int n, int *headpos,
+                                                    int *where)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u32 a = idx[i];
+    bool head = i == 0;
+    if (!head) {
+        const u32 b = idx[i - 1];
+        head = K0[a] != K0[b] || K1[a] != K1[b] || K2[a] != K2[b];
+    }
+    headpos[i] = head ? i : 0;
+    where[a] = i;
+}
+
+__device__ __forceinline__ bool check_share_exact(const float *fa, const float *fb)
+{   // check_share, tet_face_adj_m_for.cu:38-69 (through the 3x3 vertex-equality matrix)
+    bool E[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) E[i][j] = pos_equal(fa + 3 * i, fb + 3 * j);
+    bool share = false;
+#pragma unroll
+    for (int ia = 0; ia < 3; ++ia)
+#pragma unroll
+        for (int ib = 0; ib < 3; ++ib) {
+            const int ia2 = (ia + 1) % 3, ib2 = (ib + 1) % 3;
+            share = share || (E[ia][ib] && E[ia2][ib2]) || (E[ia][ib2] && E[ia2][ib]);
+        }
+    return share;
+}
+
+constexpr int kMaxNeiFast = 32;        // the sorted path keeps its candidate list in registers/scratch
+
+__global__ __launch_bounds__(256) void k_face_neighbors(const float *__restrict__ face, int F, const u32 *__restrict__ idx,
+                                                        const int *__restrict__ headpos, const int *__restrict__ where,
+                                                        const u64 *__restrict__ K0, const u64 *__restrict__ K1,
+                                                        const u64 *__restrict__ K2, float *__restrict__ adj, int max_nei)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    float fa[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) fa[i] = face[(size_t)f * 9 + i];
+    int nb[kMaxNeiFast];
+    int n = 0;
+    const int n3 = F * 3;
+    for (int e = 0; e < 3; ++e) {
+        const int p = where[f * 3 + e];
+        const int hs = headpos[p];
+        const u32 r0 = idx[hs];
+        for (int j = hs; j < n3; ++j) {
+            const u32 rj = idx[j];
+            if (j != hs && (K0[rj] != K0[r0] || K1[rj] != K1[r0] || K2[rj] != K2[r0])) break;   // end of the key group
+            const int g = (int)(rj / 3);
+            if (g == f) continue;
+            if (n == max_nei && g > nb[n - 1]) continue;             // cannot be among the max_nei smallest
+            float fb[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) fb[i] = face[(size_t)g * 9 + i];
+            if (!check_share_exact(fa, fb)) continue;
+            // insert g into the ascending list (no duplicates), keep the max_nei smallest
+            int pos = 0;
+            while (pos < n && nb[pos] < g) ++pos;
+            if (pos < n && nb[pos] == g) continue;
+            if (n < max_nei) ++n;
+            for (int k = n - 1; k > pos; --k) nb[k] = nb[k - 1];
+            if (pos < n) nb[pos] = g;
+        }
+    }
+    for (int k = 0; k < n; ++k) adj[(size_t)f * max_nei + k] = (float)nb[k];
 }
 
 // ---------------------------------------------------------------------------- A9 point -> triangle distance
@@ -364,26 +673,119 @@ __global__ __launch_bounds__(256) void k_tri_dist_bwd_sorted(const float *__rest
 using namespace deftet;
 using namespace deftet::surf;
 
+static int nn_pick_G(int M)
+{
+    int G = (int)llround(cbrt((double)(M > 0 ? M : 1) / 4.0));
+    if (G < 1) G = 1;
+    if (G > 160) G = 160;
+    return G;
+}
+
+extern "C" size_t deftet_nn_index_workspace_bytes(int B, int N, int M)
+{
+    const int G = nn_pick_G(M);
+    const size_t nc = (size_t)G * G * G + 1;
+    return nc * 4 * 2 + (size_t)(M > 0 ? M : 0) * (8 + 16) + nc * 8 + ((size_t)2 << 20);
+}
+
+// workspace == NULL: the scalar-stream brute force; otherwise the grid search (both exact).
 extern "C" int deftet_nn_index_f32(const float *queries, const float *points, int32_t *result, int B, int N, int M,
-                                   void *stream_)
+                                   void *workspace, size_t wsb, void *stream_)
 {
     DEFTET_CHECK_ARG(B >= 0 && N >= 0 && M >= 0 && B <= 65535, "bad size");
     if (B == 0 || N == 0) return DEFTET_OK;
     DEFTET_CHECK_ARG(queries && result && (M == 0 || points), "null pointer");
-    DEFTET_CHECK_ARG((long long)M * 3 < 2147483647LL, "too many points per shape");
-    DEFTET_LAUNCH(k_nn, dim3((N + 255) / 256, B), dim3(256), as_stream(stream_), queries, points, N, M, result);
+    DEFTET_CHECK_ARG((long long)M * 3 < 2147483647LL && (long long)N * 3 < 2147483647LL, "too many points per shape");
+    hipStream_t st = as_stream(stream_);
+    if (!workspace || M == 0) {
+        DEFTET_LAUNCH(k_nn, dim3((N + 255) / 256, B), dim3(256), st, queries, points, N, M, result);
+        return DEFTET_OK;
+    }
+    DEFTET_CHECK_ARG(((uintptr_t)workspace & 255) == 0 && wsb >= deftet_nn_index_workspace_bytes(B, N, M),
+                     "workspace misaligned or too small");
+    const int G = nn_pick_G(M);
+    const size_t nc = (size_t)G * G * G + 1;
+    Arena A(workspace, wsb);
+    float *part = A.take<float>(kNNBlocks * 6);
+    NNGrid *grid = A.take<NNGrid>(1);
+    int *cells = A.take<int>(nc), *start = A.take<int>(nc);
+    int2 *pcell = A.take<int2>(M);
+    float4 *sorted = A.take<float4>(M);
+    void *tmp = A.base + align_up(A.off, 256);
+    const size_t left = wsb - align_up(A.off, 256);
+    for (int b = 0; b < B; ++b) {
+        const float *pb = points + (size_t)b * M * 3, *qb = queries + (size_t)b * N * 3;
+        DEFTET_HIP(hipMemsetAsync(cells, 0, nc * 4, st));
+        DEFTET_LAUNCH(k_nn_bbox, dim3(kNNBlocks), dim3(256), st, pb, M, part);
+        DEFTET_LAUNCH(k_nn_grid, dim3(1), dim3(64), st, part, G, grid);
+        DEFTET_LAUNCH(k_nn_bin, dim3((M + 255) / 256), dim3(256), st, pb, M, grid, cells, pcell);
+        size_t need = 0;
+        hipError_t e = rocprim::exclusive_scan(nullptr, need, cells, start, 0, nc, rocprim::plus<int>(), st);
+        if (e != hipSuccess || need > left) return set_error(DEFTET_ELAUNCH, "exclusive_scan temp");
+        e = rocprim::exclusive_scan(tmp, need, cells, start, 0, nc, rocprim::plus<int>(), st);
+        if (e != hipSuccess) return set_error(DEFTET_ELAUNCH, "exclusive_scan: %s", hipGetErrorString(e));
+        DEFTET_LAUNCH(k_nn_scatter, dim3((M + 255) / 256), dim3(256), st, pb, M, pcell, start, sorted);
+        DEFTET_LAUNCH(k_nn_query, dim3((N + 255) / 256), dim3(256), st, qb, N, grid, start, sorted, result + (size_t)b * N);
+    }
     return DEFTET_OK;
 }
 
-extern "C" size_t deftet_face_edge_adj_workspace_bytes(int) { return 0; }
+extern "C" size_t deftet_face_edge_adj_workspace_bytes(int F)
+{
+    const size_t n = (size_t)(F > 0 ? F : 0) * 3;
+    return n * (5 * 8 + 2 * 4 + 3 * 4) + n * 24 + ((size_t)4 << 20);
+}
 
-extern "C" int deftet_face_edge_adj_f32(const float *face, float *adj, int F, int max_nei, void *, size_t, void *stream_)
+// workspace == NULL (or max_nei > 32): the scalar-stream brute force; otherwise the sort-based path.
+extern "C" int deftet_face_edge_adj_f32(const float *face, float *adj, int F, int max_nei, void *workspace, size_t wsb,
+                                        void *stream_)
 {
     DEFTET_CHECK_ARG(F >= 0 && max_nei >= 0, "negative size");
     if (F >= (1 << 24)) return set_error(DEFTET_ELIMIT, "n_face=%d does not fit a float-encoded index", F);
     if (F == 0 || max_nei == 0) return DEFTET_OK;
     DEFTET_CHECK_ARG(face && adj, "null pointer");
-    DEFTET_LAUNCH(k_face_edge_adj, dim3((F + 255) / 256), dim3(256), as_stream(stream_), face, adj, F, max_nei);
+    hipStream_t st = as_stream(stream_);
+    if (!workspace || max_nei > kMaxNeiFast) {
+        DEFTET_LAUNCH(k_face_edge_adj, dim3((F + 255) / 256), dim3(256), st, face, adj, F, max_nei);
+        return DEFTET_OK;
+    }
+    DEFTET_CHECK_ARG(((uintptr_t)workspace & 255) == 0 && wsb >= deftet_face_edge_adj_workspace_bytes(F),
+                     "workspace misaligned or too small");
+    const int n = F * 3;
+    Arena A(workspace, wsb);
+    u64 *K0 = A.take<u64>(n), *K1 = A.take<u64>(n), *K2 = A.take<u64>(n), *ka = A.take<u64>(n), *kb = A.take<u64>(n);
+    u32 *i0 = A.take<u32>(n), *i1 = A.take<u32>(n);
+    int *hp = A.take<int>(n), *hps = A.take<int>(n), *where = A.take<int>(n);
+    void *tmp = A.base + align_up(A.off, 256);
+    const size_t left = wsb - align_up(A.off, 256);
+    const dim3 g((n + 255) / 256), blk(256);
+    DEFTET_LAUNCH(k_edge_records, g, blk, st, face, F, K0, K1, K2, i0);
+    auto sort_pass = [&](const u64 *kin, const u32 *vin, u32 *vout) -> int {
+        size_t need = 0;
+        hipError_t e = rocprim::radix_sort_pairs(nullptr, need, kin, kb, vin, vout, (size_t)n, 0, 64, st);
+        if (e != hipSuccess || need > left) return set_error(DEFTET_ELAUNCH, "radix_sort_pairs temp (%zu bytes)", need);
+        e = rocprim::radix_sort_pairs(tmp, need, kin, kb, vin, vout, (size_t)n, 0, 64, st);
+        if (e != hipSuccess) return set_error(DEFTET_ELAUNCH, "radix_sort_pairs: %s", hipGetErrorString(e));
+        return DEFTET_OK;
+    };
+    // LSD over the three 64-bit key words (stable): K2, then K1, then K0
+    int rc = sort_pass(K2, i0, i1);
+    if (rc) return rc;
+    DEFTET_LAUNCH(k_gather64, g, blk, st, K1, i1, n, ka);
+    rc = sort_pass(ka, i1, i0);
+    if (rc) return rc;
+    DEFTET_LAUNCH(k_gather64, g, blk, st, K0, i0, n, ka);
+    rc = sort_pass(ka, i0, i1);
+    if (rc) return rc;
+    DEFTET_LAUNCH(k_edge_heads, g, blk, st, K0, K1, K2, i1, n, hp, where);
+    {
+        size_t need = 0;
+        hipError_t e = rocprim::inclusive_scan(nullptr, need, hp, hps, (size_t)n, rocprim::maximum<int>(), st);
+        if (e != hipSuccess || need > left) return set_error(DEFTET_ELAUNCH, "inclusive_scan temp");
+        e = rocprim::inclusive_scan(tmp, need, hp, hps, (size_t)n, rocprim::maximum<int>(), st);
+        if (e != hipSuccess) return set_error(DEFTET_ELAUNCH, "inclusive_scan: %s", hipGetErrorString(e));
+    }
+    DEFTET_LAUNCH(k_face_neighbors, dim3((F + 255) / 256), blk, st, face, F, i1, hps, where, K0, K1, K2, adj, max_nei);
     return DEFTET_OK;
 }
 

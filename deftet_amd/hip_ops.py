@@ -222,16 +222,19 @@ def tet_to_face(tet_list, n_point, device, with_boundary=False):
 
 
 # --------------------------------------------------------------------------------- A8 / A9 / A10 surface ops
-def face_edge_adj(face_fx3x3, n_max_nei=30):
-    """f32 [F, n_max_nei] neighbour table (-1 padded): tet_face_adj_m_for.cu:72-108."""
+def face_edge_adj(face_fx3x3, n_max_nei=30, brute=False):
+    """f32 [F, n_max_nei] neighbour table (-1 padded): tet_face_adj_m_for.cu:72-108.
+    brute=True selects the O(F^2) scalar-stream kernel (kept for cross-checks)."""
     _lib.require_gpu(face_fx3x3)
     lib = _lib.load()
     face = _f32c(face_fx3x3)
     F = face.shape[0]
     adj = torch.full((F, n_max_nei), -1.0, device=face.device, dtype=torch.float32)    # utils.py:47
     with torch.cuda.device(face.device):
-        _lib.check(lib.deftet_face_edge_adj_f32(_lib.ptr(face), _lib.ptr(adj), F, n_max_nei, None, 0,
-                                                _lib.current_stream(face.device)), "deftet_face_edge_adj_f32")
+        ws = None if brute else _lib.workspace(face.device, lib.deftet_face_edge_adj_workspace_bytes(F))
+        _lib.check(lib.deftet_face_edge_adj_f32(_lib.ptr(face), _lib.ptr(adj), F, n_max_nei, _lib.ptr(ws),
+                                                ws.numel() if ws is not None else 0, _lib.current_stream(face.device)),
+                   "deftet_face_edge_adj_f32")
     return adj
 
 
@@ -260,15 +263,19 @@ def tri_dist_bwd(pts_bxpx3, face_bxfx3x3, closest_f, dl_dd, deterministic=False)
     return out
 
 
-def nn_index(queries_bxnx3, points_bxmx3):
+def nn_index(queries_bxnx3, points_bxmx3, brute=False):
+    """int32 [B,N] index of the first strictly-nearest point (nearest_neighbor_cuda.cu:17-55).
+    brute=True selects the O(N*M) scalar-stream kernel (kept for cross-checks)."""
     _lib.require_gpu(queries_bxnx3, points_bxmx3)
     lib = _lib.load()
     q, p = _f32c(queries_bxnx3), _f32c(points_bxmx3)
-    B, N = q.shape[0], q.shape[1]
+    B, N, M = q.shape[0], q.shape[1], p.shape[1]
     out = torch.zeros(B, N, device=q.device, dtype=torch.int32)                         # nearest_neighbor.py:32-33
     with torch.cuda.device(q.device):
-        _lib.check(lib.deftet_nn_index_f32(_lib.ptr(q), _lib.ptr(p), _lib.ptr(out), B, N, p.shape[1],
-                                           _lib.current_stream(q.device)), "deftet_nn_index_f32")
+        ws = None if brute else _lib.workspace(q.device, lib.deftet_nn_index_workspace_bytes(B, N, M))
+        _lib.check(lib.deftet_nn_index_f32(_lib.ptr(q), _lib.ptr(p), _lib.ptr(out), B, N, M, _lib.ptr(ws),
+                                           ws.numel() if ws is not None else 0, _lib.current_stream(q.device)),
+                   "deftet_nn_index_f32")
     return out
 
 

@@ -164,6 +164,7 @@ int deftet_tet_energies_bwd_f32(const float *tet, const float *inv_v, const doub
  * replaces layers/DefTet/tet_face_adj_m_idx/tet_face_adj_m.cpp (forward) ->
  *          tet_face_adj_m_for.cu:72-130.  adj f32 [F,n_max_nei] pre-filled with -1 by the
  * caller (utils.py:47); neighbour g ascending, first n_max_nei kept. */
+/* workspace NULL (or n_max_nei > 32): O(F^2) scan; else exact sort-based path, O(F log F). */
 size_t deftet_face_edge_adj_workspace_bytes(int n_face);
 int deftet_face_edge_adj_f32(const float *face_fx3x3, float *adj_fxm, int n_face, int n_max_nei,
                              void *workspace, size_t workspace_bytes, void *stream);
@@ -185,8 +186,10 @@ int deftet_tri_dist_bwd_f32(const float *pts_bxpx3, const float *face_bxfx3x3, c
  * A10 brute-force nearest-neighbour index
  * replaces layers/nearest_neighbor/nearest_neighbor.cpp -> nearest_neighbor_cuda.cu:17-80
  * result int32 [B,N]: index of the first point with the strictly smallest fp32 distance. */
+size_t deftet_nn_index_workspace_bytes(int n_batch, int n_query, int n_point);
+/* workspace NULL: brute-force scan (scalar-stream); else exact uniform-grid shell search. */
 int deftet_nn_index_f32(const float *queries_bxnx3, const float *points_bxmx3, int32_t *result_bxn,
-                        int n_batch, int n_query, int n_point, void *stream);
+                        int n_batch, int n_query, int n_point, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------
  * A12 differentiable tet rasterizer with the contract of

@@ -36,6 +36,9 @@ def test_nn_index_bit_exact(cuda, oracle):
     got = NearestNeighbor()(torch.from_numpy(q).to(cuda), torch.from_numpy(p).to(cuda))
     assert got.dtype == torch.int64
     assert np.array_equal(got.cpu().numpy(), oracle.nn_index(q, p).astype(np.int64))
+    from deftet_amd import hip_ops
+    assert np.array_equal(hip_ops.nn_index(torch.from_numpy(q).to(cuda), torch.from_numpy(p).to(cuda), brute=True).cpu().numpy(),
+                          oracle.nn_index(q, p))
     # M = 0 / 1 / not a multiple of the unroll
     for m in (1, 2, 3, 5):
         got = NearestNeighbor()(torch.from_numpy(q).to(cuda), torch.from_numpy(p[:, :m].copy()).to(cuda))
@@ -45,6 +48,35 @@ def test_nn_index_bit_exact(cuda, oracle):
         NearestNeighborFunction.backward(None, None)
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_nn_index_grid_adversarial(cuda, oracle, seed):
+    """the grid search must equal the ascending scan on clustered / degenerate / far-away inputs"""
+    from deftet_amd import hip_ops
+    rng = np.random.default_rng(seed)
+    M, N = 4000, 2500
+    p = np.concatenate([rng.normal(0, 0.01, (M // 2, 3)), rng.uniform(-1, 1, (M // 4, 3)), rng.uniform(50, 60, (M // 4, 3))]).astype(np.float32)
+    if seed == 1:
+        p[:, 2] = 0.25                                   # all points in one plane (flat axis)
+    if seed == 2:
+        p[:] = p[0]                                      # all points identical
+        p[7] = p[0] + np.float32(1e-3)
+    p[100:120] = p[200:220]                              # exact duplicates
+    p[300] = np.nan
+    p[301, 1] = np.inf
+    p[302] = 3e18                                        # d ~ 2.7e37 > 1e20: never selected
+    p[303] = 1e9                                         # d ~ 3e18 < 1e20: selectable
+    q = np.concatenate([rng.normal(0, 0.02, (N // 2, 3)), rng.uniform(-2, 2, (N // 4, 3)), rng.uniform(-100, 100, (N // 4, 3))]).astype(np.float32)
+    q[:50] = p[rng.integers(0, M, 50)]                   # zero distance (NaN rows give NaN queries too)
+    q[60] = np.nan
+    q[61, 0] = np.inf
+    q[62] = 5e8
+    q[63] = 1e12                                         # every finite point is farther than sqrt(1e20)
+    for b in (p[None], p[None][:, ::-1].copy()):
+        want = oracle.nn_index(q[None], b)
+        got = hip_ops.nn_index(torch.from_numpy(q[None]).to(cuda), torch.from_numpy(b).to(cuda)).cpu().numpy()
+        assert np.array_equal(got, want)
+
+
 def test_nn_index_properties_full_size(cuda):
     """100k GT points (dataloader.py:169) x 60k queries: idempotence + optimality property."""
     g = torch.Generator(device=cuda).manual_seed(1)
@@ -52,6 +84,7 @@ def test_nn_index_properties_full_size(cuda):
     q = torch.rand(1, 60000, 3, device=cuda, generator=g) - 0.5
     from deftet_amd import hip_ops
     idx = hip_ops.nn_index(q, p).long()
+    assert torch.equal(idx, hip_ops.nn_index(q, p, brute=True).long())       # grid search == exhaustive scan, 6e9 pairs
     near = torch.gather(p, 1, idx[..., None].expand(-1, -1, 3))
     d = ((near - q) ** 2).sum(-1)
     # no sampled point is closer
@@ -73,6 +106,7 @@ def test_face_edge_adj_bit_exact(cuda, oracle, res):
     want = oracle.face_edge_adj(face, 30)
     got = hip_ops.face_edge_adj(torch.from_numpy(face).to(cuda), 30).cpu().numpy()
     assert np.array_equal(got, want)
+    assert np.array_equal(hip_ops.face_edge_adj(torch.from_numpy(face).to(cuda), 30, brute=True).cpu().numpy(), want)
     assert ((want >= 0).sum(1) == 3).mean() > 0.9          # closed manifold surface: 3 edge neighbours
     idx = tet_face_adj_m_f_idx(torch.from_numpy(face).to(cuda))
     rows, cols = np.nonzero(want >= 0)
@@ -83,8 +117,21 @@ def test_face_edge_adj_bit_exact(cuda, oracle, res):
     w2 = oracle.face_edge_adj(rep, 30)
     g2 = hip_ops.face_edge_adj(torch.from_numpy(rep).to(cuda), 30).cpu().numpy()
     assert np.array_equal(g2, w2) and (w2 >= 0).all()
-    tiny = (face[:40] * 1e-9).astype(np.float32)           # coordinates below the 1e-15 L1 tolerance scale
-    assert np.array_equal(hip_ops.face_edge_adj(torch.from_numpy(tiny).to(cuda), 30).cpu().numpy(), oracle.face_edge_adj(tiny, 30))
+    for sc in (1e-9, 3e-8, 1e-6):                          # coordinates around / below the 1e-15 L1 tolerance scale
+        tiny = (face[:60] * sc).astype(np.float32)
+        assert np.array_equal(hip_ops.face_edge_adj(torch.from_numpy(tiny).to(cuda), 30).cpu().numpy(), oracle.face_edge_adj(tiny, 30))
+    # mixed: some coordinates tiny, zeros of both signs, non-finite vertices, a perturbed duplicate
+    rng = np.random.default_rng(1)
+    mix = face[:80].copy()
+    mix[:, :, 2] = 0.0
+    mix[::3, :, 2] = -0.0
+    mix[5, 1, 0] = np.nan
+    mix[6, 2, 1] = np.inf
+    mix[7] = mix[8]
+    mix[9] = mix[10] + np.float32(1e-16)
+    mix[11, :, 1] *= np.float32(1e-9)
+    assert np.array_equal(hip_ops.face_edge_adj(torch.from_numpy(mix).to(cuda), 30).cpu().numpy(), oracle.face_edge_adj(mix, 30))
+    assert np.array_equal(hip_ops.face_edge_adj(torch.from_numpy(mix).to(cuda), 7).cpu().numpy(), oracle.face_edge_adj(mix, 7))
     empty = tet_face_adj_m_f_idx(torch.zeros(0, 3, 3, device=cuda))
     assert empty.numel() == 0 and empty.is_floating_point()
 
