@@ -66,7 +66,8 @@ __global__ __launch_bounds__(256) void k_nn(const float *__restrict__ queries, c
 // lexicographically (distance, index), which equals "first strict minimum of an ascending scan".
 constexpr int kNNBlocks = 64;
 
-struct NNGrid { float o[3], inv[3], cs[3], slack[3]; int G; };
+constexpr int kNNCoarse = 4;           // coarse cells are 4x4x4 fine cells
+struct NNGrid { float o[3], inv[3], cs[3], slack[3]; int G, Gc; };
 
 __global__ __launch_bounds__(256) void k_nn_bbox(const float *__restrict__ pts, int M, float *part)
 {
@@ -115,6 +116,7 @@ __global__ __launch_bounds__(64) void k_nn_grid(const float *__restrict__ part, 
     if (lane == 0) {
         NNGrid r;
         r.G = G;
+        r.Gc = (G + kNNCoarse - 1) / kNNCoarse;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const bool ok = hi[k] >= lo[k];
@@ -139,7 +141,7 @@ __device__ __forceinline__ int nn_cell(float x, float o, float inv, int G)
 }
 
 __global__ __launch_bounds__(256) void k_nn_bin(const float *__restrict__ pts, int M, const NNGrid *__restrict__ gp, int *cells,
-                                                int2 *pcell)
+                                                int2 *pcell, int *rep)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M) return;
@@ -147,9 +149,11 @@ __global__ __launch_bounds__(256) void k_nn_bin(const float *__restrict__ pts, i
     const float x = pts[i * 3], y = pts[i * 3 + 1], z = pts[i * 3 + 2];
     int2 r = make_int2(-1, 0);
     if (fabsf(x) < INFINITY && fabsf(y) < INFINITY && fabsf(z) < INFINITY) {
-        const int c = (nn_cell(z, g.o[2], g.inv[2], g.G) * g.G + nn_cell(y, g.o[1], g.inv[1], g.G)) * g.G + nn_cell(x, g.o[0], g.inv[0], g.G);
+        const int cx = nn_cell(x, g.o[0], g.inv[0], g.G), cy = nn_cell(y, g.o[1], g.inv[1], g.G), cz = nn_cell(z, g.o[2], g.inv[2], g.G);
+        const int c = (cz * g.G + cy) * g.G + cx;
         r.x = c;
         r.y = atomicAdd(&cells[c], 1);
+        atomicMax(&rep[((cz / kNNCoarse) * g.Gc + cy / kNNCoarse) * g.Gc + cx / kNNCoarse], i);   // any point of the coarse cell
     }
     pcell[i] = r;                                                  // non-finite points can never be nearest (d is inf/NaN)
 }
@@ -164,76 +168,150 @@ __global__ __launch_bounds__(256) void k_nn_scatter(const float *__restrict__ pt
     sorted[start[r.x] + r.y] = make_float4(pts[i * 3], pts[i * 3 + 1], pts[i * 3 + 2], __int_as_float(i));
 }
 
+// Two phases per query (one lane each):
+//  1. an UPPER bound U on the nearest distance from the coarse grid: shells of coarse cells are
+//     searched until one holds a representative point; U = smallest exact distance to those;
+//  2. every fine-grid row (cz,cy) whose slab can intersect the ball of radius sqrt(U) is visited
+//     once: the x-interval of the ball in that row is one contiguous slice of the sorted points.
+// All points with fp32 distance <= U lie in the enumerated slices (margins below), so the
+// lexicographic (distance, index) minimum over them equals the reference's ascending scan.
 __global__ __launch_bounds__(256) void k_nn_query(const float *__restrict__ queries, int N, const NNGrid *__restrict__ gp,
-                                                  const int *__restrict__ start, const float4 *__restrict__ sorted, int *result)
+                                                  const int *__restrict__ start, const float4 *__restrict__ sorted,
+                                                  const int *__restrict__ rep, const float *__restrict__ pts, int M, int *result,
+                                                  int *farList, int *nFar)
 {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= N) return;
     const NNGrid g = *gp;
-    const int G = g.G;
+    const int G = g.G, Gc = g.Gc;
     const float qx = queries[q * 3], qy = queries[q * 3 + 1], qz = queries[q * 3 + 2];
-    float best = 1e20f;                                            // nearest_neighbor_cuda.cu:28
-    int besti = 0;
     const float qq[3] = {qx, qy, qz};
     if (!(fabsf(qx) < INFINITY && fabsf(qy) < INFINITY && fabsf(qz) < INFINITY)) { result[q] = 0; return; }   // every d is inf/NaN
-    int c[3];
+    auto dist = [&](float px, float py, float pz) {
+        const float dx = px - qx, dy = py - qy, dz = pz - qz;
+        float d = 0.f;
+        d += dx * dx;                                               // nearest_neighbor_cuda.cu:42
+        d += dy * dy;                                               // :44
+        d += dz * dz;                                               // :46
+        return d;
+    };
+    // ---- phase 1: coarse shells
+    int cc[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        float f = floorf((qq[k] - g.o[k]) * g.inv[k]);
-        f = fminf(fmaxf(f, -1.f), (float)G);                       // virtual cell: -1 / G = outside the grid on that side
-        c[k] = (int)f;
+        float f = floorf((qq[k] - g.o[k]) * g.inv[k] * (1.0f / kNNCoarse));
+        f = fminf(fmaxf(f, -1.f), (float)Gc);
+        cc[k] = (int)f;
     }
-    auto visit = [&](int s, int e) {
-        for (int j = s; j < e; ++j) {
-            const float4 p = sorted[j];
-            const float dx = p.x - qx, dy = p.y - qy, dz = p.z - qz;
-            float d = 0.f;
-            d += dx * dx;                                           // :42
-            d += dy * dy;                                           // :44
-            d += dz * dz;                                           // :46
-            const int idx = __float_as_int(p.w);
-            if (d < best || (d == best && idx < besti && best < 1e20f)) { best = d; besti = idx; }
-        }
-    };
-    for (int r = 0;; ++r) {
-        const int x0 = max(c[0] - r, 0), x1 = min(c[0] + r, G - 1);
+    float U = INFINITY;
+    for (int r = 0; r <= Gc + 1; ++r) {
+        bool any_cell = false;
         for (int dz = -r; dz <= r; ++dz) {
-            const int cz = c[2] + dz;
-            if (cz < 0 || cz >= G) continue;
+            const int z = cc[2] + dz;
+            if (z < 0 || z >= Gc) continue;
             for (int dy = -r; dy <= r; ++dy) {
-                const int cy = c[1] + dy;
-                if (cy < 0 || cy >= G) continue;
-                const int row = (cz * G + cy) * G;
-                if (max(abs(dz), abs(dy)) == r) {                  // a face of the shell: the whole x-run
-                    if (x0 <= x1) visit(start[row + x0], start[row + x1 + 1]);
-                } else {                                           // interior rows: only the two end cells
-                    const int xa = c[0] - r, xb = c[0] + r;
-                    if (xa >= 0 && xa < G) visit(start[row + xa], start[row + xa + 1]);
-                    if (xb >= 0 && xb < G && xb != xa) visit(start[row + xb], start[row + xb + 1]);
+                const int y = cc[1] + dy;
+                if (y < 0 || y >= Gc) continue;
+                const bool face = max(abs(dz), abs(dy)) == r;
+                for (int dx = -r; dx <= r; dx += (face ? 1 : (r > 0 ? 2 * r : 1))) {
+                    const int x = cc[0] + dx;
+                    if (x < 0 || x >= Gc) continue;
+                    any_cell = true;
+                    const int i = rep[(z * Gc + y) * Gc + x];
+                    if (i >= 0) U = fminf(U, dist(pts[i * 3], pts[i * 3 + 1], pts[i * 3 + 2]));
                 }
             }
         }
-        // certified lower bound on the distance to any point outside the box of cells [c-r, c+r]
-        float m = INFINITY;
-        bool more = false;
+        if (U < INFINITY) break;
+        if (!any_cell && r > Gc) break;
+    }
+    float best = 1e20f;                                             // :28
+    int besti = 0;
+    if (!(U < INFINITY)) { result[q] = 0; return; }                  // no finite point at all (or all overflow to inf)
+    U = fminf(U, 1e20f);                                            // nothing farther than the initial best can win
+    // ---- phase 2: rows intersecting the ball of radius R (inflated for fp32 rounding of d and of the cell map)
+    const float R = sqrtf(U) * 1.00001f;
+    int lo[3], hi[3];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            if (c[k] - r > 0) {                                    // cells below exist on this axis
-                more = true;
-                const float edge = g.o[k] + (float)(c[k] - r) * g.cs[k];
-                m = fminf(m, fmaxf(qq[k] - edge - g.slack[k], 0.f));
+    for (int k = 0; k < 3; ++k) {
+        lo[k] = nn_cell(qq[k] - R - g.slack[k], g.o[k], g.inv[k], G);
+        hi[k] = nn_cell(qq[k] + R + g.slack[k], g.o[k], g.inv[k], G);
+    }
+    // distance from q to the slab of cell layer c on axis k (0 inside; a flat axis is one unbounded slab)
+    auto slab = [&](int k, int c) -> float {
+        if (!(g.cs[k] < INFINITY)) return 0.f;
+        const float l = g.o[k] + (float)c * g.cs[k] - g.slack[k], h = g.o[k] + (float)(c + 1) * g.cs[k] + g.slack[k];
+        return fmaxf(fmaxf(l - qq[k], qq[k] - h), 0.f);
+    };
+    const float R2 = R * R;
+    // A query far from every point (large ball) would gather a sizeable part of the cloud at
+    // ~8x the per-point cost of the streaming scan: such queries are handed to k_nn_far instead.
+    {
+        const long long rows = (long long)(hi[2] - lo[2] + 1) * (hi[1] - lo[1] + 1);
+        bool far = rows > 4096;
+        if (!far && rows > 16) {
+            long long cand = 0;
+            for (int cz = lo[2]; cz <= hi[2]; ++cz) {
+                const float dz = slab(2, cz);
+                for (int cy = lo[1]; cy <= hi[1]; ++cy) {
+                    const float dy = slab(1, cy);
+                    const float rem = R2 - dy * dy - dz * dz;
+                    if (rem < 0.f) continue;
+                    const float rx = sqrtf(rem) * 1.00001f;
+                    const int x0 = nn_cell(qx - rx - g.slack[0], g.o[0], g.inv[0], G), x1 = nn_cell(qx + rx + g.slack[0], g.o[0], g.inv[0], G);
+                    const int row = (cz * G + cy) * G;
+                    cand += start[row + x1 + 1] - start[row + x0];
+                }
             }
-            if (c[k] + r < G - 1) {                                // cells above exist
-                more = true;
-                const float edge = g.o[k] + (float)(c[k] + r + 1) * g.cs[k];
-                m = fminf(m, fmaxf(edge - qq[k] - g.slack[k], 0.f));
+            far = cand * 8 > (long long)M;
+        }
+        if (far) {
+            farList[atomicAdd(nFar, 1)] = q;
+            return;
+        }
+    }
+    for (int cz = lo[2]; cz <= hi[2]; ++cz) {
+        const float dz = slab(2, cz);
+        for (int cy = lo[1]; cy <= hi[1]; ++cy) {
+            const float dy = slab(1, cy);
+            const float rem = R2 - dy * dy - dz * dz;
+            if (rem < 0.f) continue;                                 // the whole row is farther than R
+            const float rx = sqrtf(rem) * 1.00001f;
+            const int x0 = nn_cell(qx - rx - g.slack[0], g.o[0], g.inv[0], G), x1 = nn_cell(qx + rx + g.slack[0], g.o[0], g.inv[0], G);
+            const int row = (cz * G + cy) * G;
+            const int s = start[row + x0], e = start[row + x1 + 1];
+            for (int j = s; j < e; ++j) {
+                const float4 p = sorted[j];
+                const float d = dist(p.x, p.y, p.z);
+                const int idx = __float_as_int(p.w);
+                if (d < best || (d == best && idx < besti && best < 1e20f)) { best = d; besti = idx; }
             }
         }
-        if (!more) break;                                          // the box covers the whole grid
-        const float bound = (m * m) * 0.99999f;                    // fp32 distance of an unseen point >= this
-        if (best < bound) break;
     }
     result[q] = besti;
+}
+
+// far queries: the streaming scan of k_nn over the listed queries only
+__global__ __launch_bounds__(256) void k_nn_far(const float *__restrict__ queries, const float *__restrict__ points, int M,
+                                                const int *__restrict__ farList, const int *__restrict__ nFar, int *result)
+{
+    const int n = *nFar;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.x * blockDim.x >= n) return;                      // whole block idle
+    const bool live = i < n;
+    const int q = farList[live ? i : 0];
+    const float qx = queries[q * 3], qy = queries[q * 3 + 1], qz = queries[q * 3 + 2];
+    float best = 1e20f;
+    int besti = 0;
+    for (int j = 0; j < M; ++j) {
+        const float dx = points[j * 3] - qx, dy = points[j * 3 + 1] - qy, dz = points[j * 3 + 2] - qz;   // wave-uniform -> s_load
+        float d = 0.f;
+        d += dx * dx;
+        d += dy * dy;
+        d += dz * dz;
+        if (d < best) { best = d; besti = j; }
+    }
+    if (live) result[q] = besti;
 }
 
 // ---------------------------------------------------------------------------- A8 face edge adjacency
@@ -685,7 +763,7 @@ extern "C" size_t deftet_nn_index_workspace_bytes(int B, int N, int M)
 {
     const int G = nn_pick_G(M);
     const size_t nc = (size_t)G * G * G + 1;
-    return nc * 4 * 2 + (size_t)(M > 0 ? M : 0) * (8 + 16) + nc * 8 + ((size_t)2 << 20);
+    return nc * 4 * 3 + (size_t)(M > 0 ? M : 0) * (8 + 16) + (size_t)(N > 0 ? N : 0) * 4 + nc * 8 + ((size_t)2 << 20);
 }
 
 // workspace == NULL: the scalar-stream brute force; otherwise the grid search (both exact).
@@ -708,24 +786,29 @@ extern "C" int deftet_nn_index_f32(const float *queries, const float *points, in
     Arena A(workspace, wsb);
     float *part = A.take<float>(kNNBlocks * 6);
     NNGrid *grid = A.take<NNGrid>(1);
-    int *cells = A.take<int>(nc), *start = A.take<int>(nc);
+    int *cells = A.take<int>(nc), *start = A.take<int>(nc), *rep = A.take<int>(nc);
     int2 *pcell = A.take<int2>(M);
     float4 *sorted = A.take<float4>(M);
+    int *farList = A.take<int>((size_t)N + 1), *nFar = A.take<int>(4);
     void *tmp = A.base + align_up(A.off, 256);
     const size_t left = wsb - align_up(A.off, 256);
     for (int b = 0; b < B; ++b) {
         const float *pb = points + (size_t)b * M * 3, *qb = queries + (size_t)b * N * 3;
         DEFTET_HIP(hipMemsetAsync(cells, 0, nc * 4, st));
+        DEFTET_HIP(hipMemsetAsync(rep, 0xFF, nc * 4, st));          // -1 = empty coarse cell
         DEFTET_LAUNCH(k_nn_bbox, dim3(kNNBlocks), dim3(256), st, pb, M, part);
         DEFTET_LAUNCH(k_nn_grid, dim3(1), dim3(64), st, part, G, grid);
-        DEFTET_LAUNCH(k_nn_bin, dim3((M + 255) / 256), dim3(256), st, pb, M, grid, cells, pcell);
+        DEFTET_LAUNCH(k_nn_bin, dim3((M + 255) / 256), dim3(256), st, pb, M, grid, cells, pcell, rep);
         size_t need = 0;
         hipError_t e = rocprim::exclusive_scan(nullptr, need, cells, start, 0, nc, rocprim::plus<int>(), st);
         if (e != hipSuccess || need > left) return set_error(DEFTET_ELAUNCH, "exclusive_scan temp");
         e = rocprim::exclusive_scan(tmp, need, cells, start, 0, nc, rocprim::plus<int>(), st);
         if (e != hipSuccess) return set_error(DEFTET_ELAUNCH, "exclusive_scan: %s", hipGetErrorString(e));
         DEFTET_LAUNCH(k_nn_scatter, dim3((M + 255) / 256), dim3(256), st, pb, M, pcell, start, sorted);
-        DEFTET_LAUNCH(k_nn_query, dim3((N + 255) / 256), dim3(256), st, qb, N, grid, start, sorted, result + (size_t)b * N);
+        DEFTET_HIP(hipMemsetAsync(nFar, 0, 16, st));
+        DEFTET_LAUNCH(k_nn_query, dim3((N + 255) / 256), dim3(256), st, qb, N, grid, start, sorted, rep, pb, M,
+                      result + (size_t)b * N, farList, nFar);
+        DEFTET_LAUNCH(k_nn_far, dim3((N + 255) / 256), dim3(256), st, qb, pb, M, farList, nFar, result + (size_t)b * N);
     }
     return DEFTET_OK;
 }

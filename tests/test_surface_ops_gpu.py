@@ -197,3 +197,34 @@ def test_tri_dist_backward(cuda, oracle, seed, monkeypatch):
     assert (want != 0).any()
     # the edge case writes only the first endpoint (back.cu:309-315): analytic gradient differs
     # from finite differences there by design — pinned against the oracle above, not against FD
+
+
+def test_mesh_utils_glue_runs_like_the_reference(cuda, oracle):
+    """get_surface_normal_loss / point_point_distance / point_mesh_distance composed exactly as
+    DefTet.forward does (layers/DefTet/deftet.py:168-181), with gradients to the vertices."""
+    from deftet_amd.utils import mesh_utils as mu
+    verts, tets = grids.kuhn_grid(16)
+    pos = grids.jittered_positions(verts, 16, 1)
+    f3, t2, _, _, _ = oracle.tet_to_face(tets, verts.shape[0])
+    occ = (np.linalg.norm(pos[0][tets].mean(1), axis=1) < 0.3)
+    o2 = occ[t2]
+    sel = o2.sum(1) == 1
+    bnd = f3[sel].copy()
+    bnd[o2[sel][:, 0]] = bnd[o2[sel][:, 0]][:, ::-1]
+    v = torch.from_numpy(pos).to(cuda).requires_grad_(True)
+    faces = torch.from_numpy(bnd)[None].to(cuda)
+    surface_pos = torch.gather(v.unsqueeze(2).expand(-1, -1, 3, -1), 1, faces.unsqueeze(-1).expand(-1, -1, -1, 3))
+    normal_loss = mu.get_surface_normal_loss(v, faces)
+    torch.manual_seed(0)
+    pred_pts = mu.sample_surf_point_batch(surface_pos, 20).reshape(1, -1, 3)
+    d = np.random.default_rng(0).standard_normal((20000, 3))
+    gt = torch.from_numpy((0.3 * d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32))[None].to(cuda)
+    chamfer = mu.point_point_distance(pred_pts, gt).mean(-1)
+    analytic = mu.point_mesh_distance(gt, surface_pos).mean(-1).mean(-1)
+    (normal_loss.sum() + chamfer.sum() + analytic.sum()).backward()
+    assert torch.isfinite(v.grad).all() and v.grad.abs().sum() > 0
+    assert 0 <= normal_loss.item() < 1 and 0 < chamfer.item() < 0.1 and 0 < analytic.item() < 0.1
+    # point_point_distance against a dense torch evaluation
+    dd = torch.cdist(pred_pts[0][:2000], gt[0]).min(-1).values
+    got = mu.point_point_distance(pred_pts[:, :2000].contiguous(), gt)[0]
+    assert torch.allclose(got, torch.sqrt(dd ** 2 + 1e-10), rtol=1e-3, atol=1e-5)

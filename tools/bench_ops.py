@@ -89,8 +89,19 @@ def main():
     tg = gpu_time(lambda: hip_ops.nn_index(q_d, gt_d), reps=3)
     subq = 200
     tc = cpu_time(lambda: O.nn_index(q_d[:, :subq].cpu().numpy(), gt[None])) * (nq / subq)
-    emit(op="nn_index", n_query=nq, n_point=100000, gpu_ms=round(tg * 1e3, 3), cpu_ms=round(tc * 1e3, 1),
-         cpu_kind="port (extrapolated from %d queries)" % subq, cpu_cores=1, pairs_per_s=round(nq * 1e5 / tg / 1e9, 2), unit="G distance evals/s")
+    tb = gpu_time(lambda: hip_ops.nn_index(q_d, gt_d, brute=True), reps=3)
+    emit(op="nn_index", queries="uniform in the cube (far from the point cloud)", n_query=nq, n_point=100000, gpu_ms=round(tg * 1e3, 3),
+         gpu_brute_ms=round(tb * 1e3, 3), cpu_ms=round(tc * 1e3, 1), cpu_kind="port (extrapolated from %d queries)" % subq, cpu_cores=1,
+         pairs_per_s=round(nq * 1e5 / tg / 1e9, 2), unit="G nominal distance evals/s")
+    # the training-time distribution: 20 samples per predicted boundary face (deftet.py:174-177), i.e. queries ON a
+    # surface close to the ground-truth cloud
+    from deftet_amd.utils import mesh_utils as mu
+    qs = mu.sample_surf_point_batch(face_d[None], 20).reshape(1, -1, 3).contiguous()
+    tg2 = gpu_time(lambda: hip_ops.nn_index(qs, gt_d), reps=3)
+    tb2 = gpu_time(lambda: hip_ops.nn_index(qs, gt_d, brute=True), reps=3)
+    emit(op="nn_index", queries="20 samples per boundary face (training distribution)", n_query=int(qs.shape[1]), n_point=100000,
+         gpu_ms=round(tg2 * 1e3, 3), gpu_brute_ms=round(tb2 * 1e3, 3),
+         pairs_per_s=round(qs.shape[1] * 1e5 / tg2 / 1e9, 2), unit="G nominal distance evals/s")
 
     # rasterizer, BASELINE configs[4]
     from tests.test_raster_gpu import pixel_grid, projected_grid
