@@ -13,6 +13,7 @@
 // operation by operation in fp32 with FMA contraction off (the argmin / neighbour indices
 // are decided by exact fp32 comparisons), double-typed literals promoted as C++ does.
 #pragma clang fp contract(off)
+#include <cstdlib>
 #include <cstring>
 
 #include "common.hpp"
@@ -195,7 +196,32 @@ __global__ __launch_bounds__(256) void k_nn_query(const float *__restrict__ quer
         d += dz * dz;                                               // :46
         return d;
     };
-    // ---- phase 1: coarse shells
+    // ---- phase 0: tight upper bound from the 3x3x3 fine cells around the query (near queries)
+    float U = INFINITY;
+    {
+        int c[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float f = floorf((qq[k] - g.o[k]) * g.inv[k]);
+            f = fminf(fmaxf(f, -2.f), (float)(G + 1));
+            c[k] = (int)f;
+        }
+        const int x0 = max(c[0] - 1, 0), x1 = min(c[0] + 1, G - 1);
+        if (x0 <= x1)
+            for (int cz = max(c[2] - 1, 0); cz <= min(c[2] + 1, G - 1); ++cz)
+                for (int cy = max(c[1] - 1, 0); cy <= min(c[1] + 1, G - 1); ++cy) {
+                    const int row = (cz * G + cy) * G;
+                    const int s = start[row + x0], e = start[row + x1 + 1];
+                    for (int j = s; j < e; j += 4) {
+                        float4 p[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) p[k] = sorted[min(j + k, e - 1)];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) U = fminf(U, dist(p[k].x, p[k].y, p[k].z));
+                    }
+                }
+    }
+    // ---- phase 1: otherwise a loose bound from the coarse grid (one representative point per 4^3 cells)
     int cc[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -203,9 +229,8 @@ __global__ __launch_bounds__(256) void k_nn_query(const float *__restrict__ quer
         f = fminf(fmaxf(f, -1.f), (float)Gc);
         cc[k] = (int)f;
     }
-    float U = INFINITY;
-    for (int r = 0; r <= Gc + 1; ++r) {
-        bool any_cell = false;
+    constexpr int kCoarseRings = 1;                                  // beyond that the query is "far": streaming scan
+    for (int r = 0; r <= kCoarseRings && !(U < INFINITY); ++r) {
         for (int dz = -r; dz <= r; ++dz) {
             const int z = cc[2] + dz;
             if (z < 0 || z >= Gc) continue;
@@ -216,18 +241,18 @@ __global__ __launch_bounds__(256) void k_nn_query(const float *__restrict__ quer
                 for (int dx = -r; dx <= r; dx += (face ? 1 : (r > 0 ? 2 * r : 1))) {
                     const int x = cc[0] + dx;
                     if (x < 0 || x >= Gc) continue;
-                    any_cell = true;
                     const int i = rep[(z * Gc + y) * Gc + x];
                     if (i >= 0) U = fminf(U, dist(pts[i * 3], pts[i * 3 + 1], pts[i * 3 + 2]));
                 }
             }
         }
-        if (U < INFINITY) break;
-        if (!any_cell && r > Gc) break;
     }
     float best = 1e20f;                                             // :28
     int besti = 0;
-    if (!(U < INFINITY)) { result[q] = 0; return; }                  // no finite point at all (or all overflow to inf)
+    if (!(U < INFINITY)) {                                           // nothing within one coarse ring: far (or no finite point)
+        farList[atomicAdd(nFar, 1)] = q;
+        return;
+    }
     U = fminf(U, 1e20f);                                            // nothing farther than the initial best can win
     // ---- phase 2: rows intersecting the ball of radius R (inflated for fp32 rounding of d and of the cell map)
     const float R = sqrtf(U) * 1.00001f;
@@ -244,31 +269,12 @@ __global__ __launch_bounds__(256) void k_nn_query(const float *__restrict__ quer
         return fmaxf(fmaxf(l - qq[k], qq[k] - h), 0.f);
     };
     const float R2 = R * R;
-    // A query far from every point (large ball) would gather a sizeable part of the cloud at
-    // ~8x the per-point cost of the streaming scan: such queries are handed to k_nn_far instead.
-    {
-        const long long rows = (long long)(hi[2] - lo[2] + 1) * (hi[1] - lo[1] + 1);
-        bool far = rows > 4096;
-        if (!far && rows > 16) {
-            long long cand = 0;
-            for (int cz = lo[2]; cz <= hi[2]; ++cz) {
-                const float dz = slab(2, cz);
-                for (int cy = lo[1]; cy <= hi[1]; ++cy) {
-                    const float dy = slab(1, cy);
-                    const float rem = R2 - dy * dy - dz * dz;
-                    if (rem < 0.f) continue;
-                    const float rx = sqrtf(rem) * 1.00001f;
-                    const int x0 = nn_cell(qx - rx - g.slack[0], g.o[0], g.inv[0], G), x1 = nn_cell(qx + rx + g.slack[0], g.o[0], g.inv[0], G);
-                    const int row = (cz * G + cy) * G;
-                    cand += start[row + x1 + 1] - start[row + x0];
-                }
-            }
-            far = cand * 8 > (long long)M;
-        }
-        if (far) {
-            farList[atomicAdd(nFar, 1)] = q;
-            return;
-        }
+    // A query whose ball spans many cell rows pays a dependent lookup per row and gathers points at
+    // ~4x the per-point cost of the streaming scan (measured: 80k uniform queries against 100k
+    // points on a sphere, 12-16 ms through rows vs 5.5 ms streaming): hand it to k_nn_far.
+    if ((long long)(hi[2] - lo[2] + 1) * (hi[1] - lo[1] + 1) > 100) {
+        farList[atomicAdd(nFar, 1)] = q;
+        return;
     }
     for (int cz = lo[2]; cz <= hi[2]; ++cz) {
         const float dz = slab(2, cz);
@@ -280,11 +286,16 @@ __global__ __launch_bounds__(256) void k_nn_query(const float *__restrict__ quer
             const int x0 = nn_cell(qx - rx - g.slack[0], g.o[0], g.inv[0], G), x1 = nn_cell(qx + rx + g.slack[0], g.o[0], g.inv[0], G);
             const int row = (cz * G + cy) * G;
             const int s = start[row + x0], e = start[row + x1 + 1];
-            for (int j = s; j < e; ++j) {
-                const float4 p = sorted[j];
-                const float d = dist(p.x, p.y, p.z);
-                const int idx = __float_as_int(p.w);
-                if (d < best || (d == best && idx < besti && best < 1e20f)) { best = d; besti = idx; }
+            for (int j = s; j < e; j += 4) {                         // four gathers in flight per lane
+                float4 p[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) p[k] = sorted[min(j + k, e - 1)];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float d = dist(p[k].x, p[k].y, p[k].z);
+                    const int idx = __float_as_int(p[k].w);
+                    if (j + k < e && (d < best || (d == best && idx < besti && best < 1e20f))) { best = d; besti = idx; }
+                }
             }
         }
     }
