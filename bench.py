@@ -56,7 +56,10 @@ def step(d, world):
     g_tet, _, g_pred = hip_ops.point_in_tet_bwd(d["tet"], d["pts"], cond, d["gw"], grad_occ=d["gout"])
     loss = hip_ops.rowdot(w, d["gw"]) + hip_ops.rowdot(occ, d["gout"])         # [B] per-shape loss scalars
     if world > 1:
-        loss = sharding.all_gather_losses(loss, world * loss.shape[0])        # the only collective (RCCL)
+        if torch.distributed.get_backend() == "gloo":                         # single-GPU test hook: stage through the host
+            loss = sharding.all_gather_losses(loss.cpu(), world * loss.shape[0]).to(w.device)
+        else:
+            loss = sharding.all_gather_losses(loss, world * loss.shape[0])    # the only collective (RCCL over xGMI)
     return cond, w, g_tet, g_pred, loss
 
 
@@ -99,11 +102,22 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # DEFTET_BENCH_TEST_SHARED_GPU=1 is a TEST hook for single-GPU boxes: every rank uses cuda:0 and the
+    # (CPU-staged) collectives run over gloo, so the whole multi-process control flow can be exercised
+    # where only one GPU exists.  Real runs use one GPU per rank and RCCL ("nccl" backend).
+    shared = os.environ.get("DEFTET_BENCH_TEST_SHARED_GPU", "0") not in ("", "0")
+    dev_index = 0 if shared else local_rank
+    if dev_index >= torch.cuda.device_count():
+        raise SystemExit("rank %d wants cuda:%d but only %d device(s) are visible" % (rank, dev_index, torch.cuda.device_count()))
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if shared:
+            torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from deftet_amd import _lib
     lib = _lib.load()
@@ -131,7 +145,7 @@ def main():
     lib.deftet_profile_select(b"")
 
     if world > 1:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        t = torch.tensor([elapsed], device="cpu" if shared else device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
 
