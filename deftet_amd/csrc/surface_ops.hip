@@ -630,6 +630,260 @@ __global__ __launch_bounds__(256) void k_tri_dist_fwd(const float *__restrict__ 
     }
 }
 
+// --- A9 forward, grid-accelerated (exact) -------------------------------------------------------------
+// Faces are binned by bounding box into a uniform grid whose cells are about one mean face extent
+// wide; a point evaluates the reference formula only on the faces listed in the 3x3x3 (then 5x5x5)
+// cells around it, plus a "wide" list of faces that every point must see, and stops once the best
+// value is below a certified lower bound for every face it has not seen.  Faces on the wide list:
+// non-finite, spanning > 64 cells, |n| < 1e-5 (the reference's normalisation adds 1e-10 to |n|),
+// or nearly vertical (|k3| < |n|/64): for those the reference's xy-only inside test can misfire
+// and report a plane distance for a far-away point, so their value is not bounded below by the
+// true distance.  For every other face the reference value is the true squared distance up to
+// rounding, which is what the pruning bound needs.  Points that are not settled
+// within two shells go to the streaming scan (k_tri_far).  Results are combined lexicographically
+// (value, face index) == "first strict minimum of the ascending scan" (for.cu:300-303).
+constexpr int kTGMax = 64;             // cells per axis (upper bound)
+constexpr int kTMaxCells = 64;         // faces overlapping more cells go to the wide list
+constexpr int kTParts = 64;
+
+struct TGrid { float o[3], inv[3], cs[3], slack[3]; int g[3]; float abs_slack; };
+
+__device__ __forceinline__ bool face_regular(const float *fc, float &lox, float &loy, float &loz, float &hix, float &hiy, float &hiz)
+{
+    bool finite = true;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) finite = finite && (fabsf(fc[k]) <= 1048576.0f);
+    lox = fminf(fc[0], fminf(fc[3], fc[6])); hix = fmaxf(fc[0], fmaxf(fc[3], fc[6]));
+    loy = fminf(fc[1], fminf(fc[4], fc[7])); hiy = fmaxf(fc[1], fmaxf(fc[4], fc[7]));
+    loz = fminf(fc[2], fminf(fc[5], fc[8])); hiz = fmaxf(fc[2], fmaxf(fc[5], fc[8]));
+    const float r1[3] = {fc[3] - fc[0], fc[4] - fc[1], fc[5] - fc[2]}, r2[3] = {fc[6] - fc[0], fc[7] - fc[1], fc[8] - fc[2]};
+    const float nx = r1[1] * r2[2] - r1[2] * r2[1], ny = r1[2] * r2[0] - r1[0] * r2[2], nz = r1[0] * r2[1] - r1[1] * r2[0];
+    const float len = sqrtf(nx * nx + ny * ny + nz * nz);
+    const float k3 = (fc[4] - fc[7]) * (fc[0] - fc[6]) + (fc[6] - fc[3]) * (fc[1] - fc[7]);    // as cuda_line_distance computes it
+    return finite && len >= 1e-5f && fabsf(k3) * 64.0f >= len && fabsf(nz) * 64.0f >= len;
+}
+
+__global__ __launch_bounds__(256) void k_tri_face_stats(const float *__restrict__ face, const float *__restrict__ nfb, float *part)
+{
+    __shared__ float sh[4][8];
+    const int nf = (int)nfb[0];
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}, sw = 0.f, cnt = 0.f;
+    for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < nf; f += gridDim.x * blockDim.x) {
+        float fc[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) fc[k] = face[(size_t)f * 9 + k];
+        float a, b, c, d, e, g;
+        if (face_regular(fc, a, b, c, d, e, g)) {
+            lo[0] = fminf(lo[0], a); lo[1] = fminf(lo[1], b); lo[2] = fminf(lo[2], c);
+            hi[0] = fmaxf(hi[0], d); hi[1] = fmaxf(hi[1], e); hi[2] = fmaxf(hi[2], g);
+            sw += fmaxf(fmaxf(d - a, e - b), g - c);
+            cnt += 1.f;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = fminf(lo[k], __shfl_xor(lo[k], off));
+            hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off));
+        }
+        sw += __shfl_xor(sw, off);
+        cnt += __shfl_xor(cnt, off);
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { sh[w][k] = lo[k]; sh[w][3 + k] = hi[k]; }
+        sh[w][6] = sw; sh[w][7] = cnt;
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        const int k = threadIdx.x;
+        float v = sh[0][k];
+        for (int i = 1; i < 4; ++i) v = k < 3 ? fminf(v, sh[i][k]) : (k < 6 ? fmaxf(v, sh[i][k]) : v + sh[i][k]);
+        part[blockIdx.x * 8 + k] = v;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_tri_grid(const float *__restrict__ part, TGrid *gp)
+{
+    const int lane = threadIdx.x;
+    float lo[3], hi[3], sw = part[lane * 8 + 6], cnt = part[lane * 8 + 7];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { lo[k] = part[lane * 8 + k]; hi[k] = part[lane * 8 + 3 + k]; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = fminf(lo[k], __shfl_xor(lo[k], off));
+            hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off));
+        }
+        sw += __shfl_xor(sw, off);
+        cnt += __shfl_xor(cnt, off);
+    }
+    if (lane == 0) {
+        TGrid r;
+        const float meanw = cnt > 0.f ? sw / cnt : 0.f;
+        float diag2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const bool ok = hi[k] >= lo[k];
+            const float l = ok ? lo[k] : 0.f, h = ok ? hi[k] : 0.f, ext = h - l;
+            float n = (meanw > 0.f && ext > 0.f) ? ceilf(ext / meanw) : 1.f;
+            n = fminf(fmaxf(n, 1.f), (float)kTGMax);
+            r.g[k] = (int)n;
+            r.o[k] = l;
+            r.inv[k] = ext > 1e-30f ? n / ext : 0.f;
+            r.cs[k] = ext > 1e-30f ? ext / n : INFINITY;
+            r.slack[k] = 8e-6f * (fabsf(l) + fabsf(h)) + 1e-30f;
+            diag2 += (fabsf(l) + fabsf(h)) * (fabsf(l) + fabsf(h));
+        }
+        r.abs_slack = 1e-8f * diag2;                               // see the bound in k_tri_query
+        *gp = r;
+    }
+}
+
+__device__ __forceinline__ int t_cell(float x, float o, float inv, int G)
+{
+    float f = floorf((x - o) * inv);
+    f = fminf(fmaxf(f, 0.f), (float)(G - 1));
+    return (int)f;
+}
+
+// mode 0: count cells / append to the wide list; mode 1: fill the cell lists
+__global__ __launch_bounds__(256) void k_tri_face_bin(const float *__restrict__ face, const float *__restrict__ nfb,
+                                                      const TGrid *__restrict__ gp, int mode, int *cellCount,
+                                                      const int *__restrict__ cellStart, int *cellFill, int *list, int *wide,
+                                                      int *nWide)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= (int)nfb[0]) return;
+    const TGrid g = *gp;
+    float fc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) fc[k] = face[(size_t)f * 9 + k];
+    float lox, loy, loz, hix, hiy, hiz;
+    bool tiles = face_regular(fc, lox, loy, loz, hix, hiy, hiz);
+    int x0 = 0, x1 = 0, y0 = 0, y1 = 0, z0 = 0, z1 = 0;
+    if (tiles) {
+        x0 = t_cell(lox - g.slack[0], g.o[0], g.inv[0], g.g[0]); x1 = t_cell(hix + g.slack[0], g.o[0], g.inv[0], g.g[0]);
+        y0 = t_cell(loy - g.slack[1], g.o[1], g.inv[1], g.g[1]); y1 = t_cell(hiy + g.slack[1], g.o[1], g.inv[1], g.g[1]);
+        z0 = t_cell(loz - g.slack[2], g.o[2], g.inv[2], g.g[2]); z1 = t_cell(hiz + g.slack[2], g.o[2], g.inv[2], g.g[2]);
+        tiles = (x1 - x0 + 1) * (y1 - y0 + 1) * (z1 - z0 + 1) <= kTMaxCells;
+    }
+    if (!tiles) {
+        if (mode == 0) wide[atomicAdd(nWide, 1)] = f;
+        return;
+    }
+    for (int z = z0; z <= z1; ++z)
+        for (int y = y0; y <= y1; ++y)
+            for (int x = x0; x <= x1; ++x) {
+                const int c = (z * g.g[1] + y) * g.g[0] + x;
+                if (mode == 0) atomicAdd(&cellCount[c], 1);
+                else list[cellStart[c] + atomicAdd(&cellFill[c], 1)] = f;
+            }
+}
+
+__global__ __launch_bounds__(256) void k_tri_query(const float *__restrict__ pts, const float *__restrict__ face,
+                                                   const float *__restrict__ nfb, int P, const TGrid *__restrict__ gp,
+                                                   const int *__restrict__ cellStart, const int *__restrict__ list,
+                                                   const int *__restrict__ wide, const int *__restrict__ nWide, float *closest_d,
+                                                   float *closest_f, int *farList, int *nFar)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= P) return;
+    const TGrid g = *gp;
+    const float p[3] = {pts[q * 3], pts[q * 3 + 1], pts[q * 3 + 2]};
+    float min_d = 10000.0f;                                         // for.cu:277
+    int min_idx = -1;
+    const int nf = (int)nfb[0];
+    if (nf <= 0) { closest_d[q] = min_d; closest_f[q] = -1.0f; return; }
+    const bool tame = fabsf(p[0]) <= 1048576.0f && fabsf(p[1]) <= 1048576.0f && fabsf(p[2]) <= 1048576.0f;
+    if (!tame) { farList[atomicAdd(nFar, 1)] = q; return; }          // NaN / Inf / huge points: plain scan
+    auto eval = [&](int f) {
+        float fc[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) fc[k] = face[(size_t)f * 9 + k];
+        float ret[3] = {0.f, 0.f, 0.f}, ip[3];
+        const float dis = min_triangle_distance<false>(fc, fc + 3, fc + 6, p, ret, ip, 10000.0f);
+        if (min_d > dis || (min_d == dis && f < min_idx)) { min_d = dis; min_idx = f; }   // lexicographic (value, index)
+    };
+    const int nw = *nWide;
+    for (int j = 0; j < nw; ++j) eval(wide[j]);
+    int c[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float f = floorf((p[k] - g.o[k]) * g.inv[k]);
+        f = fminf(fmaxf(f, -3.f), (float)(g.g[k] + 2));             // virtual cell (outside the grid allowed)
+        c[k] = (int)f;
+    }
+    bool done = false;
+    for (int r = 1; r <= 2 && !done; ++r) {
+        // cells of the shell between box r-1 (already visited; r == 1: nothing) and box r
+        for (int dz = -r; dz <= r; ++dz) {
+            const int z = c[2] + dz;
+            if (z < 0 || z >= g.g[2]) continue;
+            for (int dy = -r; dy <= r; ++dy) {
+                const int y = c[1] + dy;
+                if (y < 0 || y >= g.g[1]) continue;
+                for (int dx = -r; dx <= r; ++dx) {
+                    if (r == 2 && abs(dz) < 2 && abs(dy) < 2 && abs(dx) < 2) continue;   // inner 3x3x3 done at r == 1
+                    const int x = c[0] + dx;
+                    if (x < 0 || x >= g.g[0]) continue;
+                    const int cell = (z * g.g[1] + y) * g.g[0] + x;
+                    const int s = cellStart[cell], e = cellStart[cell + 1];
+                    for (int j = s; j < e; ++j) eval(list[j]);
+                }
+            }
+        }
+        // every face not seen so far lies outside the box of cells [c-r, c+r]: distance >= m
+        float m = INFINITY;
+        bool more = false;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if (!(g.cs[k] < INFINITY)) continue;                     // flat axis: one slab
+            if (c[k] - r > 0) {
+                more = true;
+                m = fminf(m, fmaxf(p[k] - (g.o[k] + (float)(c[k] - r) * g.cs[k]) - g.slack[k], 0.f));
+            }
+            if (c[k] + r < g.g[k] - 1) {
+                more = true;
+                m = fminf(m, fmaxf((g.o[k] + (float)(c[k] + r + 1) * g.cs[k]) - p[k] - g.slack[k], 0.f));
+            }
+        }
+        if (!more) done = true;                                      // the box covers the grid: every listed face was seen
+        else if (min_d < (m * m) * 0.9998f - g.abs_slack) done = true;
+    }
+    if (!done) { farList[atomicAdd(nFar, 1)] = q; return; }
+    closest_d[q] = min_d;
+    closest_f[q] = (float)min_idx;
+}
+
+// points that were not settled by the grid: the streaming scan of k_tri_dist_fwd over the listed points
+__global__ __launch_bounds__(256) void k_tri_far(const float *__restrict__ pts, const float *__restrict__ face,
+                                                 const float *__restrict__ nfb, const int *__restrict__ farList,
+                                                 const int *__restrict__ nFar, float *closest_d, float *closest_f)
+{
+    const int n = *nFar;
+    if (blockIdx.x * blockDim.x >= n) return;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i < n;
+    const int q = farList[live ? i : 0];
+    const float p[3] = {pts[q * 3], pts[q * 3 + 1], pts[q * 3 + 2]};
+    const int nf = (int)nfb[0];
+    float min_d = 10000.0f;
+    int min_idx = -1;
+    for (int f = 0; f < nf; ++f) {
+        float fc[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) fc[k] = face[(size_t)f * 9 + k];   // wave-uniform -> scalar loads
+        float ret[3] = {0.f, 0.f, 0.f}, ip[3];
+        const float dis = min_triangle_distance<false>(fc, fc + 3, fc + 6, p, ret, ip, 10000.0f);
+        if (min_d > dis) { min_d = dis; min_idx = f; }
+    }
+    if (live) { closest_d[q] = min_d; closest_f[q] = (float)min_idx; }
+}
+
 // per-point gradient contributions of the backward kernel (back.cu:591-686): up to 9 values
 // for up to 3 vertices of the saved face.  Returns the number of (slot,value) pairs written.
 __device__ __forceinline__ int tri_dist_point_grad(const float *fc, const float *p, float gp, int *slot, float *val)
@@ -883,15 +1137,57 @@ extern "C" int deftet_face_edge_adj_f32(const float *face, float *adj, int F, in
     return DEFTET_OK;
 }
 
+extern "C" size_t deftet_tri_dist_workspace_bytes(int B, int P, int Fmax)
+{
+    const size_t nc = (size_t)kTGMax * kTGMax * kTGMax + 1;
+    const size_t F = (size_t)(Fmax > 0 ? Fmax : 0), Pn = (size_t)(P > 0 ? P : 0);
+    return nc * 4 * 3 + F * kTMaxCells * 4 + F * 4 + Pn * 4 + nc * 8 + ((size_t)2 << 20);
+}
+
+// workspace == NULL: the scalar-stream brute force; otherwise the grid search (both exact).
 extern "C" int deftet_tri_dist_fwd_f32(const float *pts, const float *face, const float *n_face_b, float *closest_d,
-                                       float *closest_f, int B, int P, int Fmax, void *stream_)
+                                       float *closest_f, int B, int P, int Fmax, void *workspace, size_t wsb, void *stream_)
 {
     DEFTET_CHECK_ARG(B >= 0 && P >= 0 && Fmax >= 0 && B <= 65535, "bad size");
     if (Fmax >= (1 << 24)) return set_error(DEFTET_ELIMIT, "n_face=%d does not fit a float-encoded index", Fmax);
     if (B == 0 || P == 0) return DEFTET_OK;
     DEFTET_CHECK_ARG(pts && n_face_b && closest_d && closest_f && (Fmax == 0 || face), "null pointer");
-    DEFTET_LAUNCH(k_tri_dist_fwd, dim3((P + 255) / 256, B), dim3(256), as_stream(stream_), pts, face, n_face_b, closest_d,
-                  closest_f, P, Fmax);
+    hipStream_t st = as_stream(stream_);
+    if (!workspace || Fmax == 0) {
+        DEFTET_LAUNCH(k_tri_dist_fwd, dim3((P + 255) / 256, B), dim3(256), st, pts, face, n_face_b, closest_d, closest_f, P, Fmax);
+        return DEFTET_OK;
+    }
+    DEFTET_CHECK_ARG(((uintptr_t)workspace & 255) == 0 && wsb >= deftet_tri_dist_workspace_bytes(B, P, Fmax),
+                     "workspace misaligned or too small");
+    DEFTET_CHECK_ARG((long long)Fmax * kTMaxCells < 2147483647LL && (long long)P * 3 < 2147483647LL, "too many faces / points");
+    const size_t nc = (size_t)kTGMax * kTGMax * kTGMax + 1;
+    Arena A(workspace, wsb);
+    float *part = A.take<float>(kTParts * 8);
+    TGrid *grid = A.take<TGrid>(1);
+    int *cnt = A.take<int>(nc), *start = A.take<int>(nc), *fill = A.take<int>(nc);
+    int *list = A.take<int>((size_t)Fmax * kTMaxCells + 1), *wide = A.take<int>((size_t)Fmax + 1);
+    int *farList = A.take<int>((size_t)P + 1), *counters = A.take<int>(8);
+    void *tmp = A.base + align_up(A.off, 256);
+    const size_t left = wsb - align_up(A.off, 256);
+    for (int b = 0; b < B; ++b) {
+        const float *pb = pts + (size_t)b * P * 3, *fb = face + (size_t)b * Fmax * 9, *nb = n_face_b + b;
+        DEFTET_HIP(hipMemsetAsync(cnt, 0, nc * 4, st));
+        DEFTET_HIP(hipMemsetAsync(fill, 0, nc * 4, st));
+        DEFTET_HIP(hipMemsetAsync(counters, 0, 32, st));
+        DEFTET_LAUNCH(k_tri_face_stats, dim3(kTParts), dim3(256), st, fb, nb, part);
+        DEFTET_LAUNCH(k_tri_grid, dim3(1), dim3(64), st, part, grid);
+        DEFTET_LAUNCH(k_tri_face_bin, dim3((Fmax + 255) / 256), dim3(256), st, fb, nb, grid, 0, cnt, start, fill, list, wide, counters);
+        size_t need = 0;
+        hipError_t e = rocprim::exclusive_scan(nullptr, need, cnt, start, 0, nc, rocprim::plus<int>(), st);
+        if (e != hipSuccess || need > left) return set_error(DEFTET_ELAUNCH, "exclusive_scan temp");
+        e = rocprim::exclusive_scan(tmp, need, cnt, start, 0, nc, rocprim::plus<int>(), st);
+        if (e != hipSuccess) return set_error(DEFTET_ELAUNCH, "exclusive_scan: %s", hipGetErrorString(e));
+        DEFTET_LAUNCH(k_tri_face_bin, dim3((Fmax + 255) / 256), dim3(256), st, fb, nb, grid, 1, cnt, start, fill, list, wide, counters);
+        DEFTET_LAUNCH(k_tri_query, dim3((P + 255) / 256), dim3(256), st, pb, fb, nb, P, grid, start, list, wide, counters,
+                      closest_d + (size_t)b * P, closest_f + (size_t)b * P, farList, counters + 1);
+        DEFTET_LAUNCH(k_tri_far, dim3((P + 255) / 256), dim3(256), st, pb, fb, nb, farList, counters + 1,
+                      closest_d + (size_t)b * P, closest_f + (size_t)b * P);
+    }
     return DEFTET_OK;
 }
 

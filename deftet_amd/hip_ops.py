@@ -238,7 +238,9 @@ def face_edge_adj(face_fx3x3, n_max_nei=30, brute=False):
     return adj
 
 
-def tri_dist_fwd(pts_bxpx3, face_bxfx3x3, n_face_b):
+def tri_dist_fwd(pts_bxpx3, face_bxfx3x3, n_face_b, brute=False):
+    """(closest_d, closest_f) f32 [B,P,1] — tet_analytic_distance_for.cu:256-307.
+    brute=True selects the streaming scan over all faces (kept for cross-checks)."""
     _lib.require_gpu(pts_bxpx3, face_bxfx3x3, n_face_b)
     lib = _lib.load()
     pts, face, nfb = _f32c(pts_bxpx3), _f32c(face_bxfx3x3), _f32c(n_face_b)
@@ -246,8 +248,10 @@ def tri_dist_fwd(pts_bxpx3, face_bxfx3x3, n_face_b):
     d = torch.zeros(B, P, 1, device=pts.device, dtype=torch.float32)                    # utils.py:44-45
     f = torch.zeros(B, P, 1, device=pts.device, dtype=torch.float32)
     with torch.cuda.device(pts.device):
+        ws = None if brute else _lib.workspace(pts.device, lib.deftet_tri_dist_workspace_bytes(B, P, face.shape[1]))
         _lib.check(lib.deftet_tri_dist_fwd_f32(_lib.ptr(pts), _lib.ptr(face), _lib.ptr(nfb), _lib.ptr(d), _lib.ptr(f), B, P,
-                                               face.shape[1], _lib.current_stream(pts.device)), "deftet_tri_dist_fwd_f32")
+                                               face.shape[1], _lib.ptr(ws), ws.numel() if ws is not None else 0,
+                                               _lib.current_stream(pts.device)), "deftet_tri_dist_fwd_f32")
     return d, f
 
 

@@ -173,9 +173,11 @@ int deftet_face_edge_adj_f32(const float *face_fx3x3, float *adj_fxm, int n_face
  * A9  point -> triangle-soup squared distance
  * replaces layers/DefTet/tet_analytic_distance_batch/tet_analytic_distance.cpp ->
  *          tet_analytic_distance_for.cu:256-334 / tet_analytic_distance_back.cu:591-715 */
+size_t deftet_tri_dist_workspace_bytes(int n_batch, int n_point, int n_max_face);
+/* workspace NULL: streaming scan over all faces; else exact uniform-grid search (same results). */
 int deftet_tri_dist_fwd_f32(const float *pts_bxpx3, const float *face_bxfx3x3, const float *n_face_b,
                             float *closest_d, float *closest_f, int n_batch, int n_point, int n_max_face,
-                            void *stream);
+                            void *workspace, size_t workspace_bytes, void *stream);
 /* dldface f32 [B,F,3,3] accumulates (zeroed by the wrapper, utils.py:65).  deterministic != 0:
  * contributions are reduced in point order per face instead of by floating-point atomics. */
 int deftet_tri_dist_bwd_f32(const float *pts_bxpx3, const float *face_bxfx3x3, const float *closest_f,

@@ -158,9 +158,11 @@ def test_tri_dist_forward_bit_exact(cuda, oracle, seed):
     pts, face = _tri_case(seed)
     nfb = np.array([face.shape[1]], np.float32)
     wd, wf = oracle.tri_dist_fwd(pts, face, nfb)
-    d, f = hip_ops.tri_dist_fwd(torch.from_numpy(pts).to(cuda), torch.from_numpy(face).to(cuda), torch.from_numpy(nfb).to(cuda))
-    assert np.array_equal(f.cpu().numpy(), wf)                       # argmin face: bit-exact
-    assert np.array_equal(d.cpu().numpy(), wd)                       # same op order, no FMA: bit-exact
+    for brute in (False, True):                                      # grid search and streaming scan
+        d, f = hip_ops.tri_dist_fwd(torch.from_numpy(pts).to(cuda), torch.from_numpy(face).to(cuda), torch.from_numpy(nfb).to(cuda),
+                                    brute=brute)
+        assert np.array_equal(f.cpu().numpy(), wf)                   # argmin face: bit-exact
+        assert np.array_equal(d.cpu().numpy(), wd)                   # same op order, no FMA: bit-exact
     # ragged batch: n_face_b limits the scan
     nfb2 = np.array([face.shape[1] // 3], np.float32)
     wd2, wf2 = oracle.tri_dist_fwd(pts, face, nfb2)
@@ -170,6 +172,58 @@ def test_tri_dist_forward_bit_exact(cuda, oracle, seed):
     # zero faces: distance stays 10000, index -1 (for.cu:277-278)
     d0, f0 = hip_ops.tri_dist_fwd(torch.from_numpy(pts).to(cuda), torch.from_numpy(face).to(cuda), torch.zeros(1, device=cuda))
     assert (d0 == 10000).all() and (f0 == -1).all()
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_tri_dist_grid_adversarial(cuda, oracle, seed):
+    """grid search == ascending scan on a triangle soup with vertical / sliver / tiny / huge /
+    non-finite / duplicated faces and points near, on, far from and outside everything"""
+    from deftet_amd import hip_ops
+    rng = np.random.default_rng(seed)
+    F, P = 900, 3000
+    cen = rng.uniform(-0.5, 0.5, (F, 1, 3))
+    face = (cen + rng.normal(0, 0.03, (F, 3, 3))).astype(np.float32)
+    face[:100, :, 2] = face[:100, :1, 2] + rng.normal(0, 1e-4, (100, 3)).astype(np.float32)     # nearly horizontal
+    face[100:200, :, 0] = face[100:200, :1, 0]                                                    # exactly vertical (k3 == 0)
+    face[200:260, :, 1] = face[200:260, :1, 1] + rng.normal(0, 1e-4, (60, 3)).astype(np.float32) # nearly vertical
+    face[260:300, 2] = face[260:300, 0] * 0.5 + face[260:300, 1] * 0.5 + np.float32(1e-6)        # slivers
+    face[300:310] = (face[300:310] - cen[300:310]) * 1e-4 + cen[300:310]                          # tiny faces (|n| < 1e-5)
+    face[310:313] = cen[310:313] + rng.normal(0, 2.0, (3, 3, 3))                                  # huge faces (wide list)
+    face[313, 0, 0] = np.nan
+    face[314, 1] = np.inf
+    face[315] = face[316]                                                                         # duplicates: lower index wins
+    face[317] = 0.0                                                                               # collapsed at the origin
+    if seed == 2:
+        face[:, :, 2] *= 1e-3                                                                     # almost planar soup (thin bbox)
+    pts = rng.uniform(-0.7, 0.7, (P, 3)).astype(np.float32)
+    w = rng.dirichlet([1, 1, 1], 300).astype(np.float32)
+    pts[:300] = (face[rng.integers(320, F, 300)] * w[:, :, None]).sum(1)                          # on faces
+    pts[300:400] = face[rng.integers(320, F, 100), rng.integers(0, 3, 100)]                       # on vertices
+    pts[400:500] = rng.uniform(-30, 30, (100, 3))                                                 # far away
+    pts[500] = np.nan
+    pts[501, 2] = np.inf
+    pts[502] = 3e6
+    pts[503] = 0.0
+    face, pts = face[None].astype(np.float32), pts[None].astype(np.float32)
+    for nf in (F, 500, 1):
+        nfb = np.array([nf], np.float32)
+        wd, wf = oracle.tri_dist_fwd(pts, face, nfb)
+        d, f = hip_ops.tri_dist_fwd(torch.from_numpy(pts).to(cuda), torch.from_numpy(face).to(cuda), torch.from_numpy(nfb).to(cuda))
+        assert np.array_equal(f.cpu().numpy(), wf)
+        assert np.array_equal(d.cpu().numpy(), wd, equal_nan=True)
+
+
+def test_tri_dist_grid_equals_scan_full_size(cuda):
+    """100k GT points x the res-70 sphere surface: the grid search must reproduce the streaming scan"""
+    from deftet_amd import hip_ops
+    face = torch.from_numpy(sphere_surface(70)).to(cuda)[None]
+    d = np.random.default_rng(3000).standard_normal((100000, 3))
+    gt = torch.from_numpy((0.3 * d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)).to(cuda)[None]
+    nfb = torch.tensor([float(face.shape[1])], device=cuda)
+    a = hip_ops.tri_dist_fwd(gt, face, nfb)
+    b = hip_ops.tri_dist_fwd(gt, face, nfb, brute=True)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert a[0].max().item() < 1e-3 and (a[1] >= 0).all()
 
 
 @pytest.mark.parametrize("seed", [0, 1])

@@ -71,14 +71,16 @@ def main():
     face_d, gt_d = torch.from_numpy(face).to(dev), torch.from_numpy(gt).to(dev)[None]
     nfb = torch.tensor([float(F)], device=dev)
     tg = gpu_time(lambda: hip_ops.face_edge_adj(face_d, 30))
+    tgb = gpu_time(lambda: hip_ops.face_edge_adj(face_d, 30, brute=True))
     sub = min(F, 2000)
     tc = cpu_time(lambda: O.face_edge_adj(face[:sub], 30)) * (F / sub) ** 2
-    emit(op="face_edge_adj", n_face=F, gpu_ms=round(tg * 1e3, 3), cpu_ms=round(tc * 1e3, 1), cpu_kind="port (extrapolated from %d faces, O(F^2))" % sub,
+    emit(op="face_edge_adj", n_face=F, gpu_ms=round(tg * 1e3, 3), gpu_brute_ms=round(tgb * 1e3, 3), cpu_ms=round(tc * 1e3, 1), cpu_kind="port (extrapolated from %d faces, O(F^2))" % sub,
          cpu_cores=1, pairs_per_s=round(F * F / tg / 1e9, 2), unit="G face pairs/s")
     tg = gpu_time(lambda: hip_ops.tri_dist_fwd(gt_d, face_d[None], nfb), reps=3)
     subp = 500
     tc = cpu_time(lambda: O.tri_dist_fwd(gt[None, :subp], face[None], np.array([F], np.float32))) * (100000 / subp)
-    emit(op="tri_dist_fwd", n_face=F, n_point=100000, gpu_ms=round(tg * 1e3, 3), cpu_ms=round(tc * 1e3, 1),
+    tbr = gpu_time(lambda: hip_ops.tri_dist_fwd(gt_d, face_d[None], nfb, brute=True), reps=3)
+    emit(op="tri_dist_fwd", n_face=F, n_point=100000, gpu_ms=round(tg * 1e3, 3), gpu_brute_ms=round(tbr * 1e3, 3), cpu_ms=round(tc * 1e3, 1),
          cpu_kind="port (extrapolated from %d points)" % subp, cpu_cores=1, pairs_per_s=round(F * 1e5 / tg / 1e9, 2), unit="G point-triangle pairs/s")
     dd, ff = hip_ops.tri_dist_fwd(gt_d, face_d[None], nfb)
     gg = torch.ones_like(dd)
