@@ -49,11 +49,12 @@ def make_inputs(rank, device, res=RES, n_query=N_QUERY, batch=BATCH):
 
 
 def step(d, world):
-    """fwd: index + weights + fused paste_occ gather; bwd: dL/dtet and dL/dpred from one
-    per-tet gather pass; then the per-shape loss scalars (all-gathered when world > 1)."""
+    """fwd: index + weights + fused paste_occ gather (+ per-tet hit records); bwd: dL/dtet and
+    dL/dpred from one per-tet pass over those records (no atomics); then the per-shape loss
+    scalars (all-gathered when world > 1).  Same calls as the PointInTetOcc autograd op makes."""
     from deftet_amd import hip_ops, sharding
-    cond, w, occ = hip_ops.point_in_tet(d["tet"], d["pts"], want_bary=True, pred_bxt=d["pred"])
-    g_tet, _, g_pred = hip_ops.point_in_tet_bwd(d["tet"], d["pts"], cond, d["gw"], grad_occ=d["gout"])
+    cond, w, occ, hits = hip_ops.point_in_tet(d["tet"], d["pts"], want_bary=True, pred_bxt=d["pred"], want_hits=True)
+    g_tet, _, g_pred = hip_ops.point_in_tet_bwd(d["tet"], d["pts"], cond, d["gw"], grad_occ=d["gout"], hits=hits)
     loss = hip_ops.rowdot(w, d["gw"]) + hip_ops.rowdot(occ, d["gout"])         # [B] per-shape loss scalars
     if world > 1:
         if torch.distributed.get_backend() == "gloo":                         # single-GPU test hook: stage through the host

@@ -23,9 +23,10 @@ SIGNATURES = {
     "deftet_profile_select": (_i, [C.c_char_p]),
     "deftet_profile_read": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
     "deftet_point_in_tet_workspace_bytes": (_sz, [_i, _i, _i, _i]),
-    "deftet_point_in_tet_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "deftet_point_in_tet_hits_ints": (_sz, [_i, _i, _i]),
+    "deftet_point_in_tet_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "deftet_point_in_tet_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
-    "deftet_point_in_tet_bwd_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "deftet_point_in_tet_bwd_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "deftet_paste_occ_fwd_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "deftet_paste_occ_bwd_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "deftet_rowdot_workspace_bytes": (_sz, [_i]),

@@ -34,6 +34,16 @@ constexpr float kWMin = 9.3132257e-10f;      // 2^-30
 constexpr int kMiss = 0x7F7F7F7F;            // result sentinel (> any tet index)
 constexpr int kChunk = 2048;                 // cells per scan chunk
 constexpr int kMaxG = 96;
+constexpr int kHitOverflow = -2;            // hits[.].w: this tet has accepted queries that are not recorded
+
+// "hit record" buffer written by the forward and consumed by the backward (int32 words):
+//   [0, 4*B*T)            int4 per tet: the (<= 4) queries the tet accepted, or w == kHitOverflow
+//   [4*B*T, +kHitPad)     per shape: number of uncovered queries
+//   [.., + B*Q)           per shape: uncovered queries = hits that are NOT in their tet's record
+//                         (tet overflowed / irregular tet / NaN-Inf-huge query)
+constexpr int kHitPad = 64;
+__host__ __device__ inline size_t hit_cnt_off(int B, int T) { return (size_t)B * T * 4; }
+__host__ __device__ inline size_t hit_list_off(int B, int T) { return (size_t)B * T * 4 + (size_t)((B + kHitPad - 1) / kHitPad) * kHitPad; }
 constexpr int kXFine = 4;                   // cells are kXFine times finer along x (the run direction)
 
 // ------------------------------------------------------------------------------------
@@ -327,7 +337,7 @@ __global__ __launch_bounds__(256) void k_query_scatter(const float *__restrict__
 __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan(const float *__restrict__ tet, int T, int Q,
                                                   const float *__restrict__ gparam, int G, int Gx, const int *__restrict__ cells,
                                                   long long cellStride, const float4 *__restrict__ sortedQ, int *result, int *counters,
-                                                  int *irregT)
+                                                  int *irregT, int4 *hits)
 {
     const int b = blockIdx.y;
     // XCD-aware mapping (workgroup i is observed to run on XCD i % 8, each XCD has a private
@@ -364,9 +374,15 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan(const float *__rest
     float mn = fminf(fminf(fabsf(P.dv[0]), fabsf(P.dv[1])), fminf(fabsf(P.dv[2]), fabsf(P.dv[3])));
     bool regular = finite && (P.sv == 0u || P.sv == 15u) && (w >= kWMin) && (mn >= kTau * ((w * w) * w));
     // sv==0 with a zero dotv4 is excluded by mn >= tau*w^3 > 0
+    // hits[b,t] (optional): the queries this tet ACCEPTED (up to 4; w == kHitOverflow marks "more
+    // than fit / not recorded") — the backward filters them by condition == t, so no per-hit
+    // atomics or linked lists are needed there.
+    int4 hrec = make_int4(-1, -1, -1, -1);
+    int hcnt = 0;
     if (!regular) {
         int k = atomicAdd(&counters[b * 4 + 0], 1);
         irregT[(size_t)b * T + k] = t;
+        if (hits) hits[(size_t)b * T + t] = make_int4(-1, -1, -1, kHitOverflow);   // accepted by k_irreg, not recorded
         return;
     }
     const Grid g = load_grid(gparam + b * 12);
@@ -378,8 +394,10 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan(const float *__rest
         ehi[k] = hi[k] + m;
     }
     // no regular query can lie in the enlarged box -> nothing to do
-    if (ehi[0] < g.lo[0] || elo[0] > g.hi[0] || ehi[1] < g.lo[1] || elo[1] > g.hi[1] || ehi[2] < g.lo[2] || elo[2] > g.hi[2])
+    if (ehi[0] < g.lo[0] || elo[0] > g.hi[0] || ehi[1] < g.lo[1] || elo[1] > g.hi[1] || ehi[2] < g.lo[2] || elo[2] > g.hi[2]) {
+        if (hits) hits[(size_t)b * T + t] = hrec;
         return;
+    }
     const int cx0 = cell_of(elo[0], g.o[0], g.inv[0], Gx), cx1 = cell_of(ehi[0], g.o[0], g.inv[0], Gx);
     const int cy0 = cell_of(elo[1], g.o[1], g.inv[1], G), cy1 = cell_of(ehi[1], g.o[1], g.inv[1], G);
     const int cz0 = cell_of(elo[2], g.o[2], g.inv[2], G), cz1 = cell_of(ehi[2], g.o[2], g.inv[2], G);
@@ -396,7 +414,15 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan(const float *__rest
 #elif defined(PIT_EXP_NO_STORE)
             if (accept(P, q.x, q.y, q.z)) asm volatile("" ::"v"(t));
 #else
-            if (accept(P, q.x, q.y, q.z)) atomicMin(&res[__float_as_int(q.w)], t);
+            if (accept(P, q.x, q.y, q.z)) {
+                const int qi = __float_as_int(q.w);
+                atomicMin(&res[qi], t);
+                if (hcnt == 0) hrec.x = qi;
+                else if (hcnt == 1) hrec.y = qi;
+                else if (hcnt == 2) hrec.z = qi;
+                else if (hcnt == 3) hrec.w = qi;
+                ++hcnt;
+            }
 #endif
         }
     };
@@ -424,6 +450,10 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan(const float *__rest
         }
         if (!more) break;
         s = s2; e = e2; cy = ny; cz = nz;
+    }
+    if (hits) {
+        if (hcnt > 4) hrec.w = kHitOverflow;
+        hits[(size_t)b * T + t] = hrec;
     }
 }
 
@@ -497,7 +527,8 @@ __device__ __forceinline__ float triple(const float *a, const float *b, const fl
 
 __global__ __launch_bounds__(256) void k_finalize(const float *__restrict__ tet, const float *__restrict__ pts, int T,
                                                   int Q, const int *__restrict__ result, float *cond, float *bary,
-                                                  const float *__restrict__ pred, float *occ)
+                                                  const float *__restrict__ pred, float *occ, const int4 *__restrict__ hits,
+                                                  int *ucount, int *ulist)
 {
     const int b = blockIdx.y;
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
@@ -507,6 +538,13 @@ __global__ __launch_bounds__(256) void k_finalize(const float *__restrict__ tet,
     const bool hit = r != kMiss;
     cond[i] = hit ? (float)r : -1.0f;                               // :177, :149
     if (occ) occ[i] = pred[(size_t)b * T + (hit ? r : 0)];          // paste_occ: misses alias tet 0 (deftet.py:133-135)
+    if (hits && hit) {
+        // is this hit in its tet's record?  (not if the tet overflowed / is irregular, or if the
+        // query took the irregular-query side path, which records nothing)
+        const float *pq = pts + i * 3;
+        const bool covered = query_regular(pq[0], pq[1], pq[2]) && hits[(size_t)b * T + r].w != kHitOverflow;
+        if (!covered) ulist[(size_t)b * Q + atomicAdd(&ucount[b], 1)] = q;
+    }
     if (!bary) return;
     float4 wq = make_float4(0.f, 0.f, 0.f, 0.f);
     if (hit) {
@@ -761,6 +799,138 @@ __global__ __launch_bounds__(256) void k_bary_bwd_gather(const float *__restrict
     dst[0] = o0; dst[1] = o1; dst[2] = o2;
 }
 
+// --- backward from the forward's hit records: no atomics, no lists, no memsets ---------------------
+// per-block partial sums of the paste_occ gradient of the misses (they alias tet 0, deftet.py:133)
+constexpr int kMissParts = 64;
+__global__ __launch_bounds__(256) void k_miss_sum(const float *__restrict__ cond, const float *__restrict__ gocc, int Q, float *part)
+{
+    __shared__ float wsum[4];
+    const int b = blockIdx.y;
+    float gm = 0.f;
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < Q; q += gridDim.x * blockDim.x)
+        if (cond[(size_t)b * Q + q] < 0.f) gm += gocc[(size_t)b * Q + q];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) gm += __shfl_xor(gm, off);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = gm;
+    __syncthreads();
+    if (threadIdx.x == 0) part[b * kMissParts + blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+
+struct TetGrad {
+    float A[3], Bv[3];
+    float na[3], nb[3], nc[3], nd[3];
+    float v6;
+};
+__device__ __forceinline__ void tet_grad_setup(const float *__restrict__ tet, size_t i, TetGrad &g)
+{
+    const float4 *src = reinterpret_cast<const float4 *>(tet + i * 12);
+    const float4 t0 = src[0], t1 = src[1], t2 = src[2];
+    const float C[3] = {t1.z, t1.w, t2.x}, D[3] = {t2.y, t2.z, t2.w};
+    g.A[0] = t0.x; g.A[1] = t0.y; g.A[2] = t0.z; g.Bv[0] = t0.w; g.Bv[1] = t1.x; g.Bv[2] = t1.y;
+    float vab[3], vac[3], vad[3], vbc[3], vbd[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        vab[k] = g.Bv[k] - g.A[k]; vac[k] = C[k] - g.A[k]; vad[k] = D[k] - g.A[k];
+        vbc[k] = C[k] - g.Bv[k]; vbd[k] = D[k] - g.Bv[k];
+    }
+    cross3(vbd, vbc, g.na);
+    cross3(vac, vad, g.nb);
+    cross3(vad, vab, g.nc);
+    cross3(vab, vac, g.nd);
+    g.v6 = 1.0f / (vab[0] * g.nb[0] + vab[1] * g.nb[1] + vab[2] * g.nb[2]);
+}
+// contribution of one hit query to its tet's 12 gradient components; returns dL/dp in G3
+__device__ __forceinline__ void tet_grad_add(const TetGrad &g, const float *pp, const float4 gw, float *acc, float *G3)
+{
+    float vap[3], vbp[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { vap[k] = pp[k] - g.A[k]; vbp[k] = pp[k] - g.Bv[k]; }
+    float w[4];
+    w[0] = (vbp[0] * g.na[0] + vbp[1] * g.na[1] + vbp[2] * g.na[2]) * g.v6;
+    w[1] = (vap[0] * g.nb[0] + vap[1] * g.nb[1] + vap[2] * g.nb[2]) * g.v6;
+    w[2] = (vap[0] * g.nc[0] + vap[1] * g.nc[1] + vap[2] * g.nc[2]) * g.v6;
+    w[3] = (vap[0] * g.nd[0] + vap[1] * g.nd[1] + vap[2] * g.nd[2]) * g.v6;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) G3[k] = (gw.x * g.na[k] + gw.y * g.nb[k] + gw.z * g.nc[k] + gw.w * g.nd[k]) * g.v6;
+#pragma unroll
+    for (int vtx = 0; vtx < 4; ++vtx)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) acc[vtx * 3 + k] += -w[vtx] * G3[k];
+}
+
+__global__ __launch_bounds__(256) void k_bary_bwd_hits(const float *__restrict__ tet, const float *__restrict__ pts,
+                                                       const float *__restrict__ cond, const float *__restrict__ grad_w,
+                                                       const int4 *__restrict__ hits, int T, int Q, float *grad_tet,
+                                                       float *grad_pts, int accumulate, const float *__restrict__ gocc,
+                                                       const float *__restrict__ missPart, float *grad_pred)
+{
+    const int b = blockIdx.y;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    float acc[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) acc[k] = 0.f;
+    float gp = 0.f;
+    if (grad_pred && t == 0)
+        for (int k = 0; k < kMissParts; ++k) gp += missPart[b * kMissParts + k];     // clamped misses paste from tet 0
+    const int4 h = hits[(size_t)b * T + t];
+    if (h.x >= 0 && h.w != kHitOverflow) {                         // slots fill in order: x < 0 means no accepted query
+        TetGrad g;
+        tet_grad_setup(tet, (size_t)b * T + t, g);
+        const int hq[4] = {h.x, h.y, h.z, h.w};
+        const float tf = (float)t;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int q = hq[k];
+            if (q < 0) continue;
+            const size_t i = (size_t)b * Q + q;
+            if (cond[i] != tf) continue;                           // accepted here, but a lower-index tet won the query
+            float G3[3];
+            tet_grad_add(g, pts + i * 3, reinterpret_cast<const float4 *>(grad_w)[i], acc, G3);
+            if (grad_pts) { grad_pts[i * 3] = G3[0]; grad_pts[i * 3 + 1] = G3[1]; grad_pts[i * 3 + 2] = G3[2]; }
+            if (grad_pred) gp += gocc[i];
+        }
+    }
+    if (grad_pred) grad_pred[(size_t)b * T + t] = accumulate ? grad_pred[(size_t)b * T + t] + gp : gp;
+    float4 *dst = reinterpret_cast<float4 *>(grad_tet + ((size_t)b * T + t) * 12);
+    float4 o0 = make_float4(acc[0], acc[1], acc[2], acc[3]), o1 = make_float4(acc[4], acc[5], acc[6], acc[7]),
+           o2 = make_float4(acc[8], acc[9], acc[10], acc[11]);
+    if (accumulate) {
+        float4 p0 = dst[0], p1 = dst[1], p2 = dst[2];
+        o0.x += p0.x; o0.y += p0.y; o0.z += p0.z; o0.w += p0.w;
+        o1.x += p1.x; o1.y += p1.y; o1.z += p1.z; o1.w += p1.w;
+        o2.x += p2.x; o2.y += p2.y; o2.z += p2.z; o2.w += p2.w;
+    }
+    dst[0] = o0; dst[1] = o1; dst[2] = o2;
+}
+
+// the (normally empty) list of hits that are not in any tet record: float atomics, after k_bary_bwd_hits
+__global__ __launch_bounds__(256) void k_bary_bwd_uncovered(const float *__restrict__ tet, const float *__restrict__ pts,
+                                                            const float *__restrict__ cond, const float *__restrict__ grad_w,
+                                                            const int *__restrict__ ucount, const int *__restrict__ ulist, int T,
+                                                            int Q, float *grad_tet, float *grad_pts,
+                                                            const float *__restrict__ gocc, float *grad_pred)
+{
+    const int b = blockIdx.y;
+    const int n = ucount[b];
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        const int q = ulist[(size_t)b * Q + k];
+        const size_t i = (size_t)b * Q + q;
+        const int t = (int)cond[i];
+        TetGrad g;
+        tet_grad_setup(tet, (size_t)b * T + t, g);
+        float acc[12], G3[3];
+#pragma unroll
+        for (int j = 0; j < 12; ++j) acc[j] = 0.f;
+        tet_grad_add(g, pts + i * 3, reinterpret_cast<const float4 *>(grad_w)[i], acc, G3);
+        float *gt = grad_tet + ((size_t)b * T + t) * 12;
+#pragma unroll
+        for (int j = 0; j < 12; ++j) unsafeAtomicAdd(gt + j, acc[j]);
+        if (grad_pts) { grad_pts[i * 3] = G3[0]; grad_pts[i * 3 + 1] = G3[1]; grad_pts[i * 3 + 2] = G3[2]; }
+        if (grad_pred) unsafeAtomicAdd(&grad_pred[(size_t)b * T + t], gocc[i]);
+    }
+}
+
 // paste_occ, layers/DefTet/deftet.py:132-136
 __global__ __launch_bounds__(256) void k_paste_fwd(const float *__restrict__ pred, float *cond, float *out, int T, int Q,
                                                    int clamp_inplace)
@@ -866,10 +1036,17 @@ extern "C" size_t deftet_point_in_tet_workspace_bytes(int B, int T, int Q, int a
     return make_layout(B, T, Q, algo, nullptr, 0).bytes;
 }
 
-extern "C" int deftet_point_in_tet_f32(const float *tet, const float *pts, float *cond, float *bary, const float *pred,
-                                       float *occ, int B, int T, int Q, int algo, void *workspace, size_t workspace_bytes,
-                                       void *stream_)
+extern "C" size_t deftet_point_in_tet_hits_ints(int B, int T, int Q)
 {
+    if (B <= 0 || T < 0 || Q < 0) return 0;
+    return hit_list_off(B, T) + (size_t)B * Q;
+}
+
+extern "C" int deftet_point_in_tet_f32(const float *tet, const float *pts, float *cond, float *bary, const float *pred,
+                                       float *occ, int32_t *hit_buf, int B, int T, int Q, int algo, void *workspace,
+                                       size_t workspace_bytes, void *stream_)
+{
+    DEFTET_CHECK_ARG(!hit_buf || (((uintptr_t)hit_buf & 15) == 0 && algo == DEFTET_PIT_AUTO), "hit_buf must be 16-byte aligned and needs DEFTET_PIT_AUTO");
     DEFTET_CHECK_ARG((pred == nullptr) == (occ == nullptr), "pred and occ must be given together");
     DEFTET_CHECK_ARG(!occ || T > 0, "paste_occ needs at least one tet");
     DEFTET_CHECK_ARG(B >= 0 && T >= 0 && Q >= 0, "negative size (B=%d T=%d Q=%d)", B, T, Q);
@@ -885,6 +1062,7 @@ extern "C" int deftet_point_in_tet_f32(const float *tet, const float *pts, float
     Layout L = make_layout(B, T, Q, algo, workspace, workspace_bytes);
     DEFTET_CHECK_ARG(L.bytes <= workspace_bytes, "workspace too small: need %zu bytes, got %zu", L.bytes, workspace_bytes);
     hipStream_t st = as_stream(stream_);
+    if (hit_buf) DEFTET_HIP(hipMemsetAsync(hit_buf + hit_cnt_off(B, T), 0, (hit_list_off(B, T) - hit_cnt_off(B, T)) * 4, st));
     const dim3 blk(256);
     const dim3 gq((Q + 255) / 256, B), gt((((T + 255) / 256 + 7) / 8) * 8, B);   // gt: multiple of 8 for the XCD mapping
 
@@ -908,14 +1086,15 @@ extern "C" int deftet_point_in_tet_f32(const float *tet, const float *pts, float
         DEFTET_LAUNCH(k_query_scatter, gq, blk, st, pts, Q, L.qcell, L.cells, L.cellStride, L.sortedQ);
         if (T > 0) {
             DEFTET_LAUNCH(k_tet_scan, gt, blk, st, tet, T, Q, L.gparam, L.G, L.Gx, L.cells, L.cellStride, L.sortedQ, L.result,
-                          L.counters, L.irregT);
+                          L.counters, L.irregT, (int4 *)hit_buf);
             int qb = (Q + 255) / 256, tb = (T + 255) / 256;
             if (qb > 1024) qb = 1024;
             if (tb > 1024) tb = 1024;
             DEFTET_LAUNCH(k_irreg, dim3(qb > tb ? qb : tb, B, 2), blk, st, tet, pts, T, Q, L.counters, L.irregT, L.irregQ, L.result);
         }
     }
-    DEFTET_LAUNCH(k_finalize, gq, blk, st, tet, pts, T, Q, L.result, cond, bary, pred, occ);
+    DEFTET_LAUNCH(k_finalize, gq, blk, st, tet, pts, T, Q, L.result, cond, bary, pred, occ, (const int4 *)hit_buf,
+                  hit_buf ? hit_buf + hit_cnt_off(B, T) : nullptr, hit_buf ? hit_buf + hit_list_off(B, T) : nullptr);
     return DEFTET_OK;
 }
 
@@ -926,8 +1105,9 @@ extern "C" size_t deftet_point_in_tet_bwd_workspace_bytes(int B, int T, int Q)
 }
 
 extern "C" int deftet_point_in_tet_bwd_f32(const float *tet, const float *pts, const float *cond, const float *grad_w,
-                                           float *grad_tet, float *grad_pts, const float *grad_occ, float *grad_pred, int B,
-                                           int T, int Q, int accumulate, void *workspace, size_t workspace_bytes, void *stream_)
+                                           float *grad_tet, float *grad_pts, const float *grad_occ, float *grad_pred,
+                                           const int32_t *hit_buf, int B, int T, int Q, int accumulate, void *workspace,
+                                           size_t workspace_bytes, void *stream_)
 {
     DEFTET_CHECK_ARG(B >= 0 && T >= 0 && Q >= 0, "negative size");
     DEFTET_CHECK_ARG(B <= 65535, "n_batch=%d exceeds 65535", B);
@@ -945,7 +1125,20 @@ extern "C" int deftet_point_in_tet_bwd_f32(const float *tet, const float *pts, c
     }
     DEFTET_CHECK_ARG(tet && pts && cond && grad_w, "null pointer");
     DEFTET_CHECK_ARG(((uintptr_t)tet & 15) == 0 && ((uintptr_t)grad_w & 15) == 0, "tet/grad_w must be 16-byte aligned");
-    if (workspace) {
+    if (hit_buf) {
+        // fastest path: the forward's hit records (needs only kMissParts floats per shape of workspace)
+        DEFTET_CHECK_ARG(((uintptr_t)hit_buf & 15) == 0, "hit_buf must be 16-byte aligned");
+        float *missPart = nullptr;
+        if (grad_pred) {
+            DEFTET_CHECK_ARG(workspace && workspace_bytes >= (size_t)B * kMissParts * 4, "workspace needed for the miss sums");
+            missPart = static_cast<float *>(workspace);
+            DEFTET_LAUNCH(k_miss_sum, dim3(kMissParts, B), dim3(256), st, cond, grad_occ, Q, missPart);
+        }
+        DEFTET_LAUNCH(k_bary_bwd_hits, dim3((T + 255) / 256, B), dim3(256), st, tet, pts, cond, grad_w, (const int4 *)hit_buf, T,
+                      Q, grad_tet, grad_pts, accumulate, grad_occ, missPart, grad_pred);
+        DEFTET_LAUNCH(k_bary_bwd_uncovered, dim3(64, B), dim3(256), st, tet, pts, cond, grad_w, hit_buf + hit_cnt_off(B, T),
+                      hit_buf + hit_list_off(B, T), T, Q, grad_tet, grad_pts, grad_occ, grad_pred);
+    } else if (workspace) {
         const size_t need = deftet_point_in_tet_bwd_workspace_bytes(B, T, Q);
         DEFTET_CHECK_ARG(workspace_bytes >= need && ((uintptr_t)workspace & 255) == 0,
                          "backward workspace too small (%zu < %zu) or misaligned", workspace_bytes, need);

@@ -18,11 +18,12 @@ def _f32c(t):
 
 
 # --------------------------------------------------------------------------------- A1
-def point_in_tet(tet_bxtx4x3, pts_bxqx3, want_bary=False, algo=PIT_AUTO, pred_bxt=None):
+def point_in_tet(tet_bxtx4x3, pts_bxqx3, want_bary=False, algo=PIT_AUTO, pred_bxt=None, want_hits=False):
     """cond f32 [B,Q,1] (lowest containing tet index or -1); with want_bary also the barycentric
     weights f32 [B,Q,4] of the hit tet; with pred_bxt also occ f32 [B,Q] = the fused
     DefTet.paste_occ gather pred[b, max(index, 0)].  Returns cond | (cond, bary) | (cond, bary, occ)
-    | (cond, occ) depending on what was asked for."""
+    | (cond, occ) depending on what was asked for; want_hits appends the opaque int32 hit-record
+    buffer that makes point_in_tet_bwd atomic-free."""
     _lib.require_gpu(tet_bxtx4x3, pts_bxqx3, pred_bxt)
     lib = _lib.load()
     tet, pts = _f32c(tet_bxtx4x3), _f32c(pts_bxqx3)
@@ -38,19 +39,23 @@ def point_in_tet(tet_bxtx4x3, pts_bxqx3, want_bary=False, algo=PIT_AUTO, pred_bx
     if pred is not None and pred.shape != (B, T):
         raise RuntimeError("pred_tet_occ must be [B,T], got %s" % (tuple(pred.shape),))
     occ = torch.empty(B, Q, device=dev, dtype=torch.float32) if pred is not None else None
+    hits = None
+    if want_hits and algo == PIT_AUTO:
+        hits = torch.empty(max(lib.deftet_point_in_tet_hits_ints(B, T, Q), 4), device=dev, dtype=torch.int32)
     with torch.cuda.device(dev):
         nbytes = lib.deftet_point_in_tet_workspace_bytes(B, T, Q, algo)
         ws = _lib.workspace(dev, nbytes)
         _lib.check(lib.deftet_point_in_tet_f32(_lib.ptr(tet), _lib.ptr(pts), _lib.ptr(cond), _lib.ptr(bary), _lib.ptr(pred),
-                                               _lib.ptr(occ), B, T, Q, algo, _lib.ptr(ws), ws.numel(),
+                                               _lib.ptr(occ), _lib.ptr(hits), B, T, Q, algo, _lib.ptr(ws), ws.numel(),
                                                _lib.current_stream(dev)), "deftet_point_in_tet_f32")
-    out = (cond,) + ((bary,) if want_bary else ()) + ((occ,) if pred is not None else ())
+    out = (cond,) + ((bary,) if want_bary else ()) + ((occ,) if pred is not None else ()) + ((hits,) if want_hits else ())
     return out if len(out) > 1 else cond
 
 
-def point_in_tet_bwd(tet_bxtx4x3, pts_bxqx3, cond, grad_w, want_grad_pts=False, grad_occ=None):
+def point_in_tet_bwd(tet_bxtx4x3, pts_bxqx3, cond, grad_w, want_grad_pts=False, grad_occ=None, hits=None):
     """(grad_tet [B,T,4,3], grad_pts [B,Q,3] | None) and, when grad_occ [B,Q] is given, also
-    grad_pred [B,T] (fused paste_occ backward)."""
+    grad_pred [B,T] (fused paste_occ backward).  `hits` = the forward's hit-record buffer (same
+    tet/pts/cond): selects the atomic-free path; without it per-tet linked lists are built."""
     _lib.require_gpu(tet_bxtx4x3, pts_bxqx3, cond, grad_w, grad_occ)
     lib = _lib.load()
     tet, pts, cond, gw = _f32c(tet_bxtx4x3), _f32c(pts_bxqx3), _f32c(cond), _f32c(grad_w)
@@ -64,7 +69,8 @@ def point_in_tet_bwd(tet_bxtx4x3, pts_bxqx3, cond, grad_w, want_grad_pts=False, 
         ws = _lib.workspace(dev, lib.deftet_point_in_tet_bwd_workspace_bytes(B, T, Q))
         _lib.check(lib.deftet_point_in_tet_bwd_f32(_lib.ptr(tet), _lib.ptr(pts), _lib.ptr(cond), _lib.ptr(gw),
                                                    _lib.ptr(grad_tet), _lib.ptr(grad_pts), _lib.ptr(go), _lib.ptr(grad_pred),
-                                                   B, T, Q, 0, _lib.ptr(ws), ws.numel(), _lib.current_stream(dev)),
+                                                   _lib.ptr(hits), B, T, Q, 0, _lib.ptr(ws), ws.numel(),
+                                                   _lib.current_stream(dev)),
                    "deftet_point_in_tet_bwd_f32")
     if go is not None:
         return grad_tet, grad_pts, grad_pred

@@ -39,16 +39,16 @@ class PointInTetBary(Function):
 
     @staticmethod
     def forward(ctx, tet_bxfx4x3, point_pos_bxnx3):
-        cond, w = hip_ops.point_in_tet(tet_bxfx4x3, point_pos_bxnx3, want_bary=True)
-        ctx.save_for_backward(tet_bxfx4x3, point_pos_bxnx3, cond)
+        cond, w, hits = hip_ops.point_in_tet(tet_bxfx4x3, point_pos_bxnx3, want_bary=True, want_hits=True)
+        ctx.save_for_backward(tet_bxfx4x3, point_pos_bxnx3, cond, hits)
         ctx.mark_non_differentiable(cond)
         return cond, w
 
     @staticmethod
     def backward(ctx, _grad_cond, grad_w):
-        tet, pts, cond = ctx.saved_tensors
+        tet, pts, cond, hits = ctx.saved_tensors
         need_pts = ctx.needs_input_grad[1]
-        g_tet, g_pts = hip_ops.point_in_tet_bwd(tet, pts, cond, grad_w, want_grad_pts=need_pts)
+        g_tet, g_pts = hip_ops.point_in_tet_bwd(tet, pts, cond, grad_w, want_grad_pts=need_pts, hits=hits)
         return (g_tet if ctx.needs_input_grad[0] else None), g_pts
 
 
@@ -63,16 +63,17 @@ class PointInTetOcc(Function):
 
     @staticmethod
     def forward(ctx, tet_bxfx4x3, point_pos_bxnx3, pred_tet_occ):
-        cond, w, occ = hip_ops.point_in_tet(tet_bxfx4x3, point_pos_bxnx3, want_bary=True, pred_bxt=pred_tet_occ)
-        ctx.save_for_backward(tet_bxfx4x3, point_pos_bxnx3, cond)
+        cond, w, occ, hits = hip_ops.point_in_tet(tet_bxfx4x3, point_pos_bxnx3, want_bary=True, pred_bxt=pred_tet_occ,
+                                                  want_hits=True)
+        ctx.save_for_backward(tet_bxfx4x3, point_pos_bxnx3, cond, hits)
         ctx.mark_non_differentiable(cond)
         return cond, w, occ
 
     @staticmethod
     def backward(ctx, _grad_cond, grad_w, grad_occ):
-        tet, pts, cond = ctx.saved_tensors
+        tet, pts, cond, hits = ctx.saved_tensors
         g_tet, g_pts, g_pred = hip_ops.point_in_tet_bwd(tet, pts, cond, grad_w, want_grad_pts=ctx.needs_input_grad[1],
-                                                        grad_occ=grad_occ)
+                                                        grad_occ=grad_occ, hits=hits)
         return (g_tet if ctx.needs_input_grad[0] else None), g_pts, (g_pred if ctx.needs_input_grad[2] else None)
 
 

@@ -59,10 +59,14 @@ int deftet_profile_read(double *total_ms, long long *count);
  *      utils/tet_utils.py:28-45 (zeros for misses).
  * pred f32 [B,T] + occ f32 [B,Q] (both or neither): fused DefTet.paste_occ gather
  *      occ[b,q] = pred[b, max(index,0)] (layers/DefTet/deftet.py:132-136); cond keeps its -1s.
+ * hit_buf int32 [deftet_point_in_tet_hits_ints(B,T,Q)] or NULL (DEFTET_PIT_AUTO only): opaque
+ *      per-tet records of the accepted queries; handing it to deftet_point_in_tet_bwd_f32 makes
+ *      the backward free of atomics, lists and memsets.
  * ------------------------------------------------------------------------------- */
 size_t deftet_point_in_tet_workspace_bytes(int n_batch, int n_tet, int n_query, int algo);
+size_t deftet_point_in_tet_hits_ints(int n_batch, int n_tet, int n_query);
 int deftet_point_in_tet_f32(const float *tet, const float *pts, float *cond, float *bary,
-                            const float *pred, float *occ,
+                            const float *pred, float *occ, int32_t *hit_buf,
                             int n_batch, int n_tet, int n_query, int algo,
                             void *workspace, size_t workspace_bytes, void *stream);
 
@@ -74,12 +78,13 @@ int deftet_point_in_tet_f32(const float *tet, const float *pts, float *cond, flo
  * kernels add into wrapper-zeroed buffers (tet_analytic_distance_batch/utils.py:65).
  * grad_occ f32 [B,Q] + grad_pred f32 [B,T] (both or neither): fused backward of the paste_occ
  * gather, grad_pred[b,t] = sum of grad_occ over the queries that pasted from t (misses -> tet 0).
- * workspace (deftet_point_in_tet_bwd_workspace_bytes) enables the atomic-free gather path;
- * NULL selects a float-atomic scatter. */
+ * hit_buf (from the forward, same tet/pts/cond) selects the fastest path; else workspace
+ * (deftet_point_in_tet_bwd_workspace_bytes) enables the linked-list gather path; with neither a
+ * float-atomic scatter is used. */
 size_t deftet_point_in_tet_bwd_workspace_bytes(int n_batch, int n_tet, int n_query);
 int deftet_point_in_tet_bwd_f32(const float *tet, const float *pts, const float *cond,
                                 const float *grad_w, float *grad_tet, float *grad_pts,
-                                const float *grad_occ, float *grad_pred,
+                                const float *grad_occ, float *grad_pred, const int32_t *hit_buf,
                                 int n_batch, int n_tet, int n_query, int accumulate,
                                 void *workspace, size_t workspace_bytes, void *stream);
 

@@ -33,9 +33,9 @@ def test_library_exports_every_declared_symbol():
     assert loaded.deftet_version() >= 100
     # argument errors are reported through the status code + deftet_last_error, no GPU needed
     assert loaded.deftet_point_in_tet_workspace_bytes(8, 257250, 100000, 0) > 0
-    st = loaded.deftet_point_in_tet_f32(None, None, None, None, None, None, -1, 1, 1, 0, None, 0, None)
+    st = loaded.deftet_point_in_tet_f32(None, None, None, None, None, None, None, -1, 1, 1, 0, None, 0, None)
     assert st == -1 and b"negative" in loaded.deftet_last_error()
-    st = loaded.deftet_point_in_tet_f32(None, None, None, None, None, None, 1, 1 << 24, 1, 0, None, 0, None)
+    st = loaded.deftet_point_in_tet_f32(None, None, None, None, None, None, None, 1, 1 << 24, 1, 0, None, 0, None)
     assert st == -4
 
 

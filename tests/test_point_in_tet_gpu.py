@@ -128,14 +128,14 @@ def test_backward_atomic_fallback_matches_gather(cuda, oracle):
     g_atomic = torch.full_like(t, 7.0)          # must be overwritten when accumulate == 0
     st = _lib.current_stream(cuda)
     _lib.check(lib.deftet_point_in_tet_bwd_f32(_lib.ptr(t), _lib.ptr(p), _lib.ptr(cond), _lib.ptr(gw), _lib.ptr(g_atomic),
-                                               None, None, None, 2, t.shape[1], 3000, 0, None, 0, st), "bwd atomic")
+                                               None, None, None, None, 2, t.shape[1], 3000, 0, None, 0, st), "bwd atomic")
     torch.cuda.synchronize()
     scale = g_gather.abs().max().item()
     assert (g_gather - g_atomic).abs().max().item() <= 1e-5 * scale
     acc = torch.ones_like(t)
     ws = _lib.workspace(cuda, lib.deftet_point_in_tet_bwd_workspace_bytes(2, t.shape[1], 3000))
     _lib.check(lib.deftet_point_in_tet_bwd_f32(_lib.ptr(t), _lib.ptr(p), _lib.ptr(cond), _lib.ptr(gw), _lib.ptr(acc),
-                                               None, None, None, 2, t.shape[1], 3000, 1, _lib.ptr(ws), ws.numel(), st), "bwd acc")
+                                               None, None, None, None, 2, t.shape[1], 3000, 1, _lib.ptr(ws), ws.numel(), st), "bwd acc")
     torch.cuda.synchronize()
     assert (acc - 1.0 - g_gather).abs().max().item() <= 1e-5 * scale
     miss = cond[..., 0] < 0
@@ -193,8 +193,41 @@ def test_fused_occ_op_matches_separate_ops(cuda, oracle):
     g_pred = torch.empty(3, T, device=cuda)
     tt, pp = t1.detach().contiguous(), torch.from_numpy(pts).to(cuda)
     _lib.check(lib.deftet_point_in_tet_bwd_f32(_lib.ptr(tt), _lib.ptr(pp), _lib.ptr(cond), _lib.ptr(gw), _lib.ptr(g_tet), None,
-                                               _lib.ptr(go), _lib.ptr(g_pred), 3, T, 5000, 0, None, 0, _lib.current_stream(cuda)),
+                                               _lib.ptr(go), _lib.ptr(g_pred), None, 3, T, 5000, 0, None, 0, _lib.current_stream(cuda)),
                "fused bwd atomic")
     torch.cuda.synchronize()
     assert (g_pred - p1.grad).abs().max() <= 1e-5 * p1.grad.abs().max()
     assert (g_tet - t1.grad).abs().max() <= 1e-5 * t1.grad.abs().max()
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_backward_hit_records_adversarial(cuda, oracle, seed):
+    """the three backward paths (hit records / linked lists / atomics) agree, including tets that
+    swallow many queries (record overflow), irregular tets and NaN / huge queries"""
+    from deftet_amd import _lib, hip_ops
+    tet, pts = cases.adversarial(seed)
+    pts = np.nan_to_num(pts, nan=0.123, posinf=0.3, neginf=-0.3)        # finite coordinates: gradients stay finite
+    pts[0, 5] = 3.0e6                                                  # one huge (irregular) query stays
+    B, T, Q = 1, tet.shape[1], pts.shape[1]
+    finite_t = np.isfinite(tet).all(axis=(2, 3))[0]
+    tet = np.ascontiguousarray(tet[:, finite_t])                       # drop NaN/Inf tets (their weights are NaN by definition)
+    T = tet.shape[1]
+    t, p = torch.from_numpy(tet).to(cuda), torch.from_numpy(pts).to(cuda)
+    gen = torch.Generator(device=cuda).manual_seed(seed)
+    pred = torch.rand(B, T, device=cuda, generator=gen)
+    cond, w, occ, hits = hip_ops.point_in_tet(t, p, want_bary=True, pred_bxt=pred, want_hits=True)
+    assert np.array_equal(cond.cpu().numpy(), oracle.point_in_tet(tet, pts))
+    h4 = hits[: B * T * 4].view(B, T, 4)
+    assert (h4[..., 3] == -2).any()                                    # some tet overflowed / is irregular
+    gw = torch.randn(B, Q, 4, device=cuda, generator=gen)
+    go = torch.randn(B, Q, device=cuda, generator=gen)
+    a = hip_ops.point_in_tet_bwd(t, p, cond, gw, want_grad_pts=True, grad_occ=go, hits=hits)
+    b = hip_ops.point_in_tet_bwd(t, p, cond, gw, want_grad_pts=True, grad_occ=go)
+    fin = torch.isfinite(b[0]) & torch.isfinite(a[0])
+    assert fin.float().mean() > 0.9
+    scale = b[0][fin].abs().max()
+    assert ((a[0] - b[0])[fin]).abs().max() <= 2e-5 * scale
+    assert torch.equal(torch.isfinite(a[0]), torch.isfinite(b[0]))
+    assert (a[2] - b[2]).abs().max() <= 1e-4 * b[2].abs().max()       # grad_pred (thousands of hits on the swallowing tets)
+    fp = torch.isfinite(b[1])
+    assert ((a[1] - b[1])[fp]).abs().max() <= 2e-5 * b[1][fp].abs().max()
