@@ -452,7 +452,10 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan(const float *__rest
         s = s2; e = e2; cy = ny; cz = nz;
     }
     if (hits) {
-        if (hcnt > 4) hrec.w = kHitOverflow;
+        if (hcnt > 4) {
+            hrec.w = kHitOverflow;
+            counters[b * 4 + 2] = 1;                               // some record overflowed (benign race: all write 1)
+        }
         hits[(size_t)b * T + t] = hrec;
     }
 }
@@ -528,7 +531,7 @@ __device__ __forceinline__ float triple(const float *a, const float *b, const fl
 __global__ __launch_bounds__(256) void k_finalize(const float *__restrict__ tet, const float *__restrict__ pts, int T,
                                                   int Q, const int *__restrict__ result, float *cond, float *bary,
                                                   const float *__restrict__ pred, float *occ, const int4 *__restrict__ hits,
-                                                  int *ucount, int *ulist)
+                                                  int *ucount, int *ulist, const int *__restrict__ counters)
 {
     const int b = blockIdx.y;
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
@@ -542,7 +545,10 @@ __global__ __launch_bounds__(256) void k_finalize(const float *__restrict__ tet,
         // is this hit in its tet's record?  (not if the tet overflowed / is irregular, or if the
         // query took the irregular-query side path, which records nothing)
         const float *pq = pts + i * 3;
-        const bool covered = query_regular(pq[0], pq[1], pq[2]) && hits[(size_t)b * T + r].w != kHitOverflow;
+        // records are complete unless some tet is irregular or overflowed (wave-uniform test: the
+        // per-hit gather of the record is skipped for ordinary meshes)
+        const bool suspect = counters && (counters[b * 4 + 0] > 0 || counters[b * 4 + 2] > 0);
+        const bool covered = query_regular(pq[0], pq[1], pq[2]) && (!suspect || hits[(size_t)b * T + r].w != kHitOverflow);
         if (!covered) ulist[(size_t)b * Q + atomicAdd(&ucount[b], 1)] = q;
     }
     if (!bary) return;
@@ -1094,7 +1100,8 @@ extern "C" int deftet_point_in_tet_f32(const float *tet, const float *pts, float
         }
     }
     DEFTET_LAUNCH(k_finalize, gq, blk, st, tet, pts, T, Q, L.result, cond, bary, pred, occ, (const int4 *)hit_buf,
-                  hit_buf ? hit_buf + hit_cnt_off(B, T) : nullptr, hit_buf ? hit_buf + hit_list_off(B, T) : nullptr);
+                  hit_buf ? hit_buf + hit_cnt_off(B, T) : nullptr, hit_buf ? hit_buf + hit_list_off(B, T) : nullptr,
+                  algo == DEFTET_PIT_AUTO ? L.counters : nullptr);
     return DEFTET_OK;
 }
 
