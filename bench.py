@@ -153,7 +153,9 @@ def main():
     if rank == 0:
         pairs = float(world) * B * T * Q * args.steps
         kern_ms = tot_ms.value / max(cnt.value, 1)
-        algo_bytes = B * (48.0 * T + 16.0 * Q)          # k_tet_scan reads every tet record and sorted query once
+        # k_tet_scan reads every 48-byte tet record and every 16-byte sorted query once and writes one
+        # 16-byte hit record per tet
+        algo_bytes = B * (48.0 * T + 16.0 * Q + 16.0 * T)
         achieved = algo_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")

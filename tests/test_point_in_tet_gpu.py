@@ -231,3 +231,25 @@ def test_backward_hit_records_adversarial(cuda, oracle, seed):
     assert (a[2] - b[2]).abs().max() <= 1e-4 * b[2].abs().max()       # grad_pred (thousands of hits on the swallowing tets)
     fp = torch.isfinite(b[1])
     assert ((a[1] - b[1])[fp]).abs().max() <= 2e-5 * b[1][fp].abs().max()
+
+
+def test_binned_equals_brute_res100(cuda):
+    """BASELINE configs[3] shape size (res=100: T=750,000, Q=200,000): the binned path against the
+    independent brute-force kernel (1.5e11 pair tests), plus round-trip properties of the outputs."""
+    from deftet_amd import hip_ops
+    tet, pts = cases.jittered(100, 200000, 1)
+    t, p = torch.from_numpy(tet).to(cuda), torch.from_numpy(pts).to(cuda)
+    cond, w = hip_ops.point_in_tet(t, p, want_bary=True)
+    brute = hip_ops.point_in_tet(t, p, algo=1)
+    assert torch.equal(cond, brute)
+    hit = cond[..., 0] >= 0
+    assert 0.10 < (~hit).float().mean().item() < 0.17
+    # weights reconstruct the query from the hit tet's vertices (sum w_i v_i = p) and are a partition of unity
+    idx = cond[..., 0].clamp(min=0).long()
+    verts = torch.gather(t, 1, idx[:, :, None, None].expand(-1, -1, 4, 3))
+    rec = (w[..., None] * verts).sum(2)
+    assert (rec - p)[hit].abs().max().item() < 2e-6
+    assert (w[hit].sum(-1) - 1).abs().max().item() < 1e-5 and w[hit].min().item() > -1e-5
+    # queries outside the grid never hit
+    outside = (p.abs() > 0.5).any(-1)
+    assert not (hit & outside).any()
