@@ -460,6 +460,197 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan(const float *__rest
     }
 }
 
+// ------------------------------------------------------------------------------------
+// Wave-cooperative variant of k_tet_scan for spatially coherent tet orders.
+// The 64 tets of a wave mostly visit the same few cell rows, yet every lane fetches its row
+// bounds and candidate queries with its own gather instructions (~55 per wave, the kernel's
+// bottleneck).  Here a wave first reduces its lanes' cell ranges to one union box; if that box
+// is small (<= 64 rows, <= kSubMax cell bounds, <= kStageQ queries) the wave copies the box's
+// cell bounds and queries into LDS with a handful of full-width loads, and each lane then walks
+// ITS OWN rows out of LDS.  Same candidates, same exact test, same atomicMin — only the source of
+// the operands changes.  Waves whose box is too large (incoherent tet order, or a wave that
+// straddles two grid columns) take the per-lane gather path of k_tet_scan.
+// ------------------------------------------------------------------------------------
+constexpr int kSubMax = 448;           // staged cell bounds per wave
+constexpr int kStageQ = 224;           // staged queries per wave
+
+__device__ __forceinline__ int wave_min_i(int v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off));
+    return v;
+}
+__device__ __forceinline__ int wave_max_i(int v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off));
+    return v;
+}
+__device__ __forceinline__ void wave_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan_staged(const float *__restrict__ tet, int T, int Q,
+                                                  const float *__restrict__ gparam, int G, int Gx, const int *__restrict__ cells,
+                                                  long long cellStride, const float4 *__restrict__ sortedQ, int *result, int *counters,
+                                                  int *irregT, int4 *hits)
+{
+    __shared__ int s_cs[4][kSubMax];
+    __shared__ float4 s_q[4][kStageQ];
+    __shared__ int s_off[4][65];
+    __shared__ int s_rs[4][64];
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int nblk = gridDim.x, per = (nblk + 7) >> 3;
+    const int vb = (blockIdx.x & 7) * per + (blockIdx.x >> 3);       // XCD-aware mapping, see k_tet_scan
+    const int t = vb * blockDim.x + threadIdx.x;
+    if (t - lane >= T) return;                                       // whole wave out of range
+    const bool intet = t < T;
+    float v[12];
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(tet + ((size_t)b * T + (intet ? t : t - lane)) * 12);
+        float4 a = src[0], bq = src[1], c = src[2];
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+        v[4] = bq.x; v[5] = bq.y; v[6] = bq.z; v[7] = bq.w;
+        v[8] = c.x; v[9] = c.y; v[10] = c.z; v[11] = c.w;
+    }
+    Planes P;
+    make_planes(v, P);
+    float lo[3], hi[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        lo[k] = fminf(fminf(v[k], v[3 + k]), fminf(v[6 + k], v[9 + k]));
+        hi[k] = fmaxf(fmaxf(v[k], v[3 + k]), fmaxf(v[6 + k], v[9 + k]));
+    }
+    const float w = fmaxf(fmaxf(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]);
+    bool finite = true;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) finite = finite && (fabsf(v[k]) <= kBig);
+    const float mn = fminf(fminf(fabsf(P.dv[0]), fabsf(P.dv[1])), fminf(fabsf(P.dv[2]), fabsf(P.dv[3])));
+    const bool regular = finite && (P.sv == 0u || P.sv == 15u) && (w >= kWMin) && (mn >= kTau * ((w * w) * w));
+    int4 hrec = make_int4(-1, -1, -1, -1);
+    int hcnt = 0;
+    if (intet && !regular) {
+        const int k = atomicAdd(&counters[b * 4 + 0], 1);
+        irregT[(size_t)b * T + k] = t;
+        hrec.w = kHitOverflow;                                       // accepted by k_irreg, not recorded
+    }
+    const Grid g = load_grid(gparam + b * 12);
+    const float m = w * kMargin;
+    float elo[3], ehi[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { elo[k] = lo[k] - m; ehi[k] = hi[k] + m; }
+    const bool active = intet && regular &&
+                        !(ehi[0] < g.lo[0] || elo[0] > g.hi[0] || ehi[1] < g.lo[1] || elo[1] > g.hi[1] || ehi[2] < g.lo[2] || elo[2] > g.hi[2]);
+    const int cx0 = cell_of(elo[0], g.o[0], g.inv[0], Gx), cx1 = cell_of(ehi[0], g.o[0], g.inv[0], Gx);
+    const int cy0 = cell_of(elo[1], g.o[1], g.inv[1], G), cy1 = cell_of(ehi[1], g.o[1], g.inv[1], G);
+    const int cz0 = cell_of(elo[2], g.o[2], g.inv[2], G), cz1 = cell_of(ehi[2], g.o[2], g.inv[2], G);
+    const int *cb = cells + (size_t)b * cellStride;
+    const float4 *sq = sortedQ + (size_t)b * Q;
+    int *res = result + (size_t)b * Q;
+    auto test = [&](const float4 &q) {
+        if (q.x >= elo[0] && q.x <= ehi[0] && q.y >= elo[1] && q.y <= ehi[1] && q.z >= elo[2] && q.z <= ehi[2]) {
+            if (accept(P, q.x, q.y, q.z)) {
+                const int qi = __float_as_int(q.w);
+                atomicMin(&res[qi], t);
+                if (hcnt == 0) hrec.x = qi;
+                else if (hcnt == 1) hrec.y = qi;
+                else if (hcnt == 2) hrec.z = qi;
+                else if (hcnt == 3) hrec.w = qi;
+                ++hcnt;
+            }
+        }
+    };
+    if (__any(active)) {
+        constexpr int kBigI = 1 << 30;
+        const int ux0 = wave_min_i(active ? cx0 : kBigI), ux1 = wave_max_i(active ? cx1 : -1);
+        const int uy0 = wave_min_i(active ? cy0 : kBigI), uy1 = wave_max_i(active ? cy1 : -1);
+        const int uz0 = wave_min_i(active ? cz0 : kBigI), uz1 = wave_max_i(active ? cz1 : -1);
+        const int nx1 = ux1 - ux0 + 2, ny = uy1 - uy0 + 1, nz = uz1 - uz0 + 1, rows = ny * nz;   // nx1: bounds per row
+        bool staged = rows <= 64 && rows * nx1 <= kSubMax;           // wave-uniform
+        int total = 0;
+        if (staged) {
+            const float inv_nx1 = 1.0f / (float)nx1, inv_ny = 1.0f / (float)ny;
+            for (int i = lane; i < rows * nx1; i += 64) {
+                const int r = (int)(((float)i + 0.5f) * inv_nx1), x = i - r * nx1;      // exact for these small integers
+                const int rz = (int)(((float)r + 0.5f) * inv_ny), ry = r - rz * ny;
+                s_cs[wv][i] = cb[((uz0 + rz) * G + (uy0 + ry)) * Gx + ux0 + x];
+            }
+            wave_fence();
+            const int len = lane < rows ? s_cs[wv][lane * nx1 + nx1 - 1] - s_cs[wv][lane * nx1] : 0;
+            int incl = len;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int u = __shfl_up(incl, off);
+                if (lane >= off) incl += u;
+            }
+            total = __shfl(incl, 63);
+            s_off[wv][lane] = incl - len;
+            if (lane == 63) s_off[wv][64] = total;
+            if (lane < rows) s_rs[wv][lane] = s_cs[wv][lane * nx1];
+            staged = total <= kStageQ;
+        }
+        if (staged) {
+            wave_fence();
+            for (int i = lane; i < total; i += 64) {
+                int lo_r = 0, hi_r = rows;                              // largest r with s_off[r] <= i
+                while (hi_r - lo_r > 1) {
+                    const int mid = (lo_r + hi_r) >> 1;
+                    if (s_off[wv][mid] <= i) lo_r = mid; else hi_r = mid;
+                }
+                s_q[wv][i] = sq[s_rs[wv][lo_r] + (i - s_off[wv][lo_r])];
+            }
+            wave_fence();
+            if (active) {
+                for (int cz = cz0; cz <= cz1; ++cz)
+                    for (int cy = cy0; cy <= cy1; ++cy) {
+                        const int r = (cz - uz0) * ny + (cy - uy0), base = r * nx1;
+                        const int s = s_cs[wv][base + cx0 - ux0], e = s_cs[wv][base + cx1 + 1 - ux0];
+                        const int l0 = s_off[wv][r] + (s - s_rs[wv][r]);
+                        for (int j = 0; j < e - s; ++j) test(s_q[wv][l0 + j]);
+                    }
+            }
+        } else if (active) {
+            // per-lane gather path (identical to k_tet_scan)
+            int cy = cy0, cz = cz0;
+            int s = cb[(cz * G + cy) * Gx + cx0];
+            int e = cb[(cz * G + cy) * Gx + cx1 + 1];
+            for (;;) {
+                int ny2 = cy + 1, nz2 = cz;
+                if (ny2 > cy1) { ny2 = cy0; nz2 = cz + 1; }
+                const bool more = nz2 <= cz1;
+                int s2 = 0, e2 = 0;
+                if (more) {
+                    const int row2 = (nz2 * G + ny2) * Gx;
+                    s2 = cb[row2 + cx0];
+                    e2 = cb[row2 + cx1 + 1];
+                }
+                for (int j = s; j < e; j += PIT_BATCH) {
+                    const int last = e - 1;
+                    float4 qq[PIT_BATCH];
+#pragma unroll
+                    for (int k = 0; k < PIT_BATCH; ++k) qq[k] = sq[min(j + k, last)];
+#pragma unroll
+                    for (int k = 0; k < PIT_BATCH; ++k)
+                        if (k == 0 || j + k < e) test(qq[k]);
+                }
+                if (!more) break;
+                s = s2; e = e2; cy = ny2; cz = nz2;
+            }
+        }
+    }
+    if (hits && intet) {
+        if (hcnt > 4) {
+            hrec.w = kHitOverflow;
+            counters[b * 4 + 2] = 1;
+        }
+        hits[(size_t)b * T + t] = hrec;
+    }
+}
+
 // irregular tets x all queries
 __device__ __forceinline__ void irreg_tets_body(const float *__restrict__ tet, const float *__restrict__ pts, int T,
                                                     int Q, const int *__restrict__ counters,
@@ -1091,8 +1282,14 @@ extern "C" int deftet_point_in_tet_f32(const float *tet, const float *pts, float
         DEFTET_LAUNCH(k_scan_apply, dim3(L.nChunk, B), blk, st, L.cells, L.cellStride, L.nChunk, L.chunkTot);
         DEFTET_LAUNCH(k_query_scatter, gq, blk, st, pts, Q, L.qcell, L.cells, L.cellStride, L.sortedQ);
         if (T > 0) {
-            DEFTET_LAUNCH(k_tet_scan, gt, blk, st, tet, T, Q, L.gparam, L.G, L.Gx, L.cells, L.cellStride, L.sortedQ, L.result,
-                          L.counters, L.irregT, (int4 *)hit_buf);
+            static const bool no_stage = getenv("DEFTET_PIT_NO_STAGE") && atoi(getenv("DEFTET_PIT_NO_STAGE")) != 0;   // A/B switch
+            if (no_stage) {
+                DEFTET_LAUNCH(k_tet_scan, gt, blk, st, tet, T, Q, L.gparam, L.G, L.Gx, L.cells, L.cellStride, L.sortedQ, L.result,
+                              L.counters, L.irregT, (int4 *)hit_buf);
+            } else {
+                DEFTET_LAUNCH(k_tet_scan_staged, gt, blk, st, tet, T, Q, L.gparam, L.G, L.Gx, L.cells, L.cellStride, L.sortedQ,
+                              L.result, L.counters, L.irregT, (int4 *)hit_buf);
+            }
             int qb = (Q + 255) / 256, tb = (T + 255) / 256;
             if (qb > 1024) qb = 1024;
             if (tb > 1024) tb = 1024;
