@@ -461,7 +461,10 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan(const float *__rest
 }
 
 // ------------------------------------------------------------------------------------
-// Wave-cooperative variant of k_tet_scan for spatially coherent tet orders.
+// Wave-cooperative variant of k_tet_scan for spatially coherent tet orders (DEFTET_PIT_STAGED).
+// MEASURED NO FASTER than k_tet_scan on the BASELINE workload (0.322 vs 0.324 ms per step: 37 %
+// fewer vector-memory instructions, 16 % fewer L1 accesses, but 18 % more VALU work for the
+// staging bookkeeping; profiles/r01_pmc_k_tet_scan_variants.json) — kept selectable, not default.
 // The 64 tets of a wave mostly visit the same few cell rows, yet every lane fetches its row
 // bounds and candidate queries with its own gather instructions (~55 per wave, the kernel's
 // bottleneck).  Here a wave first reduces its lanes' cell ranges to one union box; if that box
@@ -493,7 +496,10 @@ __device__ __forceinline__ void wave_fence()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan_staged(const float *__restrict__ tet, int T, int Q,
+#ifndef PIT_STAGE_WAVES
+#define PIT_STAGE_WAVES 5
+#endif
+__global__ __launch_bounds__(256, PIT_STAGE_WAVES) void k_tet_scan_staged(const float *__restrict__ tet, int T, int Q,
                                                   const float *__restrict__ gparam, int G, int Gx, const int *__restrict__ cells,
                                                   long long cellStride, const float4 *__restrict__ sortedQ, int *result, int *counters,
                                                   int *irregT, int4 *hits)
@@ -543,7 +549,11 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan_staged(const float 
     float elo[3], ehi[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) { elo[k] = lo[k] - m; ehi[k] = hi[k] + m; }
+#ifdef PIT_EXP_NOTRAV            // timing experiment: load + classify + record only
+    const bool active = false &&
+#else
     const bool active = intet && regular &&
+#endif
                         !(ehi[0] < g.lo[0] || elo[0] > g.hi[0] || ehi[1] < g.lo[1] || elo[1] > g.hi[1] || ehi[2] < g.lo[2] || elo[2] > g.hi[2]);
     const int cx0 = cell_of(elo[0], g.o[0], g.inv[0], Gx), cx1 = cell_of(ehi[0], g.o[0], g.inv[0], Gx);
     const int cy0 = cell_of(elo[1], g.o[1], g.inv[1], G), cy1 = cell_of(ehi[1], g.o[1], g.inv[1], G);
@@ -609,8 +619,15 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan_staged(const float 
                     for (int cy = cy0; cy <= cy1; ++cy) {
                         const int r = (cz - uz0) * ny + (cy - uy0), base = r * nx1;
                         const int s = s_cs[wv][base + cx0 - ux0], e = s_cs[wv][base + cx1 + 1 - ux0];
-                        const int l0 = s_off[wv][r] + (s - s_rs[wv][r]);
-                        for (int j = 0; j < e - s; ++j) test(s_q[wv][l0 + j]);
+                        const int l0 = s_off[wv][r] + (s - s_rs[wv][r]), n = e - s;
+                        for (int j = 0; j < n; j += PIT_BATCH) {
+                            float4 qq[PIT_BATCH];
+#pragma unroll
+                            for (int k = 0; k < PIT_BATCH; ++k) qq[k] = s_q[wv][l0 + min(j + k, n - 1)];
+#pragma unroll
+                            for (int k = 0; k < PIT_BATCH; ++k)
+                                if (k == 0 || j + k < n) test(qq[k]);
+                        }
                     }
             }
         } else if (active) {
@@ -1243,11 +1260,11 @@ extern "C" int deftet_point_in_tet_f32(const float *tet, const float *pts, float
                                        float *occ, int32_t *hit_buf, int B, int T, int Q, int algo, void *workspace,
                                        size_t workspace_bytes, void *stream_)
 {
-    DEFTET_CHECK_ARG(!hit_buf || (((uintptr_t)hit_buf & 15) == 0 && algo == DEFTET_PIT_AUTO), "hit_buf must be 16-byte aligned and needs DEFTET_PIT_AUTO");
+    DEFTET_CHECK_ARG(!hit_buf || (((uintptr_t)hit_buf & 15) == 0 && algo != DEFTET_PIT_BRUTE), "hit_buf must be 16-byte aligned and needs a binned algo");
     DEFTET_CHECK_ARG((pred == nullptr) == (occ == nullptr), "pred and occ must be given together");
     DEFTET_CHECK_ARG(!occ || T > 0, "paste_occ needs at least one tet");
     DEFTET_CHECK_ARG(B >= 0 && T >= 0 && Q >= 0, "negative size (B=%d T=%d Q=%d)", B, T, Q);
-    DEFTET_CHECK_ARG(algo == DEFTET_PIT_AUTO || algo == DEFTET_PIT_BRUTE, "unknown algo %d", algo);
+    DEFTET_CHECK_ARG(algo == DEFTET_PIT_AUTO || algo == DEFTET_PIT_BRUTE || algo == DEFTET_PIT_STAGED, "unknown algo %d", algo);
     if (T >= (1 << 24)) return set_error(DEFTET_ELIMIT, "n_tet=%d does not fit a float-encoded index (2^24)", T);
     DEFTET_CHECK_ARG(B <= 65535, "n_batch=%d exceeds the grid-y limit 65535", B);
     if (B == 0 || Q == 0) return DEFTET_OK;
@@ -1282,8 +1299,7 @@ extern "C" int deftet_point_in_tet_f32(const float *tet, const float *pts, float
         DEFTET_LAUNCH(k_scan_apply, dim3(L.nChunk, B), blk, st, L.cells, L.cellStride, L.nChunk, L.chunkTot);
         DEFTET_LAUNCH(k_query_scatter, gq, blk, st, pts, Q, L.qcell, L.cells, L.cellStride, L.sortedQ);
         if (T > 0) {
-            static const bool no_stage = getenv("DEFTET_PIT_NO_STAGE") && atoi(getenv("DEFTET_PIT_NO_STAGE")) != 0;   // A/B switch
-            if (no_stage) {
+            if (algo != DEFTET_PIT_STAGED) {
                 DEFTET_LAUNCH(k_tet_scan, gt, blk, st, tet, T, Q, L.gparam, L.G, L.Gx, L.cells, L.cellStride, L.sortedQ, L.result,
                               L.counters, L.irregT, (int4 *)hit_buf);
             } else {
@@ -1298,7 +1314,7 @@ extern "C" int deftet_point_in_tet_f32(const float *tet, const float *pts, float
     }
     DEFTET_LAUNCH(k_finalize, gq, blk, st, tet, pts, T, Q, L.result, cond, bary, pred, occ, (const int4 *)hit_buf,
                   hit_buf ? hit_buf + hit_cnt_off(B, T) : nullptr, hit_buf ? hit_buf + hit_list_off(B, T) : nullptr,
-                  algo == DEFTET_PIT_AUTO ? L.counters : nullptr);
+                  algo != DEFTET_PIT_BRUTE ? L.counters : nullptr);
     return DEFTET_OK;
 }
 

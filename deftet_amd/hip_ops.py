@@ -10,7 +10,7 @@ import torch
 
 from . import _lib
 
-PIT_AUTO, PIT_BRUTE = 0, 1
+PIT_AUTO, PIT_BRUTE, PIT_STAGED = 0, 1, 2
 
 
 def _f32c(t):
@@ -40,7 +40,7 @@ def point_in_tet(tet_bxtx4x3, pts_bxqx3, want_bary=False, algo=PIT_AUTO, pred_bx
         raise RuntimeError("pred_tet_occ must be [B,T], got %s" % (tuple(pred.shape),))
     occ = torch.empty(B, Q, device=dev, dtype=torch.float32) if pred is not None else None
     hits = None
-    if want_hits and algo == PIT_AUTO:
+    if want_hits and algo != PIT_BRUTE:
         hits = torch.empty(max(lib.deftet_point_in_tet_hits_ints(B, T, Q), 4), device=dev, dtype=torch.int32)
     with torch.cuda.device(dev):
         nbytes = lib.deftet_point_in_tet_workspace_bytes(B, T, Q, algo)

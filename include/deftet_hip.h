@@ -36,6 +36,7 @@ extern "C" {
 /* point-in-tet algorithm selector */
 #define DEFTET_PIT_AUTO 0    /* uniform-grid binned, tet-centric (default) */
 #define DEFTET_PIT_BRUTE 1   /* LDS/scalar-tiled brute force: the algorithmic equivalent of the reference kernel */
+#define DEFTET_PIT_STAGED 2  /* binned, with wave-cooperative LDS staging of the cell rows (coherent tet orders) */
 
 int deftet_version(void);
 const char *deftet_last_error(void);

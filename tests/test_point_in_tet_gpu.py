@@ -19,7 +19,7 @@ def _run(tet, pts, dev, algo=0, bary=False):
     return out.cpu().numpy()
 
 
-@pytest.mark.parametrize("algo", [0, 1])
+@pytest.mark.parametrize("algo", [0, 1, 2])
 @pytest.mark.parametrize("res,nq,batch", [(4, 257, 1), (8, 3000, 3), (12, 5000, 2)])
 def test_index_bit_exact_jittered(cuda, oracle, algo, res, nq, batch):
     tet, pts = cases.jittered(res, nq, batch)
@@ -30,7 +30,7 @@ def test_index_bit_exact_jittered(cuda, oracle, algo, res, nq, batch):
     assert 0.05 < (want < 0).mean() < 0.25          # the 13.6 % miss band of SURVEY 3.2
 
 
-@pytest.mark.parametrize("algo", [0, 1])
+@pytest.mark.parametrize("algo", [0, 1, 2])
 @pytest.mark.parametrize("seed", [0, 1, 2])
 def test_index_bit_exact_adversarial(cuda, oracle, algo, seed):
     tet, pts = cases.adversarial(seed)
@@ -64,6 +64,7 @@ def test_binned_equals_brute_res40(cuda):
     a = _run(tet, pts, cuda, 0)
     b = _run(tet, pts, cuda, 1)
     assert np.array_equal(a, b)
+    assert np.array_equal(a, _run(tet, pts, cuda, 2))
     assert 0.10 < (a < 0).mean() < 0.17
 
 
