@@ -55,7 +55,7 @@ def step(d, world):
     from deftet_amd import hip_ops, sharding
     cond, w, occ, hits = hip_ops.point_in_tet(d["tet"], d["pts"], want_bary=True, pred_bxt=d["pred"], want_hits=True)
     g_tet, _, g_pred = hip_ops.point_in_tet_bwd(d["tet"], d["pts"], cond, d["gw"], grad_occ=d["gout"], hits=hits)
-    loss = hip_ops.rowdot(w, d["gw"]) + hip_ops.rowdot(occ, d["gout"])         # [B] per-shape loss scalars
+    loss = hip_ops.rowdot(w, d["gw"], occ, d["gout"])         # [B] per-shape loss scalars
     if world > 1:
         if torch.distributed.get_backend() == "gloo":                         # single-GPU test hook: stage through the host
             loss = sharding.all_gather_losses(loss.cpu(), world * loss.shape[0]).to(w.device)

@@ -32,7 +32,6 @@ constexpr float kTau = 1.0f / 128.0f;        // regular tet: min |6V| >= tau * w
 constexpr float kMargin = 1.0f / 64.0f;      // bounding-box enlargement, in units of w
 constexpr float kWMin = 9.3132257e-10f;      // 2^-30
 constexpr int kMiss = 0x7F7F7F7F;            // result sentinel (> any tet index)
-constexpr int kChunk = 2048;                 // cells per scan chunk
 constexpr int kMaxG = 96;
 constexpr int kHitOverflow = -2;            // hits[.].w: this tet has accepted queries that are not recorded
 
@@ -104,17 +103,19 @@ __device__ __forceinline__ float ord2f(int k) { return __int_as_float(k >= 0 ? k
 struct Grid {
     float o[3], inv[3], lo[3], hi[3];
 };
+constexpr int kBoxBlocks = 64;
 
-// one wave per shape: reduce the per-block query boxes into grid parameters (12 floats)
-__global__ __launch_bounds__(64) void k_grid_params(const float *__restrict__ part, int nPart, int G, int Gx, float *gparam)
+// reduce the per-block query boxes of one shape into grid parameters; called by every wave of
+// k_row_count (64 partials, a few shuffles) so that no separate launch is needed
+__device__ __forceinline__ Grid reduce_grid(const float *__restrict__ part, int nPart, int G, int Gx)
 {
-    const int b = blockIdx.x, lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int i = lane; i < nPart; i += 64) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            lo[k] = fminf(lo[k], part[((size_t)b * nPart + i) * 6 + k]);
-            hi[k] = fmaxf(hi[k], part[((size_t)b * nPart + i) * 6 + 3 + k]);
+            lo[k] = fminf(lo[k], part[(size_t)i * 6 + k]);
+            hi[k] = fmaxf(hi[k], part[(size_t)i * 6 + 3 + k]);
         }
     }
 #pragma unroll
@@ -125,20 +126,20 @@ __global__ __launch_bounds__(64) void k_grid_params(const float *__restrict__ pa
             hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off));
         }
     }
+    Grid g;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         float l = lo[k], h = hi[k];
-        bool ok = h >= l;                         // false when no regular query was seen
-        float ext = h - l;
+        const bool ok = h >= l;                   // false when no regular query was seen
+        const float ext = h - l;
         l = ok ? l : 0.f;
         h = ok ? h : 0.f;
-        if (lane == 0) {
-            gparam[b * 12 + k] = l;                                               // origin
-            gparam[b * 12 + 3 + k] = (ok && ext > 1e-30f) ? (float)(k == 0 ? Gx : G) / ext : 0.f;  // cells per unit
-            gparam[b * 12 + 6 + k] = l;
-            gparam[b * 12 + 9 + k] = h;
-        }
+        g.o[k] = l;
+        g.inv[k] = (ok && ext > 1e-30f) ? (float)(k == 0 ? Gx : G) / ext : 0.f;   // cells per unit
+        g.lo[k] = l;
+        g.hi[k] = h;
     }
+    return g;
 }
 
 __device__ __forceinline__ Grid load_grid(const float *__restrict__ gp)
@@ -170,35 +171,29 @@ __device__ __forceinline__ bool query_regular(float x, float y, float z)
 // ------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------
-__global__ void k_init(int *counters, int *cells, int *result, int nB, long long nCells, long long nQ)
-{
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    long long stride = (long long)gridDim.x * blockDim.x;
-    if (i < nB * 4) counters[i] = 0;
-    for (long long j = i; j < nCells; j += stride) cells[j] = 0;
-    for (long long j = i; j < nQ; j += stride) result[j] = kMiss;
-}
-
-// query bounding box per shape (per-block partials, no contended atomics) + list of
-// irregular queries.  part layout: [B][kBoxBlocks][6] floats (lo xyz, hi xyz); a block that
-// saw no regular query writes (+inf, -inf).
-constexpr int kBoxBlocks = 64;
-
+// query bounding box per shape (per-block partials, no contended atomics).
+// part layout: [B][kBoxBlocks][6] floats (lo xyz, hi xyz); a block that saw no regular query
+// writes (+inf, -inf).
+// The same launch also clears what the later kernels accumulate into (counters, result
+// sentinels): nothing in THIS kernel reads them.
 __global__ __launch_bounds__(256) void k_query_bbox(const float *__restrict__ pts, int Q, float *part, int *counters,
-                                                    int *irregQ)
+                                                    int *result, int nB, long long nQ)
 {
     __shared__ float sh[4][6];
     const int b = blockIdx.y;
+    {
+        const long long nblk = (long long)gridDim.x * gridDim.y, bid = (long long)blockIdx.y * gridDim.x + blockIdx.x;
+        const long long i = bid * blockDim.x + threadIdx.x, stride = nblk * blockDim.x;
+        if (i < nB * 4) counters[i] = 0;
+        for (long long j = i; j < nQ; j += stride) result[j] = kMiss;
+    }
     const float *p = pts + (size_t)b * Q * 3;
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < Q; q += gridDim.x * blockDim.x) {
         float x = p[q * 3], y = p[q * 3 + 1], z = p[q * 3 + 2];
-        if (query_regular(x, y, z)) {
+        if (query_regular(x, y, z)) {                              // irregular queries are listed by k_row_count
             lo[0] = fminf(lo[0], x); lo[1] = fminf(lo[1], y); lo[2] = fminf(lo[2], z);
             hi[0] = fmaxf(hi[0], x); hi[1] = fmaxf(hi[1], y); hi[2] = fmaxf(hi[2], z);
-        } else {
-            int k = atomicAdd(&counters[b * 4 + 1], 1);
-            irregQ[(size_t)b * Q + k] = q;
         }
     }
 #pragma unroll
@@ -223,116 +218,198 @@ __global__ __launch_bounds__(256) void k_query_bbox(const float *__restrict__ pt
     }
 }
 
-// cell id + rank inside the cell for every regular query
-constexpr int kBinPer = 4;     // queries per thread: returning atomics are latency-bound, keep 4 in flight per lane
+// ------------------------------------------------------------------------------------
+// Counting sort of the regular queries into grid cells WITHOUT global atomics.
+// (Round-1 history: one returning global atomicAdd per query = 800 k fabric transactions = 41 us;
+// random-address global atomics run at ~23-26 G/s chip-wide at ANY scope, tools/probes/.)
+// Two levels, both with LDS atomics only:
+//   rows  (cz*G+cy, <= 96^2): k_row_count (per-block LDS histogram + rank inside the block),
+//         k_row_colscan (prefix over blocks per row), k_row_scatter (queries -> row order);
+//   cells (cx inside a row, <= 384): k_row_fine, one wave per row (count, scan, place).
+// The order of queries inside a cell is arbitrary (as it was with global atomics); nothing
+// downstream depends on it except which four accepted queries a hit record keeps.
+// ------------------------------------------------------------------------------------
+constexpr int kMaxRowBlocks = 256;   // blocks per shape in k_row_count / k_row_scatter
+constexpr int kRowTile = 2048;       // smallest query chunk per block
 
-__global__ __launch_bounds__(256) void k_query_bin(const float *__restrict__ pts, int Q, const float *__restrict__ gparam,
-                                                   int G, int Gx, long long cellStride, int *cells, int2 *qcell)
+__global__ __launch_bounds__(256) void k_row_count(const float *__restrict__ pts, int Q, const float *__restrict__ bboxPart,
+                                                   float *gparam, int G, int Gx, int nblk, int chunkQ, int2 *qkey,
+                                                   int *blockHist, int *counters, int *irregQ)
 {
-    const int b = blockIdx.y;
-    const Grid g = load_grid(gparam + b * 12);
-    const int q0 = blockIdx.x * (256 * kBinPer) + threadIdx.x;
-    int cell[kBinPer];
+    __shared__ int hist[kMaxG * kMaxG];
+    const int b = blockIdx.y, blk = blockIdx.x, R = G * G;
+    const Grid g = reduce_grid(bboxPart + (size_t)b * kBoxBlocks * 6, kBoxBlocks, G, Gx);
+    if (blk == 0 && threadIdx.x < 3) {                             // publish for k_row_fine / k_tet_scan
+        const int k = threadIdx.x;
+        gparam[b * 12 + k] = g.o[k]; gparam[b * 12 + 3 + k] = g.inv[k]; gparam[b * 12 + 6 + k] = g.lo[k]; gparam[b * 12 + 9 + k] = g.hi[k];
+    }
+    for (int i = threadIdx.x; i < R; i += 256) hist[i] = 0;
+    __syncthreads();
+    const int q0 = blk * chunkQ, q1 = min(Q, q0 + chunkQ);
+    for (int qb = q0 + threadIdx.x; qb < q1; qb += 256 * 4) {
+        int row[4];
+        float3 pp[4];
 #pragma unroll
-    for (int k = 0; k < kBinPer; ++k) {
-        const int q = q0 + k * 256;
-        cell[k] = -1;
-        if (q < Q) {
-            const float *p = pts + ((size_t)b * Q + q) * 3;
-            const float x = p[0], y = p[1], z = p[2];
-            if (query_regular(x, y, z)) {
-                const int cx = cell_of(x, g.o[0], g.inv[0], Gx), cy = cell_of(y, g.o[1], g.inv[1], G),
-                          cz = cell_of(z, g.o[2], g.inv[2], G);
-                cell[k] = (cz * G + cy) * Gx + cx;
+        for (int k = 0; k < 4; ++k) {
+            const int q = qb + k * 256;
+            if (q < q1) {
+                const float *p = pts + ((size_t)b * Q + q) * 3;
+                pp[k] = make_float3(p[0], p[1], p[2]);
             }
         }
-    }
-    int rank[kBinPer];
 #pragma unroll
-    for (int k = 0; k < kBinPer; ++k) rank[k] = cell[k] >= 0 ? atomicAdd(&cells[(size_t)b * cellStride + cell[k]], 1) : 0;
-#pragma unroll
-    for (int k = 0; k < kBinPer; ++k) {
-        const int q = q0 + k * 256;
-        if (q < Q) qcell[(size_t)b * Q + q] = make_int2(cell[k], rank[k]);
+        for (int k = 0; k < 4; ++k) {
+            const int q = qb + k * 256;
+            if (q >= q1) continue;
+            int rank = 0;
+            if (query_regular(pp[k].x, pp[k].y, pp[k].z)) {
+                row[k] = cell_of(pp[k].z, g.o[2], g.inv[2], G) * G + cell_of(pp[k].y, g.o[1], g.inv[1], G);
+                rank = atomicAdd(&hist[row[k]], 1);                // LDS
+            } else {                                               // NaN / Inf / huge: tested against every tet by k_irreg
+                row[k] = -1;
+                irregQ[(size_t)b * Q + atomicAdd(&counters[b * 4 + 1], 1)] = q;
+            }
+            qkey[(size_t)b * Q + q] = make_int2(row[k], rank);
+        }
     }
-}
-
-// exclusive scan inside chunks of kChunk cells; chunk totals to chunkTot
-__global__ __launch_bounds__(256) void k_scan_chunks(int *cells, long long cellStride, int nChunk, int *chunkTot)
-{
-    __shared__ int wsum[4];
-    const int b = blockIdx.y, c = blockIdx.x;
-    int4 *base = reinterpret_cast<int4 *>(cells + (size_t)b * cellStride + (size_t)c * kChunk);
-    int4 v0 = base[threadIdx.x * 2], v1 = base[threadIdx.x * 2 + 1];
-    int s = v0.x + v0.y + v0.z + v0.w + v1.x + v1.y + v1.z + v1.w;
-    int incl = s;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        int t = __shfl_up(incl, off);
-        if (lane >= off) incl += t;
-    }
-    if (lane == 63) wsum[w] = incl;
     __syncthreads();
-    int wbase = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-        if (k < w) wbase += wsum[k];
-    int run = wbase + incl - s;
-    int4 o0, o1;
-    o0.x = run; run += v0.x; o0.y = run; run += v0.y; o0.z = run; run += v0.z; o0.w = run; run += v0.w;
-    o1.x = run; run += v1.x; o1.y = run; run += v1.y; o1.z = run; run += v1.z; o1.w = run;
-    base[threadIdx.x * 2] = o0;
-    base[threadIdx.x * 2 + 1] = o1;
-    if (threadIdx.x == 255) chunkTot[b * nChunk + c] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    int *out = blockHist + ((size_t)b * nblk + blk) * R;
+    for (int i = threadIdx.x; i < R; i += 256) out[i] = hist[i];
 }
 
-// add the exclusive prefix of the chunk totals to every cell of the chunk
-__global__ __launch_bounds__(256) void k_scan_apply(int *cells, long long cellStride, int nChunk,
-                                                    const int *__restrict__ chunkTot)
+// per row: exclusive prefix of the block histograms over the blocks (in place) + row total
+__global__ __launch_bounds__(256) void k_row_colscan(int *blockHist, int nblk, int R, int *rowTotal)
 {
+    const int b = blockIdx.y, row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= R) return;
+    int *p = blockHist + (size_t)b * nblk * R + row;
+    int run = 0, blk = 0;
+    for (; blk + 8 <= nblk; blk += 8) {
+        int v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = p[(size_t)(blk + k) * R];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            p[(size_t)(blk + k) * R] = run;
+            run += v[k];
+        }
+    }
+    for (; blk < nblk; ++blk) {
+        const int v = p[(size_t)blk * R];
+        p[(size_t)blk * R] = run;
+        run += v;
+    }
+    rowTotal[(size_t)b * R + row] = run;
+}
+
+// queries -> row order.  Every block first rebuilds the row starts (exclusive scan of <= 9216
+// row totals in LDS: cheaper than one more launch); block 0 of a shape publishes them.
+__global__ __launch_bounds__(256) void k_row_scatter(const float *__restrict__ pts, int Q, const int2 *__restrict__ qkey,
+                                                     const int *__restrict__ blockHist, const int *__restrict__ rowTotal,
+                                                     int *rowStart, int G, int nblk, int chunkQ, float4 *rowSorted)
+{
+    __shared__ int rs[kMaxG * kMaxG + 1];
     __shared__ int wsum[4];
-    const int b = blockIdx.y, c = blockIdx.x;
-    int v = 0;
-    for (int i = threadIdx.x; i < c; i += 256) v += chunkTot[b * nChunk + i];
+    const int b = blockIdx.y, blk = blockIdx.x, R = G * G;
+    {
+        const int per = (R + 255) / 256, r0 = threadIdx.x * per, r1 = min(R, r0 + per);
+        const int *rt = rowTotal + (size_t)b * R;
+        int sum = 0;
+        for (int r = r0; r < r1; ++r) sum += rt[r];
+        int incl = sum;
+        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = v;
-    __syncthreads();
-    const int base = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    if (c == 0) return;
-    int4 *p = reinterpret_cast<int4 *>(cells + (size_t)b * cellStride + (size_t)c * kChunk);
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
+        }
+        if (lane == 63) wsum[w] = incl;
+        __syncthreads();
+        int run = incl - sum;
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        int4 x = p[threadIdx.x * 2 + k];
-        x.x += base; x.y += base; x.z += base; x.w += base;
-        p[threadIdx.x * 2 + k] = x;
+        for (int k = 0; k < 4; ++k)
+            if (k < w) run += wsum[k];
+        for (int r = r0; r < r1; ++r) {
+            rs[r] = run;
+            run += rt[r];
+        }
+        if (r0 < R && r1 == R) rs[R] = run;
+        __syncthreads();
+        if (blk == 0)
+            for (int i = threadIdx.x; i <= R; i += 256) rowStart[(size_t)b * (R + 1) + i] = rs[i];
+    }
+    const int *bh = blockHist + ((size_t)b * nblk + blk) * R;
+    const int q0 = blk * chunkQ, q1 = min(Q, q0 + chunkQ);
+    for (int q = q0 + threadIdx.x; q < q1; q += 256) {
+        const int2 k = qkey[(size_t)b * Q + q];
+        if (k.x < 0) continue;
+        const float *p = pts + ((size_t)b * Q + q) * 3;
+        const int pos = rs[k.x] + bh[k.x] + k.y;
+        rowSorted[(size_t)b * Q + pos] = make_float4(p[0], p[1], p[2], __int_as_float(q));
     }
 }
 
-__global__ __launch_bounds__(256) void k_query_scatter(const float *__restrict__ pts, int Q, const int2 *__restrict__ qcell,
-                                                       const int *__restrict__ cells, long long cellStride, float4 *sortedQ)
+// one wave per row: count the row's queries per x-cell, scan, write the cell starts and place the
+// queries in cell order
+__global__ __launch_bounds__(256) void k_row_fine(const float4 *__restrict__ rowSorted, int Q, const float *__restrict__ gparam,
+                                                  int G, int Gx, const int *__restrict__ rowStart, long long cellStride, int *cells,
+                                                  float4 *sortedQ)
 {
-    const int b = blockIdx.y;
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= Q) return;
-    int2 r = qcell[(size_t)b * Q + q];
-    if (r.x < 0) return;
-    const float *p = pts + ((size_t)b * Q + q) * 3;
-    int pos = cells[(size_t)b * cellStride + r.x] + r.y;
-    sortedQ[(size_t)b * Q + pos] = make_float4(p[0], p[1], p[2], __int_as_float(q));
+    __shared__ int cnt[4][kMaxG * kXFine];
+    const int b = blockIdx.y, wv = threadIdx.x >> 6, lane = threadIdx.x & 63, R = G * G;
+    const int row = blockIdx.x * 4 + wv;
+    const bool live = row < R;
+    const float o = gparam[b * 12 + 0], inv = gparam[b * 12 + 3];
+    int s = 0, e = 0;
+    if (live) {
+        s = rowStart[(size_t)b * (R + 1) + row];
+        e = rowStart[(size_t)b * (R + 1) + row + 1];
+    }
+    for (int i = lane; i < Gx; i += 64) cnt[wv][i] = 0;
+    __syncthreads();
+    const float4 *src = rowSorted + (size_t)b * Q;
+    for (int i = s + lane; i < e; i += 64) atomicAdd(&cnt[wv][cell_of(src[i].x, o, inv, Gx)], 1);
+    __syncthreads();
+    if (live) {
+        const int per = (Gx + 63) / 64, c0 = lane * per, c1 = min(Gx, c0 + per);
+        int sum = 0;
+        for (int c = c0; c < c1; ++c) sum += cnt[wv][c];
+        int incl = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
+        }
+        int run = s + incl - sum;
+        int *cb = cells + (size_t)b * cellStride + (size_t)row * Gx;
+        for (int c = c0; c < c1; ++c) {
+            const int n = cnt[wv][c];
+            cnt[wv][c] = run;                                      // becomes the placement cursor
+            cb[c] = run;
+            run += n;
+        }
+        if (row == R - 1 && lane == 0) cb[Gx] = e;                 // end sentinel: cells has Gx*G*G+1 entries
+    }
+    __syncthreads();
+    float4 *dst = sortedQ + (size_t)b * Q;
+    for (int i = s + lane; i < e; i += 64) {
+        const float4 q = src[i];
+        dst[atomicAdd(&cnt[wv][cell_of(q.x, o, inv, Gx)], 1)] = q;
+    }
 }
 
 // The main kernel: one lane per tet, exact test inline.
 // (A two-phase variant — ballot-compacted candidate ring in LDS + dense exact test — was built
 // and measured in round 1: 14 % fewer VALU instructions but 1.5x slower, because the kernel is
 // bound by vector-memory issue/latency, not by VALU: SQ_WAIT_ANY = 66 % of SQ_WAVE_CYCLES,
-// ~55 gather instructions per wave.  See DESIGN.md "A1 kernel anatomy" and profiles/.)
+// ~55 gather instructions per wave.  A per-lane LDS candidate queue that defers the exact test so
+// that it is issued max-over-lanes times per wave instead of once per slot was also measured:
+// 133 us vs 114 us — same conclusion.  See DESIGN.md "A1 kernel anatomy" and profiles/.)
 #ifndef PIT_WAVES
 #define PIT_WAVES 6
 #endif
 #ifndef PIT_BATCH
-#define PIT_BATCH 4
+#define PIT_BATCH 2
 #endif
 __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan(const float *__restrict__ tet, int T, int Q,
                                                   const float *__restrict__ gparam, int G, int Gx, const int *__restrict__ cells,
@@ -406,44 +483,45 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan(const float *__rest
     int *res = result + (size_t)b * Q;
     // Walk the (cz, cy) rows of the cell range; the x-run of a row is contiguous in sortedQ.
     // Latency hiding per lane: the next row's [start,end) is fetched before the current
-    // row's queries are tested, and queries are fetched four at a time.
+    // row's queries are tested, and queries are fetched PIT_BATCH at a time (measured on the
+    // BASELINE workload: 2 predicated = 104 us, 4 predicated = 135 us, 4 clamped = 113 us, 2 clamped = 118 us).
     auto test = [&](const float4 &q) {
         if (q.x >= elo[0] && q.x <= ehi[0] && q.y >= elo[1] && q.y <= ehi[1] && q.z >= elo[2] && q.z <= ehi[2]) {
-#if defined(PIT_EXP_PLAIN_STORE)      // timing experiment only (wrong results on ties)
-            if (accept(P, q.x, q.y, q.z)) res[__float_as_int(q.w)] = t;
-#elif defined(PIT_EXP_NO_STORE)
-            if (accept(P, q.x, q.y, q.z)) asm volatile("" ::"v"(t));
-#else
             if (accept(P, q.x, q.y, q.z)) {
                 const int qi = __float_as_int(q.w);
+#if defined(PIT_EXP_PLAIN_STORE)      // timing experiments only (wrong results on ties)
+                res[qi] = t;
+#elif defined(PIT_EXP_NO_STORE)
+                asm volatile("" ::"v"(t), "v"(qi));
+#else
                 atomicMin(&res[qi], t);
                 if (hcnt == 0) hrec.x = qi;
                 else if (hcnt == 1) hrec.y = qi;
                 else if (hcnt == 2) hrec.z = qi;
                 else if (hcnt == 3) hrec.w = qi;
                 ++hcnt;
-            }
 #endif
+            }
         }
     };
     int cy = cy0, cz = cz0;
-    int s = cb[(cz * G + cy) * Gx + cx0];
-    int e = cb[(cz * G + cy) * Gx + cx1 + 1];          // cells has Gx*G*G+1 valid entries
+    auto bounds = [&](int row, int &s_, int &e_) {
+        s_ = cb[row + cx0];
+        e_ = cb[row + cx1 + 1];                         // cells has Gx*G*G+1 valid entries
+    };
+    int s, e;
+    bounds((cz * G + cy) * Gx, s, e);
     for (;;) {
         int ny = cy + 1, nz = cz;
         if (ny > cy1) { ny = cy0; nz = cz + 1; }
         const bool more = nz <= cz1;
         int s2 = 0, e2 = 0;
-        if (more) {
-            const int row2 = (nz * G + ny) * Gx;
-            s2 = cb[row2 + cx0];
-            e2 = cb[row2 + cx1 + 1];
-        }
+        if (more) bounds((nz * G + ny) * Gx, s2, e2);
         for (int j = s; j < e; j += PIT_BATCH) {
-            const int last = e - 1;
             float4 qq[PIT_BATCH];
 #pragma unroll
-            for (int k = 0; k < PIT_BATCH; ++k) qq[k] = sq[min(j + k, last)];
+            for (int k = 0; k < PIT_BATCH; ++k)
+                if (k == 0 || j + k < e) qq[k] = sq[j + k];     // no clamped duplicate gathers: lane-gathers are the cost
 #pragma unroll
             for (int k = 0; k < PIT_BATCH; ++k)
                 if (k == 0 || j + k < e) test(qq[k]);
@@ -474,6 +552,9 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan(const float *__rest
 // the operands changes.  Waves whose box is too large (incoherent tet order, or a wave that
 // straddles two grid columns) take the per-lane gather path of k_tet_scan.
 // ------------------------------------------------------------------------------------
+#ifndef PIT_STAGE_BATCH
+#define PIT_STAGE_BATCH 4
+#endif
 constexpr int kSubMax = 448;           // staged cell bounds per wave
 constexpr int kStageQ = 224;           // staged queries per wave
 
@@ -620,12 +701,12 @@ __global__ __launch_bounds__(256, PIT_STAGE_WAVES) void k_tet_scan_staged(const 
                         const int r = (cz - uz0) * ny + (cy - uy0), base = r * nx1;
                         const int s = s_cs[wv][base + cx0 - ux0], e = s_cs[wv][base + cx1 + 1 - ux0];
                         const int l0 = s_off[wv][r] + (s - s_rs[wv][r]), n = e - s;
-                        for (int j = 0; j < n; j += PIT_BATCH) {
-                            float4 qq[PIT_BATCH];
+                        for (int j = 0; j < n; j += PIT_STAGE_BATCH) {
+                            float4 qq[PIT_STAGE_BATCH];
 #pragma unroll
-                            for (int k = 0; k < PIT_BATCH; ++k) qq[k] = s_q[wv][l0 + min(j + k, n - 1)];
+                            for (int k = 0; k < PIT_STAGE_BATCH; ++k) qq[k] = s_q[wv][l0 + min(j + k, n - 1)];
 #pragma unroll
-                            for (int k = 0; k < PIT_BATCH; ++k)
+                            for (int k = 0; k < PIT_STAGE_BATCH; ++k)
                                 if (k == 0 || j + k < n) test(qq[k]);
                         }
                     }
@@ -645,13 +726,13 @@ __global__ __launch_bounds__(256, PIT_STAGE_WAVES) void k_tet_scan_staged(const 
                     s2 = cb[row2 + cx0];
                     e2 = cb[row2 + cx1 + 1];
                 }
-                for (int j = s; j < e; j += PIT_BATCH) {
+                for (int j = s; j < e; j += PIT_STAGE_BATCH) {
                     const int last = e - 1;
-                    float4 qq[PIT_BATCH];
+                    float4 qq[PIT_STAGE_BATCH];
 #pragma unroll
-                    for (int k = 0; k < PIT_BATCH; ++k) qq[k] = sq[min(j + k, last)];
+                    for (int k = 0; k < PIT_STAGE_BATCH; ++k) qq[k] = sq[min(j + k, last)];
 #pragma unroll
-                    for (int k = 0; k < PIT_BATCH; ++k)
+                    for (int k = 0; k < PIT_STAGE_BATCH; ++k)
                         if (k == 0 || j + k < e) test(qq[k]);
                 }
                 if (!more) break;
@@ -1201,13 +1282,13 @@ static int pick_G(int T, int Q)
 }
 
 struct Layout {
-    int G, Gx, nChunk;
-    long long cellStride;   // padded cells per shape (multiple of kChunk, >= G^3+1)
+    int G, Gx, nRowBlk, chunkQ;
+    long long cellStride;   // padded cells per shape (>= Gx*G*G + 1)
     size_t bytes;
     float *bboxPart;
-    int *counters, *cells, *chunkTot, *result, *irregT, *irregQ;
-    int2 *qcell;
-    float4 *sortedQ;
+    int *counters, *cells, *blockHist, *rowTotal, *rowStart, *result, *irregT, *irregQ;
+    int2 *qkey;
+    float4 *rowSorted, *sortedQ;
     float *rec, *gparam;
 };
 
@@ -1221,15 +1302,21 @@ static Layout make_layout(int B, int T, int Q, int algo, void *ws, size_t wsByte
     } else {
         L.G = pick_G(T, Q);
         L.Gx = L.G * kXFine;
-        long long n = (long long)L.Gx * L.G * L.G + 1;
-        L.nChunk = (int)((n + kChunk - 1) / kChunk);
-        L.cellStride = (long long)L.nChunk * kChunk;
+        const long long n = (long long)L.Gx * L.G * L.G + 1, R = (long long)L.G * L.G;
+        L.cellStride = (n + 63) / 64 * 64;
+        L.nRowBlk = (Q + kRowTile - 1) / kRowTile;
+        if (L.nRowBlk > kMaxRowBlocks) L.nRowBlk = kMaxRowBlocks;
+        if (L.nRowBlk < 1) L.nRowBlk = 1;
+        L.chunkQ = ((Q + L.nRowBlk - 1) / L.nRowBlk + 255) / 256 * 256;
         L.bboxPart = A.take<float>((size_t)B * kBoxBlocks * 6);
         L.counters = A.take<int>((size_t)B * 4);
         L.gparam = A.take<float>((size_t)B * 12);
         L.cells = A.take<int>((size_t)B * L.cellStride);
-        L.chunkTot = A.take<int>((size_t)B * L.nChunk);
-        L.qcell = A.take<int2>((size_t)B * Q);
+        L.blockHist = A.take<int>((size_t)B * L.nRowBlk * R);
+        L.rowTotal = A.take<int>((size_t)B * R);
+        L.rowStart = A.take<int>((size_t)B * (R + 1));
+        L.qkey = A.take<int2>((size_t)B * Q);
+        L.rowSorted = A.take<float4>((size_t)B * Q);
         L.sortedQ = A.take<float4>((size_t)B * Q);
         L.irregT = A.take<int>((size_t)B * T);
         L.irregQ = A.take<int>((size_t)B * Q);
@@ -1287,17 +1374,15 @@ extern "C" int deftet_point_in_tet_f32(const float *tet, const float *pts, float
         }
         DEFTET_LAUNCH(k_brute, gq, blk, st, L.rec, pts, T, Q, L.result);
     } else {
-        const long long nCells = (long long)B * L.cellStride, nQ = (long long)B * Q;
-        long long mx = nCells > nQ ? nCells : nQ;
-        int ib = (int)((mx + 255) / 256);
-        if (ib > 4096) ib = 4096;
-        DEFTET_LAUNCH(k_init, dim3(ib), blk, st, L.counters, L.cells, L.result, B, nCells, nQ);
-        DEFTET_LAUNCH(k_query_bbox, dim3(kBoxBlocks, B), blk, st, pts, Q, L.bboxPart, L.counters, L.irregQ);
-        DEFTET_LAUNCH(k_grid_params, dim3(B), dim3(64), st, L.bboxPart, kBoxBlocks, L.G, L.Gx, L.gparam);
-        DEFTET_LAUNCH(k_query_bin, dim3((Q + 256 * kBinPer - 1) / (256 * kBinPer), B), blk, st, pts, Q, L.gparam, L.G, L.Gx, L.cellStride, L.cells, L.qcell);
-        DEFTET_LAUNCH(k_scan_chunks, dim3(L.nChunk, B), blk, st, L.cells, L.cellStride, L.nChunk, L.chunkTot);
-        DEFTET_LAUNCH(k_scan_apply, dim3(L.nChunk, B), blk, st, L.cells, L.cellStride, L.nChunk, L.chunkTot);
-        DEFTET_LAUNCH(k_query_scatter, gq, blk, st, pts, Q, L.qcell, L.cells, L.cellStride, L.sortedQ);
+        const int R = L.G * L.G;
+        DEFTET_LAUNCH(k_query_bbox, dim3(kBoxBlocks, B), blk, st, pts, Q, L.bboxPart, L.counters, L.result, B, (long long)B * Q);
+        DEFTET_LAUNCH(k_row_count, dim3(L.nRowBlk, B), blk, st, pts, Q, L.bboxPart, L.gparam, L.G, L.Gx, L.nRowBlk, L.chunkQ, L.qkey,
+                      L.blockHist, L.counters, L.irregQ);
+        DEFTET_LAUNCH(k_row_colscan, dim3((R + 255) / 256, B), blk, st, L.blockHist, L.nRowBlk, R, L.rowTotal);
+        DEFTET_LAUNCH(k_row_scatter, dim3(L.nRowBlk, B), blk, st, pts, Q, L.qkey, L.blockHist, L.rowTotal, L.rowStart, L.G, L.nRowBlk,
+                      L.chunkQ, L.rowSorted);
+        DEFTET_LAUNCH(k_row_fine, dim3((R + 3) / 4, B), blk, st, L.rowSorted, Q, L.gparam, L.G, L.Gx, L.rowStart, L.cellStride, L.cells,
+                      L.sortedQ);
         if (T > 0) {
             if (algo != DEFTET_PIT_STAGED) {
                 DEFTET_LAUNCH(k_tet_scan, gt, blk, st, tet, T, Q, L.gparam, L.G, L.Gx, L.cells, L.cellStride, L.sortedQ, L.result,

@@ -1,4 +1,5 @@
-// reduce.hip — per-shape loss scalars: out[r] = sum_c a[r,c] * b[r,c]  (b may be NULL: plain row sum).
+// reduce.hip — per-shape loss scalars: out[r] = sum_c a[r,c] * b[r,c]  (b may be NULL: plain row sum),
+// optionally plus a second term sum_c a2[r,c] * b2[r,c] with its own width (one launch pair for both).
 // Deterministic (fixed reduction tree, no atomics): kParts workgroups per row write partial
 // sums into the caller's workspace, one wave per row adds them up.
 #include "common.hpp"
@@ -8,11 +9,9 @@ namespace red {
 
 constexpr int kParts = 128;
 
-__global__ __launch_bounds__(256) void k_rowdot_partial(const float *__restrict__ a, const float *__restrict__ b,
-                                                        float *part, long long n_cols)
+__device__ __forceinline__ float rowdot_slice(const float *__restrict__ a, const float *__restrict__ b, long long r,
+                                              long long n_cols)
 {
-    __shared__ float wsum[4];
-    const long long r = blockIdx.y;
     const float *pa = a + r * n_cols;
     const float *pb = b ? b + r * n_cols : nullptr;
     float acc = 0.f;
@@ -32,6 +31,17 @@ __global__ __launch_bounds__(256) void k_rowdot_partial(const float *__restrict_
     } else {
         for (long long i = tid; i < n_cols; i += stride) acc += pb ? pa[i] * pb[i] : pa[i];
     }
+    return acc;
+}
+
+__global__ __launch_bounds__(256) void k_rowdot_partial(const float *__restrict__ a, const float *__restrict__ b,
+                                                        float *part, long long n_cols, const float *__restrict__ a2,
+                                                        const float *__restrict__ b2, long long n_cols2)
+{
+    __shared__ float wsum[4];
+    const long long r = blockIdx.y;
+    float acc = rowdot_slice(a, b, r, n_cols);
+    if (a2) acc += rowdot_slice(a2, b2, r, n_cols2);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
@@ -53,16 +63,23 @@ __global__ __launch_bounds__(64) void k_rowdot_final(const float *__restrict__ p
 
 extern "C" size_t deftet_rowdot_workspace_bytes(int n_rows) { return (size_t)(n_rows > 0 ? n_rows : 0) * deftet::red::kParts * 4; }
 
-extern "C" int deftet_rowdot_f32(const float *a, const float *b, float *out, int n_rows, long long n_cols, void *workspace,
-                                 size_t workspace_bytes, void *stream_)
+extern "C" int deftet_rowdot2_f32(const float *a, const float *b, long long n_cols, const float *a2, const float *b2,
+                                  long long n_cols2, float *out, int n_rows, void *workspace, size_t workspace_bytes,
+                                  void *stream_)
 {
-    DEFTET_CHECK_ARG(n_rows >= 0 && n_cols >= 0 && n_rows <= 65535, "bad size");
+    DEFTET_CHECK_ARG(n_rows >= 0 && n_cols >= 0 && n_cols2 >= 0 && n_rows <= 65535, "bad size");
     if (n_rows == 0) return DEFTET_OK;
     DEFTET_CHECK_ARG(a && out, "null pointer");
     DEFTET_CHECK_ARG(workspace && workspace_bytes >= deftet_rowdot_workspace_bytes(n_rows), "workspace null or too small");
     hipStream_t st = deftet::as_stream(stream_);
     float *part = static_cast<float *>(workspace);
-    DEFTET_LAUNCH(deftet::red::k_rowdot_partial, dim3(deftet::red::kParts, n_rows), dim3(256), st, a, b, part, n_cols);
+    DEFTET_LAUNCH(deftet::red::k_rowdot_partial, dim3(deftet::red::kParts, n_rows), dim3(256), st, a, b, part, n_cols, a2, b2, n_cols2);
     DEFTET_LAUNCH(deftet::red::k_rowdot_final, dim3(n_rows), dim3(64), st, part, out);
     return DEFTET_OK;
+}
+
+extern "C" int deftet_rowdot_f32(const float *a, const float *b, float *out, int n_rows, long long n_cols, void *workspace,
+                                 size_t workspace_bytes, void *stream_)
+{
+    return deftet_rowdot2_f32(a, b, n_cols, nullptr, nullptr, 0, out, n_rows, workspace, workspace_bytes, stream_);
 }

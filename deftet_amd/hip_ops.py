@@ -105,20 +105,31 @@ def paste_occ_bwd(cond_bxqx1, grad_out_bxq, n_tet):
     return gp
 
 
-def rowdot(a, b=None):
-    """out[r] = sum over the trailing dims of a[r]*b[r] (row sums when b is None); f32 [R]."""
-    _lib.require_gpu(a, b)
+def rowdot(a, b=None, a2=None, b2=None):
+    """out[r] = sum over the trailing dims of a[r]*b[r] (row sums when b is None), plus the same
+    for the optional second pair (a2, b2) of its own width, in one launch pair; f32 [R]."""
+    _lib.require_gpu(a, b, a2, b2)
     lib = _lib.load()
     a = _f32c(a)
     b = _f32c(b) if b is not None else None
     if b is not None and b.shape != a.shape:
         raise RuntimeError("rowdot: shape mismatch %s vs %s" % (tuple(a.shape), tuple(b.shape)))
     R = a.shape[0]
+    n2 = 0
+    if a2 is not None:
+        a2 = _f32c(a2)
+        b2 = _f32c(b2) if b2 is not None else None
+        if a2.shape[0] != R or (b2 is not None and b2.shape != a2.shape):
+            raise RuntimeError("rowdot: second pair shape mismatch")
+        n2 = a2.numel() // max(R, 1)
+    elif b2 is not None:
+        raise RuntimeError("rowdot: b2 without a2")
     out = torch.empty(R, device=a.device, dtype=torch.float32)
     with torch.cuda.device(a.device):
         ws = _lib.workspace(a.device, lib.deftet_rowdot_workspace_bytes(R))
-        _lib.check(lib.deftet_rowdot_f32(_lib.ptr(a), _lib.ptr(b), _lib.ptr(out), R, a.numel() // max(R, 1),
-                                         _lib.ptr(ws), ws.numel(), _lib.current_stream(a.device)), "deftet_rowdot_f32")
+        _lib.check(lib.deftet_rowdot2_f32(_lib.ptr(a), _lib.ptr(b), a.numel() // max(R, 1), _lib.ptr(a2), _lib.ptr(b2), n2,
+                                          _lib.ptr(out), R, _lib.ptr(ws), ws.numel(), _lib.current_stream(a.device)),
+                   "deftet_rowdot2_f32")
     return out
 
 

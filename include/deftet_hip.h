@@ -102,6 +102,11 @@ int deftet_paste_occ_bwd_f32(const float *cond_bxq, const float *grad_out_bxq, f
 size_t deftet_rowdot_workspace_bytes(int n_rows);
 int deftet_rowdot_f32(const float *a, const float *b, float *out, int n_rows, long long n_cols,
                       void *workspace, size_t workspace_bytes, void *stream);
+/* Two terms of different width in one launch pair:
+ * out[r] = sum_c a[r,c]*b[r,c] + sum_c a2[r,c]*b2[r,c]  (a2 == NULL: first term only). */
+int deftet_rowdot2_f32(const float *a, const float *b, long long n_cols, const float *a2, const float *b2,
+                       long long n_cols2, float *out, int n_rows, void *workspace, size_t workspace_bytes,
+                       void *stream);
 
 /* ---------------------------------------------------------------------------------
  * A2-A6  adjacency builders.  Device variants take device pointers and a caller

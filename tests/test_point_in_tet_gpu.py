@@ -154,6 +154,11 @@ def test_rowdot(cuda):
         assert torch.allclose(got.double(), want, rtol=1e-5, atol=1e-3)
         assert torch.equal(got, hip_ops.rowdot(a, b))            # deterministic
         assert torch.allclose(hip_ops.rowdot(a).double(), a.double().flatten(1).sum(1), rtol=1e-5, atol=1e-3)
+        a2 = torch.randn(shape[0], 1237, device=cuda, generator=g)                # second pair of another width
+        b2 = torch.randn(shape[0], 1237, device=cuda, generator=g)
+        want2 = want + (a2.double() * b2.double()).sum(1)
+        assert torch.allclose(hip_ops.rowdot(a, b, a2, b2).double(), want2, rtol=1e-5, atol=1e-3)
+        assert torch.allclose(hip_ops.rowdot(a, b, a2).double(), want + a2.double().sum(1), rtol=1e-5, atol=1e-3)
 
 
 def test_fused_occ_op_matches_separate_ops(cuda, oracle):
