@@ -37,7 +37,7 @@ constexpr int kHitOverflow = -2;            // hits[.].w: this tet has accepted 
 
 // "hit record" buffer written by the forward and consumed by the backward (int32 words):
 //   [0, 4*B*T)            int4 per tet: the (<= 4) queries the tet accepted, or w == kHitOverflow
-//   [4*B*T, +kHitPad)     per shape: number of uncovered queries
+//   [4*B*T, +pad)         per shape: number of uncovered queries (pad = B rounded up to kHitPad)
 //   [.., + B*Q)           per shape: uncovered queries = hits that are NOT in their tet's record
 //                         (tet overflowed / irregular tet / NaN-Inf-huge query)
 constexpr int kHitPad = 64;
@@ -177,7 +177,7 @@ __device__ __forceinline__ bool query_regular(float x, float y, float z)
 // The same launch also clears what the later kernels accumulate into (counters, result
 // sentinels): nothing in THIS kernel reads them.
 __global__ __launch_bounds__(256) void k_query_bbox(const float *__restrict__ pts, int Q, float *part, int *counters,
-                                                    int *result, int nB, long long nQ)
+                                                    int *result, int nB, long long nQ, int *hitCnt, int nHitCnt)
 {
     __shared__ float sh[4][6];
     const int b = blockIdx.y;
@@ -185,6 +185,7 @@ __global__ __launch_bounds__(256) void k_query_bbox(const float *__restrict__ pt
         const long long nblk = (long long)gridDim.x * gridDim.y, bid = (long long)blockIdx.y * gridDim.x + blockIdx.x;
         const long long i = bid * blockDim.x + threadIdx.x, stride = nblk * blockDim.x;
         if (i < nB * 4) counters[i] = 0;
+        if (hitCnt && i < nHitCnt) hitCnt[i] = 0;
         for (long long j = i; j < nQ; j += stride) result[j] = kMiss;
     }
     const float *p = pts + (size_t)b * Q * 3;
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(256) void k_row_count(const float *__restrict__ pts
             if (query_regular(pp[k].x, pp[k].y, pp[k].z)) {
                 row[k] = cell_of(pp[k].z, g.o[2], g.inv[2], G) * G + cell_of(pp[k].y, g.o[1], g.inv[1], G);
                 rank = atomicAdd(&hist[row[k]], 1);                // LDS
-            } else {                                               // NaN / Inf / huge: tested against every tet by k_irreg
+            } else {                                               // NaN / Inf / huge: tested by every tet lane at the end of k_tet_scan
                 row[k] = -1;
                 irregQ[(size_t)b * Q + atomicAdd(&counters[b * 4 + 1], 1)] = q;
             }
@@ -398,6 +399,19 @@ __global__ __launch_bounds__(256) void k_row_fine(const float4 *__restrict__ row
     }
 }
 
+// Irregular queries (NaN / Inf / |x| > 2^20: not in the grid; normally none) are tested by every
+// tet lane against its own planes at the end of the tet kernels.
+__device__ __forceinline__ void irregular_queries_tail(const Planes &P, int t, int b, int Q, const float *__restrict__ pts,
+                                                       const int *__restrict__ counters, const int *__restrict__ irregQ, int *result)
+{
+    const int n = counters[b * 4 + 1];
+    for (int k = 0; k < n; ++k) {
+        const int q = irregQ[(size_t)b * Q + k];
+        const float *p = pts + ((size_t)b * Q + q) * 3;
+        if (accept(P, p[0], p[1], p[2])) atomicMin(&result[(size_t)b * Q + q], t);
+    }
+}
+
 // The main kernel: one lane per tet, exact test inline.
 // (A two-phase variant — ballot-compacted candidate ring in LDS + dense exact test — was built
 // and measured in round 1: 14 % fewer VALU instructions but 1.5x slower, because the kernel is
@@ -414,7 +428,8 @@ __global__ __launch_bounds__(256) void k_row_fine(const float4 *__restrict__ row
 __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan(const float *__restrict__ tet, int T, int Q,
                                                   const float *__restrict__ gparam, int G, int Gx, const int *__restrict__ cells,
                                                   long long cellStride, const float4 *__restrict__ sortedQ, int *result, int *counters,
-                                                  int *irregT, int4 *hits)
+                                                  int *irregT, int4 *hits, const float *__restrict__ pts,
+                                                  const int *__restrict__ irregQ)
 {
     const int b = blockIdx.y;
     // XCD-aware mapping (workgroup i is observed to run on XCD i % 8, each XCD has a private
@@ -459,7 +474,8 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan(const float *__rest
     if (!regular) {
         int k = atomicAdd(&counters[b * 4 + 0], 1);
         irregT[(size_t)b * T + k] = t;
-        if (hits) hits[(size_t)b * T + t] = make_int4(-1, -1, -1, kHitOverflow);   // accepted by k_irreg, not recorded
+        if (hits) hits[(size_t)b * T + t] = make_int4(-1, -1, -1, kHitOverflow);   // accepted by k_finalize, not recorded
+        irregular_queries_tail(P, t, b, Q, pts, counters, irregQ, result);
         return;
     }
     const Grid g = load_grid(gparam + b * 12);
@@ -473,6 +489,7 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan(const float *__rest
     // no regular query can lie in the enlarged box -> nothing to do
     if (ehi[0] < g.lo[0] || elo[0] > g.hi[0] || ehi[1] < g.lo[1] || elo[1] > g.hi[1] || ehi[2] < g.lo[2] || elo[2] > g.hi[2]) {
         if (hits) hits[(size_t)b * T + t] = hrec;
+        irregular_queries_tail(P, t, b, Q, pts, counters, irregQ, result);
         return;
     }
     const int cx0 = cell_of(elo[0], g.o[0], g.inv[0], Gx), cx1 = cell_of(ehi[0], g.o[0], g.inv[0], Gx);
@@ -536,6 +553,7 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan(const float *__rest
         }
         hits[(size_t)b * T + t] = hrec;
     }
+    irregular_queries_tail(P, t, b, Q, pts, counters, irregQ, result);
 }
 
 // ------------------------------------------------------------------------------------
@@ -583,7 +601,8 @@ __device__ __forceinline__ void wave_fence()
 __global__ __launch_bounds__(256, PIT_STAGE_WAVES) void k_tet_scan_staged(const float *__restrict__ tet, int T, int Q,
                                                   const float *__restrict__ gparam, int G, int Gx, const int *__restrict__ cells,
                                                   long long cellStride, const float4 *__restrict__ sortedQ, int *result, int *counters,
-                                                  int *irregT, int4 *hits)
+                                                  int *irregT, int4 *hits, const float *__restrict__ pts,
+                                                  const int *__restrict__ irregQ)
 {
     __shared__ int s_cs[4][kSubMax];
     __shared__ float4 s_q[4][kStageQ];
@@ -623,7 +642,7 @@ __global__ __launch_bounds__(256, PIT_STAGE_WAVES) void k_tet_scan_staged(const 
     if (intet && !regular) {
         const int k = atomicAdd(&counters[b * 4 + 0], 1);
         irregT[(size_t)b * T + k] = t;
-        hrec.w = kHitOverflow;                                       // accepted by k_irreg, not recorded
+        hrec.w = kHitOverflow;                                       // accepted by k_finalize, not recorded
     }
     const Grid g = load_grid(gparam + b * 12);
     const float m = w * kMargin;
@@ -747,65 +766,7 @@ __global__ __launch_bounds__(256, PIT_STAGE_WAVES) void k_tet_scan_staged(const 
         }
         hits[(size_t)b * T + t] = hrec;
     }
-}
-
-// irregular tets x all queries
-__device__ __forceinline__ void irreg_tets_body(const float *__restrict__ tet, const float *__restrict__ pts, int T,
-                                                    int Q, const int *__restrict__ counters,
-                                                    const int *__restrict__ irregT, int *result)
-{
-    const int b = blockIdx.y;
-    const int n = counters[b * 4 + 0];
-    if (n == 0) return;
-    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < Q; q += gridDim.x * blockDim.x) {
-        const float *p = pts + ((size_t)b * Q + q) * 3;
-        const float x = p[0], y = p[1], z = p[2];
-        int best = kMiss;
-        for (int k = 0; k < n; ++k) {
-            const int t = irregT[(size_t)b * T + k];
-            float v[12];
-            const float *src = tet + ((size_t)b * T + t) * 12;
-#pragma unroll
-            for (int i = 0; i < 12; ++i) v[i] = src[i];
-            Planes P;
-            make_planes(v, P);
-            if (accept(P, x, y, z)) best = min(best, t);
-        }
-        if (best != kMiss) atomicMin(&result[(size_t)b * Q + q], best);
-    }
-}
-
-// irregular queries x all tets
-__device__ __forceinline__ void irreg_queries_body(const float *__restrict__ tet, const float *__restrict__ pts,
-                                                       int T, int Q, const int *__restrict__ counters,
-                                                       const int *__restrict__ irregQ, int *result)
-{
-    const int b = blockIdx.y;
-    const int n = counters[b * 4 + 1];
-    if (n == 0) return;
-    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < T; t += gridDim.x * blockDim.x) {
-        float v[12];
-        const float *src = tet + ((size_t)b * T + t) * 12;
-#pragma unroll
-        for (int i = 0; i < 12; ++i) v[i] = src[i];
-        Planes P;
-        make_planes(v, P);
-        for (int k = 0; k < n; ++k) {
-            const int q = irregQ[(size_t)b * Q + k];
-            const float *p = pts + ((size_t)b * Q + q) * 3;
-            if (accept(P, p[0], p[1], p[2])) atomicMin(&result[(size_t)b * Q + q], t);
-        }
-    }
-}
-
-// both irregular side paths in one launch: blockIdx.z == 0 -> irregular tets x all queries,
-// blockIdx.z == 1 -> irregular queries x all tets (both return at once when their list is empty)
-__global__ __launch_bounds__(256) void k_irreg(const float *__restrict__ tet, const float *__restrict__ pts, int T, int Q,
-                                               const int *__restrict__ counters, const int *__restrict__ irregT,
-                                               const int *__restrict__ irregQ, int *result)
-{
-    if (blockIdx.z == 0) irreg_tets_body(tet, pts, T, Q, counters, irregT, result);
-    else irreg_queries_body(tet, pts, T, Q, counters, irregQ, result);
+    if (intet) irregular_queries_tail(P, t, b, Q, pts, counters, irregQ, result);
 }
 
 // barycentric weights, utils/tet_utils.py:25-45 (same association as the torch expression)
@@ -820,13 +781,31 @@ __device__ __forceinline__ float triple(const float *a, const float *b, const fl
 __global__ __launch_bounds__(256) void k_finalize(const float *__restrict__ tet, const float *__restrict__ pts, int T,
                                                   int Q, const int *__restrict__ result, float *cond, float *bary,
                                                   const float *__restrict__ pred, float *occ, const int4 *__restrict__ hits,
-                                                  int *ucount, int *ulist, const int *__restrict__ counters)
+                                                  int *ucount, int *ulist, const int *__restrict__ counters,
+                                                  const int *__restrict__ irregT)
 {
     const int b = blockIdx.y;
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= Q) return;
     const size_t i = (size_t)b * Q + q;
-    const int r = result[i];
+    int r = result[i];
+    // irregular tets (not certified for the grid filter; normally none) are tested here against
+    // every query: query-centric, so no atomics and no extra launch
+    const int nIrregT = counters ? counters[b * 4 + 0] : 0;
+    if (nIrregT > 0) {
+        const float *p = pts + i * 3;
+        const float x = p[0], y = p[1], z = p[2];
+        for (int k = 0; k < nIrregT; ++k) {
+            const int t = irregT[(size_t)b * T + k];
+            float v[12];
+            const float *src = tet + ((size_t)b * T + t) * 12;
+#pragma unroll
+            for (int j = 0; j < 12; ++j) v[j] = src[j];
+            Planes P;
+            make_planes(v, P);
+            if (accept(P, x, y, z)) r = min(r, t);
+        }
+    }
     const bool hit = r != kMiss;
     cond[i] = hit ? (float)r : -1.0f;                               // :177, :149
     if (occ) occ[i] = pred[(size_t)b * T + (hit ? r : 0)];          // paste_occ: misses alias tet 0 (deftet.py:133-135)
@@ -1097,19 +1076,6 @@ __global__ __launch_bounds__(256) void k_bary_bwd_gather(const float *__restrict
 // --- backward from the forward's hit records: no atomics, no lists, no memsets ---------------------
 // per-block partial sums of the paste_occ gradient of the misses (they alias tet 0, deftet.py:133)
 constexpr int kMissParts = 64;
-__global__ __launch_bounds__(256) void k_miss_sum(const float *__restrict__ cond, const float *__restrict__ gocc, int Q, float *part)
-{
-    __shared__ float wsum[4];
-    const int b = blockIdx.y;
-    float gm = 0.f;
-    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < Q; q += gridDim.x * blockDim.x)
-        if (cond[(size_t)b * Q + q] < 0.f) gm += gocc[(size_t)b * Q + q];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) gm += __shfl_xor(gm, off);
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = gm;
-    __syncthreads();
-    if (threadIdx.x == 0) part[b * kMissParts + blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
-}
 
 struct TetGrad {
     float A[3], Bv[3];
@@ -1157,17 +1123,30 @@ __global__ __launch_bounds__(256) void k_bary_bwd_hits(const float *__restrict__
                                                        const float *__restrict__ cond, const float *__restrict__ grad_w,
                                                        const int4 *__restrict__ hits, int T, int Q, float *grad_tet,
                                                        float *grad_pts, int accumulate, const float *__restrict__ gocc,
-                                                       const float *__restrict__ missPart, float *grad_pred)
+                                                       float *grad_pred, float *missPart, int nMissParts)
 {
     const int b = blockIdx.y;
+    // paste_occ sends every miss to tet 0 (deftet.py:133-135), so grad_pred[b,0] also gets the sum
+    // of grad_occ over the misses.  The first nMissParts blocks of a shape each sum a slice of the
+    // queries on the side (hidden under this kernel's own traffic); k_bary_bwd_tail adds the
+    // partials up in a fixed order.
+    if (grad_pred && (int)blockIdx.x < nMissParts) {
+        __shared__ float wsum[4];
+        float gm = 0.f;
+        for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < Q; q += nMissParts * blockDim.x)
+            if (cond[(size_t)b * Q + q] < 0.f) gm += gocc[(size_t)b * Q + q];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) gm += __shfl_xor(gm, off);
+        if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = gm;
+        __syncthreads();
+        if (threadIdx.x == 0) missPart[b * kMissParts + blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+    }
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
     float acc[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) acc[k] = 0.f;
     float gp = 0.f;
-    if (grad_pred && t == 0)
-        for (int k = 0; k < kMissParts; ++k) gp += missPart[b * kMissParts + k];     // clamped misses paste from tet 0
     const int4 h = hits[(size_t)b * T + t];
     if (h.x >= 0 && h.w != kHitOverflow) {                         // slots fill in order: x < 0 means no accepted query
         TetGrad g;
@@ -1199,14 +1178,23 @@ __global__ __launch_bounds__(256) void k_bary_bwd_hits(const float *__restrict__
     dst[0] = o0; dst[1] = o1; dst[2] = o2;
 }
 
-// the (normally empty) list of hits that are not in any tet record: float atomics, after k_bary_bwd_hits
-__global__ __launch_bounds__(256) void k_bary_bwd_uncovered(const float *__restrict__ tet, const float *__restrict__ pts,
-                                                            const float *__restrict__ cond, const float *__restrict__ grad_w,
-                                                            const int *__restrict__ ucount, const int *__restrict__ ulist, int T,
-                                                            int Q, float *grad_tet, float *grad_pts,
-                                                            const float *__restrict__ gocc, float *grad_pred)
+// After k_bary_bwd_hits, one launch for the two leftovers:
+//  * grad_pred[b,0] += sum of the miss partials (one wave, fixed order -> deterministic);
+//  * the (normally empty) list of hits that are in no tet record: float atomics.
+__global__ __launch_bounds__(256) void k_bary_bwd_tail(const float *__restrict__ tet, const float *__restrict__ pts,
+                                                       const float *__restrict__ cond, const float *__restrict__ grad_w,
+                                                       const int *__restrict__ ucount, const int *__restrict__ ulist, int T,
+                                                       int Q, float *grad_tet, float *grad_pts,
+                                                       const float *__restrict__ gocc, float *grad_pred,
+                                                       const float *__restrict__ missPart, int nMissParts)
 {
     const int b = blockIdx.y;
+    if (grad_pred && blockIdx.x == 0 && threadIdx.x < 64) {
+        float v = (int)threadIdx.x < nMissParts ? missPart[b * kMissParts + threadIdx.x] : 0.f;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if (threadIdx.x == 0) unsafeAtomicAdd(&grad_pred[(size_t)b * T], v);   // atomic only because of the list below
+    }
     const int n = ucount[b];
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
         const int q = ulist[(size_t)b * Q + k];
@@ -1363,7 +1351,6 @@ extern "C" int deftet_point_in_tet_f32(const float *tet, const float *pts, float
     Layout L = make_layout(B, T, Q, algo, workspace, workspace_bytes);
     DEFTET_CHECK_ARG(L.bytes <= workspace_bytes, "workspace too small: need %zu bytes, got %zu", L.bytes, workspace_bytes);
     hipStream_t st = as_stream(stream_);
-    if (hit_buf) DEFTET_HIP(hipMemsetAsync(hit_buf + hit_cnt_off(B, T), 0, (hit_list_off(B, T) - hit_cnt_off(B, T)) * 4, st));
     const dim3 blk(256);
     const dim3 gq((Q + 255) / 256, B), gt((((T + 255) / 256 + 7) / 8) * 8, B);   // gt: multiple of 8 for the XCD mapping
 
@@ -1375,7 +1362,8 @@ extern "C" int deftet_point_in_tet_f32(const float *tet, const float *pts, float
         DEFTET_LAUNCH(k_brute, gq, blk, st, L.rec, pts, T, Q, L.result);
     } else {
         const int R = L.G * L.G;
-        DEFTET_LAUNCH(k_query_bbox, dim3(kBoxBlocks, B), blk, st, pts, Q, L.bboxPart, L.counters, L.result, B, (long long)B * Q);
+        DEFTET_LAUNCH(k_query_bbox, dim3(kBoxBlocks, B), blk, st, pts, Q, L.bboxPart, L.counters, L.result, B, (long long)B * Q,
+                      hit_buf ? hit_buf + hit_cnt_off(B, T) : nullptr, (int)(hit_list_off(B, T) - hit_cnt_off(B, T)));
         DEFTET_LAUNCH(k_row_count, dim3(L.nRowBlk, B), blk, st, pts, Q, L.bboxPart, L.gparam, L.G, L.Gx, L.nRowBlk, L.chunkQ, L.qkey,
                       L.blockHist, L.counters, L.irregQ);
         DEFTET_LAUNCH(k_row_colscan, dim3((R + 255) / 256, B), blk, st, L.blockHist, L.nRowBlk, R, L.rowTotal);
@@ -1386,20 +1374,16 @@ extern "C" int deftet_point_in_tet_f32(const float *tet, const float *pts, float
         if (T > 0) {
             if (algo != DEFTET_PIT_STAGED) {
                 DEFTET_LAUNCH(k_tet_scan, gt, blk, st, tet, T, Q, L.gparam, L.G, L.Gx, L.cells, L.cellStride, L.sortedQ, L.result,
-                              L.counters, L.irregT, (int4 *)hit_buf);
+                              L.counters, L.irregT, (int4 *)hit_buf, pts, L.irregQ);
             } else {
                 DEFTET_LAUNCH(k_tet_scan_staged, gt, blk, st, tet, T, Q, L.gparam, L.G, L.Gx, L.cells, L.cellStride, L.sortedQ,
-                              L.result, L.counters, L.irregT, (int4 *)hit_buf);
+                              L.result, L.counters, L.irregT, (int4 *)hit_buf, pts, L.irregQ);
             }
-            int qb = (Q + 255) / 256, tb = (T + 255) / 256;
-            if (qb > 1024) qb = 1024;
-            if (tb > 1024) tb = 1024;
-            DEFTET_LAUNCH(k_irreg, dim3(qb > tb ? qb : tb, B, 2), blk, st, tet, pts, T, Q, L.counters, L.irregT, L.irregQ, L.result);
         }
     }
     DEFTET_LAUNCH(k_finalize, gq, blk, st, tet, pts, T, Q, L.result, cond, bary, pred, occ, (const int4 *)hit_buf,
                   hit_buf ? hit_buf + hit_cnt_off(B, T) : nullptr, hit_buf ? hit_buf + hit_list_off(B, T) : nullptr,
-                  algo != DEFTET_PIT_BRUTE ? L.counters : nullptr);
+                  algo != DEFTET_PIT_BRUTE ? L.counters : nullptr, L.irregT);
     return DEFTET_OK;
 }
 
@@ -1437,12 +1421,13 @@ extern "C" int deftet_point_in_tet_bwd_f32(const float *tet, const float *pts, c
         if (grad_pred) {
             DEFTET_CHECK_ARG(workspace && workspace_bytes >= (size_t)B * kMissParts * 4, "workspace needed for the miss sums");
             missPart = static_cast<float *>(workspace);
-            DEFTET_LAUNCH(k_miss_sum, dim3(kMissParts, B), dim3(256), st, cond, grad_occ, Q, missPart);
         }
-        DEFTET_LAUNCH(k_bary_bwd_hits, dim3((T + 255) / 256, B), dim3(256), st, tet, pts, cond, grad_w, (const int4 *)hit_buf, T,
-                      Q, grad_tet, grad_pts, accumulate, grad_occ, missPart, grad_pred);
-        DEFTET_LAUNCH(k_bary_bwd_uncovered, dim3(64, B), dim3(256), st, tet, pts, cond, grad_w, hit_buf + hit_cnt_off(B, T),
-                      hit_buf + hit_list_off(B, T), T, Q, grad_tet, grad_pts, grad_occ, grad_pred);
+        const int tblocks = (T + 255) / 256, nMissParts = tblocks < kMissParts ? tblocks : kMissParts;
+        DEFTET_LAUNCH(k_bary_bwd_hits, dim3(tblocks, B), dim3(256), st, tet, pts, cond, grad_w, (const int4 *)hit_buf, T, Q,
+                      grad_tet, grad_pts, accumulate, grad_occ, grad_pred, missPart, nMissParts);
+        static_assert(kMissParts == 64, "k_bary_bwd_tail sums the partials with one wave");
+        DEFTET_LAUNCH(k_bary_bwd_tail, dim3(64, B), dim3(256), st, tet, pts, cond, grad_w, hit_buf + hit_cnt_off(B, T),
+                      hit_buf + hit_list_off(B, T), T, Q, grad_tet, grad_pts, grad_occ, grad_pred, missPart, nMissParts);
     } else if (workspace) {
         const size_t need = deftet_point_in_tet_bwd_workspace_bytes(B, T, Q);
         DEFTET_CHECK_ARG(workspace_bytes >= need && ((uintptr_t)workspace & 255) == 0,

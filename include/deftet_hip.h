@@ -79,7 +79,8 @@ int deftet_point_in_tet_f32(const float *tet, const float *pts, float *cond, flo
  * kernels add into wrapper-zeroed buffers (tet_analytic_distance_batch/utils.py:65).
  * grad_occ f32 [B,Q] + grad_pred f32 [B,T] (both or neither): fused backward of the paste_occ
  * gather, grad_pred[b,t] = sum of grad_occ over the queries that pasted from t (misses -> tet 0).
- * hit_buf (from the forward, same tet/pts/cond) selects the fastest path; else workspace
+ * hit_buf (from the forward, same tet/pts/cond) selects the fastest path (with grad_pred it
+ * also needs 64*n_batch floats of workspace); else workspace
  * (deftet_point_in_tet_bwd_workspace_bytes) enables the linked-list gather path; with neither a
  * float-atomic scatter is used. */
 size_t deftet_point_in_tet_bwd_workspace_bytes(int n_batch, int n_tet, int n_query);
