@@ -153,10 +153,14 @@ def main():
     if rank == 0:
         pairs = float(world) * B * T * Q * args.steps
         kern_ms = tot_ms.value / max(cnt.value, 1)
-        # k_tet_scan reads every 48-byte tet record and every 16-byte sorted query once and writes one
-        # 16-byte hit record per tet
-        algo_bytes = B * (48.0 * T + 16.0 * Q + 16.0 * T)
+        # SURVEY.md 8(d), A1 fwd: B*(48*T + 12*Q + 4*Q) algorithmic bytes per call — exactly what k_tet_scan must
+        # touch once (48-byte tet records, 16-byte sorted queries).  Its 16-byte-per-tet hit records and the
+        # result atomics are overhead of THIS design and are not counted.
+        algo_bytes = B * (48.0 * T + 16.0 * Q)
         achieved = algo_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+        # whole step: fwd with weights B*(48T+16Q+16Q), bwd B*(32Q + 48*hits + 48T), hits ~ 0.864*Q
+        step_bytes = B * (48.0 * T + 32.0 * Q) + B * (32.0 * Q + 48.0 * 0.864 * Q + 48.0 * T)
+        step_gbs = step_bytes / (elapsed / args.steps) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
@@ -179,7 +183,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dominant.decode(), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": round(kern_ms, 5),
-                         "launches_timed": int(cnt.value)},
+                         "launches_timed": int(cnt.value),
+                         "whole_step": {"algorithmic_bytes": step_bytes, "achieved": round(step_gbs, 1),
+                                        "frac": round(step_gbs / HBM_PEAK_GBS, 4)}},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(host)

@@ -1,0 +1,54 @@
+"""Turns two rocprofv3 counter passes into profiles/pmc_traffic.json.
+
+    cd /tmp && export TMPDIR=/tmp
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $R/gpurun_out/pmc_fetch -o f --output-format csv -- \
+        python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $R/gpurun_out/pmc_write -o w --output-format csv -- \
+        python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline
+    python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write > profiles/pmc_traffic.json
+
+Corrections per /opt/skills/guides/MI355X_MICROARCH.md (HBM / rocprofv3 section): both counters are in
+KiB; on gfx950 FETCH_SIZE reports half of a coalesced stream (calibrated on this box: k_query_bbox
+reads 9.6 MB of points and reports 4.8 MB), WRITE_SIZE is exact.  Values are averages per launch.
+"""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+
+def per_kernel(d, counter):
+    files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+    if not files:
+        raise SystemExit("no *counter_collection.csv under %s" % d)
+    tot, cnt = defaultdict(float), defaultdict(int)
+    for row in csv.DictReader(open(files[0])):
+        if row["Counter_Name"] != counter:
+            continue
+        name = re.sub(r"\(.*", "", row["Kernel_Name"]).replace("void ", "")
+        tot[name] += float(row["Counter_Value"]) * 1024.0
+        cnt[name] += 1
+    return {k: tot[k] / cnt[k] for k in tot}
+
+
+def main(fetch_dir, write_dir):
+    f, w = per_kernel(fetch_dir, "FETCH_SIZE"), per_kernel(write_dir, "WRITE_SIZE")
+    out = {"note": __doc__.split("Corrections", 1)[1].strip().replace("\n", " "), "per_kernel": {}}
+    for k in sorted(set(f) | set(w)):
+        if not k.startswith("deftet::"):
+            continue
+        out["per_kernel"][k] = {"FETCH_SIZE_bytes_raw": round(f.get(k, 0.0)), "fetch_bytes_corrected_x2": round(2 * f.get(k, 0.0)),
+                                "WRITE_SIZE_bytes": round(w.get(k, 0.0))}
+    ts = out["per_kernel"].get("deftet::pit::k_tet_scan")
+    if ts:
+        out["k_tet_scan_hbm_bytes_per_launch"] = ts["fetch_bytes_corrected_x2"] + ts["WRITE_SIZE_bytes"]
+    step = sum(v["fetch_bytes_corrected_x2"] + v["WRITE_SIZE_bytes"] for v in out["per_kernel"].values())
+    out["whole_step_hbm_bytes"] = step
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:3])
