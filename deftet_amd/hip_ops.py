@@ -300,6 +300,75 @@ def nn_index(queries_bxnx3, points_bxmx3, brute=False):
     return out
 
 
+# --------------------------------------------------------------------------------- N2 vertex <-> tet gather
+def _idx64(tet_idx):
+    if tet_idx.dtype != torch.int64:
+        tet_idx = tet_idx.long()
+    if tet_idx.dim() == 2:
+        tet_idx = tet_idx[None]
+    return tet_idx.contiguous()
+
+
+def tet_gather(pos_bxvx3, tet_idx, check=False):
+    """tet_bxfx4x3 f32 [B,T,4,3] = gather of vertex positions (layers/DefTet/deftet.py:65-68).
+    tet_idx int [T,4] (shared) or [B,T,4].  check=True synchronises and raises on an index
+    outside [0,V) like torch.gather does (otherwise such corners are NaN)."""
+    _lib.require_gpu(pos_bxvx3, tet_idx)
+    lib = _lib.load()
+    pos, idx = _f32c(pos_bxvx3), _idx64(tet_idx)
+    B, V, T = pos.shape[0], pos.shape[1], idx.shape[1]
+    if idx.shape[0] not in (1, B) or idx.shape[2] != 4 or pos.shape[2] != 3:
+        raise RuntimeError("tet_gather: pos [B,V,3] and tet_idx [T,4] or [B,T,4] expected")
+    out = torch.empty(B, T, 4, 3, device=pos.device, dtype=torch.float32)
+    bad = torch.zeros(1, device=pos.device, dtype=torch.int32) if check else None
+    with torch.cuda.device(pos.device):
+        _lib.check(lib.deftet_tet_gather_fwd_f32(_lib.ptr(pos), _lib.ptr(idx), _lib.ptr(out), _lib.ptr(bad), B, V, T, idx.shape[0],
+                                                 _lib.current_stream(pos.device)), "deftet_tet_gather_fwd_f32")
+    if check and int(bad.item()):
+        raise RuntimeError("tet_gather: index out of range [0, %d)" % V)
+    return out
+
+
+def tet_vertex_csr(tet_idx, n_vertex):
+    """(offsets int32 [Bi*V+1], slots int32 [Bi*4T], Bi): incidences (4*t+corner, ascending) per
+    vertex — built once per topology for tet_gather_bwd.  Raises on an out-of-range index."""
+    _lib.require_gpu(tet_idx)
+    lib = _lib.load()
+    idx = _idx64(tet_idx)
+    Bi, T, V = idx.shape[0], idx.shape[1], int(n_vertex)
+    dev = idx.device
+    offsets = torch.empty(Bi * V + 1, device=dev, dtype=torch.int32)
+    slots = torch.empty(Bi * T * 4, device=dev, dtype=torch.int32)
+    bad = torch.zeros(1, device=dev, dtype=torch.int32)
+    with torch.cuda.device(dev):
+        ws = _lib.workspace(dev, lib.deftet_tet_vertex_csr_workspace_bytes(Bi, V, T))
+        _lib.check(lib.deftet_tet_vertex_csr_i32(_lib.ptr(idx), _lib.ptr(offsets), _lib.ptr(slots), _lib.ptr(bad), Bi, V, T,
+                                                 _lib.ptr(ws), ws.numel(), _lib.current_stream(dev)), "deftet_tet_vertex_csr_i32")
+    if int(bad.item()):
+        raise RuntimeError("tet_vertex_csr: index out of range [0, %d)" % V)
+    return offsets, slots, Bi
+
+
+def tet_gather_bwd(grad_tet_bxtx4x3, csr, n_vertex, out=None):
+    """grad_pos f32 [B,V,3] = per-vertex sum of grad_tet in ascending (tet, corner) order
+    (deterministic, no atomics).  out: existing [B,V,3] tensor to ADD to."""
+    _lib.require_gpu(grad_tet_bxtx4x3)
+    lib = _lib.load()
+    g = _f32c(grad_tet_bxtx4x3)
+    offsets, slots, Bi = csr
+    B, T, V = g.shape[0], g.shape[1], int(n_vertex)
+    if slots.numel() != Bi * T * 4 or offsets.numel() != Bi * V + 1:
+        raise RuntimeError("tet_gather_bwd: CSR does not match grad_tet / n_vertex")
+    acc = out is not None
+    if acc and (out.shape != (B, V, 3) or out.dtype != torch.float32 or not out.is_contiguous()):
+        raise RuntimeError("tet_gather_bwd: out must be contiguous f32 [B,V,3]")
+    gp = out if acc else torch.empty(B, V, 3, device=g.device, dtype=torch.float32)
+    with torch.cuda.device(g.device):
+        _lib.check(lib.deftet_tet_gather_bwd_f32(_lib.ptr(g), _lib.ptr(offsets), _lib.ptr(slots), _lib.ptr(gp), B, V, T, Bi,
+                                                 1 if acc else 0, _lib.current_stream(g.device)), "deftet_tet_gather_bwd_f32")
+    return gp
+
+
 # --------------------------------------------------------------------------------- A7 / A11
 def boundary_index(tet_face_fx3, tet_idx_fx2, occ_bxn, mode=1):
     """list of B int64 [Fb_i,3] tensors — DefTet.get_boundary_index (mode 1) /

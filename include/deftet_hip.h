@@ -161,6 +161,30 @@ int deftet_boundary_index_i64(const int64_t *face_fx3, const int64_t *tetidx_fx2
                               int64_t *out_rows, int32_t *offsets, int n_batch, int n_tet, int n_face, int mode,
                               void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---------------------------------------------------------------------------------
+ * N2  the vertex <-> tet gather either side of the per-tet operators:
+ *   tet_bxfx4x3 = torch.gather(vertice_pos, tetrahedron_bxfx4)          layers/DefTet/deftet.py:65-68
+ * pos f32 [B,V,3]; tet_idx int64 [idx_batch,T,4] with idx_batch == 1 (one topology shared by all
+ * shapes) or == n_batch (the reference's tetrahedron_bxfx4); out f32 [B,T,4,3].
+ * An index outside [0,V) (torch.gather raises) yields NaNs and sets *bad_flag (device int32,
+ * may be NULL) to 1.
+ * Backward: torch's is a scatter-add of 12*T float atomics per shape; here the topology is turned
+ * once into a CSR of (tet,corner) incidences per vertex (deftet_tet_vertex_csr_i32: offsets int32
+ * [idx_batch*V+1], slots int32 [idx_batch*4*T] holding 4*t+corner in ascending order per vertex;
+ * *bad_flag (device int32, required) = 1 when an index is out of range) and
+ * deftet_tet_gather_bwd_f32 sums grad_tet f32 [B,T,4,3] per vertex in that order into grad_pos
+ * f32 [B,V,3] (overwritten, or added to when accumulate != 0): no atomics, deterministic.
+ * --------------------------------------------------------------------------------- */
+int deftet_tet_gather_fwd_f32(const float *pos, const int64_t *tet_idx, float *out, int32_t *bad_flag,
+                              int n_batch, int n_vertex, int n_tet, int idx_batch, void *stream);
+size_t deftet_tet_vertex_csr_workspace_bytes(int idx_batch, int n_vertex, int n_tet);
+int deftet_tet_vertex_csr_i32(const int64_t *tet_idx, int32_t *offsets, int32_t *slots, int32_t *bad_flag,
+                              int idx_batch, int n_vertex, int n_tet,
+                              void *workspace, size_t workspace_bytes, void *stream);
+int deftet_tet_gather_bwd_f32(const float *grad_tet, const int32_t *offsets, const int32_t *slots,
+                              float *grad_pos, int n_batch, int n_vertex, int n_tet, int idx_batch,
+                              int accumulate, void *stream);
+
 /* A11 fused per-tet energies, layers/DefTet/deftet.py:239-338: out f32 [B,3] =
  * {volume_variance(pow_v), amips_energy(inv_v f32 [T,3,3]; 0 when NULL), edge_length(pow_e)};
  * stats f64 [B,8] is produced by the forward and consumed by the backward, which writes

@@ -302,3 +302,39 @@ class RefBuilders:
         n = np.zeros(1, np.int32)
         self.colaps.run(_p(pts, _f32p), _p(m, _i32p), _p(inv, _i32p), _p(n, _i32p), C.c_int(N))
         return m, inv[: n[0]]
+
+
+# ----------------------------------------------------------------------------- N2 vertex <-> tet gather
+def tet_gather(pos_bxvx3, tet_idx):
+    """numpy restatement of torch.gather(vertice_pos, tetrahedron_bxfx4)
+    (/root/reference/layers/DefTet/deftet.py:65-68): [B,T,4,3]."""
+    pos = np.asarray(pos_bxvx3, dtype=np.float32)
+    idx = np.asarray(tet_idx, dtype=np.int64)
+    if idx.ndim == 2:
+        idx = np.broadcast_to(idx[None], (pos.shape[0],) + idx.shape)
+    return np.stack([pos[b][idx[b]] for b in range(pos.shape[0])]).astype(np.float32)
+
+
+def tet_gather_bwd(grad_tet_bxtx4x3, tet_idx, n_vertex):
+    """Backward of the gather in the FIXED fp32 summation order of the HIP kernel
+    (deftet_amd/csrc/vertex_ops.hip k_gather_bwd), so the comparison is bit-exact: the incidences
+    4*t+corner of a vertex are taken in ascending order; position j of that list goes to partial
+    sum j % 4 (each accumulated sequentially from 0, np.add.at applies updates in index order),
+    and the result is (s0 + s1) + (s2 + s3).  torch's scatter-add computes the same sum in an
+    unspecified order; equality with it is checked to fp32 round-off in the tests."""
+    g = np.asarray(grad_tet_bxtx4x3, dtype=np.float32)
+    idx = np.asarray(tet_idx, dtype=np.int64)
+    B = g.shape[0]
+    if idx.ndim == 2:
+        idx = np.broadcast_to(idx[None], (B,) + idx.shape)
+    out = np.zeros((B, n_vertex, 3), dtype=np.float32)
+    for b in range(B):
+        flat = idx[b].reshape(-1)
+        order = np.argsort(flat, kind="stable")                       # ascending slot inside each vertex
+        sv = flat[order]
+        start = np.searchsorted(sv, sv, side="left")                  # first list position of the vertex
+        lane = (np.arange(sv.size) - start) % 4
+        part = np.zeros((n_vertex, 4, 3), dtype=np.float32)
+        np.add.at(part, (sv, lane), g[b].reshape(-1, 3)[order])
+        out[b] = (part[:, 0] + part[:, 1]) + (part[:, 2] + part[:, 3])
+    return out

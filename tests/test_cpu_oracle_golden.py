@@ -186,3 +186,23 @@ def test_deftet_module_fixture_is_selfconsistent():
     c[c < 0] = 0
     assert np.array_equal(g["cond_after"], c)
     assert np.array_equal(g["pasted"], np.take_along_axis(g["pred"], c[..., 0].astype(int), 1))
+
+
+def test_tet_gather_oracle_matches_torch_autograd():
+    """N2: the numpy restatement of the vertex->tet gather and of its backward equals
+    torch.gather / torch autograd (the expression at layers/DefTet/deftet.py:65-68)."""
+    import torch
+    from oracle import oracle
+    rng = np.random.default_rng(3)
+    B, V, T = 3, 40, 300
+    pos = rng.standard_normal((B, V, 3)).astype(np.float32)
+    idx = rng.integers(0, V, (B, T, 4))
+    g = rng.standard_normal((B, T, 4, 3)).astype(np.float32)
+    p = torch.tensor(pos, dtype=torch.float64, requires_grad=True)
+    out = torch.gather(p.unsqueeze(2).expand(-1, -1, 4, -1), 1, torch.tensor(idx).unsqueeze(-1).expand(-1, -1, -1, 3))
+    assert np.array_equal(out.detach().numpy().astype(np.float32), oracle.tet_gather(pos, idx))
+    out.backward(torch.tensor(g, dtype=torch.float64))
+    got = oracle.tet_gather_bwd(g, idx, V)
+    assert np.abs(p.grad.numpy() - got).max() <= 1e-5 * np.abs(p.grad.numpy()).max()
+    # shared topology broadcast
+    assert np.array_equal(oracle.tet_gather(pos, idx[0]), oracle.tet_gather(pos, np.broadcast_to(idx[0], idx.shape)))

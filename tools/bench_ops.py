@@ -126,6 +126,29 @@ def main():
          nominal_pixel_face_tests_per_s=round(Pn * Fn / tg / 1e9, 1), unit="G pixel-face tests/s (fwd)",
          hits=int((face_i >= 0).sum().item()), parity="unpinned (Kaolin not in the reference tree)")
 
+    # ---- N2: vertex <-> tet gather (deftet.py:65-68) against torch's own gather / scatter-add on the same GPU
+    Bv = 2 if quick else 8
+    posv = torch.from_numpy(grids.jittered_positions(verts, res, Bv, 0.1).astype(np.float32)).to(dev)
+    idx1 = tets_d.long()
+    idxB = idx1[None].expand(Bv, -1, -1).contiguous()
+    gt = torch.randn(Bv, T, 4, 3, device=dev)
+    csr = hip_ops.tet_vertex_csr(idx1, n_point)
+    t_csr = gpu_time(lambda: hip_ops.tet_vertex_csr(idx1, n_point))
+    t_f = gpu_time(lambda: hip_ops.tet_gather(posv, idx1), reps=10)
+    t_b = gpu_time(lambda: hip_ops.tet_gather_bwd(gt, csr, n_point), reps=10)
+
+    def torch_fwd():
+        return torch.gather(posv.unsqueeze(2).expand(-1, -1, 4, -1), 1, idxB.unsqueeze(-1).expand(-1, -1, -1, 3))
+
+    def torch_bwd():
+        out = torch.zeros(Bv, n_point, 3, device=dev)
+        return out.scatter_add_(1, idxB.reshape(Bv, -1, 1).expand(-1, -1, 3), gt.reshape(Bv, -1, 3))
+
+    tt_f, tt_b = gpu_time(torch_fwd, reps=10), gpu_time(torch_bwd, reps=10)
+    emit(op="tet_gather", res=res, batch=Bv, n_tet=T, n_vertex=n_point, fwd_ms=round(t_f * 1e3, 4), bwd_ms=round(t_b * 1e3, 4),
+         csr_build_ms=round(t_csr * 1e3, 3), torch_gather_ms=round(tt_f * 1e3, 4), torch_scatter_add_ms=round(tt_b * 1e3, 4),
+         bwd_speedup_vs_torch=round(tt_b / t_b, 1), note="torch ops run on the same MI355X; bwd bytes = %.1f MB read" % (Bv * T * 48 / 1e6))
+
 
 if __name__ == "__main__":
     main()
