@@ -29,6 +29,11 @@ SIGNATURES = {
     "deftet_point_in_tet_bwd_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "deftet_paste_occ_fwd_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "deftet_paste_occ_bwd_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "deftet_tet_edges_i64": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _sz, _vp]),
+    "deftet_subdivide_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "deftet_point_adj_table_i64": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
+    "deftet_delete_tet_i64": (_i, [_vp, _vp, _f, _vp, _vp, _i, _i, _vp, _sz, _vp]),
+    "deftet_tet_neighbour_weights_f32": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "deftet_tet_gather_fwd_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "deftet_tet_vertex_csr_workspace_bytes": (_sz, [_i, _i, _i]),
     "deftet_tet_vertex_csr_i32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),

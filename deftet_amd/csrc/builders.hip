@@ -327,6 +327,166 @@ __global__ __launch_bounds__(256) void k_colaps_emit(const int *__restrict__ fir
 }
 
 // ---------------------------------------------------------------------------- host helpers
+// ---------------------------------------------------------------------------- N3
+// Render-side geometry rebuilds, diff_render/diftet_6_subdiv/3_model/prepare_for_wz.py:
+// generate_edge (:184-203), generate_tet_edge_idx (:223-236, the O(E*T) matchedgelist :206-221
+// becomes one sort), generate_subdivision (:255-301), generate_point_adj_idx (:108-146, the
+// dense P x P matrix becomes the sorted pair list of A4), delete_tet (:171-180),
+// tetweights2tetneighbourweights (3_model/deftet.py:316-331).
+__constant__ int kEdgeEnds[6][2] = {{0, 1}, {0, 2}, {0, 3}, {1, 2}, {1, 3}, {2, 3}};   // edges_all_connect_6x2, :190
+
+// incidence m = t*6 + e: key = min*n + max (np.unique(axis=0) sorts rows lexicographically = by this key)
+__global__ __launch_bounds__(256) void k_uedge_keys(const long long *__restrict__ tet, int T, u64 n, u64 *key, u32 *inc, int *bad)
+{
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= T * 6) return;
+    const int t = m / 6, e = m % 6;
+    const long long a = tet[(size_t)t * 4 + kEdgeEnds[e][0]], b = tet[(size_t)t * 4 + kEdgeEnds[e][1]];
+    if (a < 0 || b < 0 || a >= (long long)n || b >= (long long)n) *bad = 1;      // caller raises; keys stay defined
+    const u64 lo = (u64)(a < b ? a : b), hi = (u64)(a < b ? b : a);
+    key[m] = lo * n + hi;
+    inc[m] = (u32)m;
+}
+
+__global__ __launch_bounds__(256) void k_uedge_emit(const u64 *__restrict__ key, const u32 *__restrict__ inc,
+                                                    const int *__restrict__ flag, const int *__restrict__ pos, int n, u64 np,
+                                                    long long *edges, long long *tet_edge, int *n_out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int u = pos[i] + flag[i] - 1;                          // index of this incidence's edge in the unique list
+    if (flag[i]) {
+        edges[(size_t)u * 2] = (long long)(key[i] / np);
+        edges[(size_t)u * 2 + 1] = (long long)(key[i] % np);
+    }
+    tet_edge[inc[i]] = u;                                        // [T,6] row-major: inc = t*6 + e
+    if (i == n - 1) *n_out = u + 1;
+}
+
+// new vertices: first the old ones, then one midpoint per edge, (a + b) / 2 in fp32 (:238-252)
+__global__ __launch_bounds__(256) void k_subdiv_points(const float *__restrict__ src, const long long *__restrict__ edges, int P, int E,
+                                                       int K, float *dst)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)(P + E) * K) return;
+    const int r = (int)(i / K), c = (int)(i % K);
+    if (r < P) {
+        dst[i] = src[i];
+    } else {
+        const long long a = edges[(size_t)(r - P) * 2], b = edges[(size_t)(r - P) * 2 + 1];
+        dst[i] = (src[(size_t)a * K + c] + src[(size_t)b * K + c]) / 2.0f;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_subdiv_flags(const unsigned char *__restrict__ sig, int T, int *keepOld, int *split)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    const int s = sig ? (sig[t] != 0) : 1;
+    keepOld[t] = 1 - s;
+    split[t] = s;
+}
+
+// the eight children of a tet (:270-281) in the reference's order; unsplit tets are copied first
+__global__ __launch_bounds__(256) void k_subdiv_tets(const long long *__restrict__ tet, const long long *__restrict__ tet_edge,
+                                                     const unsigned char *__restrict__ sig, const int *__restrict__ posOld,
+                                                     const int *__restrict__ posSplit, int T, int P, long long *out, int *n_out)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    const int s = sig ? (sig[t] != 0) : 1;
+    const int nOld = sig ? posOld[T - 1] + (sig[T - 1] ? 0 : 1) : 0;
+    if (t == T - 1) *n_out = nOld + 8 * (posSplit[T - 1] + s);
+    const long long a = tet[(size_t)t * 4], b = tet[(size_t)t * 4 + 1], c = tet[(size_t)t * 4 + 2], d = tet[(size_t)t * 4 + 3];
+    if (!s) {
+        long long *o = out + (size_t)posOld[t] * 4;
+        o[0] = a; o[1] = b; o[2] = c; o[3] = d;
+        return;
+    }
+    const long long *te = tet_edge + (size_t)t * 6;
+    const long long ab = te[0] + P, ac = te[1] + P, ad = te[2] + P, bc = te[3] + P, bd = te[4] + P, cd = te[5] + P;
+    const long long ch[8][4] = {{a, ab, ac, ad}, {b, bc, ab, bd}, {c, ac, bc, cd}, {d, ad, cd, bd},
+                                {ab, ac, ad, bd}, {ab, ac, bd, bc}, {cd, ac, bd, ad}, {cd, ac, bc, bd}};
+    long long *o = out + ((size_t)nOld + (size_t)posSplit[t] * 8) * 4;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        o[k * 4] = ch[k][0]; o[k * 4 + 1] = ch[k][1]; o[k * 4 + 2] = ch[k][2]; o[k * 4 + 3] = ch[k][3];
+    }
+}
+
+// point adjacency table from the sorted unique ordered pairs (i, j) of A4: row starts by key boundaries
+__global__ __launch_bounds__(256) void k_adj_rowstart(const int *__restrict__ pairs, int n, int P, int *rowStart)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    const int prev = i == 0 ? -1 : pairs[(size_t)(i - 1) * 2];
+    const int cur = i == n ? P : pairs[(size_t)i * 2];
+    for (int k = prev + 1; k <= cur; ++k) rowStart[k] = i;
+}
+
+__global__ __launch_bounds__(256) void k_adj_degree(const int *__restrict__ rowStart, int P, float *adjsum, int *maxDeg)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    int d = 0;
+    if (p < P) {
+        d = rowStart[p + 1] - rowStart[p];
+        adjsum[p] = (float)d;                                     // np.sum of a float32 0/1 row, :139
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) d = max(d, __shfl_xor(d, off));
+    if ((threadIdx.x & 63) == 0 && d > 0) atomicMax(maxDeg, d);
+}
+
+__global__ __launch_bounds__(256) void k_adj_fill(const int *__restrict__ pairs, const int *__restrict__ rowStart, int P, int M,
+                                                  long long *table)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)P * M) return;
+    const int p = (int)(i / M), c = (int)(i % M);
+    const int s = rowStart[p], d = rowStart[p + 1] - s;
+    table[i] = c < d ? (long long)pairs[(size_t)(s + c) * 2 + 1] : -1;   // ascending neighbours, then -1 (:141-145)
+}
+
+// delete_tet: keep = (max over the row, NaN-propagating like np.max) > thres
+__global__ __launch_bounds__(256) void k_delete_flags(const float *__restrict__ w, int T, int K, float thres, int *keep)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    float m = -INFINITY;
+    bool nan = false;
+    for (int k = 0; k < K; ++k) {
+        const float x = w[(size_t)t * K + k];
+        nan = nan || (x != x);
+        m = fmaxf(m, x);
+    }
+    keep[t] = (!nan && K > 0 && m > thres) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void k_compact_tets(const long long *__restrict__ tet, const int *__restrict__ keep,
+                                                      const int *__restrict__ pos, int T, long long *out, int *n_out)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    if (keep[t]) {
+        long long *o = out + (size_t)pos[t] * 4;
+        const long long *s = tet + (size_t)t * 4;
+        o[0] = s[0]; o[1] = s[1]; o[2] = s[2]; o[3] = s[3];
+    }
+    if (t == T - 1) *n_out = pos[t] + keep[t];
+}
+
+// one level of tetweights2tetneighbourweights: out[t, j*K + c] = w[nei[t,j], c], zero row for nei = -1
+__global__ __launch_bounds__(256) void k_neighbour_weights(const float *__restrict__ w, const long long *__restrict__ nei, int T, int K,
+                                                           float *out)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)T * 4 * K) return;
+    const int c = (int)(i % K);
+    const long long tj = i / K;
+    const long long n = nei[tj];
+    out[i] = (n >= 0 && n < T) ? w[(size_t)n * K + c] : 0.f;
+}
+
 static int key_bits(u64 max_key)
 {
     int b = 1;
@@ -551,6 +711,124 @@ extern "C" int deftet_colaps_v_f32(const float *pts, int32_t *map_array, int32_t
     DEFTET_LAUNCH(k_colaps_first, grid_for(n), dim3(256), st, hps, i1, N, first, isf);
     TRY(ex_scan(W, isf, nid, n, st));
     DEFTET_LAUNCH(k_colaps_emit, grid_for(n), dim3(256), st, first, isf, nid, N, map_array, inverse_idx, n_out);
+    return DEFTET_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// N3 entry points
+// ---------------------------------------------------------------------------------------------
+static int check_i64(const void *tet, int n_point, int n_tet, void *ws)
+{
+    DEFTET_CHECK_ARG(n_tet >= 0 && n_point >= 0, "negative size");
+    DEFTET_CHECK_ARG(n_point <= 2000000000 && n_tet <= 100000000, "size too large");
+    DEFTET_CHECK_ARG(n_tet == 0 || tet, "null tet list");
+    DEFTET_CHECK_ARG(n_tet == 0 || (ws && ((uintptr_t)ws & 255) == 0), "workspace null or not 256-byte aligned");
+    return DEFTET_OK;
+}
+
+extern "C" int deftet_tet_edges_i64(const int64_t *tet, int64_t *edges_ex2, int64_t *tet_edge_tx6, int32_t *n_edge, int32_t *bad_flag,
+                                    int n_point, int T, void *workspace, size_t wsb, void *stream_)
+{
+    TRY(check_i64(tet, n_point, T, workspace));
+    hipStream_t st = as_stream(stream_);
+    DEFTET_CHECK_ARG(n_edge && bad_flag, "null n_edge / bad_flag");
+    DEFTET_HIP(hipMemsetAsync(bad_flag, 0, 4, st));
+    if (T == 0) { DEFTET_HIP(hipMemsetAsync(n_edge, 0, 4, st)); return DEFTET_OK; }
+    DEFTET_CHECK_ARG(edges_ex2 && tet_edge_tx6, "null output");
+    const size_t n = (size_t)T * 6;
+    Ws W(workspace, wsb);
+    u64 *key = W.A.take<u64>(n), *skey = W.A.take<u64>(n);
+    u32 *inc = W.A.take<u32>(n), *sinc = W.A.take<u32>(n);
+    int *flag = W.A.take<int>(n), *pos = W.A.take<int>(n);
+    DEFTET_CHECK_ARG(W.A.ok(), "workspace too small");
+    const u64 np = (u64)(n_point > 0 ? n_point : 1);
+    DEFTET_LAUNCH(k_uedge_keys, grid_for(n), dim3(256), st, (const long long *)tet, T, np, key, inc, bad_flag);
+    TRY(sort_pairs(W, key, skey, inc, sinc, n, key_bits(np * np), st));
+    DEFTET_LAUNCH(k_unique_flag, grid_for(n), dim3(256), st, skey, (int)n, flag);
+    TRY(ex_scan(W, flag, pos, n, st));
+    DEFTET_LAUNCH(k_uedge_emit, grid_for(n), dim3(256), st, skey, sinc, flag, pos, (int)n, np, (long long *)edges_ex2,
+                  (long long *)tet_edge_tx6, n_edge);
+    return DEFTET_OK;
+}
+
+extern "C" int deftet_subdivide_f32(const int64_t *tet, const int64_t *tet_edge_tx6, const int64_t *edges_ex2, const float *points,
+                                    const float *feat, const uint8_t *subdiv_sig, float *points_new, float *feat_new,
+                                    int64_t *tet_new, int32_t *n_tet_new, int n_point, int T, int n_edge, int n_feat,
+                                    void *workspace, size_t wsb, void *stream_)
+{
+    TRY(check_i64(tet, n_point, T, workspace));
+    DEFTET_CHECK_ARG(n_edge >= 0 && n_feat >= 0, "negative size");
+    DEFTET_CHECK_ARG(n_tet_new, "null n_tet_new");
+    hipStream_t st = as_stream(stream_);
+    if (n_point + n_edge > 0) {
+        DEFTET_CHECK_ARG(points && points_new && (n_edge == 0 || edges_ex2), "null point arrays");
+        DEFTET_LAUNCH(k_subdiv_points, grid_for((size_t)(n_point + n_edge) * 3), dim3(256), st, points, (const long long *)edges_ex2,
+                      n_point, n_edge, 3, points_new);
+        if (n_feat > 0) {
+            DEFTET_CHECK_ARG(feat && feat_new, "null feature arrays");
+            DEFTET_LAUNCH(k_subdiv_points, grid_for((size_t)(n_point + n_edge) * n_feat), dim3(256), st, feat,
+                          (const long long *)edges_ex2, n_point, n_edge, n_feat, feat_new);
+        }
+    }
+    if (T == 0) { DEFTET_HIP(hipMemsetAsync(n_tet_new, 0, 4, st)); return DEFTET_OK; }
+    DEFTET_CHECK_ARG(tet_edge_tx6 && tet_new, "null tet arrays");
+    Ws W(workspace, wsb);
+    int *keepOld = W.A.take<int>(T), *split = W.A.take<int>(T), *posOld = W.A.take<int>(T), *posSplit = W.A.take<int>(T);
+    DEFTET_CHECK_ARG(W.A.ok(), "workspace too small");
+    DEFTET_LAUNCH(k_subdiv_flags, grid_for(T), dim3(256), st, subdiv_sig, T, keepOld, split);
+    TRY(ex_scan(W, keepOld, posOld, (size_t)T, st));
+    TRY(ex_scan(W, split, posSplit, (size_t)T, st));
+    DEFTET_LAUNCH(k_subdiv_tets, grid_for(T), dim3(256), st, (const long long *)tet, (const long long *)tet_edge_tx6, subdiv_sig,
+                  posOld, posSplit, T, n_point, (long long *)tet_new, n_tet_new);
+    return DEFTET_OK;
+}
+
+extern "C" int deftet_point_adj_table_i64(const int32_t *pairs_nx2, int n_pairs, int n_point, int64_t *table_pxm, int width,
+                                          float *adjsum_px1, int32_t *max_degree, void *workspace, size_t wsb, void *stream_)
+{
+    DEFTET_CHECK_ARG(n_pairs >= 0 && n_point >= 0 && width >= 0, "negative size");
+    DEFTET_CHECK_ARG(n_pairs == 0 || pairs_nx2, "null pairs");
+    DEFTET_CHECK_ARG(workspace && ((uintptr_t)workspace & 255) == 0 && wsb >= ((size_t)n_point + 1) * 4, "workspace null, misaligned or too small");
+    hipStream_t st = as_stream(stream_);
+    int *rowStart = static_cast<int *>(workspace);
+    DEFTET_LAUNCH(k_adj_rowstart, grid_for((size_t)n_pairs + 1), dim3(256), st, pairs_nx2, n_pairs, n_point, rowStart);
+    if (width == 0) {                                             // phase A: degrees and the table width
+        DEFTET_CHECK_ARG(max_degree && (n_point == 0 || adjsum_px1), "null adjsum / max_degree");
+        DEFTET_HIP(hipMemsetAsync(max_degree, 0, 4, st));
+        if (n_point > 0) DEFTET_LAUNCH(k_adj_degree, grid_for(n_point), dim3(256), st, rowStart, n_point, adjsum_px1, max_degree);
+    } else if (n_point > 0) {                                     // phase B: the padded table
+        DEFTET_CHECK_ARG(table_pxm, "null table");
+        DEFTET_LAUNCH(k_adj_fill, grid_for((size_t)n_point * width), dim3(256), st, pairs_nx2, rowStart, n_point, width,
+                      (long long *)table_pxm);
+    }
+    return DEFTET_OK;
+}
+
+extern "C" int deftet_delete_tet_i64(const int64_t *tet, const float *weights_txk, float thres, int64_t *tet_kept, int32_t *n_kept,
+                                     int T, int K, void *workspace, size_t wsb, void *stream_)
+{
+    DEFTET_CHECK_ARG(T >= 0 && K >= 0 && n_kept, "bad argument");
+    hipStream_t st = as_stream(stream_);
+    if (T == 0) { DEFTET_HIP(hipMemsetAsync(n_kept, 0, 4, st)); return DEFTET_OK; }
+    DEFTET_CHECK_ARG(tet && tet_kept && (K == 0 || weights_txk), "null pointer");
+    DEFTET_CHECK_ARG(workspace && ((uintptr_t)workspace & 255) == 0, "workspace null or not 256-byte aligned");
+    Ws W(workspace, wsb);
+    int *keep = W.A.take<int>(T), *pos = W.A.take<int>(T);
+    DEFTET_CHECK_ARG(W.A.ok(), "workspace too small");
+    DEFTET_LAUNCH(k_delete_flags, grid_for(T), dim3(256), st, weights_txk, T, K, thres, keep);
+    TRY(ex_scan(W, keep, pos, (size_t)T, st));
+    DEFTET_LAUNCH(k_compact_tets, grid_for(T), dim3(256), st, (const long long *)tet, keep, pos, T, (long long *)tet_kept, n_kept);
+    return DEFTET_OK;
+}
+
+extern "C" int deftet_tet_neighbour_weights_f32(const float *weights_txk, const int64_t *nei_tx4, float *out_tx4k, int T, int K,
+                                                void *stream_)
+{
+    DEFTET_CHECK_ARG(T >= 0 && K >= 0, "negative size");
+    if (T == 0 || K == 0) return DEFTET_OK;
+    DEFTET_CHECK_ARG(weights_txk && nei_tx4 && out_tx4k, "null pointer");
+    DEFTET_LAUNCH(k_neighbour_weights, grid_for((size_t)T * 4 * K), dim3(256), as_stream(stream_), weights_txk,
+                  (const long long *)nei_tx4, T, K, out_tx4k);
     return DEFTET_OK;
 }
 

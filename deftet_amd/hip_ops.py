@@ -6,6 +6,7 @@ reference's names and signatures) lives in deftet_amd/layers/ and deftet_amd/uti
 """
 from __future__ import annotations
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -298,6 +299,120 @@ def nn_index(queries_bxnx3, points_bxmx3, brute=False):
                                            ws.numel() if ws is not None else 0, _lib.current_stream(q.device)),
                    "deftet_nn_index_f32")
     return out
+
+
+# --------------------------------------------------------------------------------- N3 render-side rebuilds
+def _i64_tets(tet_tx4):
+    t = tet_tx4 if tet_tx4.dtype == torch.int64 else tet_tx4.long()
+    if t.dim() != 2 or t.shape[1] != 4:
+        raise RuntimeError("tet list [T,4] expected, got %s" % (tuple(t.shape),))
+    return t.contiguous()
+
+
+def tet_edges(tet_tx4, n_point):
+    """(edges [E,2] int64 — unique (min,max) rows in lexicographic order, tet_edge [T,6] int64):
+    generate_edge + generate_tet_edge_idx of prepare_for_wz.py:184-236."""
+    _lib.require_gpu(tet_tx4)
+    lib = _lib.load()
+    tet = _i64_tets(tet_tx4)
+    T, dev = tet.shape[0], tet.device
+    edges = torch.empty(max(6 * T, 1), 2, device=dev, dtype=torch.int64)
+    tet_edge = torch.empty(T, 6, device=dev, dtype=torch.int64)
+    cnt = torch.zeros(2, device=dev, dtype=torch.int32)
+    with torch.cuda.device(dev):
+        ws = _builder_ws(lib, dev, n_point, T)
+        _lib.check(lib.deftet_tet_edges_i64(_lib.ptr(tet), _lib.ptr(edges), _lib.ptr(tet_edge), _lib.ptr(cnt), _lib.ptr(cnt[1:]),
+                                            int(n_point), T, _lib.ptr(ws), ws.numel(), _lib.current_stream(dev)), "deftet_tet_edges_i64")
+    n, bad = cnt.tolist()
+    if bad:
+        raise IndexError("tet_edges: vertex index outside [0, %d)" % n_point)
+    return edges[:n], tet_edge
+
+
+def subdivide(tet_tx4, points_px3, feat_pxk, subdiv_sig=None):
+    """(points_new [P+E,3], feat_new [P+E,K], tet_new [T',4]): generate_subdivision, prepare_for_wz.py:255-301."""
+    _lib.require_gpu(tet_tx4, points_px3, feat_pxk, subdiv_sig)
+    lib = _lib.load()
+    tet, pts, feat = _i64_tets(tet_tx4), _f32c(points_px3), _f32c(feat_pxk)
+    P, K, T, dev = pts.shape[0], feat.shape[1], tet.shape[0], tet.device
+    if feat.shape[0] != P or pts.shape[1] != 3:
+        raise RuntimeError("subdivide: points [P,3] and features [P,K] expected")
+    edges, tet_edge = tet_edges(tet, P)
+    E = edges.shape[0]
+    sig = None
+    if subdiv_sig is not None:
+        if subdiv_sig.numel() != T:
+            raise RuntimeError("subdivide: subdiv_sig needs one entry per tet")
+        sig = subdiv_sig.to(torch.bool).contiguous().view(torch.uint8)
+    pn = torch.empty(P + E, 3, device=dev, dtype=torch.float32)
+    fn = torch.empty(P + E, K, device=dev, dtype=torch.float32)
+    tn = torch.empty(max(8 * T, 1), 4, device=dev, dtype=torch.int64)
+    cnt = torch.zeros(1, device=dev, dtype=torch.int32)
+    with torch.cuda.device(dev):
+        ws = _builder_ws(lib, dev, P, T)
+        _lib.check(lib.deftet_subdivide_f32(_lib.ptr(tet), _lib.ptr(tet_edge), _lib.ptr(edges), _lib.ptr(pts), _lib.ptr(feat), _lib.ptr(sig),
+                                            _lib.ptr(pn), _lib.ptr(fn), _lib.ptr(tn), _lib.ptr(cnt), P, T, E, K,
+                                            _lib.ptr(ws), ws.numel(), _lib.current_stream(dev)), "deftet_subdivide_f32")
+    return pn, fn, tn[: int(cnt.item())]
+
+
+def point_adj_idx(n_point, tet_tx4):
+    """(pointadj_idx [P,m] int64 — ascending neighbours, -1 padded; adjsum [P,1] f32):
+    generate_point_adj_idx, prepare_for_wz.py:134-146, without the dense P x P matrix."""
+    _lib.require_gpu(tet_tx4)
+    lib = _lib.load()
+    dev, P = tet_tx4.device, int(n_point)
+    pairs = tet_point_adj(tet_tx4.to(torch.int32), P, dev)                 # sorted unique ordered pairs (A4)
+    n = pairs.shape[0]
+    adjsum = torch.zeros(P, 1, device=dev, dtype=torch.float32)
+    mx = torch.zeros(1, device=dev, dtype=torch.int32)
+    with torch.cuda.device(dev):
+        ws = _lib.workspace(dev, (P + 1) * 4 + 256)
+        args = (_lib.ptr(pairs), n, P)
+        _lib.check(lib.deftet_point_adj_table_i64(*args, None, 0, _lib.ptr(adjsum), _lib.ptr(mx), _lib.ptr(ws), ws.numel(),
+                                                  _lib.current_stream(dev)), "deftet_point_adj_table_i64")
+        m = int(mx.item())
+        table = torch.empty(P, m, device=dev, dtype=torch.int64)
+        if m > 0:
+            _lib.check(lib.deftet_point_adj_table_i64(*args, _lib.ptr(table), m, None, None, _lib.ptr(ws), ws.numel(),
+                                                      _lib.current_stream(dev)), "deftet_point_adj_table_i64")
+    return table, adjsum
+
+
+def delete_tet(tet_tx4, tet_weights_txk, thres=0.01):
+    """tets whose largest weight is > thres, order kept: delete_tet, prepare_for_wz.py:171-180."""
+    _lib.require_gpu(tet_tx4, tet_weights_txk)
+    lib = _lib.load()
+    tet, w = _i64_tets(tet_tx4), _f32c(tet_weights_txk)
+    T, dev = tet.shape[0], tet.device
+    if w.dim() != 2 or w.shape[0] != T:
+        raise RuntimeError("delete_tet: weights [T,k] expected")
+    out = torch.empty(max(T, 1), 4, device=dev, dtype=torch.int64)
+    cnt = torch.zeros(1, device=dev, dtype=torch.int32)
+    with torch.cuda.device(dev):
+        ws = _builder_ws(lib, dev, 0, T)
+        _lib.check(lib.deftet_delete_tet_i64(_lib.ptr(tet), _lib.ptr(w), float(np.float32(thres)), _lib.ptr(out), _lib.ptr(cnt), T, w.shape[1],
+                                             _lib.ptr(ws), ws.numel(), _lib.current_stream(dev)), "deftet_delete_tet_i64")
+    return out[: int(cnt.item())]
+
+
+def tet_neighbour_weights(tet_weights_txk, tet_neighbour_idx_tx4, neilevel=1):
+    """tetweights2tetneighbourweights, diff_render/diftet_6_subdiv/3_model/deftet.py:316-331."""
+    _lib.require_gpu(tet_weights_txk, tet_neighbour_idx_tx4)
+    lib = _lib.load()
+    w = _f32c(tet_weights_txk)
+    nei = tet_neighbour_idx_tx4.long().contiguous()
+    T = w.shape[0]
+    if nei.shape != (T, 4):
+        raise RuntimeError("tet_neighbour_weights: neighbour index [T,4] expected")
+    with torch.cuda.device(w.device):
+        for _ in range(int(neilevel)):
+            K = w.shape[1]
+            out = torch.empty(T, 4 * K, device=w.device, dtype=torch.float32)
+            _lib.check(lib.deftet_tet_neighbour_weights_f32(_lib.ptr(w), _lib.ptr(nei), _lib.ptr(out), T, K,
+                                                            _lib.current_stream(w.device)), "deftet_tet_neighbour_weights_f32")
+            w = out
+    return w
 
 
 # --------------------------------------------------------------------------------- N2 vertex <-> tet gather

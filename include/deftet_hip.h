@@ -162,6 +162,45 @@ int deftet_boundary_index_i64(const int64_t *face_fx3, const int64_t *tetidx_fx2
                               void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------
+ * N3  render-side geometry rebuilds of diff_render/diftet_6_subdiv/3_model/
+ * prepare_for_wz.py, all on int64 index arrays like the reference's numpy code.  Workspace:
+ * deftet_builder_workspace_bytes(n_point, n_tet).  Counts come back in device int32 words.
+ *
+ * deftet_tet_edges_i64: generate_edge (:184-203) + generate_tet_edge_idx (:223-236).
+ *   edges_ex2 int64 [6*n_tet capacity, 2] = unique (min,max) rows in lexicographic order
+ *   (np.unique(axis=0)); tet_edge_tx6 int64 [n_tet,6] = row of each tet edge in that list, columns
+ *   in the order (0,1),(0,2),(0,3),(1,2),(1,3),(2,3); *bad_flag = 1 if an index is outside [0,n_point).
+ * deftet_subdivide_f32: generate_subdivision (:255-301).  points_new f32 [n_point+n_edge,3] and
+ *   feat_new f32 [n_point+n_edge,n_feat] = old rows, then edge midpoints (a+b)/2; tet_new int64
+ *   [8*n_tet capacity,4]: with subdiv_sig == NULL the eight children of every tet in order, else
+ *   the tets with sig == 0 first (unchanged, in order), then the children of those with sig != 0.
+ * deftet_point_adj_table_i64: generate_point_adj_idx (:134-146) from the sorted unique ordered pairs
+ *   of deftet_tet_point_adj_i32 (A4).  width == 0: adjsum_px1 f32 [n_point] (degrees) and
+ *   *max_degree; width > 0: table_pxm int64 [n_point,width] = ascending neighbours, -1 padded.
+ *   workspace: (n_point+1) int32.
+ * deftet_delete_tet_i64: delete_tet (:171-180): keeps, in order, the tets whose row maximum of
+ *   weights_txk f32 [n_tet,k] is > thres (NaN rows are dropped, as np.max propagates NaN).
+ * deftet_tet_neighbour_weights_f32: one level of tetweights2tetneighbourweights (3_model/deftet.py:
+ *   316-331): out f32 [n_tet,4*k], out[t, j*k+c] = weights[nei[t,j], c], zeros where nei == -1.
+ * --------------------------------------------------------------------------------- */
+int deftet_tet_edges_i64(const int64_t *tet_tx4, int64_t *edges_ex2, int64_t *tet_edge_tx6, int32_t *n_edge,
+                         int32_t *bad_flag, int n_point, int n_tet,
+                         void *workspace, size_t workspace_bytes, void *stream);
+int deftet_subdivide_f32(const int64_t *tet_tx4, const int64_t *tet_edge_tx6, const int64_t *edges_ex2,
+                         const float *points_px3, const float *feat_pxk, const uint8_t *subdiv_sig,
+                         float *points_new, float *feat_new, int64_t *tet_new, int32_t *n_tet_new,
+                         int n_point, int n_tet, int n_edge, int n_feat,
+                         void *workspace, size_t workspace_bytes, void *stream);
+int deftet_point_adj_table_i64(const int32_t *pairs_nx2, int n_pairs, int n_point, int64_t *table_pxm, int width,
+                               float *adjsum_px1, int32_t *max_degree,
+                               void *workspace, size_t workspace_bytes, void *stream);
+int deftet_delete_tet_i64(const int64_t *tet_tx4, const float *weights_txk, float thres, int64_t *tet_kept,
+                          int32_t *n_kept, int n_tet, int k,
+                          void *workspace, size_t workspace_bytes, void *stream);
+int deftet_tet_neighbour_weights_f32(const float *weights_txk, const int64_t *nei_tx4, float *out_tx4k,
+                                     int n_tet, int k, void *stream);
+
+/* ---------------------------------------------------------------------------------
  * N2  the vertex <-> tet gather either side of the per-tet operators:
  *   tet_bxfx4x3 = torch.gather(vertice_pos, tetrahedron_bxfx4)          layers/DefTet/deftet.py:65-68
  * pos f32 [B,V,3]; tet_idx int64 [idx_batch,T,4] with idx_batch == 1 (one topology shared by all

@@ -338,3 +338,82 @@ def tet_gather_bwd(grad_tet_bxtx4x3, tet_idx, n_vertex):
         np.add.at(part, (sv, lane), g[b].reshape(-1, 3)[order])
         out[b] = (part[:, 0] + part[:, 1]) + (part[:, 2] + part[:, 3])
     return out
+
+
+# ----------------------------------------------------------------------------- N3 render-side rebuilds
+# Vectorised numpy restatements of /root/reference/diff_render/diftet_6_subdiv/3_model/prepare_for_wz.py
+# (the reference versions loop in Python, matchedgelist is O(E*T), generate_point_adj is a dense
+# P x P matrix); pinned by tests/golden/n3_*.npz, produced by the reference functions themselves.
+_EDGE_ENDS = np.array([[0, 1], [0, 2], [0, 3], [1, 2], [1, 3], [2, 3]])          # :190
+
+
+def generate_edge(tet_tx4):
+    """:184-203 — unique (min,max) rows, np.unique(axis=0) order."""
+    t = np.asarray(tet_tx4, dtype=np.int64)
+    a, b = t[:, _EDGE_ENDS[:, 0]].T.reshape(-1), t[:, _EDGE_ENDS[:, 1]].T.reshape(-1)
+    e = np.stack([np.minimum(a, b), np.maximum(a, b)], axis=1)
+    return np.unique(e, axis=0) if e.size else e.reshape(0, 2)
+
+
+def generate_tet_edge_idx(tet_tx4, edges_ex2):
+    """:206-236 — row of every tet edge in the unique list (matchedgelist as a key lookup)."""
+    t = np.asarray(tet_tx4, dtype=np.int64)
+    n = int(max(t.max(initial=-1), np.asarray(edges_ex2).max(initial=-1))) + 1
+    ekey = edges_ex2[:, 0] * n + edges_ex2[:, 1]                                 # ascending, unique
+    a, b = t[:, _EDGE_ENDS[:, 0]], t[:, _EDGE_ENDS[:, 1]]
+    key = np.minimum(a, b) * n + np.maximum(a, b)
+    return np.searchsorted(ekey, key).astype(np.int64)
+
+
+def generate_subdivision(tet_tx4, points_px3, feat_pxk, sig=None):
+    """:255-301."""
+    t = np.asarray(tet_tx4, dtype=np.int64)
+    pts, feat = np.asarray(points_px3, dtype=np.float32), np.asarray(feat_pxk, dtype=np.float32)
+    edges = generate_edge(t)
+    te = generate_tet_edge_idx(t, edges)
+    pn = np.concatenate([pts, (pts[edges[:, 0]] + pts[edges[:, 1]]) / 2], axis=0)
+    fn = np.concatenate([feat, (feat[edges[:, 0]] + feat[edges[:, 1]]) / 2], axis=0)
+    P = pts.shape[0]
+    a, b, c, d = t.T
+    ab, ac, ad, bc, bd, cd = (te + P).T
+    ch = np.stack([np.stack(x, axis=1) for x in ([a, ab, ac, ad], [b, bc, ab, bd], [c, ac, bc, cd], [d, ad, cd, bd],
+                                                 [ab, ac, ad, bd], [ab, ac, bd, bc], [cd, ac, bd, ad], [cd, ac, bc, bd])], axis=1)
+    if sig is None:
+        tn = ch.reshape(-1, 4)
+    else:
+        sig = np.asarray(sig, dtype=bool)
+        tn = np.concatenate([t[~sig], ch[sig].reshape(-1, 4)], axis=0)
+    return pn, fn, tn
+
+
+def generate_point_adj_idx(n_point, tet_tx4):
+    """:108-146 — ascending neighbour table padded with -1, and the degrees as float32 [P,1]."""
+    t = np.asarray(tet_tx4, dtype=np.int64)
+    i = np.repeat(t, 3, axis=1).reshape(-1)                                       # every ordered pair of distinct corners
+    j = t[:, [1, 2, 3, 0, 2, 3, 1, 0, 3, 1, 0, 2]].reshape(-1)
+    pair = np.unique(np.stack([i, j], axis=1), axis=0) if t.size else np.zeros((0, 2), dtype=np.int64)
+    deg = np.bincount(pair[:, 0], minlength=n_point).astype(np.int64)
+    m = int(deg.max()) if n_point else 0
+    table = -np.ones((n_point, m), dtype=np.int64)
+    start = np.concatenate([[0], np.cumsum(deg)[:-1]]) if n_point else np.zeros(0, dtype=np.int64)
+    col = np.arange(pair.shape[0]) - start[pair[:, 0]]
+    table[pair[:, 0], col] = pair[:, 1]
+    return table, deg.astype(np.float32).reshape(-1, 1)
+
+
+def delete_tet(tet_tx4, weights_txk, thres=0.01):
+    """:171-180."""
+    w = np.asarray(weights_txk, dtype=np.float32)
+    return np.asarray(tet_tx4)[np.max(w, axis=1) > thres]
+
+
+def tetweights2tetneighbourweights(weights_txk, nei_tx4, neilevel=1):
+    """3_model/deftet.py:316-331."""
+    w = np.asarray(weights_txk, dtype=np.float32)
+    nei = np.asarray(nei_tx4, dtype=np.int64)
+    for _ in range(neilevel):
+        t, k = w.shape
+        w1 = np.zeros((t + 1, k), dtype=np.float32)
+        w1[1:] = w
+        w = w1[nei.reshape(-1) + 1].reshape(t, -1)
+    return w

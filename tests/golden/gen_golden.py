@@ -20,6 +20,11 @@ What is pinned:
                        get_internal_index (:197-203), paste_occ (:132-136),
                        volume_variance (:239-263), amips_energy (:266-298),
                        edge_length (:320-338), tet_inverse_v (:300-318).
+  n3_rebuilds.npz      diff_render/diftet_6_subdiv/3_model/prepare_for_wz.py: generate_edge (:184-203),
+                       generate_tet_edge_idx (:223-236), generate_subdivision (:255-301, with and
+                       without a split mask), generate_point_adj_idx (:134-146), delete_tet
+                       (:171-180); 3_model/deftet.py tetweights2tetneighbourweights (:316-331),
+                       on a Kuhn grid and on a random soup with repeated vertices.
 """
 import hashlib
 import os
@@ -201,6 +206,46 @@ def main():
         out["boundary_%d" % i] = bnd[i].numpy()
         out["internal_%d" % i] = inn[i].numpy()
     np.savez_compressed(os.path.join(HERE, "deftet_module.npz"), **out)
+
+    # ---------------- render-side rebuilds (prepare_for_wz.py, 3_model/deftet.py)
+    import prepare_for_wz as W
+    for modname in ("cameraop", "config", "utils_mesh"):
+        m = types.ModuleType(modname)
+        for attr in ("perspective", "rootdir", "savemesh", "savemeshfweights", "savemeshfweightscolor"):
+            setattr(m, attr, "/tmp" if attr == "rootdir" else None)
+        sys.modules[modname] = m
+    sys.modules.pop("deftet", None)
+    import deftet as RD                     # diff_render/diftet_6_subdiv/3_model/deftet.py
+
+    class _Self:
+        pass
+
+    out = {}
+    rng = np.random.default_rng(11)
+    verts, tets = grids.kuhn_grid(6)
+    soup = rng.integers(0, 40, (120, 4)).astype(np.int64)
+    soup[::7, 1] = soup[::7, 0]                                  # repeated vertices inside a tet
+    for name, t, P in (("grid", tets.astype(np.int64), verts.shape[0]), ("soup", soup, 45)):
+        pts = rng.standard_normal((P, 3)).astype(np.float32)
+        feat = rng.standard_normal((P, 5)).astype(np.float32)
+        sig = rng.random(len(t)) < 0.35
+        e = W.generate_edge(t)
+        te = W.generate_tet_edge_idx(t, e)
+        pn, fn, tn = W.generate_subdivision(t, pts, feat)
+        pn2, fn2, tn2 = W.generate_subdivision(t, pts, feat, sig)
+        table, adjsum = W.generate_point_adj_idx(P, t)
+        w = (rng.random((len(t), 4)) * 0.02).astype(np.float32)
+        w[3] = np.nan
+        kept = W.delete_tet(t, w, 0.01)
+        nei = rng.integers(-1, len(t), (len(t), 4)).astype(np.int64)
+        holder = _Self()
+        holder.tet_neighbour_idx = nei
+        nw1 = RD.Deftet.tetweights2tetneighbourweights(holder, w, 1)
+        nw2 = RD.Deftet.tetweights2tetneighbourweights(holder, w, 2)
+        out.update({name + "_" + k: v for k, v in dict(
+            tet=t, n_point=np.int64(P), pts=pts, feat=feat, sig=sig, edges=e, tet_edge=te, sub_pts=pn, sub_feat=fn, sub_tet=tn,
+            sub_tet_sig=tn2, sub_pts_sig=pn2, adj_table=table, adjsum=adjsum, weights=w, kept=kept, nei=nei, nw1=nw1, nw2=nw2).items()})
+    np.savez_compressed(os.path.join(HERE, "n3_rebuilds.npz"), **out)
     print("golden fixtures written to", HERE)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):

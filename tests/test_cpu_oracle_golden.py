@@ -206,3 +206,26 @@ def test_tet_gather_oracle_matches_torch_autograd():
     assert np.abs(p.grad.numpy() - got).max() <= 1e-5 * np.abs(p.grad.numpy()).max()
     # shared topology broadcast
     assert np.array_equal(oracle.tet_gather(pos, idx[0]), oracle.tet_gather(pos, np.broadcast_to(idx[0], idx.shape)))
+
+
+@pytest.mark.parametrize("name", ["grid", "soup"])
+def test_n3_rebuild_oracle_matches_reference_outputs(name):
+    """N3: the vectorised restatements equal what prepare_for_wz.py / 3_model/deftet.py produced
+    (tests/golden/n3_rebuilds.npz, written by tests/golden/gen_golden.py from the reference)."""
+    from oracle import oracle
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "n3_rebuilds.npz"))
+    G = {k[len(name) + 1:]: g[k] for k in g.files if k.startswith(name + "_")}
+    t, P = G["tet"], int(G["n_point"])
+    e = oracle.generate_edge(t)
+    assert np.array_equal(e, G["edges"])
+    assert np.array_equal(oracle.generate_tet_edge_idx(t, e), G["tet_edge"])
+    pn, fn, tn = oracle.generate_subdivision(t, G["pts"], G["feat"])
+    assert np.array_equal(pn, G["sub_pts"]) and np.array_equal(fn, G["sub_feat"]) and np.array_equal(tn, G["sub_tet"])
+    pn2, _, tn2 = oracle.generate_subdivision(t, G["pts"], G["feat"], G["sig"])
+    assert np.array_equal(pn2, G["sub_pts_sig"]) and np.array_equal(tn2, G["sub_tet_sig"])
+    table, adjsum = oracle.generate_point_adj_idx(P, t)
+    assert np.array_equal(table, G["adj_table"]) and np.array_equal(adjsum, G["adjsum"]) and adjsum.dtype == G["adjsum"].dtype
+    with np.errstate(invalid="ignore"):
+        assert np.array_equal(oracle.delete_tet(t, G["weights"], 0.01), G["kept"])
+    assert np.array_equal(oracle.tetweights2tetneighbourweights(G["weights"], G["nei"], 1), G["nw1"], equal_nan=True)
+    assert np.array_equal(oracle.tetweights2tetneighbourweights(G["weights"], G["nei"], 2), G["nw2"], equal_nan=True)

@@ -149,6 +149,22 @@ def main():
          csr_build_ms=round(t_csr * 1e3, 3), torch_gather_ms=round(tt_f * 1e3, 4), torch_scatter_add_ms=round(tt_b * 1e3, 4),
          bwd_speedup_vs_torch=round(tt_b / t_b, 1), note="torch ops run on the same MI355X; bwd bytes = %.1f MB read" % (Bv * T * 48 / 1e6))
 
+    # ---- N3: render-side rebuilds (prepare_for_wz.py) vs the vectorised numpy port (the reference's own
+    # matchedgelist is O(E*T) Python: ~E*T*1e-8 s, hours at this size)
+    t64 = tets.astype(np.int64)
+    ptsn = np.random.default_rng(0).standard_normal((n_point, 3)).astype(np.float32)
+    featn = np.random.default_rng(1).standard_normal((n_point, 8)).astype(np.float32)
+    td, pd, fd = torch.from_numpy(t64).to(dev), torch.from_numpy(ptsn).to(dev), torch.from_numpy(featn).to(dev)
+    tg = gpu_time(lambda: hip_ops.subdivide(td, pd, fd), reps=3)
+    tc = cpu_time(lambda: O.generate_subdivision(t64, ptsn, featn))
+    emit(op="generate_subdivision", res=res, n_tet=T, n_point=n_point, gpu_ms=round(tg * 1e3, 3), cpu_ms=round(tc * 1e3, 1),
+         cpu_kind="port (vectorised numpy)", cpu_cores=1, speedup=round(tc / tg, 1))
+    tg = gpu_time(lambda: hip_ops.point_adj_idx(n_point, td), reps=3)
+    tc = cpu_time(lambda: O.generate_point_adj_idx(n_point, t64))
+    emit(op="generate_point_adj_idx", res=res, n_tet=T, n_point=n_point, gpu_ms=round(tg * 1e3, 3), cpu_ms=round(tc * 1e3, 1),
+         cpu_kind="port (vectorised numpy; the reference allocates a dense %d x %d float matrix = %.1f GB)" % (n_point, n_point, n_point * n_point * 4 / 1e9),
+         cpu_cores=1, speedup=round(tc / tg, 1))
+
 
 if __name__ == "__main__":
     main()
