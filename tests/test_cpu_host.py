@@ -124,3 +124,33 @@ def test_all_gather_losses_gloo_world2(n_items):
         assert p.exitcode == 0
     want = np.stack([[float(i), float(i) * 0.5 + 1.0] for i in range(n_items)]).astype(np.float32)
     assert np.array_equal(got[0], want) and np.array_equal(got[1], want)
+
+
+def test_read_tetrahedron_mirror(tmp_path):
+    """N4: .tet text format + the boundary snapping rule of utils/dataloder_helper.py:30-69."""
+    from deftet_amd.utils.dataloder_helper import read_tetrahedron, tet_file_name
+    from deftet_amd import grids
+    root = str(tmp_path)
+    v, t, mask = read_tetrahedron(res=8, root=root)            # file missing -> synthetic grid is written
+    fn, r = tet_file_name(8, root)
+    assert os.path.exists(fn) and fn.endswith("cube_0.125000_tet.tet") and r == 0.125
+    head = open(fn).readline().split()
+    assert head == ["tet", str(v.shape[0]), str(t.shape[0])]
+    v0, t0 = grids.kuhn_grid(8)
+    assert np.array_equal(t, t0) and np.allclose(v, v0) and t.dtype == np.int64 and v.dtype == np.float64
+    assert mask.shape == v.shape
+    interior = np.logical_and(v0 > 0, v0 < 1)
+    assert np.array_equal(mask, interior)
+    # snapping: coordinates within res/4 of the faces of the unit cube move onto them
+    w = v0.copy()
+    w[w == 0] = 0.03
+    w[w == 1] = 0.97
+    grids.write_tet(fn, w, t0)
+    v2, _, mask2 = read_tetrahedron(res=8, root=root)
+    assert np.array_equal(v2, v0) and np.array_equal(mask2, interior)
+    # second call reads the existing file; a malformed one raises
+    open(fn, "w").write("tet 2 1\n0 0 0\n1 1 1\n0 1\n")
+    with pytest.raises(ValueError):
+        read_tetrahedron(res=8, root=root)
+    with pytest.raises(FileNotFoundError):
+        read_tetrahedron(res=10, root=root, generate_missing=False)
