@@ -301,6 +301,30 @@ def nn_index(queries_bxnx3, points_bxmx3, brute=False):
     return out
 
 
+# --------------------------------------------------------------------------------- N1 check_sign
+def check_sign(verts_bxvx3, faces_fx3, points_bxnx3, brute=False, return_count=False, check=True):
+    """bool [B,N]: point inside the (watertight) mesh — kal.ops.mesh.check_sign restated
+    (parity unpinned, contract in oracle/deftet_oracle_sign.c)."""
+    _lib.require_gpu(verts_bxvx3, faces_fx3, points_bxnx3)
+    lib = _lib.load()
+    v, p = _f32c(verts_bxvx3), _f32c(points_bxnx3)
+    f = faces_fx3.long().contiguous()
+    if v.dim() != 3 or p.dim() != 3 or f.dim() != 2 or f.shape[1] != 3 or v.shape[0] != p.shape[0] or v.shape[2] != 3 or p.shape[2] != 3:
+        raise RuntimeError("check_sign: verts [B,V,3], faces [F,3], points [B,N,3] expected")
+    B, V, N, F, dev = v.shape[0], v.shape[1], p.shape[1], f.shape[0], v.device
+    out = torch.empty(B, N, device=dev, dtype=torch.uint8)
+    cnt = torch.empty(B, N, device=dev, dtype=torch.int32) if return_count else None
+    bad = torch.zeros(1, device=dev, dtype=torch.int32)
+    algo = 1 if brute else 0
+    with torch.cuda.device(dev):
+        ws = _lib.workspace(dev, lib.deftet_check_sign_workspace_bytes(B, F, algo))
+        _lib.check(lib.deftet_check_sign_f32(_lib.ptr(v), _lib.ptr(f), _lib.ptr(p), _lib.ptr(out), _lib.ptr(cnt), _lib.ptr(bad), B, V, F, N,
+                                             algo, _lib.ptr(ws), ws.numel(), _lib.current_stream(dev)), "deftet_check_sign_f32")
+    if check and int(bad.item()):
+        raise IndexError("check_sign: face index outside [0, %d)" % V)
+    return (out.bool(), cnt) if return_count else out.bool()
+
+
 # --------------------------------------------------------------------------------- N3 render-side rebuilds
 def _i64_tets(tet_tx4):
     t = tet_tx4 if tet_tx4.dtype == torch.int64 else tet_tx4.long()

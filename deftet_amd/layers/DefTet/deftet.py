@@ -8,10 +8,11 @@
     point queries                             (:110-112)  -> check_condition_f_base
     gather_tet_pos (vertex -> tet gather)     (:65-68)    -> deftet_tet_gather_{fwd,bwd}_f32
 
-`forward_surface_align` itself is not provided: it needs the ground-truth occupancy of tet
-centroids from kaolin.ops.mesh.check_sign (:33-49), which is third-party and outside this
-build's scope; the pieces it composes are all here or in
-deftet_amd.layers / deftet_amd.utils.
+    check_tet_inside_sdfs                     (:33-49)    -> deftet_check_sign_f32 (Kaolin's
+                                                             check_sign restated; parity unpinned)
+
+`forward_surface_align` itself (network glue around these calls) is not provided; the pieces it
+composes are all here or in deftet_amd.layers / deftet_amd.utils.
 """
 import torch
 import torch.nn as nn
@@ -65,6 +66,18 @@ class DefTet(nn.Module):
             self._topo = TetTopology(tetrahedron_bxfx4, vertice_pos.shape[1])
             self._topo_key = key
         return self._topo.gather(vertice_pos)
+
+    # --- N1: GT occupancy of the tet centroids (deftet.py:33-49)
+    def check_tet_inside_sdfs(self, tet_bxfx4x3, mesh_list):
+        verts, faces = mesh_list[0], mesh_list[1]
+        with torch.no_grad():
+            occupancy = []
+            for v, f, tet_fx4x3 in zip(verts, faces, tet_bxfx4x3):
+                center = torch.mean(tet_fx4x3, dim=1)
+                result = hip_ops.check_sign(v, f[0], center.unsqueeze(dim=0))
+                occupancy.append(result.unsqueeze(-1))
+            occupancy = torch.cat(occupancy, dim=0).float()
+        return occupancy
 
     # --- A7
     def get_boundary_index(self, tet_face_fx3, tet_idx_fx2, occ_bxn):

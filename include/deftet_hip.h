@@ -162,6 +162,24 @@ int deftet_boundary_index_i64(const int64_t *face_fx3, const int64_t *tetidx_fx2
                               void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------
+ * N1  ground-truth occupancy by ray parity:
+ *   kal.ops.mesh.check_sign(verts, faces, points, hash_resolution=512)
+ * (layers/DefTet/deftet.py:46, eval.py:239, dataloader.py:92).  PARITY UNPINNED — Kaolin is not in
+ * the reference tree; the contract (ray along +x, Moller-Trumbore in fp32, eps 1e-7, odd number of
+ * crossings = inside) is oracle/deftet_oracle_sign.c, which the kernels match bit for bit.
+ * verts f32 [B,V,3]; faces int64 [F,3] (shared by the batch, like Kaolin); points f32 [B,N,3];
+ * inside uint8 [B,N] (0/1); count int32 [B,N] or NULL (number of crossings); *bad_flag (device
+ * int32) = 1 if a face index is outside [0,V).  algo: DEFTET_CS_AUTO = faces binned in the (y,z)
+ * plane (exact, certified like the tets), DEFTET_CS_BRUTE = every point against every face.
+ * --------------------------------------------------------------------------------- */
+#define DEFTET_CS_AUTO 0
+#define DEFTET_CS_BRUTE 1
+size_t deftet_check_sign_workspace_bytes(int n_batch, int n_face, int algo);
+int deftet_check_sign_f32(const float *verts, const int64_t *faces, const float *points, uint8_t *inside,
+                          int32_t *count, int32_t *bad_flag, int n_batch, int n_vertex, int n_face, int n_point,
+                          int algo, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------
  * N3  render-side geometry rebuilds of diff_render/diftet_6_subdiv/3_model/
  * prepare_for_wz.py, all on int64 index arrays like the reference's numpy code.  Workspace:
  * deftet_builder_workspace_bytes(n_point, n_tet).  Counts come back in device int32 words.

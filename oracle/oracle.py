@@ -23,7 +23,7 @@ _f64p = C.POINTER(C.c_double)
 
 def build(force: bool = False) -> None:
     """Compile the restatement and (when /root/reference is present) oracle/_ref."""
-    src = [os.path.join(HERE, f) for f in ("deftet_oracle.c", "deftet_oracle_surface.c", "deftet_oracle_render.c", "Makefile")]
+    src = [os.path.join(HERE, f) for f in ("deftet_oracle.c", "deftet_oracle_surface.c", "deftet_oracle_render.c", "deftet_oracle_sign.c", "Makefile")]
     stale = (not os.path.exists(LIB_PATH) or
              any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in src))
     need_ref = os.path.isdir("/root/reference/utils/lib") and not all(
@@ -417,3 +417,15 @@ def tetweights2tetneighbourweights(weights_txk, nei_tx4, neilevel=1):
         w1[1:] = w
         w = w1[nei.reshape(-1) + 1].reshape(t, -1)
     return w
+
+
+# ----------------------------------------------------------------------------- N1 check_sign (parity unpinned)
+def check_sign(verts_bxvx3, faces_fx3, points_bxnx3, return_count=False):
+    """kal.ops.mesh.check_sign restated (oracle/deftet_oracle_sign.c): bool [B,N]."""
+    v, f, p = _c(verts_bxvx3, np.float32), _c(faces_fx3, np.int64), _c(points_bxnx3, np.float32)
+    B, V, N, F = v.shape[0], v.shape[1], p.shape[1], f.shape[0]
+    out = np.zeros((B, N), np.uint8)
+    cnt = np.zeros((B, N), np.int32)
+    lib().oracle_check_sign_f32(_p(v, _f32p), _p(f, C.POINTER(C.c_int64)), _p(p, _f32p), _p(out, C.POINTER(C.c_uint8)),
+                                _p(cnt, _i32p), B, V, F, N)
+    return (out.astype(bool), cnt) if return_count else out.astype(bool)

@@ -165,6 +165,23 @@ def main():
          cpu_kind="port (vectorised numpy; the reference allocates a dense %d x %d float matrix = %.1f GB)" % (n_point, n_point, n_point * n_point * 4 / 1e9),
          cpu_cores=1, speedup=round(tc / tg, 1))
 
+    # ---- N1: check_sign of all tet centroids against a closed surface (layers/DefTet/deftet.py:33-49)
+    Bc = 2 if quick else 8
+    posc = grids.jittered_positions(verts, res, Bc, 0.1).astype(np.float32)
+    f3, t2, _, _, _ = O.tet_to_face(tets, n_point)
+    occ = np.linalg.norm((verts - 0.5)[tets].mean(1), axis=1) < 0.3
+    faces = f3[occ[t2].sum(1) == 1].astype(np.int64)
+    cen = posc[:, tets].mean(2).astype(np.float32)
+    vd, fdv, cd = torch.from_numpy(posc).to(dev), torch.from_numpy(faces).to(dev), torch.from_numpy(cen).to(dev)
+    tg = gpu_time(lambda: hip_ops.check_sign(vd, fdv, cd, check=False), reps=5)
+    tbr = gpu_time(lambda: hip_ops.check_sign(vd, fdv, cd, brute=True, check=False), reps=2, warm=1)
+    sub = 2000
+    tc = cpu_time(lambda: O.check_sign(posc[:1], faces, cen[:1, :sub])) * (cen.shape[1] / sub) * Bc
+    emit(op="check_sign", res=res, batch=Bc, n_point=int(cen.shape[1]), n_face=int(faces.shape[0]), gpu_ms=round(tg * 1e3, 3),
+         gpu_brute_ms=round(tbr * 1e3, 2), cpu_ms=round(tc * 1e3, 0), cpu_kind="port (OpenMP, extrapolated from %d points)" % sub,
+         cpu_cores=os.cpu_count(), nominal_ray_face_tests_per_s=round(Bc * cen.shape[1] * faces.shape[0] / tg / 1e12, 2),
+         unit="T ray-face tests/s", parity="unpinned (Kaolin not in the reference tree)")
+
 
 if __name__ == "__main__":
     main()
