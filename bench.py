@@ -48,12 +48,16 @@ def make_inputs(rank, device, res=RES, n_query=N_QUERY, batch=BATCH):
     return host, dev
 
 
+ALGO = int(os.environ.get("DEFTET_BENCH_ALGO", "0"))      # A/B switch for the traversal kernel (0 = shipped default)
+DOMINANT = {0: b"k_tet_scan", 2: b"k_tet_scan_staged", 3: b"k_tet_scan_rows"}.get(ALGO, b"k_tet_scan")
+
+
 def step(d, world):
     """fwd: index + weights + fused paste_occ gather (+ per-tet hit records); bwd: dL/dtet and
     dL/dpred from one per-tet pass over those records (no atomics); then the per-shape loss
     scalars (all-gathered when world > 1).  Same calls as the PointInTetOcc autograd op makes."""
     from deftet_amd import hip_ops, sharding
-    cond, w, occ, hits = hip_ops.point_in_tet(d["tet"], d["pts"], want_bary=True, pred_bxt=d["pred"], want_hits=True)
+    cond, w, occ, hits = hip_ops.point_in_tet(d["tet"], d["pts"], want_bary=True, pred_bxt=d["pred"], want_hits=True, algo=ALGO)
     g_tet, _, g_pred = hip_ops.point_in_tet_bwd(d["tet"], d["pts"], cond, d["gw"], grad_occ=d["gout"], hits=hits)
     loss = hip_ops.rowdot(w, d["gw"], occ, d["gout"])         # [B] per-shape loss scalars
     if world > 1:
@@ -129,7 +133,7 @@ def main():
         step(d, world)
     torch.cuda.synchronize()
 
-    dominant = b"k_tet_scan"
+    dominant = DOMINANT
     lib.deftet_profile_select(dominant)
     if world > 1:
         torch.distributed.barrier()

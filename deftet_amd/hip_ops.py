@@ -11,7 +11,7 @@ import torch
 
 from . import _lib
 
-PIT_AUTO, PIT_BRUTE, PIT_STAGED = 0, 1, 2
+PIT_AUTO, PIT_BRUTE, PIT_STAGED, PIT_ROWS = 0, 1, 2, 3
 
 
 def _f32c(t):

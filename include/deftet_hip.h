@@ -37,6 +37,7 @@ extern "C" {
 #define DEFTET_PIT_AUTO 0    /* uniform-grid binned, tet-centric (default) */
 #define DEFTET_PIT_BRUTE 1   /* LDS/scalar-tiled brute force: the algorithmic equivalent of the reference kernel */
 #define DEFTET_PIT_STAGED 2  /* binned, with wave-cooperative LDS staging of the cell rows (coherent tet orders) */
+#define DEFTET_PIT_ROWS 3    /* binned, (tet,row) pairs balanced across the lanes of a wave through LDS */
 
 int deftet_version(void);
 const char *deftet_last_error(void);

@@ -19,7 +19,7 @@ def _run(tet, pts, dev, algo=0, bary=False):
     return out.cpu().numpy()
 
 
-@pytest.mark.parametrize("algo", [0, 1, 2])
+@pytest.mark.parametrize("algo", [0, 1, 2, 3])
 @pytest.mark.parametrize("res,nq,batch", [(4, 257, 1), (8, 3000, 3), (12, 5000, 2)])
 def test_index_bit_exact_jittered(cuda, oracle, algo, res, nq, batch):
     tet, pts = cases.jittered(res, nq, batch)
@@ -30,7 +30,7 @@ def test_index_bit_exact_jittered(cuda, oracle, algo, res, nq, batch):
     assert 0.05 < (want < 0).mean() < 0.25          # the 13.6 % miss band of SURVEY 3.2
 
 
-@pytest.mark.parametrize("algo", [0, 1, 2])
+@pytest.mark.parametrize("algo", [0, 1, 2, 3])
 @pytest.mark.parametrize("seed", [0, 1, 2])
 def test_index_bit_exact_adversarial(cuda, oracle, algo, seed):
     tet, pts = cases.adversarial(seed)
@@ -206,8 +206,9 @@ def test_fused_occ_op_matches_separate_ops(cuda, oracle):
     assert (g_tet - t1.grad).abs().max() <= 1e-5 * t1.grad.abs().max()
 
 
+@pytest.mark.parametrize("algo", [0, 2, 3])
 @pytest.mark.parametrize("seed", [0, 1, 2])
-def test_backward_hit_records_adversarial(cuda, oracle, seed):
+def test_backward_hit_records_adversarial(cuda, oracle, seed, algo):
     """the three backward paths (hit records / linked lists / atomics) agree, including tets that
     swallow many queries (record overflow), irregular tets and NaN / huge queries"""
     from deftet_amd import _lib, hip_ops
@@ -221,7 +222,7 @@ def test_backward_hit_records_adversarial(cuda, oracle, seed):
     t, p = torch.from_numpy(tet).to(cuda), torch.from_numpy(pts).to(cuda)
     gen = torch.Generator(device=cuda).manual_seed(seed)
     pred = torch.rand(B, T, device=cuda, generator=gen)
-    cond, w, occ, hits = hip_ops.point_in_tet(t, p, want_bary=True, pred_bxt=pred, want_hits=True)
+    cond, w, occ, hits = hip_ops.point_in_tet(t, p, want_bary=True, pred_bxt=pred, want_hits=True, algo=algo)
     assert np.array_equal(cond.cpu().numpy(), oracle.point_in_tet(tet, pts))
     h4 = hits[: B * T * 4].view(B, T, 4)
     assert (h4[..., 3] == -2).any()                                    # some tet overflowed / is irregular
