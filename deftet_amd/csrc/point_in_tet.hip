@@ -43,7 +43,13 @@ constexpr int kHitOverflow = -2;            // hits[.].w: this tet has accepted 
 constexpr int kHitPad = 64;
 __host__ __device__ inline size_t hit_cnt_off(int B, int T) { return (size_t)B * T * 4; }
 __host__ __device__ inline size_t hit_list_off(int B, int T) { return (size_t)B * T * 4 + (size_t)((B + kHitPad - 1) / kHitPad) * kHitPad; }
-constexpr int kXFine = 4;                   // cells are kXFine times finer along x (the run direction)
+#ifndef PIT_XFINE
+#define PIT_XFINE 4
+#endif
+#ifndef PIT_GDIV
+#define PIT_GDIV 6.0
+#endif
+constexpr int kXFine = PIT_XFINE;           // cells are kXFine times finer along x (the run direction)
 
 // ------------------------------------------------------------------------------------
 // exact predicate pieces (check_condition_tet_for.cu:105-121, :172-176)
@@ -1434,7 +1440,7 @@ __global__ __launch_bounds__(256) void k_paste_bwd(const float *__restrict__ con
 // ------------------------------------------------------------------------------------
 static int pick_G(int T, int Q)
 {
-    double a = T / 6.0, bq = (Q > 0 ? Q : 1) / 2.0;
+    double a = T / (double)(PIT_GDIV), bq = (Q > 0 ? Q : 1) / 2.0;
     double m = a < bq ? a : bq;
     int G = (int)llround(cbrt(m < 1 ? 1 : m));
     if (G < 1) G = 1;

@@ -160,94 +160,91 @@ __device__ __forceinline__ FaceBox face_box(const float *__restrict__ xy, int f,
     return r;
 }
 
-__global__ __launch_bounds__(256) void k_face_count(const float *__restrict__ xy, int F, const Grid2 *__restrict__ gp,
-                                                    float eps, int *tileCount, int *wide, int *nWide)
+// Tile lists WITHOUT atomics and without a per-tile sort (round-1 history: atomic count + atomic
+// fill + a bitonic sort per tile = 0.58 + 0.59 + 1.71 ms at configs[4]): every face reports how
+// many tiles it overlaps, an exclusive scan turns that into pair offsets, the (tile, face) pairs
+// are written in ascending face order and ONE stable radix sort by tile (rocPRIM, 19 key bits)
+// leaves every tile's faces ascending.  The wide list is a stream compaction (ascending by
+// construction).  Unused pair slots carry the key kPadKey and sort to the end.
+constexpr unsigned kPadKey = 1u << 18;             // > any tile id (kG2Max^2 = 2^18 tiles at most)
+
+__global__ __launch_bounds__(256) void k_face_span(const float *__restrict__ xy, int F, const Grid2 *__restrict__ gp, float eps,
+                                                   int *span, int *isWide)
 {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= F) return;
     const Grid2 g = *gp;
     const FaceBox fb = face_box(xy, f, g, eps);
-    if (fb.mode == 2) { wide[atomicAdd(nWide, 1)] = f; return; }
-    if (fb.mode == 0) return;
-    for (int ty = fb.ty0; ty <= fb.ty1; ++ty)
-        for (int tx = fb.tx0; tx <= fb.tx1; ++tx) atomicAdd(&tileCount[ty * g.gx + tx], 1);
+    span[f] = fb.mode == 1 ? (fb.tx1 - fb.tx0 + 1) * (fb.ty1 - fb.ty0 + 1) : 0;
+    isWide[f] = fb.mode == 2 ? 1 : 0;
 }
 
-__global__ __launch_bounds__(256) void k_face_fill(const float *__restrict__ xy, int F, const Grid2 *__restrict__ gp,
-                                                   float eps, const int *__restrict__ tileStart, int *tileFill, int *list)
+__global__ __launch_bounds__(256) void k_face_pairs(const float *__restrict__ xy, int F, const Grid2 *__restrict__ gp, float eps,
+                                                    const int *__restrict__ pairOff, const int *__restrict__ wideOff,
+                                                    unsigned *key, unsigned *val, int *wide, int *nWide, long long cap)
 {
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= F) return;
-    const Grid2 g = *gp;
-    const FaceBox fb = face_box(xy, f, g, eps);
-    if (fb.mode != 1) return;
-    for (int ty = fb.ty0; ty <= fb.ty1; ++ty)
-        for (int tx = fb.tx0; tx <= fb.tx1; ++tx) {
-            const int t = ty * g.gx + tx;
-            list[tileStart[t] + atomicAdd(&tileFill[t], 1)] = f;
-        }
-}
-
-// ascending sort of one tile's face list (block per tile; the wide list is "tile" nTiles).
-// <= 2048 entries: bitonic sort in LDS; longer lists: rank sort through global scratch.
-__global__ __launch_bounds__(256) void k_tile_sort(int *list, const int *__restrict__ tileStart, const Grid2 *__restrict__ gp,
-                                                   int *wide, const int *__restrict__ nWide, int *scratch,
-                                                   long long wideScratchOff)
-{
-    __shared__ int sh[2048];
-    const int nTiles = gp->gx * gp->gy;
-    for (int tile = blockIdx.x; tile <= nTiles; tile += gridDim.x) {
-    int *base;
-    int n;
-    if (tile < nTiles) { base = list + tileStart[tile]; n = tileStart[tile + 1] - tileStart[tile]; }
-    else { base = wide; n = *nWide; }
-    if (n <= 1) continue;
-    __syncthreads();                                   // sh is reused across iterations
-    if (n <= 2048) {
-        int m = 1;
-        while (m < n) m <<= 1;
-        for (int i = threadIdx.x; i < m; i += 256) sh[i] = i < n ? base[i] : 0x7FFFFFFF;
-        __syncthreads();
-        for (int k = 2; k <= m; k <<= 1)
-            for (int j = k >> 1; j > 0; j >>= 1) {
-                for (int i = threadIdx.x; i < m; i += 256) {
-                    const int l = i ^ j;
-                    if (l > i) {
-                        const int a = sh[i], b = sh[l];
-                        const bool up = (i & k) == 0;
-                        if ((a > b) == up) { sh[i] = b; sh[l] = a; }
-                    }
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < F) {
+        const int f = (int)i;
+        const Grid2 g = *gp;
+        const FaceBox fb = face_box(xy, f, g, eps);
+        if (fb.mode == 2) wide[wideOff[f]] = f;
+        if (fb.mode == 1) {
+            int o = pairOff[f];
+            for (int ty = fb.ty0; ty <= fb.ty1; ++ty)
+                for (int tx = fb.tx0; tx <= fb.tx1; ++tx) {
+                    key[o] = (unsigned)(ty * g.gx + tx);
+                    val[o] = (unsigned)f;
+                    ++o;
                 }
-                __syncthreads();
-            }
-        for (int i = threadIdx.x; i < n; i += 256) base[i] = sh[i];
-    } else {
-        // face ids are distinct inside a list: rank = number of smaller ids
-        int *tmp = tile < nTiles ? scratch + (base - list) : scratch + wideScratchOff;
-        for (int i = threadIdx.x; i < n; i += 256) {
-            const int v = base[i];
-            int r = 0;
-            for (int j = 0; j < n; ++j) r += base[j] < v ? 1 : 0;
-            tmp[r] = v;
         }
-        __syncthreads();
-        for (int i = threadIdx.x; i < n; i += 256) base[i] = tmp[i];
+        if (f == F - 1) *nWide = wideOff[F];
     }
+    // pad the unused tail of the pair arrays (grid covers max(F, cap))
+    const int used = pairOff[F];
+    if (i >= used && i < cap) key[i] = kPadKey;
+}
+
+// tileStart[t] = first sorted position whose key is >= t (binary search, one lane per tile;
+// a boundary scan would leave one lane writing the whole run of empty tiles)
+__global__ __launch_bounds__(256) void k_tile_starts(const unsigned *__restrict__ skey, long long n, int nTilesCap, int *tileStart)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > nTilesCap) return;
+    long long lo = 0, hi = n;                                      // first i in [0,n] with skey[i] >= t
+    while (lo < hi) {
+        const long long mid = (lo + hi) >> 1;
+        if (skey[mid] < (unsigned)t) lo = mid + 1; else hi = mid;
     }
+    tileStart[t] = (int)lo;
+}
+
+// pixels keyed by their tile, so that the lanes of a wave walk the same face list
+__global__ __launch_bounds__(256) void k_pix_keys(const float *__restrict__ pix, int P, const Grid2 *__restrict__ gp, unsigned *key,
+                                                  unsigned *val)
+{
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= P) return;
+    const Grid2 g = *gp;
+    const float px = pix[p * 2], py = pix[p * 2 + 1];
+    const bool tame = fabsf(px) <= kBig && fabsf(py) <= kBig;
+    key[p] = tame ? (unsigned)(cell_of(py, g.oy, g.iy, g.gy) * g.gx + cell_of(px, g.ox, g.ix, g.gx)) : kPadKey;
+    val[p] = (unsigned)p;
 }
 
 struct Hit { int f; float z, w1, w2; };
 
-// one lane per pixel: walk the tile list merged with the wide list in ascending face order
+// one lane per pixel (taken in tile order): walk the tile list merged with the wide list in ascending face order
 __global__ __launch_bounds__(256) void k_pix_raster(const float *__restrict__ pix, const float *__restrict__ rng,
                                                     const float *__restrict__ fz, const float *__restrict__ fxy, int P,
                                                     const Grid2 *__restrict__ gp, const int *__restrict__ tileStart,
                                                     const int *__restrict__ list, const int *__restrict__ wide,
                                                     const int *__restrict__ nWide, int F, int knum, float eps, int4 *hits,
-                                                    int *nhit)
+                                                    int *nhit, const unsigned *__restrict__ pixOrder)
 {
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= P) return;
+    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= P) return;
+    const int p = (int)pixOrder[slot];                 // pixels in tile order: a wave shares (mostly) one face list
     const float px = pix[p * 2], py = pix[p * 2 + 1];
     const float zmin = rng[p * 2], zmax = rng[p * 2 + 1];
     const Grid2 g = *gp;
@@ -395,10 +392,12 @@ struct Layout {
     size_t bytes;
     float *part, *fpart;
     Grid2 *grid;
-    int *tileCount, *tileStart, *tileFill, *wide, *nWide, *list, *scratch, *nhit;
+    int *tileStart, *wide, *nWide, *span, *isWide, *pairOff, *wideOff, *nhit;
+    unsigned *pkey, *pval, *skey, *list, *xkey, *xval, *xskey, *pixOrder;
+    long long cap;
     int4 *hits;
-    void *scanTmp;
-    size_t scanTmpBytes;
+    void *tmp;
+    size_t tmpBytes;
 };
 
 static Layout make_layout(int P, int F, int knum, void *ws, size_t wsb)
@@ -409,17 +408,35 @@ static Layout make_layout(int P, int F, int knum, void *ws, size_t wsb)
     L.part = A.take<float>(kBoxBlocks * 4);
     L.fpart = A.take<float>(kBoxBlocks * 2);
     L.grid = A.take<Grid2>(1);
-    L.tileCount = A.take<int>((size_t)L.nTiles + 1);
-    L.tileStart = A.take<int>((size_t)L.nTiles + 1);
-    L.tileFill = A.take<int>((size_t)L.nTiles + 1);
+    L.tileStart = A.take<int>((size_t)L.nTiles + 2);
     L.nWide = A.take<int>(4);
     L.wide = A.take<int>((size_t)F + 1);
-    L.list = A.take<int>((size_t)F * kMaxTiles + 1);
-    L.scratch = A.take<int>((size_t)F * (kMaxTiles + 1) + 2);
+    L.span = A.take<int>((size_t)F + 1);
+    L.isWide = A.take<int>((size_t)F + 1);
+    L.pairOff = A.take<int>((size_t)F + 1);
+    L.wideOff = A.take<int>((size_t)F + 1);
+    L.cap = (long long)F * kMaxTiles + 1;
+    L.pkey = A.take<unsigned>((size_t)L.cap);
+    L.pval = A.take<unsigned>((size_t)L.cap);
+    L.skey = A.take<unsigned>((size_t)L.cap);
+    L.list = A.take<unsigned>((size_t)L.cap);
+    L.xkey = A.take<unsigned>((size_t)P + 1);
+    L.xval = A.take<unsigned>((size_t)P + 1);
+    L.xskey = A.take<unsigned>((size_t)P + 1);
+    L.pixOrder = A.take<unsigned>((size_t)P + 1);
     L.nhit = A.take<int>((size_t)P + 1);
     L.hits = A.take<int4>((size_t)P * knum + 1);
-    L.scanTmpBytes = (size_t)L.nTiles * 8 + (1 << 20);
-    L.scanTmp = A.take<char>(L.scanTmpBytes);
+    {
+        size_t a1 = 0, a2 = 0, a3 = 0;
+        unsigned *u = nullptr;
+        int *ip = nullptr;
+        (void)rocprim::radix_sort_pairs(nullptr, a1, u, u, u, u, (size_t)L.cap, 0, 19, (hipStream_t) nullptr);
+        (void)rocprim::radix_sort_pairs(nullptr, a2, u, u, u, u, (size_t)P + 1, 0, 19, (hipStream_t) nullptr);
+        (void)rocprim::exclusive_scan(nullptr, a3, ip, ip, 0, (size_t)F + 1, rocprim::plus<int>(), (hipStream_t) nullptr);
+        L.tmpBytes = a1 > a2 ? a1 : a2;
+        if (a3 > L.tmpBytes) L.tmpBytes = a3;
+    }
+    L.tmp = A.take<char>(L.tmpBytes);
     L.bytes = align_up(A.off, 256);
     return L;
 }
@@ -452,27 +469,36 @@ extern "C" int deftet_sparse_render_fwd_f32(const float *pix, const float *rng, 
     for (int b = 0; b < B; ++b) {
         const float *pb = pix + (size_t)b * P * 2, *rb = rng + (size_t)b * P * 2;
         const float *zb = fz + (size_t)b * F * 3, *xb = fxy + (size_t)b * F * 6, *fb = feat + (size_t)b * F * 3 * D;
-        DEFTET_HIP(hipMemsetAsync(L.tileCount, 0, ((size_t)L.nTiles + 1) * 4, st));
-        DEFTET_HIP(hipMemsetAsync(L.tileFill, 0, ((size_t)L.nTiles + 1) * 4, st));
-        DEFTET_HIP(hipMemsetAsync(L.nWide, 0, 16, st));
         DEFTET_LAUNCH(k_pix_bbox, dim3(kBoxBlocks), dim3(256), st, pb, P, L.part);
         DEFTET_LAUNCH(k_face_stats, dim3(kBoxBlocks), dim3(256), st, xb, F, L.fpart);
         DEFTET_LAUNCH(k_pix_grid, dim3(1), dim3(64), st, L.part, L.fpart, L.grid);
+        size_t need = L.tmpBytes;
+        hipError_t e;
+#define RAST_RP(call)                                                                              \
+    do {                                                                                           \
+        need = L.tmpBytes;                                                                         \
+        e = (call);                                                                                \
+        if (e != hipSuccess) return set_error(DEFTET_ELAUNCH, "%s: %s", #call, hipGetErrorString(e)); \
+    } while (0)
         if (F > 0) {
-            DEFTET_LAUNCH(k_face_count, dim3((F + 255) / 256), dim3(256), st, xb, F, L.grid, eps, L.tileCount, L.wide, L.nWide);
+            DEFTET_LAUNCH(k_face_span, dim3((F + 255) / 256), dim3(256), st, xb, F, L.grid, eps, L.span, L.isWide);
+            DEFTET_HIP(hipMemsetAsync(L.span + F, 0, 4, st));
+            DEFTET_HIP(hipMemsetAsync(L.isWide + F, 0, 4, st));
+            RAST_RP(rocprim::exclusive_scan(L.tmp, need, L.span, L.pairOff, 0, (size_t)F + 1, rocprim::plus<int>(), st));
+            RAST_RP(rocprim::exclusive_scan(L.tmp, need, L.isWide, L.wideOff, 0, (size_t)F + 1, rocprim::plus<int>(), st));
+            DEFTET_LAUNCH(k_face_pairs, dim3((unsigned)((L.cap + 255) / 256)), dim3(256), st, xb, F, L.grid, eps, L.pairOff, L.wideOff, L.pkey,
+                          L.pval, L.wide, L.nWide, L.cap);
+            RAST_RP(rocprim::radix_sort_pairs(L.tmp, need, L.pkey, L.skey, L.pval, L.list, (size_t)L.cap, 0, 19, st));
+            DEFTET_LAUNCH(k_tile_starts, dim3((L.nTiles + 256) / 256), dim3(256), st, L.skey, L.cap, L.nTiles, L.tileStart);
+        } else {
+            DEFTET_HIP(hipMemsetAsync(L.tileStart, 0, ((size_t)L.nTiles + 2) * 4, st));
+            DEFTET_HIP(hipMemsetAsync(L.nWide, 0, 16, st));
         }
-        size_t need = 0;
-        hipError_t e = rocprim::exclusive_scan(nullptr, need, L.tileCount, L.tileStart, 0, (size_t)L.nTiles + 1, rocprim::plus<int>(), st);
-        if (e != hipSuccess || need > L.scanTmpBytes) return set_error(DEFTET_ELAUNCH, "exclusive_scan temp (%zu bytes)", need);
-        e = rocprim::exclusive_scan(L.scanTmp, need, L.tileCount, L.tileStart, 0, (size_t)L.nTiles + 1, rocprim::plus<int>(), st);
-        if (e != hipSuccess) return set_error(DEFTET_ELAUNCH, "exclusive_scan: %s", hipGetErrorString(e));
-        if (F > 0) {
-            DEFTET_LAUNCH(k_face_fill, dim3((F + 255) / 256), dim3(256), st, xb, F, L.grid, eps, L.tileStart, L.tileFill, L.list);
-            DEFTET_LAUNCH(k_tile_sort, dim3(4096), dim3(256), st, L.list, L.tileStart, L.grid, L.wide, L.nWide, L.scratch,
-                          (long long)F * kMaxTiles + 1);
-        }
-        DEFTET_LAUNCH(k_pix_raster, dim3((P + 255) / 256), dim3(256), st, pb, rb, zb, xb, P, L.grid, L.tileStart, L.list,
-                      L.wide, L.nWide, F, knum, eps, L.hits, L.nhit);
+        DEFTET_LAUNCH(k_pix_keys, dim3((P + 255) / 256), dim3(256), st, pb, P, L.grid, L.xkey, L.xval);
+        RAST_RP(rocprim::radix_sort_pairs(L.tmp, need, L.xkey, L.xskey, L.xval, L.pixOrder, (size_t)P, 0, 19, st));
+#undef RAST_RP
+        DEFTET_LAUNCH(k_pix_raster, dim3((P + 255) / 256), dim3(256), st, pb, rb, zb, xb, P, L.grid, L.tileStart, (const int *)L.list,
+                      L.wide, L.nWide, F, knum, eps, L.hits, L.nhit, (const unsigned *)L.pixOrder);
         DEFTET_LAUNCH(k_pix_emit, dim3((P + 3) / 4), dim3(256), st, L.hits, L.nhit, fb, P, D, knum,
                       out_feat + (size_t)b * P * knum * D, (long long *)out_face + (size_t)b * P * knum, out_w + (size_t)b * P * knum * 3);
     }
