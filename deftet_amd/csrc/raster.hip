@@ -228,62 +228,140 @@ __global__ __launch_bounds__(256) void k_pix_keys(const float *__restrict__ pix,
     const Grid2 g = *gp;
     const float px = pix[p * 2], py = pix[p * 2 + 1];
     const bool tame = fabsf(px) <= kBig && fabsf(py) <= kBig;
-    key[p] = tame ? (unsigned)(cell_of(py, g.oy, g.iy, g.gy) * g.gx + cell_of(px, g.ox, g.ix, g.gx)) : kPadKey;
+    unsigned k = kPadKey * 4u;
+    if (tame) {
+        const int tx = cell_of(px, g.ox, g.ix, g.gx), ty = cell_of(py, g.oy, g.iy, g.gy);
+        // two more key bits: the quadrant of the tile, so that 64 consecutive pixels form a compact patch
+        const float fx = (px - g.ox) * g.ix - (float)tx, fy = (py - g.oy) * g.iy - (float)ty;
+        k = (unsigned)(ty * g.gx + tx) * 4u + (fy >= 0.5f ? 2u : 0u) + (fx >= 0.5f ? 1u : 0u);
+    }
+    key[p] = k;
     val[p] = (unsigned)p;
+}
+
+// pixStart[t] = first tile-sorted pixel slot whose key is >= t (t in [0, nTilesCap + 1]; the key
+// nTilesCap = kPadKey collects the NaN/Inf/huge pixels), and the number of 64-pixel chunks of tile t
+__global__ __launch_bounds__(256) void k_pix_chunks(const unsigned *__restrict__ xskey, int P, int nTilesCap, int *pixStart,
+                                                    int *chunkCount)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t > nTilesCap + 1) return;
+    auto lower = [&](unsigned k) {
+        int lo = 0, hi = P;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (xskey[mid] < k) lo = mid + 1; else hi = mid;
+        }
+        return lo;
+    };
+    const int s0 = lower((unsigned)t * 4u);                       // keys carry two quadrant bits below the tile id
+    pixStart[t] = s0;
+    if (t <= nTilesCap) chunkCount[t] = (lower(((unsigned)t + 1u) * 4u) - s0 + 63) >> 6;
+    else chunkCount[t] = 0;
 }
 
 struct Hit { int f; float z, w1, w2; };
 
-// one lane per pixel (taken in tile order): walk the tile list merged with the wide list in ascending face order
+// One wave per 64 pixels OF ONE TILE: the face list is then the same for every lane, so the wave
+// loads 64 list entries and their 36 bytes of face data with one coalesced round trip (lane k holds
+// face k) and broadcasts them one after the other with v_readlane — the per-lane formulation spent
+// two dependent gather latencies on every candidate (1.5 ms at configs[4], lists of ~1,700 faces).
+// Faces are visited in ascending index (tile list merged with the wide list), every lane keeps its
+// first `knum` hits, the wave stops when all its lanes are full.  The chunk of NaN/Inf/huge pixels
+// (pseudo-tile nTilesCap) visits every face.
+__device__ __forceinline__ float bcast(float v, int k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k)); }
+
 __global__ __launch_bounds__(256) void k_pix_raster(const float *__restrict__ pix, const float *__restrict__ rng,
                                                     const float *__restrict__ fz, const float *__restrict__ fxy, int P,
-                                                    const Grid2 *__restrict__ gp, const int *__restrict__ tileStart,
+                                                    int nTilesCap, const int *__restrict__ tileStart,
                                                     const int *__restrict__ list, const int *__restrict__ wide,
                                                     const int *__restrict__ nWide, int F, int knum, float eps, int4 *hits,
-                                                    int *nhit, const unsigned *__restrict__ pixOrder)
+                                                    int *nhit, const unsigned *__restrict__ pixOrder,
+                                                    const int *__restrict__ pixStart, const int *__restrict__ chunkStart)
 {
-    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
-    if (slot >= P) return;
-    const int p = (int)pixOrder[slot];                 // pixels in tile order: a wave shares (mostly) one face list
+    const int lane = threadIdx.x & 63;
+    const int W = blockIdx.x * 4 + (threadIdx.x >> 6);              // chunk id (wave-uniform)
+    if (W >= chunkStart[nTilesCap + 1]) return;
+    int lo = 0, hi = nTilesCap + 1;                                 // largest tile with chunkStart[tile] <= W
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (chunkStart[mid] <= W) lo = mid; else hi = mid;
+    }
+    const int tile = lo;
+    const int slot = pixStart[tile] + (W - chunkStart[tile]) * 64 + lane;
+    const bool live = slot < pixStart[tile + 1];
+    const int p = live ? (int)pixOrder[slot] : 0;
     const float px = pix[p * 2], py = pix[p * 2 + 1];
     const float zmin = rng[p * 2], zmax = rng[p * 2 + 1];
-    const Grid2 g = *gp;
-    const bool tame = fabsf(px) <= kBig && fabsf(py) <= kBig;
-    int i = 0, ie = 0;
-    if (tame) {
-        const int t = cell_of(py, g.oy, g.iy, g.gy) * g.gx + cell_of(px, g.ox, g.ix, g.gx);
-        i = tileStart[t];
-        ie = tileStart[t + 1];
-    }
-    int j = 0;
-    const int je = tame ? *nWide : 0;
-    // a pixel that is NaN/Inf/huge falls outside every certified box: it scans all faces
-    int all = tame ? F : 0;
-    int nh = 0;
+    int nh = live ? 0 : knum;                                       // dead lanes count as full
     int4 *out = hits + (size_t)p * knum;
-    while (nh < knum) {
-        int f;
-        if (!tame) {
-            if (all >= F) break;
-            f = all++;
-        } else {
-            const int fi = i < ie ? list[i] : 0x7FFFFFFF, fj = j < je ? wide[j] : 0x7FFFFFFF;
-            if (fi == 0x7FFFFFFF && fj == 0x7FFFFFFF) break;
-            if (fi < fj) { f = fi; ++i; } else { f = fj; ++j; }
-        }
-        const float2 a = reinterpret_cast<const float2 *>(fxy)[f * 3], b = reinterpret_cast<const float2 *>(fxy)[f * 3 + 1],
-                     c = reinterpret_cast<const float2 *>(fxy)[f * 3 + 2];
-        const float m = b.x - a.x, pp = b.y - a.y, n = c.x - a.x, q = c.y - a.y, s = px - a.x, t = py - a.y;
-        const float k1 = s * q - n * t, k2 = m * t - s * pp, k3 = m * q - n * pp;
+    auto test = [&](int f, float ax, float ay, float bx, float by, float cx, float cy, float az, float bz, float cz) {
+        if (nh >= knum) return;
+        const float m = bx - ax, pp = by - ay, n = cx - ax, q = cy - ay, s_ = px - ax, t = py - ay;
+        const float k1 = s_ * q - n * t, k2 = m * t - s_ * pp, k3 = m * q - n * pp;
         const float den = k3 + eps;
         const float w1 = k1 / den, w2 = k2 / den, w0 = 1 - w1 - w2;
-        if (!(w0 >= 0 && w1 >= 0 && w2 >= 0)) continue;
-        const float z = (w0 * fz[f * 3] + w1 * fz[f * 3 + 1]) + w2 * fz[f * 3 + 2];
-        if (!(z >= zmin && z <= zmax)) continue;
+        if (!(w0 >= 0 && w1 >= 0 && w2 >= 0)) return;
+        const float z = (w0 * az + w1 * bz) + w2 * cz;
+        if (!(z >= zmin && z <= zmax)) return;
         out[nh] = make_int4(f, __float_as_int(z), __float_as_int(w1), __float_as_int(w2));
         ++nh;
+    };
+    const bool allFaces = tile == nTilesCap;                        // the non-tame pixels: every face, no lists
+    const int ib = allFaces ? 0 : tileStart[tile], ie = allFaces ? F : tileStart[tile + 1];
+    int j = 0;
+    const int je = allFaces ? 0 : *nWide;
+    auto wide_before = [&](int fLimit) {                            // wide faces with index < fLimit (normally none)
+        while (j < je) {
+            const int f = wide[j];
+            if (f >= fLimit) break;
+            const float2 a = reinterpret_cast<const float2 *>(fxy)[f * 3], b = reinterpret_cast<const float2 *>(fxy)[f * 3 + 1],
+                         c = reinterpret_cast<const float2 *>(fxy)[f * 3 + 2];
+            test(f, a.x, a.y, b.x, b.y, c.x, c.y, fz[f * 3], fz[f * 3 + 1], fz[f * 3 + 2]);
+            ++j;
+        }
+    };
+    // image-space box of this wave's pixels: a listed (regular) face whose enlarged box misses it
+    // cannot be accepted by any lane (the certified-box argument of face_box) and is skipped
+    float cxl = live ? px : INFINITY, cxh = live ? px : -INFINITY, cyl = live ? py : INFINITY, cyh = live ? py : -INFINITY;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        cxl = fminf(cxl, __shfl_xor(cxl, off)); cxh = fmaxf(cxh, __shfl_xor(cxh, off));
+        cyl = fminf(cyl, __shfl_xor(cyl, off)); cyh = fmaxf(cyh, __shfl_xor(cyh, off));
     }
-    nhit[p] = nh;
+    for (int base = ib; base < ie; base += 64) {
+        if (__all(nh >= knum)) break;
+        const int idx = base + lane;
+        const bool have = idx < ie;
+        const int fm = have ? (allFaces ? idx : list[idx]) : 0;
+        float2 a = make_float2(0.f, 0.f), b = a, c = a;
+        float az = 0.f, bz = 0.f, cz = 0.f;
+        bool cand = have;
+        if (have) {
+            a = reinterpret_cast<const float2 *>(fxy)[fm * 3]; b = reinterpret_cast<const float2 *>(fxy)[fm * 3 + 1];
+            c = reinterpret_cast<const float2 *>(fxy)[fm * 3 + 2];
+            az = fz[fm * 3]; bz = fz[fm * 3 + 1]; cz = fz[fm * 3 + 2];
+            if (!allFaces) {                                        // same enlarged box as face_box()
+                const float lox = fminf(a.x, fminf(b.x, c.x)), hix = fmaxf(a.x, fmaxf(b.x, c.x));
+                const float loy = fminf(a.y, fminf(b.y, c.y)), hiy = fmaxf(a.y, fmaxf(b.y, c.y));
+                const float mg = fmaxf(hix - lox, hiy - loy) * kMargin;
+                cand = !(hix + mg < cxl || lox - mg > cxh || hiy + mg < cyl || loy - mg > cyh);
+            }
+        }
+        unsigned long long todo = __ballot(cand);
+        int since = 0;
+        while (todo) {
+            const int k = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const int f = __builtin_amdgcn_readlane(fm, k);
+            if (je > 0) wide_before(f);
+            test(f, bcast(a.x, k), bcast(a.y, k), bcast(b.x, k), bcast(b.y, k), bcast(c.x, k), bcast(c.y, k), bcast(az, k), bcast(bz, k),
+                 bcast(cz, k));
+            if ((++since & 7) == 0 && __all(nh >= knum)) break;
+        }
+    }
+    if (je > 0) wide_before(0x7FFFFFFF);
+    if (live) nhit[p] = nh;
 }
 
 // one wave per pixel: rank by (z descending, face ascending), write the sorted outputs
@@ -394,6 +472,7 @@ struct Layout {
     Grid2 *grid;
     int *tileStart, *wide, *nWide, *span, *isWide, *pairOff, *wideOff, *nhit;
     unsigned *pkey, *pval, *skey, *list, *xkey, *xval, *xskey, *pixOrder;
+    int *pixStart, *chunkCount, *chunkStart;
     long long cap;
     int4 *hits;
     void *tmp;
@@ -424,6 +503,9 @@ static Layout make_layout(int P, int F, int knum, void *ws, size_t wsb)
     L.xval = A.take<unsigned>((size_t)P + 1);
     L.xskey = A.take<unsigned>((size_t)P + 1);
     L.pixOrder = A.take<unsigned>((size_t)P + 1);
+    L.pixStart = A.take<int>((size_t)L.nTiles + 3);
+    L.chunkCount = A.take<int>((size_t)L.nTiles + 3);
+    L.chunkStart = A.take<int>((size_t)L.nTiles + 3);
     L.nhit = A.take<int>((size_t)P + 1);
     L.hits = A.take<int4>((size_t)P * knum + 1);
     {
@@ -431,8 +513,8 @@ static Layout make_layout(int P, int F, int knum, void *ws, size_t wsb)
         unsigned *u = nullptr;
         int *ip = nullptr;
         (void)rocprim::radix_sort_pairs(nullptr, a1, u, u, u, u, (size_t)L.cap, 0, 19, (hipStream_t) nullptr);
-        (void)rocprim::radix_sort_pairs(nullptr, a2, u, u, u, u, (size_t)P + 1, 0, 19, (hipStream_t) nullptr);
-        (void)rocprim::exclusive_scan(nullptr, a3, ip, ip, 0, (size_t)F + 1, rocprim::plus<int>(), (hipStream_t) nullptr);
+        (void)rocprim::radix_sort_pairs(nullptr, a2, u, u, u, u, (size_t)P + 1, 0, 21, (hipStream_t) nullptr);
+        (void)rocprim::exclusive_scan(nullptr, a3, ip, ip, 0, (size_t)(F > L.nTiles ? F : L.nTiles) + 3, rocprim::plus<int>(), (hipStream_t) nullptr);
         L.tmpBytes = a1 > a2 ? a1 : a2;
         if (a3 > L.tmpBytes) L.tmpBytes = a3;
     }
@@ -495,10 +577,19 @@ extern "C" int deftet_sparse_render_fwd_f32(const float *pix, const float *rng, 
             DEFTET_HIP(hipMemsetAsync(L.nWide, 0, 16, st));
         }
         DEFTET_LAUNCH(k_pix_keys, dim3((P + 255) / 256), dim3(256), st, pb, P, L.grid, L.xkey, L.xval);
-        RAST_RP(rocprim::radix_sort_pairs(L.tmp, need, L.xkey, L.xskey, L.xval, L.pixOrder, (size_t)P, 0, 19, st));
+        RAST_RP(rocprim::radix_sort_pairs(L.tmp, need, L.xkey, L.xskey, L.xval, L.pixOrder, (size_t)P, 0, 21, st));
 #undef RAST_RP
-        DEFTET_LAUNCH(k_pix_raster, dim3((P + 255) / 256), dim3(256), st, pb, rb, zb, xb, P, L.grid, L.tileStart, (const int *)L.list,
-                      L.wide, L.nWide, F, knum, eps, L.hits, L.nhit, (const unsigned *)L.pixOrder);
+        DEFTET_LAUNCH(k_pix_chunks, dim3((L.nTiles + 2 + 255) / 256), dim3(256), st, (const unsigned *)L.xskey, P, L.nTiles, L.pixStart,
+                      L.chunkCount);
+        need = L.tmpBytes;
+        e = rocprim::exclusive_scan(L.tmp, need, L.chunkCount, L.chunkStart, 0, (size_t)L.nTiles + 2, rocprim::plus<int>(), st);
+        if (e != hipSuccess) return set_error(DEFTET_ELAUNCH, "rocprim::exclusive_scan: %s", hipGetErrorString(e));
+        {
+            const long long maxChunks = (long long)(P + 63) / 64 + L.nTiles + 1;     // every tile may end with a partial chunk
+            DEFTET_LAUNCH(k_pix_raster, dim3((unsigned)((maxChunks + 3) / 4)), dim3(256), st, pb, rb, zb, xb, P, L.nTiles, L.tileStart,
+                          (const int *)L.list, L.wide, L.nWide, F, knum, eps, L.hits, L.nhit, (const unsigned *)L.pixOrder,
+                          (const int *)L.pixStart, (const int *)L.chunkStart);
+        }
         DEFTET_LAUNCH(k_pix_emit, dim3((P + 3) / 4), dim3(256), st, L.hits, L.nhit, fb, P, D, knum,
                       out_feat + (size_t)b * P * knum * D, (long long *)out_face + (size_t)b * P * knum, out_w + (size_t)b * P * knum * 3);
     }
