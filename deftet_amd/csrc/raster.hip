@@ -369,7 +369,8 @@ __global__ __launch_bounds__(256) void k_pix_emit(const int4 *__restrict__ hits,
                                                   const float *__restrict__ feat, int P, int D, int knum, float *out_feat,
                                                   long long *out_face, float *out_w)
 {
-    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // wave-uniform pixel: the inner-loop reads of hits[j] then go through the scalar cache
+    const int p = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
     if (p >= P) return;
     const int n = nhit[p];
@@ -380,7 +381,7 @@ __global__ __launch_bounds__(256) void k_pix_emit(const int4 *__restrict__ hits,
             const float zi = __int_as_float(me.y);
             int r = 0;
             for (int j = 0; j < n; ++j) {
-                const int4 o = h[j];
+                const int2 o = *reinterpret_cast<const int2 *>(h + j);   // (face, z): wave-uniform address, one scalar-width load
                 const float zj = __int_as_float(o.y);
                 r += (zj > zi || (zj == zi && o.x < me.x)) ? 1 : 0;
             }
