@@ -14,11 +14,12 @@
 //
 // MI355X design (the brute-force formulation is pixels x faces = 1.4e11 tests at 512x512 over a
 // res-70 grid): pixels define a uniform 2-D tile grid; faces are binned into the tiles their
-// (slightly enlarged) image-space box overlaps, each tile list is sorted by face index, and a
-// pixel only walks its own tile's list (merged with a short list of "wide" faces — degenerate,
-// non-finite or spanning more than kMaxTiles tiles — which every pixel tests).  The backward is
-// atomic-free: hits are threaded into per-face linked lists and one lane per face accumulates
-// its gradients in registers.
+// (slightly enlarged) image-space box overlaps by one stable radix sort (lists come out ascending
+// in face index), pixels are sorted by tile, and one wave rasterises 64 pixels of one tile against
+// that tile's list with cooperative loads and lane broadcasts (merged with a short list of "wide"
+// faces — degenerate, non-finite or spanning more than kMaxTiles tiles — which every pixel tests).
+// The backward is atomic-free: hits are threaded into per-face linked lists and one lane per face
+// accumulates its gradients in registers.
 #pragma clang fp contract(off)
 #include <cstring>
 
