@@ -784,14 +784,33 @@ __global__ __launch_bounds__(256) void k_tri_face_bin(const float *__restrict__ 
             }
 }
 
+// Points keyed by their (clamped) grid cell: after one radix sort the 64 lanes of a wave are
+// neighbours in space, walk (nearly) the same cells and fetch the same face records — the GT point
+// cloud itself comes in arbitrary order.
+__global__ __launch_bounds__(256) void k_tri_point_keys(const float *__restrict__ pts, int P, const TGrid *__restrict__ gp, unsigned *key)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= P) return;
+    const TGrid g = *gp;
+    int c[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float f = floorf((pts[q * 3 + k] - g.o[k]) * g.inv[k]);
+        f = fminf(fmaxf(f, 0.f), (float)(g.g[k] - 1));               // NaN -> 0
+        c[k] = (int)f;
+    }
+    key[q] = (unsigned)((c[2] * kTGMax + c[1]) * kTGMax + c[0]);       // 18 bits
+}
+
 __global__ __launch_bounds__(256) void k_tri_query(const float *__restrict__ pts, const float *__restrict__ face,
                                                    const float *__restrict__ nfb, int P, const TGrid *__restrict__ gp,
                                                    const int *__restrict__ cellStart, const int *__restrict__ list,
                                                    const int *__restrict__ wide, const int *__restrict__ nWide, float *closest_d,
-                                                   float *closest_f, int *farList, int *nFar)
+                                                   float *closest_f, int *farList, int *nFar, const unsigned *__restrict__ order)
 {
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= P) return;
+    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= P) return;
+    const int q = (int)order[slot];                                  // points in cell order (k_tri_point_keys)
     const TGrid g = *gp;
     const float p[3] = {pts[q * 3], pts[q * 3 + 1], pts[q * 3 + 2]};
     float min_d = 10000.0f;                                         // for.cu:277
@@ -1141,7 +1160,7 @@ extern "C" size_t deftet_tri_dist_workspace_bytes(int B, int P, int Fmax)
 {
     const size_t nc = (size_t)kTGMax * kTGMax * kTGMax + 1;
     const size_t F = (size_t)(Fmax > 0 ? Fmax : 0), Pn = (size_t)(P > 0 ? P : 0);
-    return nc * 4 * 3 + F * kTMaxCells * 4 + F * 4 + Pn * 4 + nc * 8 + ((size_t)2 << 20);
+    return nc * 4 * 3 + F * kTMaxCells * 4 + F * 4 + Pn * 4 + Pn * 12 + Pn * 16 + nc * 8 + ((size_t)2 << 20);
 }
 
 // workspace == NULL: the scalar-stream brute force; otherwise the grid search (both exact).
@@ -1167,6 +1186,7 @@ extern "C" int deftet_tri_dist_fwd_f32(const float *pts, const float *face, cons
     int *cnt = A.take<int>(nc), *start = A.take<int>(nc), *fill = A.take<int>(nc);
     int *list = A.take<int>((size_t)Fmax * kTMaxCells + 1), *wide = A.take<int>((size_t)Fmax + 1);
     int *farList = A.take<int>((size_t)P + 1), *counters = A.take<int>(8);
+    unsigned *pkey = A.take<unsigned>((size_t)P + 1), *pskey = A.take<unsigned>((size_t)P + 1), *order = A.take<unsigned>((size_t)P + 1);
     void *tmp = A.base + align_up(A.off, 256);
     const size_t left = wsb - align_up(A.off, 256);
     for (int b = 0; b < B; ++b) {
@@ -1183,8 +1203,14 @@ extern "C" int deftet_tri_dist_fwd_f32(const float *pts, const float *face, cons
         e = rocprim::exclusive_scan(tmp, need, cnt, start, 0, nc, rocprim::plus<int>(), st);
         if (e != hipSuccess) return set_error(DEFTET_ELAUNCH, "exclusive_scan: %s", hipGetErrorString(e));
         DEFTET_LAUNCH(k_tri_face_bin, dim3((Fmax + 255) / 256), dim3(256), st, fb, nb, grid, 1, cnt, start, fill, list, wide, counters);
+        DEFTET_LAUNCH(k_tri_point_keys, dim3((P + 255) / 256), dim3(256), st, pb, P, grid, pkey);
+        need = 0;
+        e = rocprim::radix_sort_pairs(nullptr, need, pkey, pskey, rocprim::counting_iterator<unsigned>(0), order, (size_t)P, 0, 18, st);
+        if (e != hipSuccess || need > left) return set_error(DEFTET_ELAUNCH, "radix_sort temp");
+        e = rocprim::radix_sort_pairs(tmp, need, pkey, pskey, rocprim::counting_iterator<unsigned>(0), order, (size_t)P, 0, 18, st);
+        if (e != hipSuccess) return set_error(DEFTET_ELAUNCH, "radix_sort_pairs: %s", hipGetErrorString(e));
         DEFTET_LAUNCH(k_tri_query, dim3((P + 255) / 256), dim3(256), st, pb, fb, nb, P, grid, start, list, wide, counters,
-                      closest_d + (size_t)b * P, closest_f + (size_t)b * P, farList, counters + 1);
+                      closest_d + (size_t)b * P, closest_f + (size_t)b * P, farList, counters + 1, (const unsigned *)order);
         DEFTET_LAUNCH(k_tri_far, dim3((P + 255) / 256), dim3(256), st, pb, fb, nb, farList, counters + 1,
                       closest_d + (size_t)b * P, closest_f + (size_t)b * P);
     }
