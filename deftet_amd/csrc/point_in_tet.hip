@@ -512,18 +512,12 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan(const float *__rest
         if (q.x >= elo[0] && q.x <= ehi[0] && q.y >= elo[1] && q.y <= ehi[1] && q.z >= elo[2] && q.z <= ehi[2]) {
             if (accept(P, q.x, q.y, q.z)) {
                 const int qi = __float_as_int(q.w);
-#if defined(PIT_EXP_PLAIN_STORE)      // timing experiments only (wrong results on ties)
-                res[qi] = t;
-#elif defined(PIT_EXP_NO_STORE)
-                asm volatile("" ::"v"(t), "v"(qi));
-#else
                 atomicMin(&res[qi], t);
                 if (hcnt == 0) hrec.x = qi;
                 else if (hcnt == 1) hrec.y = qi;
                 else if (hcnt == 2) hrec.z = qi;
                 else if (hcnt == 3) hrec.w = qi;
                 ++hcnt;
-#endif
             }
         }
     };
@@ -655,11 +649,7 @@ __global__ __launch_bounds__(256, PIT_STAGE_WAVES) void k_tet_scan_staged(const 
     float elo[3], ehi[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) { elo[k] = lo[k] - m; ehi[k] = hi[k] + m; }
-#ifdef PIT_EXP_NOTRAV            // timing experiment: load + classify + record only
-    const bool active = false &&
-#else
     const bool active = intet && regular &&
-#endif
                         !(ehi[0] < g.lo[0] || elo[0] > g.hi[0] || ehi[1] < g.lo[1] || elo[1] > g.hi[1] || ehi[2] < g.lo[2] || elo[2] > g.hi[2]);
     const int cx0 = cell_of(elo[0], g.o[0], g.inv[0], Gx), cx1 = cell_of(ehi[0], g.o[0], g.inv[0], Gx);
     const int cy0 = cell_of(elo[1], g.o[1], g.inv[1], G), cy1 = cell_of(ehi[1], g.o[1], g.inv[1], G);
