@@ -314,7 +314,19 @@ __global__ __launch_bounds__(256) void k_nn_far(const float *__restrict__ querie
     const float qx = queries[q * 3], qy = queries[q * 3 + 1], qz = queries[q * 3 + 2];
     float best = 1e20f;
     int besti = 0;
-    for (int j = 0; j < M; ++j) {
+    int j = 0;
+    for (; j + 4 <= M; j += 4) {                                    // 12 floats per scalar-load batch, like k_nn
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float dx = points[(j + k) * 3] - qx, dy = points[(j + k) * 3 + 1] - qy, dz = points[(j + k) * 3 + 2] - qz;
+            float d = 0.f;
+            d += dx * dx;
+            d += dy * dy;
+            d += dz * dz;
+            if (d < best) { best = d; besti = j + k; }
+        }
+    }
+    for (; j < M; ++j) {
         const float dx = points[j * 3] - qx, dy = points[j * 3 + 1] - qy, dz = points[j * 3 + 2] - qz;   // wave-uniform -> s_load
         float d = 0.f;
         d += dx * dx;
