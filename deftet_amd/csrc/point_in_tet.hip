@@ -1320,7 +1320,14 @@ __global__ __launch_bounds__(256) void k_bary_bwd_hits(const float *__restrict__
     if (h.x >= 0 && h.w != kHitOverflow) {                         // slots fill in order: x < 0 means no accepted query
         TetGrad g;
         tet_grad_setup(tet, (size_t)b * T + t, g);
-        const int hq[4] = {h.x, h.y, h.z, h.w};
+        // the record lists the accepted queries in traversal order, which depends on the (arbitrary)
+        // order of queries inside a grid cell: sort the four ids so that the fp32 sums below are
+        // added in the same order on every run (empty slots, -1, go last)
+        unsigned hu[4] = {(unsigned)h.x, (unsigned)h.y, (unsigned)h.z, (unsigned)h.w};
+#define DEFTET_CSWAP(a, b) { const unsigned lo_ = min(hu[a], hu[b]), hi_ = max(hu[a], hu[b]); hu[a] = lo_; hu[b] = hi_; }
+        DEFTET_CSWAP(0, 1) DEFTET_CSWAP(2, 3) DEFTET_CSWAP(0, 2) DEFTET_CSWAP(1, 3) DEFTET_CSWAP(1, 2)
+#undef DEFTET_CSWAP
+        const int hq[4] = {(int)hu[0], (int)hu[1], (int)hu[2], (int)hu[3]};
         const float tf = (float)t;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
