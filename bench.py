@@ -52,6 +52,9 @@ ALGO = int(os.environ.get("DEFTET_BENCH_ALGO", "0"))      # A/B switch for the t
 DOMINANT = {0: b"k_tet_scan", 2: b"k_tet_scan_staged", 3: b"k_tet_scan_rows"}.get(ALGO, b"k_tet_scan")
 
 
+GATHER = None                    # sharding.LossGather(), created in main() once the process group exists
+
+
 def step(d, world):
     """fwd: index + weights + fused paste_occ gather (+ per-tet hit records); bwd: dL/dtet and
     dL/dpred from one per-tet pass over those records (no atomics); then the per-shape loss
@@ -61,10 +64,12 @@ def step(d, world):
     g_tet, _, g_pred = hip_ops.point_in_tet_bwd(d["tet"], d["pts"], cond, d["gw"], grad_occ=d["gout"], hits=hits)
     loss = hip_ops.rowdot(w, d["gw"], occ, d["gout"])         # [B] per-shape loss scalars
     if world > 1:
+        # the only collective (RCCL over xGMI): enqueued asynchronously, consumed one step later, so
+        # the next step's kernels do not wait for it; main() flushes the last one inside the timed region
         if torch.distributed.get_backend() == "gloo":                         # single-GPU test hook: stage through the host
-            loss = sharding.all_gather_losses(loss.cpu(), world * loss.shape[0]).to(w.device)
+            loss = GATHER.submit(loss.cpu())
         else:
-            loss = sharding.all_gather_losses(loss, world * loss.shape[0])    # the only collective (RCCL over xGMI)
+            loss = GATHER.submit(loss)
     return cond, w, g_tet, g_pred, loss
 
 
@@ -129,8 +134,13 @@ def main():
     host, d = make_inputs(rank, device)
     B, T, Q = d["tet"].shape[0], d["tet"].shape[1], d["pts"].shape[1]
 
+    global GATHER
+    from deftet_amd import sharding
+    GATHER = sharding.LossGather()
     for _ in range(args.warmup):
         step(d, world)
+    if world > 1:
+        GATHER.flush()
     torch.cuda.synchronize()
 
     dominant = DOMINANT
@@ -141,6 +151,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step(d, world)
+    if world > 1:
+        GATHER.flush()                                   # the last step's all-gather belongs to the timed region
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()

@@ -52,3 +52,36 @@ def all_gather_losses(local_losses: torch.Tensor, n_items: int | None = None, gr
     out = x.new_empty((world * m,) + tuple(x.shape[1:]))
     dist.all_gather_into_tensor(out, pad, group=group)
     return torch.cat([out[r * m: r * m + sizes[r]] for r in range(world)], 0)
+
+
+class LossGather:
+    """The all-gather of the per-shape losses, taken OFF the critical path: `submit` enqueues the
+    collective with async_op=True (RCCL runs it on its own stream once the producer kernels have
+    finished) and returns the PREVIOUS step's gathered losses, so the next step's kernels never wait
+    for the exchange; `flush` waits for the outstanding one.  Equal shard sizes only (the bench /
+    training batch layout); ragged shards use all_gather_losses."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self._work = None
+        self._out = None
+
+    def submit(self, local_losses: torch.Tensor):
+        prev = self.flush()
+        if not (dist.is_available() and dist.is_initialized()):
+            self._out = local_losses
+            return prev
+        x = local_losses.contiguous()
+        world = dist.get_world_size(self.group)
+        self._out = x.new_empty((world * x.shape[0],) + tuple(x.shape[1:]))
+        self._keep = x                                   # keep the input alive until the collective has run
+        self._work = dist.all_gather_into_tensor(self._out, x, group=self.group, async_op=True)
+        return prev
+
+    def flush(self):
+        """Wait for the outstanding collective (if any) and return its result (None if none)."""
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        out, self._out = self._out, None
+        return out

@@ -126,6 +126,48 @@ def test_all_gather_losses_gloo_world2(n_items):
     assert np.array_equal(got[0], want) and np.array_equal(got[1], want)
 
 
+def _worker_pipelined(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = sharding.LossGather()
+        outs = []
+        for step in range(4):                                       # submit returns the PREVIOUS step's result
+            local = torch.full((3,), float(10 * step + rank))
+            outs.append(g.submit(local))
+        outs.append(g.flush())
+        assert g.flush() is None
+        q.put((rank, [None if o is None else o.numpy() for o in outs]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_loss_gather_pipelined_gloo_world2():
+    """the asynchronous all-gather bench.py uses for N > 1: results arrive one step late, in order"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_pipelined, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(2):
+        outs = got[r]
+        assert outs[0] is None and len(outs) == 5
+        for step in range(4):
+            want = np.concatenate([np.full(3, 10.0 * step + k, np.float32) for k in range(2)])
+            assert np.array_equal(outs[step + 1], want)
+    # without a process group the class degrades to a one-step delay line
+    g = sharding.LossGather()
+    assert g.submit(torch.ones(2)) is None and torch.equal(g.submit(torch.zeros(2)), torch.ones(2))
+
+
 def test_read_tetrahedron_mirror(tmp_path):
     """N4: .tet text format + the boundary snapping rule of utils/dataloder_helper.py:30-69."""
     from deftet_amd.utils.dataloder_helper import read_tetrahedron, tet_file_name
