@@ -182,6 +182,32 @@ def main():
          cpu_cores=os.cpu_count(), nominal_ray_face_tests_per_s=round(Bc * cen.shape[1] * faces.shape[0] / tg / 1e12, 2),
          unit="T ray-face tests/s", parity="unpinned (Kaolin not in the reference tree)")
 
+    # ---- A11: fused per-tet energies (layers/DefTet/deftet.py:239-338) vs the same expressions as torch ops (fp32, same GPU)
+    Be = 2 if quick else 8
+    tete = torch.from_numpy(grids.gather_tets(grids.jittered_positions(verts, res, Be), tets)).to(dev).requires_grad_(True)
+    rest = torch.from_numpy((verts - 0.5).astype(np.float32)).to(dev)[tets_d.long()] * 20
+    inv = torch.inverse(torch.stack([rest[:, 1] - rest[:, 0], rest[:, 2] - rest[:, 0], rest[:, 3] - rest[:, 0]], 1))
+    gsel = torch.ones(Be, 3, device=dev)
+
+    def fused():
+        out = hip_ops.tet_energies(tete, inv, 4, 4, 20.0)
+        return torch.autograd.grad((out * gsel).sum(), tete)
+
+    def torch_ref():
+        A, Bv, C, Dd = (tete[:, :, i] for i in range(4))
+        V = -(torch.cross(Bv - Dd, C - Dd, dim=-1) * (A - Dd)).sum(-1) / 6
+        vv = ((V - V.mean(-1, keepdim=True)) ** 4).sum(-1)
+        off = torch.stack([Bv * 20 - A * 20, C * 20 - A * 20, Dd * 20 - A * 20], 2)
+        J = off @ inv[None]
+        det = (J[..., 0, :] * torch.cross(J[..., 1, :], J[..., 2, :], dim=-1)).sum(-1)
+        am = ((J ** 2).sum((-1, -2)) * (det ** 2 + 1e-10) ** (-1.0 / 3.0) * (det >= 0)).mean(-1)
+        el = sum((((p - q) * 20.0) ** 4).sum(-1).sum(-1) for p, q in ((A, Dd), (Bv, Dd), (C, Dd), (A, Bv), (A, C), (Bv, C))) / (6 * T)
+        return torch.autograd.grad((torch.stack([vv, am, el], -1) * gsel).sum(), tete)
+
+    tf_, tt_ = gpu_time(fused, reps=10), gpu_time(torch_ref, reps=5)
+    emit(op="tet_energies fwd+bwd", res=res, batch=Be, n_tet=T, gpu_ms=round(tf_ * 1e3, 3), torch_same_gpu_ms=round(tt_ * 1e3, 3),
+         speedup_vs_torch=round(tt_ / tf_, 1), algorithmic_mb=round(Be * T * 96 / 1e6, 1))
+
 
 if __name__ == "__main__":
     main()
