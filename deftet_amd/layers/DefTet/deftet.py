@@ -71,10 +71,15 @@ class DefTet(nn.Module):
     def check_tet_inside_sdfs(self, tet_bxfx4x3, mesh_list):
         verts, faces = mesh_list[0], mesh_list[1]
         with torch.no_grad():
+            center = torch.mean(tet_bxfx4x3, dim=2)                     # [B,T,3], same reduction as per shape
+            same_mesh = all(f[0] is faces[0][0] for f in faces) and all(v.shape == verts[0].shape for v in verts)
+            if same_mesh and len(verts) == tet_bxfx4x3.shape[0]:
+                # one launch sequence for the whole batch (faces shared, per-shape vertices)
+                v = torch.cat([x.reshape(1, -1, 3) for x in verts], dim=0)
+                return hip_ops.check_sign(v, faces[0][0], center, check=False).unsqueeze(-1).float()
             occupancy = []
-            for v, f, tet_fx4x3 in zip(verts, faces, tet_bxfx4x3):
-                center = torch.mean(tet_fx4x3, dim=1)
-                result = hip_ops.check_sign(v, f[0], center.unsqueeze(dim=0))
+            for b, (v, f) in enumerate(zip(verts, faces)):              # per-shape meshes, like the reference's loop
+                result = hip_ops.check_sign(v.reshape(1, -1, 3), f[0], center[b:b + 1], check=False)
                 occupancy.append(result.unsqueeze(-1))
             occupancy = torch.cat(occupancy, dim=0).float()
         return occupancy

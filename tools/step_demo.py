@@ -1,0 +1,105 @@
+#!/usr/bin/env python
+"""The geometry side of one DefTet training step (layers/DefTet/deftet.py:52-130,
+forward_surface_align without the networks), end to end on the HIP operators:
+
+    vertices --gather--> tets --check_sign--> centroid occupancy --get_boundary_index--> surface faces
+             tets + query points --point_in_tet_occ--> (index, weights, pasted occupancy)
+             tets --energies--> (volume variance, AMIPS, edge length)
+    loss.backward(): d/d tets of all of it --gather_bwd--> d/d vertices (no atomics anywhere)
+
+Prints one JSON line with the time of each stage at BASELINE configs[2] sizes.
+    python tools/step_demo.py [--res 70 --batch 8 --queries 100000]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from deftet_amd import grids, hip_ops  # noqa: E402
+from deftet_amd.layers.DefTet.deftet import DefTet  # noqa: E402
+from deftet_amd.layers.DefTet.check_condition_tetrahedron_base.utils import point_in_tet_occ  # noqa: E402
+
+
+def build_case(res, B, Q, dev):
+    verts, tets = grids.kuhn_grid(res)
+    pos = torch.from_numpy(grids.jittered_positions(verts, res, B).astype(np.float32)).to(dev)
+    idx = torch.from_numpy(tets.astype(np.int64)).to(dev)
+    f3, t2 = hip_ops.tet_to_face(idx.int(), verts.shape[0], dev)[:2]
+    # ground-truth surface: boundary of the tets of the UNJITTERED grid inside a sphere (a closed mesh)
+    occ0 = torch.from_numpy(np.linalg.norm((verts - 0.5)[tets].mean(1), axis=1) < 0.3).to(dev)
+    gt_faces = f3[occ0[t2].sum(1) == 1].contiguous()
+    gt_verts = torch.from_numpy((verts - 0.5).astype(np.float32)).to(dev)
+    pts = torch.from_numpy(grids.random_queries(B, Q)).to(dev)
+    rest = gt_verts[idx] * 20
+    inv_v = torch.inverse(torch.stack([rest[:, 1] - rest[:, 0], rest[:, 2] - rest[:, 0], rest[:, 3] - rest[:, 0]], 1))
+    return pos, idx, f3, t2, gt_verts, gt_faces, pts, inv_v
+
+
+def run_step(m, pos, idx, f3, t2, gt_verts, gt_faces, pts, inv_v, pred, times=None):
+    def mark(name, t0):
+        if times is not None:
+            torch.cuda.synchronize()
+            times[name] = times.get(name, 0.0) + time.perf_counter() - t0
+        return time.perf_counter()
+
+    B = pos.shape[0]
+    t0 = time.perf_counter()
+    tet = m.gather_tet_pos(pos, idx[None].expand(B, -1, -1) if idx.dim() == 2 else idx)
+    t0 = mark("gather", t0)
+    center_occ = m.check_tet_inside_sdfs(tet.detach(), ([gt_verts[None]] * B, [[gt_faces]] * B))
+    t0 = mark("check_sign", t0)
+    boundary = m.get_boundary_index(f3, t2, center_occ.squeeze(-1))
+    t0 = mark("boundary_index", t0)
+    cond, w, occ = point_in_tet_occ(tet, pts, pred)
+    t0 = mark("point_in_tet_occ", t0)
+    vv, am, el = m.energies(tet, inv_v)
+    t0 = mark("energies", t0)
+    loss = (w * w).sum() + (occ - 0.5).pow(2).sum() + 1e-3 * am.sum() + 1e-3 * el.sum() + 1e-6 * vv.sum()
+    t0 = mark("loss (torch)", t0)
+    loss.backward()
+    mark("backward (all ops + gather_bwd)", t0)
+    return loss, boundary, cond
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--res", type=int, default=70)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--queries", type=int, default=100000)
+    ap.add_argument("--steps", type=int, default=10)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    case = build_case(a.res, a.batch, a.queries, dev)
+    pos = case[0].clone().requires_grad_(True)
+    pred = torch.rand(a.batch, case[1].shape[0], device=dev, requires_grad=True)
+    m = DefTet(device=dev)
+    idxB = case[1][None].expand(a.batch, -1, -1).contiguous()
+    for _ in range(2):
+        pos.grad = None
+        run_step(m, pos, idxB, *case[2:], pred)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        pos.grad = None
+        pred.grad = None
+        run_step(m, pos, idxB, *case[2:], pred)
+    torch.cuda.synchronize()
+    total = (time.perf_counter() - t0) / a.steps
+    times = {}
+    for _ in range(a.steps):
+        pos.grad = None
+        pred.grad = None
+        run_step(m, pos, idxB, *case[2:], pred, times)
+    print(json.dumps({"op": "DefTet geometry step (gather, check_sign, boundary, point-in-tet+paste, energies, backward to vertices)",
+                      "res": a.res, "batch": a.batch, "n_tet": int(case[1].shape[0]), "n_query": a.queries,
+                      "n_gt_face": int(case[5].shape[0]), "ms_per_step": round(total * 1e3, 3),
+                      "stage_ms_with_sync": {k: round(v / a.steps * 1e3, 3) for k, v in times.items()}}))
+
+
+if __name__ == "__main__":
+    main()
