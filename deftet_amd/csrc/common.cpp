@@ -46,14 +46,14 @@ void prof_begin(hipStream_t st)
             g_prof.ev.push_back(e);
         }
     }
-    hipEventRecord(g_prof.ev[g_prof.used], st);
+    (void)hipEventRecord(g_prof.ev[g_prof.used], st);        // timing aid: a failed record only loses a sample
 }
 
 void prof_end(hipStream_t st)
 {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     if (g_prof.used + 2 > g_prof.ev.size()) return;
-    hipEventRecord(g_prof.ev[g_prof.used + 1], st);
+    (void)hipEventRecord(g_prof.ev[g_prof.used + 1], st);
     g_prof.used += 2;
 }
 
