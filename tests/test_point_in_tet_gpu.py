@@ -260,3 +260,40 @@ def test_binned_equals_brute_res100(cuda):
     # queries outside the grid never hit
     outside = (p.abs() > 0.5).any(-1)
     assert not (hit & outside).any()
+
+
+@pytest.mark.parametrize("B,T,Q", [(1, 1, 1), (2, 3, 2), (1, 63, 64), (5, 64, 65), (1, 65, 2047), (2, 200, 2048), (1, 1000, 2049),
+                                   (9, 37, 4100), (1, 5000, 6000)])
+@pytest.mark.parametrize("pattern", ["uniform", "clustered", "plane"])
+def test_random_soups_and_query_patterns(cuda, oracle, B, T, Q, pattern):
+    """overlapping random tets (many queries accepted by several tets) x query sets that stress the
+    counting sort: everything in one cell / one row, sizes around the 2048-query chunk and the
+    64-lane wave; all binned variants against the oracle, hit-record backward against the list backward"""
+    from deftet_amd import hip_ops
+    rng = np.random.default_rng(B * 1000003 + T * 1009 + Q)
+    c = rng.random((B, T, 1, 3)).astype(np.float32) - 0.5
+    tet = (c + 0.35 * (rng.random((B, T, 4, 3)).astype(np.float32) - 0.5)).astype(np.float32)
+    if pattern == "uniform":
+        pts = (rng.random((B, Q, 3)) - 0.5).astype(np.float32)
+    elif pattern == "clustered":                                       # one grid cell, a few stragglers that span the box
+        pts = (0.1 + 1e-4 * rng.random((B, Q, 3))).astype(np.float32)
+        pts[:, : max(1, Q // 50)] = (rng.random((B, max(1, Q // 50), 3)) - 0.5).astype(np.float32)
+    else:                                                              # a plane: one (cz) slab of rows
+        pts = (rng.random((B, Q, 3)) - 0.5).astype(np.float32)
+        pts[..., 2] = 0.0625
+    want = oracle.point_in_tet(tet, pts)
+    t, p = torch.from_numpy(tet).to(cuda), torch.from_numpy(pts).to(cuda)
+    for algo in (0, 2, 3):
+        cond = hip_ops.point_in_tet(t, p, algo=algo)
+        assert np.array_equal(cond.cpu().numpy(), want), algo
+    gen = torch.Generator(device=cuda).manual_seed(1)
+    pred = torch.rand(B, T, device=cuda, generator=gen)
+    cond, w, occ, hits = hip_ops.point_in_tet(t, p, want_bary=True, pred_bxt=pred, want_hits=True)
+    assert np.array_equal(cond.cpu().numpy(), want)
+    gw, go = torch.randn(B, Q, 4, device=cuda, generator=gen), torch.randn(B, Q, device=cuda, generator=gen)
+    a = hip_ops.point_in_tet_bwd(t, p, cond, gw, want_grad_pts=True, grad_occ=go, hits=hits)
+    b = hip_ops.point_in_tet_bwd(t, p, cond, gw, want_grad_pts=True, grad_occ=go)
+    for x, y in zip(a, b):
+        f = torch.isfinite(x) & torch.isfinite(y)
+        assert f.float().mean() > 0.99
+        assert ((x - y)[f]).abs().max() <= 1e-4 * max(y[f].abs().max().item(), 1e-30)
