@@ -297,3 +297,23 @@ def test_random_soups_and_query_patterns(cuda, oracle, B, T, Q, pattern):
         f = torch.isfinite(x) & torch.isfinite(y)
         assert f.float().mean() > 0.99
         assert ((x - y)[f]).abs().max() <= 1e-4 * max(y[f].abs().max().item(), 1e-30)
+
+
+def test_more_queries_than_row_blocks(cuda):
+    """Q beyond 256 chunks x 2048 (the counting sort then loops inside a block) and Q >> T: the
+    binned path against the independent brute-force kernel"""
+    from deftet_amd import hip_ops
+    tet, _ = cases.jittered(14, 10, 2)
+    rng = np.random.default_rng(5)
+    pts = (1.05 * (rng.random((2, 600000, 3)) - 0.5)).astype(np.float32)
+    t, p = torch.from_numpy(tet).to(cuda), torch.from_numpy(pts).to(cuda)
+    cond, w, hits = hip_ops.point_in_tet(t, p, want_bary=True, want_hits=True)
+    assert torch.equal(cond, hip_ops.point_in_tet(t, p, algo=1))
+    hit = cond[..., 0] >= 0
+    assert 0.8 < hit.float().mean().item() < 0.9
+    assert (w[hit].sum(-1) - 1).abs().max().item() < 1e-5
+    # every tet swallows ~250 queries: all records overflow, the backward runs through the uncovered list
+    gw = torch.randn(2, 600000, 4, device=cuda, generator=torch.Generator(device=cuda).manual_seed(2))
+    a = hip_ops.point_in_tet_bwd(t, p, cond, gw, hits=hits)[0]
+    b = hip_ops.point_in_tet_bwd(t, p, cond, gw)[0]
+    assert (a - b).abs().max() <= 1e-3 * b.abs().max()
