@@ -53,6 +53,16 @@ DOMINANT = {0: b"k_tet_scan", 2: b"k_tet_scan_staged", 3: b"k_tet_scan_rows"}.ge
 
 
 GATHER = None                    # sharding.LossGather(), created in main() once the process group exists
+PIPELINE = os.environ.get("DEFTET_BENCH_PIPELINE", "1") not in ("", "0")
+OVERLAP_WITH = os.environ.get("DEFTET_BENCH_OVERLAP", "fwd")      # "fwd": start at once (measured 0.262 ms/step); "bwd": after this step's forward (0.276)
+_SIDE = None
+
+
+def side_stream():
+    global _SIDE
+    if _SIDE is None:
+        _SIDE = torch.cuda.Stream()
+    return _SIDE
 
 
 def step(d, world):
@@ -60,7 +70,22 @@ def step(d, world):
     dL/dpred from one per-tet pass over those records (no atomics); then the per-shape loss
     scalars (all-gathered when world > 1).  Same calls as the PointInTetOcc autograd op makes."""
     from deftet_amd import hip_ops, sharding
-    cond, w, occ, hits = hip_ops.point_in_tet(d["tet"], d["pts"], want_bary=True, pred_bxt=d["pred"], want_hits=True, algo=ALGO)
+    if PIPELINE:
+        # software pipelining across steps: the query side of the operator (bounding box + counting sort,
+        # five small latency-bound kernels that need only the points) is enqueued on a second stream as
+        # soon as the previous step's traversal has been launched, so it overlaps with that step's big
+        # kernels; every step still does all of its work (K sorts in the K timed steps)
+        pq = d.pop("pq", None)
+        if pq is None:
+            pq = hip_ops.prepare_queries(d["pts"], d["tet"].shape[1], algo=ALGO)
+        cond, w, occ, hits = hip_ops.point_in_tet(d["tet"], d["pts"], want_bary=True, pred_bxt=d["pred"], want_hits=True, algo=ALGO,
+                                                  prepared=pq)
+        if OVERLAP_WITH == "bwd":                                     # start it when this step's forward has finished
+            side_stream().wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side_stream()):
+            d["pq"] = hip_ops.prepare_queries(d["pts"], d["tet"].shape[1], algo=ALGO)
+    else:
+        cond, w, occ, hits = hip_ops.point_in_tet(d["tet"], d["pts"], want_bary=True, pred_bxt=d["pred"], want_hits=True, algo=ALGO)
     g_tet, _, g_pred = hip_ops.point_in_tet_bwd(d["tet"], d["pts"], cond, d["gw"], grad_occ=d["gout"], hits=hits)
     loss = hip_ops.rowdot(w, d["gw"], occ, d["gout"])         # [B] per-shape loss scalars
     if world > 1:
@@ -195,7 +220,8 @@ def main():
             "config": {"workload": "BASELINE configs[2]: res=70 Kuhn tet grid (T=%d), %d uniform queries, batch=%d shapes "
                                    "per GPU, point-in-tet index + weights + paste_occ, fwd+bwd, grid build included" % (T, Q, B),
                        "res": RES, "n_tet": T, "n_query": Q, "batch_per_gpu": B,
-                       "sharding": "shapes sharded by rank; all-gather of %d loss scalars" % (world * B)},
+                       "sharding": "shapes sharded by rank; all-gather of %d loss scalars" % (world * B),
+                       "pipelining": ("query sort of step i+1 enqueued on a second stream during step i" if PIPELINE else "none")},
             "roofline": {"bound": "hbm", "kernel": dominant.decode(), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": round(kern_ms, 5),

@@ -183,7 +183,7 @@ __device__ __forceinline__ bool query_regular(float x, float y, float z)
 // The same launch also clears what the later kernels accumulate into (counters, result
 // sentinels): nothing in THIS kernel reads them.
 __global__ __launch_bounds__(256) void k_query_bbox(const float *__restrict__ pts, int Q, float *part, int *counters,
-                                                    int *result, int nB, long long nQ, int *hitCnt, int nHitCnt)
+                                                    int *result, int nB, long long nQ)
 {
     __shared__ float sh[4][6];
     const int b = blockIdx.y;
@@ -191,7 +191,6 @@ __global__ __launch_bounds__(256) void k_query_bbox(const float *__restrict__ pt
         const long long nblk = (long long)gridDim.x * gridDim.y, bid = (long long)blockIdx.y * gridDim.x + blockIdx.x;
         const long long i = bid * blockDim.x + threadIdx.x, stride = nblk * blockDim.x;
         if (i < nB * 4) counters[i] = 0;
-        if (hitCnt && i < nHitCnt) hitCnt[i] = 0;
         for (long long j = i; j < nQ; j += stride) result[j] = kMiss;
     }
     const float *p = pts + (size_t)b * Q * 3;
@@ -435,8 +434,9 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan(const float *__rest
                                                   const float *__restrict__ gparam, int G, int Gx, const int *__restrict__ cells,
                                                   long long cellStride, const float4 *__restrict__ sortedQ, int *result, int *counters,
                                                   int *irregT, int4 *hits, const float *__restrict__ pts,
-                                                  const int *__restrict__ irregQ)
+                                                  const int *__restrict__ irregQ, int *ucount)
 {
+    if (ucount && blockIdx.x == 0 && threadIdx.x == 0) ucount[blockIdx.y] = 0;   // uncovered-hit counter of the hit buffer (k_finalize appends)
     const int b = blockIdx.y;
     // XCD-aware mapping (workgroup i is observed to run on XCD i % 8, each XCD has a private
     // L2): give every XCD one CONTIGUOUS eighth of the tet range, so a mesh whose tet order is
@@ -602,8 +602,9 @@ __global__ __launch_bounds__(256, PIT_STAGE_WAVES) void k_tet_scan_staged(const 
                                                   const float *__restrict__ gparam, int G, int Gx, const int *__restrict__ cells,
                                                   long long cellStride, const float4 *__restrict__ sortedQ, int *result, int *counters,
                                                   int *irregT, int4 *hits, const float *__restrict__ pts,
-                                                  const int *__restrict__ irregQ)
+                                                  const int *__restrict__ irregQ, int *ucount)
 {
+    if (ucount && blockIdx.x == 0 && threadIdx.x == 0) ucount[blockIdx.y] = 0;   // uncovered-hit counter of the hit buffer (k_finalize appends)
     __shared__ int s_cs[4][kSubMax];
     __shared__ float4 s_q[4][kStageQ];
     __shared__ int s_off[4][65];
@@ -780,8 +781,9 @@ __global__ __launch_bounds__(256, 4) void k_tet_scan_rows(const float *__restric
                                                   const float *__restrict__ gparam, int G, int Gx, const int *__restrict__ cells,
                                                   long long cellStride, const float4 *__restrict__ sortedQ, int *result, int *counters,
                                                   int *irregT, int4 *hits, const float *__restrict__ pts,
-                                                  const int *__restrict__ irregQ)
+                                                  const int *__restrict__ irregQ, int *ucount)
 {
+    if (ucount && blockIdx.x == 0 && threadIdx.x == 0) ucount[blockIdx.y] = 0;   // uncovered-hit counter of the hit buffer (k_finalize appends)
     __shared__ float s_rec[4][kRowWords][64];
     __shared__ int s_off[4][65];
     __shared__ int s_hcnt[4][64];
@@ -1507,9 +1509,8 @@ extern "C" size_t deftet_point_in_tet_hits_ints(int B, int T, int Q)
     return hit_list_off(B, T) + (size_t)B * Q;
 }
 
-extern "C" int deftet_point_in_tet_f32(const float *tet, const float *pts, float *cond, float *bary, const float *pred,
-                                       float *occ, int32_t *hit_buf, int B, int T, int Q, int algo, void *workspace,
-                                       size_t workspace_bytes, void *stream_)
+static int pit_check(const float *tet, const float *pts, const float *cond, const float *bary, const float *pred, const float *occ,
+                     const int32_t *hit_buf, int B, int T, int Q, int algo, const void *workspace)
 {
     DEFTET_CHECK_ARG(!hit_buf || (((uintptr_t)hit_buf & 15) == 0 && algo != DEFTET_PIT_BRUTE), "hit_buf must be 16-byte aligned and needs a binned algo");
     DEFTET_CHECK_ARG((pred == nullptr) == (occ == nullptr), "pred and occ must be given together");
@@ -1525,46 +1526,104 @@ extern "C" int deftet_point_in_tet_f32(const float *tet, const float *pts, float
     DEFTET_CHECK_ARG(((uintptr_t)tet & 15) == 0, "tet must be 16-byte aligned");
     DEFTET_CHECK_ARG(!bary || ((uintptr_t)bary & 15) == 0, "bary must be 16-byte aligned");
     DEFTET_CHECK_ARG(workspace && ((uintptr_t)workspace & 255) == 0, "workspace null or not 256-byte aligned");
+    return DEFTET_OK;
+}
+
+// query side: resets + bounding box + counting sort of the queries into grid cells (depends on pts, B, T, Q only)
+static int pit_prepare(const Layout &L, const float *pts, int B, int Q, hipStream_t st)
+{
+    const dim3 blk(256);
+    const int R = L.G * L.G;
+    DEFTET_LAUNCH(k_query_bbox, dim3(kBoxBlocks, B), blk, st, pts, Q, L.bboxPart, L.counters, L.result, B, (long long)B * Q);
+    DEFTET_LAUNCH(k_row_count, dim3(L.nRowBlk, B), blk, st, pts, Q, L.bboxPart, L.gparam, L.G, L.Gx, L.nRowBlk, L.chunkQ, L.qkey,
+                  L.blockHist, L.counters, L.irregQ);
+    DEFTET_LAUNCH(k_row_colscan, dim3((R + 255) / 256, B), blk, st, L.blockHist, L.nRowBlk, R, L.rowTotal);
+    DEFTET_LAUNCH(k_row_scatter, dim3(L.nRowBlk, B), blk, st, pts, Q, L.qkey, L.blockHist, L.rowTotal, L.rowStart, L.G, L.nRowBlk,
+                  L.chunkQ, L.rowSorted);
+    DEFTET_LAUNCH(k_row_fine, dim3((R + 3) / 4, B), blk, st, L.rowSorted, Q, L.gparam, L.G, L.Gx, L.rowStart, L.cellStride, L.cells,
+                  L.sortedQ);
+    return DEFTET_OK;
+}
+
+// tet side: traversal + finalize; consumes the prepared state (result sentinels, counters)
+static int pit_scan(const Layout &L, const float *tet, const float *pts, float *cond, float *bary, const float *pred, float *occ,
+                    int32_t *hit_buf, int B, int T, int Q, int algo, hipStream_t st)
+{
+    const dim3 blk(256);
+    const dim3 gq((Q + 255) / 256, B), gt((((T + 255) / 256 + 7) / 8) * 8, B);   // gt: multiple of 8 for the XCD mapping
+    int *ucount = hit_buf ? hit_buf + hit_cnt_off(B, T) : nullptr;
+    if (T > 0) {
+        if (algo == DEFTET_PIT_ROWS) {
+            DEFTET_LAUNCH(k_tet_scan_rows, gt, blk, st, tet, T, Q, L.gparam, L.G, L.Gx, L.cells, L.cellStride, L.sortedQ, L.result,
+                          L.counters, L.irregT, (int4 *)hit_buf, pts, L.irregQ, ucount);
+        } else if (algo != DEFTET_PIT_STAGED) {
+            DEFTET_LAUNCH(k_tet_scan, gt, blk, st, tet, T, Q, L.gparam, L.G, L.Gx, L.cells, L.cellStride, L.sortedQ, L.result,
+                          L.counters, L.irregT, (int4 *)hit_buf, pts, L.irregQ, ucount);
+        } else {
+            DEFTET_LAUNCH(k_tet_scan_staged, gt, blk, st, tet, T, Q, L.gparam, L.G, L.Gx, L.cells, L.cellStride, L.sortedQ,
+                          L.result, L.counters, L.irregT, (int4 *)hit_buf, pts, L.irregQ, ucount);
+        }
+    } else if (ucount) {
+        DEFTET_HIP(hipMemsetAsync(ucount, 0, (size_t)B * 4, st));
+    }
+    DEFTET_LAUNCH(k_finalize, gq, blk, st, tet, pts, T, Q, L.result, cond, bary, pred, occ, (const int4 *)hit_buf, ucount,
+                  hit_buf ? hit_buf + hit_list_off(B, T) : nullptr, L.counters, L.irregT);
+    return DEFTET_OK;
+}
+
+extern "C" int deftet_point_in_tet_f32(const float *tet, const float *pts, float *cond, float *bary, const float *pred,
+                                       float *occ, int32_t *hit_buf, int B, int T, int Q, int algo, void *workspace,
+                                       size_t workspace_bytes, void *stream_)
+{
+    int rc = pit_check(tet, pts, cond, bary, pred, occ, hit_buf, B, T, Q, algo, workspace);
+    if (rc != DEFTET_OK || B == 0 || Q == 0) return rc;
     Layout L = make_layout(B, T, Q, algo, workspace, workspace_bytes);
     DEFTET_CHECK_ARG(L.bytes <= workspace_bytes, "workspace too small: need %zu bytes, got %zu", L.bytes, workspace_bytes);
     hipStream_t st = as_stream(stream_);
-    const dim3 blk(256);
-    const dim3 gq((Q + 255) / 256, B), gt((((T + 255) / 256 + 7) / 8) * 8, B);   // gt: multiple of 8 for the XCD mapping
-
     if (algo == DEFTET_PIT_BRUTE) {
+        const dim3 blk(256), gq((Q + 255) / 256, B);
         if (T > 0) {
             long long n = (long long)B * T;
             DEFTET_LAUNCH(k_prep_records, dim3((unsigned)((n + 255) / 256)), blk, st, tet, n, L.rec);
         }
         DEFTET_LAUNCH(k_brute, gq, blk, st, L.rec, pts, T, Q, L.result);
-    } else {
-        const int R = L.G * L.G;
-        DEFTET_LAUNCH(k_query_bbox, dim3(kBoxBlocks, B), blk, st, pts, Q, L.bboxPart, L.counters, L.result, B, (long long)B * Q,
-                      hit_buf ? hit_buf + hit_cnt_off(B, T) : nullptr, (int)(hit_list_off(B, T) - hit_cnt_off(B, T)));
-        DEFTET_LAUNCH(k_row_count, dim3(L.nRowBlk, B), blk, st, pts, Q, L.bboxPart, L.gparam, L.G, L.Gx, L.nRowBlk, L.chunkQ, L.qkey,
-                      L.blockHist, L.counters, L.irregQ);
-        DEFTET_LAUNCH(k_row_colscan, dim3((R + 255) / 256, B), blk, st, L.blockHist, L.nRowBlk, R, L.rowTotal);
-        DEFTET_LAUNCH(k_row_scatter, dim3(L.nRowBlk, B), blk, st, pts, Q, L.qkey, L.blockHist, L.rowTotal, L.rowStart, L.G, L.nRowBlk,
-                      L.chunkQ, L.rowSorted);
-        DEFTET_LAUNCH(k_row_fine, dim3((R + 3) / 4, B), blk, st, L.rowSorted, Q, L.gparam, L.G, L.Gx, L.rowStart, L.cellStride, L.cells,
-                      L.sortedQ);
-        if (T > 0) {
-            if (algo == DEFTET_PIT_ROWS) {
-                DEFTET_LAUNCH(k_tet_scan_rows, gt, blk, st, tet, T, Q, L.gparam, L.G, L.Gx, L.cells, L.cellStride, L.sortedQ, L.result,
-                              L.counters, L.irregT, (int4 *)hit_buf, pts, L.irregQ);
-            } else if (algo != DEFTET_PIT_STAGED) {
-                DEFTET_LAUNCH(k_tet_scan, gt, blk, st, tet, T, Q, L.gparam, L.G, L.Gx, L.cells, L.cellStride, L.sortedQ, L.result,
-                              L.counters, L.irregT, (int4 *)hit_buf, pts, L.irregQ);
-            } else {
-                DEFTET_LAUNCH(k_tet_scan_staged, gt, blk, st, tet, T, Q, L.gparam, L.G, L.Gx, L.cells, L.cellStride, L.sortedQ,
-                              L.result, L.counters, L.irregT, (int4 *)hit_buf, pts, L.irregQ);
-            }
-        }
+        DEFTET_LAUNCH(k_finalize, gq, blk, st, tet, pts, T, Q, L.result, cond, bary, pred, occ, (const int4 *)nullptr, (int *)nullptr,
+                      (int *)nullptr, (const int *)nullptr, L.irregT);
+        return DEFTET_OK;
     }
-    DEFTET_LAUNCH(k_finalize, gq, blk, st, tet, pts, T, Q, L.result, cond, bary, pred, occ, (const int4 *)hit_buf,
-                  hit_buf ? hit_buf + hit_cnt_off(B, T) : nullptr, hit_buf ? hit_buf + hit_list_off(B, T) : nullptr,
-                  algo != DEFTET_PIT_BRUTE ? L.counters : nullptr, L.irregT);
-    return DEFTET_OK;
+    rc = pit_prepare(L, pts, B, Q, st);
+    if (rc != DEFTET_OK) return rc;
+    return pit_scan(L, tet, pts, cond, bary, pred, occ, hit_buf, B, T, Q, algo, st);
+}
+
+// The same operator in two calls: the QUERY side (bounding box + counting sort: depends on pts and on
+// the sizes only) can be enqueued ahead of time — e.g. on another stream while the previous step's
+// backward is still running — and the TET side consumes it.  One prepare feeds exactly one scan
+// (the scan uses up the result sentinels and counters the prepare resets); both must see the same
+// pts, sizes, algo and workspace.
+extern "C" int deftet_point_in_tet_prepare_f32(const float *pts, int B, int T, int Q, int algo, void *workspace,
+                                               size_t workspace_bytes, void *stream_)
+{
+    DEFTET_CHECK_ARG(B >= 0 && T >= 0 && Q >= 0 && B <= 65535, "bad size (B=%d T=%d Q=%d)", B, T, Q);
+    DEFTET_CHECK_ARG(algo == DEFTET_PIT_AUTO || algo == DEFTET_PIT_STAGED || algo == DEFTET_PIT_ROWS, "prepare needs a binned algo (got %d)", algo);
+    if (B == 0 || Q == 0) return DEFTET_OK;
+    DEFTET_CHECK_ARG(pts, "null pts pointer");
+    DEFTET_CHECK_ARG(workspace && ((uintptr_t)workspace & 255) == 0, "workspace null or not 256-byte aligned");
+    Layout L = make_layout(B, T, Q, algo, workspace, workspace_bytes);
+    DEFTET_CHECK_ARG(L.bytes <= workspace_bytes, "workspace too small: need %zu bytes, got %zu", L.bytes, workspace_bytes);
+    return pit_prepare(L, pts, B, Q, as_stream(stream_));
+}
+
+extern "C" int deftet_point_in_tet_scan_f32(const float *tet, const float *pts, float *cond, float *bary, const float *pred,
+                                            float *occ, int32_t *hit_buf, int B, int T, int Q, int algo, void *workspace,
+                                            size_t workspace_bytes, void *stream_)
+{
+    DEFTET_CHECK_ARG(algo != DEFTET_PIT_BRUTE, "scan needs a binned algo");
+    int rc = pit_check(tet, pts, cond, bary, pred, occ, hit_buf, B, T, Q, algo, workspace);
+    if (rc != DEFTET_OK || B == 0 || Q == 0) return rc;
+    Layout L = make_layout(B, T, Q, algo, workspace, workspace_bytes);
+    DEFTET_CHECK_ARG(L.bytes <= workspace_bytes, "workspace too small: need %zu bytes, got %zu", L.bytes, workspace_bytes);
+    return pit_scan(L, tet, pts, cond, bary, pred, occ, hit_buf, B, T, Q, algo, as_stream(stream_));
 }
 
 extern "C" size_t deftet_point_in_tet_bwd_workspace_bytes(int B, int T, int Q)

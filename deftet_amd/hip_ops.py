@@ -19,7 +19,45 @@ def _f32c(t):
 
 
 # --------------------------------------------------------------------------------- A1
-def point_in_tet(tet_bxtx4x3, pts_bxqx3, want_bary=False, algo=PIT_AUTO, pred_bxt=None, want_hits=False):
+class PreparedQueries:
+    """The query side of point_in_tet (bounding box + counting sort into grid cells) enqueued ahead
+    of the tet side — typically on a second stream while the previous step's backward is running:
+
+        with torch.cuda.stream(side):
+            pq = hip_ops.prepare_queries(pts_next, n_tet)          # 5 small kernels, no tets needed
+        ...
+        cond, w = hip_ops.point_in_tet(tet, pts_next, want_bary=True, prepared=pq)   # waits for pq's event
+
+    It owns its workspace and is consumed by exactly ONE point_in_tet call."""
+
+    def __init__(self, pts, n_tet, algo):
+        self.pts, self.n_tet, self.algo = pts, int(n_tet), int(algo)
+        self.workspace = None
+        self.event = None
+        self.consumed = False
+
+
+def prepare_queries(pts_bxqx3, n_tet, algo=PIT_AUTO):
+    _lib.require_gpu(pts_bxqx3)
+    if algo == PIT_BRUTE:
+        raise RuntimeError("prepare_queries needs a binned algo")
+    lib = _lib.load()
+    pts = _f32c(pts_bxqx3)
+    if pts.dim() != 3 or pts.shape[2] != 3:
+        raise RuntimeError("point_pos_bxnx3 must be [B,Q,3], got %s" % (tuple(pts.shape),))
+    B, Q, dev = pts.shape[0], pts.shape[1], pts.device
+    pq = PreparedQueries(pts, n_tet, algo)
+    with torch.cuda.device(dev):
+        nbytes = max(lib.deftet_point_in_tet_workspace_bytes(B, pq.n_tet, Q, algo), 256)
+        pq.workspace = torch.empty(nbytes, device=dev, dtype=torch.uint8)       # private: outlives the cached per-stream workspace
+        _lib.check(lib.deftet_point_in_tet_prepare_f32(_lib.ptr(pts), B, pq.n_tet, Q, algo, _lib.ptr(pq.workspace), nbytes,
+                                                       _lib.current_stream(dev)), "deftet_point_in_tet_prepare_f32")
+        pq.event = torch.cuda.Event()
+        pq.event.record(torch.cuda.current_stream(dev))
+    return pq
+
+
+def point_in_tet(tet_bxtx4x3, pts_bxqx3, want_bary=False, algo=PIT_AUTO, pred_bxt=None, want_hits=False, prepared=None):
     """cond f32 [B,Q,1] (lowest containing tet index or -1); with want_bary also the barycentric
     weights f32 [B,Q,4] of the hit tet; with pred_bxt also occ f32 [B,Q] = the fused
     DefTet.paste_occ gather pred[b, max(index, 0)].  Returns cond | (cond, bary) | (cond, bary, occ)
@@ -44,11 +82,24 @@ def point_in_tet(tet_bxtx4x3, pts_bxqx3, want_bary=False, algo=PIT_AUTO, pred_bx
     if want_hits and algo != PIT_BRUTE:
         hits = torch.empty(max(lib.deftet_point_in_tet_hits_ints(B, T, Q), 4), device=dev, dtype=torch.int32)
     with torch.cuda.device(dev):
-        nbytes = lib.deftet_point_in_tet_workspace_bytes(B, T, Q, algo)
-        ws = _lib.workspace(dev, nbytes)
-        _lib.check(lib.deftet_point_in_tet_f32(_lib.ptr(tet), _lib.ptr(pts), _lib.ptr(cond), _lib.ptr(bary), _lib.ptr(pred),
-                                               _lib.ptr(occ), _lib.ptr(hits), B, T, Q, algo, _lib.ptr(ws), ws.numel(),
-                                               _lib.current_stream(dev)), "deftet_point_in_tet_f32")
+        if prepared is not None:
+            if prepared.consumed or prepared.algo != algo or prepared.n_tet != T or prepared.pts.data_ptr() != pts.data_ptr() \
+                    or prepared.pts.shape != pts.shape:
+                raise RuntimeError("point_in_tet: `prepared` was made for other points / sizes / algo, or was already used")
+            cur = torch.cuda.current_stream(dev)
+            cur.wait_event(prepared.event)                             # the sort may have run on another stream
+            ws = prepared.workspace
+            ws.record_stream(cur)
+            prepared.consumed = True
+            _lib.check(lib.deftet_point_in_tet_scan_f32(_lib.ptr(tet), _lib.ptr(pts), _lib.ptr(cond), _lib.ptr(bary), _lib.ptr(pred),
+                                                        _lib.ptr(occ), _lib.ptr(hits), B, T, Q, algo, _lib.ptr(ws), ws.numel(),
+                                                        _lib.current_stream(dev)), "deftet_point_in_tet_scan_f32")
+        else:
+            nbytes = lib.deftet_point_in_tet_workspace_bytes(B, T, Q, algo)
+            ws = _lib.workspace(dev, nbytes)
+            _lib.check(lib.deftet_point_in_tet_f32(_lib.ptr(tet), _lib.ptr(pts), _lib.ptr(cond), _lib.ptr(bary), _lib.ptr(pred),
+                                                   _lib.ptr(occ), _lib.ptr(hits), B, T, Q, algo, _lib.ptr(ws), ws.numel(),
+                                                   _lib.current_stream(dev)), "deftet_point_in_tet_f32")
     out = (cond,) + ((bary,) if want_bary else ()) + ((occ,) if pred is not None else ()) + ((hits,) if want_hits else ())
     return out if len(out) > 1 else cond
 

@@ -72,6 +72,20 @@ int deftet_point_in_tet_f32(const float *tet, const float *pts, float *cond, flo
                             int n_batch, int n_tet, int n_query, int algo,
                             void *workspace, size_t workspace_bytes, void *stream);
 
+/* The same operator in two calls.  The QUERY side (bounding box + counting sort of the queries
+ * into grid cells) depends only on pts and on the sizes, so it can be enqueued ahead of time —
+ * e.g. on a second stream while the previous step's backward is still running — and the TET side
+ * (traversal + finalize) consumes it.  One prepare feeds exactly ONE scan (the scan uses up the
+ * result sentinels and counters that prepare resets); both calls must see the same pts, sizes,
+ * algo (a binned one) and workspace, and the scan must be ordered after the prepare (same stream
+ * or an event).  deftet_point_in_tet_f32 == prepare followed by scan on one stream. */
+int deftet_point_in_tet_prepare_f32(const float *pts, int n_batch, int n_tet, int n_query, int algo,
+                                    void *workspace, size_t workspace_bytes, void *stream);
+int deftet_point_in_tet_scan_f32(const float *tet, const float *pts, float *cond, float *bary,
+                                 const float *pred, float *occ, int32_t *hit_buf,
+                                 int n_batch, int n_tet, int n_query, int algo,
+                                 void *workspace, size_t workspace_bytes, void *stream);
+
 /* A1b  backward of the weights (the reference's own backward,
  * check_condition_tetrahedron_base/utils.py:55-58, returns None).
  * grad_w f32 [B,Q,4] -> grad_tet f32 [B,T,4,3] = d(sum grad_w*w)/d tet; grad_pts f32 [B,Q,3]

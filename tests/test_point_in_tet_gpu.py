@@ -317,3 +317,31 @@ def test_more_queries_than_row_blocks(cuda):
     a = hip_ops.point_in_tet_bwd(t, p, cond, gw, hits=hits)[0]
     b = hip_ops.point_in_tet_bwd(t, p, cond, gw)[0]
     assert (a - b).abs().max() <= 1e-3 * b.abs().max()
+
+
+def test_prepared_queries_two_streams(cuda, oracle):
+    """deftet_point_in_tet_prepare_f32 + _scan_f32 == the fused call, with the query sort on another stream"""
+    from deftet_amd import hip_ops
+    tet, pts = cases.jittered(10, 4000, 3)
+    tet2 = tet[:, ::-1].copy()                                        # another tet set for the same queries
+    t, t2, p = torch.from_numpy(tet).to(cuda), torch.from_numpy(tet2).to(cuda), torch.from_numpy(pts).to(cuda)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        pq = hip_ops.prepare_queries(p, t.shape[1])
+        pq2 = hip_ops.prepare_queries(p, t.shape[1], algo=2)
+    pred = torch.rand(3, t.shape[1], device=cuda, generator=torch.Generator(device=cuda).manual_seed(3))
+    cond, w, occ, hits = hip_ops.point_in_tet(t, p, want_bary=True, pred_bxt=pred, want_hits=True, prepared=pq)
+    ref = hip_ops.point_in_tet(t, p, want_bary=True, pred_bxt=pred, want_hits=True)
+    assert np.array_equal(cond.cpu().numpy(), oracle.point_in_tet(tet, pts))
+    assert torch.equal(cond, ref[0]) and torch.equal(w, ref[1]) and torch.equal(occ, ref[2])
+    gw = torch.randn_like(w)
+    a = hip_ops.point_in_tet_bwd(t, p, cond, gw, hits=hits)[0]
+    b = hip_ops.point_in_tet_bwd(t, p, ref[0], gw, hits=ref[3])[0]
+    assert (a - b).abs().max() <= 1e-5 * b.abs().max()
+    cond2 = hip_ops.point_in_tet(t2, p, algo=2, prepared=pq2)
+    assert np.array_equal(cond2.cpu().numpy(), oracle.point_in_tet(tet2, pts))
+    with pytest.raises(RuntimeError):
+        hip_ops.point_in_tet(t, p, prepared=pq)                       # a prepare feeds exactly one scan
+    with pytest.raises(RuntimeError):
+        hip_ops.prepare_queries(p, t.shape[1], algo=1)
