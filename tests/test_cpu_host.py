@@ -196,3 +196,33 @@ def test_read_tetrahedron_mirror(tmp_path):
         read_tetrahedron(res=8, root=root)
     with pytest.raises(FileNotFoundError):
         read_tetrahedron(res=10, root=root, generate_missing=False)
+
+
+def test_integration_overlay_names_exist():
+    """every module of the overlay imports on a CPU-only host and exports the
+    reference's names (the operators themselves refuse to run without a GPU)."""
+    import importlib
+    names = {
+        "deftet_amd.layers.DefTet.check_condition_tetrahedron_base.utils": ["check_condition_f_base", "point_in_tet_bary", "paste_occ"],
+        "deftet_amd.layers.DefTet.tet_face_adj_m_idx.utils": ["tet_face_adj_m_f_idx"],
+        "deftet_amd.layers.DefTet.tet_analytic_distance_batch.utils": ["tet_analytic_distance_f_batch"],
+        "deftet_amd.layers.nearest_neighbor": ["NearestNeighbor"],
+        "deftet_amd.layers.DefTet.deftet": ["DefTet", "TetTopology"],
+        "deftet_amd.utils.lib.tet_point_adj.interface": ["Tet_point_adj"],
+        "deftet_amd.utils.lib.tet_face_adj.interface": ["Tet_face_adj"],
+        "deftet_amd.utils.lib.tet_adj_share.interface": ["Tet_adj_share"],
+        "deftet_amd.utils.lib.colaps_v.interface": ["Tet_point_adj"],
+        "deftet_amd.utils.tet_utils": ["tet_to_face"],
+        "deftet_amd.utils.dataloder_helper": ["read_tetrahedron"],
+        "deftet_amd.render.deftet_sparse_render": ["deftet_sparse_render", "peel2mask", "vertex2face", "perspective"],
+        "deftet_amd.render.prepare_for_wz": ["generate_edge", "generate_tet_edge_idx", "generate_subdivision", "generate_point_adj_idx",
+                                             "delete_tet", "tetweights2tetneighbourweights"],
+    }
+    for mod, attrs in names.items():
+        m = importlib.import_module(mod)
+        for a in attrs:
+            assert hasattr(m, a), "%s lacks %s" % (mod, a)
+    from deftet_amd.layers.DefTet.deftet import DefTet
+    for meth in ("check_tet_inside_sdfs", "gather_tet_pos", "get_boundary_index", "get_internal_index", "paste_occ", "volume_variance",
+                 "amips_energy", "edge_length", "tet_inverse_v"):
+        assert callable(getattr(DefTet, meth))
