@@ -33,6 +33,8 @@ SIGNATURES = {
     "deftet_paste_occ_bwd_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "deftet_check_sign_workspace_bytes": (_sz, [_i, _i, _i]),
     "deftet_check_sign_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
+    "deftet_check_sign_ragged_workspace_bytes": (_sz, [_i, _ll, _i, _i]),
+    "deftet_check_sign_ragged_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _ll, _i, _i, _i, _vp, _sz, _vp]),
     "deftet_tet_edges_i64": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _sz, _vp]),
     "deftet_subdivide_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "deftet_point_adj_table_i64": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _sz, _vp]),

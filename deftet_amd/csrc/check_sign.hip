@@ -66,6 +66,28 @@ __device__ __forceinline__ int cell_of(float x, float o, float inv, int G)
     return (int)f;
 }
 
+// one shape's slice of the vertex / face / record arrays.  Uniform batches: V and F per shape, ONE face
+// list shared by all shapes (Kaolin's signature); ragged batches (a different ground-truth mesh per shape,
+// as in layers/DefTet/deftet.py:44-47): offsets into concatenated arrays.
+struct Mesh {
+    long long vBase, fBase, rBase;
+    int V, F;
+};
+__device__ __forceinline__ Mesh mesh_of(int b, int V, int F, const int *__restrict__ vOff, const int *__restrict__ fOff)
+{
+    Mesh m;
+    if (fOff) {
+        m.vBase = vOff[b]; m.V = vOff[b + 1] - vOff[b];
+        m.fBase = fOff[b]; m.F = fOff[b + 1] - fOff[b];
+        m.rBase = m.fBase;
+    } else {
+        m.vBase = (long long)b * V; m.V = V;
+        m.fBase = 0; m.F = F;
+        m.rBase = (long long)b * F;
+    }
+    return m;
+}
+
 struct Box {
     float ylo, yhi, zlo, zhi;                           // enlarged (y,z) box of a regular face
 };
@@ -91,11 +113,15 @@ __device__ __forceinline__ int classify(const float *v1, const float *v2, const 
 // records + classification + per-block partial of the regular boxes; irregular faces are listed
 __global__ __launch_bounds__(256) void k_prep(const float *__restrict__ verts, const long long *__restrict__ faces, int V, int F,
                                               float4 *rec, signed char *kind, float4 *box, float *part, int *counters, int *irreg,
-                                              int *bad)
+                                              int *bad, const int *__restrict__ vOff, const int *__restrict__ fOff)
 {
     __shared__ float sh[4][4];
     const int b = blockIdx.y;
-    const float *vb = verts + (size_t)b * V * 3;
+    const Mesh M = mesh_of(b, V, F, vOff, fOff);
+    V = M.V;
+    F = M.F;
+    const float *vb = verts + (size_t)M.vBase * 3;
+    faces += (size_t)M.fBase * 3;
     float lo[2] = {INFINITY, INFINITY}, hi[2] = {-INFINITY, -INFINITY};
     for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < F; k += gridDim.x * blockDim.x) {
         long long i0 = faces[(size_t)k * 3], i1 = faces[(size_t)k * 3 + 1], i2 = faces[(size_t)k * 3 + 2];
@@ -109,20 +135,20 @@ __global__ __launch_bounds__(256) void k_prep(const float *__restrict__ verts, c
         const float e1x = v2[0] - v1[0], e1y = v2[1] - v1[1], e1z = v2[2] - v1[2];
         const float e2x = v3[0] - v1[0], e2y = v3[1] - v1[1], e2z = v3[2] - v1[2];
         const float a = e1y * (-e2z) + e1z * e2y;
-        float4 *r = rec + ((size_t)b * F + k) * 3;
+        float4 *r = rec + ((size_t)M.rBase + k) * 3;
         r[0] = make_float4(v1[0], v1[1], v1[2], e1x);
         r[1] = make_float4(e1y, e1z, e2x, e2y);
         r[2] = make_float4(e2z, a, 0.f, 0.f);
         if (!kind) continue;                                         // brute path: records only
         Box bx = {0.f, 0.f, 0.f, 0.f};
         const int kd = classify(v1, v2, v3, a, bx);
-        kind[(size_t)b * F + k] = (signed char)kd;
-        box[(size_t)b * F + k] = make_float4(bx.ylo, bx.yhi, bx.zlo, bx.zhi);
+        kind[(size_t)M.rBase + k] = (signed char)kd;
+        box[(size_t)M.rBase + k] = make_float4(bx.ylo, bx.yhi, bx.zlo, bx.zhi);
         if (kd == 1) {
             lo[0] = fminf(lo[0], bx.ylo); hi[0] = fmaxf(hi[0], bx.yhi);
             lo[1] = fminf(lo[1], bx.zlo); hi[1] = fmaxf(hi[1], bx.zhi);
         } else if (kd == 2) {
-            irreg[(size_t)b * F + atomicAdd(&counters[b * 2], 1)] = k;
+            irreg[(size_t)M.rBase + atomicAdd(&counters[b * 2], 1)] = k;
         }
     }
     if (!kind) return;
@@ -177,23 +203,25 @@ template <int PASS>
 __global__ __launch_bounds__(256) void k_bin(const signed char *kind, const float4 *__restrict__ box,
                                              const float *__restrict__ part, int nPart, int F, int G, float *dom, int *cellCount,
                                              const int *__restrict__ cellStart, int *cellFill, int *list, int *counters, int *irreg,
-                                             signed char *kindOut)
+                                             signed char *kindOut, const int *__restrict__ fOff)
 {
     const int b = blockIdx.y;
+    const Mesh M = mesh_of(b, 0, F, fOff, fOff);
+    F = M.F;
     const Dom d = reduce_domain(part + (size_t)b * kParts * 4, nPart, G);
     if (PASS == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
         dom[b * 4] = d.oy; dom[b * 4 + 1] = d.oz; dom[b * 4 + 2] = d.invy; dom[b * 4 + 3] = d.invz;
     }
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= F) return;
-    const size_t i = (size_t)b * F + k;
+    const size_t i = (size_t)M.rBase + k;
     if (kind[i] != 1) return;
     const float4 bx = box[i];
     const int cy0 = cell_of(bx.x, d.oy, d.invy, G), cy1 = cell_of(bx.y, d.oy, d.invy, G);
     const int cz0 = cell_of(bx.z, d.oz, d.invz, G), cz1 = cell_of(bx.w, d.oz, d.invz, G);
     const int span = (cy1 - cy0 + 1) * (cz1 - cz0 + 1);
     if (PASS == 0 && span > kMaxSpan) {
-        irreg[(size_t)b * F + atomicAdd(&counters[b * 2], 1)] = k;
+        irreg[(size_t)M.rBase + atomicAdd(&counters[b * 2], 1)] = k;
         kindOut[i] = 3;                                              // wide: handled with the irregular ones
         return;
     }
@@ -209,14 +237,17 @@ __global__ __launch_bounds__(256) void k_bin(const signed char *kind, const floa
 __global__ __launch_bounds__(256) void k_query(const float *__restrict__ points, const float4 *__restrict__ rec, int N, int F, int G,
                                                const float *__restrict__ dom, const int *__restrict__ cellStart,
                                                const int *__restrict__ list, const int *__restrict__ counters,
-                                               const int *__restrict__ irreg, unsigned char *out, int *count)
+                                               const int *__restrict__ irreg, unsigned char *out, int *count,
+                                               const int *__restrict__ fOff)
 {
     const int b = blockIdx.y;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
+    const Mesh M = mesh_of(b, 0, F, fOff, fOff);
+    F = M.F;
     const float *p = points + ((size_t)b * N + i) * 3;
     const float px = p[0], py = p[1], pz = p[2];
-    const float4 *rb = rec + (size_t)b * F * 3;
+    const float4 *rb = rec + (size_t)M.rBase * 3;
     int c = 0;
     const bool regular = fabsf(px) <= kBig && fabsf(py) <= kBig && fabsf(pz) <= kBig;     // NaN fails
     if (!regular) {                                                 // not certified for the grid: every face
@@ -239,7 +270,7 @@ __global__ __launch_bounds__(256) void k_query(const float *__restrict__ points,
         }
         const int nI = counters[b * 2];                              // wave-uniform: irregular + wide faces
         for (int q = 0; q < nI; ++q) {
-            const int k = irreg[(size_t)b * F + q];
+            const int k = irreg[(size_t)M.rBase + q];
             c += hit(rb[k * 3], rb[k * 3 + 1], rb[k * 3 + 2], px, py, pz);
         }
     }
@@ -249,14 +280,16 @@ __global__ __launch_bounds__(256) void k_query(const float *__restrict__ points,
 
 // brute force: the face index is wave-uniform, records arrive as scalar loads
 __global__ __launch_bounds__(256) void k_brute(const float *__restrict__ points, const float4 *__restrict__ rec, int N, int F,
-                                               unsigned char *out, int *count)
+                                               unsigned char *out, int *count, const int *__restrict__ fOff)
 {
     const int b = blockIdx.y;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i < N;
+    const Mesh M = mesh_of(b, 0, F, fOff, fOff);
+    F = M.F;
     const float *p = points + ((size_t)b * N + (live ? i : 0)) * 3;
     const float px = p[0], py = p[1], pz = p[2];
-    const float4 *rb = rec + (size_t)b * F * 3;
+    const float4 *rb = rec + (size_t)M.rBase * 3;
     int c = 0;
     for (int k = 0; k < F; ++k) c += hit(rb[k * 3], rb[k * 3 + 1], rb[k * 3 + 2], px, py, pz);
     if (live) {
@@ -283,24 +316,24 @@ struct Layout {
     void *scanTmp;
 };
 
-static Layout make_layout(int B, int F, int algo, void *ws, size_t wsBytes)
+static Layout make_layout(int B, int F, long long nRec, int algo, void *ws, size_t wsBytes)   // F: largest mesh, nRec: all faces
 {
     Layout L{};
     Arena A(ws, wsBytes);
-    L.rec = A.take<float4>((size_t)B * F * 3);
+    L.rec = A.take<float4>((size_t)nRec * 3);
     if (algo != 1) {
         L.G = pick_G(F);
         const size_t nc = (size_t)B * ((size_t)L.G * L.G + 1);
-        L.box = A.take<float4>((size_t)B * F);
-        L.kind = A.take<signed char>((size_t)B * F);
+        L.box = A.take<float4>((size_t)nRec);
+        L.kind = A.take<signed char>((size_t)nRec);
         L.part = A.take<float>((size_t)B * kParts * 4);
         L.dom = A.take<float>((size_t)B * 4);
-        L.irreg = A.take<int>((size_t)B * F);
+        L.irreg = A.take<int>((size_t)nRec);
         L.counters = A.take<int>((size_t)B * 2);
         L.cellCount = A.take<int>(nc);                               // counters, cellCount, cellFill are cleared together
         L.cellFill = A.take<int>(nc);
         L.cellStart = A.take<int>(nc);
-        L.list = A.take<int>((size_t)B * F * kMaxSpan);
+        L.list = A.take<int>((size_t)nRec * kMaxSpan);
         size_t need = 0;
         (void)rocprim::exclusive_scan(nullptr, need, L.cellCount, L.cellStart, 0, nc, rocprim::plus<int>(), (hipStream_t) nullptr);
         L.scanTmpBytes = need;
@@ -316,55 +349,81 @@ static Layout make_layout(int B, int F, int algo, void *ws, size_t wsBytes)
 using namespace deftet;
 using namespace deftet::cs;
 
-extern "C" size_t deftet_check_sign_workspace_bytes(int B, int F, int algo)
+// shared implementation: uniform batches (vOff == fOff == NULL: V, F per shape, one shared face list)
+// and ragged ones (concatenated meshes with int32 offsets [B+1], F = largest mesh, nRec = all faces)
+static int check_sign_run(const float *verts, const int64_t *faces, const int *vOff, const int *fOff, const float *points,
+                          uint8_t *inside, int32_t *count, int32_t *bad_flag, int B, int V, int F, long long nRec, int N, int algo,
+                          void *workspace, size_t workspace_bytes, void *stream_)
 {
-    if (B <= 0 || F < 0) return 0;
-    return make_layout(B, F, algo, nullptr, 0).bytes;
-}
-
-extern "C" int deftet_check_sign_f32(const float *verts, const int64_t *faces, const float *points, uint8_t *inside, int32_t *count,
-                                     int32_t *bad_flag, int B, int V, int F, int N, int algo, void *workspace, size_t workspace_bytes,
-                                     void *stream_)
-{
-    DEFTET_CHECK_ARG(B >= 0 && V >= 0 && F >= 0 && N >= 0, "negative size");
+    DEFTET_CHECK_ARG(B >= 0 && V >= 0 && F >= 0 && N >= 0 && nRec >= 0, "negative size");
     DEFTET_CHECK_ARG(algo == 0 || algo == 1, "unknown algo %d", algo);
     DEFTET_CHECK_ARG(B <= 65535, "n_batch=%d exceeds 65535", B);
-    DEFTET_CHECK_ARG((long long)F * kMaxSpan * B < 0x7FFFFFFFLL, "too many faces");
+    DEFTET_CHECK_ARG(nRec * kMaxSpan < 0x7FFFFFFFLL, "too many faces");
     if (B == 0 || N == 0) return DEFTET_OK;
     DEFTET_CHECK_ARG(points && inside && bad_flag, "null pointer");
     hipStream_t st = as_stream(stream_);
     DEFTET_HIP(hipMemsetAsync(bad_flag, 0, 4, st));
     const dim3 blk(256), gn((N + 255) / 256, B);
-    if (F == 0) {                                                    // no surface: everything is outside
+    if (F == 0 || nRec == 0) {                                       // no surface: everything is outside
         DEFTET_HIP(hipMemsetAsync(inside, 0, (size_t)B * N, st));
         if (count) DEFTET_HIP(hipMemsetAsync(count, 0, (size_t)B * N * 4, st));
         return DEFTET_OK;
     }
     DEFTET_CHECK_ARG(verts && faces, "null mesh");
     DEFTET_CHECK_ARG(workspace && ((uintptr_t)workspace & 255) == 0, "workspace null or not 256-byte aligned");
-    Layout L = make_layout(B, F, algo, workspace, workspace_bytes);
+    Layout L = make_layout(B, F, nRec, algo, workspace, workspace_bytes);
     DEFTET_CHECK_ARG(L.bytes <= workspace_bytes, "workspace too small: need %zu bytes, got %zu", L.bytes, workspace_bytes);
     int pb = (F + 255) / 256;
     if (pb > kParts) pb = kParts;
     if (algo == 1) {
         DEFTET_LAUNCH(k_prep, dim3(pb, B), blk, st, verts, (const long long *)faces, V, F, L.rec, (signed char *)nullptr,
-                      (float4 *)nullptr, (float *)nullptr, (int *)nullptr, (int *)nullptr, bad_flag);
-        DEFTET_LAUNCH(k_brute, gn, blk, st, points, (const float4 *)L.rec, N, F, inside, count);
+                      (float4 *)nullptr, (float *)nullptr, (int *)nullptr, (int *)nullptr, bad_flag, vOff, fOff);
+        DEFTET_LAUNCH(k_brute, gn, blk, st, points, (const float4 *)L.rec, N, F, inside, count, fOff);
         return DEFTET_OK;
     }
     const size_t nc = (size_t)B * ((size_t)L.G * L.G + 1);
     DEFTET_HIP(hipMemsetAsync(L.counters, 0, (size_t)((char *)L.cellStart - (char *)L.counters), st));   // counters, cellCount, cellFill
     DEFTET_LAUNCH(k_prep, dim3(pb, B), blk, st, verts, (const long long *)faces, V, F, L.rec, L.kind, L.box, L.part, L.counters, L.irreg,
-                  bad_flag);
+                  bad_flag, vOff, fOff);
     const dim3 gf((F + 255) / 256, B);
     DEFTET_LAUNCH(k_bin<0>, gf, blk, st, (const signed char *)L.kind, (const float4 *)L.box, (const float *)L.part, pb, F, L.G, L.dom,
-                  L.cellCount, (const int *)nullptr, (int *)nullptr, (int *)nullptr, L.counters, L.irreg, L.kind);
+                  L.cellCount, (const int *)nullptr, (int *)nullptr, (int *)nullptr, L.counters, L.irreg, L.kind, fOff);
     size_t need = L.scanTmpBytes;
     hipError_t e = rocprim::exclusive_scan(L.scanTmp, need, L.cellCount, L.cellStart, 0, nc, rocprim::plus<int>(), st);
     if (e != hipSuccess) return set_error(DEFTET_ELAUNCH, "rocprim::exclusive_scan: %s", hipGetErrorString(e));
     DEFTET_LAUNCH(k_bin<1>, gf, blk, st, (const signed char *)L.kind, (const float4 *)L.box, (const float *)L.part, pb, F, L.G, L.dom,
-                  L.cellCount, (const int *)L.cellStart, L.cellFill, L.list, L.counters, L.irreg, L.kind);
+                  L.cellCount, (const int *)L.cellStart, L.cellFill, L.list, L.counters, L.irreg, L.kind, fOff);
     DEFTET_LAUNCH(k_query, gn, blk, st, points, (const float4 *)L.rec, N, F, L.G, (const float *)L.dom, (const int *)L.cellStart,
-                  (const int *)L.list, (const int *)L.counters, (const int *)L.irreg, inside, count);
+                  (const int *)L.list, (const int *)L.counters, (const int *)L.irreg, inside, count, fOff);
     return DEFTET_OK;
+}
+
+extern "C" size_t deftet_check_sign_workspace_bytes(int B, int F, int algo)
+{
+    if (B <= 0 || F < 0) return 0;
+    return make_layout(B, F, (long long)B * F, algo, nullptr, 0).bytes;
+}
+
+extern "C" int deftet_check_sign_f32(const float *verts, const int64_t *faces, const float *points, uint8_t *inside, int32_t *count,
+                                     int32_t *bad_flag, int B, int V, int F, int N, int algo, void *workspace, size_t workspace_bytes,
+                                     void *stream_)
+{
+    return check_sign_run(verts, faces, nullptr, nullptr, points, inside, count, bad_flag, B, V, F, (long long)B * F, N, algo, workspace,
+                          workspace_bytes, stream_);
+}
+
+extern "C" size_t deftet_check_sign_ragged_workspace_bytes(int B, long long n_face_total, int n_face_max, int algo)
+{
+    if (B <= 0 || n_face_total < 0 || n_face_max < 0) return 0;
+    return make_layout(B, n_face_max, n_face_total, algo, nullptr, 0).bytes;
+}
+
+extern "C" int deftet_check_sign_ragged_f32(const float *verts_cat, const int32_t *vert_offsets, const int64_t *faces_cat,
+                                            const int32_t *face_offsets, const float *points, uint8_t *inside, int32_t *count,
+                                            int32_t *bad_flag, int B, long long n_face_total, int n_face_max, int N, int algo,
+                                            void *workspace, size_t workspace_bytes, void *stream_)
+{
+    DEFTET_CHECK_ARG(B == 0 || (vert_offsets && face_offsets), "null offset arrays");
+    return check_sign_run(verts_cat, faces_cat, vert_offsets, face_offsets, points, inside, count, bad_flag, B, 0, n_face_max,
+                          n_face_total, N, algo, workspace, workspace_bytes, stream_);
 }

@@ -376,6 +376,36 @@ def check_sign(verts_bxvx3, faces_fx3, points_bxnx3, brute=False, return_count=F
     return (out.bool(), cnt) if return_count else out.bool()
 
 
+def check_sign_ragged(verts_list, faces_list, points_bxnx3, brute=False, return_count=False, check=False):
+    """check_sign for a different mesh per shape in ONE launch sequence: verts_list[b] f32 [V_b,3] (or
+    [1,V_b,3]), faces_list[b] int [F_b,3] with indices local to mesh b, points [B,N,3] -> bool [B,N]."""
+    _lib.require_gpu(points_bxnx3, *verts_list, *faces_list)
+    lib = _lib.load()
+    p = _f32c(points_bxnx3)
+    B, N, dev = p.shape[0], p.shape[1], p.device
+    if len(verts_list) != B or len(faces_list) != B:
+        raise RuntimeError("check_sign_ragged: one mesh per shape expected")
+    vs = [_f32c(v).reshape(-1, 3) for v in verts_list]
+    fs = [f.long().reshape(-1, 3) for f in faces_list]
+    v_off = torch.tensor([0] + list(np.cumsum([v.shape[0] for v in vs])), dtype=torch.int32, device=dev)
+    f_cnt = [f.shape[0] for f in fs]
+    f_off = torch.tensor([0] + list(np.cumsum(f_cnt)), dtype=torch.int32, device=dev)
+    v_cat, f_cat = torch.cat(vs, 0).contiguous(), torch.cat(fs, 0).contiguous()
+    out = torch.empty(B, N, device=dev, dtype=torch.uint8)
+    cnt = torch.empty(B, N, device=dev, dtype=torch.int32) if return_count else None
+    bad = torch.zeros(1, device=dev, dtype=torch.int32)
+    algo = 1 if brute else 0
+    ftot, fmax = int(sum(f_cnt)), int(max(f_cnt) if f_cnt else 0)
+    with torch.cuda.device(dev):
+        ws = _lib.workspace(dev, lib.deftet_check_sign_ragged_workspace_bytes(B, ftot, fmax, algo))
+        _lib.check(lib.deftet_check_sign_ragged_f32(_lib.ptr(v_cat), _lib.ptr(v_off), _lib.ptr(f_cat), _lib.ptr(f_off), _lib.ptr(p),
+                                                    _lib.ptr(out), _lib.ptr(cnt), _lib.ptr(bad), B, ftot, fmax, N, algo, _lib.ptr(ws),
+                                                    ws.numel(), _lib.current_stream(dev)), "deftet_check_sign_ragged_f32")
+    if check and int(bad.item()):
+        raise IndexError("check_sign_ragged: face index outside its mesh")
+    return (out.bool(), cnt) if return_count else out.bool()
+
+
 # --------------------------------------------------------------------------------- N3 render-side rebuilds
 def _i64_tets(tet_tx4):
     t = tet_tx4 if tet_tx4.dtype == torch.int64 else tet_tx4.long()

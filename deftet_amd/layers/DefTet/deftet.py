@@ -77,12 +77,8 @@ class DefTet(nn.Module):
                 # one launch sequence for the whole batch (faces shared, per-shape vertices)
                 v = torch.cat([x.reshape(1, -1, 3) for x in verts], dim=0)
                 return hip_ops.check_sign(v, faces[0][0], center, check=False).unsqueeze(-1).float()
-            occupancy = []
-            for b, (v, f) in enumerate(zip(verts, faces)):              # per-shape meshes, like the reference's loop
-                result = hip_ops.check_sign(v.reshape(1, -1, 3), f[0], center[b:b + 1], check=False)
-                occupancy.append(result.unsqueeze(-1))
-            occupancy = torch.cat(occupancy, dim=0).float()
-        return occupancy
+            # a different ground-truth mesh per shape (the reference loops over the batch): one ragged call
+            return hip_ops.check_sign_ragged(list(verts), [f[0] for f in faces], center).unsqueeze(-1).float()
 
     # --- A7
     def get_boundary_index(self, tet_face_fx3, tet_idx_fx2, occ_bxn):

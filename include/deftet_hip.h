@@ -193,6 +193,16 @@ size_t deftet_check_sign_workspace_bytes(int n_batch, int n_face, int algo);
 int deftet_check_sign_f32(const float *verts, const int64_t *faces, const float *points, uint8_t *inside,
                           int32_t *count, int32_t *bad_flag, int n_batch, int n_vertex, int n_face, int n_point,
                           int algo, void *workspace, size_t workspace_bytes, void *stream);
+/* The same for a DIFFERENT mesh per shape (layers/DefTet/deftet.py:44-47 loops over the batch):
+ * verts_cat f32 [sum V_b,3] and faces_cat int64 [sum F_b,3] (vertex indices local to their shape) are
+ * the meshes back to back, vert_offsets / face_offsets int32 [B+1] (device) their row offsets;
+ * n_face_total = sum F_b, n_face_max = max F_b.  One launch sequence for the whole batch. */
+size_t deftet_check_sign_ragged_workspace_bytes(int n_batch, long long n_face_total, int n_face_max, int algo);
+int deftet_check_sign_ragged_f32(const float *verts_cat, const int32_t *vert_offsets, const int64_t *faces_cat,
+                                 const int32_t *face_offsets, const float *points, uint8_t *inside,
+                                 int32_t *count, int32_t *bad_flag, int n_batch, long long n_face_total,
+                                 int n_face_max, int n_point, int algo,
+                                 void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------
  * N3  render-side geometry rebuilds of diff_render/diftet_6_subdiv/3_model/

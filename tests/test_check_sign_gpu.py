@@ -113,3 +113,40 @@ def test_grid_equals_brute_full_size(cuda):
     b, cb = hip_ops.check_sign(v, f, p, brute=True, return_count=True)
     assert torch.equal(ca, cb)
     assert np.array_equal(a.cpu().numpy(), np.broadcast_to(occ, (2, tets.shape[0])))
+
+
+def test_ragged_batch_of_different_meshes(cuda, oracle):
+    """a different ground-truth mesh per shape (layers/DefTet/deftet.py:44-47) in one launch sequence:
+    crossing counts equal the per-shape oracle, for the binned and the brute path"""
+    from deftet_amd import hip_ops
+    from deftet_amd.layers.DefTet.deftet import DefTet
+    meshes = []
+    for res, r in ((8, 0.3), (12, 0.25), (6, 0.35)):
+        pos, faces, tets, occ = closed_surface(res, 1, r)
+        meshes.append((pos[0], faces, tets, occ))
+    sv, sf, _ = _soup(3)
+    meshes.append((sv[0], sf, None, None))
+    B, N = len(meshes), 3000
+    rng = np.random.default_rng(9)
+    pts = (rng.random((B, N, 3)) - 0.5).astype(np.float32)
+    pts[3, :5] = np.nan
+    vl = [torch.from_numpy(m[0]).to(cuda) for m in meshes]
+    fl = [torch.from_numpy(m[1]).to(cuda) for m in meshes]
+    p = torch.from_numpy(pts).to(cuda)
+    for brute in (False, True):
+        got, cnt = hip_ops.check_sign_ragged(vl, fl, p, brute=brute, return_count=True)
+        for b, m in enumerate(meshes):
+            with np.errstate(all="ignore"):
+                want, cw = oracle.check_sign(m[0][None], m[1], pts[b:b + 1], return_count=True)
+            assert np.array_equal(cnt[b].cpu().numpy(), cw[0]), (brute, b)
+            assert np.array_equal(got[b].cpu().numpy(), want[0])
+    with pytest.raises(IndexError):
+        hip_ops.check_sign_ragged(vl, [fl[0], fl[1], fl[2], torch.tensor([[0, 1, 10 ** 6]], device=cuda)], p, check=True)
+    # the DefTet mirror with per-shape meshes: centroids of each shape's own grid
+    m3 = meshes[:3]
+    T = min(x[2].shape[0] for x in m3)
+    tet = torch.stack([torch.from_numpy(x[0][x[2][:T]]) for x in m3]).to(cuda)
+    occ_m = DefTet(device=cuda).check_tet_inside_sdfs(tet, ([v[None] for v in vl[:3]], [[f] for f in fl[:3]]))
+    assert occ_m.shape == (3, T, 1)
+    for b, x in enumerate(m3):
+        assert np.array_equal(occ_m[b, :, 0].cpu().numpy() > 0.5, x[3][:T])
