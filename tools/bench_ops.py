@@ -208,6 +208,17 @@ def main():
     emit(op="tet_energies fwd+bwd", res=res, batch=Be, n_tet=T, gpu_ms=round(tf_ * 1e3, 3), torch_same_gpu_ms=round(tt_ * 1e3, 3),
          speedup_vs_torch=round(tt_ / tf_, 1), algorithmic_mb=round(Be * T * 96 / 1e6, 1))
 
+    # ---- A1 forward: the binned path against the brute-force HIP formulation (the algorithmic equivalent of the
+    # reference kernel: every query meets every tet in index order), BASELINE configs[2]
+    Bp, Qp = (2, 20000) if quick else (8, 100000)
+    tetp = torch.from_numpy(grids.gather_tets(grids.jittered_positions(verts, res, Bp), tets)).to(dev)
+    ptsp = torch.from_numpy(grids.random_queries(Bp, Qp)).to(dev)
+    t_bin = gpu_time(lambda: hip_ops.point_in_tet(tetp, ptsp, want_bary=True), reps=10)
+    t_bru = gpu_time(lambda: hip_ops.point_in_tet(tetp, ptsp, want_bary=True, algo=1), reps=2, warm=1)
+    emit(op="point_in_tet forward (index + weights)", res=res, batch=Bp, n_tet=T, n_query=Qp, binned_ms=round(t_bin * 1e3, 3),
+         brute_hip_ms=round(t_bru * 1e3, 2), speedup=round(t_bru / t_bin, 1),
+         brute_pairs_per_s=round(Bp * T * Qp / t_bru / 1e12, 2), unit="T tet-point tests/s (brute)")
+
 
 if __name__ == "__main__":
     main()
