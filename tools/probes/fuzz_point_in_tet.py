@@ -1,0 +1,56 @@
+"""Fuzz: binned point-in-tet variants and both backwards against the independent brute-force HIP kernel
+on random sizes / tet soups / query patterns.   python tools/probes/fuzz_point_in_tet.py [seconds]"""
+import os, sys, time
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from deftet_amd import hip_ops
+
+dev = torch.device("cuda:0")
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(int(os.environ.get("FUZZ_SEED", "1")))
+g = torch.Generator(device=dev).manual_seed(7)
+t_end = time.time() + budget
+n = 0
+while time.time() < t_end:
+    B = int(rng.integers(1, 5)); T = int(rng.choice([1, 2, 5, 63, 64, 65, 300, 1000, 3000, 20000])); Q = int(rng.choice([1, 2, 63, 64, 65, 255, 256, 257, 2047, 2048, 2049, 6000, 30000]))
+    kind = rng.integers(0, 5)
+    scale = float(rng.choice([1e-3, 1.0, 1.0, 1.0, 50.0]))
+    c = torch.rand(B, T, 1, 3, device=dev, generator=g) - 0.5
+    size = float(rng.choice([0.02, 0.1, 0.4, 1.5]))
+    tet = (c + size * (torch.rand(B, T, 4, 3, device=dev, generator=g) - 0.5)) * scale
+    if kind == 1:                                        # degenerate / non-finite tets mixed in
+        m = torch.rand(B, T, device=dev, generator=g)
+        tet[m < 0.05] = tet[m < 0.05][:, :1].expand(-1, 4, -1)            # collapsed
+        tet[(m > 0.05) & (m < 0.07)] = float("nan")
+        tet[(m > 0.07) & (m < 0.09)] *= 1e7
+    pts = (torch.rand(B, Q, 3, device=dev, generator=g) - 0.5) * scale * 1.1
+    if kind == 2:
+        pts = pts * 1e-3 + 0.1 * scale                   # one cell
+    if kind == 3:
+        pts[..., int(rng.integers(0, 3))] = 0.03 * scale  # a plane
+    if kind == 4:
+        k = max(1, Q // 20)
+        pts[:, :k] = float("nan"); pts[:, k:2 * k] = 3e6 * scale
+    ref = hip_ops.point_in_tet(tet, pts, algo=1)
+    for algo in (0, 2, 3):
+        got = hip_ops.point_in_tet(tet, pts, algo=algo)
+        if not torch.equal(got, ref):
+            bad = (got != ref).nonzero()[0].tolist()
+            print("MISMATCH algo=%d B=%d T=%d Q=%d kind=%d scale=%g size=%g at %s: %s vs %s" % (algo, B, T, Q, kind, scale, size, bad, got[tuple(bad)].item(), ref[tuple(bad)].item()), flush=True)
+            sys.exit(1)
+    pred = torch.rand(B, T, device=dev, generator=g)
+    cond, w, occ, hits = hip_ops.point_in_tet(tet, pts, want_bary=True, pred_bxt=pred, want_hits=True)
+    assert torch.equal(cond, ref)
+    gw = torch.randn(B, Q, 4, device=dev, generator=g); go = torch.randn(B, Q, device=dev, generator=g)
+    a = hip_ops.point_in_tet_bwd(tet, pts, cond, gw, grad_occ=go, hits=hits)
+    b = hip_ops.point_in_tet_bwd(tet, pts, cond, gw, grad_occ=go)
+    for x, y in ((a[0], b[0]), (a[2], b[2])):
+        f = torch.isfinite(x) & torch.isfinite(y)
+        if f.any():
+            err = ((x - y)[f]).abs().max().item(); ref_mag = y[f].abs().max().item()
+            if err > 2e-3 * max(ref_mag, 1e-30):
+                print("BACKWARD MISMATCH B=%d T=%d Q=%d kind=%d: err %g of %g" % (B, T, Q, kind, err, ref_mag), flush=True)
+                sys.exit(1)
+    n += 1
+print("fuzz ok: %d random cases" % n, flush=True)
