@@ -57,6 +57,8 @@ SIGNATURES = {
     "deftet_colaps_v_f32": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "deftet_colaps_v_host": (_i, [_vp, _vp, _vp, _vp, _i]),
     "deftet_tet_to_face_i32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "deftet_tet_neighbours_workspace_bytes": (_sz, [_i]),
+    "deftet_tet_neighbours_i64": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "deftet_boundary_index_workspace_bytes": (_sz, [_i, _i]),
     "deftet_boundary_index_i64": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "deftet_tet_energies_workspace_bytes": (_sz, [_i]),

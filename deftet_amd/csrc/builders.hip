@@ -569,6 +569,64 @@ static int check_common(const void *tet, int n_point, int n_tet, void *ws)
 
 static inline dim3 grid_for(size_t n) { return dim3((unsigned)((n + 255) / 256)); }
 
+
+// ------------------------------------------------------------------------------------
+// Per-tet neighbour table and per-tet-face owner table from the unique-face table of
+// deftet_tet_to_face_i32(with_boundary=1):
+//   tet_neighbour_idx [T,4]  diff_render/diftet_6_subdiv/3_model/utils_tetsv.py:41-58 — the shared faces are
+//       visited in first-seen order and each appends the partner to both owners' rows, so a tet's row lists
+//       its partners in ascending order of the shared face's position in the unique-face table; -1 padded;
+//   tet_face_tetidx [4T,2]   utils/tet_utils.py:259-300 (tet_to_face_withtet): for global face 4t+i the owners
+//       of its key in insertion order, a lone owner padded with 0.
+// One lane per unique face scatters into per-(tet, local face) slots (each slot belongs to exactly one face
+// key), then one lane per tet orders its four slots with a sorting network.
+// ------------------------------------------------------------------------------------
+// slot filler for the face position = 0x7F7F7F7F (memset pattern): sorts after every real face position
+
+__global__ __launch_bounds__(256) void k_owner_scatter(const long long *__restrict__ tetidx_fx2, const long long *__restrict__ tetfaceidx_fx2,
+                                                       int F, int *slotFace, int *slotNbr, long long *withtet_4tx2)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    const long long t0 = tetidx_fx2[2 * f], t1 = tetidx_fx2[2 * f + 1];
+    const long long l0 = tetfaceidx_fx2[2 * f], l1 = tetfaceidx_fx2[2 * f + 1];
+    const long long g0 = t0 * 4 + l0;
+    if (t1 >= 0) {
+        const long long g1 = t1 * 4 + l1;
+        slotFace[g0] = f; slotNbr[g0] = (int)t1;
+        slotFace[g1] = f; slotNbr[g1] = (int)t0;
+        if (withtet_4tx2) {
+            withtet_4tx2[2 * g0] = t0; withtet_4tx2[2 * g0 + 1] = t1;
+            withtet_4tx2[2 * g1] = t0; withtet_4tx2[2 * g1 + 1] = t1;
+        }
+    } else if (withtet_4tx2) {                                           // boundary face: single owner, padded with 0 (:293-294)
+        withtet_4tx2[2 * g0] = t0; withtet_4tx2[2 * g0 + 1] = 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_neighbour_rows(const int *__restrict__ slotFace, const int *__restrict__ slotNbr, int T,
+                                                        long long *nbr_tx4)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    const int4 f4 = reinterpret_cast<const int4 *>(slotFace)[t], n4 = reinterpret_cast<const int4 *>(slotNbr)[t];
+    // order the four slots by (position of the face in the unique-face table, local face id); the local id only
+    // matters when one tet owns both sides of a face (repeated vertices): the reference then appends the tet to
+    // its own row twice in a row
+    unsigned long long key[4] = {((unsigned long long)(unsigned)f4.x << 2) | 0u, ((unsigned long long)(unsigned)f4.y << 2) | 1u,
+                                 ((unsigned long long)(unsigned)f4.z << 2) | 2u, ((unsigned long long)(unsigned)f4.w << 2) | 3u};
+    int nb[4] = {n4.x, n4.y, n4.z, n4.w};
+#define DEFTET_CSWAP_KV(a, b)                                                                     \
+    if (key[b] < key[a]) {                                                                        \
+        const unsigned long long tk_ = key[a]; key[a] = key[b]; key[b] = tk_;                     \
+        const int tn_ = nb[a]; nb[a] = nb[b]; nb[b] = tn_;                                        \
+    }
+    DEFTET_CSWAP_KV(0, 1) DEFTET_CSWAP_KV(2, 3) DEFTET_CSWAP_KV(0, 2) DEFTET_CSWAP_KV(1, 3) DEFTET_CSWAP_KV(1, 2)
+#undef DEFTET_CSWAP_KV
+#pragma unroll
+    for (int i = 0; i < 4; ++i) nbr_tx4[(size_t)t * 4 + i] = (long long)nb[i];     // unfilled slots hold -1 (memset 0xFF) and sort last
+}
+
 }  // namespace bld
 }  // namespace deftet
 
@@ -635,6 +693,31 @@ extern "C" int deftet_tet_to_face_i32(const int32_t *tet, int64_t *face_fx3, int
     DEFTET_LAUNCH(k_face_emit, grid_for(n), dim3(256), st, tet, gsize, second, f_in, p_in, f_bd, p_bd, f_mu, p_mu, (int)n,
                   (long long *)face_fx3, (long long *)tetidx_fx2, (long long *)tetfaceidx_fx2, (long long *)boundary_fx3,
                   counts);
+    return DEFTET_OK;
+}
+
+extern "C" size_t deftet_tet_neighbours_workspace_bytes(int n_tet)
+{
+    return align_up((size_t)(n_tet > 0 ? n_tet : 0) * 16, 256) * 2 + 256;
+}
+
+extern "C" int deftet_tet_neighbours_i64(const int64_t *tetidx_fx2, const int64_t *tetfaceidx_fx2, int n_face, int T,
+                                         int64_t *nbr_tx4, int64_t *withtet_4tx2, void *workspace, size_t wsb, void *stream_)
+{
+    DEFTET_CHECK_ARG(n_face >= 0 && T >= 0, "negative size");
+    if (T == 0) return DEFTET_OK;
+    DEFTET_CHECK_ARG(nbr_tx4, "null nbr_tx4");
+    DEFTET_CHECK_ARG(n_face == 0 || (tetidx_fx2 && tetfaceidx_fx2), "null face table");
+    DEFTET_CHECK_ARG(workspace && ((uintptr_t)workspace & 255) == 0 && wsb >= deftet_tet_neighbours_workspace_bytes(T), "workspace null, misaligned or too small");
+    hipStream_t st = as_stream(stream_);
+    Arena A(workspace, wsb);
+    int *slotFace = A.take<int>((size_t)T * 4), *slotNbr = A.take<int>((size_t)T * 4);
+    DEFTET_HIP(hipMemsetAsync(slotFace, 0x7F, (size_t)T * 16, st));
+    DEFTET_HIP(hipMemsetAsync(slotNbr, 0xFF, (size_t)T * 16, st));
+    if (n_face > 0)
+        DEFTET_LAUNCH(k_owner_scatter, grid_for((size_t)n_face), dim3(256), st, (const long long *)tetidx_fx2, (const long long *)tetfaceidx_fx2,
+                      n_face, slotFace, slotNbr, (long long *)withtet_4tx2);
+    DEFTET_LAUNCH(k_neighbour_rows, grid_for((size_t)T), dim3(256), st, slotFace, slotNbr, T, (long long *)nbr_tx4);
     return DEFTET_OK;
 }
 

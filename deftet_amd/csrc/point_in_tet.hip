@@ -1641,9 +1641,10 @@ extern "C" int deftet_point_in_tet_bwd_f32(const float *tet, const float *pts, c
     DEFTET_CHECK_ARG(B <= 65535, "n_batch=%d exceeds 65535", B);
     DEFTET_CHECK_ARG((grad_occ == nullptr) == (grad_pred == nullptr), "grad_occ and grad_pred must be given together");
     hipStream_t st = as_stream(stream_);
-    if (B == 0 || T == 0) return DEFTET_OK;
+    if (B == 0) return DEFTET_OK;
+    if (grad_pts && Q > 0) DEFTET_HIP(hipMemsetAsync(grad_pts, 0, (size_t)B * Q * 12, st));   // also when T == 0: no tet, zero gradient
+    if (T == 0) return DEFTET_OK;
     DEFTET_CHECK_ARG(grad_tet && ((uintptr_t)grad_tet & 15) == 0, "grad_tet null or not 16-byte aligned");
-    if (grad_pts && Q > 0) DEFTET_HIP(hipMemsetAsync(grad_pts, 0, (size_t)B * Q * 12, st));
     if (Q == 0) {
         if (!accumulate) {
             DEFTET_HIP(hipMemsetAsync(grad_tet, 0, (size_t)B * T * 48, st));

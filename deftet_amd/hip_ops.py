@@ -32,6 +32,7 @@ class PreparedQueries:
 
     def __init__(self, pts, n_tet, algo):
         self.pts, self.n_tet, self.algo = pts, int(n_tet), int(algo)
+        self.version = pts._version                    # the sorted copy is a snapshot: in-place updates of pts invalidate it
         self.workspace = None
         self.event = None
         self.consumed = False
@@ -86,6 +87,8 @@ def point_in_tet(tet_bxtx4x3, pts_bxqx3, want_bary=False, algo=PIT_AUTO, pred_bx
             if prepared.consumed or prepared.algo != algo or prepared.n_tet != T or prepared.pts.data_ptr() != pts.data_ptr() \
                     or prepared.pts.shape != pts.shape:
                 raise RuntimeError("point_in_tet: `prepared` was made for other points / sizes / algo, or was already used")
+            if prepared.version != pts._version:
+                raise RuntimeError("point_in_tet: the points were modified in place after prepare_queries (stale sorted copy)")
             cur = torch.cuda.current_stream(dev)
             cur.wait_event(prepared.event)                             # the sort may have run on another stream
             ws = prepared.workspace
@@ -288,6 +291,26 @@ def tet_to_face(tet_list, n_point, device, with_boundary=False):
                                               _lib.current_stream(dev)), "deftet_tet_to_face_i32")
     nf, nb, nm = (int(x) for x in counts.tolist())
     return f3[:nf], t2[:nf], tf2[:nf], b3[:nb], nm
+
+
+def tet_neighbours(tet_list, n_point, device, want_face_owners=False):
+    """tet_neighbour_idx int64 [T,4] (-1 padded) — the T x 4 table utils_tetsv.tet_adj_share returns
+    (diff_render/diftet_6_subdiv/3_model/utils_tetsv.py:16-75) — and, with want_face_owners, also the
+    [4T,2] owner table of utils/tet_utils.py:259-300 (tet_to_face_withtet).  Raises ValueError when a face
+    has more than two owners, as both reference functions do."""
+    lib = _lib.load()
+    dev = torch.device(device)
+    f3, t2, tf2, _b3, n_multi = tet_to_face(tet_list, n_point, dev, with_boundary=True)
+    if n_multi:
+        raise ValueError("%d faces are shared by more than two tetrahedra" % n_multi)
+    T = int(torch.as_tensor(tet_list).shape[0])
+    nbr = torch.empty(T, 4, dtype=torch.int64, device=dev)
+    owners = torch.empty(T * 4, 2, dtype=torch.int64, device=dev) if want_face_owners else None
+    with torch.cuda.device(dev):
+        ws = _lib.workspace(dev, lib.deftet_tet_neighbours_workspace_bytes(T))
+        _lib.check(lib.deftet_tet_neighbours_i64(_lib.ptr(t2), _lib.ptr(tf2), int(t2.shape[0]), T, _lib.ptr(nbr), _lib.ptr(owners),
+                                                 _lib.ptr(ws), ws.numel(), _lib.current_stream(dev)), "deftet_tet_neighbours_i64")
+    return (nbr, owners) if want_face_owners else nbr
 
 
 # --------------------------------------------------------------------------------- A8 / A9 / A10 surface ops

@@ -11,13 +11,15 @@
     check_tet_inside_sdfs                     (:33-49)    -> deftet_check_sign_f32 (Kaolin's
                                                              check_sign restated; parity unpinned)
 
-`forward_surface_align` itself (network glue around these calls) is not provided; the pieces it
-composes are all here or in deftet_amd.layers / deftet_amd.utils.
+    forward_surface_align / forward           (:51-184)   composed from the operators above plus the surface
+                                                             terms in deftet_amd/surface_losses.py (A8/A9/A10); same
+                                                             arguments, same tuple order as the reference
+    laplacian_sparse                          (:340-343)  torch.sparse.mm (vendor SpMM)
 """
 import torch
 import torch.nn as nn
 
-from deftet_amd import hip_ops
+from deftet_amd import hip_ops, surface_losses
 from deftet_amd.layers.DefTet.check_condition_tetrahedron_base.utils import check_condition_f_base, paste_occ
 
 EPS = 1e-10
@@ -61,18 +63,29 @@ class DefTet(nn.Module):
 
     # --- N2: tet_bxfx4x3 from vertex positions (deftet.py:65-68)
     def gather_tet_pos(self, vertice_pos, tetrahedron_bxfx4):
-        key = (tetrahedron_bxfx4.data_ptr(), tuple(tetrahedron_bxfx4.shape), tetrahedron_bxfx4._version, vertice_pos.shape[1])
-        if getattr(self, "_topo_key", None) != key:
-            self._topo = TetTopology(tetrahedron_bxfx4, vertice_pos.shape[1])
-            self._topo_key = key
-        return self._topo.gather(vertice_pos)
+        # Cache of the incidence CSR.  Fast path: the very same index tensor object, unmodified (a reference is
+        # kept, so its storage cannot be recycled for another tensor behind our back).  Otherwise — e.g.
+        # nn.DataParallel scatters a fresh copy every step — the CONTENT is compared with the cached indices
+        # (one small kernel + sync; the CSR rebuild it avoids is 40x that); never address/shape alone.
+        topo = getattr(self, "_topo", None)
+        same = (topo is not None and topo.n_vertex == vertice_pos.shape[1] and self._topo_src is tetrahedron_bxfx4
+                and self._topo_version == tetrahedron_bxfx4._version)
+        if not same and topo is not None and topo.n_vertex == vertice_pos.shape[1] \
+                and topo.tet_idx.shape == tetrahedron_bxfx4.shape and topo.tet_idx.device == tetrahedron_bxfx4.device:
+            same = bool(torch.equal(topo.tet_idx, tetrahedron_bxfx4.long()))
+        if not same:
+            topo = self._topo = TetTopology(tetrahedron_bxfx4, vertice_pos.shape[1])
+        self._topo_src, self._topo_version = tetrahedron_bxfx4, tetrahedron_bxfx4._version
+        return topo.gather(vertice_pos)
 
     # --- N1: GT occupancy of the tet centroids (deftet.py:33-49)
     def check_tet_inside_sdfs(self, tet_bxfx4x3, mesh_list):
         verts, faces = mesh_list[0], mesh_list[1]
         with torch.no_grad():
             center = torch.mean(tet_bxfx4x3, dim=2)                     # [B,T,3], same reduction as per shape
-            same_mesh = all(f[0] is faces[0][0] for f in faces) and all(v.shape == verts[0].shape for v in verts)
+            f0 = faces[0][0]                                            # f[0] makes a new view object each time: compare storage
+            same_mesh = all(f[0].data_ptr() == f0.data_ptr() and f[0].shape == f0.shape and f[0].stride() == f0.stride()
+                            for f in faces) and all(v.shape == verts[0].shape for v in verts)
             if same_mesh and len(verts) == tet_bxfx4x3.shape[0]:
                 # one launch sequence for the whole batch (faces shared, per-shape vertices)
                 v = torch.cat([x.reshape(1, -1, 3) for x in verts], dim=0)
@@ -112,6 +125,65 @@ class DefTet(nn.Module):
         forward_surface_align (:82-83,:105) needs per step."""
         out = hip_ops.tet_energies(tet_bxfx4x3, inverse_v, pow_v=self.pow, pow_e=self.pow, scale=20.0)
         return out[:, 0], out[:, 1], out[:, 2]
+
+    # --- the per-step composition (deftet.py:51-130): one fused launch sequence per operator for the whole
+    #     batch; only the surface terms loop over shapes (a different predicted surface per shape)
+    def forward_surface_align(self, vertice_pos, point_pos_bxpx3, tetrahedron_bxfx4=None, mesh_list=None,
+                              gt_surface_points=None, tet_face_bxfx3=None, inference=False, pred_occ=None,
+                              tet_face_tet_bx4fx2=None, save=False, save_name=None, inference_threshold=0.4):
+        if save:
+            raise NotImplementedError("save=True writes OBJ files through utils/mesh_utils.py (out of scope here)")
+        n_shape = vertice_pos.shape[0]
+        tet_bxfx4x3 = self.gather_tet_pos(vertice_pos, tetrahedron_bxfx4)
+        center_occ = self.check_tet_inside_sdfs(tet_bxfx4x3, mesh_list)                       # [B,T,1], no grad
+        face_fx3, face_tet_fx2 = tet_face_bxfx3[0], tet_face_tet_bx4fx2[0]
+        boundary = self.get_boundary_index(face_fx3, face_tet_fx2, center_occ.squeeze(dim=-1))
+        inv_v = self.inverse_v.to(tet_bxfx4x3.device)
+        volume_variance, amips_energy, edge = self.energies(tet_bxfx4x3, inv_v)
+        sum_chamfer = sum_analytic = sum_normal = 0.0
+        for i in range(n_shape):
+            chamfer, analytic, normal = self.forward(v_pos_bxnx3=vertice_pos[i:i + 1], tet_bxfx4=tetrahedron_bxfx4[i:i + 1],
+                                                     boundary_bxfx3=boundary[i].unsqueeze(dim=0),
+                                                     gt_surface_point=gt_surface_points[i:i + 1], inverse_offset=self.inverse_v,
+                                                     tet_bxfx4x3=tet_bxfx4x3[i:i + 1], calculate_amips_volume=False)
+            sum_chamfer = sum_chamfer + chamfer / n_shape
+            sum_analytic = sum_analytic + analytic / n_shape
+            sum_normal = sum_normal + normal / n_shape
+        center_occ = center_occ.squeeze(-1)
+        if inference:
+            assert point_pos_bxpx3 is not None, 'point_pos_bxpx3 not given'
+            condition = check_condition_f_base(tet_bxfx4x3, point_pos_bxpx3)
+            pred_surface_face = self.get_boundary_index(face_fx3, face_tet_fx2, (pred_occ > inference_threshold).float())
+            return (amips_energy, edge, volume_variance, sum_analytic, sum_normal, center_occ, condition, boundary,
+                    pred_surface_face, sum_chamfer)
+        return (amips_energy, edge, volume_variance, sum_analytic, sum_normal, center_occ, boundary, sum_chamfer,
+                torch.zeros_like(sum_normal))
+
+    def forward(self, v_pos_bxnx3=None, tet_bxfx4=None, boundary_bxfx3=None, gt_surface_point=None, inverse_offset=None,
+                tet_bxfx4x3=None, calculate_amips_volume=True):
+        """(chamfer, analytic, normal[, volume variance, amips, tet positions]) of one predicted surface
+        (deftet.py:138-184); all ones when the surface is empty (:159-163)."""
+        extra = ()
+        if calculate_amips_volume:
+            tet_pos = tet_bxfx4x3 if tet_bxfx4x3 is not None else self.gather_tet_pos(v_pos_bxnx3, tet_bxfx4)
+            if inverse_offset is not None:
+                vv, am, _ = self.energies(tet_pos, inverse_offset.to(tet_pos.device))
+            else:
+                vv = self.volume_variance(tet_pos, pow=self.pow)
+                am = torch.zeros_like(vv)
+            extra = (vv, am, tet_pos)
+        if boundary_bxfx3.shape[1] == 0:
+            one = torch.ones(1, device=boundary_bxfx3.device)
+            return (one, one, one) + extra
+        return surface_losses.surface_terms(v_pos_bxnx3, boundary_bxfx3, gt_surface_point, per_face=20) + extra
+
+    def laplacian_sparse(self, offset, adj):
+        """sum over vertices and coordinates of (mean of the neighbours' offsets - own offset)^2, per shape;
+        adj = row-normalised vertex adjacency [V,V] (c_tet_to_adj_sparse(normalize=True))."""
+        n_shape, n_vertex, width = offset.shape
+        flat = offset.permute(1, 0, 2).reshape(n_vertex, n_shape * width)
+        nei = torch.sparse.mm(adj, flat).reshape(n_vertex, n_shape, width).permute(1, 0, 2)
+        return ((nei - offset) ** 2).sum(dim=(1, 2))
 
     # --- init-time helpers (pure torch, as in the reference)
     def my_inverse(self, T):

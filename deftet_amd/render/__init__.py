@@ -1,1 +1,2 @@
-from .deftet_sparse_render import deftet_sparse_render, peel2mask, vertex2face, perspective  # noqa: F401
+from .deftet_sparse_render import deftet_sparse_render  # noqa: F401
+from .compositing import alpha_composite  # noqa: F401

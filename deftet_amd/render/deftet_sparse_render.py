@@ -1,8 +1,8 @@
 """Differentiable tet-face rasterizer with the call signature of
 `kaolin.render.mesh.deftet_sparse_render` as the reference uses it
-(/root/reference/diff_render/diftet_6_subdiv/5_rendereq/deftetrneder.py:97-100), plus the
-in-tree host pieces around it restated exactly: `peel2mask` (deftetrneder.py:31-64),
-`vertex2face` (4_render/vertex2face.py:12-28), `perspective` (3_model/cameraop.py:19-33).
+(/root/reference/diff_render/diftet_6_subdiv/5_rendereq/deftetrneder.py:97-100).  The host code
+around the call (`peel2mask`, `vertex2face`, `perspective`) stays the reference's own under the
+INTEGRATION.md overlay; `deftet_amd/render/compositing.py` holds this repository's compositing step.
 
 PARITY UNPINNED for the rasterizer itself: Kaolin is not part of the reference tree and the
 reference does not pin a version (README.md:30); see deftet_amd/csrc/raster.hip for the exact
@@ -70,44 +70,3 @@ def deftet_sparse_render(pixel_coords, render_ranges, face_vertices_z, face_vert
     (features [B,P,knum,D] sorted nearest-first, face_idx int64 [B,P,knum], -1 = empty)."""
     return _SparseRender.apply(pixel_coords, render_ranges, face_vertices_z, face_vertices_image, face_features,
                                int(knum), float(eps))
-
-
-def vertex2face(vertex_features_bxpxk, faces_fx3):
-    """4_render/vertex2face.py:12-28"""
-    vertex_features_bxf3xk = vertex_features_bxpxk[:, faces_fx3.view(-1)]
-    bnum = vertex_features_bxpxk.shape[0]
-    knum = vertex_features_bxpxk.shape[2]
-    return vertex_features_bxf3xk.view(bnum, -1, knum * 3)
-
-
-def perspective(points_bxpx3, cameras):
-    """3_model/cameraop.py:19-33"""
-    camera_rot_bx3x3, camera_pos_bx3, camera_proj_3x1 = cameras
-    cameratrans_rot_bx3x3 = camera_rot_bx3x3.permute(0, 2, 1)
-    points_bxpx3 = points_bxpx3 - camera_pos_bx3.view(-1, 1, 3)
-    points_bxpx3 = torch.matmul(points_bxpx3, cameratrans_rot_bx3x3)
-    camera_proj_bx1x3 = camera_proj_3x1.view(-1, 1, 3)
-    xy_bxpx3 = points_bxpx3 * camera_proj_bx1x3
-    xy_bxpx2 = xy_bxpx3[:, :, :2] / xy_bxpx3[:, :, 2:3]
-    return points_bxpx3, xy_bxpx2
-
-
-def peel2mask(ims_bxpxkxd, imdepth_bxpxkx1=None):
-    """5_rendereq/deftetrneder.py:31-64: front-to-back alpha compositing over the k sorted hits."""
-    immask_bxpxkx1 = ims_bxpxkxd[:, :, :, :1]
-    imcolor_bxpxkxc = ims_bxpxkxd[:, :, :, 1:]
-    eps = 1e-10
-    immask_bxpxkx1 = torch.clamp(immask_bxpxkx1, eps, 1.0 - eps)
-    xprob_shift = torch.nn.functional.pad(1 - immask_bxpxkx1[:, :, :-1, :], pad=(0, 0, 1, 0), mode='constant', value=1)
-    xprob_shiftsum = torch.cumprod(xprob_shift, dim=2)
-    xvis = immask_bxpxkx1 * xprob_shiftsum
-    xcolor = (imcolor_bxpxkxc * xvis).sum(dim=2)
-    if imdepth_bxpxkx1 is not None:
-        imdepth_bxpx1 = (imdepth_bxpxkx1 * xvis).sum(dim=2)
-    else:
-        imdepth_bxpx1 = None
-    xvis = xvis.sum(2)
-    xcolor = xcolor + (1. - xvis)                       # white background
-    if imdepth_bxpx1 is not None:
-        imdepth_bxpx1 = imdepth_bxpx1 + -6.0 * (1.0 - xvis)
-    return xcolor, xvis, imdepth_bxpx1

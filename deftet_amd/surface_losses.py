@@ -1,0 +1,93 @@
+"""Surface terms of the DefTet geometry loss, composed from this repository's HIP operators.
+
+`DefTet.forward` (/root/reference/layers/DefTet/deftet.py:138-184) measures a predicted boundary
+surface against a ground-truth point cloud with three scalars per shape; the reference routes them
+through helper functions of its `utils/mesh_utils.py` (:16-39, :290-299, :360-374).  Under the
+INTEGRATION.md overlay the reference's own helper file keeps doing that on top of the replaced L1
+operators.  This module is what `deftet_amd.layers.DefTet.deftet.DefTet.forward` uses when it runs
+WITHOUT a reference checkout: the same three quantities, written against `hip_ops`.
+
+    normal_consistency(v, faces)      mean over edge-adjacent face pairs of 1 - <n_i, n_j>      (A8)
+    sample_on_faces(tri, n)           n area-uniform random points per triangle
+    cloud_to_cloud(src, dst)          sqrt(|src_i - NN_dst(src_i)|^2 + 1e-10)                  (A10)
+    cloud_to_surface(pts, tri)        sqrt(min_f d^2(pts_i, tri_f) + 1e-10), grad -> tri        (A9)
+"""
+import torch
+
+from deftet_amd.layers.DefTet.tet_analytic_distance_batch.utils import tet_analytic_distance_f_batch
+from deftet_amd.layers.DefTet.tet_face_adj_m_idx.utils import tet_face_adj_m_f_idx
+from deftet_amd.layers.nearest_neighbor import NearestNeighbor
+
+SQRT_EPS = 1e-10          # inside every square root (utils/mesh_utils.py:14)
+NORMAL_EPS = 1e-12        # inside the normal's length (utils/mesh_utils.py:50-51)
+
+_nn = NearestNeighbor()
+
+
+def corners(vertices_bxnx3, faces_bxfx3):
+    """[B,F,3,3] corner positions of indexed triangles (differentiable w.r.t. the vertices)."""
+    B, F = faces_bxfx3.shape[0], faces_bxfx3.shape[1]
+    flat = faces_bxfx3.reshape(B, F * 3, 1).expand(-1, -1, 3)
+    return torch.gather(vertices_bxnx3, 1, flat).reshape(B, F, 3, 3)
+
+
+def unit_normals(tri_bxfx3x3):
+    e1 = tri_bxfx3x3[:, :, 1] - tri_bxfx3x3[:, :, 0]
+    e2 = tri_bxfx3x3[:, :, 2] - tri_bxfx3x3[:, :, 0]
+    n = torch.linalg.cross(e1, e2, dim=-1)
+    return n / torch.sqrt((n * n).sum(-1, keepdim=True) + NORMAL_EPS)
+
+
+def normal_consistency(vertices_bxnx3, faces_bxfx3):
+    """Per shape: mean of 1 - cos(angle between the unit normals) over all ordered pairs of triangles
+    that share an edge BY POSITION (operator A8 on the first shape's corner positions, like the
+    reference, which passes `face[0]`).  Zero when no pair exists."""
+    tri = corners(vertices_bxnx3, faces_bxfx3)
+    with torch.no_grad():
+        pairs = tet_face_adj_m_f_idx(tri[0].float())
+    if pairs.numel() == 0 or int(pairs.sum()) == 0:
+        return torch.zeros(vertices_bxnx3.shape[0], device=faces_bxfx3.device, dtype=torch.float32)
+    n = unit_normals(tri)
+    cos = (n[:, pairs[0]] * n[:, pairs[1]]).sum(-1)
+    return (1.0 - cos).mean(-1)
+
+
+def sample_on_faces(tri_bxfx3x3, per_face=20, generator=None):
+    """[B,F,per_face,3] points distributed uniformly over each triangle's area
+    (square-root warp of two uniform numbers)."""
+    B, F = tri_bxfx3x3.shape[:2]
+    r = torch.rand(2, B, F, per_face, 1, device=tri_bxfx3x3.device, generator=generator)
+    s = torch.sqrt(r[0])
+    wa, wb, wc = 1.0 - s, s * (1.0 - r[1]), s * r[1]
+    a, b, c = (tri_bxfx3x3[:, :, k:k + 1, :] for k in range(3))
+    return wa * a + wb * b + wc * c
+
+
+def cloud_to_cloud(src_bxnx3, dst_bxmx3):
+    """Distance from every source point to its nearest destination point (index from operator A10;
+    the gradient flows through the gathered coordinates, as with torch.gather)."""
+    idx = _nn(src_bxnx3, dst_bxmx3)
+    near = torch.gather(dst_bxmx3, 1, idx[..., None].expand(-1, -1, 3))
+    return torch.sqrt(((src_bxnx3 - near) ** 2).sum(-1) + SQRT_EPS)
+
+
+def cloud_to_surface(pts_bxpx3, tri_bxfx3x3):
+    """Distance from every point to the triangle soup (operator A9; all F triangles of every shape valid)."""
+    B, F = tri_bxfx3x3.shape[:2]
+    n_face = torch.full((B,), float(F), device=tri_bxfx3x3.device, dtype=torch.float32)
+    d2, _ = tet_analytic_distance_f_batch(pts_bxpx3, tri_bxfx3x3, n_face)
+    return torch.sqrt(d2 + SQRT_EPS)
+
+
+def surface_terms(vertices_bxnx3, boundary_bxfx3, gt_points_bxmx3, per_face=20, generator=None):
+    """(chamfer [B], analytic [B], normal [B]) for one predicted surface vs one ground-truth cloud:
+    predicted-sample -> cloud nearest-neighbour distance, cloud -> predicted-surface distance, and
+    the normal consistency of the predicted surface (deftet.py:168-181)."""
+    tri = corners(vertices_bxnx3, boundary_bxfx3)
+    normal = normal_consistency(vertices_bxnx3, boundary_bxfx3)
+    B = tri.shape[0]
+    samples = sample_on_faces(tri, per_face, generator).reshape(B, -1, 3)
+    gt = gt_points_bxmx3.reshape(B, -1, 3)
+    chamfer = cloud_to_cloud(samples, gt).mean(-1)
+    analytic = cloud_to_surface(gt, tri).mean(-1).mean(-1)
+    return chamfer, analytic, normal

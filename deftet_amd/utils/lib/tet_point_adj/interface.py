@@ -5,7 +5,6 @@ import ctypes as c
 
 import numpy as np
 import torch
-from scipy.sparse import coo_matrix
 
 from deftet_amd.utils.lib import _host
 
@@ -21,17 +20,12 @@ class Tet_point_adj:
         n_edge = np.zeros(1, dtype=np.int32)
         _host.call(self.run_native, "deftet_tet_point_adj_host", tet_list.ctypes.data_as(_host.I32P),
                    edge.ctypes.data_as(_host.I32P), n_edge.ctypes.data_as(_host.I32P), int(n_point), tet_list.shape[0])
-        idx = edge[:n_edge[0], :]
-        v = np.ones(idx.shape[0])
-        if normalize:                                              # interface.py:42-54
-            adj_m = coo_matrix((v, (idx[:, 0], idx[:, 1])), shape=(n_point, n_point))
-            sum_adj = 1.0 / adj_m.sum(axis=-1)
-            n_point = sum_adj.shape[0]
-            new_idx = list(range(n_point))
-            sum_m = coo_matrix((np.asarray(sum_adj).reshape(-1), (new_idx, new_idx)), shape=(n_point, n_point))
-            adj = sum_m.dot(adj_m)
-            idx = np.asarray(adj.nonzero())
-            return torch.sparse_coo_tensor(torch.from_numpy(idx).long(), torch.from_numpy(adj.data).float(),
-                                           torch.Size([n_point, n_point]))
-        idx = torch.from_numpy(idx.astype(np.int64))
-        return torch.sparse_coo_tensor(idx.transpose(0, 1), torch.ones(idx.shape[0]), torch.Size([n_point, n_point]))
+        idx = torch.from_numpy(edge[:n_edge[0], :].astype(np.int64))
+        if normalize:
+            # D^-1 A: every stored entry of row r weighs 1/deg(r) (reference interface.py:42-54 gets the same
+            # numbers from two scipy products); entries are unique, so deg is a plain count
+            deg = torch.bincount(idx[:, 0], minlength=int(n_point)).double()
+            val = (1.0 / deg)[idx[:, 0]].float()
+        else:
+            val = torch.ones(idx.shape[0])
+        return torch.sparse_coo_tensor(idx.t().contiguous(), val, torch.Size([int(n_point), int(n_point)]))

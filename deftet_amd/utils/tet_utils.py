@@ -59,3 +59,15 @@ def tet_to_face_idx(n_point, tet_list, with_boundary=False, device="cuda"):
     """prepare_for_wz.py:49-104: boundary faces inline with partner -1 when with_boundary."""
     f3, t2, tf2, b3, n_multi = hip_ops.tet_to_face(np.asarray(tet_list), n_point, device, with_boundary=with_boundary)
     return f3.cpu().numpy(), t2.cpu().numpy(), tf2.cpu().numpy()
+
+
+def tet_to_face_withtet(points, tet_list, device="cuda"):
+    """utils/tet_utils.py:259-300: int64 [4T,2], row 4t+i = the owners of local face i's key in insertion
+    order, a lone owner padded with 0."""
+    return hip_ops.tet_neighbours(np.asarray(tet_list), points.shape[0], device, want_face_owners=True)[1].cpu().numpy()
+
+
+def tet_neighbour_table(tet_list_tx4, n_point, device="cuda"):
+    """The T x 4 `tet_neighbour_idx` that diff_render/diftet_6_subdiv/3_model/utils_tetsv.py:16-75 returns next to
+    the four adjacency matrices (consumed at 3_model/deftet.py:152,327)."""
+    return hip_ops.tet_neighbours(np.asarray(tet_list_tx4), n_point, device).cpu().numpy()

@@ -166,6 +166,14 @@ int deftet_tet_to_face_i32(const int32_t *tet_list, int64_t *face_fx3, int64_t *
                            int n_point, int n_tet, int with_boundary,
                            void *workspace, size_t workspace_bytes, void *stream);
 
+/* Per-tet neighbour table [T,4] (-1 padded; partners in the order of the shared faces' positions in the unique-face
+ * table) = the second return value of diff_render/diftet_6_subdiv/3_model/utils_tetsv.py:16-75 (tet_adj_share), and,
+ * optionally, the per-tet-face owner table [4T,2] of utils/tet_utils.py:259-300 (tet_to_face_withtet; NULL = skip).
+ * Inputs are the tetidx/tetfaceidx tables of deftet_tet_to_face_i32(with_boundary=1) (n_face rows). */
+size_t deftet_tet_neighbours_workspace_bytes(int n_tet);
+int deftet_tet_neighbours_i64(const int64_t *tetidx_fx2, const int64_t *tetfaceidx_fx2, int n_face, int n_tet,
+                              int64_t *nbr_tx4, int64_t *withtet_4tx2, void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---------------------------------------------------------------------------------
  * A7  DefTet.get_boundary_index (mode 1) / get_internal_index (mode 2), layers/DefTet/deftet.py:186-203.
  * face_fx3, tetidx_fx2 int64 (tet_to_face outputs), occ f32 [B,T].  out_rows int64 [B*F,3] receives

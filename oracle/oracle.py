@@ -176,6 +176,32 @@ def tet_to_face(tet_list, n_point, with_boundary=False):
     return f3[: nf[0]], t2[: nf[0]], tf2[: nf[0]], b3[: nb[0]], int(nm[0])
 
 
+def tet_neighbours(tet_list, n_point):
+    """(tet_neighbour_idx [T,4], tet_face_tetidx [4T,2]) restated in plain loops from
+    diff_render/diftet_6_subdiv/3_model/utils_tetsv.py:41-58 and utils/tet_utils.py:288-298, driven by the
+    first-seen unique-face table (oracle tet_to_face with_boundary=True): shared faces are visited in table
+    order and append the partner to both owners' rows; a lone owner's face row is padded with 0."""
+    tet = _c(tet_list, np.int32)
+    T = tet.shape[0]
+    _, t2, tf2, _, n_multi = tet_to_face(tet, n_point, with_boundary=True)
+    if n_multi:
+        raise ValueError("face shared by more than two tetrahedra")
+    nbr = -np.ones((T, 4), np.int64)
+    fill = np.zeros(T, np.int64)
+    owners = np.zeros((T * 4, 2), np.int64)
+    for (t0, t1), (l0, l1) in zip(t2, tf2):
+        if t1 >= 0:
+            nbr[t0, fill[t0]] = t1
+            fill[t0] += 1
+            nbr[t1, fill[t1]] = t0
+            fill[t1] += 1
+            owners[4 * t0 + l0] = (t0, t1)
+            owners[4 * t1 + l1] = (t0, t1)
+        else:
+            owners[4 * t0 + l0] = (t0, 0)
+    return nbr, owners
+
+
 # --------------------------------------------------------------------------- surface ops
 def face_edge_adj(face_fx3x3, n_max_nei=30):
     face = _c(face_fx3x3, np.float32)

@@ -20,6 +20,12 @@ What is pinned:
                        get_internal_index (:197-203), paste_occ (:132-136),
                        volume_variance (:239-263), amips_energy (:266-298),
                        edge_length (:320-338), tet_inverse_v (:300-318).
+  pit_index_<case>.npz A1 index pin: utils/tet_utils.py:28-45 bary_centric_tet evaluated (fp64) for EVERY
+                       (tet, query) pair of seeded cases; expected = lowest tet index whose four reference
+                       weights all exceed MARGIN, `ambiguous` = queries where a tet at or below that index
+                       has its smallest weight within +-MARGIN (face/edge/vertex contacts, where the fp32
+                       sign tests of check_condition_tet_for.cu:105-189 may legitimately go either way).
+  cube40_grid.npz      the shipped diff_render/diftet_6_subdiv/data/cube_40_tet.tet re-encoded (data fixture).
   n3_rebuilds.npz      diff_render/diftet_6_subdiv/3_model/prepare_for_wz.py: generate_edge (:184-203),
                        generate_tet_edge_idx (:223-236), generate_subdivision (:255-301, with and
                        without a split mask), generate_point_adj_idx (:134-146), delete_tet
@@ -112,6 +118,70 @@ def builders_fixture(name, verts, tets, tu, pw, tsv, store_full=True):
         np.savez_compressed(os.path.join(HERE, "builders_%s.npz" % name), **out)
     return {k: sha(v) for k, v in out.items()}, out
 
+PIT_MARGIN = 1e-4
+
+
+def pit_index_case(tu, torch, tet, pts, chunk=256):
+    """Reference answer for the point-in-tet query from the imported bary_centric_tet
+    (utils/tet_utils.py:28-45), all T x Q pairs in float64."""
+    t64 = torch.from_numpy(np.asarray(tet, np.float32)).double()
+    a, b, c, d = (t64[None, :, i, :] for i in range(4))
+    T, Q = t64.shape[0], pts.shape[0]
+    expected = np.full(Q, -1, np.int32)
+    ambiguous = np.zeros(Q, bool)
+    w_exp = np.zeros((Q, 4), np.float32)
+    for q0 in range(0, Q, chunk):
+        p = torch.from_numpy(np.asarray(pts[q0:q0 + chunk], np.float32)).double()[:, None, :]
+        W = torch.stack(tu.bary_centric_tet(a, b, c, d, p), -1)            # [q,T,4]
+        wmin = W.min(-1).values.numpy()
+        inside = wmin > PIT_MARGIN
+        touch = np.abs(wmin) <= PIT_MARGIN
+        has = inside.any(1)
+        first = np.where(has, inside.argmax(1), T)
+        expected[q0:q0 + chunk] = np.where(has, first, -1)
+        tidx = np.arange(T)[None, :]
+        ambiguous[q0:q0 + chunk] = (touch & (tidx <= first[:, None])).any(1)
+        # reference weights (fp32 evaluation of the same function) of the expected tet
+        sel = np.where(has, first, 0)
+        t32 = torch.from_numpy(np.asarray(tet, np.float32))[sel]
+        p32 = torch.from_numpy(np.asarray(pts[q0:q0 + chunk], np.float32))
+        w32 = torch.stack(tu.bary_centric_tet(t32[:, 0], t32[:, 1], t32[:, 2], t32[:, 3], p32), -1).numpy()
+        w_exp[q0:q0 + chunk] = np.where(has[:, None], w32, 0)
+    return expected, ambiguous, w_exp
+
+
+def pit_index_fixtures(tu, torch):
+    rng = np.random.default_rng(2024)
+    cases = {}
+    for res, nq, jit in ((4, 1500, 0.15), (8, 2000, 0.1), (20, 2500, 0.1)):
+        tet, pts, _, _ = grids.make_case(res, nq, 1, jit)
+        cases["kuhn%d" % res] = (tet[0], pts[0])
+    # overlapping soup: random well-shaped tets (half of them inverted, some duplicated), queries drawn
+    # inside tets, on the cloud's box and outside it
+    n = 300
+    ctr = rng.uniform(-0.4, 0.4, (n, 1, 3))
+    soup = (ctr + rng.uniform(-0.15, 0.15, (n, 4, 3))).astype(np.float32)
+    vol = grids.tet_orientation(soup[None])[0]
+    soup = soup[np.abs(vol) > 1e-4]
+    soup[::2, [0, 1]] = soup[::2, [1, 0]]                                     # flip orientation of every other tet
+    soup = np.concatenate([soup, soup[rng.integers(0, soup.shape[0], 20)]], 0)   # exact duplicates (lowest index wins)
+    w4 = rng.dirichlet([1, 1, 1, 1], 1200).astype(np.float32)
+    inside_pts = (soup[rng.integers(0, soup.shape[0], 1200)] * w4[:, :, None]).sum(1)
+    qs = np.concatenate([inside_pts, rng.uniform(-0.6, 0.6, (800, 3))], 0).astype(np.float32)
+    cases["soup"] = (np.ascontiguousarray(soup), qs[rng.permutation(qs.shape[0])])
+    # the shipped QuarTet grid at its rest positions (train_multigpu.py:65-66 shift), tets via cube40_grid.npz
+    v40, t40 = grids.read_tet(os.path.join(REF, "diff_render/diftet_6_subdiv/data/cube_40_tet.tet"))
+    tet40 = (v40 - 0.5).astype(np.float32)[t40]
+    cases["cube40"] = (tet40, grids.random_queries(1, 1200, seed0=2040)[0])
+    for name, (tet, pts) in cases.items():
+        exp, amb, w = pit_index_case(tu, torch, tet, pts)
+        out = dict(pts=pts, expected=exp, ambiguous=amb, w_ref_f32=w, margin=np.float64(PIT_MARGIN))
+        if name != "cube40":
+            out["tet"] = tet                                                  # cube40: rebuilt from cube40_grid.npz
+        np.savez_compressed(os.path.join(HERE, "pit_index_%s.npz" % name), **out)
+        print("pit_index_%-7s T=%6d Q=%5d hit=%5d miss=%5d ambiguous=%4d" % (
+            name, tet.shape[0], pts.shape[0], int((exp >= 0).sum()), int((exp < 0).sum()), int(amb.sum())))
+
 
 def main():
     if not os.path.isdir(REF):
@@ -133,11 +203,17 @@ def main():
     for name, (v, t) in dict(one=one, two=two, kuhn2=k2, kuhn4=k4, kuhn4perm=k4p, kuhn8=k8).items():
         builders_fixture(name, np.asarray(v, float), np.asarray(t), tu, pw, tsv)
     v40, t40 = grids.read_tet(os.path.join(REF, "diff_render/diftet_6_subdiv/data/cube_40_tet.tet"))
+    np.savez_compressed(os.path.join(HERE, "cube40_grid.npz"), verts=np.asarray(v40, np.float64), tets=np.asarray(t40, np.int32))
     h40, full40 = builders_fixture("cube40", v40, t40, tu, pw, tsv, store_full=False)
     np.savez_compressed(os.path.join(HERE, "cube40_hashes.npz"),
                         **{k: np.frombuffer(bytes.fromhex(v), np.uint8) for k, v in h40.items()},
                         shapes=np.array([full40[k].shape[0] for k in sorted(full40)], np.int64),
                         keys=np.array(sorted(full40)))
+
+    # ---------------- A1 index pin (reference barycentrics on every pair)
+    pit_index_fixtures(tu, torch)
+    if os.environ.get("GEN_GOLDEN_ONLY") == "pit":
+        return
 
     # ---------------- barycentric weights + autograd gradients (A1b oracle)
     for name, res in (("kuhn4", 4), ("kuhn8", 8)):

@@ -146,3 +146,40 @@ def test_builders_res70_properties(cuda):
     ka = torch.sort(fa[:, 0].long() * (4 * T) + fa[:, 1].long()).values
     kb = torch.sort(fb[:, 0].long() * (4 * T) + fb[:, 1].long()).values
     assert torch.equal(ka, kb)
+
+
+@pytest.mark.parametrize("name", ["two", "kuhn2", "kuhn4", "kuhn4perm", "kuhn8", "cube40"])
+def test_neighbour_table_and_face_owner_table_vs_reference_outputs(cuda, name):
+    """T x 4 `tet_neighbour_idx` (utils_tetsv.tet_adj_share, diff_render/.../utils_tetsv.py:16-75) and the 4T x 2
+    owner table of tet_to_face_withtet (utils/tet_utils.py:259-300): bit-exact against what the reference
+    functions returned (fixtures written by gen_golden.py; sha256 for the shipped cube_40 grid)."""
+    import hashlib
+    from deftet_amd import hip_ops
+    from deftet_amd.utils import tet_utils as TU
+    if name == "cube40":
+        g = load("cube40_grid.npz")
+        tets, n_point = g["tets"], g["verts"].shape[0]
+        h = load("cube40_hashes.npz")
+        nbr, own = hip_ops.tet_neighbours(tets, n_point, cuda, want_face_owners=True)
+        for key, arr in (("adj_share_nbr_tx4", nbr), ("face_withtet_4tx2", own)):
+            got = hashlib.sha256(np.ascontiguousarray(arr.cpu().numpy().astype(np.int64)).tobytes()).digest()
+            assert got == h[key].tobytes(), key
+        return
+    gold = load("builders_%s.npz" % name)
+    tets, n_point = gold["tets"], gold["verts"].shape[0]
+    nbr, own = hip_ops.tet_neighbours(tets, n_point, cuda, want_face_owners=True)
+    assert nbr.dtype == torch.int64 and np.array_equal(nbr.cpu().numpy(), gold["adj_share_nbr_tx4"])
+    assert np.array_equal(own.cpu().numpy(), gold["face_withtet_4tx2"])
+    assert np.array_equal(TU.tet_neighbour_table(tets, n_point), gold["adj_share_nbr_tx4"])
+    assert np.array_equal(TU.tet_to_face_withtet(gold["verts"], tets), gold["face_withtet_4tx2"])
+    # the table feeds tetweights2tetneighbourweights (N3) unchanged
+    w = torch.rand(tets.shape[0], 3, device=cuda)
+    out = hip_ops.tet_neighbour_weights(w, nbr, 1)
+    assert out.shape[0] == tets.shape[0]
+
+
+def test_neighbour_table_rejects_non_manifold(cuda):
+    from deftet_amd import hip_ops
+    tets = np.array([[0, 1, 2, 3], [0, 1, 2, 4], [0, 1, 2, 5]], np.int32)        # face (0,1,2) has three owners
+    with pytest.raises(ValueError):
+        hip_ops.tet_neighbours(tets, 6, cuda)

@@ -4,6 +4,7 @@ import ctypes
 import os
 import re
 import socket
+import sys
 
 import numpy as np
 import pytest
@@ -214,7 +215,9 @@ def test_integration_overlay_names_exist():
         "deftet_amd.utils.lib.colaps_v.interface": ["Tet_point_adj"],
         "deftet_amd.utils.tet_utils": ["tet_to_face"],
         "deftet_amd.utils.dataloder_helper": ["read_tetrahedron"],
-        "deftet_amd.render.deftet_sparse_render": ["deftet_sparse_render", "peel2mask", "vertex2face", "perspective"],
+        "deftet_amd.render.deftet_sparse_render": ["deftet_sparse_render"],
+        "deftet_amd.render.compositing": ["alpha_composite"],
+        "deftet_amd.surface_losses": ["normal_consistency", "sample_on_faces", "cloud_to_cloud", "cloud_to_surface", "surface_terms"],
         "deftet_amd.render.prepare_for_wz": ["generate_edge", "generate_tet_edge_idx", "generate_subdivision", "generate_point_adj_idx",
                                              "delete_tet", "tetweights2tetneighbourweights"],
     }
@@ -224,5 +227,86 @@ def test_integration_overlay_names_exist():
             assert hasattr(m, a), "%s lacks %s" % (mod, a)
     from deftet_amd.layers.DefTet.deftet import DefTet
     for meth in ("check_tet_inside_sdfs", "gather_tet_pos", "get_boundary_index", "get_internal_index", "paste_occ", "volume_variance",
-                 "amips_energy", "edge_length", "tet_inverse_v"):
+                 "amips_energy", "edge_length", "tet_inverse_v", "forward", "forward_surface_align", "laplacian_sparse"):
         assert callable(getattr(DefTet, meth))
+
+
+def _clean_overlay_names():
+    for k in [k for k in sys.modules if k.split(".")[0] in ("layers", "utils", "kaolin", "cv2")]:
+        del sys.modules[k]
+
+
+def test_overlay_installs_and_reference_shaped_callers_resolve_to_hip_ops():
+    """INTEGRATION.md section A, executed: after overlay.install() the reference's own import statements
+    (tests/ref_shaped_callers.py mirrors them) bind to this repository's operators, incl. the two Kaolin
+    entry points; nothing is imported from a CPU fallback."""
+    import inspect
+    import deftet_amd.overlay as overlay
+    saved = dict(sys.modules)
+    _clean_overlay_names()
+    try:
+        names = overlay.install(kaolin=True)
+        assert set(overlay.L1_MODULES) <= set(names) and "kaolin.ops.mesh" in names and "kaolin.render.mesh" in names
+        from tests import ref_shaped_callers as C
+        got = C.import_like_reference()
+        import deftet_amd.layers.DefTet.check_condition_tetrahedron_base.utils as ours
+        assert got["check_condition_f_base"] is ours.check_condition_f_base
+        import deftet_amd.layers.DefTet.tet_face_adj_m_idx.utils as ours_b
+        import deftet_amd.layers.DefTet.tet_analytic_distance_batch.utils as ours_c
+        assert got["tet_face_adj_m_f_idx"] is ours_b.tet_face_adj_m_f_idx
+        assert got["tet_analytic_distance_f_batch"] is ours_c.tet_analytic_distance_f_batch
+        for k in ("NearestNeighbor", "Tet_point_adj", "Tet_face_adj", "Tet_adj_share"):
+            assert got[k].__module__.startswith("deftet_amd."), k
+        kal = got["kal"]
+        assert inspect.signature(kal.ops.mesh.check_sign).parameters.keys() >= {"verts", "faces", "points", "hash_resolution"}
+        sig = inspect.signature(kal.render.mesh.deftet_sparse_render)
+        assert list(sig.parameters)[:5] == ["pixel_coords", "render_ranges", "face_vertices_z", "face_vertices_image", "face_features"]
+        assert sig.parameters["knum"].default == 300 and sig.parameters["eps"].default == 1e-8
+        # the operators refuse CPU tensors instead of falling back
+        import torch
+        from deftet_amd import _lib
+        with pytest.raises(_lib.DefTetHipError):
+            C.query_and_paste(torch.zeros(1, 2, 4, 3), torch.zeros(1, 3, 3), torch.zeros(1, 2))
+        with pytest.raises(_lib.DefTetHipError):
+            kal.ops.mesh.check_sign(torch.zeros(1, 4, 3), torch.zeros(2, 3, dtype=torch.long), torch.zeros(1, 5, 3))
+        overlay.uninstall(names)
+    finally:
+        _clean_overlay_names()
+        sys.modules.update({k: v for k, v in saved.items() if k not in sys.modules})
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/layers"), reason="needs the reference checkout (authoring container only)")
+def test_unchanged_reference_modules_import_through_the_overlay():
+    """The reference's own layers/DefTet/deftet.py, utils/mesh_utils.py and utils/tet_utils.py — unmodified, from
+    /root/reference — import with the overlay installed (no nvcc, no THC, no cv2, no kaolin, no run.so in the CWD)
+    and end up holding this repository's operators."""
+    import deftet_amd.overlay as overlay
+    saved, saved_path = dict(sys.modules), list(sys.path)
+    _clean_overlay_names()
+    try:
+        names = overlay.install(kaolin=True)
+        sys.path.insert(0, "/root/reference")
+        import importlib
+        ref_deftet = importlib.import_module("layers.DefTet.deftet")
+        ref_mesh = importlib.import_module("utils.mesh_utils")
+        ref_tet = importlib.import_module("utils.tet_utils")
+        assert ref_deftet.__file__.startswith("/root/reference/") and ref_tet.__file__.startswith("/root/reference/")
+        import deftet_amd.layers.DefTet.check_condition_tetrahedron_base.utils as a
+        import deftet_amd.layers.DefTet.tet_face_adj_m_idx.utils as b
+        import deftet_amd.layers.DefTet.tet_analytic_distance_batch.utils as c
+        import deftet_amd.layers.nearest_neighbor as d
+        assert ref_deftet.check_condition_f_base is a.check_condition_f_base
+        assert ref_mesh.tet_face_adj_m_f_idx is b.tet_face_adj_m_f_idx
+        assert ref_mesh.tet_analytic_distance_f_batch is c.tet_analytic_distance_f_batch
+        assert ref_mesh.NearestNeighbor is d.NearestNeighbor
+        assert type(ref_tet.c_tet_point_adj).__module__ == "deftet_amd.utils.lib.tet_point_adj.interface"
+        assert type(ref_tet.c_tet_face_adj).__module__ == "deftet_amd.utils.lib.tet_face_adj.interface"
+        assert type(ref_tet.c_obj_tet_adj_share).__module__ == "deftet_amd.utils.lib.tet_adj_share.interface"
+        assert getattr(ref_deftet.kal, "__deftet_amd_shim__", False)
+        m = ref_deftet.DefTet()                                  # the reference's module object, our operators underneath
+        assert hasattr(m, "forward_surface_align")
+        overlay.uninstall(names)
+    finally:
+        sys.path[:] = saved_path
+        _clean_overlay_names()
+        sys.modules.update({k: v for k, v in saved.items() if k not in sys.modules})

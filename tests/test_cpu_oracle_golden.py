@@ -173,6 +173,48 @@ def test_point_in_tet_semantics_vs_reference_barycentrics(oracle, res, jit):
     assert (m >= 0).all()
 
 
+@pytest.mark.parametrize("name", ["two", "kuhn2", "kuhn4", "kuhn4perm", "kuhn8"])
+def test_neighbour_tables_oracle_matches_reference_outputs(oracle, name):
+    """T x 4 tet_neighbour_idx (utils_tetsv.py:16-75) and 4T x 2 tet_to_face_withtet (utils/tet_utils.py:259-300)
+    restated from the unique-face table == the reference functions' own outputs (gen_golden.py)."""
+    gold = load("builders_%s.npz" % name)
+    nbr, owners = oracle.tet_neighbours(gold["tets"], gold["verts"].shape[0])
+    assert np.array_equal(nbr, gold["adj_share_nbr_tx4"])
+    assert np.array_equal(owners, gold["face_withtet_4tx2"])
+
+
+def _pit_fixture(name):
+    g = load("pit_index_%s.npz" % name)
+    if name == "cube40":                                   # tets rebuilt from the shipped grid (train_multigpu.py:65-66 shift)
+        c = load("cube40_grid.npz")
+        tet = (c["verts"] - 0.5).astype(np.float32)[c["tets"]]
+    else:
+        tet = g["tet"]
+    return tet, g["pts"], g["expected"], g["ambiguous"], g["w_ref_f32"]
+
+
+@pytest.mark.parametrize("name", ["kuhn4", "kuhn8", "kuhn20", "soup", "cube40"])
+def test_point_in_tet_index_pinned_by_reference_barycentrics(oracle, name):
+    """A1 pin: tests/golden/pit_index_*.npz hold, for every query, the lowest tet index whose four
+    weights from the reference's own bary_centric_tet (utils/tet_utils.py:28-45, imported and run on
+    ALL T x Q pairs by gen_golden.py) exceed 1e-4, and a mask of the queries that touch a tet at or
+    below that index within 1e-4.  Outside that mask the restatement of
+    check_condition_tet_for.cu:105-189 must return exactly that index (or -1)."""
+    tet, pts, expected, ambiguous, w_ref = _pit_fixture(name)
+    got = oracle.point_in_tet(tet[None], pts[None])[0, :, 0].astype(np.int64)
+    clear = ~ambiguous
+    assert clear.mean() > 0.99
+    assert np.array_equal(got[clear], expected[clear].astype(np.int64))
+    # ambiguous queries: whatever the fp32 tests decide, the answer is a tet that touches the query
+    # (checked through the weights of that tet) or -1
+    w = oracle.bary(tet[None], pts[None], got[None].astype(np.float32))[0]
+    hit = got >= 0
+    assert (w[hit].min(-1) > -2e-4).all()
+    # the A1b weights of the pinned tet agree with the reference's fp32 evaluation
+    sel = clear & (expected >= 0)
+    assert np.abs(w[sel] - w_ref[sel]).max() <= 1e-5 * max(1.0, np.abs(w_ref[sel]).max())
+
+
 def test_deftet_module_fixture_is_selfconsistent():
     """deftet_module.npz pins the reference's own outputs for A7 / paste_occ / A11; here only
     shapes and invariants are checked on CPU (the HIP counterparts are tested with -m gpu)."""

@@ -42,3 +42,112 @@ def test_geometry_step_chain(cuda):
         return 1e-3 * am.sum() + 1e-3 * el.sum() + 1e-6 * vv.sum()
     g_sum = grad_of(point_terms) + grad_of(energy_terms)
     assert (g_all - g_sum).abs().max() <= 1e-5 * g_all.abs().max()
+
+
+def _case(cuda, B=2, Q=3000, res=10):
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import step_demo
+    return step_demo.build_case(res, B, Q, cuda)
+
+
+def test_forward_surface_align_end_to_end(cuda, oracle):
+    """DefTet.forward_surface_align on the HIP-backed module, both modes, with the reference's argument list and
+    tuple order (layers/DefTet/deftet.py:51-130); every piece is compared with its separately verified operator,
+    and the training-mode losses back-propagate to the vertices."""
+    from deftet_amd import hip_ops, surface_losses
+    from deftet_amd.layers.DefTet.deftet import DefTet
+    B, Q = 2, 3000
+    pos0, idx, f3, t2, gt_verts, gt_faces, pts, inv_v = _case(cuda, B, Q)
+    T = idx.shape[0]
+    idxB = idx[None].expand(B, -1, -1).contiguous()
+    m = DefTet(device=cuda)
+    m.inverse_v = inv_v
+    d = np.random.default_rng(0).standard_normal((B, 5000, 3))
+    gt_pts = torch.from_numpy((0.3 * d / np.linalg.norm(d, axis=-1, keepdims=True)).astype(np.float32)).to(cuda)
+    mesh_list = ([gt_verts[None]] * B, [gt_faces[None]] * B)          # per shape: verts [1,V,3], faces [1,F,3] like the dataloader
+    pred_occ = torch.rand(B, T, device=cuda, generator=torch.Generator(device=cuda).manual_seed(2))
+    kw = dict(tetrahedron_bxfx4=idxB, mesh_list=mesh_list, gt_surface_points=gt_pts, tet_face_bxfx3=f3[None].expand(B, -1, -1),
+              tet_face_tet_bx4fx2=t2[None].expand(B, -1, -1))
+    # ---- inference
+    with torch.no_grad():
+        out = m.forward_surface_align(pos0, pts, inference=True, pred_occ=pred_occ, **kw)
+    assert len(out) == 10
+    amips, edge, volvar, analytic, normal, center_occ, condition, boundary, pred_face, chamfer = out
+    tet = hip_ops.tet_gather(pos0, idxB)
+    assert np.array_equal(condition.cpu().numpy(), oracle.point_in_tet(tet.cpu().numpy(), pts.cpu().numpy()))
+    assert center_occ.shape == (B, T) and 0.05 < center_occ.mean().item() < 0.25
+    assert torch.equal(center_occ.bool(), hip_ops.check_sign(gt_verts[None].expand(B, -1, -1).contiguous(), gt_faces, tet.mean(2)))
+    want_b = hip_ops.boundary_index(f3, t2, center_occ, mode=1)
+    assert all(torch.equal(a, b) for a, b in zip(boundary, want_b)) and len(boundary) == B
+    want_p = hip_ops.boundary_index(f3, t2, (pred_occ > 0.4).float(), mode=1)
+    assert all(torch.equal(a, b) for a, b in zip(pred_face, want_p))
+    e = hip_ops.tet_energies(tet, inv_v, pow_v=4, pow_e=4, scale=20.0)
+    assert torch.equal(torch.stack([volvar, amips, edge], 1), e)
+    for x in (analytic, normal, chamfer):
+        assert x.shape == (1,) and torch.isfinite(x).all() and x.item() > 0
+    assert m.paste_occ(pred_occ, condition.clone()).shape == (B, Q)
+    # ---- training mode: 9-tuple, gradients reach the vertices through every term
+    pos = pos0.clone().requires_grad_(True)
+    out = m.forward_surface_align(pos, None, **kw)
+    assert len(out) == 9
+    amips, edge, volvar, analytic, normal, center_occ2, boundary2, chamfer, lap = out
+    assert torch.equal(center_occ2, center_occ) and lap.shape == normal.shape and (lap == 0).all()
+    for term in (amips.sum(), edge.sum(), analytic.sum(), normal.sum(), chamfer.sum()):
+        (g,) = torch.autograd.grad(term, pos, retain_graph=True)
+        assert torch.isfinite(g).all() and g.abs().sum() > 0
+    # the surface terms of shape 0 alone == forward() on that shape (same random samples via the global generator)
+    torch.manual_seed(7)
+    a = m.forward(v_pos_bxnx3=pos0[:1], tet_bxfx4=idxB[:1], boundary_bxfx3=boundary[0][None], gt_surface_point=gt_pts[:1],
+                  inverse_offset=inv_v, tet_bxfx4x3=tet[:1], calculate_amips_volume=True)
+    assert len(a) == 6 and torch.equal(a[3], e[:1, 0]) and torch.equal(a[4], e[:1, 1]) and torch.equal(a[5], tet[:1])
+    torch.manual_seed(7)
+    c2, an2, n2 = surface_losses.surface_terms(pos0[:1], boundary[0][None], gt_pts[:1], per_face=20)
+    assert torch.equal(a[0], c2) and torch.equal(a[1], an2) and torch.equal(a[2], n2)
+    # empty surface -> ones (deftet.py:159-163)
+    empty = m.forward(v_pos_bxnx3=pos0[:1], tet_bxfx4=idxB[:1], boundary_bxfx3=boundary[0][None][:, :0], gt_surface_point=gt_pts[:1],
+                      tet_bxfx4x3=tet[:1], calculate_amips_volume=False)
+    assert all(x.shape == (1,) and x.item() == 1 for x in empty)
+    # laplacian_sparse vs a dense evaluation
+    from deftet_amd.utils.lib.tet_point_adj.interface import Tet_point_adj
+    V = pos0.shape[1]
+    adj = Tet_point_adj().run(V, idx.int().cpu().numpy(), normalize=True).to(cuda)
+    off = torch.randn(B, V, 3, device=cuda, generator=torch.Generator(device=cuda).manual_seed(4))
+    lap = m.laplacian_sparse(off, adj)
+    dense = adj.to_dense()
+    want = ((torch.einsum("vw,bwk->bvk", dense, off) - off) ** 2).sum(dim=(1, 2))
+    assert torch.allclose(lap, want, rtol=1e-4)
+    assert torch.allclose(dense.sum(1), torch.ones(V, device=cuda), atol=1e-5)            # rows of D^-1 A sum to one
+
+
+def test_overlay_reference_shaped_callers_run_on_gpu(cuda, oracle):
+    """deftet_amd.overlay.install(), then code written like the reference's callers (tests/ref_shaped_callers.py:
+    reference import paths, Kaolin entry points) runs on the GPU and returns what the verified operators return."""
+    import sys
+    import deftet_amd.overlay as overlay
+    from deftet_amd import hip_ops
+    B, Q = 2, 2000
+    pos0, idx, f3, t2, gt_verts, gt_faces, pts, inv_v = _case(cuda, B, Q, res=8)
+    saved = dict(sys.modules)
+    for k in [k for k in sys.modules if k.split(".")[0] in ("layers", "utils", "kaolin", "cv2")]:
+        del sys.modules[k]
+    try:
+        names = overlay.install(kaolin=True, deftet_module=True)
+        from tests import ref_shaped_callers as C
+        from layers.DefTet.deftet import DefTet                       # resolves to the HIP-backed module
+        tet = hip_ops.tet_gather(pos0, idx[None].expand(B, -1, -1).contiguous())
+        occ = C.occupancy_of_centroids(tet, [gt_verts[None]] * B, [gt_faces[None]] * B)
+        assert torch.equal(occ, DefTet().check_tet_inside_sdfs(tet, ([gt_verts[None]] * B, [gt_faces[None]] * B)))
+        pred = torch.rand(B, idx.shape[0], device=cuda, generator=torch.Generator(device=cuda).manual_seed(0))
+        cond, pasted = C.query_and_paste(tet, pts, pred)
+        assert np.array_equal(cond.cpu().numpy(), oracle.point_in_tet(tet.cpu().numpy(), pts.cpu().numpy()))
+        assert torch.equal(pasted, torch.gather(pred, 1, cond[..., 0].clamp(min=0).long()))
+        adj = C.vertex_adjacency(pos0.shape[1], idx.int().cpu().numpy()).coalesce()
+        want = oracle.tet_point_adj(idx.int().cpu().numpy(), pos0.shape[1])
+        got = adj.indices().t().numpy()
+        assert np.array_equal(got[np.lexsort((got[:, 1], got[:, 0]))], want[np.lexsort((want[:, 1], want[:, 0]))])
+        overlay.uninstall(names)
+    finally:
+        for k in [k for k in sys.modules if k.split(".")[0] in ("layers", "utils", "kaolin", "cv2")]:
+            del sys.modules[k]
+        sys.modules.update({k: v for k, v in saved.items() if k not in sys.modules})

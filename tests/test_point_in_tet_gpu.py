@@ -56,6 +56,12 @@ def test_empty_and_ragged(cuda):
     tet, p = cases.jittered(4, 5, 1)
     out = hip_ops.point_in_tet(torch.from_numpy(tet).to(cuda), torch.zeros(1, 0, 3, device=cuda))
     assert out.shape == (1, 0, 1)
+    # no tets: the backward still defines grad_pts (zeros), not uninitialised memory
+    tet0 = torch.zeros(2, 0, 4, 3, device=cuda)
+    pts = torch.rand(2, 10, 3, device=cuda)
+    cond = hip_ops.point_in_tet(tet0, pts)
+    g_tet, g_pts = hip_ops.point_in_tet_bwd(tet0, pts, cond, torch.ones(2, 10, 4, device=cuda), want_grad_pts=True)
+    assert g_tet.shape == (2, 0, 4, 3) and (g_pts == 0).all()
 
 
 def test_binned_equals_brute_res40(cuda):
@@ -345,3 +351,88 @@ def test_prepared_queries_two_streams(cuda, oracle):
         hip_ops.point_in_tet(t, p, prepared=pq)                       # a prepare feeds exactly one scan
     with pytest.raises(RuntimeError):
         hip_ops.prepare_queries(p, t.shape[1], algo=1)
+
+
+# ---------------------------------------------------------------------------------------------
+# reference-derived pins and the BASELINE.json configurations at full size
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("algo", [0, 1, 2, 3])
+@pytest.mark.parametrize("name", ["kuhn4", "kuhn8", "kuhn20", "soup", "cube40"])
+def test_index_pinned_by_reference_barycentrics(cuda, name, algo):
+    """HIP path vs tests/golden/pit_index_*.npz: expected index from the reference's own
+    bary_centric_tet (utils/tet_utils.py:28-45) evaluated on every (tet, query) pair; queries that
+    touch a tet within 1e-4 are masked (`ambiguous`)."""
+    from tests.test_cpu_oracle_golden import _pit_fixture
+    tet, pts, expected, ambiguous, w_ref = _pit_fixture(name)
+    cond, w = _run(tet[None], pts[None], cuda, algo, bary=True) if algo != 1 else (_run(tet[None], pts[None], cuda, algo), None)
+    got = cond[0, :, 0].astype(np.int64)
+    clear = ~ambiguous
+    assert np.array_equal(got[clear], expected[clear].astype(np.int64))
+    if w is not None:
+        sel = clear & (expected >= 0)
+        assert np.abs(w[0][sel] - w_ref[sel]).max() <= 1e-5 * max(1.0, np.abs(w_ref[sel]).max())
+
+
+def _check_outputs(t, p, cond, w):
+    """size-independent properties of (index, weights): partition of unity, sum w_i v_i = p, no hit outside the grid"""
+    hit = cond[..., 0] >= 0
+    idx = cond[..., 0].clamp(min=0).long()
+    verts = torch.gather(t, 1, idx[:, :, None, None].expand(-1, -1, 4, 3))
+    rec = (w[..., None] * verts).sum(2)
+    assert (rec - p)[hit].abs().max().item() < 2e-6
+    assert (w[hit].sum(-1) - 1).abs().max().item() < 1e-5 and w[hit].min().item() > -1e-5
+    assert (w[~hit] == 0).all()
+    assert not (hit & (p.abs() > 0.5).any(-1)).any()
+    return hit
+
+
+def test_config0_res20_10k_b1_vs_oracle(cuda, oracle):
+    """BASELINE configs[0]: res=20 grid (T=6,000), 10k queries, batch 1 — HIP (all traversal variants and the
+    brute kernel) vs the full CPU oracle, plus weights/backward vs fp64 autograd of the reference formula."""
+    from deftet_amd import hip_ops
+    tet, pts = cases.jittered(20, 10000, 1)
+    want = oracle.point_in_tet(tet, pts, omp=True)
+    for algo in (0, 1, 2, 3):
+        assert np.array_equal(_run(tet, pts, cuda, algo), want), algo
+    t, p = torch.from_numpy(tet).to(cuda), torch.from_numpy(pts).to(cuda)
+    cond, w, hits = hip_ops.point_in_tet(t, p, want_bary=True, want_hits=True)
+    _check_outputs(t, p, cond, w)
+    gw = torch.from_numpy(np.random.default_rng(4000).standard_normal((1, 10000, 4)).astype(np.float32)).to(cuda)
+    g = hip_ops.point_in_tet_bwd(t, p, cond, gw, hits=hits)[0].cpu().numpy()
+    w64, gt64 = oracle.point_in_tet_bwd_torch(tet, pts, want, gw.cpu().numpy())
+    hit = want[..., 0] >= 0
+    assert np.abs(w.cpu().numpy() - w64)[hit].max() <= 1e-5 * max(1.0, np.abs(w64).max())
+    assert np.abs(g - gt64).max() <= 1e-5 * np.abs(gt64).max() * 8
+
+
+@pytest.mark.parametrize("res,nq,batch,sub", [(40, 50000, 8, 4000), (70, 100000, 8, 2000)])
+def test_config_full_size_b8(cuda, oracle, res, nq, batch, sub):
+    """BASELINE configs[1] (res=40, 50k, B=8) and configs[2] (res=70, 100k, B=8) at FULL size:
+    binned == independent brute-force kernel on every query of every shape, HIP == CPU oracle (OpenMP) on
+    a `sub`-query subsample of every shape, output properties, and the hit-record backward against the
+    list backward."""
+    from deftet_amd import hip_ops
+    tet, pts = cases.jittered(res, nq, batch)
+    t, p = torch.from_numpy(tet).to(cuda), torch.from_numpy(pts).to(cuda)
+    gen = torch.Generator(device=cuda).manual_seed(res)
+    pred = torch.rand(batch, tet.shape[1], device=cuda, generator=gen)
+    cond, w, occ, hits = hip_ops.point_in_tet(t, p, want_bary=True, pred_bxt=pred, want_hits=True)
+    brute = hip_ops.point_in_tet(t, p, algo=1)
+    assert torch.equal(cond, brute)
+    hit = _check_outputs(t, p, cond, w)
+    assert 0.10 < (~hit).float().mean().item() < 0.17
+    # CPU oracle on a subsample of each shape (the oracle scans all T tets per query)
+    rng = np.random.default_rng(res)
+    pick = np.sort(rng.choice(nq, sub, replace=False))
+    want = oracle.point_in_tet(tet, np.ascontiguousarray(pts[:, pick]), omp=True)
+    assert np.array_equal(cond[:, pick].cpu().numpy(), want)
+    # pasted occupancy = pred[cond] with misses aliased to tet 0 (deftet.py:132-136)
+    idx = cond[..., 0].clamp(min=0).long()
+    assert torch.equal(occ, torch.gather(pred, 1, idx))
+    # backward: hit records vs per-tet lists
+    gw = torch.randn(batch, nq, 4, device=cuda, generator=gen)
+    go = torch.randn(batch, nq, device=cuda, generator=gen)
+    a = hip_ops.point_in_tet_bwd(t, p, cond, gw, grad_occ=go, hits=hits)
+    b = hip_ops.point_in_tet_bwd(t, p, cond, gw, grad_occ=go)
+    assert (a[0] - b[0]).abs().max() <= 2e-5 * b[0].abs().max()
+    assert (a[2] - b[2]).abs().max() <= 1e-4 * b[2].abs().max()

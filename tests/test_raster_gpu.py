@@ -93,7 +93,7 @@ def test_forward_matches_oracle_adversarial(cuda, oracle):
 
 
 def test_backward_matches_fp64_autograd(cuda, oracle):
-    from deftet_amd.render import deftet_sparse_render, peel2mask
+    from deftet_amd.render import deftet_sparse_render, alpha_composite
     fz, fxy, ff = projected_grid(6)
     pix, rngs = pixel_grid(24)
     pix = pix * 0.6
@@ -101,7 +101,7 @@ def test_backward_matches_fp64_autograd(cuda, oracle):
     txy = torch.from_numpy(fxy).to(cuda).requires_grad_(True)
     tff = torch.from_numpy(ff).to(cuda).requires_grad_(True)
     feat, face = deftet_sparse_render(tp, tr, tz, txy, tff, knum=48)
-    color, vis, _ = peel2mask(feat)                        # the reference's compositing on top
+    color, vis, _ = alpha_composite(feat)                  # front-to-back compositing on top (deftetrneder.py:102-113)
     g = torch.Generator(device=cuda).manual_seed(0)
     loss = (color * torch.rand(color.shape, device=cuda, generator=g)).sum() + (vis ** 2).sum()
     loss.backward()
@@ -110,7 +110,7 @@ def test_backward_matches_fp64_autograd(cuda, oracle):
     ff64 = torch.from_numpy(ff).double().requires_grad_(True)
     feat64 = oracle.sparse_render_torch(torch.from_numpy(pix).double(), xy64, ff64, face.cpu())
     assert torch.allclose(feat64.float(), feat.detach().cpu(), rtol=1e-4, atol=1e-5)
-    c64, v64, _ = peel2mask(feat64)
+    c64, v64, _ = alpha_composite(feat64)
     g = torch.Generator(device=cuda).manual_seed(0)
     wts = torch.rand(color.shape, device=cuda, generator=g).cpu().double()
     ((c64 * wts).sum() + (v64 ** 2).sum()).backward()

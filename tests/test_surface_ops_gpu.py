@@ -253,10 +253,11 @@ def test_tri_dist_backward(cuda, oracle, seed, monkeypatch):
     # from finite differences there by design — pinned against the oracle above, not against FD
 
 
-def test_mesh_utils_glue_runs_like_the_reference(cuda, oracle):
-    """get_surface_normal_loss / point_point_distance / point_mesh_distance composed exactly as
-    DefTet.forward does (layers/DefTet/deftet.py:168-181), with gradients to the vertices."""
-    from deftet_amd.utils import mesh_utils as mu
+def test_surface_terms_compose_like_deftet_forward(cuda, oracle):
+    """normal consistency / sample->cloud / cloud->surface terms composed as DefTet.forward does
+    (layers/DefTet/deftet.py:168-181), with gradients to the vertices; each term against a dense torch
+    evaluation of its definition."""
+    from deftet_amd import surface_losses as SL
     verts, tets = grids.kuhn_grid(16)
     pos = grids.jittered_positions(verts, 16, 1)
     f3, t2, _, _, _ = oracle.tet_to_face(tets, verts.shape[0])
@@ -267,18 +268,29 @@ def test_mesh_utils_glue_runs_like_the_reference(cuda, oracle):
     bnd[o2[sel][:, 0]] = bnd[o2[sel][:, 0]][:, ::-1]
     v = torch.from_numpy(pos).to(cuda).requires_grad_(True)
     faces = torch.from_numpy(bnd)[None].to(cuda)
-    surface_pos = torch.gather(v.unsqueeze(2).expand(-1, -1, 3, -1), 1, faces.unsqueeze(-1).expand(-1, -1, -1, 3))
-    normal_loss = mu.get_surface_normal_loss(v, faces)
-    torch.manual_seed(0)
-    pred_pts = mu.sample_surf_point_batch(surface_pos, 20).reshape(1, -1, 3)
     d = np.random.default_rng(0).standard_normal((20000, 3))
     gt = torch.from_numpy((0.3 * d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32))[None].to(cuda)
-    chamfer = mu.point_point_distance(pred_pts, gt).mean(-1)
-    analytic = mu.point_mesh_distance(gt, surface_pos).mean(-1).mean(-1)
+    gen = torch.Generator(device=cuda).manual_seed(0)
+    chamfer, analytic, normal_loss = SL.surface_terms(v, faces, gt, per_face=20, generator=gen)
     (normal_loss.sum() + chamfer.sum() + analytic.sum()).backward()
     assert torch.isfinite(v.grad).all() and v.grad.abs().sum() > 0
     assert 0 <= normal_loss.item() < 1 and 0 < chamfer.item() < 0.1 and 0 < analytic.item() < 0.1
-    # point_point_distance against a dense torch evaluation
-    dd = torch.cdist(pred_pts[0][:2000], gt[0]).min(-1).values
-    got = mu.point_point_distance(pred_pts[:, :2000].contiguous(), gt)[0]
-    assert torch.allclose(got, torch.sqrt(dd ** 2 + 1e-10), rtol=1e-3, atol=1e-5)
+    tri = SL.corners(v.detach(), faces)
+    assert torch.equal(tri[0], v.detach()[0][faces[0]])
+    # samples lie on their triangles: barycentric reconstruction error ~ 0, and they are area-uniform on average
+    smp = SL.sample_on_faces(tri, 64, generator=gen)
+    cen = smp.mean(2)
+    assert (cen - tri.mean(2)).abs().max() < 0.02
+    # sample -> cloud against a dense torch evaluation
+    pred_pts = SL.sample_on_faces(tri, 20, generator=gen).reshape(1, -1, 3)[:, :2000].contiguous()
+    dd = torch.cdist(pred_pts[0], gt[0]).min(-1).values
+    assert torch.allclose(SL.cloud_to_cloud(pred_pts, gt)[0], torch.sqrt(dd ** 2 + 1e-10), rtol=1e-3, atol=1e-5)
+    # normal consistency against the oracle's adjacency + fp64 normals
+    tab = oracle.face_edge_adj(tri[0].cpu().numpy())                   # [F,30] neighbour table, -1 padded
+    fi, ki = np.nonzero(tab >= 0)
+    adj = np.stack([fi, tab[fi, ki].astype(np.int64)])
+    n64 = torch.linalg.cross(tri[0, :, 1].double() - tri[0, :, 0].double(), tri[0, :, 2].double() - tri[0, :, 0].double())
+    n64 = n64 / torch.sqrt((n64 * n64).sum(-1, keepdim=True) + 1e-12)
+    a = torch.from_numpy(np.asarray(adj)).to(cuda).long()
+    want = (1 - (n64[a[0]] * n64[a[1]]).sum(-1)).mean()
+    assert abs(want.item() - normal_loss.item()) < 1e-5

@@ -97,8 +97,8 @@ def main():
          pairs_per_s=round(nq * 1e5 / tg / 1e9, 2), unit="G nominal distance evals/s")
     # the training-time distribution: 20 samples per predicted boundary face (deftet.py:174-177), i.e. queries ON a
     # surface close to the ground-truth cloud
-    from deftet_amd.utils import mesh_utils as mu
-    qs = mu.sample_surf_point_batch(face_d[None], 20).reshape(1, -1, 3).contiguous()
+    from deftet_amd import surface_losses
+    qs = surface_losses.sample_on_faces(face_d[None], 20).reshape(1, -1, 3).contiguous()
     tg2 = gpu_time(lambda: hip_ops.nn_index(qs, gt_d), reps=3)
     tb2 = gpu_time(lambda: hip_ops.nn_index(qs, gt_d, brute=True), reps=3)
     emit(op="nn_index", queries="20 samples per boundary face (training distribution)", n_query=int(qs.shape[1]), n_point=100000,
