@@ -4,13 +4,20 @@
 Metric (BASELINE.json): M tet-point tests/s (fwd+bwd) at res=70, 100k queries.
 One "step" = one pass of the hot path over one batch of B=8 synthetic shapes per GPU:
     fwd : point-in-tet index (A1) + barycentric weights of the hit tet + paste_occ gather
-    bwd : dL/dtet scatter (A1b) + dL/dpred scatter (paste_occ backward)
-`value` counts NOMINAL tet-point pairs B*T*Q per step (what the reference's brute-force
-kernel enumerates), inputs resident in HBM, acceleration-structure build included.
+    bwd : dL/dtet scatter (A1b) + dL/dpred scatter (paste_occ backward) + per-shape loss scalars
+`value` counts NOMINAL tet-point pairs B*T*Q per step (what the reference's brute-force kernel
+enumerates), inputs resident in HBM, acceleration-structure build included.  The steps rotate over
+N_SETS distinct input sets (different deformed grids, queries and gradients) so that no step finds
+its inputs in the 256 MiB Infinity Cache left by the previous one.
 
-    python bench.py [--gpus N --steps K --warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py [--gpus N --steps K --warmup W] [--config {1,2,3,4}]
+
+--gpus N > 1 without a torch.distributed environment re-launches itself under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N` (one rank per GPU, RCCL);
+when the driver has already launched it that way (WORLD_SIZE set) it just runs as a rank.
+--config picks the BASELINE.json configuration that is timed as the main line (default 2 =
+configs[2], the one the metric is quoted on); at N=1 the other configurations are measured after the
+timed region and reported under "other_configs" in the same JSON line.
 """
 from __future__ import annotations
 
@@ -18,6 +25,9 @@ import argparse
 import ctypes
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -27,98 +37,284 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-RES, N_QUERY, BATCH = 70, 100_000, 8          # BASELINE.json configs[2]
-HBM_PEAK_GBS = 8000.0                         # MI355X_MICROARCH.md: 8 TB/s spec
+HBM_PEAK_GBS = 8000.0                         # MI355X_MICROARCH.md: 8 TB/s HBM3E spec
+N_SETS = 3                                    # distinct input sets the steps rotate over
 
-
-def make_inputs(rank, device, res=RES, n_query=N_QUERY, batch=BATCH):
-    from deftet_amd import grids
-    verts, tets = grids.kuhn_grid(res)
-    pos = grids.jittered_positions(verts, res, batch, 0.1, seed0=1000 + rank * batch)
-    tet = grids.gather_tets(pos, tets)
-    pts = grids.random_queries(batch, n_query, seed0=2000 + rank * batch)
-    gw = np.stack([np.random.default_rng(4000 + rank * batch + b).standard_normal((n_query, 4)).astype(np.float32)
-                   for b in range(batch)])
-    pred = np.stack([np.random.default_rng(5000 + rank * batch + b).random(tet.shape[1]).astype(np.float32)
-                     for b in range(batch)])
-    gout = np.stack([np.random.default_rng(6000 + rank * batch + b).standard_normal(n_query).astype(np.float32)
-                     for b in range(batch)])
-    host = dict(tet=tet, pts=pts)
-    dev = {k: torch.from_numpy(v).to(device) for k, v in dict(tet=tet, pts=pts, gw=gw, pred=pred, gout=gout).items()}
-    return host, dev
-
+# BASELINE.json configs[i] -> workload.  configs[3] is "batch=64 sharded 8 shapes/GPU across 8 GPUs":
+# 8 shapes per GPU, so `--gpus 8 --config 3` IS that configuration and `--gpus 1 --config 3` one GPU's share.
+CONFIGS = {
+    1: dict(kind="pit", res=40, n_query=50_000, batch=8, sets=3,
+            name="BASELINE configs[1]: res=40 Kuhn tet grid, 50k queries, batch=8"),
+    2: dict(kind="pit", res=70, n_query=100_000, batch=8, sets=N_SETS,
+            name="BASELINE configs[2]: res=70 Kuhn tet grid (paper config), 100k queries, batch=8"),
+    3: dict(kind="pit", res=100, n_query=200_000, batch=8, sets=2,
+            name="BASELINE configs[3]: res=100 Kuhn tet grid, 200k queries, 8 shapes per GPU (batch=64 over 8 GPUs)"),
+    4: dict(kind="raster", res=70, npx=512, knum=64, batch=1, sets=1,
+            name="BASELINE configs[4]: tet rasterizer, 512x512 rays x k=64 over the unique faces of the res=70 grid"),
+}
 
 ALGO = int(os.environ.get("DEFTET_BENCH_ALGO", "0"))      # A/B switch for the traversal kernel (0 = shipped default)
-DOMINANT = {0: b"k_tet_scan", 2: b"k_tet_scan_staged", 3: b"k_tet_scan_rows"}.get(ALGO, b"k_tet_scan")
-
-
-GATHER = None                    # sharding.LossGather(), created in main() once the process group exists
 PIPELINE = os.environ.get("DEFTET_BENCH_PIPELINE", "1") not in ("", "0")
-OVERLAP_WITH = os.environ.get("DEFTET_BENCH_OVERLAP", "fwd")      # "fwd": start at once (measured 0.262 ms/step); "bwd": after this step's forward (0.276)
-_SIDE = None
 
 
-def side_stream():
-    global _SIDE
-    if _SIDE is None:
-        _SIDE = torch.cuda.Stream()
-    return _SIDE
+def dominant_kernel(algo):
+    from deftet_amd import hip_ops
+    return hip_ops.pit_kernel_name(algo).encode()
 
 
-def step(d, world):
-    """fwd: index + weights + fused paste_occ gather (+ per-tet hit records); bwd: dL/dtet and
-    dL/dpred from one per-tet pass over those records (no atomics); then the per-shape loss
-    scalars (all-gathered when world > 1).  Same calls as the PointInTetOcc autograd op makes."""
-    from deftet_amd import hip_ops, sharding
-    if PIPELINE:
-        # software pipelining across steps: the query side of the operator (bounding box + counting sort,
-        # five small latency-bound kernels that need only the points) is enqueued on a second stream as
-        # soon as the previous step's traversal has been launched, so it overlaps with that step's big
-        # kernels; every step still does all of its work (K sorts in the K timed steps)
-        pq = d.pop("pq", None)
-        if pq is None:
-            pq = hip_ops.prepare_queries(d["pts"], d["tet"].shape[1], algo=ALGO)
-        cond, w, occ, hits = hip_ops.point_in_tet(d["tet"], d["pts"], want_bary=True, pred_bxt=d["pred"], want_hits=True, algo=ALGO,
-                                                  prepared=pq)
-        if OVERLAP_WITH == "bwd":                                     # start it when this step's forward has finished
-            side_stream().wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side_stream()):
-            d["pq"] = hip_ops.prepare_queries(d["pts"], d["tet"].shape[1], algo=ALGO)
-    else:
-        cond, w, occ, hits = hip_ops.point_in_tet(d["tet"], d["pts"], want_bary=True, pred_bxt=d["pred"], want_hits=True, algo=ALGO)
-    g_tet, _, g_pred = hip_ops.point_in_tet_bwd(d["tet"], d["pts"], cond, d["gw"], grad_occ=d["gout"], hits=hits)
-    loss = hip_ops.rowdot(w, d["gw"], occ, d["gout"])         # [B] per-shape loss scalars
-    if world > 1:
-        # the only collective (RCCL over xGMI): enqueued asynchronously, consumed one step later, so
-        # the next step's kernels do not wait for it; main() flushes the last one inside the timed region
-        if torch.distributed.get_backend() == "gloo":                         # single-GPU test hook: stage through the host
-            loss = GATHER.submit(loss.cpu())
+class PitWorkload:
+    """point-in-tet fwd+bwd (A1 + A1b + paste_occ) on `sets` rotating input sets."""
+
+    def __init__(self, cfg, rank, device, world, gather=None, pipeline=PIPELINE, algo=ALGO):
+        from deftet_amd import grids
+        self.cfg, self.world, self.gather, self.pipeline, self.algo = cfg, world, gather, pipeline, algo
+        res, Q, B = cfg["res"], cfg["n_query"], cfg["batch"]
+        verts, tets = grids.kuhn_grid(res)
+        self.sets, self.host = [], None
+        for s in range(cfg["sets"]):
+            base = rank * B + s * 100_000                 # distinct seeds per rank and per set
+            pos = grids.jittered_positions(verts, res, B, 0.1, seed0=1000 + base)
+            tet = grids.gather_tets(pos, tets)
+            pts = grids.random_queries(B, Q, seed0=2000 + base)
+            T = tet.shape[1]
+            gw = np.stack([np.random.default_rng(4000 + base + b).standard_normal((Q, 4)).astype(np.float32) for b in range(B)])
+            pred = np.stack([np.random.default_rng(5000 + base + b).random(T).astype(np.float32) for b in range(B)])
+            gout = np.stack([np.random.default_rng(6000 + base + b).standard_normal(Q).astype(np.float32) for b in range(B)])
+            if s == 0:
+                self.host = dict(tet=tet[:1].copy(), pts=pts[:1].copy())
+            self.sets.append({k: torch.from_numpy(v).to(device) for k, v in dict(tet=tet, pts=pts, gw=gw, pred=pred, gout=gout).items()})
+        self.B, self.T, self.Q = B, self.sets[0]["tet"].shape[1], Q
+        self.pairs_per_step = float(B) * self.T * Q
+        self.unit = "M tet-point tests/s"
+        self.dominant = dominant_kernel(algo)
+        # SURVEY.md 8(d), A1 fwd: B*(48*T + 12*Q + 4*Q) algorithmic bytes per call — what the traversal kernel must
+        # touch once (48-byte tet records, 16-byte sorted queries); its per-tet hit records and the result atomics are
+        # overhead of THIS design and are not counted (DESIGN.md section 4)
+        self.dominant_bytes = B * (48.0 * self.T + 16.0 * Q)
+        # whole step (SURVEY 8(d)): fwd with weights B*(48T+16Q+16Q), bwd B*(32Q + 48*hits + 48T), hits ~ 0.864*Q
+        self.step_bytes = B * (48.0 * self.T + 32.0 * Q) + B * (32.0 * Q + 48.0 * 0.864 * Q + 48.0 * self.T)
+        self._side = None
+        self._pq = {}
+        self.last = None
+
+    def side_stream(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+        return self._side
+
+    def step(self, i):
+        """fwd: index + weights + fused paste_occ gather (+ per-tet hit records); bwd: dL/dtet and dL/dpred from one
+        per-tet pass over those records (no atomics); then the per-shape loss scalars (all-gathered when world > 1).
+        Same calls as the PointInTetOcc autograd op makes."""
+        from deftet_amd import hip_ops
+        d = self.sets[i % len(self.sets)]
+        if self.pipeline:
+            # software pipelining across steps: the query side of the operator (bounding box + counting sort, small
+            # latency-bound kernels that need only the points) of step i+1 is enqueued on a second stream as soon as
+            # step i's traversal has been launched; every step still does all of its work (K sorts in K timed steps)
+            pq = self._pq.pop(i, None)
+            if pq is None:
+                pq = hip_ops.prepare_queries(d["pts"], self.T, algo=self.algo)
+            cond, w, occ, hits = hip_ops.point_in_tet(d["tet"], d["pts"], want_bary=True, pred_bxt=d["pred"], want_hits=True,
+                                                      algo=self.algo, prepared=pq)
+            nxt = self.sets[(i + 1) % len(self.sets)]
+            with torch.cuda.stream(self.side_stream()):
+                self._pq = {i + 1: hip_ops.prepare_queries(nxt["pts"], self.T, algo=self.algo)}
         else:
-            loss = GATHER.submit(loss)
-    return cond, w, g_tet, g_pred, loss
+            cond, w, occ, hits = hip_ops.point_in_tet(d["tet"], d["pts"], want_bary=True, pred_bxt=d["pred"], want_hits=True,
+                                                      algo=self.algo)
+        g_tet, _, g_pred = hip_ops.point_in_tet_bwd(d["tet"], d["pts"], cond, d["gw"], grad_occ=d["gout"], hits=hits)
+        loss = hip_ops.rowdot(w, d["gw"], occ, d["gout"])         # [B] per-shape loss scalars
+        if self.world > 1:
+            # the only collective (RCCL over xGMI): enqueued asynchronously, consumed one step later
+            loss = self.gather.submit(loss.cpu() if torch.distributed.get_backend() == "gloo" else loss)
+        self.last = (cond, w, g_tet, g_pred, loss)
+
+    def drain(self):
+        self._pq = {}
+        if self.world > 1 and self.gather is not None:
+            self.gather.flush()                           # the last step's all-gather belongs to the timed region
+
+    def describe(self):
+        return {"workload": "%s: T=%d tets, %d uniform queries, %d shapes per GPU, point-in-tet index + weights + paste_occ, "
+                            "fwd+bwd, grid build included, %d rotating input sets" % (self.cfg["name"], self.T, self.Q, self.B, len(self.sets)),
+                "res": self.cfg["res"], "n_tet": self.T, "n_query": self.Q, "batch_per_gpu": self.B, "input_sets": len(self.sets),
+                "sharding": "shapes sharded by rank; all-gather of %d loss scalars" % (self.world * self.B),
+                "pipelining": ("query sort of step i+1 enqueued on a second stream during step i" if self.pipeline else "none")}
 
 
-def cpu_baseline(host):
+class RasterWorkload:
+    """deftet_sparse_render fwd+bwd at BASELINE configs[4] (parity unpinned w.r.t. Kaolin)."""
+
+    def __init__(self, cfg, rank, device, world, gather=None):
+        from deftet_amd import grids, hip_ops
+        self.cfg, self.world = cfg, world
+        verts, tets = grids.kuhn_grid(cfg["res"])
+        f3 = hip_ops.tet_to_face(tets, verts.shape[0], device, with_boundary=True)[0].cpu().numpy()
+        fz, fxy, ff = grids.project_faces(verts, f3, seed=rank)
+        pix, rngs = grids.pixel_grid(cfg["npx"])
+        self.t = [torch.from_numpy(x).to(device) for x in (pix, rngs, fz, fxy, ff)]
+        self.t[3].requires_grad_(True)
+        self.t[4].requires_grad_(True)
+        self.P, self.F, self.k = pix.shape[1], fxy.shape[1], cfg["knum"]
+        self.go = torch.rand(1, self.P, self.k, 4, device=device, generator=torch.Generator(device=device).manual_seed(rank))
+        self.pairs_per_step = float(self.P) * self.F
+        self.unit = "M ray-face tests/s"
+        self.dominant = b"k_pix_raster"
+        # SURVEY 8(d) A12 fwd: F*(12+24+48) + P*(8+8) + P*k*(16+4)
+        self.dominant_bytes = self.F * 84.0 + self.P * 16.0 + self.P * self.k * 20.0
+        self.step_bytes = 2.0 * self.dominant_bytes
+        self.last = None
+
+    def step(self, i):
+        from deftet_amd.render import deftet_sparse_render
+        feat, face = deftet_sparse_render(*self.t, knum=self.k)
+        gxy, gff = torch.autograd.grad(feat, (self.t[3], self.t[4]), self.go)
+        self.last = (feat, face, gxy, gff)
+
+    def drain(self):
+        pass
+
+    def describe(self):
+        return {"workload": "%s: %d rays x %d faces, k=%d, fwd+bwd, tile binning included; PARITY UNPINNED (Kaolin absent)" % (
+            self.cfg["name"], self.P, self.F, self.k), "n_ray": self.P, "n_face": self.F, "knum": self.k}
+
+
+def make_workload(cfg_id, rank, device, world, gather=None, **kw):
+    cfg = CONFIGS[cfg_id]
+    return (PitWorkload if cfg["kind"] == "pit" else RasterWorkload)(cfg, rank, device, world, gather, **kw)
+
+
+def timed(wl, lib, steps, warmup, world, barrier=True):
+    """W untimed warm-up steps, then exactly K steps bracketed by barrier + synchronize on both sides.  Returns the wall
+    time, the per-step HIP-event times (ms) and the dominant kernel's (total ms, launches) from the library's own
+    events on the launch stream."""
+    for i in range(warmup):
+        wl.step(i)
+    wl.drain()
+    torch.cuda.synchronize()
+    lib.deftet_profile_select(wl.dominant)
+    if world > 1 and barrier:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    t0 = time.perf_counter()
+    for i in range(steps):
+        evs[i].record()
+        wl.step(warmup + i)
+    evs[steps].record()
+    wl.drain()
+    torch.cuda.synchronize()
+    if world > 1 and barrier:
+        torch.distributed.barrier()
+    elapsed = time.perf_counter() - t0
+    tot_ms, cnt = ctypes.c_double(0), ctypes.c_longlong(0)
+    lib.deftet_profile_read(ctypes.byref(tot_ms), ctypes.byref(cnt))
+    lib.deftet_profile_select(b"")
+    per_step = [evs[i].elapsed_time(evs[i + 1]) for i in range(steps)]
+    return elapsed, per_step, tot_ms.value, cnt.value
+
+
+def measure_bandwidth(device):
+    """What this box's HBM actually delivers: device-to-device copy (read + write) and a read-only streaming sum
+    (the library's rowdot kernel) over 1 GiB, HIP-event timed.  Quoted beside the 8 TB/s spec figure."""
+    from deftet_amd import hip_ops
+    n = 1 << 28
+    src = torch.empty(n, device=device, dtype=torch.float32).uniform_()
+    dst = torch.empty_like(src)
+    out = {}
+    for name, fn, nbytes in (("copy", lambda: dst.copy_(src), 8.0 * n), ("read", lambda: hip_ops.rowdot(src.view(256, -1)), 4.0 * n)):
+        for _ in range(3):
+            fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 10
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        out[name] = nbytes * reps / (a.elapsed_time(b) * 1e-3) / 1e9
+    del src, dst
+    return out
+
+
+def cpu_baseline(wl):
     """Oracle (CPU restatement, kind="port") on a bounded sample of the same workload."""
     from oracle import oracle as O
-    tet = host["tet"][:1]
+    tet, pts = wl.host["tet"], wl.host["pts"]
     ncpu = os.cpu_count() or 1
     q1 = 1500
     t0 = time.perf_counter()
-    O.point_in_tet(tet, host["pts"][:1, :q1])
+    O.point_in_tet(tet, pts[:1, :q1])
     t1 = time.perf_counter() - t0
-    qn = min(N_QUERY, max(2000, 1200 * ncpu))
+    qn = min(wl.Q, max(2000, 1200 * ncpu))
     t0 = time.perf_counter()
-    _, nthreads = O.point_in_tet(tet, host["pts"][:1, :qn], omp=True, return_executed=True)
+    _, nthreads = O.point_in_tet(tet, pts[:1, :qn], omp=True, return_executed=True)
     tn = time.perf_counter() - t0
     T = tet.shape[1]
     return {
         "value": round(T * qn / tn / 1e6, 2), "unit": "M tet-point tests/s (fwd only)", "cores": int(nthreads),
         "kind": "port",
         "sample": "oracle/deftet_oracle.c brute-force scan, 1 shape res=%d (T=%d), first %d queries, OpenMP over "
-                  "queries; single-core on %d queries: %.2f M/s" % (RES, T, qn, q1, T * q1 / t1 / 1e6),
+                  "queries; single-core on %d queries: %.2f M/s" % (wl.cfg["res"], T, qn, q1, T * q1 / t1 / 1e6),
         "value_1core": round(T * q1 / t1 / 1e6, 2),
     }
+
+
+def traffic_record(kernel):
+    """HBM bytes per launch of the dominant kernel from the rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE, corrected as
+    MI355X_MICROARCH.md prescribes).  Counters cannot be read from inside the timed process, so this is the figure
+    tools/pmc_traffic.py collected for the same command; its source file is named next to it."""
+    for rel in ("profiles/r02_pmc_traffic.json", "profiles/pmc_traffic.json"):
+        path = os.path.join(ROOT, rel)
+        if os.path.exists(path):
+            try:
+                rec = json.load(open(path))
+            except Exception:
+                continue
+            v = rec.get("%s_hbm_bytes_per_launch" % kernel)
+            if v is not None:
+                return v, rel
+    return None, None
+
+
+def summarize(wl, elapsed, per_step, kern_ms_tot, kern_cnt, steps, world, peak_measured=None):
+    kern_ms = kern_ms_tot / max(kern_cnt, 1)
+    achieved = wl.dominant_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+    step_gbs = wl.step_bytes / (elapsed / steps) / 1e9
+    kernel = wl.dominant.decode()
+    traffic, src = traffic_record(kernel)
+    roof = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": src,
+            "algorithmic_bytes_per_launch": wl.dominant_bytes, "avg_launch_ms": round(kern_ms, 5), "launches_timed": int(kern_cnt),
+            "whole_step": {"algorithmic_bytes": wl.step_bytes, "achieved": round(step_gbs, 1), "frac": round(step_gbs / HBM_PEAK_GBS, 4)}}
+    if peak_measured:
+        roof["peak_measured"] = {"copy_GBs": round(peak_measured["copy"], 1), "read_GBs": round(peak_measured["read"], 1),
+                                 "how": "1 GiB device-to-device copy (read+write bytes) and read-only streaming sum on this GPU, HIP events"}
+        roof["frac_of_measured_read"] = round(achieved / peak_measured["read"], 4)
+    return {
+        "value": round(world * wl.pairs_per_step * steps / elapsed / 1e6, 1), "unit": wl.unit,
+        "ms_per_step": round(elapsed / steps * 1e3, 4), "ms_per_step_median": round(statistics.median(per_step), 4),
+        "roofline": roof,
+    }
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` started without a torch.distributed environment: become the launcher."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -126,15 +322,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     # DEFTET_BENCH_TEST_SHARED_GPU=1 is a TEST hook for single-GPU boxes: every rank uses cuda:0 and the
@@ -146,6 +345,7 @@ def main():
         raise SystemExit("rank %d wants cuda:%d but only %d device(s) are visible" % (rank, dev_index, torch.cuda.device_count()))
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
+    backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -153,86 +353,64 @@ def main():
             torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
         else:
             torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        backend = torch.distributed.get_backend()
 
-    from deftet_amd import _lib
+    from deftet_amd import _lib, sharding
     lib = _lib.load()
-    host, d = make_inputs(rank, device)
-    B, T, Q = d["tet"].shape[0], d["tet"].shape[1], d["pts"].shape[1]
-
-    global GATHER
-    from deftet_amd import sharding
-    GATHER = sharding.LossGather()
-    for _ in range(args.warmup):
-        step(d, world)
-    if world > 1:
-        GATHER.flush()
-    torch.cuda.synchronize()
-
-    dominant = DOMINANT
-    lib.deftet_profile_select(dominant)
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step(d, world)
-    if world > 1:
-        GATHER.flush()                                   # the last step's all-gather belongs to the timed region
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    elapsed = time.perf_counter() - t0
-    tot_ms, cnt = ctypes.c_double(0), ctypes.c_longlong(0)
-    lib.deftet_profile_read(ctypes.byref(tot_ms), ctypes.byref(cnt))
-    lib.deftet_profile_select(b"")
-
+    gather = sharding.LossGather()
+    wl = make_workload(args.config, rank, device, world, gather)
+    elapsed, per_step, kms, kcnt = timed(wl, lib, args.steps, args.warmup, world)
     if world > 1:
         t = torch.tensor([elapsed], device="cpu" if shared else device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
 
     if rank == 0:
-        pairs = float(world) * B * T * Q * args.steps
-        kern_ms = tot_ms.value / max(cnt.value, 1)
-        # SURVEY.md 8(d), A1 fwd: B*(48*T + 12*Q + 4*Q) algorithmic bytes per call — exactly what k_tet_scan must
-        # touch once (48-byte tet records, 16-byte sorted queries).  Its 16-byte-per-tet hit records and the
-        # result atomics are overhead of THIS design and are not counted.
-        algo_bytes = B * (48.0 * T + 16.0 * Q)
-        achieved = algo_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
-        # whole step: fwd with weights B*(48T+16Q+16Q), bwd B*(32Q + 48*hits + 48T), hits ~ 0.864*Q
-        step_bytes = B * (48.0 * T + 32.0 * Q) + B * (32.0 * Q + 48.0 * 0.864 * Q + 48.0 * T)
-        step_gbs = step_bytes / (elapsed / args.steps) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("k_tet_scan_hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        peak = measure_bandwidth(device) if world == 1 else None
+        main_line = summarize(wl, elapsed, per_step, kms, kcnt, args.steps, world, peak)
         line = {
-            "metric": "M tet-point tests/s (fwd+bwd) at res=70, 100k queries",
-            "value": round(pairs / elapsed / 1e6, 1),
-            "unit": "M tet-point tests/s",
+            "metric": ("M tet-point tests/s (fwd+bwd) at res=70, 100k queries" if args.config == 2 else
+                       "%s (fwd+bwd), %s" % (wl.unit, CONFIGS[args.config]["name"])),
+            "value": main_line["value"], "unit": main_line["unit"],
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "ms_per_step": main_line["ms_per_step"], "ms_per_step_median": main_line["ms_per_step_median"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: res=70 Kuhn tet grid (T=%d), %d uniform queries, batch=%d shapes "
-                                   "per GPU, point-in-tet index + weights + paste_occ, fwd+bwd, grid build included" % (T, Q, B),
-                       "res": RES, "n_tet": T, "n_query": Q, "batch_per_gpu": B,
-                       "sharding": "shapes sharded by rank; all-gather of %d loss scalars" % (world * B),
-                       "pipelining": ("query sort of step i+1 enqueued on a second stream during step i" if PIPELINE else "none")},
-            "roofline": {"bound": "hbm", "kernel": dominant.decode(), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": round(kern_ms, 5),
-                         "launches_timed": int(cnt.value),
-                         "whole_step": {"algorithmic_bytes": step_bytes, "achieved": round(step_gbs, 1),
-                                        "frac": round(step_gbs / HBM_PEAK_GBS, 4)}},
+            "config": wl.describe(),
+            "roofline": main_line["roofline"],
         }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(host)
+        if world > 1:
+            line["rccl_ranks"] = torch.distributed.get_world_size()
+            line["backend"] = backend
+        if world == 1:
+            if isinstance(wl, PitWorkload) and wl.pipeline:
+                # per-call latency without the cross-step overlap (not the headline; printed beside it)
+                wl.pipeline = False
+                e2, ps2, _, _ = timed(wl, lib, args.steps, 2, 1, barrier=False)
+                line["ms_per_step_unpipelined"] = round(e2 / args.steps * 1e3, 4)
+                line["ms_per_step_unpipelined_median"] = round(statistics.median(ps2), 4)
+                wl.pipeline = True
+            if not args.no_cpu_baseline and isinstance(wl, PitWorkload):
+                line["cpu_baseline"] = cpu_baseline(wl)
+            if not args.no_other_configs:
+                del wl
+                torch.cuda.empty_cache()
+                others = []
+                for cid in sorted(CONFIGS):
+                    if cid == args.config:
+                        continue
+                    w2 = make_workload(cid, 0, device, 1, None)
+                    e, ps, km, kc = timed(w2, lib, max(5, args.steps // 2), 2, 1, barrier=False)
+                    rec = summarize(w2, e, ps, km, kc, max(5, args.steps // 2), 1, peak)
+                    others.append({"config_id": cid, "config": w2.describe()["workload"], "value": rec["value"], "unit": rec["unit"],
+                                   "ms_per_step": rec["ms_per_step"], "ms_per_step_median": rec["ms_per_step_median"],
+                                   "roofline": {k: rec["roofline"][k] for k in ("kernel", "achieved", "frac", "avg_launch_ms", "whole_step")}})
+                    del w2
+                    torch.cuda.empty_cache()
+                line["other_configs"] = others
         print(json.dumps(line), flush=True)
     if world > 1:
+        torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 
 

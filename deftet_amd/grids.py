@@ -22,7 +22,7 @@ import numpy as np
 
 __all__ = [
     "kuhn_grid", "jittered_positions", "gather_tets", "random_queries",
-    "make_case", "read_tet", "write_tet", "tet_orientation",
+    "make_case", "read_tet", "write_tet", "tet_orientation", "project_faces", "pixel_grid",
 ]
 
 
@@ -136,3 +136,34 @@ def write_tet(path: str, verts: np.ndarray, tets: np.ndarray) -> None:
         f.write("tet %d %d\n" % (verts.shape[0], tets.shape[0]))
         np.savetxt(f, verts, fmt="%.9g")
         np.savetxt(f, tets, fmt="%d")
+
+
+# ---------------------------------------------------------------------------------
+# Rasterizer inputs (BASELINE configs[4]): the grid scaled by `coef`
+# (diff_render/diftet_6_subdiv expconfig.py:53-56), one camera at radius `cam_z` looking down -z with the
+# NeRF-blender projection vector [2f/W, 2f/H, -1] (2_data/load_blender.py:189-190), image coordinates
+# multiplied by 1000 (3_model/deftet.py:459-468); per-vertex RGBA features U[0,1).
+# ---------------------------------------------------------------------------------
+def project_faces(verts01, face_fx3, rot=(0.35, 0.5), cam_z=4.0, focal=1111.0 / 800.0 * 2.0, mult=1000.0, coef=2.5, seed=0):
+    """face_z [1,F,3], face_xy [1,F,3,2], feat [1,F,3,4] (float32) of the indexed triangles `face_fx3`."""
+    p = (np.asarray(verts01, np.float64) - 0.5) * coef
+    ax, ay = rot
+    Rx = np.array([[1, 0, 0], [0, np.cos(ax), -np.sin(ax)], [0, np.sin(ax), np.cos(ax)]])
+    Ry = np.array([[np.cos(ay), 0, np.sin(ay)], [0, 1, 0], [-np.sin(ay), 0, np.cos(ay)]])
+    p = p @ (Rx @ Ry).T
+    pc = p - np.array([0, 0, cam_z])
+    xy3 = pc * np.array([focal, focal, -1.0])
+    xy = xy3[:, :2] / xy3[:, 2:3] * mult
+    feat_v = np.random.default_rng(seed).random((p.shape[0], 4))
+    f3 = np.asarray(face_fx3, np.int64)
+    return (pc[f3][:, :, 2][None].astype(np.float32), xy[f3][None].astype(np.float32), feat_v[f3][None].astype(np.float32))
+
+
+def pixel_grid(n, mult=1000.0):
+    """pixel centres [1,n*n,2] on [-1,1]^2 * mult and render ranges [1,n*n,2] = [-1000, 0] (3_model/deftet.py:459-468)."""
+    a = (np.arange(n) + 0.5) / n * 2 - 1
+    X, Y = np.meshgrid(a, a, indexing="xy")
+    pix = np.stack([X, Y], -1).reshape(1, -1, 2) * mult
+    rngs = np.zeros_like(pix)
+    rngs[..., 0] = -1000.0
+    return pix.astype(np.float32), rngs.astype(np.float32)

@@ -12,6 +12,12 @@ import torch
 from . import _lib
 
 PIT_AUTO, PIT_BRUTE, PIT_STAGED, PIT_ROWS = 0, 1, 2, 3
+_PIT_KERNEL = {PIT_AUTO: "k_tet_scan", PIT_BRUTE: "k_brute", PIT_STAGED: "k_tet_scan_staged", PIT_ROWS: "k_tet_scan_rows"}
+
+
+def pit_kernel_name(algo=PIT_AUTO):
+    """Name of the traversal kernel an `algo` value launches (what deftet_profile_select / rocprofv3 show)."""
+    return _PIT_KERNEL[int(algo)]
 
 
 def _f32c(t):

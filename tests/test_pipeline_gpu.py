@@ -151,3 +151,23 @@ def test_overlay_reference_shaped_callers_run_on_gpu(cuda, oracle):
         for k in [k for k in sys.modules if k.split(".")[0] in ("layers", "utils", "kaolin", "cv2")]:
             del sys.modules[k]
         sys.modules.update({k: v for k, v in saved.items() if k not in sys.modules})
+
+
+def test_bench_self_launches_two_ranks(cuda):
+    """`python bench.py --gpus 2` with no torch.distributed environment re-launches itself under torch.distributed.run
+    and rank 0 prints the JSON line (the driver's command).  Single-GPU box: both ranks share cuda:0 and the collectives
+    are staged over gloo (DEFTET_BENCH_TEST_SHARED_GPU=1); on a multi-GPU node the same command runs over RCCL."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DEFTET_BENCH_TEST_SHARED_GPU="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--config", "1"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["rccl_ranks"] == 2 and rec["steps"] == 3 and rec["value"] > 0
+    assert rec["roofline"]["launches_timed"] == 3 and 0 < rec["roofline"]["frac"] < 1
+    assert "cpu_baseline" not in rec                         # rank 0 at N=1 only

@@ -11,34 +11,16 @@ from deftet_amd import grids
 pytestmark = pytest.mark.gpu
 
 
-def projected_grid(res, rot=(0.35, 0.5), cam_z=4.0, focal=1111.0 / 800.0 * 2.0, mult=1000.0, coef=2.5, seed=0):
-    """Unique faces (incl. boundary) of a res=R Kuhn grid scaled by `coef`, rotated, projected by
-    the reference's perspective() (3_model/cameraop.py:19-33) and multiplied by 1000
-    (3_model/deftet.py:459-468).  Returns face_z [1,F,3], face_xy [1,F,3,2], feat [1,F,3,4]."""
+def projected_grid(res, **kw):
+    """Unique faces (incl. boundary) of a res=R Kuhn grid (from the ORACLE's face table), projected by
+    grids.project_faces.  Returns face_z [1,F,3], face_xy [1,F,3,2], feat [1,F,3,4]."""
     from oracle import oracle as O
     verts, tets = grids.kuhn_grid(res)
     f3, _, _, _, _ = O.tet_to_face(tets, verts.shape[0], with_boundary=True)
-    p = (verts - 0.5) * coef
-    ax, ay = rot
-    Rx = np.array([[1, 0, 0], [0, np.cos(ax), -np.sin(ax)], [0, np.sin(ax), np.cos(ax)]])
-    Ry = np.array([[np.cos(ay), 0, np.sin(ay)], [0, 1, 0], [-np.sin(ay), 0, np.cos(ay)]])
-    p = p @ (Rx @ Ry).T
-    pc = p - np.array([0, 0, cam_z])
-    proj = np.array([focal, focal, -1.0])
-    xy3 = pc * proj
-    xy = xy3[:, :2] / xy3[:, 2:3] * mult
-    rng = np.random.default_rng(seed)
-    feat_v = rng.random((verts.shape[0], 4))
-    return (pc[f3][:, :, 2][None].astype(np.float32), xy[f3][None].astype(np.float32), feat_v[f3][None].astype(np.float32))
+    return grids.project_faces(verts, f3, **kw)
 
 
-def pixel_grid(n, mult=1000.0):
-    a = (np.arange(n) + 0.5) / n * 2 - 1
-    X, Y = np.meshgrid(a, a, indexing="xy")
-    pix = np.stack([X, Y], -1).reshape(1, -1, 2) * mult
-    rngs = np.zeros_like(pix)
-    rngs[..., 0] = -1000.0
-    return pix.astype(np.float32), rngs.astype(np.float32)
+pixel_grid = grids.pixel_grid
 
 
 def run(pix, rngs, fz, fxy, ff, knum, dev, eps=1e-8):
