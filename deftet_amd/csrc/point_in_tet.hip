@@ -49,7 +49,8 @@ __host__ __device__ inline size_t hit_list_off(int B, int T) { return (size_t)B 
 #ifndef PIT_GDIV
 #define PIT_GDIV 6.0
 #endif
-constexpr int kXFine = PIT_XFINE;           // cells are kXFine times finer along x (the run direction)
+constexpr int kXFine = PIT_XFINE;           // default: cells are kXFine times finer along x (the run direction)
+constexpr int kMaxXFine = 8;                // upper bound of the runtime override DEFTET_PIT_XFINE (LDS sizing of k_row_fine)
 
 // ------------------------------------------------------------------------------------
 // exact predicate pieces (check_condition_tet_for.cu:105-121, :172-176)
@@ -361,7 +362,7 @@ __global__ __launch_bounds__(256) void k_row_fine(const float4 *__restrict__ row
                                                   int G, int Gx, const int *__restrict__ rowStart, long long cellStride, int *cells,
                                                   float4 *sortedQ)
 {
-    __shared__ int cnt[4][kMaxG * kXFine];
+    __shared__ int cnt[4][kMaxG * kMaxXFine];
     const int b = blockIdx.y, wv = threadIdx.x >> 6, lane = threadIdx.x & 63, R = G * G;
     const int row = blockIdx.x * 4 + wv;
     const bool live = row < R;
@@ -554,6 +555,278 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan(const float *__rest
         hits[(size_t)b * T + t] = hrec;
     }
     irregular_queries_tail(P, t, b, Q, pts, counters, irregQ, result);
+}
+
+// ------------------------------------------------------------------------------------
+// k_tet_scan_fma (DEFTET_PIT_FMA / DEFTET_PIT_FMA2): same traversal as k_tet_scan, but the per-candidate work
+// — box test (6 compares) + exact predicate (4 x [3 sub, 3 mul, 2 add, 1 cmp]) — is replaced by a CERTIFIED
+// fused filter: one 3-FMA chain per face plane, one min over the four, two compares.  The exact predicate runs
+// only for candidates the filter cannot decide (a band of a few fp32 ulps around the face planes: ~1e-4 of the
+// candidates on the BASELINE workload), so the result is still bit-exact.  k_tet_scan is bound by VALU issue
+// (44.8 M wave-instructions x 4 cycles = 83 us of its 105 us; profiles/r01_pmc_k_tet_scan_variants.json), and
+// ~80 % of those instructions are the per-candidate tests.
+//
+// For a regular tet (see k_tet_scan) with sigma = sign of its four dotv4, the reference accepts p iff
+//     sigma * dotp_i(p) > 0  for i = 0..3        (dotp_i = fl(n_i . fl(p - a_i)), source operation order)
+// ("all four false" cannot happen for regular tets).  With D_i = n_i . (p - a_i) in exact
+// arithmetic over the COMPUTED normals:  |dotp_i - D_i| <= 4.0001 u * sum_k |n_ik| (|p_k| + |a_ik|),  u = 2^-24.
+// The filter evaluates  A_i = fma(N_i0, x, fma(N_i1, y, fma(N_i2, z, C_i))),  N_i = sigma n_i,
+// C_i = fl(-sigma c_i - E_i),  c_i = fma(n_i0, a_i0, fma(n_i1, a_i1, n_i2 a_i2)),  which equals
+// sigma D_i - E_i up to  3u sum|n||p| + 7u sum|n||a| + 4u E_i.  With
+//     E_i = 16 u * sum_k |n_ik| (P_k + 2 M_k) + 2^-120,   P_k >= |p_k| for every regular query (grid box),
+//                                                         M_k >= |vertex coordinate k| of this tet,
+// E_i exceeds the sum of both error bounds (7u + 4u on |p|, 11u + 4u... on |a|, with a factor ~2 to spare for the
+// fp32 evaluation of E_i itself), hence
+//     min_i A_i > 0              =>  every sigma * dotp_i > 0        =>  the reference accepts   (certain)
+//     min_i A_i < -2 max_i E_i   =>  some  sigma * dotp_j < 0        =>  the reference rejects   (certain)
+// and anything in between is handed to the exact predicate.  No box test is needed: a point outside the tet
+// violates at least one plane.  2^-120 absorbs products that underflow in either evaluation.
+// PACKED: two candidates per instruction (v_pk_fma_f32).
+// ------------------------------------------------------------------------------------
+constexpr float kErrScale = 9.5367431640625e-07f;      // 16 u = 2^-20
+constexpr float kErrAbs = 7.5231638e-37f;              // 2^-120
+
+struct Filter {
+    float N[4][3];
+    float C[4];
+    float twoEmax;
+};
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Exact re-scan of ONE tet's candidates (box test + reference predicate, as k_tet_scan does), used by k_tet_scan_fma for
+// the rare tets whose traversal met the filter's undecided band or more than four acceptances.  Out of line and called
+// AFTER the traversal loop, so that nothing of it is scheduled (or kept in registers) inside the loop.  Publishes every
+// accepted query with atomicMin (idempotent w.r.t. the ones the filter already accepted) and returns the hit record.
+__device__ __noinline__ int4 exact_rescan(const float *__restrict__ tv, int t, const int *__restrict__ cb, const float4 *__restrict__ sq,
+                                          int *res, int G, int Gx, int cx0, int cx1, int cy0, int cy1, int cz0, int cz1,
+                                          float m, int *overflowFlag)
+{
+    float vv[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) vv[k] = tv[k];
+    Planes P;
+    make_planes(vv, P);
+    float elo[3], ehi[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        elo[k] = fminf(fminf(vv[k], vv[3 + k]), fminf(vv[6 + k], vv[9 + k])) - m;
+        ehi[k] = fmaxf(fmaxf(vv[k], vv[3 + k]), fmaxf(vv[6 + k], vv[9 + k])) + m;
+    }
+    int4 hrec = make_int4(-1, -1, -1, -1);
+    int hcnt = 0;
+    for (int cz = cz0; cz <= cz1; ++cz)
+        for (int cy = cy0; cy <= cy1; ++cy) {
+            const int row = (cz * G + cy) * Gx;
+            const int s = cb[row + cx0], e = cb[row + cx1 + 1];
+            for (int j = s; j < e; ++j) {
+                const float4 q = sq[j];
+                if (q.x >= elo[0] && q.x <= ehi[0] && q.y >= elo[1] && q.y <= ehi[1] && q.z >= elo[2] && q.z <= ehi[2] &&
+                    accept(P, q.x, q.y, q.z)) {
+                    const int qi = __float_as_int(q.w);
+                    atomicMin(&res[qi], t);
+                    if (hcnt == 0) hrec.x = qi;
+                    else if (hcnt == 1) hrec.y = qi;
+                    else if (hcnt == 2) hrec.z = qi;
+                    else if (hcnt == 3) hrec.w = qi;
+                    ++hcnt;
+                }
+            }
+        }
+    if (hcnt > 4) {
+        hrec.w = kHitOverflow;
+        *overflowFlag = 1;
+    }
+    return hrec;
+}
+
+// irregular queries (NaN / Inf / huge; normally none): re-load the tet so that its vertices need not stay in
+// registers across the traversal loop
+__device__ __noinline__ void fma_irregular_tail_slow(const float *__restrict__ tet, int t, int b, int T, int Q, const float *__restrict__ pts,
+                                                     const int *__restrict__ counters, const int *__restrict__ irregQ, int *result)
+{
+    float v[12];
+    const float *src = tet + ((size_t)b * T + t) * 12;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) v[k] = src[k];
+    Planes P;
+    make_planes(v, P);
+    irregular_queries_tail(P, t, b, Q, pts, counters, irregQ, result);
+}
+__device__ __forceinline__ void fma_irregular_tail(const float *__restrict__ tet, int t, int b, int T, int Q, const float *__restrict__ pts,
+                                                   const int *__restrict__ counters, const int *__restrict__ irregQ, int *result)
+{
+    if (counters[b * 4 + 1] > 0) fma_irregular_tail_slow(tet, t, b, T, Q, pts, counters, irregQ, result);
+}
+
+template <bool PACKED>
+__global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan_fma(const float *__restrict__ tet, int T, int Q,
+                                                  const float *__restrict__ gparam, int G, int Gx, const int *__restrict__ cells,
+                                                  long long cellStride, const float4 *__restrict__ sortedQ, int *result, int *counters,
+                                                  int *irregT, int4 *hits, const float *__restrict__ pts,
+                                                  const int *__restrict__ irregQ, int *ucount)
+{
+    if (ucount && blockIdx.x == 0 && threadIdx.x == 0) ucount[blockIdx.y] = 0;
+    const int b = blockIdx.y;
+    const int nblk = gridDim.x;
+    const int per = (nblk + 7) >> 3;
+    const int vb = (blockIdx.x & 7) * per + (blockIdx.x >> 3);        // XCD-aware mapping, see k_tet_scan
+    const int t = vb * blockDim.x + threadIdx.x;
+    if (vb >= nblk || t >= T) return;
+    float v[12];
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(tet + ((size_t)b * T + t) * 12);
+        float4 a = src[0], bq = src[1], c = src[2];
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+        v[4] = bq.x; v[5] = bq.y; v[6] = bq.z; v[7] = bq.w;
+        v[8] = c.x; v[9] = c.y; v[10] = c.z; v[11] = c.w;
+    }
+    float lo[3], hi[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        lo[k] = fminf(fminf(v[k], v[3 + k]), fminf(v[6 + k], v[9 + k]));
+        hi[k] = fmaxf(fmaxf(v[k], v[3 + k]), fmaxf(v[6 + k], v[9 + k]));
+    }
+    const float w = fmaxf(fmaxf(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]);
+    Filter F;
+    unsigned sv;
+    float sigma;
+    bool regular;
+    const Grid g = load_grid(gparam + b * 12);
+    {
+        Planes P;
+        make_planes(v, P);
+        bool finite = true;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) finite = finite && (fabsf(v[k]) <= kBig);
+        const float mn = fminf(fminf(fabsf(P.dv[0]), fabsf(P.dv[1])), fminf(fabsf(P.dv[2]), fabsf(P.dv[3])));
+        regular = finite && (P.sv == 0u || P.sv == 15u) && (w >= kWMin) && (mn >= kTau * ((w * w) * w));
+        sv = P.sv;
+        sigma = P.sv == 15u ? 1.0f : -1.0f;
+        if (!regular) {
+            int k = atomicAdd(&counters[b * 4 + 0], 1);
+            irregT[(size_t)b * T + k] = t;
+            if (hits) hits[(size_t)b * T + t] = make_int4(-1, -1, -1, kHitOverflow);
+            irregular_queries_tail(P, t, b, Q, pts, counters, irregQ, result);
+            return;
+        }
+        float S[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            S[k] = kErrScale * (fmaxf(fabsf(g.lo[k]), fabsf(g.hi[k])) + 2.0f * fmaxf(fabsf(lo[k]), fabsf(hi[k])));
+        float emax = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float n0 = P.n[i][0], n1 = P.n[i][1], n2 = P.n[i][2];
+            const float c = fmaf(n0, P.a[i][0], fmaf(n1, P.a[i][1], n2 * P.a[i][2]));
+            const float E = fmaf(fabsf(n0), S[0], fmaf(fabsf(n1), S[1], fabsf(n2) * S[2])) + kErrAbs;
+            F.N[i][0] = sigma * n0; F.N[i][1] = sigma * n1; F.N[i][2] = sigma * n2;
+            F.C[i] = -sigma * c - E;
+            emax = fmaxf(emax, E);
+        }
+        F.twoEmax = 2.0f * emax;
+    }
+    const float m = w * kMargin;
+    float elo[3], ehi[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        elo[k] = lo[k] - m;
+        ehi[k] = hi[k] + m;
+    }
+    int hcnt = 0;
+    if (ehi[0] < g.lo[0] || elo[0] > g.hi[0] || ehi[1] < g.lo[1] || elo[1] > g.hi[1] || ehi[2] < g.lo[2] || elo[2] > g.hi[2]) {
+        if (hits) hits[(size_t)b * T + t] = make_int4(-1, -1, -1, -1);
+        fma_irregular_tail(tet, t, b, T, Q, pts, counters, irregQ, result);
+        return;
+    }
+    const int cx0 = cell_of(elo[0], g.o[0], g.inv[0], Gx), cx1 = cell_of(ehi[0], g.o[0], g.inv[0], Gx);
+    const int cy0 = cell_of(elo[1], g.o[1], g.inv[1], G), cy1 = cell_of(ehi[1], g.o[1], g.inv[1], G);
+    const int cz0 = cell_of(elo[2], g.o[2], g.inv[2], G), cz1 = cell_of(ehi[2], g.o[2], g.inv[2], G);
+    const int *cb = cells + (size_t)b * cellStride;
+    const float4 *sq = sortedQ + (size_t)b * Q;
+    int *res = result + (size_t)b * Q;
+    // Accepted queries are collected WITHOUT a branch: the hit record doubles as a four-deep shift register
+    // (x = newest), and the atomicMin of the recorded queries is issued once, after the traversal.  Only the rare
+    // fifth acceptance of a tet pushes an entry out, which is then published on the spot.
+    // The loop body is branch-free.  Accepted queries go into a four-deep shift register (h0 = newest) and are
+    // published with atomicMin once, after the traversal.  A candidate in the filter's undecided band, or a fifth
+    // acceptance, only raises a flag; such tets (~1e-4 of them) are re-scanned exactly afterwards.
+    int h0 = -1, h1 = -1, h2 = -1, h3 = -1;
+    int nslow = 0;
+    auto decide = [&](float a, int qi, bool live) {
+        const bool acc = live && a > 0.f;
+        nslow += (live && !acc && a >= -F.twoEmax) ? 1 : 0;
+        h3 = acc ? h2 : h3;
+        h2 = acc ? h1 : h2;
+        h1 = acc ? h0 : h1;
+        h0 = acc ? qi : h0;
+        hcnt += acc ? 1 : 0;
+    };
+    int cy = cy0, cz = cz0;
+    auto bounds = [&](int row, int &s_, int &e_) {
+        s_ = cb[row + cx0];
+        e_ = cb[row + cx1 + 1];
+    };
+    int s, e;
+    bounds((cz * G + cy) * Gx, s, e);
+    for (;;) {
+        int ny = cy + 1, nz = cz;
+        if (ny > cy1) { ny = cy0; nz = cz + 1; }
+        const bool more = nz <= cz1;
+        int s2 = 0, e2 = 0;
+        if (more) bounds((nz * G + ny) * Gx, s2, e2);
+        for (int j = s; j < e; j += 2) {
+            const bool two = j + 1 < e;
+            const float4 q0 = sq[j];
+            float4 q1;                                                  // only read under `two`; no copy of q0 is materialised
+            q1.x = __builtin_nondeterministic_value(q0.x); q1.y = __builtin_nondeterministic_value(q0.y);
+            q1.z = __builtin_nondeterministic_value(q0.z); q1.w = __builtin_nondeterministic_value(q0.w);
+            if (two) q1 = sq[j + 1];
+            if constexpr (PACKED) {
+                const f32x2 X = {q0.x, q1.x}, Y = {q0.y, q1.y}, Z = {q0.z, q1.z};
+                f32x2 A[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const f32x2 n0 = {F.N[i][0], F.N[i][0]}, n1 = {F.N[i][1], F.N[i][1]}, n2 = {F.N[i][2], F.N[i][2]}, cc = {F.C[i], F.C[i]};
+                    A[i] = __builtin_elementwise_fma(n0, X, __builtin_elementwise_fma(n1, Y, __builtin_elementwise_fma(n2, Z, cc)));
+                }
+                const float a0 = fminf(fminf(A[0].x, A[1].x), fminf(A[2].x, A[3].x));
+                const float a1 = fminf(fminf(A[0].y, A[1].y), fminf(A[2].y, A[3].y));
+                decide(a0, __float_as_int(q0.w), true);
+                decide(a1, __float_as_int(q1.w), two);
+            } else {
+                float a0, a1;
+                {
+                    float A[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) A[i] = fmaf(F.N[i][0], q0.x, fmaf(F.N[i][1], q0.y, fmaf(F.N[i][2], q0.z, F.C[i])));
+                    a0 = fminf(fminf(A[0], A[1]), fminf(A[2], A[3]));
+                }
+                {
+                    float A[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) A[i] = fmaf(F.N[i][0], q1.x, fmaf(F.N[i][1], q1.y, fmaf(F.N[i][2], q1.z, F.C[i])));
+                    a1 = fminf(fminf(A[0], A[1]), fminf(A[2], A[3]));
+                }
+                decide(a0, __float_as_int(q0.w), true);
+                decide(a1, __float_as_int(q1.w), two);
+            }
+        }
+        if (!more) break;
+        s = s2; e = e2; cy = ny; cz = nz;
+    }
+    if (nslow > 0 || hcnt > 4) {
+        const int4 r = exact_rescan(tet + ((size_t)b * T + t) * 12, t, cb, sq, res, G, Gx, cx0, cx1, cy0, cy1, cz0, cz1, m,
+                                    &counters[b * 4 + 2]);
+        if (hits) hits[(size_t)b * T + t] = r;
+    } else {
+        if (hcnt > 0) atomicMin(&res[h0], t);
+        if (hcnt > 1) atomicMin(&res[h1], t);
+        if (hcnt > 2) atomicMin(&res[h2], t);
+        if (hcnt > 3) atomicMin(&res[h3], t);
+        if (hits) hits[(size_t)b * T + t] = make_int4(h0, h1, h2, h3);
+    }
+    fma_irregular_tail(tet, t, b, T, Q, pts, counters, irregQ, result);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1439,7 +1712,17 @@ __global__ __launch_bounds__(256) void k_paste_bwd(const float *__restrict__ con
 // ------------------------------------------------------------------------------------
 static int pick_G(int T, int Q)
 {
-    double a = T / (double)(PIT_GDIV), bq = (Q > 0 ? Q : 1) / 2.0;
+    double gdiv = PIT_GDIV;
+    if (const char *e = getenv("DEFTET_PIT_GDIV")) {            // experiments only: tets per cell
+        const double v = atof(e);
+        if (v >= 0.25 && v <= 4096.0) gdiv = v;
+    }
+    double qdiv = 2.0;
+    if (const char *e = getenv("DEFTET_PIT_QDIV")) {            // experiments only: queries per cell
+        const double v = atof(e);
+        if (v >= 0.03 && v <= 4096.0) qdiv = v;
+    }
+    double a = T / gdiv, bq = (Q > 0 ? Q : 1) / qdiv;
     double m = a < bq ? a : bq;
     int G = (int)llround(cbrt(m < 1 ? 1 : m));
     if (G < 1) G = 1;
@@ -1467,7 +1750,12 @@ static Layout make_layout(int B, int T, int Q, int algo, void *ws, size_t wsByte
         L.rec = A.take<float>((size_t)B * T * 32);
     } else {
         L.G = pick_G(T, Q);
-        L.Gx = L.G * kXFine;
+        int xfine = kXFine;
+        if (const char *e = getenv("DEFTET_PIT_XFINE")) {         // experiments only: x-refinement of the cells
+            const int v = atoi(e);
+            if (v >= 1 && v <= kMaxXFine) xfine = v;
+        }
+        L.Gx = L.G * xfine;
         const long long n = (long long)L.Gx * L.G * L.G + 1, R = (long long)L.G * L.G;
         L.cellStride = (n + 63) / 64 * 64;
         L.nRowBlk = (Q + kRowTile - 1) / kRowTile;
@@ -1516,7 +1804,8 @@ static int pit_check(const float *tet, const float *pts, const float *cond, cons
     DEFTET_CHECK_ARG((pred == nullptr) == (occ == nullptr), "pred and occ must be given together");
     DEFTET_CHECK_ARG(!occ || T > 0, "paste_occ needs at least one tet");
     DEFTET_CHECK_ARG(B >= 0 && T >= 0 && Q >= 0, "negative size (B=%d T=%d Q=%d)", B, T, Q);
-    DEFTET_CHECK_ARG(algo == DEFTET_PIT_AUTO || algo == DEFTET_PIT_BRUTE || algo == DEFTET_PIT_STAGED || algo == DEFTET_PIT_ROWS,
+    DEFTET_CHECK_ARG(algo == DEFTET_PIT_AUTO || algo == DEFTET_PIT_BRUTE || algo == DEFTET_PIT_STAGED || algo == DEFTET_PIT_ROWS ||
+                         algo == DEFTET_PIT_FMA || algo == DEFTET_PIT_FMA2,
                      "unknown algo %d", algo);
     if (T >= (1 << 24)) return set_error(DEFTET_ELIMIT, "n_tet=%d does not fit a float-encoded index (2^24)", T);
     DEFTET_CHECK_ARG(B <= 65535, "n_batch=%d exceeds the grid-y limit 65535", B);
@@ -1555,6 +1844,12 @@ static int pit_scan(const Layout &L, const float *tet, const float *pts, float *
     if (T > 0) {
         if (algo == DEFTET_PIT_ROWS) {
             DEFTET_LAUNCH(k_tet_scan_rows, gt, blk, st, tet, T, Q, L.gparam, L.G, L.Gx, L.cells, L.cellStride, L.sortedQ, L.result,
+                          L.counters, L.irregT, (int4 *)hit_buf, pts, L.irregQ, ucount);
+        } else if (algo == DEFTET_PIT_FMA) {
+            DEFTET_LAUNCH(k_tet_scan_fma<false>, gt, blk, st, tet, T, Q, L.gparam, L.G, L.Gx, L.cells, L.cellStride, L.sortedQ, L.result,
+                          L.counters, L.irregT, (int4 *)hit_buf, pts, L.irregQ, ucount);
+        } else if (algo == DEFTET_PIT_FMA2) {
+            DEFTET_LAUNCH(k_tet_scan_fma<true>, gt, blk, st, tet, T, Q, L.gparam, L.G, L.Gx, L.cells, L.cellStride, L.sortedQ, L.result,
                           L.counters, L.irregT, (int4 *)hit_buf, pts, L.irregQ, ucount);
         } else if (algo != DEFTET_PIT_STAGED) {
             DEFTET_LAUNCH(k_tet_scan, gt, blk, st, tet, T, Q, L.gparam, L.G, L.Gx, L.cells, L.cellStride, L.sortedQ, L.result,
@@ -1605,7 +1900,7 @@ extern "C" int deftet_point_in_tet_prepare_f32(const float *pts, int B, int T, i
                                                size_t workspace_bytes, void *stream_)
 {
     DEFTET_CHECK_ARG(B >= 0 && T >= 0 && Q >= 0 && B <= 65535, "bad size (B=%d T=%d Q=%d)", B, T, Q);
-    DEFTET_CHECK_ARG(algo == DEFTET_PIT_AUTO || algo == DEFTET_PIT_STAGED || algo == DEFTET_PIT_ROWS, "prepare needs a binned algo (got %d)", algo);
+    DEFTET_CHECK_ARG(algo != DEFTET_PIT_BRUTE && algo >= 0 && algo <= DEFTET_PIT_FMA2, "prepare needs a binned algo (got %d)", algo);
     if (B == 0 || Q == 0) return DEFTET_OK;
     DEFTET_CHECK_ARG(pts, "null pts pointer");
     DEFTET_CHECK_ARG(workspace && ((uintptr_t)workspace & 255) == 0, "workspace null or not 256-byte aligned");

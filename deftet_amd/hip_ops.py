@@ -11,8 +11,9 @@ import torch
 
 from . import _lib
 
-PIT_AUTO, PIT_BRUTE, PIT_STAGED, PIT_ROWS = 0, 1, 2, 3
-_PIT_KERNEL = {PIT_AUTO: "k_tet_scan", PIT_BRUTE: "k_brute", PIT_STAGED: "k_tet_scan_staged", PIT_ROWS: "k_tet_scan_rows"}
+PIT_AUTO, PIT_BRUTE, PIT_STAGED, PIT_ROWS, PIT_FMA, PIT_FMA2 = 0, 1, 2, 3, 4, 5
+_PIT_KERNEL = {PIT_AUTO: "k_tet_scan", PIT_BRUTE: "k_brute", PIT_STAGED: "k_tet_scan_staged", PIT_ROWS: "k_tet_scan_rows",
+               PIT_FMA: "k_tet_scan_fma<false>", PIT_FMA2: "k_tet_scan_fma<true>"}
 
 
 def pit_kernel_name(algo=PIT_AUTO):

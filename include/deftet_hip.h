@@ -38,6 +38,8 @@ extern "C" {
 #define DEFTET_PIT_BRUTE 1   /* LDS/scalar-tiled brute force: the algorithmic equivalent of the reference kernel */
 #define DEFTET_PIT_STAGED 2  /* binned, with wave-cooperative LDS staging of the cell rows (coherent tet orders) */
 #define DEFTET_PIT_ROWS 3    /* binned, (tet,row) pairs balanced across the lanes of a wave through LDS */
+#define DEFTET_PIT_FMA 4     /* binned, certified fused plane filter instead of box test + exact predicate per candidate */
+#define DEFTET_PIT_FMA2 5    /* same, two candidates per packed-fp32 instruction */
 
 int deftet_version(void);
 const char *deftet_last_error(void);

@@ -33,7 +33,7 @@ while time.time() < t_end:
         k = max(1, Q // 20)
         pts[:, :k] = float("nan"); pts[:, k:2 * k] = 3e6 * scale
     ref = hip_ops.point_in_tet(tet, pts, algo=1)
-    for algo in (0, 2, 3):
+    for algo in (0, 2, 3, 4, 5):
         got = hip_ops.point_in_tet(tet, pts, algo=algo)
         if not torch.equal(got, ref):
             bad = (got != ref).nonzero()[0].tolist()
