@@ -69,7 +69,11 @@ class PitWorkload:
         from deftet_amd import grids
         self.cfg, self.world, self.gather, self.pipeline, self.algo = cfg, world, gather, pipeline, algo
         res, Q, B = cfg["res"], cfg["n_query"], cfg["batch"]
-        verts, tets = grids.kuhn_grid(res)
+        if cfg.get("mesh") == "cube40":                   # the shipped QuarTet grid (probe use: a non-Kuhn tet order)
+            g40 = np.load(os.path.join(ROOT, "tests", "golden", "cube40_grid.npz"))
+            verts, tets = g40["verts"], g40["tets"]
+        else:
+            verts, tets = grids.kuhn_grid(res)
         self.sets, self.host = [], None
         for s in range(cfg["sets"]):
             base = rank * B + s * 100_000                 # distinct seeds per rank and per set

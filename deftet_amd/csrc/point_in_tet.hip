@@ -664,15 +664,19 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan_fma(const float *__
                                                   const float *__restrict__ gparam, int G, int Gx, const int *__restrict__ cells,
                                                   long long cellStride, const float4 *__restrict__ sortedQ, int *result, int *counters,
                                                   int *irregT, int4 *hits, const float *__restrict__ pts,
-                                                  const int *__restrict__ irregQ, int *ucount)
+                                                  const int *__restrict__ irregQ, int *ucount, const int *__restrict__ list)
 {
     if (ucount && blockIdx.x == 0 && threadIdx.x == 0) ucount[blockIdx.y] = 0;
     const int b = blockIdx.y;
     const int nblk = gridDim.x;
     const int per = (nblk + 7) >> 3;
     const int vb = (blockIdx.x & 7) * per + (blockIdx.x >> 3);        // XCD-aware mapping, see k_tet_scan
-    const int t = vb * blockDim.x + threadIdx.x;
+    int t = vb * blockDim.x + threadIdx.x;
     if (vb >= nblk || t >= T) return;
+    if (list) {                                                        // list mode: the tets k_tet_scan_grp deferred (count in counters[.][3])
+        if (t >= counters[b * 4 + 3]) return;
+        t = list[(size_t)b * T + t];
+    }
     float v[12];
     {
         const float4 *src = reinterpret_cast<const float4 *>(tet + ((size_t)b * T + t) * 12);
@@ -827,6 +831,314 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan_fma(const float *__
         if (hits) hits[(size_t)b * T + t] = make_int4(h0, h1, h2, h3);
     }
     fma_irregular_tail(tet, t, b, T, Q, pts, counters, irregQ, result);
+}
+
+// ------------------------------------------------------------------------------------
+// k_tet_scan_grp<NP> (DEFTET_PIT_GRP2/4/6): K = 2*NP CONSECUTIVE tets per lane share one candidate stream.
+//
+// What bounds the one-tet-per-lane kernels is the divergent-gather path: every lane fetches its own row bounds and
+// its own candidate queries, ~20 lane-requests per tet at BASELINE configs[2], and the texture-address unit retires
+// about one divergent lane-request per clock per CU (measured: traversal time = requests / (256 CU x ~2 GHz) within
+// 20 % at configs[1..3]; cutting the VALU work by 40 % with the fused filter moved the time by 7 %,
+// profiles/r02_scan_variants_fma_sweep.jsonl).  Consecutive tets of a mesh are almost always neighbours (the six
+// Kuhn tets of a cube have the same bounding box; in the shipped QuarTet grid the median pair of consecutive tets
+// needs 1.25x the cells of one), so a lane that owns K consecutive tets walks the UNION of their cell ranges once
+// and tests every fetched candidate against all K tets: requests per tet drop by up to K.
+// The K-tet test is where packed fp32 pays: two tets sit in the two halves of a register pair, so the fused filter
+// (see k_tet_scan_fma) costs 12 v_pk_fma_f32 per candidate per PAIR of tets, and the whole per-tet setup (planes,
+// conditioning test, filter coefficients) runs as packed arithmetic too — with the same operation order and
+// rounding per half, so every decision is bit-identical to the one-tet kernels.
+//
+// Accepted (candidate, tet-set) pairs go into an 8-deep shift register per lane (query id | K-bit tet mask); after
+// the traversal each entry is published with ONE atomicMin (the lowest accepting tet of the group is all that can
+// win) and decoded into the per-tet hit records.  Groups whose union range has more cells than the sum of its
+// members' ranges (mesh-order jumps; ~2 % of the groups of the shipped grid) are appended to a list that a second,
+// one-tet-per-lane launch of k_tet_scan_fma processes.  Candidates in the filter's undecided band, or more than
+// eight accepting candidates, send the group to the exact re-scan.
+// ------------------------------------------------------------------------------------
+constexpr int kGrpDepth = 8;
+
+struct TetCells { int cx0, cx1, cy0, cy1, cz0, cz1; };
+
+// Setup of one PAIR of tets in packed arithmetic (.x = first tet, .y = second).  Returns per half: regular, active
+// (regular + live + box meets the query grid), cell range; fills the filter coefficients (zero / -inf for halves that
+// must never accept) and raises twoE to 2 * max E.
+__device__ __forceinline__ void pair_setup(const float *__restrict__ recA, const float *__restrict__ recB, bool liveA, bool liveB,
+                                           const Grid &g, int G, int Gx, f32x2 (&N)[4][3], f32x2 (&C)[4], float &twoE,
+                                           bool (&regular)[2], bool (&active)[2], TetCells (&cells)[2])
+{
+    f32x2 v[12];
+    {
+        const float4 *sa = reinterpret_cast<const float4 *>(recA), *sb = reinterpret_cast<const float4 *>(recB);
+        const float4 a0 = sa[0], a1 = sa[1], a2 = sa[2], b0 = sb[0], b1 = sb[1], b2 = sb[2];
+        v[0] = f32x2{a0.x, b0.x}; v[1] = f32x2{a0.y, b0.y}; v[2] = f32x2{a0.z, b0.z}; v[3] = f32x2{a0.w, b0.w};
+        v[4] = f32x2{a1.x, b1.x}; v[5] = f32x2{a1.y, b1.y}; v[6] = f32x2{a1.z, b1.z}; v[7] = f32x2{a1.w, b1.w};
+        v[8] = f32x2{a2.x, b2.x}; v[9] = f32x2{a2.y, b2.y}; v[10] = f32x2{a2.z, b2.z}; v[11] = f32x2{a2.w, b2.w};
+    }
+    constexpr int ord[4][4] = {{0, 1, 2, 3}, {1, 0, 3, 2}, {2, 3, 0, 1}, {3, 2, 1, 0}};    // check_condition_tet_for.cu:172-175
+    f32x2 n[4][3], dv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f32x2 *a = v + 3 * ord[i][0], *b = v + 3 * ord[i][1], *c = v + 3 * ord[i][2], *d = v + 3 * ord[i][3];
+        const f32x2 r1x = b[0] - a[0], r1y = b[1] - a[1], r1z = b[2] - a[2];               // :111
+        const f32x2 r2x = c[0] - a[0], r2y = c[1] - a[1], r2z = c[2] - a[2];               // :112
+        n[i][0] = r1y * r2z - r1z * r2y;                                                     // :63
+        n[i][1] = r1z * r2x - r1x * r2z;                                                     // :64
+        n[i][2] = r1x * r2y - r1y * r2x;                                                     // :65
+        const f32x2 dx = d[0] - a[0], dy = d[1] - a[1], dz = d[2] - a[2];                   // :114
+        dv[i] = n[i][0] * dx + n[i][1] * dy + n[i][2] * dz;                                  // :115
+    }
+    f32x2 lo[3], hi[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        lo[k] = __builtin_elementwise_min(__builtin_elementwise_min(v[k], v[3 + k]), __builtin_elementwise_min(v[6 + k], v[9 + k]));
+        hi[k] = __builtin_elementwise_max(__builtin_elementwise_max(v[k], v[3 + k]), __builtin_elementwise_max(v[6 + k], v[9 + k]));
+    }
+    const f32x2 w = __builtin_elementwise_max(__builtin_elementwise_max(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]);
+    const f32x2 mn = __builtin_elementwise_min(__builtin_elementwise_min(__builtin_elementwise_abs(dv[0]), __builtin_elementwise_abs(dv[1])),
+                                               __builtin_elementwise_min(__builtin_elementwise_abs(dv[2]), __builtin_elementwise_abs(dv[3])));
+    const f32x2 thr = kTau * ((w * w) * w);
+    const f32x2 mg = w * kMargin;
+    f32x2 sigma, S[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const f32x2 M = __builtin_elementwise_max(__builtin_elementwise_abs(lo[k]), __builtin_elementwise_abs(hi[k]));
+        S[k] = kErrScale * (fmaxf(fabsf(g.lo[k]), fabsf(g.hi[k])) + 2.0f * M);
+    }
+    const bool live[2] = {liveA, liveB};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        bool finite = true;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) finite = finite && (fabsf(v[k][h]) <= kBig);            // NaN fails
+        const unsigned sv = (dv[0][h] > 0 ? 1u : 0u) | (dv[1][h] > 0 ? 2u : 0u) | (dv[2][h] > 0 ? 4u : 0u) | (dv[3][h] > 0 ? 8u : 0u);   // :119
+        regular[h] = finite && (sv == 0u || sv == 15u) && (w[h] >= kWMin) && (mn[h] >= thr[h]);
+        sigma[h] = sv == 15u ? 1.0f : -1.0f;
+        const float elo0 = lo[0][h] - mg[h], ehi0 = hi[0][h] + mg[h], elo1 = lo[1][h] - mg[h], ehi1 = hi[1][h] + mg[h],
+                    elo2 = lo[2][h] - mg[h], ehi2 = hi[2][h] + mg[h];
+        const bool ingrid = !(ehi0 < g.lo[0] || elo0 > g.hi[0] || ehi1 < g.lo[1] || elo1 > g.hi[1] || ehi2 < g.lo[2] || elo2 > g.hi[2]);
+        active[h] = live[h] && regular[h] && ingrid;
+        cells[h].cx0 = cell_of(elo0, g.o[0], g.inv[0], Gx); cells[h].cx1 = cell_of(ehi0, g.o[0], g.inv[0], Gx);
+        cells[h].cy0 = cell_of(elo1, g.o[1], g.inv[1], G);  cells[h].cy1 = cell_of(ehi1, g.o[1], g.inv[1], G);
+        cells[h].cz0 = cell_of(elo2, g.o[2], g.inv[2], G);  cells[h].cz1 = cell_of(ehi2, g.o[2], g.inv[2], G);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f32x2 *a = v + 3 * ord[i][0];
+        const f32x2 c = __builtin_elementwise_fma(n[i][0], a[0], __builtin_elementwise_fma(n[i][1], a[1], n[i][2] * a[2]));
+        const f32x2 E = __builtin_elementwise_fma(__builtin_elementwise_abs(n[i][0]), S[0],
+                                                  __builtin_elementwise_fma(__builtin_elementwise_abs(n[i][1]), S[1],
+                                                                            __builtin_elementwise_abs(n[i][2]) * S[2])) + kErrAbs;
+        f32x2 Nx = sigma * n[i][0], Ny = sigma * n[i][1], Nz = sigma * n[i][2];
+        f32x2 Cc = -sigma * c - E;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            // inactive half: never accepts, never "undecided" (selects, not branches)
+            Nx[h] = active[h] ? Nx[h] : 0.f; Ny[h] = active[h] ? Ny[h] : 0.f; Nz[h] = active[h] ? Nz[h] : 0.f;
+            Cc[h] = active[h] ? Cc[h] : -INFINITY;
+            twoE = fmaxf(twoE, active[h] ? 2.0f * E[h] : 0.f);
+        }
+        N[i][0] = Nx; N[i][1] = Ny; N[i][2] = Nz; C[i] = Cc;
+    }
+}
+
+// exact re-scan of one tet with its OWN cell range (for the grouped kernel's rare slow path)
+__device__ __noinline__ void exact_rescan_tet(const float *__restrict__ tet, int t, int b, int T, const float *__restrict__ gparam, int G, int Gx,
+                                              const int *__restrict__ cb, const float4 *__restrict__ sq, int *res, int4 *hits, int *counters)
+{
+    const float *tv = tet + ((size_t)b * T + t) * 12;
+    float lo[3], hi[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        lo[k] = fminf(fminf(tv[k], tv[3 + k]), fminf(tv[6 + k], tv[9 + k]));
+        hi[k] = fmaxf(fmaxf(tv[k], tv[3 + k]), fmaxf(tv[6 + k], tv[9 + k]));
+    }
+    const float w = fmaxf(fmaxf(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]);
+    const float m = w * kMargin;
+    const Grid g = load_grid(gparam + b * 12);
+    const int cx0 = cell_of(lo[0] - m, g.o[0], g.inv[0], Gx), cx1 = cell_of(hi[0] + m, g.o[0], g.inv[0], Gx);
+    const int cy0 = cell_of(lo[1] - m, g.o[1], g.inv[1], G), cy1 = cell_of(hi[1] + m, g.o[1], g.inv[1], G);
+    const int cz0 = cell_of(lo[2] - m, g.o[2], g.inv[2], G), cz1 = cell_of(hi[2] + m, g.o[2], g.inv[2], G);
+    const int4 r = exact_rescan(tv, t, cb, sq, res, G, Gx, cx0, cx1, cy0, cy1, cz0, cz1, m, &counters[b * 4 + 2]);
+    if (hits) hits[(size_t)b * T + t] = r;
+}
+
+template <int NP>
+__global__ __launch_bounds__(256, NP == 1 ? 5 : (NP == 2 ? 4 : 3)) void k_tet_scan_grp(
+    const float *__restrict__ tet, int T, int Q, const float *__restrict__ gparam, int G, int Gx, const int *__restrict__ cells,
+    long long cellStride, const float4 *__restrict__ sortedQ, int *result, int *counters, int *irregT, int4 *hits,
+    const float *__restrict__ pts, const int *__restrict__ irregQ, int *ucount, int *deferT)
+{
+    constexpr int K = 2 * NP;
+    constexpr int kShift = 32 - K;                          // entry = query id | tet mask << kShift   (host guarantees Q < 2^kShift)
+    constexpr unsigned kIdMask = (1u << kShift) - 1u;
+    if (ucount && blockIdx.x == 0 && threadIdx.x == 0) ucount[blockIdx.y] = 0;
+    const int b = blockIdx.y;
+    const int nblk = gridDim.x, per = (nblk + 7) >> 3;
+    const int vb = (blockIdx.x & 7) * per + (blockIdx.x >> 3);        // XCD-aware mapping, see k_tet_scan
+    const long long grp = (long long)vb * blockDim.x + threadIdx.x;
+    const long long t0l = grp * K;
+    if (vb >= nblk || t0l >= T) return;
+    const int t0 = (int)t0l;
+    const Grid g = load_grid(gparam + b * 12);
+    f32x2 N[NP][4][3], C[NP][4];
+    float twoE = 0.f;
+    unsigned regM = 0, actM = 0, liveM = 0;                 // bit k: tet t0 + k is regular / active / exists
+    int ux0 = 0x7FFFFFFF, ux1 = -1, uy0 = 0x7FFFFFFF, uy1 = -1, uz0 = 0x7FFFFFFF, uz1 = -1;
+    long long vsum = 0;
+    int nact = 0;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int tA = t0 + 2 * p, tB = tA + 1;
+        const bool liveA = tA < T, liveB = tB < T;
+        const float *recA = tet + ((size_t)b * T + (liveA ? tA : t0)) * 12, *recB = tet + ((size_t)b * T + (liveB ? tB : t0)) * 12;
+        bool r2[2], a2[2];
+        TetCells c2[2];
+        pair_setup(recA, recB, liveA, liveB, g, G, Gx, N[p], C[p], twoE, r2, a2, c2);
+        const bool lv[2] = {liveA, liveB};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int k = 2 * p + h;
+            if (lv[h]) liveM |= 1u << k;
+            if (lv[h] && r2[h]) regM |= 1u << k;
+            if (a2[h]) {
+                actM |= 1u << k;
+                ux0 = min(ux0, c2[h].cx0); ux1 = max(ux1, c2[h].cx1);
+                uy0 = min(uy0, c2[h].cy0); uy1 = max(uy1, c2[h].cy1);
+                uz0 = min(uz0, c2[h].cz0); uz1 = max(uz1, c2[h].cz1);
+                vsum += (long long)(c2[h].cx1 - c2[h].cx0 + 1) * (c2[h].cy1 - c2[h].cy0 + 1) * (c2[h].cz1 - c2[h].cz0 + 1);
+                ++nact;
+            }
+        }
+    }
+    // irregular tets (normally none): listed for k_finalize's brute-force pass, never recorded
+    if (regM != liveM) {
+#pragma unroll 1
+        for (int k = 0; k < K; ++k) {
+            if (((liveM & ~regM) >> k) & 1u) {
+                const int i = atomicAdd(&counters[b * 4 + 0], 1);
+                irregT[(size_t)b * T + i] = t0 + k;
+                if (hits) hits[(size_t)b * T + t0 + k] = make_int4(-1, -1, -1, kHitOverflow);
+            }
+        }
+    }
+    // regular members whose box misses the query grid: empty record
+    if (hits && (regM & ~actM)) {
+#pragma unroll 1
+        for (int k = 0; k < K; ++k)
+            if (((regM & ~actM) >> k) & 1u) hits[(size_t)b * T + t0 + k] = make_int4(-1, -1, -1, -1);
+    }
+    const int *cb = cells + (size_t)b * cellStride;
+    const float4 *sq = sortedQ + (size_t)b * Q;
+    int *res = result + (size_t)b * Q;
+    int e0 = -1, e1 = -1, e2 = -1, e3 = -1, e4 = -1, e5 = -1, e6 = -1, e7 = -1;
+    int cnt = 0, nslow = 0;
+    bool traversed = false;
+    if (nact > 0) {
+        const long long vu = (long long)(ux1 - ux0 + 1) * (uy1 - uy0 + 1) * (uz1 - uz0 + 1);
+        if (vu > vsum) {
+            // a jump in the mesh order inside this group: its members go to the one-tet-per-lane pass
+            const int base = atomicAdd(&counters[b * 4 + 3], nact);
+            int o = 0;
+#pragma unroll 1
+            for (int k = 0; k < K; ++k)
+                if ((actM >> k) & 1u) deferT[(size_t)b * T + base + (o++)] = t0 + k;
+        } else {
+            traversed = true;
+            auto test = [&](const float4 &q, bool live) {
+                unsigned bits = 0;
+                bool unc = false;
+                const f32x2 X = {q.x, q.x}, Y = {q.y, q.y}, Z = {q.z, q.z};
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    f32x2 A[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        A[i] = __builtin_elementwise_fma(N[p][i][0], X, __builtin_elementwise_fma(N[p][i][1], Y,
+                                                                                                    __builtin_elementwise_fma(N[p][i][2], Z, C[p][i])));
+                    const float ax = fminf(fminf(A[0].x, A[1].x), fminf(A[2].x, A[3].x));
+                    const float ay = fminf(fminf(A[0].y, A[1].y), fminf(A[2].y, A[3].y));
+                    const bool accx = ax > 0.f, accy = ay > 0.f;
+                    unc = unc | ((!accx) & (ax >= -twoE)) | ((!accy) & (ay >= -twoE));   // bitwise on purpose: no branches in this loop
+                    bits = (bits << 2) | (accx ? 2u : 0u) | (accy ? 1u : 0u);           // first tet of the group = most significant bit
+                }
+                nslow += (live & unc) ? 1 : 0;
+                const bool push = live & (bits != 0u);
+                const int entry = (int)(((unsigned)__float_as_int(q.w) & kIdMask) | (bits << kShift));
+                e7 = push ? e6 : e7; e6 = push ? e5 : e6; e5 = push ? e4 : e5; e4 = push ? e3 : e4;
+                e3 = push ? e2 : e3; e2 = push ? e1 : e2; e1 = push ? e0 : e1; e0 = push ? entry : e0;
+                cnt += push ? 1 : 0;
+            };
+            int cy = uy0, cz = uz0;
+            int s = cb[(cz * G + cy) * Gx + ux0], e = cb[(cz * G + cy) * Gx + ux1 + 1];
+            for (;;) {
+                int ny = cy + 1, nz = cz;
+                if (ny > uy1) { ny = uy0; nz = cz + 1; }
+                const bool more = nz <= uz1;
+                int s2 = 0, e2r = 0;
+                if (more) {
+                    const int row2 = (nz * G + ny) * Gx;
+                    s2 = cb[row2 + ux0];
+                    e2r = cb[row2 + ux1 + 1];
+                }
+                for (int j = s; j < e; j += 2) {
+                    const bool two = j + 1 < e;
+                    const float4 q0 = sq[j];
+                    float4 q1;
+                    q1.x = __builtin_nondeterministic_value(q0.x); q1.y = __builtin_nondeterministic_value(q0.y);
+                    q1.z = __builtin_nondeterministic_value(q0.z); q1.w = __builtin_nondeterministic_value(q0.w);
+                    if (two) q1 = sq[j + 1];
+                    test(q0, true);
+                    test(q1, two);
+                }
+                if (!more) break;
+                s = s2; e = e2r; cy = ny; cz = nz;
+            }
+        }
+    }
+    if (traversed) {
+        if (nslow > 0 || cnt > kGrpDepth) {
+            // undecided band met, or more accepting candidates than the register holds: exact re-scan of every active member
+#pragma unroll 1
+            for (int k = 0; k < K; ++k)
+                if ((actM >> k) & 1u) exact_rescan_tet(tet, t0 + k, b, T, gparam, G, Gx, cb, sq, res, hits, counters);
+        } else {
+            const int ent[kGrpDepth] = {e0, e1, e2, e3, e4, e5, e6, e7};
+            // one atomicMin per entry: only the lowest accepting tet of the group can be the query's answer
+#pragma unroll
+            for (int i = 0; i < kGrpDepth; ++i) {
+                if (i < cnt) {
+                    const unsigned bits = (unsigned)ent[i] >> kShift;
+                    const int first = K - 1 - (31 - __clz((int)bits));          // most significant set bit = first tet
+                    atomicMin(&res[(unsigned)ent[i] & kIdMask], t0 + first);
+                }
+            }
+            if (hits) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    if (!((actM >> k) & 1u)) continue;
+                    int r0 = -1, r1 = -1, r2 = -1, r3 = -1, c = 0;
+#pragma unroll
+                    for (int i = 0; i < kGrpDepth; ++i) {
+                        const bool has = i < cnt && (((unsigned)ent[i] >> (kShift + K - 1 - k)) & 1u);
+                        const int qi = (int)((unsigned)ent[i] & kIdMask);
+                        r3 = has ? r2 : r3; r2 = has ? r1 : r2; r1 = has ? r0 : r1; r0 = has ? qi : r0;
+                        c += has ? 1 : 0;
+                    }
+                    if (c > 4) {
+                        r3 = kHitOverflow;
+                        counters[b * 4 + 2] = 1;
+                    }
+                    hits[(size_t)b * T + t0 + k] = make_int4(r0, r1, r2, r3);
+                }
+            }
+        }
+    }
+    if (counters[b * 4 + 1] > 0) {                                     // irregular queries (normally none)
+#pragma unroll 1
+        for (int k = 0; k < K; ++k)
+            if ((regM >> k) & 1u) fma_irregular_tail_slow(tet, t0 + k, b, T, Q, pts, counters, irregQ, result);
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -1735,7 +2047,7 @@ struct Layout {
     long long cellStride;   // padded cells per shape (>= Gx*G*G + 1)
     size_t bytes;
     float *bboxPart;
-    int *counters, *cells, *blockHist, *rowTotal, *rowStart, *result, *irregT, *irregQ;
+    int *counters, *cells, *blockHist, *rowTotal, *rowStart, *result, *irregT, *irregQ, *deferT;
     int2 *qkey;
     float4 *rowSorted, *sortedQ;
     float *rec, *gparam;
@@ -1774,6 +2086,7 @@ static Layout make_layout(int B, int T, int Q, int algo, void *ws, size_t wsByte
         L.sortedQ = A.take<float4>((size_t)B * Q);
         L.irregT = A.take<int>((size_t)B * T);
         L.irregQ = A.take<int>((size_t)B * Q);
+        L.deferT = A.take<int>((size_t)B * T);
     }
     L.bytes = align_up(A.off, 256);
     return L;
@@ -1805,7 +2118,8 @@ static int pit_check(const float *tet, const float *pts, const float *cond, cons
     DEFTET_CHECK_ARG(!occ || T > 0, "paste_occ needs at least one tet");
     DEFTET_CHECK_ARG(B >= 0 && T >= 0 && Q >= 0, "negative size (B=%d T=%d Q=%d)", B, T, Q);
     DEFTET_CHECK_ARG(algo == DEFTET_PIT_AUTO || algo == DEFTET_PIT_BRUTE || algo == DEFTET_PIT_STAGED || algo == DEFTET_PIT_ROWS ||
-                         algo == DEFTET_PIT_FMA || algo == DEFTET_PIT_FMA2,
+                         algo == DEFTET_PIT_FMA || algo == DEFTET_PIT_FMA2 || algo == DEFTET_PIT_GRP2 || algo == DEFTET_PIT_GRP4 ||
+                         algo == DEFTET_PIT_GRP6,
                      "unknown algo %d", algo);
     if (T >= (1 << 24)) return set_error(DEFTET_ELIMIT, "n_tet=%d does not fit a float-encoded index (2^24)", T);
     DEFTET_CHECK_ARG(B <= 65535, "n_batch=%d exceeds the grid-y limit 65535", B);
@@ -1838,6 +2152,8 @@ static int pit_prepare(const Layout &L, const float *pts, int B, int Q, hipStrea
 static int pit_scan(const Layout &L, const float *tet, const float *pts, float *cond, float *bary, const float *pred, float *occ,
                     int32_t *hit_buf, int B, int T, int Q, int algo, hipStream_t st)
 {
+    if ((algo == DEFTET_PIT_GRP2 && Q >= (1 << 30)) || (algo == DEFTET_PIT_GRP4 && Q >= (1 << 28)) || (algo == DEFTET_PIT_GRP6 && Q >= (1 << 26)))
+        algo = DEFTET_PIT_FMA;                                       // query id + tet mask no longer fit one 32-bit entry
     const dim3 blk(256);
     const dim3 gq((Q + 255) / 256, B), gt((((T + 255) / 256 + 7) / 8) * 8, B);   // gt: multiple of 8 for the XCD mapping
     int *ucount = hit_buf ? hit_buf + hit_cnt_off(B, T) : nullptr;
@@ -1847,10 +2163,27 @@ static int pit_scan(const Layout &L, const float *tet, const float *pts, float *
                           L.counters, L.irregT, (int4 *)hit_buf, pts, L.irregQ, ucount);
         } else if (algo == DEFTET_PIT_FMA) {
             DEFTET_LAUNCH(k_tet_scan_fma<false>, gt, blk, st, tet, T, Q, L.gparam, L.G, L.Gx, L.cells, L.cellStride, L.sortedQ, L.result,
-                          L.counters, L.irregT, (int4 *)hit_buf, pts, L.irregQ, ucount);
+                          L.counters, L.irregT, (int4 *)hit_buf, pts, L.irregQ, ucount, (const int *)nullptr);
         } else if (algo == DEFTET_PIT_FMA2) {
             DEFTET_LAUNCH(k_tet_scan_fma<true>, gt, blk, st, tet, T, Q, L.gparam, L.G, L.Gx, L.cells, L.cellStride, L.sortedQ, L.result,
-                          L.counters, L.irregT, (int4 *)hit_buf, pts, L.irregQ, ucount);
+                          L.counters, L.irregT, (int4 *)hit_buf, pts, L.irregQ, ucount, (const int *)nullptr);
+        } else if (algo == DEFTET_PIT_GRP2 || algo == DEFTET_PIT_GRP4 || algo == DEFTET_PIT_GRP6) {
+            const int K = algo == DEFTET_PIT_GRP2 ? 2 : (algo == DEFTET_PIT_GRP4 ? 4 : 6);
+            const int ng = (T + K - 1) / K;
+            const dim3 gg((((ng + 255) / 256 + 7) / 8) * 8, B);
+            if (K == 2) {
+                DEFTET_LAUNCH(k_tet_scan_grp<1>, gg, blk, st, tet, T, Q, L.gparam, L.G, L.Gx, L.cells, L.cellStride, L.sortedQ, L.result,
+                              L.counters, L.irregT, (int4 *)hit_buf, pts, L.irregQ, ucount, L.deferT);
+            } else if (K == 4) {
+                DEFTET_LAUNCH(k_tet_scan_grp<2>, gg, blk, st, tet, T, Q, L.gparam, L.G, L.Gx, L.cells, L.cellStride, L.sortedQ, L.result,
+                              L.counters, L.irregT, (int4 *)hit_buf, pts, L.irregQ, ucount, L.deferT);
+            } else {
+                DEFTET_LAUNCH(k_tet_scan_grp<3>, gg, blk, st, tet, T, Q, L.gparam, L.G, L.Gx, L.cells, L.cellStride, L.sortedQ, L.result,
+                              L.counters, L.irregT, (int4 *)hit_buf, pts, L.irregQ, ucount, L.deferT);
+            }
+            // the groups with a mesh-order jump inside (normally a few per cent, possibly none), one tet per lane
+            DEFTET_LAUNCH(k_tet_scan_fma<false>, gt, blk, st, tet, T, Q, L.gparam, L.G, L.Gx, L.cells, L.cellStride, L.sortedQ, L.result,
+                          L.counters, L.irregT, (int4 *)hit_buf, pts, L.irregQ, (int *)nullptr, (const int *)L.deferT);
         } else if (algo != DEFTET_PIT_STAGED) {
             DEFTET_LAUNCH(k_tet_scan, gt, blk, st, tet, T, Q, L.gparam, L.G, L.Gx, L.cells, L.cellStride, L.sortedQ, L.result,
                           L.counters, L.irregT, (int4 *)hit_buf, pts, L.irregQ, ucount);
@@ -1900,7 +2233,7 @@ extern "C" int deftet_point_in_tet_prepare_f32(const float *pts, int B, int T, i
                                                size_t workspace_bytes, void *stream_)
 {
     DEFTET_CHECK_ARG(B >= 0 && T >= 0 && Q >= 0 && B <= 65535, "bad size (B=%d T=%d Q=%d)", B, T, Q);
-    DEFTET_CHECK_ARG(algo != DEFTET_PIT_BRUTE && algo >= 0 && algo <= DEFTET_PIT_FMA2, "prepare needs a binned algo (got %d)", algo);
+    DEFTET_CHECK_ARG(algo != DEFTET_PIT_BRUTE && algo >= 0 && algo <= DEFTET_PIT_GRP6, "prepare needs a binned algo (got %d)", algo);
     if (B == 0 || Q == 0) return DEFTET_OK;
     DEFTET_CHECK_ARG(pts, "null pts pointer");
     DEFTET_CHECK_ARG(workspace && ((uintptr_t)workspace & 255) == 0, "workspace null or not 256-byte aligned");

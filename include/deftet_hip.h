@@ -40,6 +40,9 @@ extern "C" {
 #define DEFTET_PIT_ROWS 3    /* binned, (tet,row) pairs balanced across the lanes of a wave through LDS */
 #define DEFTET_PIT_FMA 4     /* binned, certified fused plane filter instead of box test + exact predicate per candidate */
 #define DEFTET_PIT_FMA2 5    /* same, two candidates per packed-fp32 instruction */
+#define DEFTET_PIT_GRP2 6    /* binned, 2 consecutive tets per lane share one candidate stream (packed-fp32 pair) + fused filter */
+#define DEFTET_PIT_GRP4 7    /* same, 4 consecutive tets per lane */
+#define DEFTET_PIT_GRP6 8    /* same, 6 consecutive tets per lane */
 
 int deftet_version(void);
 const char *deftet_last_error(void);
