@@ -22,6 +22,8 @@
 
 #include <stdlib.h>
 
+#include <vector>
+
 #include "common.hpp"
 
 namespace deftet {
@@ -191,7 +193,7 @@ __global__ __launch_bounds__(256) void k_query_bbox(const float *__restrict__ pt
     {
         const long long nblk = (long long)gridDim.x * gridDim.y, bid = (long long)blockIdx.y * gridDim.x + blockIdx.x;
         const long long i = bid * blockDim.x + threadIdx.x, stride = nblk * blockDim.x;
-        if (i < nB * 4) counters[i] = 0;
+        if (i < nB * 8) counters[i] = 0;                             // [0, 4B): counters; [4B, 8B): traversal statistics
         for (long long j = i; j < nQ; j += stride) result[j] = kMiss;
     }
     const float *p = pts + (size_t)b * Q * 3;
@@ -820,6 +822,7 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan_fma(const float *__
         s = s2; e = e2; cy = ny; cz = nz;
     }
     if (nslow > 0 || hcnt > 4) {
+        atomicAdd(&counters[gridDim.y * 4 + b * 4 + 1], 1);                   // statistics: tets re-scanned
         const int4 r = exact_rescan(tet + ((size_t)b * T + t) * 12, t, cb, sq, res, G, Gx, cx0, cx1, cy0, cy1, cz0, cz1, m,
                                     &counters[b * 4 + 2]);
         if (hits) hits[(size_t)b * T + t] = r;
@@ -1099,6 +1102,7 @@ __global__ __launch_bounds__(256, NP == 1 ? 5 : (NP == 2 ? 4 : 3)) void k_tet_sc
     if (traversed) {
         if (nslow > 0 || cnt > kGrpDepth) {
             // undecided band met, or more accepting candidates than the register holds: exact re-scan of every active member
+            atomicAdd(&counters[gridDim.y * 4 + b * 4 + 0], 1);              // statistics: groups re-scanned
 #pragma unroll 1
             for (int k = 0; k < K; ++k)
                 if ((actM >> k) & 1u) exact_rescan_tet(tet, t0 + k, b, T, gparam, G, Gx, cb, sq, res, hits, counters);
@@ -2075,7 +2079,7 @@ static Layout make_layout(int B, int T, int Q, int algo, void *ws, size_t wsByte
         if (L.nRowBlk < 1) L.nRowBlk = 1;
         L.chunkQ = ((Q + L.nRowBlk - 1) / L.nRowBlk + 255) / 256 * 256;
         L.bboxPart = A.take<float>((size_t)B * kBoxBlocks * 6);
-        L.counters = A.take<int>((size_t)B * 4);
+        L.counters = A.take<int>((size_t)B * 8);              // 4 counters + 4 statistics words per shape
         L.gparam = A.take<float>((size_t)B * 12);
         L.cells = A.take<int>((size_t)B * L.cellStride);
         L.blockHist = A.take<int>((size_t)B * L.nRowBlk * R);
@@ -2252,6 +2256,28 @@ extern "C" int deftet_point_in_tet_scan_f32(const float *tet, const float *pts, 
     Layout L = make_layout(B, T, Q, algo, workspace, workspace_bytes);
     DEFTET_CHECK_ARG(L.bytes <= workspace_bytes, "workspace too small: need %zu bytes, got %zu", L.bytes, workspace_bytes);
     return pit_scan(L, tet, pts, cond, bary, pred, occ, hit_buf, B, T, Q, algo, as_stream(stream_));
+}
+
+// Diagnostics: copies the 8 int32 words per shape that the last forward on this workspace left behind —
+// [0] irregular tets, [1] irregular queries, [2] hit-record overflow flag, [3] tets deferred by the grouped traversal,
+// [4] groups re-scanned exactly, [5] tets re-scanned exactly (one-tet filter kernel), [6..7] unused — to host memory.
+// Synchronises the stream.
+extern "C" int deftet_point_in_tet_read_stats(const void *workspace, size_t workspace_bytes, int B, int T, int Q, int algo,
+                                              int32_t *out_host, void *stream_)
+{
+    DEFTET_CHECK_ARG(workspace && out_host && B > 0 && algo != DEFTET_PIT_BRUTE, "bad argument");
+    Layout L = make_layout(B, T, Q, algo, const_cast<void *>(workspace), workspace_bytes);
+    DEFTET_CHECK_ARG(L.bytes <= workspace_bytes, "workspace too small");
+    hipStream_t st = as_stream(stream_);
+    std::vector<int32_t> tmp((size_t)B * 8);
+    DEFTET_HIP(hipMemcpyAsync(tmp.data(), L.counters, (size_t)B * 32, hipMemcpyDeviceToHost, st));
+    DEFTET_HIP(hipStreamSynchronize(st));
+    for (int b = 0; b < B; ++b)
+        for (int k = 0; k < 4; ++k) {
+            out_host[b * 8 + k] = tmp[(size_t)b * 4 + k];
+            out_host[b * 8 + 4 + k] = tmp[(size_t)B * 4 + (size_t)b * 4 + k];
+        }
+    return DEFTET_OK;
 }
 
 extern "C" size_t deftet_point_in_tet_bwd_workspace_bytes(int B, int T, int Q)

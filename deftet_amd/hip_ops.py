@@ -115,6 +115,19 @@ def point_in_tet(tet_bxtx4x3, pts_bxqx3, want_bary=False, algo=PIT_AUTO, pred_bx
     return out if len(out) > 1 else cond
 
 
+def point_in_tet_stats(B, T, Q, algo, device):
+    """Diagnostics of the LAST un-prepared point_in_tet call on this device/stream (it shares the cached workspace):
+    int32 [B,8] = irregular tets, irregular queries, record-overflow flag, deferred tets, groups re-scanned, tets re-scanned, 0, 0."""
+    lib = _lib.load()
+    dev = torch.device(device)
+    out = np.zeros((B, 8), np.int32)
+    with torch.cuda.device(dev):
+        ws = _lib.workspace(dev, lib.deftet_point_in_tet_workspace_bytes(B, T, Q, algo))
+        _lib.check(lib.deftet_point_in_tet_read_stats(_lib.ptr(ws), ws.numel(), B, T, Q, algo, out.ctypes.data, _lib.current_stream(dev)),
+                   "deftet_point_in_tet_read_stats")
+    return out
+
+
 def point_in_tet_bwd(tet_bxtx4x3, pts_bxqx3, cond, grad_w, want_grad_pts=False, grad_occ=None, hits=None):
     """(grad_tet [B,T,4,3], grad_pts [B,Q,3] | None) and, when grad_occ [B,Q] is given, also
     grad_pred [B,T] (fused paste_occ backward).  `hits` = the forward's hit-record buffer (same

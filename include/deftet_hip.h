@@ -103,6 +103,12 @@ int deftet_point_in_tet_scan_f32(const float *tet, const float *pts, float *cond
  * also needs 64*n_batch floats of workspace); else workspace
  * (deftet_point_in_tet_bwd_workspace_bytes) enables the linked-list gather path; with neither a
  * float-atomic scatter is used. */
+/* Diagnostics (not on the hot path): 8 int32 per shape left in `workspace` by the last forward — irregular tets, irregular
+ * queries, hit-record overflow flag, tets deferred by the grouped traversal, groups / tets re-scanned exactly, 2 unused.
+ * Copies to host memory and synchronises the stream. */
+int deftet_point_in_tet_read_stats(const void *workspace, size_t workspace_bytes, int n_batch, int n_tet, int n_query, int algo,
+                                   int32_t *out_host_8xB, void *stream);
+
 size_t deftet_point_in_tet_bwd_workspace_bytes(int n_batch, int n_tet, int n_query);
 int deftet_point_in_tet_bwd_f32(const float *tet, const float *pts, const float *cond,
                                 const float *grad_w, float *grad_tet, float *grad_pts,

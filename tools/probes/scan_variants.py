@@ -47,6 +47,7 @@ def run(wl, lib, algo, reps):
     tot, cnt = ctypes.c_double(0), ctypes.c_longlong(0)
     lib.deftet_profile_read(ctypes.byref(tot), ctypes.byref(cnt))
     lib.deftet_profile_select(b"")
+    run.stats = hip_ops.point_in_tet_stats(wl.B, wl.T, wl.Q, algo, d["tet"].device).sum(0).tolist()
     # backward from this variant's hit records
     t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
     t0.record()
@@ -89,7 +90,7 @@ def main():
         algo_bytes = wl.dominant_bytes
         print(json.dumps({"config": a.config, "mesh": a.mesh or "kuhn", "n_tet": wl.T, "algo": algo, "kernel": hip_ops.pit_kernel_name(algo), "xfine": xf, "gdiv": gd, "qdiv": qd,
                           "traversal_us": round(k_us, 2), "fwd_us": round(fwd_us, 1), "bwd_us": round(bwd_us, 1),
-                          "roofline_frac_of_8TBs": round(algo_bytes / (k_us * 1e-6) / 8e12, 4), "same_as_default": same,
+                          "roofline_frac_of_8TBs": round(algo_bytes / (k_us * 1e-6) / 8e12, 4), "same_as_default": same, "stats_irrT_irrQ_ovf_defer_grpRescan_tetRescan": run.stats[:6],
                           "bwd_rel_diff": gerr}), flush=True)
     set_env(DEFTET_PIT_XFINE=None, DEFTET_PIT_GDIV=None, DEFTET_PIT_QDIV=None)
 
