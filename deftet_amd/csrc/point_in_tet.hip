@@ -768,20 +768,25 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan_fma(const float *__
         h0 = acc ? qi : h0;
         hcnt += acc ? 1 : 0;
     };
-    int cy = cy0, cz = cz0;
-    auto bounds = [&](int row, int &s_, int &e_) {
-        s_ = cb[row + cx0];
-        e_ = cb[row + cx1 + 1];
-    };
-    int s, e;
-    bounds((cz * G + cy) * Gx, s, e);
-    for (;;) {
-        int ny = cy + 1, nz = cz;
-        if (ny > cy1) { ny = cy0; nz = cz + 1; }
-        const bool more = nz <= cz1;
-        int s2 = 0, e2 = 0;
-        if (more) bounds((nz * G + ny) * Gx, s2, e2);
-        for (int j = s; j < e; j += 2) {
+    // per-lane cursor over (row, position), see k_tet_scan_grp: every wave-iteration each lane takes ITS next two candidates
+    int cy = cy0, cz = cz0;                                             // the row whose bounds sit in (s2, e2)
+    int j = 0, e = 0;
+    int s2 = cb[(cz * G + cy) * Gx + cx0], e2 = cb[(cz * G + cy) * Gx + cx1 + 1];
+    bool haveNext = true;
+    while (j < e || haveNext) {
+        if (j >= e) {                                                   // enter the prefetched row, prefetch the one after it
+            j = s2;
+            e = e2;
+            ++cy;
+            if (cy > cy1) { cy = cy0; ++cz; }
+            haveNext = cz <= cz1;
+            if (haveNext) {
+                const int row2 = (cz * G + cy) * Gx;
+                s2 = cb[row2 + cx0];
+                e2 = cb[row2 + cx1 + 1];
+            }
+        }
+        if (j < e) {
             const bool two = j + 1 < e;
             const float4 q0 = sq[j];
             float4 q1;                                                  // only read under `two`; no copy of q0 is materialised
@@ -817,9 +822,8 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan_fma(const float *__
                 decide(a0, __float_as_int(q0.w), true);
                 decide(a1, __float_as_int(q1.w), two);
             }
+            j += 2;
         }
-        if (!more) break;
-        s = s2; e = e2; cy = ny; cz = nz;
     }
     if (nslow > 0 || hcnt > 4) {
         atomicAdd(&counters[gridDim.y * 4 + b * 4 + 1], 1);                   // statistics: tets re-scanned
@@ -1072,19 +1076,28 @@ __global__ __launch_bounds__(256, NP == 1 ? 5 : (NP == 2 ? 4 : 3)) void k_tet_sc
                 e3 = push ? e2 : e3; e2 = push ? e1 : e2; e1 = push ? e0 : e1; e0 = push ? entry : e0;
                 cnt += push ? 1 : 0;
             };
-            int cy = uy0, cz = uz0;
-            int s = cb[(cz * G + cy) * Gx + ux0], e = cb[(cz * G + cy) * Gx + ux1 + 1];
-            for (;;) {
-                int ny = cy + 1, nz = cz;
-                if (ny > uy1) { ny = uy0; nz = cz + 1; }
-                const bool more = nz <= uz1;
-                int s2 = 0, e2r = 0;
-                if (more) {
-                    const int row2 = (nz * G + ny) * Gx;
-                    s2 = cb[row2 + ux0];
-                    e2r = cb[row2 + ux1 + 1];
+            // Per-lane cursor over (row, position): in every wave-iteration each lane takes ITS next two candidates,
+            // wherever they are — a lane whose run is exhausted enters its next row while the others keep testing.
+            // (Looping row by row instead makes the wave spend max-over-lanes iterations on EVERY row: ~30 wave-
+            // iterations for ~6.5 per lane at configs[2], i.e. 20 % lane utilisation and 30 dependent gather round trips.)
+            int cy = uy0, cz = uz0;                                   // the row whose bounds sit in (s2, e2r)
+            int j = 0, e = 0;
+            int s2 = cb[(cz * G + cy) * Gx + ux0], e2r = cb[(cz * G + cy) * Gx + ux1 + 1];
+            bool haveNext = true;
+            while (j < e || haveNext) {
+                if (j >= e) {                                         // enter the prefetched row, prefetch the one after it
+                    j = s2;
+                    e = e2r;
+                    ++cy;
+                    if (cy > uy1) { cy = uy0; ++cz; }
+                    haveNext = cz <= uz1;
+                    if (haveNext) {
+                        const int row2 = (cz * G + cy) * Gx;
+                        s2 = cb[row2 + ux0];
+                        e2r = cb[row2 + ux1 + 1];
+                    }
                 }
-                for (int j = s; j < e; j += 2) {
+                if (j < e) {
                     const bool two = j + 1 < e;
                     const float4 q0 = sq[j];
                     float4 q1;
@@ -1093,9 +1106,8 @@ __global__ __launch_bounds__(256, NP == 1 ? 5 : (NP == 2 ? 4 : 3)) void k_tet_sc
                     if (two) q1 = sq[j + 1];
                     test(q0, true);
                     test(q1, two);
+                    j += 2;
                 }
-                if (!more) break;
-                s = s2; e = e2r; cy = ny; cz = nz;
             }
         }
     }
