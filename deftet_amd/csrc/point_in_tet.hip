@@ -1158,6 +1158,258 @@ __global__ __launch_bounds__(256, NP == 1 ? 5 : (NP == 2 ? 4 : 3)) void k_tet_sc
 }
 
 // ------------------------------------------------------------------------------------
+// k_tet_scan_lds<STAGE_Q> (DEFTET_PIT_LDSB / DEFTET_PIT_LDS): the fused-filter traversal with the block's slice of the
+// grid staged in LDS.  What the one-tet-per-lane kernels pay for is the divergent-gather path: ~8 row-bound loads and ~12
+// candidate loads per tet, each lane with its own address (TA_TA_BUSY ~85 % of the kernel time, profiles/r02_pmc_*).  The
+// 256 consecutive tets of a workgroup are neighbours in any sensibly ordered mesh, so the workgroup
+//   1. reduces its lanes' cell ranges to one union box (six LDS atomics per lane),
+//   2. copies the box's cell starts into LDS with coalesced loads                       (<= kCapB ints), and, with STAGE_Q,
+//   3. the queries of the box's row runs as well: per-row LDS offsets by a block scan   (<= kCapQ queries),
+// after which every lane walks ITS OWN cell range exactly as k_tet_scan_fma does, but out of LDS.  Same candidates, same
+// certified filter, same exact fallback, same records: results are bit-identical.  A workgroup whose box does not fit
+// (incoherent tet order, list mode) keeps the per-lane global loads for whatever did not fit.
+// ------------------------------------------------------------------------------------
+constexpr int kCapB = 2048;        // staged cell starts per workgroup (8 KB)
+constexpr int kCapQ = 1024;        // staged queries per workgroup (16 KB)
+constexpr int kCapRows = 512;      // rows of the union box (2 per thread in the offset scan)
+
+template <bool STAGE_Q>
+__global__ __launch_bounds__(256, 5) void k_tet_scan_lds(const float *__restrict__ tet, int T, int Q,
+                                                  const float *__restrict__ gparam, int G, int Gx, const int *__restrict__ cells,
+                                                  long long cellStride, const float4 *__restrict__ sortedQ, int *result, int *counters,
+                                                  int *irregT, int4 *hits, const float *__restrict__ pts,
+                                                  const int *__restrict__ irregQ, int *ucount)
+{
+    __shared__ int s_box[8];
+    __shared__ int s_cb[kCapB];
+    __shared__ int s_delta[STAGE_Q ? kCapRows : 1];        // LDS position of a row's first staged query minus its global position
+    __shared__ float4 s_q[STAGE_Q ? kCapQ : 1];
+    __shared__ int s_wsum[5];
+    if (ucount && blockIdx.x == 0 && threadIdx.x == 0) ucount[blockIdx.y] = 0;
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int nblk = gridDim.x;
+    const int per = (nblk + 7) >> 3;
+    const int vb = (blockIdx.x & 7) * per + (blockIdx.x >> 3);        // XCD-aware mapping, see k_tet_scan
+    if (vb >= nblk || vb * 256 >= T) return;                           // whole workgroup out of range (uniform)
+    const int t = vb * 256 + tid;
+    const bool live = t < T;
+    if (tid < 3) s_box[tid] = 0x7FFFFFFF;
+    else if (tid < 6) s_box[tid] = -1;
+    const Grid g = load_grid(gparam + b * 12);
+    Filter F;
+    bool regular = false, active = false;
+    int cx0 = 0, cx1 = -1, cy0 = 0, cy1 = -1, cz0 = 0, cz1 = -1;
+    float m = 0.f;
+    {
+        float v[12];
+        const float4 *src = reinterpret_cast<const float4 *>(tet + ((size_t)b * T + (live ? t : vb * 256)) * 12);
+        const float4 a = src[0], bq = src[1], c = src[2];
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+        v[4] = bq.x; v[5] = bq.y; v[6] = bq.z; v[7] = bq.w;
+        v[8] = c.x; v[9] = c.y; v[10] = c.z; v[11] = c.w;
+        float lo[3], hi[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = fminf(fminf(v[k], v[3 + k]), fminf(v[6 + k], v[9 + k]));
+            hi[k] = fmaxf(fmaxf(v[k], v[3 + k]), fmaxf(v[6 + k], v[9 + k]));
+        }
+        const float w = fmaxf(fmaxf(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]);
+        Planes P;
+        make_planes(v, P);
+        bool finite = true;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) finite = finite && (fabsf(v[k]) <= kBig);
+        const float mn = fminf(fminf(fabsf(P.dv[0]), fabsf(P.dv[1])), fminf(fabsf(P.dv[2]), fabsf(P.dv[3])));
+        regular = finite && (P.sv == 0u || P.sv == 15u) && (w >= kWMin) && (mn >= kTau * ((w * w) * w));
+        const float sigma = P.sv == 15u ? 1.0f : -1.0f;
+        float S[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            S[k] = kErrScale * (fmaxf(fabsf(g.lo[k]), fabsf(g.hi[k])) + 2.0f * fmaxf(fabsf(lo[k]), fabsf(hi[k])));
+        float emax = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float n0 = P.n[i][0], n1 = P.n[i][1], n2 = P.n[i][2];
+            const float c2 = fmaf(n0, P.a[i][0], fmaf(n1, P.a[i][1], n2 * P.a[i][2]));
+            const float E = fmaf(fabsf(n0), S[0], fmaf(fabsf(n1), S[1], fabsf(n2) * S[2])) + kErrAbs;
+            F.N[i][0] = sigma * n0; F.N[i][1] = sigma * n1; F.N[i][2] = sigma * n2;
+            F.C[i] = -sigma * c2 - E;
+            emax = fmaxf(emax, E);
+        }
+        F.twoEmax = 2.0f * emax;
+        m = w * kMargin;
+        const float e0 = lo[0] - m, e1 = hi[0] + m, e2 = lo[1] - m, e3 = hi[1] + m, e4 = lo[2] - m, e5 = hi[2] + m;
+        const bool ingrid = !(e1 < g.lo[0] || e0 > g.hi[0] || e3 < g.lo[1] || e2 > g.hi[1] || e5 < g.lo[2] || e4 > g.hi[2]);
+        active = live && regular && ingrid;
+        if (active) {
+            cx0 = cell_of(e0, g.o[0], g.inv[0], Gx); cx1 = cell_of(e1, g.o[0], g.inv[0], Gx);
+            cy0 = cell_of(e2, g.o[1], g.inv[1], G);  cy1 = cell_of(e3, g.o[1], g.inv[1], G);
+            cz0 = cell_of(e4, g.o[2], g.inv[2], G);  cz1 = cell_of(e5, g.o[2], g.inv[2], G);
+        }
+        if (live && !regular) {                                        // irregular tet (normally none): k_finalize tests it against every query
+            const int k = atomicAdd(&counters[b * 4 + 0], 1);
+            irregT[(size_t)b * T + k] = t;
+            if (hits) hits[(size_t)b * T + t] = make_int4(-1, -1, -1, kHitOverflow);
+        }
+        if (live && regular && !ingrid && hits) hits[(size_t)b * T + t] = make_int4(-1, -1, -1, -1);
+    }
+    // ---- 1. union box of the workgroup's active lanes
+    __syncthreads();
+    if (active) {
+        atomicMin(&s_box[0], cx0); atomicMin(&s_box[1], cy0); atomicMin(&s_box[2], cz0);
+        atomicMax(&s_box[3], cx1); atomicMax(&s_box[4], cy1); atomicMax(&s_box[5], cz1);
+    }
+    __syncthreads();
+    const int ux0 = s_box[0], uy0 = s_box[1], uz0 = s_box[2], ux1 = s_box[3], uy1 = s_box[4], uz1 = s_box[5];
+    const int *cb = cells + (size_t)b * cellStride;
+    const float4 *sq = sortedQ + (size_t)b * Q;
+    int *res = result + (size_t)b * Q;
+    bool stB = false, stQ = false;
+    int nx1 = 1, ny = 1;
+    if (ux1 >= ux0) {                                                  // some lane is active (uniform)
+        nx1 = ux1 - ux0 + 2;
+        ny = uy1 - uy0 + 1;
+        const int nz = uz1 - uz0 + 1;
+        const long long rowsl = (long long)ny * nz;
+        stB = rowsl <= kCapRows && rowsl * nx1 <= kCapB;
+        if (stB) {
+            // ---- 2. cell starts of the box -> LDS (row r = (cz - uz0) * ny + (cy - uy0), nx1 starts per row)
+            const int rows = (int)rowsl, n = rows * nx1;
+            const float inv_nx1 = 1.0f / (float)nx1, inv_ny = 1.0f / (float)ny;
+            for (int i = tid; i < n; i += 256) {
+                const int r = (int)(((float)i + 0.5f) * inv_nx1), x = i - r * nx1;          // exact for these small integers
+                const int rz = (int)(((float)r + 0.5f) * inv_ny), ry = r - rz * ny;
+                s_cb[i] = cb[((uz0 + rz) * G + (uy0 + ry)) * Gx + ux0 + x];
+            }
+            __syncthreads();
+            if (STAGE_Q) {
+                // ---- 3. per-row LDS offsets (block exclusive scan of the run lengths, two rows per thread)
+                const int r0 = tid * 2, r1 = r0 + 1;
+                const int st0 = r0 < rows ? s_cb[r0 * nx1] : 0, st1 = r1 < rows ? s_cb[r1 * nx1] : 0;
+                const int len0 = r0 < rows ? s_cb[r0 * nx1 + nx1 - 1] - st0 : 0;
+                const int len1 = r1 < rows ? s_cb[r1 * nx1 + nx1 - 1] - st1 : 0;
+                const int sum = len0 + len1;
+                int incl = sum;
+                const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int u = __shfl_up(incl, off);
+                    if (lane >= off) incl += u;
+                }
+                if (lane == 63) s_wsum[wv] = incl;
+                __syncthreads();
+                int base = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (k < wv) base += s_wsum[k];
+                const int total = (s_wsum[0] + s_wsum[1]) + (s_wsum[2] + s_wsum[3]);
+                const int excl = base + incl - sum;
+                stQ = total <= kCapQ;                                   // uniform
+                if (stQ) {
+                    if (r0 < rows) s_delta[r0] = excl - st0;
+                    if (r1 < rows) s_delta[r1] = excl + len0 - st1;
+                }
+                __syncthreads();
+                if (stQ) {
+                    // the queries of the box's row runs -> LDS, eight lanes per row (128 contiguous bytes per step)
+                    for (int r = tid >> 3; r < rows; r += 32) {
+                        const int st = s_cb[r * nx1], nq = s_cb[r * nx1 + nx1 - 1] - st, d = s_delta[r];
+                        for (int k = tid & 7; k < nq; k += 8) s_q[st + k + d] = sq[st + k];
+                    }
+                    __syncthreads();
+                }
+            }
+        }
+    }
+    // ---- traversal (per-lane cursor, see k_tet_scan_grp), operands from LDS where staged
+    int hcnt = 0, nslow = 0;
+    int h0 = -1, h1 = -1, h2 = -1, h3 = -1;
+    if (active) {
+        auto decide = [&](float a, int qi, bool lv) {
+            const bool acc = lv && a > 0.f;
+            nslow += (lv && !acc && a >= -F.twoEmax) ? 1 : 0;
+            h3 = acc ? h2 : h3;
+            h2 = acc ? h1 : h2;
+            h1 = acc ? h0 : h1;
+            h0 = acc ? qi : h0;
+            hcnt += acc ? 1 : 0;
+        };
+        auto filter = [&](const float4 &q) {
+            float A[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) A[i] = fmaf(F.N[i][0], q.x, fmaf(F.N[i][1], q.y, fmaf(F.N[i][2], q.z, F.C[i])));
+            return fminf(fminf(A[0], A[1]), fminf(A[2], A[3]));
+        };
+        const int bx0 = cx0 - ux0, bx1 = cx1 + 1 - ux0;               // positions of this lane's two bounds inside a staged row
+        int cy = cy0, cz = cz0;                                         // the row whose bounds sit in (s2, e2)
+        int j = 0, e = 0, d = 0, d2 = 0;
+        int s2, e2;
+        if (stB) {
+            const int r = (cz - uz0) * ny + (cy - uy0);
+            s2 = s_cb[r * nx1 + bx0];
+            e2 = s_cb[r * nx1 + bx1];
+            if (stQ) d2 = s_delta[r];
+        } else {
+            s2 = cb[(cz * G + cy) * Gx + cx0];
+            e2 = cb[(cz * G + cy) * Gx + cx1 + 1];
+        }
+        bool haveNext = true;
+        while (j < e || haveNext) {
+            if (j >= e) {                                               // enter the prefetched row, prefetch the one after it
+                j = s2;
+                e = e2;
+                d = d2;
+                ++cy;
+                if (cy > cy1) { cy = cy0; ++cz; }
+                haveNext = cz <= cz1;
+                if (haveNext) {
+                    if (stB) {
+                        const int r = (cz - uz0) * ny + (cy - uy0);
+                        s2 = s_cb[r * nx1 + bx0];
+                        e2 = s_cb[r * nx1 + bx1];
+                        if (stQ) d2 = s_delta[r];
+                    } else {
+                        const int row2 = (cz * G + cy) * Gx;
+                        s2 = cb[row2 + cx0];
+                        e2 = cb[row2 + cx1 + 1];
+                    }
+                }
+            }
+            if (j < e) {
+                const bool two = j + 1 < e;
+                float4 q0, q1;
+                if (stQ) {
+                    q0 = s_q[j + d];
+                    q1 = s_q[two ? j + d + 1 : j + d];
+                } else {
+                    q0 = sq[j];
+                    q1.x = __builtin_nondeterministic_value(q0.x); q1.y = __builtin_nondeterministic_value(q0.y);
+                    q1.z = __builtin_nondeterministic_value(q0.z); q1.w = __builtin_nondeterministic_value(q0.w);
+                    if (two) q1 = sq[j + 1];
+                }
+                const float a0 = filter(q0), a1 = filter(q1);
+                decide(a0, __float_as_int(q0.w), true);
+                decide(a1, __float_as_int(q1.w), two);
+                j += 2;
+            }
+        }
+        if (nslow > 0 || hcnt > 4) {
+            atomicAdd(&counters[gridDim.y * 4 + b * 4 + 1], 1);               // statistics: tets re-scanned
+            const int4 r = exact_rescan(tet + ((size_t)b * T + t) * 12, t, cb, sq, res, G, Gx, cx0, cx1, cy0, cy1, cz0, cz1, m,
+                                        &counters[b * 4 + 2]);
+            if (hits) hits[(size_t)b * T + t] = r;
+        } else {
+            if (hcnt > 0) atomicMin(&res[h0], t);
+            if (hcnt > 1) atomicMin(&res[h1], t);
+            if (hcnt > 2) atomicMin(&res[h2], t);
+            if (hcnt > 3) atomicMin(&res[h3], t);
+            if (hits) hits[(size_t)b * T + t] = make_int4(h0, h1, h2, h3);
+        }
+    }
+    if (live) fma_irregular_tail(tet, t, b, T, Q, pts, counters, irregQ, result);
+}
+
+// ------------------------------------------------------------------------------------
 // Wave-cooperative variant of k_tet_scan for spatially coherent tet orders (DEFTET_PIT_STAGED).
 // MEASURED NO FASTER than k_tet_scan on the BASELINE workload (0.322 vs 0.324 ms per step: 37 %
 // fewer vector-memory instructions, 16 % fewer L1 accesses, but 18 % more VALU work for the
@@ -2135,7 +2387,7 @@ static int pit_check(const float *tet, const float *pts, const float *cond, cons
     DEFTET_CHECK_ARG(B >= 0 && T >= 0 && Q >= 0, "negative size (B=%d T=%d Q=%d)", B, T, Q);
     DEFTET_CHECK_ARG(algo == DEFTET_PIT_AUTO || algo == DEFTET_PIT_BRUTE || algo == DEFTET_PIT_STAGED || algo == DEFTET_PIT_ROWS ||
                          algo == DEFTET_PIT_FMA || algo == DEFTET_PIT_FMA2 || algo == DEFTET_PIT_GRP2 || algo == DEFTET_PIT_GRP4 ||
-                         algo == DEFTET_PIT_GRP6,
+                         algo == DEFTET_PIT_GRP6 || algo == DEFTET_PIT_LDSB || algo == DEFTET_PIT_LDS,
                      "unknown algo %d", algo);
     if (T >= (1 << 24)) return set_error(DEFTET_ELIMIT, "n_tet=%d does not fit a float-encoded index (2^24)", T);
     DEFTET_CHECK_ARG(B <= 65535, "n_batch=%d exceeds the grid-y limit 65535", B);
@@ -2183,6 +2435,12 @@ static int pit_scan(const Layout &L, const float *tet, const float *pts, float *
         } else if (algo == DEFTET_PIT_FMA2) {
             DEFTET_LAUNCH(k_tet_scan_fma<true>, gt, blk, st, tet, T, Q, L.gparam, L.G, L.Gx, L.cells, L.cellStride, L.sortedQ, L.result,
                           L.counters, L.irregT, (int4 *)hit_buf, pts, L.irregQ, ucount, (const int *)nullptr);
+        } else if (algo == DEFTET_PIT_LDSB) {
+            DEFTET_LAUNCH(k_tet_scan_lds<false>, gt, blk, st, tet, T, Q, L.gparam, L.G, L.Gx, L.cells, L.cellStride, L.sortedQ, L.result,
+                          L.counters, L.irregT, (int4 *)hit_buf, pts, L.irregQ, ucount);
+        } else if (algo == DEFTET_PIT_LDS) {
+            DEFTET_LAUNCH(k_tet_scan_lds<true>, gt, blk, st, tet, T, Q, L.gparam, L.G, L.Gx, L.cells, L.cellStride, L.sortedQ, L.result,
+                          L.counters, L.irregT, (int4 *)hit_buf, pts, L.irregQ, ucount);
         } else if (algo == DEFTET_PIT_GRP2 || algo == DEFTET_PIT_GRP4 || algo == DEFTET_PIT_GRP6) {
             const int K = algo == DEFTET_PIT_GRP2 ? 2 : (algo == DEFTET_PIT_GRP4 ? 4 : 6);
             const int ng = (T + K - 1) / K;
@@ -2249,7 +2507,7 @@ extern "C" int deftet_point_in_tet_prepare_f32(const float *pts, int B, int T, i
                                                size_t workspace_bytes, void *stream_)
 {
     DEFTET_CHECK_ARG(B >= 0 && T >= 0 && Q >= 0 && B <= 65535, "bad size (B=%d T=%d Q=%d)", B, T, Q);
-    DEFTET_CHECK_ARG(algo != DEFTET_PIT_BRUTE && algo >= 0 && algo <= DEFTET_PIT_GRP6, "prepare needs a binned algo (got %d)", algo);
+    DEFTET_CHECK_ARG(algo != DEFTET_PIT_BRUTE && algo >= 0 && algo <= DEFTET_PIT_LDS, "prepare needs a binned algo (got %d)", algo);
     if (B == 0 || Q == 0) return DEFTET_OK;
     DEFTET_CHECK_ARG(pts, "null pts pointer");
     DEFTET_CHECK_ARG(workspace && ((uintptr_t)workspace & 255) == 0, "workspace null or not 256-byte aligned");

@@ -43,6 +43,8 @@ extern "C" {
 #define DEFTET_PIT_GRP2 6    /* binned, 2 consecutive tets per lane share one candidate stream (packed-fp32 pair) + fused filter */
 #define DEFTET_PIT_GRP4 7    /* same, 4 consecutive tets per lane */
 #define DEFTET_PIT_GRP6 8    /* same, 6 consecutive tets per lane */
+#define DEFTET_PIT_LDSB 9    /* fused filter, the workgroup's cell starts staged in LDS */
+#define DEFTET_PIT_LDS 10    /* fused filter, the workgroup's cell starts AND candidate queries staged in LDS */
 
 int deftet_version(void);
 const char *deftet_last_error(void);
