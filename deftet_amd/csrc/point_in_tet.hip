@@ -1169,6 +1169,19 @@ __global__ __launch_bounds__(256, NP == 1 ? 5 : (NP == 2 ? 4 : 3)) void k_tet_sc
 // certified filter, same exact fallback, same records: results are bit-identical.  A workgroup whose box does not fit
 // (incoherent tet order, list mode) keeps the per-lane global loads for whatever did not fit.
 // ------------------------------------------------------------------------------------
+__device__ __forceinline__ int wave_min_i(int v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off));
+    return v;
+}
+__device__ __forceinline__ int wave_max_i(int v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off));
+    return v;
+}
+
 constexpr int kCapB = 2048;        // staged cell starts per workgroup (8 KB)
 constexpr int kCapQ = 1024;        // staged queries per workgroup (16 KB)
 constexpr int kCapRows = 512;      // rows of the union box (2 per thread in the offset scan)
@@ -1180,7 +1193,7 @@ __global__ __launch_bounds__(256, 5) void k_tet_scan_lds(const float *__restrict
                                                   int *irregT, int4 *hits, const float *__restrict__ pts,
                                                   const int *__restrict__ irregQ, int *ucount)
 {
-    __shared__ int s_box[8];
+    __shared__ int s_box4[24];
     __shared__ int s_cb[kCapB];
     __shared__ int s_delta[STAGE_Q ? kCapRows : 1];        // LDS position of a row's first staged query minus its global position
     __shared__ float4 s_q[STAGE_Q ? kCapQ : 1];
@@ -1193,8 +1206,6 @@ __global__ __launch_bounds__(256, 5) void k_tet_scan_lds(const float *__restrict
     if (vb >= nblk || vb * 256 >= T) return;                           // whole workgroup out of range (uniform)
     const int t = vb * 256 + tid;
     const bool live = t < T;
-    if (tid < 3) s_box[tid] = 0x7FFFFFFF;
-    else if (tid < 6) s_box[tid] = -1;
     const Grid g = load_grid(gparam + b * 12);
     Filter F;
     bool regular = false, active = false;
@@ -1253,14 +1264,21 @@ __global__ __launch_bounds__(256, 5) void k_tet_scan_lds(const float *__restrict
         }
         if (live && regular && !ingrid && hits) hits[(size_t)b * T + t] = make_int4(-1, -1, -1, -1);
     }
-    // ---- 1. union box of the workgroup's active lanes
-    __syncthreads();
-    if (active) {
-        atomicMin(&s_box[0], cx0); atomicMin(&s_box[1], cy0); atomicMin(&s_box[2], cz0);
-        atomicMax(&s_box[3], cx1); atomicMax(&s_box[4], cy1); atomicMax(&s_box[5], cz1);
+    // ---- 1. union box of the workgroup's active lanes: wave butterflies, then four partials per bound through LDS
+    //         (64 lanes hitting one LDS word with an atomic serialise: measured 2x the whole kernel)
+    {
+        constexpr int kBigI = 0x7FFFFFFF;
+        const int m0 = wave_min_i(active ? cx0 : kBigI), m1 = wave_min_i(active ? cy0 : kBigI), m2 = wave_min_i(active ? cz0 : kBigI);
+        const int m3 = wave_max_i(active ? cx1 : -1), m4 = wave_max_i(active ? cy1 : -1), m5 = wave_max_i(active ? cz1 : -1);
+        if ((tid & 63) == 0) {
+            int *dst = s_box4 + (tid >> 6) * 6;
+            dst[0] = m0; dst[1] = m1; dst[2] = m2; dst[3] = m3; dst[4] = m4; dst[5] = m5;
+        }
     }
     __syncthreads();
-    const int ux0 = s_box[0], uy0 = s_box[1], uz0 = s_box[2], ux1 = s_box[3], uy1 = s_box[4], uz1 = s_box[5];
+    const int ux0 = min(min(s_box4[0], s_box4[6]), min(s_box4[12], s_box4[18])), uy0 = min(min(s_box4[1], s_box4[7]), min(s_box4[13], s_box4[19]));
+    const int uz0 = min(min(s_box4[2], s_box4[8]), min(s_box4[14], s_box4[20])), ux1 = max(max(s_box4[3], s_box4[9]), max(s_box4[15], s_box4[21]));
+    const int uy1 = max(max(s_box4[4], s_box4[10]), max(s_box4[16], s_box4[22])), uz1 = max(max(s_box4[5], s_box4[11]), max(s_box4[17], s_box4[23]));
     const int *cb = cells + (size_t)b * cellStride;
     const float4 *sq = sortedQ + (size_t)b * Q;
     int *res = result + (size_t)b * Q;
@@ -1429,18 +1447,6 @@ __global__ __launch_bounds__(256, 5) void k_tet_scan_lds(const float *__restrict
 constexpr int kSubMax = 448;           // staged cell bounds per wave
 constexpr int kStageQ = 224;           // staged queries per wave
 
-__device__ __forceinline__ int wave_min_i(int v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off));
-    return v;
-}
-__device__ __forceinline__ int wave_max_i(int v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off));
-    return v;
-}
 __device__ __forceinline__ void wave_fence()
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
