@@ -46,7 +46,7 @@ constexpr int kHitPad = 64;
 __host__ __device__ inline size_t hit_cnt_off(int B, int T) { return (size_t)B * T * 4; }
 __host__ __device__ inline size_t hit_list_off(int B, int T) { return (size_t)B * T * 4 + (size_t)((B + kHitPad - 1) / kHitPad) * kHitPad; }
 #ifndef PIT_XFINE
-#define PIT_XFINE 4
+#define PIT_XFINE 6
 #endif
 #ifndef PIT_GDIV
 #define PIT_GDIV 6.0
@@ -594,6 +594,13 @@ struct Filter {
     float twoEmax;
 };
 
+// load at a 32-bit unsigned BYTE offset from a (wave-uniform) base pointer: scalar-base + vector-offset addressing
+template <typename T>
+__device__ __forceinline__ T ld_off(const void *base, unsigned byte_off)
+{
+    return *reinterpret_cast<const T *>(static_cast<const char *>(base) + byte_off);
+}
+
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // Exact re-scan of ONE tet's candidates (box test + reference predicate, as k_tet_scan does), used by k_tet_scan_fma for
@@ -751,48 +758,49 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan_fma(const float *__
     const int *cb = cells + (size_t)b * cellStride;
     const float4 *sq = sortedQ + (size_t)b * Q;
     int *res = result + (size_t)b * Q;
-    // Accepted queries are collected WITHOUT a branch: the hit record doubles as a four-deep shift register
-    // (x = newest), and the atomicMin of the recorded queries is issued once, after the traversal.  Only the rare
-    // fifth acceptance of a tet pushes an entry out, which is then published on the spot.
     // The loop body is branch-free.  Accepted queries go into a four-deep shift register (h0 = newest) and are
     // published with atomicMin once, after the traversal.  A candidate in the filter's undecided band, or a fifth
     // acceptance, only raises a flag; such tets (~1e-4 of them) are re-scanned exactly afterwards.
     int h0 = -1, h1 = -1, h2 = -1, h3 = -1;
-    int nslow = 0;
+    float amin = INFINITY;                                             // smallest |filter value| met: <= 2 Emax <=> the undecided band was touched
     auto decide = [&](float a, int qi, bool live) {
         const bool acc = live && a > 0.f;
-        nslow += (live && !acc && a >= -F.twoEmax) ? 1 : 0;
+        amin = fminf(amin, fabsf(a));                                  // a dead second slot repeats the first candidate: no mask needed
         h3 = acc ? h2 : h3;
         h2 = acc ? h1 : h2;
         h1 = acc ? h0 : h1;
         h0 = acc ? qi : h0;
         hcnt += acc ? 1 : 0;
     };
-    // per-lane cursor over (row, position), see k_tet_scan_grp: every wave-iteration each lane takes ITS next two candidates
-    int cy = cy0, cz = cz0;                                             // the row whose bounds sit in (s2, e2)
+    // per-lane cursor over (row, position), see k_tet_scan_grp: every wave-iteration each lane takes ITS next two candidates.
+    // All addresses are 32-bit BYTE offsets from wave-uniform bases (scalar base + vector offset addressing: no 64-bit
+    // address arithmetic in the loop); the row offset advances by additions (no integer multiply).
+    const unsigned rowStepB = (unsigned)Gx * 4u;                                        // next cy
+    const unsigned rowWrapB = (unsigned)((G - (cy1 - cy0)) * Gx) * 4u;                 // cy wraps to cy0, cz + 1
+    const unsigned x0B = (unsigned)cx0 * 4u, x1B = (unsigned)(cx1 + 1) * 4u;
+    unsigned rowB = (unsigned)((cz0 * G + cy0) * Gx) * 4u;                              // the row whose bounds sit in (s2, e2)
+    int cy = cy0, cz = cz0;
     int j = 0, e = 0;
-    int s2 = cb[(cz * G + cy) * Gx + cx0], e2 = cb[(cz * G + cy) * Gx + cx1 + 1];
+    int s2 = ld_off<int>(cb, rowB + x0B), e2 = ld_off<int>(cb, rowB + x1B);
     bool haveNext = true;
     while (j < e || haveNext) {
         if (j >= e) {                                                   // enter the prefetched row, prefetch the one after it
             j = s2;
             e = e2;
-            ++cy;
-            if (cy > cy1) { cy = cy0; ++cz; }
+            const bool wrap = cy == cy1;
+            cy = wrap ? cy0 : cy + 1;
+            cz += wrap ? 1 : 0;
+            rowB += wrap ? rowWrapB : rowStepB;
             haveNext = cz <= cz1;
             if (haveNext) {
-                const int row2 = (cz * G + cy) * Gx;
-                s2 = cb[row2 + cx0];
-                e2 = cb[row2 + cx1 + 1];
+                s2 = ld_off<int>(cb, rowB + x0B);
+                e2 = ld_off<int>(cb, rowB + x1B);
             }
         }
         if (j < e) {
             const bool two = j + 1 < e;
-            const float4 q0 = sq[j];
-            float4 q1;                                                  // only read under `two`; no copy of q0 is materialised
-            q1.x = __builtin_nondeterministic_value(q0.x); q1.y = __builtin_nondeterministic_value(q0.y);
-            q1.z = __builtin_nondeterministic_value(q0.z); q1.w = __builtin_nondeterministic_value(q0.w);
-            if (two) q1 = sq[j + 1];
+            const float4 q0 = ld_off<float4>(sq, (unsigned)j * 16u);
+            const float4 q1 = ld_off<float4>(sq, (unsigned)(two ? j + 1 : j) * 16u);   // dead slot: the same candidate again (never recorded)
             if constexpr (PACKED) {
                 const f32x2 X = {q0.x, q1.x}, Y = {q0.y, q1.y}, Z = {q0.z, q1.z};
                 f32x2 A[4];
@@ -825,7 +833,7 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan_fma(const float *__
             j += 2;
         }
     }
-    if (nslow > 0 || hcnt > 4) {
+    if (amin <= F.twoEmax || hcnt > 4) {
         atomicAdd(&counters[gridDim.y * 4 + b * 4 + 1], 1);                   // statistics: tets re-scanned
         const int4 r = exact_rescan(tet + ((size_t)b * T + t) * 12, t, cb, sq, res, G, Gx, cx0, cx1, cy0, cy1, cz0, cz1, m,
                                     &counters[b * 4 + 2]);
@@ -2393,10 +2401,11 @@ static int pit_check(const float *tet, const float *pts, const float *cond, cons
     DEFTET_CHECK_ARG(B >= 0 && T >= 0 && Q >= 0, "negative size (B=%d T=%d Q=%d)", B, T, Q);
     DEFTET_CHECK_ARG(algo == DEFTET_PIT_AUTO || algo == DEFTET_PIT_BRUTE || algo == DEFTET_PIT_STAGED || algo == DEFTET_PIT_ROWS ||
                          algo == DEFTET_PIT_FMA || algo == DEFTET_PIT_FMA2 || algo == DEFTET_PIT_GRP2 || algo == DEFTET_PIT_GRP4 ||
-                         algo == DEFTET_PIT_GRP6 || algo == DEFTET_PIT_LDSB || algo == DEFTET_PIT_LDS,
+                         algo == DEFTET_PIT_GRP6 || algo == DEFTET_PIT_LDSB || algo == DEFTET_PIT_LDS || algo == DEFTET_PIT_EXACT,
                      "unknown algo %d", algo);
     if (T >= (1 << 24)) return set_error(DEFTET_ELIMIT, "n_tet=%d does not fit a float-encoded index (2^24)", T);
     DEFTET_CHECK_ARG(B <= 65535, "n_batch=%d exceeds the grid-y limit 65535", B);
+    if (Q >= (1 << 27)) return set_error(DEFTET_ELIMIT, "n_query=%d: 16-byte query records are addressed with 32-bit byte offsets (limit 2^27)", Q);
     if (B == 0 || Q == 0) return DEFTET_OK;
     DEFTET_CHECK_ARG(pts && cond, "null pts/cond pointer");
     DEFTET_CHECK_ARG(T == 0 || tet, "null tet pointer");
@@ -2435,7 +2444,7 @@ static int pit_scan(const Layout &L, const float *tet, const float *pts, float *
         if (algo == DEFTET_PIT_ROWS) {
             DEFTET_LAUNCH(k_tet_scan_rows, gt, blk, st, tet, T, Q, L.gparam, L.G, L.Gx, L.cells, L.cellStride, L.sortedQ, L.result,
                           L.counters, L.irregT, (int4 *)hit_buf, pts, L.irregQ, ucount);
-        } else if (algo == DEFTET_PIT_FMA) {
+        } else if (algo == DEFTET_PIT_FMA || algo == DEFTET_PIT_AUTO) {
             DEFTET_LAUNCH(k_tet_scan_fma<false>, gt, blk, st, tet, T, Q, L.gparam, L.G, L.Gx, L.cells, L.cellStride, L.sortedQ, L.result,
                           L.counters, L.irregT, (int4 *)hit_buf, pts, L.irregQ, ucount, (const int *)nullptr);
         } else if (algo == DEFTET_PIT_FMA2) {
@@ -2464,7 +2473,7 @@ static int pit_scan(const Layout &L, const float *tet, const float *pts, float *
             // the groups with a mesh-order jump inside (normally a few per cent, possibly none), one tet per lane
             DEFTET_LAUNCH(k_tet_scan_fma<false>, gt, blk, st, tet, T, Q, L.gparam, L.G, L.Gx, L.cells, L.cellStride, L.sortedQ, L.result,
                           L.counters, L.irregT, (int4 *)hit_buf, pts, L.irregQ, (int *)nullptr, (const int *)L.deferT);
-        } else if (algo != DEFTET_PIT_STAGED) {
+        } else if (algo == DEFTET_PIT_EXACT) {
             DEFTET_LAUNCH(k_tet_scan, gt, blk, st, tet, T, Q, L.gparam, L.G, L.Gx, L.cells, L.cellStride, L.sortedQ, L.result,
                           L.counters, L.irregT, (int4 *)hit_buf, pts, L.irregQ, ucount);
         } else {
@@ -2513,7 +2522,7 @@ extern "C" int deftet_point_in_tet_prepare_f32(const float *pts, int B, int T, i
                                                size_t workspace_bytes, void *stream_)
 {
     DEFTET_CHECK_ARG(B >= 0 && T >= 0 && Q >= 0 && B <= 65535, "bad size (B=%d T=%d Q=%d)", B, T, Q);
-    DEFTET_CHECK_ARG(algo != DEFTET_PIT_BRUTE && algo >= 0 && algo <= DEFTET_PIT_LDS, "prepare needs a binned algo (got %d)", algo);
+    DEFTET_CHECK_ARG(algo != DEFTET_PIT_BRUTE && algo >= 0 && algo <= DEFTET_PIT_EXACT, "prepare needs a binned algo (got %d)", algo);
     if (B == 0 || Q == 0) return DEFTET_OK;
     DEFTET_CHECK_ARG(pts, "null pts pointer");
     DEFTET_CHECK_ARG(workspace && ((uintptr_t)workspace & 255) == 0, "workspace null or not 256-byte aligned");

@@ -11,8 +11,8 @@ import torch
 
 from . import _lib
 
-PIT_AUTO, PIT_BRUTE, PIT_STAGED, PIT_ROWS, PIT_FMA, PIT_FMA2, PIT_GRP2, PIT_GRP4, PIT_GRP6, PIT_LDSB, PIT_LDS = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
-_PIT_KERNEL = {PIT_AUTO: "k_tet_scan", PIT_BRUTE: "k_brute", PIT_STAGED: "k_tet_scan_staged", PIT_ROWS: "k_tet_scan_rows",
+PIT_AUTO, PIT_BRUTE, PIT_STAGED, PIT_ROWS, PIT_FMA, PIT_FMA2, PIT_GRP2, PIT_GRP4, PIT_GRP6, PIT_LDSB, PIT_LDS, PIT_EXACT = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
+_PIT_KERNEL = {PIT_AUTO: "k_tet_scan_fma<false>", PIT_EXACT: "k_tet_scan", PIT_BRUTE: "k_brute", PIT_STAGED: "k_tet_scan_staged", PIT_ROWS: "k_tet_scan_rows",
                PIT_FMA: "k_tet_scan_fma<false>", PIT_FMA2: "k_tet_scan_fma<true>", PIT_GRP2: "k_tet_scan_grp<1>",
                PIT_GRP4: "k_tet_scan_grp<2>", PIT_GRP6: "k_tet_scan_grp<3>", PIT_LDSB: "k_tet_scan_lds<false>",
                PIT_LDS: "k_tet_scan_lds<true>"}

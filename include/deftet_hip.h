@@ -34,7 +34,7 @@ extern "C" {
 #define DEFTET_ELIMIT (-4)   /* size exceeds what the float-encoded index outputs can represent (2^24) */
 
 /* point-in-tet algorithm selector */
-#define DEFTET_PIT_AUTO 0    /* uniform-grid binned, tet-centric (default) */
+#define DEFTET_PIT_AUTO 0    /* uniform-grid binned, tet-centric, certified fused plane filter (default = DEFTET_PIT_FMA) */
 #define DEFTET_PIT_BRUTE 1   /* LDS/scalar-tiled brute force: the algorithmic equivalent of the reference kernel */
 #define DEFTET_PIT_STAGED 2  /* binned, with wave-cooperative LDS staging of the cell rows (coherent tet orders) */
 #define DEFTET_PIT_ROWS 3    /* binned, (tet,row) pairs balanced across the lanes of a wave through LDS */
@@ -45,6 +45,7 @@ extern "C" {
 #define DEFTET_PIT_GRP6 8    /* same, 6 consecutive tets per lane */
 #define DEFTET_PIT_LDSB 9    /* fused filter, the workgroup's cell starts staged in LDS */
 #define DEFTET_PIT_LDS 10    /* fused filter, the workgroup's cell starts AND candidate queries staged in LDS */
+#define DEFTET_PIT_EXACT 11  /* binned, box test + exact predicate on every candidate (the round-1 default, k_tet_scan) */
 
 int deftet_version(void);
 const char *deftet_last_error(void);

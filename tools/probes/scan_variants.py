@@ -64,7 +64,7 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--sweep", action="store_true")
     ap.add_argument("--mesh", default=None, help="cube40: the shipped QuarTet grid (res 40 sizes) instead of the Kuhn grid")
-    ap.add_argument("--algos", default="0,4,6,9,10")
+    ap.add_argument("--algos", default="0,11,6,9,10")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = _lib.load()
