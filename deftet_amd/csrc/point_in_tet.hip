@@ -45,6 +45,18 @@ constexpr int kHitOverflow = -2;            // hits[.].w: this tet has accepted 
 constexpr int kHitPad = 64;
 __host__ __device__ inline size_t hit_cnt_off(int B, int T) { return (size_t)B * T * 4; }
 __host__ __device__ inline size_t hit_list_off(int B, int T) { return (size_t)B * T * 4 + (size_t)((B + kHitPad - 1) / kHitPad) * kHitPad; }
+// Tets whose hit record overflowed (> 4 accepted queries; ~1e-4 of the tets at BASELINE configs[2]) are also LISTED, so
+// that k_finalize can tell "this hit is not in its tet's record" from a short wave-uniform list instead of gathering the
+// winning tet's 16-byte record for every query of the shape.  The list lives behind the counter block:
+//   counters[0, 4B) counters | [4B, 8B) statistics ([.][2] = number of overflowed tets) | [8B, 8B + B*kOvfCap) the lists.
+constexpr int kOvfCap = 128;
+__device__ __forceinline__ void note_overflow(int *counters, int nB, int b, int t)
+{
+    counters[b * 4 + 2] = 1;                                           // some record overflowed (benign race: all write 1)
+    const int k = atomicAdd(&counters[nB * 4 + b * 4 + 2], 1);
+    if (k < kOvfCap) counters[nB * 8 + b * kOvfCap + k] = t;
+}
+
 #ifndef PIT_XFINE
 #define PIT_XFINE 6
 #endif
@@ -552,7 +564,7 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan(const float *__rest
     if (hits) {
         if (hcnt > 4) {
             hrec.w = kHitOverflow;
-            counters[b * 4 + 2] = 1;                               // some record overflowed (benign race: all write 1)
+            note_overflow(counters, gridDim.y, b, t);
         }
         hits[(size_t)b * T + t] = hrec;
     }
@@ -609,7 +621,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // accepted query with atomicMin (idempotent w.r.t. the ones the filter already accepted) and returns the hit record.
 __device__ __noinline__ int4 exact_rescan(const float *__restrict__ tv, int t, const int *__restrict__ cb, const float4 *__restrict__ sq,
                                           int *res, int G, int Gx, int cx0, int cx1, int cy0, int cy1, int cz0, int cz1,
-                                          float m, int *overflowFlag)
+                                          float m, int *counters, int nB, int b)
 {
     float vv[12];
 #pragma unroll
@@ -644,7 +656,7 @@ __device__ __noinline__ int4 exact_rescan(const float *__restrict__ tv, int t, c
         }
     if (hcnt > 4) {
         hrec.w = kHitOverflow;
-        *overflowFlag = 1;
+        note_overflow(counters, nB, b, t);
     }
     return hrec;
 }
@@ -836,7 +848,7 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan_fma(const float *__
     if (amin <= F.twoEmax || hcnt > 4) {
         atomicAdd(&counters[gridDim.y * 4 + b * 4 + 1], 1);                   // statistics: tets re-scanned
         const int4 r = exact_rescan(tet + ((size_t)b * T + t) * 12, t, cb, sq, res, G, Gx, cx0, cx1, cy0, cy1, cz0, cz1, m,
-                                    &counters[b * 4 + 2]);
+                                    counters, gridDim.y, b);
         if (hits) hits[(size_t)b * T + t] = r;
     } else {
         if (hcnt > 0) atomicMin(&res[h0], t);
@@ -974,7 +986,7 @@ __device__ __noinline__ void exact_rescan_tet(const float *__restrict__ tet, int
     const int cx0 = cell_of(lo[0] - m, g.o[0], g.inv[0], Gx), cx1 = cell_of(hi[0] + m, g.o[0], g.inv[0], Gx);
     const int cy0 = cell_of(lo[1] - m, g.o[1], g.inv[1], G), cy1 = cell_of(hi[1] + m, g.o[1], g.inv[1], G);
     const int cz0 = cell_of(lo[2] - m, g.o[2], g.inv[2], G), cz1 = cell_of(hi[2] + m, g.o[2], g.inv[2], G);
-    const int4 r = exact_rescan(tv, t, cb, sq, res, G, Gx, cx0, cx1, cy0, cy1, cz0, cz1, m, &counters[b * 4 + 2]);
+    const int4 r = exact_rescan(tv, t, cb, sq, res, G, Gx, cx0, cx1, cy0, cy1, cz0, cz1, m, counters, gridDim.y, b);
     if (hits) hits[(size_t)b * T + t] = r;
 }
 
@@ -1151,7 +1163,7 @@ __global__ __launch_bounds__(256, NP == 1 ? 5 : (NP == 2 ? 4 : 3)) void k_tet_sc
                     }
                     if (c > 4) {
                         r3 = kHitOverflow;
-                        counters[b * 4 + 2] = 1;
+                        note_overflow(counters, gridDim.y, b, t0 + k);
                     }
                     hits[(size_t)b * T + t0 + k] = make_int4(r0, r1, r2, r3);
                 }
@@ -1422,7 +1434,7 @@ __global__ __launch_bounds__(256, 5) void k_tet_scan_lds(const float *__restrict
         if (nslow > 0 || hcnt > 4) {
             atomicAdd(&counters[gridDim.y * 4 + b * 4 + 1], 1);               // statistics: tets re-scanned
             const int4 r = exact_rescan(tet + ((size_t)b * T + t) * 12, t, cb, sq, res, G, Gx, cx0, cx1, cy0, cy1, cz0, cz1, m,
-                                        &counters[b * 4 + 2]);
+                                        counters, gridDim.y, b);
             if (hits) hits[(size_t)b * T + t] = r;
         } else {
             if (hcnt > 0) atomicMin(&res[h0], t);
@@ -1626,7 +1638,7 @@ __global__ __launch_bounds__(256, PIT_STAGE_WAVES) void k_tet_scan_staged(const 
     if (hits && intet) {
         if (hcnt > 4) {
             hrec.w = kHitOverflow;
-            counters[b * 4 + 2] = 1;
+            note_overflow(counters, gridDim.y, b, t);
         }
         hits[(size_t)b * T + t] = hrec;
     }
@@ -1789,7 +1801,7 @@ __global__ __launch_bounds__(256, 4) void k_tet_scan_rows(const float *__restric
         if (irregularTet) hrec = make_int4(-1, -1, -1, kHitOverflow);          // accepted by k_finalize, not recorded
         if (hcnt > 4) {
             hrec.w = kHitOverflow;
-            counters[b * 4 + 2] = 1;
+            note_overflow(counters, gridDim.y, b, t);
         }
         hits[(size_t)b * T + t] = hrec;
     }
@@ -1853,8 +1865,18 @@ __global__ __launch_bounds__(256) void k_finalize(const float *__restrict__ tet,
         const float *pq = pts + i * 3;
         // records are complete unless some tet is irregular or overflowed (wave-uniform test: the
         // per-hit gather of the record is skipped for ordinary meshes)
-        const bool suspect = counters && (counters[b * 4 + 0] > 0 || counters[b * 4 + 2] > 0);
-        const bool covered = query_regular(pq[0], pq[1], pq[2]) && (!suspect || hits[(size_t)b * T + r].w != kHitOverflow);
+        bool covered = query_regular(pq[0], pq[1], pq[2]);
+        if (counters) {
+            const int nB = gridDim.y, nOvf = counters[nB * 4 + b * 4 + 2];
+            if (counters[b * 4 + 0] > 0 || nOvf > kOvfCap) {
+                // irregular tets exist, or more overflowed tets than the list holds: read the winning tet's record
+                covered = covered && hits[(size_t)b * T + r].w != kHitOverflow;
+            } else {
+                // the usual case: a handful of overflowed tets per shape, listed; wave-uniform scalar reads, no gather
+                const int *ovf = counters + nB * 8 + b * kOvfCap;
+                for (int k = 0; k < nOvf; ++k) covered = covered && ovf[k] != r;
+            }
+        }
         if (!covered) ulist[(size_t)b * Q + atomicAdd(&ucount[b], 1)] = q;
     }
     if (!bary) return;
@@ -2357,7 +2379,7 @@ static Layout make_layout(int B, int T, int Q, int algo, void *ws, size_t wsByte
         if (L.nRowBlk < 1) L.nRowBlk = 1;
         L.chunkQ = ((Q + L.nRowBlk - 1) / L.nRowBlk + 255) / 256 * 256;
         L.bboxPart = A.take<float>((size_t)B * kBoxBlocks * 6);
-        L.counters = A.take<int>((size_t)B * 8);              // 4 counters + 4 statistics words per shape
+        L.counters = A.take<int>((size_t)B * (8 + kOvfCap));  // 4 counters + 4 statistics words per shape, then the overflowed-tet lists
         L.gparam = A.take<float>((size_t)B * 12);
         L.cells = A.take<int>((size_t)B * L.cellStride);
         L.blockHist = A.take<int>((size_t)B * L.nRowBlk * R);
