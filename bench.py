@@ -329,6 +329,7 @@ def main():
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--no-bandwidth-probe", action="store_true", help="skip the 1 GiB copy/read probe (profiling runs: keeps its launches out of the kernel table)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -370,7 +371,7 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
-        peak = measure_bandwidth(device) if world == 1 else None
+        peak = measure_bandwidth(device) if (world == 1 and not args.no_bandwidth_probe) else None
         main_line = summarize(wl, elapsed, per_step, kms, kcnt, args.steps, world, peak)
         line = {
             "metric": ("M tet-point tests/s (fwd+bwd) at res=70, 100k queries" if args.config == 2 else

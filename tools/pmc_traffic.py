@@ -2,9 +2,9 @@
 
     cd /tmp && export TMPDIR=/tmp
     rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $R/gpurun_out/pmc_fetch -o f --output-format csv -- \
-        python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline
+        python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs --no-bandwidth-probe
     rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $R/gpurun_out/pmc_write -o w --output-format csv -- \
-        python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline
+        python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-other-configs --no-bandwidth-probe
     python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write > profiles/pmc_traffic.json
 
 Corrections per /opt/skills/guides/MI355X_MICROARCH.md (HBM / rocprofv3 section): both counters are in
