@@ -606,6 +606,23 @@ struct Filter {
     float twoEmax;
 };
 
+// Select with the lane mask in an SGPR pair (VOP3 v_cndmask_b32_e64).  hipcc likes to shrink selects whose mask sits in
+// VCC to the VOP2 form `v_cndmask_b32_e32 …, vcc`, which gfx950 issues ~7.5x slower than an FMA (9.4 vs 1.25 ns per
+// wave-instruction per SIMD, tools/probes/valu_rate_probe.hip; the SGPR-pair form: 1.85 ns).  The traversal loops carry
+// ten selects per iteration, so the form matters more than the count.
+typedef unsigned long long lanemask_t;
+__device__ __forceinline__ int sel(lanemask_t m, int if_set, int if_clear)
+{
+    int d;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(d) : "v"(if_clear), "v"(if_set), "s"(m));
+    return d;
+}
+__device__ __forceinline__ unsigned sel(lanemask_t m, unsigned if_set, unsigned if_clear)
+{
+    return (unsigned)sel(m, (int)if_set, (int)if_clear);
+}
+__device__ __forceinline__ lanemask_t mask_of(bool c) { return __builtin_amdgcn_ballot_w64(c); }
+
 // load at a 32-bit unsigned BYTE offset from a (wave-uniform) base pointer: scalar-base + vector-offset addressing
 template <typename T>
 __device__ __forceinline__ T ld_off(const void *base, unsigned byte_off)
@@ -776,13 +793,13 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan_fma(const float *__
     int h0 = -1, h1 = -1, h2 = -1, h3 = -1;
     float amin = INFINITY;                                             // smallest |filter value| met: <= 2 Emax <=> the undecided band was touched
     auto decide = [&](float a, int qi, bool live) {
-        const bool acc = live && a > 0.f;
+        const lanemask_t acc = mask_of(live && a > 0.f);
         amin = fminf(amin, fabsf(a));                                  // a dead second slot repeats the first candidate: no mask needed
-        h3 = acc ? h2 : h3;
-        h2 = acc ? h1 : h2;
-        h1 = acc ? h0 : h1;
-        h0 = acc ? qi : h0;
-        hcnt += acc ? 1 : 0;
+        h3 = sel(acc, h2, h3);
+        h2 = sel(acc, h1, h2);
+        h1 = sel(acc, h0, h1);
+        h0 = sel(acc, qi, h0);
+        hcnt += sel(acc, 1, 0);
     };
     // per-lane cursor over (row, position), see k_tet_scan_grp: every wave-iteration each lane takes ITS next two candidates.
     // All addresses are 32-bit BYTE offsets from wave-uniform bases (scalar base + vector offset addressing: no 64-bit
@@ -799,10 +816,10 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan_fma(const float *__
         if (j >= e) {                                                   // enter the prefetched row, prefetch the one after it
             j = s2;
             e = e2;
-            const bool wrap = cy == cy1;
-            cy = wrap ? cy0 : cy + 1;
-            cz += wrap ? 1 : 0;
-            rowB += wrap ? rowWrapB : rowStepB;
+            const lanemask_t wrap = mask_of(cy == cy1);
+            cy = sel(wrap, cy0, cy + 1);
+            cz += sel(wrap, 1, 0);
+            rowB += sel(wrap, rowWrapB, rowStepB);
             haveNext = cz <= cz1;
             if (haveNext) {
                 s2 = ld_off<int>(cb, rowB + x0B);
@@ -812,7 +829,7 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan_fma(const float *__
         if (j < e) {
             const bool two = j + 1 < e;
             const float4 q0 = ld_off<float4>(sq, (unsigned)j * 16u);
-            const float4 q1 = ld_off<float4>(sq, (unsigned)(two ? j + 1 : j) * 16u);   // dead slot: the same candidate again (never recorded)
+            const float4 q1 = ld_off<float4>(sq, (unsigned)sel(mask_of(two), j + 1, j) * 16u);   // dead slot: the same candidate again (never recorded)
             if constexpr (PACKED) {
                 const f32x2 X = {q0.x, q1.x}, Y = {q0.y, q1.y}, Z = {q0.z, q1.z};
                 f32x2 A[4];
