@@ -22,6 +22,7 @@
 
 #include <stdlib.h>
 
+#include <type_traits>
 #include <vector>
 
 #include "common.hpp"
@@ -1376,18 +1377,21 @@ __global__ __launch_bounds__(256, 5) void k_tet_scan_lds(const float *__restrict
             }
         }
     }
-    // ---- traversal (per-lane cursor, see k_tet_scan_grp), operands from LDS where staged
-    int hcnt = 0, nslow = 0;
+    // ---- traversal (per-lane cursor, see k_tet_scan_grp), operands from LDS where staged.  Three specialisations of
+    //      one loop (MODE 0: bounds and queries from global memory; 1: bounds from LDS; 2: both from LDS), picked by a
+    //      workgroup-uniform branch OUTSIDE the loop.  Row positions advance by additions; selects use SGPR-pair masks.
+    int hcnt = 0;
     int h0 = -1, h1 = -1, h2 = -1, h3 = -1;
+    float amin = INFINITY;
     if (active) {
         auto decide = [&](float a, int qi, bool lv) {
-            const bool acc = lv && a > 0.f;
-            nslow += (lv && !acc && a >= -F.twoEmax) ? 1 : 0;
-            h3 = acc ? h2 : h3;
-            h2 = acc ? h1 : h2;
-            h1 = acc ? h0 : h1;
-            h0 = acc ? qi : h0;
-            hcnt += acc ? 1 : 0;
+            const lanemask_t acc = mask_of(lv && a > 0.f);
+            amin = fminf(amin, fabsf(a));                              // a dead second slot repeats the first candidate
+            h3 = sel(acc, h2, h3);
+            h2 = sel(acc, h1, h2);
+            h1 = sel(acc, h0, h1);
+            h0 = sel(acc, qi, h0);
+            hcnt += sel(acc, 1, 0);
         };
         auto filter = [&](const float4 &q) {
             float A[4];
@@ -1395,64 +1399,82 @@ __global__ __launch_bounds__(256, 5) void k_tet_scan_lds(const float *__restrict
             for (int i = 0; i < 4; ++i) A[i] = fmaf(F.N[i][0], q.x, fmaf(F.N[i][1], q.y, fmaf(F.N[i][2], q.z, F.C[i])));
             return fminf(fminf(A[0], A[1]), fminf(A[2], A[3]));
         };
-        const int bx0 = cx0 - ux0, bx1 = cx1 + 1 - ux0;               // positions of this lane's two bounds inside a staged row
-        int cy = cy0, cz = cz0;                                         // the row whose bounds sit in (s2, e2)
-        int j = 0, e = 0, d = 0, d2 = 0;
-        int s2, e2;
-        if (stB) {
-            const int r = (cz - uz0) * ny + (cy - uy0);
-            s2 = s_cb[r * nx1 + bx0];
-            e2 = s_cb[r * nx1 + bx1];
-            if (stQ) d2 = s_delta[r];
-        } else {
-            s2 = cb[(cz * G + cy) * Gx + cx0];
-            e2 = cb[(cz * G + cy) * Gx + cx1 + 1];
-        }
-        bool haveNext = true;
-        while (j < e || haveNext) {
-            if (j >= e) {                                               // enter the prefetched row, prefetch the one after it
-                j = s2;
-                e = e2;
-                d = d2;
-                ++cy;
-                if (cy > cy1) { cy = cy0; ++cz; }
-                haveNext = cz <= cz1;
-                if (haveNext) {
-                    if (stB) {
-                        const int r = (cz - uz0) * ny + (cy - uy0);
-                        s2 = s_cb[r * nx1 + bx0];
-                        e2 = s_cb[r * nx1 + bx1];
-                        if (stQ) d2 = s_delta[r];
+        auto traverse = [&](auto modeTag) {
+            constexpr int MODE = decltype(modeTag)::value;
+            // global addressing (MODE 0): byte offsets from the scalar base, as in k_tet_scan_fma
+            const unsigned rowStepB = (unsigned)Gx * 4u, rowWrapB = (unsigned)((G - (cy1 - cy0)) * Gx) * 4u;
+            const unsigned x0B = (unsigned)cx0 * 4u, x1B = (unsigned)(cx1 + 1) * 4u;
+            unsigned rowB = (unsigned)((cz0 * G + cy0) * Gx) * 4u;
+            // LDS addressing (MODE 1, 2): staged row r = (cz - uz0) * ny + (cy - uy0); its starts sit at s_cb[r * nx1 ...]
+            const int rStep = 1, rWrap = ny - (cy1 - cy0);
+            int r = (cz0 - uz0) * ny + (cy0 - uy0);
+            int rb0 = r * nx1 + (cx0 - ux0), rb1 = r * nx1 + (cx1 + 1 - ux0);          // positions of this lane's two bounds
+            const int rbStep = nx1, rbWrap = rWrap * nx1;
+            int cy = cy0, cz = cz0;                                     // the row whose bounds sit in (s2, e2)
+            int j = 0, e = 0, d = 0, d2 = 0;
+            int s2, e2;
+            if (MODE == 0) {
+                s2 = ld_off<int>(cb, rowB + x0B);
+                e2 = ld_off<int>(cb, rowB + x1B);
+            } else {
+                s2 = s_cb[rb0];
+                e2 = s_cb[rb1];
+                if (MODE == 2) d2 = s_delta[r];
+            }
+            bool haveNext = true;
+            while (j < e || haveNext) {
+                if (j >= e) {                                           // enter the prefetched row, prefetch the one after it
+                    j = s2;
+                    e = e2;
+                    d = d2;
+                    const lanemask_t wrap = mask_of(cy == cy1);
+                    cy = sel(wrap, cy0, cy + 1);
+                    cz += sel(wrap, 1, 0);
+                    haveNext = cz <= cz1;
+                    if (MODE == 0) {
+                        rowB += sel(wrap, rowWrapB, rowStepB);
+                        if (haveNext) {
+                            s2 = ld_off<int>(cb, rowB + x0B);
+                            e2 = ld_off<int>(cb, rowB + x1B);
+                        }
                     } else {
-                        const int row2 = (cz * G + cy) * Gx;
-                        s2 = cb[row2 + cx0];
-                        e2 = cb[row2 + cx1 + 1];
+                        const int inc = sel(wrap, rbWrap, rbStep);
+                        rb0 += inc;
+                        rb1 += inc;
+                        if (MODE == 2) r += sel(wrap, rWrap, rStep);
+                        if (haveNext) {
+                            s2 = s_cb[rb0];
+                            e2 = s_cb[rb1];
+                            if (MODE == 2) d2 = s_delta[r];
+                        }
                     }
                 }
-            }
-            if (j < e) {
-                const bool two = j + 1 < e;
-                float4 q0, q1;
-                if (stQ) {
-                    q0 = s_q[j + d];
-                    q1 = s_q[two ? j + d + 1 : j + d];
-                } else {
-                    q0 = sq[j];
-                    q1.x = __builtin_nondeterministic_value(q0.x); q1.y = __builtin_nondeterministic_value(q0.y);
-                    q1.z = __builtin_nondeterministic_value(q0.z); q1.w = __builtin_nondeterministic_value(q0.w);
-                    if (two) q1 = sq[j + 1];
+                if (j < e) {
+                    const bool two = j + 1 < e;
+                    const int j1 = sel(mask_of(two), j + 1, j);         // dead slot: the same candidate again (never recorded)
+                    float4 q0, q1;
+                    if (MODE == 2) {
+                        q0 = s_q[j + d];
+                        q1 = s_q[j1 + d];
+                    } else {
+                        q0 = ld_off<float4>(sq, (unsigned)j * 16u);
+                        q1 = ld_off<float4>(sq, (unsigned)j1 * 16u);
+                    }
+                    const float a0 = filter(q0), a1 = filter(q1);
+                    decide(a0, __float_as_int(q0.w), true);
+                    decide(a1, __float_as_int(q1.w), two);
+                    j += 2;
                 }
-                const float a0 = filter(q0), a1 = filter(q1);
-                decide(a0, __float_as_int(q0.w), true);
-                decide(a1, __float_as_int(q1.w), two);
-                j += 2;
             }
-        }
-        if (nslow > 0 || hcnt > 4) {
+        };
+        if (stQ) traverse(std::integral_constant<int, 2>{});
+        else if (stB) traverse(std::integral_constant<int, 1>{});
+        else traverse(std::integral_constant<int, 0>{});
+        if (amin <= F.twoEmax || hcnt > 4) {
             atomicAdd(&counters[gridDim.y * 4 + b * 4 + 1], 1);               // statistics: tets re-scanned
-            const int4 r = exact_rescan(tet + ((size_t)b * T + t) * 12, t, cb, sq, res, G, Gx, cx0, cx1, cy0, cy1, cz0, cz1, m,
-                                        counters, gridDim.y, b);
-            if (hits) hits[(size_t)b * T + t] = r;
+            const int4 r4 = exact_rescan(tet + ((size_t)b * T + t) * 12, t, cb, sq, res, G, Gx, cx0, cx1, cy0, cy1, cz0, cz1, m,
+                                         counters, gridDim.y, b);
+            if (hits) hits[(size_t)b * T + t] = r4;
         } else {
             if (hcnt > 0) atomicMin(&res[h0], t);
             if (hcnt > 1) atomicMin(&res[h1], t);
