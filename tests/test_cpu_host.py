@@ -310,3 +310,27 @@ def test_unchanged_reference_modules_import_through_the_overlay():
         sys.path[:] = saved_path
         _clean_overlay_names()
         sys.modules.update({k: v for k, v in saved.items() if k not in sys.modules})
+
+
+def test_bench_self_launch_command(monkeypatch):
+    """`python bench.py --gpus N` with no torch.distributed environment must become the launcher the driver would
+    otherwise be: torch.distributed.run, one node, N ranks, loopback rendezvous, the original arguments passed on."""
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 0
+
+    monkeypatch.setattr(bench.subprocess, "call", fake_call)
+    monkeypatch.setattr(bench.sys, "argv", ["bench.py", "--gpus", "4", "--steps", "7", "--warmup", "2"])
+    args = type("A", (), {"gpus": 4})()
+    assert bench.self_launch(args) == 0
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # every BASELINE configuration has a workload definition
+    assert sorted(bench.CONFIGS) == [1, 2, 3, 4] and bench.CONFIGS[2]["res"] == 70 and bench.CONFIGS[2]["n_query"] == 100_000
