@@ -26,6 +26,9 @@ What is pinned:
                        has its smallest weight within +-MARGIN (face/edge/vertex contacts, where the fp32
                        sign tests of check_condition_tet_for.cu:105-189 may legitimately go either way).
   cube40_grid.npz      the shipped diff_render/diftet_6_subdiv/data/cube_40_tet.tet re-encoded (data fixture).
+  n4_read_tetrahedron.npz  utils/dataloder_helper.py:30-69 read_tetrahedron(res=40) run on the shipped cube_40_tet.tet
+                       (copied to <tmp>/quartet/meshes/cube_0.025000_tet.tet, so that the QuarTet binary is not needed):
+                       sha256 of the returned vertices (after boundary snapping), tets and interior mask + a few raw rows.
   n3_rebuilds.npz      diff_render/diftet_6_subdiv/3_model/prepare_for_wz.py: generate_edge (:184-203),
                        generate_tet_edge_idx (:223-236), generate_subdivision (:255-301, with and
                        without a split mask), generate_point_adj_idx (:134-146), delete_tet
@@ -210,9 +213,26 @@ def main():
                         shapes=np.array([full40[k].shape[0] for k in sorted(full40)], np.int64),
                         keys=np.array(sorted(full40)))
 
+
+    # ---------------- N4: the reference's .tet reader on the shipped grid
+    sys.path.insert(0, REF)
+    from utils import dataloder_helper as DH
+    root = tempfile.mkdtemp(prefix="deftet_n4_")
+    os.makedirs(os.path.join(root, "quartet", "meshes"))
+    shutil.copy(os.path.join(REF, "diff_render/diftet_6_subdiv/data/cube_40_tet.tet"),
+                os.path.join(root, "quartet", "meshes", "cube_%f_tet.tet" % (1.0 / 40)))
+    rv, rt, rm = DH.read_tetrahedron(res=40, root=root)
+    np.savez_compressed(os.path.join(HERE, "n4_read_tetrahedron.npz"),
+                        verts_sha=np.frombuffer(bytes.fromhex(sha(rv.astype(np.float64))), np.uint8),
+                        tets_sha=np.frombuffer(bytes.fromhex(sha(rt.astype(np.int64))), np.uint8),
+                        mask_sha=np.frombuffer(bytes.fromhex(sha(rm.astype(np.uint8))), np.uint8),
+                        shape=np.array([rv.shape[0], rt.shape[0]], np.int64), n_interior=np.int64(rm.sum()),
+                        n_snapped_to_0=np.int64((rv == 0).sum()), n_snapped_to_1=np.int64((rv == 1).sum()),
+                        first_rows=rv[:16].astype(np.float64), res=np.float64(1.0 / 40))
+
     # ---------------- A1 index pin (reference barycentrics on every pair)
     pit_index_fixtures(tu, torch)
-    if os.environ.get("GEN_GOLDEN_ONLY") == "pit":
+    if os.environ.get("GEN_GOLDEN_ONLY") in ("pit", "n4"):
         return
 
     # ---------------- barycentric weights + autograd gradients (A1b oracle)

@@ -199,6 +199,32 @@ def test_read_tetrahedron_mirror(tmp_path):
         read_tetrahedron(res=10, root=root, generate_missing=False)
 
 
+def test_read_tetrahedron_vs_reference_outputs_on_shipped_grid(tmp_path):
+    """N4 pin: what the reference's read_tetrahedron (utils/dataloder_helper.py:30-69) returned for the shipped
+    cube_40_tet.tet (tests/golden/n4_read_tetrahedron.npz, written by gen_golden.py) == what the mirror returns for
+    the same grid written in the same text format."""
+    import hashlib
+    from deftet_amd import grids
+    from deftet_amd.utils.dataloder_helper import read_tetrahedron, tet_file_name
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "n4_read_tetrahedron.npz"))
+    g40 = np.load(os.path.join(os.path.dirname(__file__), "golden", "cube40_grid.npz"))
+    fn, res = tet_file_name(40, str(tmp_path))
+    assert res == float(gold["res"])
+    os.makedirs(os.path.dirname(fn))
+    with open(fn, "w") as f:                                       # 17 significant digits: the float64 values survive the text format
+        f.write("tet %d %d\n" % (g40["verts"].shape[0], g40["tets"].shape[0]))
+        np.savetxt(f, g40["verts"], fmt="%.17g")
+        np.savetxt(f, g40["tets"], fmt="%d")
+    v, t, mask = read_tetrahedron(res=40, root=str(tmp_path), generate_missing=False)
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest()
+    assert list(gold["shape"]) == [v.shape[0], t.shape[0]]
+    assert sha(v.astype(np.float64)) == gold["verts_sha"].tobytes()
+    assert sha(t.astype(np.int64)) == gold["tets_sha"].tobytes()
+    assert sha(mask.astype(np.uint8)) == gold["mask_sha"].tobytes()
+    assert int(mask.sum()) == int(gold["n_interior"]) and int((v == 0).sum()) == int(gold["n_snapped_to_0"])
+    assert np.array_equal(v[:16], gold["first_rows"])
+
+
 def test_integration_overlay_names_exist():
     """every module of the overlay imports on a CPU-only host and exports the
     reference's names (the operators themselves refuse to run without a GPU)."""
