@@ -29,6 +29,10 @@ What is pinned:
   n4_read_tetrahedron.npz  utils/dataloder_helper.py:30-69 read_tetrahedron(res=40) run on the shipped cube_40_tet.tet
                        (copied to <tmp>/quartet/meshes/cube_0.025000_tet.tet, so that the QuarTet binary is not needed):
                        sha256 of the returned vertices (after boundary snapping), tets and interior mask + a few raw rows.
+  surface_glue.npz     utils/mesh_utils.py get_normal (:42-52), get_surface_normal_loss (:16-39) and point_point_distance
+                       (:360-366) run on CPU with the two CUDA operators they call replaced by index tables computed
+                       beforehand (edge-adjacent face pairs, nearest-neighbour indices): pins the glue arithmetic that
+                       deftet_amd/surface_losses.py re-implements.
   n3_rebuilds.npz      diff_render/diftet_6_subdiv/3_model/prepare_for_wz.py: generate_edge (:184-203),
                        generate_tet_edge_idx (:223-236), generate_subdivision (:255-301, with and
                        without a split mask), generate_point_adj_idx (:134-146), delete_tet
@@ -230,9 +234,56 @@ def main():
                         n_snapped_to_0=np.int64((rv == 0).sum()), n_snapped_to_1=np.int64((rv == 1).sum()),
                         first_rows=rv[:16].astype(np.float64), res=np.float64(1.0 / 40))
 
+    # ---------------- surface-loss glue of utils/mesh_utils.py (CUDA operators stubbed by precomputed index tables)
+    from oracle import oracle as ORC
+    verts16, tets16 = grids.kuhn_grid(8)
+    pos16 = grids.jittered_positions(verts16, 8, 1)
+    f3o, t2o, _, _, _ = ORC.tet_to_face(tets16, verts16.shape[0])
+    occ16 = np.linalg.norm(pos16[0][tets16].mean(1), axis=1) < 0.3
+    o2 = occ16[t2o]
+    selb = o2.sum(1) == 1
+    bnd = f3o[selb].copy()
+    bnd[o2[selb][:, 0]] = bnd[o2[selb][:, 0]][:, ::-1]
+    tri = pos16[0][bnd]                                                     # [F,3,3] float32
+    tab = ORC.face_edge_adj(tri)
+    fi, ki = np.nonzero(tab >= 0)
+    pairs = np.stack([fi, tab[fi, ki].astype(np.int64)])
+    rng_s = np.random.default_rng(21)
+    src = rng_s.uniform(-0.35, 0.35, (1, 500, 3)).astype(np.float32)
+    dst = rng_s.uniform(-0.35, 0.35, (1, 700, 3)).astype(np.float32)
+    nn = ((src[0][:, None, :].astype(np.float64) - dst[0][None].astype(np.float64)) ** 2).sum(-1).argmin(1)
+    stub_names = ("layers.DefTet.tet_face_adj_m_idx.utils", "layers.nearest_neighbor", "layers.DefTet.tet_analytic_distance_batch.utils")
+    saved = {k: sys.modules.get(k) for k in stub_names}
+    m1 = types.ModuleType(stub_names[0]); m1.tet_face_adj_m_f_idx = lambda face: torch.from_numpy(pairs)
+    m2 = types.ModuleType(stub_names[1])
+
+    class _NN:
+        def __call__(self, a, b):
+            return torch.from_numpy(nn)[None]
+    m2.NearestNeighbor = _NN
+    m3 = types.ModuleType(stub_names[2]); m3.tet_analytic_distance_f_batch = None
+    sys.modules.update({stub_names[0]: m1, stub_names[1]: m2, stub_names[2]: m3})
+    sys.modules.pop("utils.mesh_utils", None)
+    sys.path.insert(0, REF)
+    from utils import mesh_utils as MU
+    vt = torch.from_numpy(pos16)
+    ft = torch.from_numpy(bnd)[None]
+    tri_t = torch.from_numpy(tri)
+    normals = MU.get_normal(tri_t[:, 0], tri_t[:, 1], tri_t[:, 2])
+    nloss = MU.get_surface_normal_loss(vt, ft)
+    ppd = MU.point_point_distance(torch.from_numpy(src), torch.from_numpy(dst))
+    np.savez_compressed(os.path.join(HERE, "surface_glue.npz"), verts=pos16, faces=bnd, pairs=pairs, normals=normals.numpy(),
+                        normal_loss=nloss.numpy(), src=src, dst=dst, nn=nn, point_point_distance=ppd.numpy())
+    for k, v in saved.items():
+        if v is None:
+            sys.modules.pop(k, None)
+        else:
+            sys.modules[k] = v
+    sys.modules.pop("utils.mesh_utils", None)
+
     # ---------------- A1 index pin (reference barycentrics on every pair)
     pit_index_fixtures(tu, torch)
-    if os.environ.get("GEN_GOLDEN_ONLY") in ("pit", "n4"):
+    if os.environ.get("GEN_GOLDEN_ONLY") in ("pit", "n4", "glue"):
         return
 
     # ---------------- barycentric weights + autograd gradients (A1b oracle)

@@ -183,6 +183,25 @@ def test_neighbour_tables_oracle_matches_reference_outputs(oracle, name):
     assert np.array_equal(owners, gold["face_withtet_4tx2"])
 
 
+def test_surface_glue_normals_match_reference_mesh_utils():
+    """deftet_amd/surface_losses.py corners / unit_normals (pure torch) == the reference's get_normal
+    (utils/mesh_utils.py:42-52) on the boundary faces of a jittered grid (tests/golden/surface_glue.npz)."""
+    import torch
+    from deftet_amd import surface_losses as SL
+    g = load("surface_glue.npz")
+    v = torch.from_numpy(g["verts"])
+    f = torch.from_numpy(g["faces"])[None]
+    tri = SL.corners(v, f)
+    assert torch.equal(tri[0], v[0][f[0]])
+    n = SL.unit_normals(tri)[0].numpy()
+    assert np.abs(n - g["normals"]).max() <= 1e-6
+    # the loss value itself from the stored adjacency pairs (what normal_consistency computes once the A8 operator has produced them)
+    pairs = torch.from_numpy(g["pairs"])
+    nn_ = SL.unit_normals(tri)
+    loss = (1.0 - (nn_[:, pairs[0]] * nn_[:, pairs[1]]).sum(-1)).mean(-1).numpy()
+    assert np.abs(loss - g["normal_loss"]).max() <= 1e-6
+
+
 def _pit_fixture(name):
     g = load("pit_index_%s.npz" % name)
     if name == "cube40":                                   # tets rebuilt from the shipped grid (train_multigpu.py:65-66 shift)

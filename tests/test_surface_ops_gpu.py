@@ -294,3 +294,24 @@ def test_surface_terms_compose_like_deftet_forward(cuda, oracle):
     a = torch.from_numpy(np.asarray(adj)).to(cuda).long()
     want = (1 - (n64[a[0]] * n64[a[1]]).sum(-1)).mean()
     assert abs(want.item() - normal_loss.item()) < 1e-5
+
+
+def test_surface_terms_vs_reference_mesh_utils_outputs(cuda):
+    """normal_consistency and cloud_to_cloud on the GPU == what the reference's get_surface_normal_loss / point_point_distance
+    (utils/mesh_utils.py:16-39, :360-366) returned on CPU for the same inputs (tests/golden/surface_glue.npz; there the two
+    CUDA operators were replaced by precomputed index tables, which the HIP operators must reproduce)."""
+    import os
+    from deftet_amd import hip_ops, surface_losses as SL
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "surface_glue.npz"))
+    v = torch.from_numpy(g["verts"]).to(cuda)
+    f = torch.from_numpy(g["faces"])[None].to(cuda)
+    tri = SL.corners(v, f)
+    from deftet_amd.layers.DefTet.tet_face_adj_m_idx.utils import tet_face_adj_m_f_idx
+    pairs = tet_face_adj_m_f_idx(tri[0].contiguous())
+    assert np.array_equal(pairs.cpu().numpy(), g["pairs"])                      # A8 == the oracle's table the fixture was made with
+    loss = SL.normal_consistency(v, f)
+    assert np.abs(loss.cpu().numpy() - g["normal_loss"]).max() <= 1e-6
+    src, dst = torch.from_numpy(g["src"]).to(cuda), torch.from_numpy(g["dst"]).to(cuda)
+    assert np.array_equal(hip_ops.nn_index(src, dst)[0].cpu().numpy(), g["nn"])   # A10 == fp64 argmin (no ties in this cloud)
+    d = SL.cloud_to_cloud(src, dst)
+    assert np.abs(d.cpu().numpy() - g["point_point_distance"]).max() <= 1e-6
