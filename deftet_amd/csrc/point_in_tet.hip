@@ -22,6 +22,7 @@
 
 #include <stdlib.h>
 
+#include <algorithm>
 #include <type_traits>
 #include <vector>
 
@@ -624,6 +625,26 @@ __device__ __forceinline__ unsigned sel(lanemask_t m, unsigned if_set, unsigned 
 }
 __device__ __forceinline__ lanemask_t mask_of(bool c) { return __builtin_amdgcn_ballot_w64(c); }
 
+#ifdef PIT_PHASE_TIMING
+// Diagnostic build only (tools/probes/build_variant.sh … -DPIT_PHASE_TIMING): per-phase wall cycles of the traversal
+// kernels.  Lane 0 of every wave adds its s_memtime deltas to a slot of its own (no atomics: same-address atomics from
+// 32 k waves would dominate what is being measured); deftet_debug_phase_read sums the slots.
+constexpr int kPhaseWaves = 1 << 16;
+__device__ unsigned long long g_phase[kPhaseWaves][16];
+#define PHASE_DECL                                                                                      \
+    long long ph_t_ = clock64();                                                                        \
+    const unsigned ph_w_ = (((unsigned)blockIdx.y * gridDim.x + blockIdx.x) * 4u + (threadIdx.x >> 6)) & (kPhaseWaves - 1)
+#define PHASE_MARK(i)                                                                  \
+    do {                                                                               \
+        const long long ph_n_ = clock64();                                             \
+        if ((threadIdx.x & 63) == 0) g_phase[ph_w_][i] += (unsigned long long)(ph_n_ - ph_t_); \
+        ph_t_ = ph_n_;                                                                 \
+    } while (0)
+#else
+#define PHASE_DECL
+#define PHASE_MARK(i)
+#endif
+
 // load at a 32-bit unsigned BYTE offset from a (wave-uniform) base pointer: scalar-base + vector-offset addressing
 template <typename T>
 __device__ __forceinline__ T ld_off(const void *base, unsigned byte_off)
@@ -712,6 +733,7 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan_fma(const float *__
     const int vb = (blockIdx.x & 7) * per + (blockIdx.x >> 3);        // XCD-aware mapping, see k_tet_scan
     int t = vb * blockDim.x + threadIdx.x;
     if (vb >= nblk || t >= T) return;
+    PHASE_DECL;
     if (list) {                                                        // list mode: the tets k_tet_scan_grp deferred (count in counters[.][3])
         if (t >= counters[b * 4 + 3]) return;
         t = list[(size_t)b * T + t];
@@ -788,6 +810,7 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan_fma(const float *__
     const int *cb = cells + (size_t)b * cellStride;
     const float4 *sq = sortedQ + (size_t)b * Q;
     int *res = result + (size_t)b * Q;
+    PHASE_MARK(0);                                                       // [0] load + setup
     // The loop body is branch-free.  Accepted queries go into a four-deep shift register (h0 = newest) and are
     // published with atomicMin once, after the traversal.  A candidate in the filter's undecided band, or a fifth
     // acceptance, only raises a flag; such tets (~1e-4 of them) are re-scanned exactly afterwards.
@@ -863,6 +886,7 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan_fma(const float *__
             j += 2;
         }
     }
+    PHASE_MARK(1);                                                       // [1] traversal loop
     if (amin <= F.twoEmax || hcnt > 4) {
         atomicAdd(&counters[gridDim.y * 4 + b * 4 + 1], 1);                   // statistics: tets re-scanned
         const int4 r = exact_rescan(tet + ((size_t)b * T + t) * 12, t, cb, sq, res, G, Gx, cx0, cx1, cy0, cy1, cz0, cz1, m,
@@ -876,6 +900,7 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan_fma(const float *__
         if (hits) hits[(size_t)b * T + t] = make_int4(h0, h1, h2, h3);
     }
     fma_irregular_tail(tet, t, b, T, Q, pts, counters, irregQ, result);
+    PHASE_MARK(2);                                                       // [2] publish (atomics, record store) / re-scan
 }
 
 // ------------------------------------------------------------------------------------
@@ -1244,6 +1269,7 @@ __global__ __launch_bounds__(256, 5) void k_tet_scan_lds(const float *__restrict
     if (vb >= nblk || vb * 256 >= T) return;                           // whole workgroup out of range (uniform)
     const int t = vb * 256 + tid;
     const bool live = t < T;
+    PHASE_DECL;
     const Grid g = load_grid(gparam + b * 12);
     Filter F;
     bool regular = false, active = false;
@@ -1302,6 +1328,7 @@ __global__ __launch_bounds__(256, 5) void k_tet_scan_lds(const float *__restrict
         }
         if (live && regular && !ingrid && hits) hits[(size_t)b * T + t] = make_int4(-1, -1, -1, -1);
     }
+    PHASE_MARK(4);                                                       // [4] load + setup
     // ---- 1. union box of the workgroup's active lanes: wave butterflies, then four partials per bound through LDS
     //         (64 lanes hitting one LDS word with an atomic serialise: measured 2x the whole kernel)
     {
@@ -1320,6 +1347,7 @@ __global__ __launch_bounds__(256, 5) void k_tet_scan_lds(const float *__restrict
     const int *cb = cells + (size_t)b * cellStride;
     const float4 *sq = sortedQ + (size_t)b * Q;
     int *res = result + (size_t)b * Q;
+    PHASE_MARK(5);                                                       // [5] union box (butterflies + barrier)
     bool stB = false, stQ = false;
     int nx1 = 1, ny = 1;
     if (ux1 >= ux0) {                                                  // some lane is active (uniform)
@@ -1338,6 +1366,7 @@ __global__ __launch_bounds__(256, 5) void k_tet_scan_lds(const float *__restrict
                 s_cb[i] = cb[((uz0 + rz) * G + (uy0 + ry)) * Gx + ux0 + x];
             }
             __syncthreads();
+            PHASE_MARK(6);                                               // [6] cell starts -> LDS (+ barrier)
             if (STAGE_Q) {
                 // ---- 3. per-row LDS offsets (block exclusive scan of the run lengths, two rows per thread)
                 const int r0 = tid * 2, r1 = r0 + 1;
@@ -1377,6 +1406,7 @@ __global__ __launch_bounds__(256, 5) void k_tet_scan_lds(const float *__restrict
             }
         }
     }
+    PHASE_MARK(7);                                                       // [7] offsets scan + queries -> LDS (+ barriers)
     // ---- traversal (per-lane cursor, see k_tet_scan_grp), operands from LDS where staged.  Three specialisations of
     //      one loop (MODE 0: bounds and queries from global memory; 1: bounds from LDS; 2: both from LDS), picked by a
     //      workgroup-uniform branch OUTSIDE the loop.  Row positions advance by additions; selects use SGPR-pair masks.
@@ -1470,6 +1500,7 @@ __global__ __launch_bounds__(256, 5) void k_tet_scan_lds(const float *__restrict
         if (stQ) traverse(std::integral_constant<int, 2>{});
         else if (stB) traverse(std::integral_constant<int, 1>{});
         else traverse(std::integral_constant<int, 0>{});
+        PHASE_MARK(8);                                                   // [8] traversal loop
         if (amin <= F.twoEmax || hcnt > 4) {
             atomicAdd(&counters[gridDim.y * 4 + b * 4 + 1], 1);               // statistics: tets re-scanned
             const int4 r4 = exact_rescan(tet + ((size_t)b * T + t) * 12, t, cb, sq, res, G, Gx, cx0, cx1, cy0, cy1, cz0, cz1, m,
@@ -1484,6 +1515,7 @@ __global__ __launch_bounds__(256, 5) void k_tet_scan_lds(const float *__restrict
         }
     }
     if (live) fma_irregular_tail(tet, t, b, T, Q, pts, counters, irregQ, result);
+    PHASE_MARK(9);                                                       // [9] publish / re-scan
 }
 
 // ------------------------------------------------------------------------------------
@@ -2625,6 +2657,22 @@ extern "C" int deftet_point_in_tet_read_stats(const void *workspace, size_t work
         }
     return DEFTET_OK;
 }
+
+#ifdef PIT_PHASE_TIMING
+extern "C" int deftet_debug_phase_read(unsigned long long *out16, int reset)
+{
+    std::vector<unsigned long long> h((size_t)kPhaseWaves * 16);
+    DEFTET_HIP(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(deftet::pit::g_phase), h.size() * sizeof(unsigned long long)));
+    for (int i = 0; i < 16; ++i) out16[i] = 0;
+    for (size_t w = 0; w < (size_t)kPhaseWaves; ++w)
+        for (int i = 0; i < 16; ++i) out16[i] += h[w * 16 + i];
+    if (reset) {
+        std::fill(h.begin(), h.end(), 0ull);
+        DEFTET_HIP(hipMemcpyToSymbol(HIP_SYMBOL(deftet::pit::g_phase), h.data(), h.size() * sizeof(unsigned long long)));
+    }
+    return DEFTET_OK;
+}
+#endif
 
 extern "C" size_t deftet_point_in_tet_bwd_workspace_bytes(int B, int T, int Q)
 {
