@@ -74,6 +74,10 @@ class PitWorkload:
             verts, tets = g40["verts"], g40["tets"]
         else:
             verts, tets = grids.kuhn_grid(res)
+        if cfg.get("order") == "xfast":                   # probe use: cubes enumerated with x fastest instead of z fastest
+            n = res // 2
+            idx = np.arange(n * n * n * 6).reshape(n, n, n, 6)       # [ix, iy, iz, k] -> current position
+            tets = tets[idx.transpose(2, 1, 0, 3).reshape(-1)]       # new position ((iz*n + iy)*n + ix)*6 + k
         self.sets, self.host = [], None
         for s in range(cfg["sets"]):
             base = rank * B + s * 100_000                 # distinct seeds per rank and per set

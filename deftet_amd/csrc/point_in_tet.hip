@@ -253,7 +253,10 @@ __global__ __launch_bounds__(256) void k_query_bbox(const float *__restrict__ pt
 // downstream depends on it except which four accepted queries a hit record keeps.
 // ------------------------------------------------------------------------------------
 constexpr int kMaxRowBlocks = 256;   // blocks per shape in k_row_count / k_row_scatter
-constexpr int kRowTile = 2048;       // smallest query chunk per block
+#ifndef PIT_ROWTILE
+#define PIT_ROWTILE 2048
+#endif
+constexpr int kRowTile = PIT_ROWTILE;  // smallest query chunk per block
 
 __global__ __launch_bounds__(256) void k_row_count(const float *__restrict__ pts, int Q, const float *__restrict__ bboxPart,
                                                    float *gparam, int G, int Gx, int nblk, int chunkQ, int2 *qkey,

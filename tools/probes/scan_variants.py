@@ -63,6 +63,7 @@ def main():
     ap.add_argument("--config", type=int, default=2)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--sweep", action="store_true")
+    ap.add_argument("--order", default=None, help="xfast: enumerate the Kuhn cubes with x fastest (the grid's run axis) instead of z fastest")
     ap.add_argument("--mesh", default=None, help="cube40: the shipped QuarTet grid (res 40 sizes) instead of the Kuhn grid")
     ap.add_argument("--algos", default="0,11,6,9,10")
     a = ap.parse_args()
@@ -71,6 +72,8 @@ def main():
     cfg = dict(bench.CONFIGS[a.config], sets=1)
     if a.mesh:
         cfg["mesh"] = a.mesh
+    if a.order:
+        cfg["order"] = a.order
     wl = bench.PitWorkload(cfg, 0, dev, 1, None, pipeline=False)
     set_env(DEFTET_PIT_XFINE=None, DEFTET_PIT_GDIV=None, DEFTET_PIT_QDIV=None)
     ref, gref, *_ = run(wl, lib, 0, 2)
@@ -88,7 +91,7 @@ def main():
         same = bool(torch.equal(outs[0], ref[0]) and torch.equal(outs[1], ref[1]) and torch.equal(outs[2], ref[2]))
         gerr = float((g[0] - gref[0]).abs().max() / gref[0].abs().max())
         algo_bytes = wl.dominant_bytes
-        print(json.dumps({"config": a.config, "mesh": a.mesh or "kuhn", "n_tet": wl.T, "algo": algo, "kernel": hip_ops.pit_kernel_name(algo), "xfine": xf, "gdiv": gd, "qdiv": qd,
+        print(json.dumps({"config": a.config, "mesh": (a.mesh or "kuhn") + ("/" + a.order if a.order else ""), "n_tet": wl.T, "algo": algo, "kernel": hip_ops.pit_kernel_name(algo), "xfine": xf, "gdiv": gd, "qdiv": qd,
                           "traversal_us": round(k_us, 2), "fwd_us": round(fwd_us, 1), "bwd_us": round(bwd_us, 1),
                           "roofline_frac_of_8TBs": round(algo_bytes / (k_us * 1e-6) / 8e12, 4), "same_as_default": same, "stats_irrT_irrQ_ovf_defer_grpRescan_tetRescan": run.stats[:6],
                           "bwd_rel_diff": gerr}), flush=True)
