@@ -389,82 +389,244 @@ __global__ __launch_bounds__(256) void k_pix_emit(const int4 *__restrict__ hits,
             const size_t o = (size_t)p * knum + r;
             const float w1 = __int_as_float(me.z), w2 = __int_as_float(me.w), w0 = 1 - w1 - w2;
             out_face[o] = me.x;
-            out_w[o * 3] = w0; out_w[o * 3 + 1] = w1; out_w[o * 3 + 2] = w2;
+            if (out_w) { out_w[o * 3] = w0; out_w[o * 3 + 1] = w1; out_w[o * 3 + 2] = w2; }
             const float *ff = feat + (size_t)me.x * 3 * D;
             for (int d = 0; d < D; ++d) out_feat[o * D + d] = (w0 * ff[d] + w1 * ff[D + d]) + w2 * ff[2 * D + d];
         } else {
             const size_t o = (size_t)p * knum + i;                 // slots n..knum-1 stay empty
             out_face[o] = -1;
-            out_w[o * 3] = 0.f; out_w[o * 3 + 1] = 0.f; out_w[o * 3 + 2] = 0.f;
+            if (out_w) { out_w[o * 3] = 0.f; out_w[o * 3 + 1] = 0.f; out_w[o * 3 + 2] = 0.f; }
             for (int d = 0; d < D; ++d) out_feat[o * D + d] = 0.f;
         }
     }
 }
 
 // ---------------------------------------------------------------------------- backward
-__global__ __launch_bounds__(256) void k_link(const long long *__restrict__ face_idx, long long n, int F, int *head, int *next)
+// Hits are grouped by face with ONE stable radix sort of (face, slot) pairs: the keys are read straight
+// from face_idx through a transform iterator (empty slots get the padding key F and sort to the end),
+// the values come from a counting iterator.  Then one lane per SORTED hit (k_bwd_sorted): the slot list
+// is read coalesced, the hit's pixel and output gradient are the only divergent gathers (the face data of
+// neighbouring lanes coincide), the barycentric weights are recomputed exactly as the forward computed
+// them, and the per-hit contributions are combined by a segmented scan across the wave (DPP moves) and a
+// carry across the 16 waves of the block (LDS), all in a fixed order.  A face whose hits lie inside one
+// block is written with plain stores; one that straddles a block boundary (1,024 sorted hits) adds its
+// partial sums atomically into the cleared output, so only faces with more than 1,024 hits can see
+// different summation orders between runs.
+// Measured history at configs[4] (15.4 M hits, 521,850 faces): per-face linked lists built with atomicExch
+// + one lane per face chasing them 0.45 + 2.12 ms (a chain of dependent, fully divergent gathers); sorted
+// hits with ds_bpermute shuffles 1.07 ms (LDS pipe); DPP moves 0.89 ms; wave-local runs flushed with 36
+// float atomics per wave -> carried through LDS instead: 0.46 ms.  The sort itself costs 0.49 ms.
+struct FaceKey {
+    int F;
+    __host__ __device__ unsigned operator()(long long f) const { return (f >= 0 && f < (long long)F) ? (unsigned)f : (unsigned)F; }
+};
+using KeyIter = rocprim::transform_iterator<const long long *, FaceKey, unsigned>;
+using ValIter = rocprim::counting_iterator<unsigned>;
+
+constexpr int kDChunk = 4;
+
+// Data-parallel-primitive moves (full-rate VALU; ds_bpermute shuffles made this kernel LDS-pipe bound: 1.07 ms):
+// row_shr:n inside the 16-lane rows, then row_bcast:15 (lane 15 of each row to the next row; rows 1 and 3
+// written) and row_bcast:31 (lane 31 to rows 2 and 3).  Lanes without a source receive 0.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_mov(int x) { return __builtin_amdgcn_update_dpp(0, x, CTRL, ROW_MASK, 0xf, false); }
+
+struct SegFlags { bool s1, s2, s4, s8, b15, b31; };
+
+// which lanes of the sorted key sequence continue the run of the lane the move reads from
+__device__ __forceinline__ SegFlags seg_flags(unsigned key, int lane)
 {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const long long f = face_idx[i];
-    if (f >= 0 && f < F) next[i] = atomicExch(&head[f], (int)i);
+    const int k = (int)key, r = lane & 15;
+    SegFlags f;
+    const int k1 = dpp_mov<0x111, 0xf>(k), k2 = dpp_mov<0x112, 0xf>(k), k4 = dpp_mov<0x114, 0xf>(k), k8 = dpp_mov<0x118, 0xf>(k);
+    const int k15 = dpp_mov<0x142, 0xa>(k), k31 = dpp_mov<0x143, 0xc>(k);
+    f.s1 = r >= 1 && k1 == k; f.s2 = r >= 2 && k2 == k; f.s4 = r >= 4 && k4 == k; f.s8 = r >= 8 && k8 == k;
+    f.b15 = (lane & 16) != 0 && k15 == k;
+    f.b31 = (lane & 32) != 0 && k31 == k;
+    return f;
 }
 
-constexpr int kDChunk = 8;
-
-__global__ __launch_bounds__(256) void k_bwd_gather(const float *__restrict__ pix, const float *__restrict__ fxy,
-                                                    const float *__restrict__ feat, const float *__restrict__ w,
-                                                    const float *__restrict__ gout, const int *__restrict__ head,
-                                                    const int *__restrict__ next, int F, int D, int knum, float eps,
-                                                    float *gxy, float *gfeat)
+// inclusive segmented scan over the wave (segments = runs of equal sorted keys), fixed order of additions
+template <int N>
+__device__ __forceinline__ void seg_scan(float (&v)[N], const SegFlags &f)
 {
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= F) return;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        float x = v[k], t;                                           // every move is executed by all lanes, then selected
+        t = __int_as_float(dpp_mov<0x111, 0xf>(__float_as_int(x))); x += f.s1 ? t : 0.f;
+        t = __int_as_float(dpp_mov<0x112, 0xf>(__float_as_int(x))); x += f.s2 ? t : 0.f;
+        t = __int_as_float(dpp_mov<0x114, 0xf>(__float_as_int(x))); x += f.s4 ? t : 0.f;
+        t = __int_as_float(dpp_mov<0x118, 0xf>(__float_as_int(x))); x += f.s8 ? t : 0.f;
+        t = __int_as_float(dpp_mov<0x142, 0xa>(__float_as_int(x))); x += f.b15 ? t : 0.f;
+        t = __int_as_float(dpp_mov<0x143, 0xc>(__float_as_int(x))); x += f.b31 ? t : 0.f;
+        v[k] = x;
+    }
+}
+
+constexpr int kBwdWaves = 16;           // waves per block of k_bwd_sorted
+
+// What a wave knows about the runs that cross its two ends (wave-uniform).
+struct WaveEnds {
+    bool contL;     // the run holding lane 0 started before this wave
+    bool contR;     // the run holding lane 63 goes on in the next wave
+    int w;          // wave index in the block
+};
+
+// Carry the partial sums of runs across the waves of a block through LDS.  On entry v[] holds the wave's
+// inclusive segmented scan.  On return the lane that ENDS a run (knext != key) holds the run's sum over the whole
+// block in v[]; `ext` tells it whether the run began in an earlier block.  Fixed order of additions.
+template <int N>
+__device__ __forceinline__ void block_carry(float (&v)[N], float (*s_sum)[20], const int *s_one, const WaveEnds &e, int lane,
+                                            bool inFirstRun, bool &ext)
+{
+    __syncthreads();                                                // LDS free again (previous use)
+    if (lane == 63)
+#pragma unroll
+        for (int k = 0; k < N; ++k) s_sum[e.w][k] = v[k];
+    __syncthreads();
+    float c = 0.f;
+    bool fromBefore = e.contL && e.w == 0;
+    if (e.contL && e.w > 0 && lane < N) {
+        for (int u = e.w - 1; u >= 0; --u) {
+            c += s_sum[u][lane];
+            if (!s_one[u]) break;
+        }
+    }
+    if (e.contL && e.w > 0) {
+        int u = e.w - 1;
+        while (u > 0 && s_one[u]) --u;
+        fromBefore = u == 0 && s_one[0];
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const float ck = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c), k));
+        v[k] += inFirstRun ? ck : 0.f;
+    }
+    ext = inFirstRun && fromBefore;
+}
+
+template <int DT>   // DT = number of feature channels when it is 4 (16-byte loads and stores, loops unroll), 0 = run-time D
+__global__ __launch_bounds__(kBwdWaves * 64) void k_bwd_sorted(const float *__restrict__ pix, const float *__restrict__ fxy,
+                                                               const float *__restrict__ feat, const float *__restrict__ gout,
+                                                               const unsigned *__restrict__ skey, const unsigned *__restrict__ sval,
+                                                               long long n, int F, int D, int knum, float eps, float *gxy, float *gfeat)
+{
+    __shared__ float s_sum[kBwdWaves][20];
+    __shared__ int s_one[kBwdWaves];
+    const long long i0 = (long long)blockIdx.x * blockDim.x;
+    if (skey[i0] >= (unsigned)F) return;                            // the padding tail (keys are sorted): whole block idle
+    const long long i = i0 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    if (DT) D = DT;
+    const unsigned key = i < n ? skey[i] : (unsigned)F;
+    const bool valid = key < (unsigned)F;
+    const unsigned kprev = (valid && i > 0) ? skey[i - 1] : 0xFFFFFFFFu;
+    const unsigned knext = (valid && i + 1 < n) ? skey[i + 1] : 0xFFFFFFFFu;
+    const SegFlags same = seg_flags(key, lane);
+    const unsigned long long heads = __ballot(!valid || kprev != key);
+    const bool inFirstRun = valid && (heads & ((2ull << lane) - 1ull)) == 0ull;   // no run starts at or below this lane
+    const bool ends = valid && knext != key;                                        // the run's last hit
+    WaveEnds e;
+    e.w = threadIdx.x >> 6;
+    e.contL = (heads & 1ull) == 0ull;
+    e.contR = (__ballot(valid && knext == key) >> 63) != 0ull;
+    if (lane == 0) s_one[e.w] = (e.contL && heads == 0ull && e.contR) ? 1 : 0;      // one run from before the wave to after it
+    const bool lastWave = e.w == kBwdWaves - 1;
+    // who writes: the lane that ends a run, plus lane 63 of the block's last wave for a run that goes on in the next block
+    const bool spill = lastWave && lane == 63 && valid && knext == key;
+    const int f = valid ? (int)key : 0;
+    const unsigned h = valid ? sval[i] : 0u;
+    const int p = (int)(h / (unsigned)knum);
+    const float2 px = reinterpret_cast<const float2 *>(pix)[p];
     const float2 a = reinterpret_cast<const float2 *>(fxy)[f * 3], b = reinterpret_cast<const float2 *>(fxy)[f * 3 + 1],
                  c = reinterpret_cast<const float2 *>(fxy)[f * 3 + 2];
-    const float m = b.x - a.x, pp = b.y - a.y, n = c.x - a.x, q = c.y - a.y;
-    const float den = (m * q - n * pp) + eps;
+    const float m = b.x - a.x, pp = b.y - a.y, nn = c.x - a.x, q = c.y - a.y, s = px.x - a.x, t = px.y - a.y;
+    const float k1 = s * q - nn * t, k2 = m * t - s * pp, k3 = m * q - nn * pp;
+    const float den = k3 + eps;
+    const float w1 = k1 / den, w2 = k2 / den, w0 = 1 - w1 - w2;     // the forward's expressions, bit for bit
+    const float *g = gout + (size_t)h * D;
     const float *ff = feat + (size_t)f * 3 * D;
-    float gax = 0.f, gay = 0.f, gbx = 0.f, gby = 0.f, gcx = 0.f, gcy = 0.f;
-    for (int c0 = 0; c0 < D; c0 += kDChunk) {
-        float acc[3][kDChunk];
+    {
+        float gw1 = 0.f, gw2 = 0.f;                                  // dL/dw1, dL/dw2 (w0 = 1 - w1 - w2)
 #pragma unroll
-        for (int v = 0; v < 3; ++v)
-#pragma unroll
-            for (int d = 0; d < kDChunk; ++d) acc[v][d] = 0.f;
-        for (int h = head[f]; h >= 0; h = next[h]) {
-            const float w0 = w[(size_t)h * 3], w1 = w[(size_t)h * 3 + 1], w2 = w[(size_t)h * 3 + 2];
-            const float *g = gout + (size_t)h * D;
-#pragma unroll
-            for (int d = 0; d < kDChunk; ++d)
-                if (c0 + d < D) {
-                    const float gd = g[c0 + d];
-                    acc[0][d] += w0 * gd; acc[1][d] += w1 * gd; acc[2][d] += w2 * gd;
-                }
-            if (c0 == 0) {
-                float gw1 = 0.f, gw2 = 0.f;                         // dL/dw1, dL/dw2 (w0 = 1 - w1 - w2)
-                for (int d = 0; d < D; ++d) {
-                    const float gd = g[d];
-                    gw1 += gd * (ff[D + d] - ff[d]);
-                    gw2 += gd * (ff[2 * D + d] - ff[d]);
-                }
-                const int p = h / knum;
-                const float s = pix[p * 2] - a.x, t = pix[p * 2 + 1] - a.y;
-                const float gk1 = gw1 / den, gk2 = gw2 / den, gk3 = -(gw1 * w1 + gw2 * w2) / den;
-                const float gm = gk2 * t + gk3 * q, gp_ = -gk2 * s - gk3 * n, gn = -gk1 * t - gk3 * pp, gq = gk1 * s + gk3 * m;
-                const float gs = gk1 * q - gk2 * pp, gt = -gk1 * n + gk2 * m;
-                gbx += gm; gby += gp_; gcx += gn; gcy += gq;
-                gax += -(gm + gn + gs); gay += -(gp_ + gq + gt);
-            }
+        for (int d = 0; d < (DT ? DT : D); ++d) {
+            const float gd = g[d];
+            gw1 += gd * (ff[D + d] - ff[d]);
+            gw2 += gd * (ff[2 * D + d] - ff[d]);
         }
+        const float gk1 = gw1 / den, gk2 = gw2 / den, gk3 = -(gw1 * w1 + gw2 * w2) / den;
+        const float gm = gk2 * t + gk3 * q, gp_ = -gk2 * s - gk3 * nn, gn = -gk1 * t - gk3 * pp, gq = gk1 * s + gk3 * m;
+        const float gs = gk1 * q - gk2 * pp, gt = -gk1 * nn + gk2 * m;
+        float v[6] = {-(gm + gn + gs), -(gp_ + gq + gt), gm, gp_, gn, gq};
+        if (!valid)
 #pragma unroll
-        for (int v = 0; v < 3; ++v)
+            for (int k = 0; k < 6; ++k) v[k] = 0.f;
+        seg_scan(v, same);
+        bool ext;
+        block_carry(v, s_sum, s_one, e, lane, inFirstRun, ext);
+        float *o = gxy + (size_t)f * 6;
+        if (ends && !ext) {
 #pragma unroll
-            for (int d = 0; d < kDChunk; ++d)
-                if (c0 + d < D) gfeat[((size_t)f * 3 + v) * D + c0 + d] = acc[v][d];
+            for (int k = 0; k < 3; ++k) reinterpret_cast<float2 *>(o)[k] = make_float2(v[2 * k], v[2 * k + 1]);
+        } else if ((ends && ext) || spill) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) unsafeAtomicAdd(o + k, v[k]);
+        }
     }
-    float *o = gxy + (size_t)f * 6;
-    o[0] = gax; o[1] = gay; o[2] = gbx; o[3] = gby; o[4] = gcx; o[5] = gcy;
+    for (int c0 = 0; c0 < (DT ? DT : D); c0 += kDChunk) {         // one trip when DT == 4
+        float v[3 * kDChunk];
+#pragma unroll
+        for (int d = 0; d < kDChunk; ++d) {
+            const float gd = (valid && c0 + d < D) ? g[c0 + d] : 0.f;
+            v[d] = w0 * gd; v[kDChunk + d] = w1 * gd; v[2 * kDChunk + d] = w2 * gd;
+        }
+        seg_scan(v, same);
+        bool ext;
+        block_carry(v, s_sum, s_one, e, lane, inFirstRun, ext);
+        float *o = gfeat + (size_t)f * 3 * D + c0;
+        if (ends && !ext) {
+            if (DT == 4) {
+#pragma unroll
+                for (int vtx = 0; vtx < 3; ++vtx)
+                    reinterpret_cast<float4 *>(o)[vtx] = make_float4(v[vtx * 4], v[vtx * 4 + 1], v[vtx * 4 + 2], v[vtx * 4 + 3]);
+            } else {
+#pragma unroll
+                for (int vtx = 0; vtx < 3; ++vtx)
+#pragma unroll
+                    for (int d = 0; d < kDChunk; ++d)
+                        if (c0 + d < D) o[(size_t)vtx * D + d] = v[vtx * kDChunk + d];
+            }
+        } else if ((ends && ext) || spill) {
+#pragma unroll
+            for (int vtx = 0; vtx < 3; ++vtx)
+#pragma unroll
+                for (int d = 0; d < kDChunk; ++d)
+                    if (c0 + d < D) unsafeAtomicAdd(o + (size_t)vtx * D + d, v[vtx * kDChunk + d]);
+        }
+    }
+}
+
+struct BwdLayout {
+    size_t bytes, tmpBytes;
+    unsigned *skey, *sval;
+    void *tmp;
+    int bits;
+};
+
+static BwdLayout make_bwd_layout(int P, int F, int knum, void *ws, size_t wsb)
+{
+    BwdLayout L{};
+    Arena A(ws, wsb);
+    const size_t n = (size_t)P * knum;
+    L.skey = A.take<unsigned>(n + 1);
+    L.sval = A.take<unsigned>(n + 1);
+    L.bits = 1;
+    while (L.bits < 32 && (1ull << L.bits) <= (unsigned long long)F) ++L.bits;       // keys are 0..F inclusive
+    (void)rocprim::radix_sort_pairs(nullptr, L.tmpBytes, KeyIter(nullptr, FaceKey{F}), (unsigned *)nullptr, ValIter(0u), (unsigned *)nullptr,
+                                    n, 0, L.bits, (hipStream_t) nullptr);
+    L.tmp = A.take<char>(L.tmpBytes);
+    L.bytes = align_up(A.off, 256);
+    return L;
 }
 
 struct Layout {
@@ -544,7 +706,7 @@ extern "C" int deftet_sparse_render_fwd_f32(const float *pix, const float *rng, 
     DEFTET_CHECK_ARG(B >= 0 && P >= 0 && F >= 0 && D >= 0 && knum >= 0, "negative size");
     DEFTET_CHECK_ARG((long long)P * knum < 2147483647LL && (long long)F * kMaxTiles < 2147483647LL, "P*knum or F too large");
     if (B == 0 || P == 0 || knum == 0) return DEFTET_OK;
-    DEFTET_CHECK_ARG(pix && rng && out_feat && out_face && out_w && (F == 0 || (fz && fxy && feat)), "null pointer");
+    DEFTET_CHECK_ARG(pix && rng && out_feat && out_face && (F == 0 || (fz && fxy && feat)), "null pointer");
     DEFTET_CHECK_ARG(((uintptr_t)fxy & 7) == 0, "face_vertices_image must be 8-byte aligned");
     DEFTET_CHECK_ARG(workspace && ((uintptr_t)workspace & 255) == 0, "workspace null or misaligned");
     Layout L = make_layout(P, F, knum, workspace, wsb);
@@ -593,41 +755,49 @@ extern "C" int deftet_sparse_render_fwd_f32(const float *pix, const float *rng, 
                           (const int *)L.pixStart, (const int *)L.chunkStart);
         }
         DEFTET_LAUNCH(k_pix_emit, dim3((P + 3) / 4), dim3(256), st, L.hits, L.nhit, fb, P, D, knum,
-                      out_feat + (size_t)b * P * knum * D, (long long *)out_face + (size_t)b * P * knum, out_w + (size_t)b * P * knum * 3);
+                      out_feat + (size_t)b * P * knum * D, (long long *)out_face + (size_t)b * P * knum,
+                      out_w ? out_w + (size_t)b * P * knum * 3 : nullptr);
     }
     return DEFTET_OK;
 }
 
 extern "C" size_t deftet_sparse_render_bwd_workspace_bytes(int B, int P, int F, int knum)
 {
-    if (P < 0 || F < 0 || knum < 0) return 0;
-    return align_up((size_t)F * 4, 256) + align_up((size_t)P * knum * 4, 256);
+    if (P < 0 || F < 0 || knum < 0 || (long long)P * knum >= 2147483647LL) return 0;
+    return make_bwd_layout(P, F, knum, nullptr, 0).bytes;  // shapes are processed one after another
 }
 
 extern "C" int deftet_sparse_render_bwd_f32(const float *pix, const float *fxy, const float *feat, const int64_t *face_idx,
                                             const float *w, const float *gout, float *gxy, float *gfeat, int B, int P, int F,
                                             int D, int knum, float eps, void *workspace, size_t wsb, void *stream_)
 {
+    (void)w;                                                   // recomputed from the pixel and the face (may be NULL)
     DEFTET_CHECK_ARG(B >= 0 && P >= 0 && F >= 0 && D >= 0 && knum >= 0, "negative size");
     DEFTET_CHECK_ARG((long long)P * knum < 2147483647LL, "P*knum too large");
     if (B == 0 || F == 0) return DEFTET_OK;
     DEFTET_CHECK_ARG(fxy && feat && gxy && gfeat, "null pointer");
-    DEFTET_CHECK_ARG(((uintptr_t)fxy & 7) == 0, "face_vertices_image must be 8-byte aligned");
+    DEFTET_CHECK_ARG(((uintptr_t)fxy & 7) == 0 && ((uintptr_t)pix & 7) == 0, "face_vertices_image and pixel_coords must be 8-byte aligned");
     hipStream_t st = as_stream(stream_);
-    DEFTET_CHECK_ARG(workspace && ((uintptr_t)workspace & 255) == 0 && wsb >= deftet_sparse_render_bwd_workspace_bytes(B, P, F, knum),
-                     "backward workspace null, misaligned or too small");
-    int *head = static_cast<int *>(workspace);
-    int *next = reinterpret_cast<int *>(static_cast<char *>(workspace) + align_up((size_t)F * 4, 256));
     const long long n = (long long)P * knum;
+    DEFTET_HIP(hipMemsetAsync(gxy, 0, (size_t)B * F * 6 * sizeof(float), st));
+    DEFTET_HIP(hipMemsetAsync(gfeat, 0, (size_t)B * F * 3 * D * sizeof(float), st));
+    if (n == 0) return DEFTET_OK;
+    DEFTET_CHECK_ARG(pix && face_idx && gout, "null pointer");
+    DEFTET_CHECK_ARG(workspace && ((uintptr_t)workspace & 255) == 0, "backward workspace null or misaligned");
+    BwdLayout L = make_bwd_layout(P, F, knum, workspace, wsb);
+    DEFTET_CHECK_ARG(L.bytes <= wsb, "backward workspace too small: need %zu bytes, got %zu", L.bytes, wsb);
     for (int b = 0; b < B; ++b) {
-        DEFTET_HIP(hipMemsetAsync(head, 0xFF, (size_t)F * 4, st));
-        if (n > 0) {
-            DEFTET_CHECK_ARG(pix && face_idx && w && gout, "null pointer");
-            DEFTET_LAUNCH(k_link, dim3((unsigned)((n + 255) / 256)), dim3(256), st, (const long long *)face_idx + (size_t)b * n, n, F, head, next);
-        }
-        DEFTET_LAUNCH(k_bwd_gather, dim3((F + 255) / 256), dim3(256), st, pix + (size_t)b * P * 2, fxy + (size_t)b * F * 6,
-                      feat + (size_t)b * F * 3 * D, w + (size_t)b * n * 3, gout + (size_t)b * n * D, head, next, F, D, knum, eps,
-                      gxy + (size_t)b * F * 6, gfeat + (size_t)b * F * 3 * D);
+        size_t need = L.tmpBytes;
+        const hipError_t e = rocprim::radix_sort_pairs(L.tmp, need, KeyIter((const long long *)face_idx + (size_t)b * n, FaceKey{F}), L.skey,
+                                                       ValIter(0u), L.sval, (size_t)n, 0, L.bits, st);
+        if (e != hipSuccess) return set_error(DEFTET_ELAUNCH, "rocprim::radix_sort_pairs: %s", hipGetErrorString(e));
+#define RAST_BWD(DT)                                                                                                                  \
+    DEFTET_LAUNCH(k_bwd_sorted<DT>, dim3((unsigned)((n + kBwdWaves * 64 - 1) / (kBwdWaves * 64))), dim3(kBwdWaves * 64), st, pix + (size_t)b * P * 2, fxy + (size_t)b * F * 6, \
+                  feat + (size_t)b * F * 3 * D, gout + (size_t)b * n * D, (const unsigned *)L.skey, (const unsigned *)L.sval, n, F, D,   \
+                  knum, eps, gxy + (size_t)b * F * 6, gfeat + (size_t)b * F * 3 * D)
+        if (D == 4 && (((uintptr_t)feat | (uintptr_t)gout | (uintptr_t)gfeat) & 15) == 0) RAST_BWD(4);
+        else RAST_BWD(0);
+#undef RAST_BWD
     }
     return DEFTET_OK;
 }

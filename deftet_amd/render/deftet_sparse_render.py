@@ -32,21 +32,20 @@ class _SparseRender(Function):
         dev = pix.device
         feat = torch.empty(B, P, knum, D, device=dev, dtype=torch.float32)
         face = torch.empty(B, P, knum, device=dev, dtype=torch.int64)
-        w = torch.empty(B, P, knum, 3, device=dev, dtype=torch.float32)
         with torch.cuda.device(dev):
             ws = _lib.workspace(dev, lib.deftet_sparse_render_workspace_bytes(B, P, F, knum))
             _lib.check(lib.deftet_sparse_render_fwd_f32(_lib.ptr(pix), _lib.ptr(rng), _lib.ptr(fz), _lib.ptr(fxy), _lib.ptr(ff),
-                                                        _lib.ptr(feat), _lib.ptr(face), _lib.ptr(w), B, P, F, D, knum, eps,
+                                                        _lib.ptr(feat), _lib.ptr(face), _lib.ptr(None), B, P, F, D, knum, eps,
                                                         _lib.ptr(ws), ws.numel(), _lib.current_stream(dev)),
                        "deftet_sparse_render_fwd_f32")
-        ctx.save_for_backward(pix, fxy, ff, face, w)
+        ctx.save_for_backward(pix, fxy, ff, face)
         ctx.eps = eps
         ctx.mark_non_differentiable(face)
         return feat, face
 
     @staticmethod
     def backward(ctx, grad_feat, _grad_face):
-        pix, fxy, ff, face, w = ctx.saved_tensors
+        pix, fxy, ff, face = ctx.saved_tensors
         lib = _lib.load()
         B, P, knum = face.shape
         F, D = fxy.shape[1], ff.shape[3]
@@ -56,7 +55,7 @@ class _SparseRender(Function):
         dev = pix.device
         with torch.cuda.device(dev):
             ws = _lib.workspace(dev, lib.deftet_sparse_render_bwd_workspace_bytes(B, P, F, knum))
-            _lib.check(lib.deftet_sparse_render_bwd_f32(_lib.ptr(pix), _lib.ptr(fxy), _lib.ptr(ff), _lib.ptr(face), _lib.ptr(w),
+            _lib.check(lib.deftet_sparse_render_bwd_f32(_lib.ptr(pix), _lib.ptr(fxy), _lib.ptr(ff), _lib.ptr(face), _lib.ptr(None),
                                                         _lib.ptr(g), _lib.ptr(gxy), _lib.ptr(gff), B, P, F, D, knum, ctx.eps,
                                                         _lib.ptr(ws), ws.numel(), _lib.current_stream(dev)),
                        "deftet_sparse_render_bwd_f32")

@@ -339,6 +339,7 @@ int deftet_nn_index_f32(const float *queries_bxnx3, const float *points_bxmx3, i
  * diff_render/diftet_6_subdiv/5_rendereq/deftetrneder.py:97-100 (Kaolin itself is not part
  * of the reference tree: parity unpinned). */
 size_t deftet_sparse_render_workspace_bytes(int n_batch, int n_pixel, int n_face, int knum);
+/* out_w (the barycentric weights of every recorded hit) is optional: NULL skips it. */
 int deftet_sparse_render_fwd_f32(const float *pixel_bxpx2, const float *range_bxpx2,
                                  const float *face_z_bxfx3, const float *face_xy_bxfx3x2,
                                  const float *face_feat_bxfx3xd, float *out_feat_bxpxkxd,
@@ -346,7 +347,9 @@ int deftet_sparse_render_fwd_f32(const float *pixel_bxpx2, const float *range_bx
                                  int n_batch, int n_pixel, int n_face, int n_feat, int knum, float eps,
                                  void *workspace, size_t workspace_bytes, void *stream);
 /* backward: gradients to face_vertices_image [B,F,3,2] and face_features [B,F,3,D] (both fully
- * overwritten), none to z / pixels — as Kaolin documents.  Atomic-free (per-face hit lists). */
+ * overwritten), none to z / pixels — as Kaolin documents.  Hits are grouped by face with one stable radix
+ * sort and reduced by a segmented scan; w_bxpxkx3 is not read (the weights are recomputed from the pixel
+ * and the face exactly as the forward computed them) and may be NULL. */
 size_t deftet_sparse_render_bwd_workspace_bytes(int n_batch, int n_pixel, int n_face, int knum);
 int deftet_sparse_render_bwd_f32(const float *pixel_bxpx2, const float *face_xy_bxfx3x2,
                                  const float *face_feat_bxfx3xd, const int64_t *face_bxpxk,

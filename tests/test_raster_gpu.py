@@ -106,6 +106,40 @@ def test_backward_matches_fp64_autograd(cuda, oracle):
     assert (txy.grad.cpu()[0][~hit] == 0).all() and (tff.grad.cpu()[0][~hit] == 0).all()
 
 
+def test_backward_baseline_config_fp64(cuda, oracle):
+    """BASELINE configs[4] backward (15 M hits, faces with more than 64 hits straddle waves): fp64 autograd of the
+    same interpolation on the same face indices, evaluated on the GPU."""
+    from deftet_amd.render import deftet_sparse_render
+    fz, fxy, ff = projected_grid(70)
+    pix, rngs = pixel_grid(512)
+    tp, tr, tz = (torch.from_numpy(x).to(cuda) for x in (pix, rngs, fz))
+    txy = torch.from_numpy(fxy).to(cuda).requires_grad_(True)
+    tff = torch.from_numpy(ff).to(cuda).requires_grad_(True)
+    feat, face = deftet_sparse_render(tp, tr, tz, txy, tff, knum=64)
+    g = torch.Generator(device=cuda).manual_seed(1)
+    go = torch.rand(feat.shape, device=cuda, generator=g)
+    gxy, gff = torch.autograd.grad(feat, (txy, tff), go)
+    gxy2, gff2 = torch.autograd.grad(deftet_sparse_render(tp, tr, tz, txy, tff, knum=64)[0], (txy, tff), go)
+    xy64 = txy.detach().double().requires_grad_(True)
+    ff64 = tff.detach().double().requires_grad_(True)
+    feat64 = oracle.sparse_render_torch(tp.double(), xy64, ff64, face)
+    assert torch.allclose(feat64.float(), feat.detach(), rtol=1e-4, atol=1e-4)
+    wxy, wff = torch.autograd.grad(feat64, (xy64, ff64), go.double())
+    for got, again, want in ((gxy, gxy2, wxy), (gff, gff2, wff)):
+        # per-face error relative to that face's own gradient magnitude (sums of up to a few hundred hits)
+        mag = want.abs().reshape(want.shape[1], -1).max(-1).values.clamp(min=1e-30)
+        err = (got.double() - want).abs().reshape(want.shape[1], -1).max(-1).values
+        big = mag > 1e-3 * mag.max()
+        assert (err[big] / mag[big]).max().item() < 2e-3
+        assert err.max().item() <= 2e-4 * want.abs().max().item()
+        # run-to-run: only faces whose hits straddle three or more waves may differ, and only by rounding
+        assert (again.double() - got.double()).abs().max().item() <= 1e-5 * want.abs().max().item()
+    hit = torch.zeros(fxy.shape[1], dtype=torch.bool, device=cuda)
+    hit[face[face >= 0]] = True
+    assert (gxy[0][~hit] == 0).all() and (gff[0][~hit] == 0).all()
+    assert (gff[0][hit].abs().reshape(int(hit.sum()), -1).max(-1).values > 0).all()
+
+
 def test_baseline_config_properties(cuda):
     """BASELINE configs[4]: 512x512 rays, k=64, unique faces of the res=70 grid."""
     fz, fxy, ff = projected_grid(70)
