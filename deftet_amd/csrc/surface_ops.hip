@@ -169,6 +169,27 @@ __global__ __launch_bounds__(256) void k_nn_scatter(const float *__restrict__ pt
     sorted[start[r.x] + r.y] = make_float4(pts[i * 3], pts[i * 3 + 1], pts[i * 3 + 2], __int_as_float(i));
 }
 
+// Sort key of the queries k_nn_query answered itself: the first power of two above every Morton key of the grid (three
+// interleaved coordinates 0..G+1), so that the far queries sort to the front on 3*bits + 1 key bits (16 for G <= 30).
+static int nn_far_key_bits(int G)
+{
+    int bits = 1;
+    while ((1 << bits) < G + 2) ++bits;
+    return 3 * bits;
+}
+#ifndef NN_FAR_ROWS
+#define NN_FAR_ROWS 25
+#endif
+constexpr int kFarRows = NN_FAR_ROWS;
+
+__device__ __forceinline__ unsigned spread3(unsigned v)            // bit i of an 8-bit value -> bit 3i
+{
+    v = (v | (v << 8)) & 0x0000F00Fu;
+    v = (v | (v << 4)) & 0x000C30C3u;
+    v = (v | (v << 2)) & 0x00249249u;
+    return v;
+}
+
 // Two phases per query (one lane each):
 //  1. an UPPER bound U on the nearest distance from the coarse grid: shells of coarse cells are
 //     searched until one holds a representative point; U = smallest exact distance to those;
@@ -179,7 +200,7 @@ __global__ __launch_bounds__(256) void k_nn_scatter(const float *__restrict__ pt
 __global__ __launch_bounds__(256) void k_nn_query(const float *__restrict__ queries, int N, const NNGrid *__restrict__ gp,
                                                   const int *__restrict__ start, const float4 *__restrict__ sorted,
                                                   const int *__restrict__ rep, const float *__restrict__ pts, int M, int *result,
-                                                  int *farList, int *nFar)
+                                                  unsigned *farKey, unsigned notFar)
 {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= N) return;
@@ -187,7 +208,19 @@ __global__ __launch_bounds__(256) void k_nn_query(const float *__restrict__ quer
     const int G = g.G, Gc = g.Gc;
     const float qx = queries[q * 3], qy = queries[q * 3 + 1], qz = queries[q * 3 + 2];
     const float qq[3] = {qx, qy, qz};
+    farKey[q] = notFar;
     if (!(fabsf(qx) < INFINITY && fabsf(qy) < INFINITY && fabsf(qz) < INFINITY)) { result[q] = 0; return; }   // every d is inf/NaN
+    // a far query is keyed by the Morton code of its (clamped) fine cell: sorted by it, the lanes of k_nn_far are neighbours
+    auto far_key = [&]() {
+        unsigned key = 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float f = floorf((qq[k] - g.o[k]) * g.inv[k]);
+            f = fminf(fmaxf(f, -1.f), (float)G) + 1.f;              // 0 .. G+1 <= 161: eight bits
+            key |= spread3((unsigned)f) << k;
+        }
+        return key;
+    };
     auto dist = [&](float px, float py, float pz) {
         const float dx = px - qx, dy = py - qy, dz = pz - qz;
         float d = 0.f;
@@ -250,7 +283,7 @@ __global__ __launch_bounds__(256) void k_nn_query(const float *__restrict__ quer
     float best = 1e20f;                                             // :28
     int besti = 0;
     if (!(U < INFINITY)) {                                           // nothing within one coarse ring: far (or no finite point)
-        farList[atomicAdd(nFar, 1)] = q;
+        farKey[q] = far_key();
         return;
     }
     U = fminf(U, 1e20f);                                            // nothing farther than the initial best can win
@@ -270,10 +303,11 @@ __global__ __launch_bounds__(256) void k_nn_query(const float *__restrict__ quer
     };
     const float R2 = R * R;
     // A query whose ball spans many cell rows pays a dependent lookup per row and gathers points at
-    // ~4x the per-point cost of the streaming scan (measured: 80k uniform queries against 100k
-    // points on a sphere, 12-16 ms through rows vs 5.5 ms streaming): hand it to k_nn_far.
-    if ((long long)(hi[2] - lo[2] + 1) * (hi[1] - lo[1] + 1) > 100) {
-        farList[atomicAdd(nFar, 1)] = q;
+    // ~4x the per-point cost of a wave-uniform stream: hand it to the k_nn_far_* kernels.  (Threshold measured on 80k
+    // queries against 100k points on a sphere: uniform queries 1.03 / 1.39 / 2.66 ms for 9 / 25 / 100 rows; queries sampled
+    // on a nearby surface 0.59 / 0.47 / 0.47 ms — the far path has ~0.15 ms of dependent-load latency of its own.)
+    if ((long long)(hi[2] - lo[2] + 1) * (hi[1] - lo[1] + 1) > kFarRows) {
+        farKey[q] = far_key();
         return;
     }
     for (int cz = lo[2]; cz <= hi[2]; ++cz) {
@@ -302,39 +336,250 @@ __global__ __launch_bounds__(256) void k_nn_query(const float *__restrict__ quer
     result[q] = besti;
 }
 
-// far queries: the streaming scan of k_nn over the listed queries only
-__global__ __launch_bounds__(256) void k_nn_far(const float *__restrict__ queries, const float *__restrict__ points, int M,
-                                                const int *__restrict__ farList, const int *__restrict__ nFar, int *result)
+// compact helper tables for k_nn_far: the representatives as (x, y, z, index) records and the first sorted slot of
+// every cell row; both padded so that k_nn_far can read them eight entries at a time
+constexpr int kNNBatch = 8;
+
+__global__ __launch_bounds__(256) void k_nn_far_tables(const int *__restrict__ rep, const float *__restrict__ pts, int Gc3,
+                                                       const int *__restrict__ start, int G, float4 *repList, int *nRep,
+                                                       int *rowStart, float4 *sorted)
 {
-    const int n = *nFar;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (blockIdx.x * blockDim.x >= n) return;                      // whole block idle
-    const bool live = i < n;
-    const int q = farList[live ? i : 0];
-    const float qx = queries[q * 3], qy = queries[q * 3 + 1], qz = queries[q * 3 + 2];
-    float best = 1e20f;
-    int besti = 0;
-    int j = 0;
-    for (; j + 4 <= M; j += 4) {                                    // 12 floats per scalar-load batch, like k_nn
+    if (i < Gc3) {
+        const int r = rep[i];
+        const unsigned long long m = __ballot(r >= 0);
+        int base = 0;
+        if ((threadIdx.x & 63) == 0 && m) base = atomicAdd(nRep, __popcll(m));
+        base = __shfl(base, 0);
+        if (r >= 0)
+            repList[base + __popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull))] =
+                make_float4(pts[r * 3], pts[r * 3 + 1], pts[r * 3 + 2], __int_as_float(r));
+    }
+    const int total = start[G * G * G];
+    if (i < G * G + 2 * kNNBatch) rowStart[i] = i < G * G ? start[i * G] : total;
+    if (i < 64) sorted[total + i] = make_float4(INFINITY, INFINITY, INFINITY, 0.f);   // tile padding (never considered)
+}
+
+__global__ __launch_bounds__(64) void k_nn_far_pad(float4 *repList, const int *__restrict__ nRep)
+{
+    repList[*nRep + threadIdx.x] = make_float4(INFINITY, INFINITY, INFINITY, 0.f);   // tile padding (64 threads)
+}
+
+// Far queries (answer farther than one coarse ring, or a ball over more than kFarRows cell rows).  One lane per query,
+// the queries SORTED by the Morton code of their cell so that a wave holds 64 neighbours, and everything a wave reads
+// is wave-uniform (scalar loads, eight records per batch, points as SGPR operands — the vector memory pipe is idle):
+//   k_nn_far_bound  A. every coarse cell's representative point bounds the answer from above;
+//                   B. the points of the coarse cells holding the lanes' best representatives tighten the bound;
+//   k_nn_far_rows   C. the cell rows (cz,cy) are visited; a row is skipped when its slab is farther than the current
+//                      best of EVERY lane (same certified margins as k_nn_query), otherwise the x-range the lanes can
+//                      still need is streamed;
+//   k_nn_far_final  scatters the answers back to query order.
+// Any point is a valid candidate for any lane (reading a few records past a row's end is harmless), and candidates are
+// combined as the 64-bit word (distance bits, index) under min — distances are non-negative, so that is the
+// lexicographic (distance, index) minimum = the reference's first strict minimum of an ascending scan — first in
+// registers, then across the four waves of a block in LDS, then across blocks with one atomicMin per lane.
+// A group of 64 queries at the centre of a sphere needs every point: 6.4 M distance evaluations that must not land on
+// one CU, so the rows of every group are split over kFarSlices blocks.
+// (Measured history, 80,640 uniform queries against 100,000 points on a sphere, plain scan 5.5 ms: far list appended
+// with one same-address atomic per query and every far query scanning ALL points 7.2 ms; pruned rows, one wave per 64
+// queries, one scalar load per record 14.3 ms; batches of eight and 4 / 16 waves per group 4.5 / 2.4 ms; A and B shared
+// between the waves 1.55 ms — the group that needs every point then kept one CU busy for 1 ms.)
+#ifndef NN_FAR_SLICES
+#define NN_FAR_SLICES 8
+#endif
+constexpr int kFarSlices = NN_FAR_SLICES;   // blocks per group of 64 far queries in k_nn_far_rows
+constexpr int kFarWaves = 4;            // waves per block; they split the block's records
+
+struct FarLane {
+    float qx, qy, qz, best;
+    int besti;
+    __device__ __forceinline__ void consider(const float4 p)
+    {
+        const float dx = p.x - qx, dy = p.y - qy, dz = p.z - qz;
+        const int idx = __float_as_int(p.w);
+        float d = 0.f;
+        d += dx * dx;                                               // nearest_neighbor_cuda.cu:42
+        d += dy * dy;                                               // :44
+        d += dz * dz;                                               // :46
+        if (d < best || (d == best && idx < besti && best < 1e20f)) { best = d; besti = idx; }
+    }
+    // records [s, e) of a wave-uniform table (and up to seven more: the tables are padded with d = inf records)
+    __device__ __forceinline__ void stream(const float4 *__restrict__ src, int s, int e)
+    {
+        for (int j = s; j < e; j += kNNBatch) {
+            float4 p[kNNBatch];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float dx = points[(j + k) * 3] - qx, dy = points[(j + k) * 3 + 1] - qy, dz = points[(j + k) * 3 + 2] - qz;
-            float d = 0.f;
-            d += dx * dx;
-            d += dy * dy;
-            d += dz * dz;
-            if (d < best) { best = d; besti = j + k; }
+            for (int k = 0; k < kNNBatch; ++k) p[k] = src[j + k];
+#pragma unroll
+            for (int k = 0; k < kNNBatch; ++k) consider(p[k]);
         }
     }
-    for (; j < M; ++j) {
-        const float dx = points[j * 3] - qx, dy = points[j * 3 + 1] - qy, dz = points[j * 3 + 2] - qz;   // wave-uniform -> s_load
-        float d = 0.f;
-        d += dx * dx;
-        d += dy * dy;
-        d += dz * dz;
-        if (d < best) { best = d; besti = j; }
+    __device__ __forceinline__ unsigned long long packed() const
+    {
+        return ((unsigned long long)(unsigned)__float_as_int(best) << 32) | (unsigned)besti;
     }
-    if (live) result[q] = besti;
+    __device__ __forceinline__ void unpack(unsigned long long v)
+    {
+        best = __int_as_float((int)(v >> 32));
+        besti = (int)(unsigned)v;
+    }
+    // every wave of the block leaves with the block's best answer so far
+    __device__ __forceinline__ void share(unsigned long long (*s_pack)[64], int part, int lane)
+    {
+        s_pack[part][lane] = packed();
+        __syncthreads();
+        unsigned long long v = s_pack[0][lane];
+#pragma unroll
+        for (int w = 1; w < kFarWaves; ++w) v = min(v, s_pack[w][lane]);
+        unpack(v);
+        __syncthreads();
+    }
+};
+
+__device__ __forceinline__ int far_count(const unsigned *__restrict__ farKeyS, int N, unsigned notFar)
+{
+    int lo = 0, hi = N;                                            // first sorted key == notFar
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (farKeyS[mid] < notFar) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(kFarWaves * 64) void k_nn_far_bound(const float *__restrict__ queries, const NNGrid *__restrict__ gp,
+                                                                 const int *__restrict__ start, const float4 *__restrict__ sorted,
+                                                                 const float4 *__restrict__ repList, const int *__restrict__ nRepP,
+                                                                 const float *__restrict__ pts, int N,
+                                                                 const unsigned *__restrict__ farKeyS, const unsigned *__restrict__ farList,
+                                                                 unsigned long long *bound, int *nFar, unsigned notFar)
+{
+    __shared__ unsigned long long s_pack[kFarWaves][64];
+    const int n = far_count(farKeyS, N, notFar);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *nFar = n;
+    const int lane = threadIdx.x & 63;
+    const int part = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform for the compiler too: scalar loads below
+    const int i = blockIdx.x * 64 + lane;
+    if (blockIdx.x * 64 >= n) return;                              // whole block idle
+    const int q = (int)farList[i < n ? i : n - 1];                 // idle lanes shadow the last far query
+    const NNGrid g = *gp;
+    const int G = g.G, Gc = g.Gc;
+    FarLane L;
+    L.qx = queries[q * 3]; L.qy = queries[q * 3 + 1]; L.qz = queries[q * 3 + 2];
+    L.best = 1e20f;                                                 // nearest_neighbor_cuda.cu:28
+    L.besti = 0;
+    // ---- A: representatives, one batch per wave and turn
+    {
+        const int nRep = *nRepP;
+        for (int j = part * kNNBatch; j < nRep; j += kFarWaves * kNNBatch) L.stream(repList, j, j + kNNBatch);
+    }
+    L.share(s_pack, part, lane);
+    // ---- B: the coarse cells of the lanes' best representatives (at most four distinct ones per block); a coarse cell
+    //         is 4 x 4 rows of four cells: four rows per wave
+    {
+        const bool have = L.best < 1e20f;
+        const int bi = have ? L.besti : 0;
+        const float bx = pts[bi * 3], by = pts[bi * 3 + 1], bz = pts[bi * 3 + 2];
+        const int mine = ((nn_cell(bz, g.o[2], g.inv[2], G) / kNNCoarse) * Gc + nn_cell(by, g.o[1], g.inv[1], G) / kNNCoarse) * Gc +
+                         nn_cell(bx, g.o[0], g.inv[0], G) / kNNCoarse;
+        unsigned long long todo = __ballot(have);
+        for (int round = 0; round < 4 && todo; ++round) {
+            const int c = __builtin_amdgcn_readlane(mine, __ffsll((long long)todo) - 1);
+            todo &= ~__ballot(mine == c);
+            const int x0 = (c % Gc) * kNNCoarse, x1 = min(x0 + kNNCoarse - 1, G - 1);
+            const int cy0 = ((c / Gc) % Gc) * kNNCoarse, cz = (c / (Gc * Gc)) * kNNCoarse + part;
+            int se[2 * kNNCoarse];
+#pragma unroll
+            for (int k = 0; k < kNNCoarse; ++k) {
+                const int row = (min(cz, G - 1) * G + min(cy0 + k, G - 1)) * G;
+                se[2 * k] = start[row + x0]; se[2 * k + 1] = start[row + x1 + 1];
+            }
+#pragma unroll
+            for (int k = 0; k < kNNCoarse; ++k)
+                if (cz < G && cy0 + k < G) L.stream(sorted, se[2 * k], se[2 * k + 1]);
+        }
+    }
+    L.share(s_pack, part, lane);
+    if (part == 0 && i < n) bound[i] = L.packed();
+}
+
+__global__ __launch_bounds__(kFarWaves * 64) void k_nn_far_rows(const float *__restrict__ queries, const NNGrid *__restrict__ gp,
+                                                                const int *__restrict__ start, const float4 *__restrict__ sorted,
+                                                                const int *__restrict__ rowStart, const int *__restrict__ nFar,
+                                                                const unsigned *__restrict__ farList, unsigned long long *bound)
+{
+    __shared__ unsigned long long s_pack[kFarWaves][64];
+    const int n = *nFar;
+    const int lane = threadIdx.x & 63;
+    const int part = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = blockIdx.x * 64 + lane;
+    if (blockIdx.x * 64 >= n) return;                              // whole block idle
+    const int ii = i < n ? i : n - 1;                              // idle lanes shadow the last far query
+    const int q = (int)farList[ii];
+    const NNGrid g = *gp;
+    const int G = g.G;
+    FarLane L;
+    L.qx = queries[q * 3]; L.qy = queries[q * 3 + 1]; L.qz = queries[q * 3 + 2];
+    L.unpack(bound[ii]);                                           // as k_nn_far_bound left it (other slices may have improved it)
+    const float qq[3] = {L.qx, L.qy, L.qz};
+    auto slab = [&](int k, int c) -> float {                        // as in k_nn_query
+        if (!(g.cs[k] < INFINITY)) return 0.f;
+        const float l = g.o[k] + (float)c * g.cs[k] - g.slack[k], h = g.o[k] + (float)(c + 1) * g.cs[k] + g.slack[k];
+        return fmaxf(fmaxf(l - qq[k], qq[k] - h), 0.f);
+    };
+    const int nb = (G + kNNBatch - 1) / kNNBatch;                   // work item = (layer cz, batch of eight rows cy0..cy0+7)
+    for (int item = blockIdx.y * kFarWaves + part; item < G * nb; item += kFarWaves * kFarSlices) {
+        const int cz = item / nb, cy0 = (item % nb) * kNNBatch;
+        const float dz = slab(2, cz);
+        if (!__any(!(L.best * 1.00003f - dz * dz < 0.f))) continue; // the whole layer is out of reach of every lane
+        int rs[kNNBatch + 1];
+#pragma unroll
+        for (int k = 0; k <= kNNBatch; ++k) rs[k] = rowStart[cz * G + cy0 + k];   // padded: reads past G*G return the total
+        // first the slice [s, e) of each of the eight rows that some lane can still need (lane k of vs/ve keeps row k's;
+        // the eight pairs of cell-start loads are independent), then ONE copy of the streaming loop walks them
+        int vs = 0, ve = 0;
+#pragma unroll
+        for (int k = 0; k < kNNBatch; ++k) {
+            const int cy = cy0 + k;
+            int s = 0, e = 0;
+            if (cy < G && rs[k] != rs[k + 1]) {
+                const float dy = slab(1, cy);
+                // squared reach, inflated for the fp32 rounding of d and of the cell map (k_nn_query: R = sqrt(U) * 1.00001)
+                const float rem = L.best * 1.00003f - dy * dy - dz * dz;
+                const bool need = !(rem < 0.f);
+                if (__any(need)) {
+                    s = rs[k]; e = rs[k + 1];
+                    if (e - s > 3 * kNNBatch) {                     // long row: only the x-range the lanes can reach
+                        const float rx = sqrtf(fmaxf(rem, 0.f)) * 1.00001f;
+                        int x0 = need ? nn_cell(L.qx - rx - g.slack[0], g.o[0], g.inv[0], G) : G - 1;
+                        int x1 = need ? nn_cell(L.qx + rx + g.slack[0], g.o[0], g.inv[0], G) : 0;
+                        if (need && !(rx < INFINITY)) { x0 = 0; x1 = G - 1; }
+#pragma unroll
+                        for (int off = 32; off > 0; off >>= 1) {
+                            x0 = min(x0, __shfl_xor(x0, off));
+                            x1 = max(x1, __shfl_xor(x1, off));
+                        }
+                        x0 = __builtin_amdgcn_readfirstlane(x0);
+                        x1 = __builtin_amdgcn_readfirstlane(x1);
+                        const int row = (cz * G + cy) * G;
+                        s = start[row + x0]; e = start[row + x1 + 1];
+                    }
+                }
+            }
+            vs = lane == k ? s : vs;
+            ve = lane == k ? e : ve;
+        }
+#pragma unroll 1
+        for (int k = 0; k < kNNBatch; ++k) L.stream(sorted, __builtin_amdgcn_readlane(vs, k), __builtin_amdgcn_readlane(ve, k));
+    }
+    L.share(s_pack, part, lane);
+    if (part == 0 && i < n) atomicMin(&bound[i], L.packed());
+}
+
+__global__ __launch_bounds__(256) void k_nn_far_final(const unsigned long long *__restrict__ bound, const int *__restrict__ nFar,
+                                                      const unsigned *__restrict__ farList, int *result)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < *nFar) result[farList[i]] = (int)(unsigned)bound[i];
 }
 
 // ---------------------------------------------------------------------------- A8 face edge adjacency
@@ -1119,7 +1364,11 @@ extern "C" size_t deftet_nn_index_workspace_bytes(int B, int N, int M)
 {
     const int G = nn_pick_G(M);
     const size_t nc = (size_t)G * G * G + 1;
-    return nc * 4 * 3 + (size_t)(M > 0 ? M : 0) * (8 + 16) + (size_t)(N > 0 ? N : 0) * 4 + nc * 8 + ((size_t)2 << 20);
+    size_t sortTmp = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, sortTmp, (unsigned *)nullptr, (unsigned *)nullptr, rocprim::counting_iterator<unsigned>(0),
+                                    (unsigned *)nullptr, (size_t)(N > 0 ? N : 0), 0, 25, (hipStream_t) nullptr);
+    return nc * 4 * 3 + (size_t)(M > 0 ? M : 0) * (8 + 16) + (size_t)(N > 0 ? N : 0) * 20 + nc * 8 + nc + 4096 + (size_t)G * G * 4 + sortTmp +
+           ((size_t)2 << 20);
 }
 
 // workspace == NULL: the scalar-stream brute force; otherwise the grid search (both exact).
@@ -1137,15 +1386,19 @@ extern "C" int deftet_nn_index_f32(const float *queries, const float *points, in
     }
     DEFTET_CHECK_ARG(((uintptr_t)workspace & 255) == 0 && wsb >= deftet_nn_index_workspace_bytes(B, N, M),
                      "workspace misaligned or too small");
-    const int G = nn_pick_G(M);
+    const int G = nn_pick_G(M), keyBits = nn_far_key_bits(G);
     const size_t nc = (size_t)G * G * G + 1;
     Arena A(workspace, wsb);
     float *part = A.take<float>(kNNBlocks * 6);
     NNGrid *grid = A.take<NNGrid>(1);
     int *cells = A.take<int>(nc), *start = A.take<int>(nc), *rep = A.take<int>(nc);
     int2 *pcell = A.take<int2>(M);
-    float4 *sorted = A.take<float4>(M);
-    int *farList = A.take<int>((size_t)N + 1), *nFar = A.take<int>(4);
+    float4 *sorted = A.take<float4>((size_t)M + 64);                                  // k_nn_far reads whole 64-record tiles
+    float4 *repList = A.take<float4>(nc / (kNNCoarse * kNNCoarse) + 64 + 64);         // >= Gc^3 + pad
+    int *rowStart = A.take<int>((size_t)G * G + 2 * kNNBatch), *nRep = A.take<int>(4);
+    unsigned *farKey = A.take<unsigned>((size_t)N + 1), *farKeyS = A.take<unsigned>((size_t)N + 1), *farList = A.take<unsigned>((size_t)N + 1);
+    unsigned long long *bound = A.take<unsigned long long>((size_t)N + 1);
+    int *nFar = A.take<int>(4);
     void *tmp = A.base + align_up(A.off, 256);
     const size_t left = wsb - align_up(A.off, 256);
     for (int b = 0; b < B; ++b) {
@@ -1161,10 +1414,25 @@ extern "C" int deftet_nn_index_f32(const float *queries, const float *points, in
         e = rocprim::exclusive_scan(tmp, need, cells, start, 0, nc, rocprim::plus<int>(), st);
         if (e != hipSuccess) return set_error(DEFTET_ELAUNCH, "exclusive_scan: %s", hipGetErrorString(e));
         DEFTET_LAUNCH(k_nn_scatter, dim3((M + 255) / 256), dim3(256), st, pb, M, pcell, start, sorted);
-        DEFTET_HIP(hipMemsetAsync(nFar, 0, 16, st));
         DEFTET_LAUNCH(k_nn_query, dim3((N + 255) / 256), dim3(256), st, qb, N, grid, start, sorted, rep, pb, M,
-                      result + (size_t)b * N, farList, nFar);
-        DEFTET_LAUNCH(k_nn_far, dim3((N + 255) / 256), dim3(256), st, qb, pb, M, farList, nFar, result + (size_t)b * N);
+                      result + (size_t)b * N, farKey, 1u << keyBits);
+        need = 0;
+        e = rocprim::radix_sort_pairs(nullptr, need, farKey, farKeyS, rocprim::counting_iterator<unsigned>(0), farList, (size_t)N, 0, keyBits + 1, st);
+        if (e != hipSuccess || need > left) return set_error(DEFTET_ELAUNCH, "radix_sort temp");
+        e = rocprim::radix_sort_pairs(tmp, need, farKey, farKeyS, rocprim::counting_iterator<unsigned>(0), farList, (size_t)N, 0, keyBits + 1, st);
+        if (e != hipSuccess) return set_error(DEFTET_ELAUNCH, "radix_sort_pairs: %s", hipGetErrorString(e));
+        const int Gc = (G + kNNCoarse - 1) / kNNCoarse, Gc3 = Gc * Gc * Gc, nt = std::max(Gc3, G * G + 2 * kNNBatch);
+        DEFTET_HIP(hipMemsetAsync(nRep, 0, 16, st));
+        DEFTET_LAUNCH(k_nn_far_tables, dim3((nt + 255) / 256), dim3(256), st, (const int *)rep, pb, Gc3, (const int *)start, G, repList, nRep,
+                      rowStart, sorted);
+        DEFTET_LAUNCH(k_nn_far_pad, dim3(1), dim3(64), st, repList, (const int *)nRep);
+        DEFTET_LAUNCH(k_nn_far_bound, dim3((N + 63) / 64), dim3(kFarWaves * 64), st, qb, grid, start, (const float4 *)sorted,
+                      (const float4 *)repList, (const int *)nRep, pb, N, (const unsigned *)farKeyS, (const unsigned *)farList, bound, nFar,
+                      1u << keyBits);
+        DEFTET_LAUNCH(k_nn_far_rows, dim3((N + 63) / 64, kFarSlices), dim3(kFarWaves * 64), st, qb, grid, start, (const float4 *)sorted,
+                      (const int *)rowStart, (const int *)nFar, (const unsigned *)farList, bound);
+        DEFTET_LAUNCH(k_nn_far_final, dim3((N + 255) / 256), dim3(256), st, (const unsigned long long *)bound, (const int *)nFar,
+                      (const unsigned *)farList, result + (size_t)b * N);
     }
     return DEFTET_OK;
 }

@@ -77,6 +77,23 @@ def test_nn_index_grid_adversarial(cuda, oracle, seed):
         assert np.array_equal(got, want)
 
 
+def test_nn_index_far_queries_full_size(cuda):
+    """80,640 queries spread over the cube against 100,000 points on a sphere: most queries take the far path
+    (sorted by cell, rows split over blocks, answers combined with a 64-bit atomicMin) and must equal the plain scan;
+    also with duplicated points (ties resolved towards the lower index across blocks)."""
+    from deftet_amd import hip_ops
+    rng = np.random.default_rng(11)
+    d = rng.normal(size=(100000, 3))
+    gt = (0.3 * d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    gt[50000:60000] = gt[:10000]                                     # exact duplicates far apart in index
+    p = torch.from_numpy(gt).to(cuda)[None]
+    q = torch.from_numpy(rng.uniform(-0.3, 0.3, (1, 80640, 3)).astype(np.float32)).to(cuda)
+    q[0, :64] = 0.0                                                  # one group needs every point
+    assert torch.equal(hip_ops.nn_index(q, p), hip_ops.nn_index(q, p, brute=True))
+    far_out = torch.from_numpy(rng.uniform(-5, 5, (1, 20000, 3)).astype(np.float32)).to(cuda)   # mostly outside the grid
+    assert torch.equal(hip_ops.nn_index(far_out, p), hip_ops.nn_index(far_out, p, brute=True))
+
+
 def test_nn_index_properties_full_size(cuda):
     """100k GT points (dataloader.py:169) x 60k queries: idempotence + optimality property."""
     g = torch.Generator(device=cuda).manual_seed(1)
