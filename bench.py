@@ -128,6 +128,8 @@ class PitWorkload:
             cond, w, occ, hits = hip_ops.point_in_tet(d["tet"], d["pts"], want_bary=True, pred_bxt=d["pred"], want_hits=True,
                                                       algo=self.algo, prepared=pq)
             nxt = self.sets[(i + 1) % len(self.sets)]
+            # (making the side stream wait for this step's forward, so that the sort overlaps the HBM-bound backward instead
+            # of the traversal, was measured: 0.257-0.259 vs 0.247-0.248 ms/step)
             with torch.cuda.stream(self.side_stream()):
                 self._pq = {i + 1: hip_ops.prepare_queries(nxt["pts"], self.T, algo=self.algo)}
         else:
