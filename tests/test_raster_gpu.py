@@ -106,6 +106,62 @@ def test_backward_matches_fp64_autograd(cuda, oracle):
     assert (txy.grad.cpu()[0][~hit] == 0).all() and (tff.grad.cpu()[0][~hit] == 0).all()
 
 
+@pytest.mark.parametrize("D,B", [(3, 2), (6, 1), (9, 2)])
+def test_backward_other_feature_widths_and_batches(cuda, oracle, D, B):
+    """run-time feature width (the D != 4 kernel, several 4-channel chunks) and B > 1 against fp64 autograd"""
+    from deftet_amd.render import deftet_sparse_render
+    rng = np.random.default_rng(D * 10 + B)
+    fz, fxy, _ = projected_grid(6)
+    pix, rngs = pixel_grid(40)
+    rep = lambda a: np.concatenate([a * (1 + 0.03 * b) for b in range(B)], 0)
+    fz, fxy, pix = rep(fz), rep(fxy), rep(pix * 0.6)
+    rngs = np.concatenate([rngs] * B, 0)
+    ff = rng.random((B, fxy.shape[1], 3, D)).astype(np.float32)
+    tp, tr, tz = (torch.from_numpy(x).to(cuda) for x in (pix, rngs, fz))
+    txy = torch.from_numpy(fxy).to(cuda).requires_grad_(True)
+    tff = torch.from_numpy(ff).to(cuda).requires_grad_(True)
+    feat, face = deftet_sparse_render(tp, tr, tz, txy, tff, knum=40)
+    go = torch.rand(feat.shape, device=cuda, generator=torch.Generator(device=cuda).manual_seed(3))
+    gxy, gff = torch.autograd.grad(feat, (txy, tff), go)
+    xy64 = txy.detach().double().requires_grad_(True)
+    ff64 = tff.detach().double().requires_grad_(True)
+    feat64 = oracle.sparse_render_torch(tp.double(), xy64, ff64, face)
+    wxy, wff = torch.autograd.grad(feat64, (xy64, ff64), go.double())
+    for got, want in ((gxy, wxy), (gff, wff)):
+        assert (got.double() - want).abs().max().item() <= 2e-4 * want.abs().max().item()
+    assert (face >= 0).sum().item() > 1000 * B
+
+
+def test_backward_face_with_thousands_of_hits(cuda, oracle):
+    """two big triangles covering a 96 x 96 pixel grid: 9,216 hits per face, i.e. runs of sorted hits that span nine
+    blocks of the backward kernel (partial sums meet through float atomics), next to small faces"""
+    from deftet_amd.render import deftet_sparse_render
+    rng = np.random.default_rng(5)
+    pix, rngs = pixel_grid(96)
+    big = np.array([[[-3000.0, -3000.0], [5000.0, -3000.0], [-3000.0, 5000.0]],
+                    [[-2500.0, -3500.0], [6000.0, -2000.0], [-3500.0, 6000.0]]], np.float32)
+    small = (rng.uniform(-900, 900, (300, 1, 2)) + rng.uniform(-60, 60, (300, 3, 2))).astype(np.float32)
+    fxy = np.concatenate([small[:150], big, small[150:]], 0)[None]
+    F = fxy.shape[1]
+    fz = rng.uniform(-900, -100, (1, F, 3)).astype(np.float32)
+    ff = rng.random((1, F, 3, 4)).astype(np.float32)
+    tp, tr, tz = (torch.from_numpy(x).to(cuda) for x in (pix, rngs, fz))
+    txy = torch.from_numpy(fxy).to(cuda).requires_grad_(True)
+    tff = torch.from_numpy(ff).to(cuda).requires_grad_(True)
+    feat, face = deftet_sparse_render(tp, tr, tz, txy, tff, knum=16)
+    assert (face == 150).sum().item() == 96 * 96 and (face == 151).sum().item() == 96 * 96
+    go = torch.rand(feat.shape, device=cuda, generator=torch.Generator(device=cuda).manual_seed(4))
+    gxy, gff = torch.autograd.grad(feat, (txy, tff), go)
+    xy64 = txy.detach().double().requires_grad_(True)
+    ff64 = tff.detach().double().requires_grad_(True)
+    feat64 = oracle.sparse_render_torch(tp.double(), xy64, ff64, face)
+    wxy, wff = torch.autograd.grad(feat64, (xy64, ff64), go.double())
+    for got, want in ((gxy, wxy), (gff, wff)):
+        for f in (150, 151):
+            assert (got[0, f].double() - want[0, f]).abs().max().item() <= 1e-4 * want[0, f].abs().max().item()
+        assert (got.double() - want).abs().max().item() <= 2e-4 * want.abs().max().item()
+
+
 def test_backward_baseline_config_fp64(cuda, oracle):
     """BASELINE configs[4] backward (15 M hits, faces with more than 64 hits straddle waves): fp64 autograd of the
     same interpolation on the same face indices, evaluated on the GPU."""
