@@ -296,17 +296,26 @@ __global__ __launch_bounds__(256) void k_pix_raster(const float *__restrict__ pi
     const float zmin = rng[p * 2], zmax = rng[p * 2 + 1];
     int nh = live ? 0 : knum;                                       // dead lanes count as full
     int4 *out = hits + (size_t)p * knum;
-    auto test = [&](int f, float ax, float ay, float bx, float by, float cx, float cy, float az, float bz, float cz) {
+    // The face-only terms (m, pp, n, q, den = k3 + eps) are computed once by the lane that loaded the face and broadcast;
+    // same fp32 operations as the contract, evaluated in another lane.
+    // (A certified wave-level early out before the two divisions — every lane surely outside by the signs of k1, k2 and
+    // k1 + k2 - den with rounding margins — was measured: it rarely holds for all 64 pixels and its dozen instructions
+    // made the kernel slower, 850 vs 739 us.)
+    auto test = [&](int f, float ax, float ay, float m, float pp, float n, float q, float den, float az, float bz, float cz) {
         if (nh >= knum) return;
-        const float m = bx - ax, pp = by - ay, n = cx - ax, q = cy - ay, s_ = px - ax, t = py - ay;
-        const float k1 = s_ * q - n * t, k2 = m * t - s_ * pp, k3 = m * q - n * pp;
-        const float den = k3 + eps;
+        const float s_ = px - ax, t = py - ay;
+        const float k1 = s_ * q - n * t, k2 = m * t - s_ * pp;
         const float w1 = k1 / den, w2 = k2 / den, w0 = 1 - w1 - w2;
         if (!(w0 >= 0 && w1 >= 0 && w2 >= 0)) return;
         const float z = (w0 * az + w1 * bz) + w2 * cz;
         if (!(z >= zmin && z <= zmax)) return;
         out[nh] = make_int4(f, __float_as_int(z), __float_as_int(w1), __float_as_int(w2));
         ++nh;
+    };
+    auto face_terms = [&](float2 a, float2 b, float2 c, float &m, float &pp, float &n, float &q, float &den) {
+        m = b.x - a.x; pp = b.y - a.y; n = c.x - a.x; q = c.y - a.y;
+        const float k3 = m * q - n * pp;
+        den = k3 + eps;
     };
     const bool allFaces = tile == nTilesCap;                        // the non-tame pixels: every face, no lists
     const int ib = allFaces ? 0 : tileStart[tile], ie = allFaces ? F : tileStart[tile + 1];
@@ -318,7 +327,9 @@ __global__ __launch_bounds__(256) void k_pix_raster(const float *__restrict__ pi
             if (f >= fLimit) break;
             const float2 a = reinterpret_cast<const float2 *>(fxy)[f * 3], b = reinterpret_cast<const float2 *>(fxy)[f * 3 + 1],
                          c = reinterpret_cast<const float2 *>(fxy)[f * 3 + 2];
-            test(f, a.x, a.y, b.x, b.y, c.x, c.y, fz[f * 3], fz[f * 3 + 1], fz[f * 3 + 2]);
+            float m, pp, n, q, den;
+            face_terms(a, b, c, m, pp, n, q, den);
+            test(f, a.x, a.y, m, pp, n, q, den, fz[f * 3], fz[f * 3 + 1], fz[f * 3 + 2]);
             ++j;
         }
     };
@@ -330,25 +341,42 @@ __global__ __launch_bounds__(256) void k_pix_raster(const float *__restrict__ pi
         cxl = fminf(cxl, __shfl_xor(cxl, off)); cxh = fmaxf(cxh, __shfl_xor(cxh, off));
         cyl = fminf(cyl, __shfl_xor(cyl, off)); cyh = fmaxf(cyh, __shfl_xor(cyh, off));
     }
+    // Software pipeline over the list, 64 entries per stage: while batch k is tested, the face data of batch k+1 (whose
+    // list entries arrived during batch k-1) and the list entries of batch k+2 are in flight — the two dependent round
+    // trips per batch were exposed with only ~4.5 waves per SIMD.
+    struct Batch { float2 a, b, c; float az, bz, cz; };
+    auto load_entry = [&](int idx) { return idx < ie ? (allFaces ? idx : list[idx]) : -1; };
+    auto load_faces = [&](int fm) {
+        Batch d;
+        const int f = fm < 0 ? 0 : fm;                               // idle lanes read face 0 (F > 0 whenever ib < ie)
+        d.a = reinterpret_cast<const float2 *>(fxy)[f * 3]; d.b = reinterpret_cast<const float2 *>(fxy)[f * 3 + 1];
+        d.c = reinterpret_cast<const float2 *>(fxy)[f * 3 + 2];
+        d.az = fz[f * 3]; d.bz = fz[f * 3 + 1]; d.cz = fz[f * 3 + 2];
+        return d;
+    };
+    int fmCur = -1, fmNext = -1;
+    Batch cur = {}, nxt = {};
+    if (ib < ie) {
+        fmCur = load_entry(ib + lane);
+        cur = load_faces(fmCur);
+        fmNext = load_entry(ib + 64 + lane);
+    }
     for (int base = ib; base < ie; base += 64) {
         if (__all(nh >= knum)) break;
-        const int idx = base + lane;
-        const bool have = idx < ie;
-        const int fm = have ? (allFaces ? idx : list[idx]) : 0;
-        float2 a = make_float2(0.f, 0.f), b = a, c = a;
-        float az = 0.f, bz = 0.f, cz = 0.f;
-        bool cand = have;
-        if (have) {
-            a = reinterpret_cast<const float2 *>(fxy)[fm * 3]; b = reinterpret_cast<const float2 *>(fxy)[fm * 3 + 1];
-            c = reinterpret_cast<const float2 *>(fxy)[fm * 3 + 2];
-            az = fz[fm * 3]; bz = fz[fm * 3 + 1]; cz = fz[fm * 3 + 2];
-            if (!allFaces) {                                        // same enlarged box as face_box()
-                const float lox = fminf(a.x, fminf(b.x, c.x)), hix = fmaxf(a.x, fmaxf(b.x, c.x));
-                const float loy = fminf(a.y, fminf(b.y, c.y)), hiy = fmaxf(a.y, fmaxf(b.y, c.y));
-                const float mg = fmaxf(hix - lox, hiy - loy) * kMargin;
-                cand = !(hix + mg < cxl || lox - mg > cxh || hiy + mg < cyl || loy - mg > cyh);
-            }
+        if (base + 64 < ie) nxt = load_faces(fmNext);
+        const int fmAfter = load_entry(base + 128 + lane);
+        const int fm = fmCur;
+        const float2 a = cur.a, b = cur.b, c = cur.c;
+        const float az = cur.az, bz = cur.bz, cz = cur.cz;
+        bool cand = fm >= 0;
+        if (cand && !allFaces) {                                    // same enlarged box as face_box()
+            const float lox = fminf(a.x, fminf(b.x, c.x)), hix = fmaxf(a.x, fmaxf(b.x, c.x));
+            const float loy = fminf(a.y, fminf(b.y, c.y)), hiy = fmaxf(a.y, fmaxf(b.y, c.y));
+            const float mg = fmaxf(hix - lox, hiy - loy) * kMargin;
+            cand = !(hix + mg < cxl || lox - mg > cxh || hiy + mg < cyl || loy - mg > cyh);
         }
+        float fm_, fpp, fn, fq, fden;
+        face_terms(a, b, c, fm_, fpp, fn, fq, fden);
         unsigned long long todo = __ballot(cand);
         int since = 0;
         while (todo) {
@@ -356,10 +384,11 @@ __global__ __launch_bounds__(256) void k_pix_raster(const float *__restrict__ pi
             todo &= todo - 1;
             const int f = __builtin_amdgcn_readlane(fm, k);
             if (je > 0) wide_before(f);
-            test(f, bcast(a.x, k), bcast(a.y, k), bcast(b.x, k), bcast(b.y, k), bcast(c.x, k), bcast(c.y, k), bcast(az, k), bcast(bz, k),
-                 bcast(cz, k));
+            test(f, bcast(a.x, k), bcast(a.y, k), bcast(fm_, k), bcast(fpp, k), bcast(fn, k), bcast(fq, k), bcast(fden, k), bcast(az, k),
+                 bcast(bz, k), bcast(cz, k));
             if ((++since & 7) == 0 && __all(nh >= knum)) break;
         }
+        fmCur = fmNext; cur = nxt; fmNext = fmAfter;
     }
     if (je > 0) wide_before(0x7FFFFFFF);
     if (live) nhit[p] = nh;
