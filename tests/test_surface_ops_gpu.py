@@ -243,6 +243,34 @@ def test_tri_dist_grid_equals_scan_full_size(cuda):
     assert a[0].max().item() < 1e-3 and (a[1] >= 0).all()
 
 
+@pytest.mark.parametrize("scale", [1.3, 0.5, 2.5])
+def test_tri_dist_far_points_full_size(cuda, scale):
+    """points 30 % outside / halfway inside / far outside the surface (early training): nothing is settled by the two
+    shells, every point takes the far path (cell-ordered groups, certified row pruning, LDS bitset, 64-bit atomicMin
+    across blocks); must equal the streaming scan, also with duplicated faces (ties towards the lower index), two
+    shapes with different face counts and a few NaN / huge points"""
+    from deftet_amd import hip_ops
+    f0 = sphere_surface(70)
+    f1 = np.concatenate([f0[:1500], f0[:1500]], 0)                   # second shape: every face twice
+    F = max(f0.shape[0], f1.shape[0])
+    face = np.zeros((2, F, 3, 3), np.float32)
+    face[0, :f0.shape[0]] = f0
+    face[1, :f1.shape[0]] = f1
+    rng = np.random.default_rng(int(scale * 10))
+    d = rng.standard_normal((2, 30000, 3))
+    pts = (0.3 * scale * d / np.linalg.norm(d, axis=2, keepdims=True)).astype(np.float32)
+    pts[0, 5] = np.nan
+    pts[1, 7] = 3e7
+    pts[1, 100:164] = 0.0                                            # one group at the centre: every face within reach
+    nfb = torch.tensor([float(f0.shape[0]), float(f1.shape[0])], device=cuda)
+    tp, tf = torch.from_numpy(pts).to(cuda), torch.from_numpy(face).to(cuda)
+    a = hip_ops.tri_dist_fwd(tp, tf, nfb)
+    b = hip_ops.tri_dist_fwd(tp, tf, nfb, brute=True)
+    assert torch.equal(a[1], b[1])
+    assert torch.equal(a[0], b[0])
+    assert (a[1][1] < 1500).all()                                    # duplicates: the lower index wins
+
+
 @pytest.mark.parametrize("seed", [0, 1])
 def test_tri_dist_backward(cuda, oracle, seed, monkeypatch):
     from deftet_amd import hip_ops

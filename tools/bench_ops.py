@@ -82,6 +82,10 @@ def main():
     tbr = gpu_time(lambda: hip_ops.tri_dist_fwd(gt_d, face_d[None], nfb, brute=True), reps=3)
     emit(op="tri_dist_fwd", n_face=F, n_point=100000, gpu_ms=round(tg * 1e3, 3), gpu_brute_ms=round(tbr * 1e3, 3), cpu_ms=round(tc * 1e3, 1),
          cpu_kind="port (extrapolated from %d points)" % subp, cpu_cores=1, pairs_per_s=round(F * 1e5 / tg / 1e9, 2), unit="G point-triangle pairs/s")
+    far_d = gt_d * 1.3                                                # early training: the cloud 30 % off the predicted surface
+    tgf = gpu_time(lambda: hip_ops.tri_dist_fwd(far_d, face_d[None], nfb), reps=3)
+    emit(op="tri_dist_fwd", points="30 % outside the surface (far path)", n_face=F, n_point=100000, gpu_ms=round(tgf * 1e3, 3),
+         gpu_brute_ms=round(tbr * 1e3, 3), pairs_per_s=round(F * 1e5 / tgf / 1e9, 2), unit="G point-triangle pairs/s")
     dd, ff = hip_ops.tri_dist_fwd(gt_d, face_d[None], nfb)
     gg = torch.ones_like(dd)
     tg = gpu_time(lambda: hip_ops.tri_dist_bwd(gt_d, face_d[None], ff, gg))
