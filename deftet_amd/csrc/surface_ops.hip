@@ -1137,6 +1137,10 @@ __global__ __launch_bounds__(256) void k_tri_query_coop(const float *__restrict_
     // only from its CANONICAL cell, the lowest cell of the box it overlaps (per axis max(face's first
     // cell, box's first cell)) — one evaluation per distinct face instead of up to 8.
     // entries [s, e) of one cell (cx, cy, cz): cooperative load, canonical filter (ballot), broadcast
+    // reach2 / plo / phi (set per shell below): a regular face whose box is farther than sqrt(reach2) from the box of the
+    // wave's unsettled points cannot bring any of them under its certification threshold, so it is not evaluated here —
+    // either the lane is settled by a nearer face or it goes to the far path, which is exact.
+    float reach2 = INFINITY, plo[3] = {0.f, 0.f, 0.f}, phi[3] = {0.f, 0.f, 0.f};
     auto cell_run = [&](const int *__restrict__ lst, int s, int e, bool filter, int cx, int cy, int cz, int bx0, int by0, int bz0) {
         for (int base = s; base < e; base += 64) {
             const int idx = base + lane;
@@ -1151,6 +1155,14 @@ __global__ __launch_bounds__(256) void k_tri_query_coop(const float *__restrict_
                 const int fy0 = t_cell(fminf(fv[1], fminf(fv[4], fv[7])) - g.slack[1], g.o[1], g.inv[1], g.g[1]);
                 const int fz0 = t_cell(fminf(fv[2], fminf(fv[5], fv[8])) - g.slack[2], g.o[2], g.inv[2], g.g[2]);
                 use = cx == max(fx0, bx0) && cy == max(fy0, by0) && cz == max(fz0, bz0);
+                float d2 = 0.f;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float flo = fminf(fv[k], fminf(fv[3 + k], fv[6 + k])), fhi = fmaxf(fv[k], fmaxf(fv[3 + k], fv[6 + k]));
+                    const float d = fmaxf(fmaxf(plo[k] - fhi, flo - phi[k]), 0.f);
+                    d2 += d * d;
+                }
+                use = use && !(d2 * 0.9999f > reach2);
             }
             unsigned long long todo = __ballot(use);
             while (todo) {
@@ -1204,16 +1216,7 @@ __global__ __launch_bounds__(256) void k_tri_query_coop(const float *__restrict_
         const int bx0 = max(C[0] - r, 0), bx1 = min(C[0] + r, g.g[0] - 1);
         const int by0 = max(C[1] - r, 0), by1 = min(C[1] + r, g.g[1] - 1);
         const int bz0 = max(C[2] - r, 0), bz1 = min(C[2] + r, g.g[2] - 1);
-        for (int z = bz0; z <= bz1; ++z)
-            for (int y = by0; y <= by1; ++y) {
-                const int row = (z * g.g[1] + y) * g.g[0];
-                if (cellStart[row + bx0] == cellStart[row + bx1 + 1]) continue;   // nothing in this row of the box: one pair of
-                for (int x = bx0; x <= bx1; ++x) {                             // dependent loads instead of one per cell
-                    const int s0 = cellStart[row + x], e0 = cellStart[row + x + 1];
-                    if (s0 < e0) cell_run(list, s0, e0, true, x, y, z, bx0, by0, bz0);
-                }
-            }
-        // every face not seen so far lies outside the box of cells [C-r, C+r]: distance >= m (per lane)
+        // every face not seen after this shell lies outside the box of cells [C-r, C+r]: distance >= m (per lane)
         float m = INFINITY;
         bool more = false;
 #pragma unroll
@@ -1228,6 +1231,31 @@ __global__ __launch_bounds__(256) void k_tri_query_coop(const float *__restrict_
                 m = fminf(m, fmaxf((g.o[k] + (float)(C[k] + r + 1) * g.cs[k]) - p[k] - g.slack[k], 0.f));
             }
         }
+        {   // what the unsettled lanes of this wave can still use: the largest threshold radius and the box of their points
+            const bool act = live && tame && !done;
+            float r2 = act ? (more ? m * m : INFINITY) : 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { plo[k] = act ? p[k] : INFINITY; phi[k] = act ? p[k] : -INFINITY; }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                r2 = fmaxf(r2, __shfl_xor(r2, off));
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    plo[k] = fminf(plo[k], __shfl_xor(plo[k], off));
+                    phi[k] = fmaxf(phi[k], __shfl_xor(phi[k], off));
+                }
+            }
+            reach2 = r2;
+        }
+        for (int z = bz0; z <= bz1; ++z)
+            for (int y = by0; y <= by1; ++y) {
+                const int row = (z * g.g[1] + y) * g.g[0];
+                if (cellStart[row + bx0] == cellStart[row + bx1 + 1]) continue;   // nothing in this row of the box: one pair of
+                for (int x = bx0; x <= bx1; ++x) {                             // dependent loads instead of one per cell
+                    const int s0 = cellStart[row + x], e0 = cellStart[row + x + 1];
+                    if (s0 < e0) cell_run(list, s0, e0, true, x, y, z, bx0, by0, bz0);
+                }
+            }
         if (!more) done = true;                                      // the box covers the grid: every listed face was seen
         else if (min_d < (m * m) * 0.9998f - g.abs_slack) done = true;
     }
