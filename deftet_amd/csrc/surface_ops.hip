@@ -1134,13 +1134,15 @@ __global__ __launch_bounds__(256) void k_tri_query_coop(const float *__restrict_
         if (min_d > dis || (min_d == dis && f < min_idx)) { min_d = dis; min_idx = f; }   // lexicographic (value, index)
     };
     // A face overlapping several cells is listed in each of them: inside a search box it is evaluated
-    // only from its CANONICAL cell, the lowest cell of the box it overlaps (per axis max(face's first
-    // cell, box's first cell)) — one evaluation per distinct face instead of up to 8.
+    // only from its CANONICAL cell — of its cells inside the box, the one nearest to the wave's cell on
+    // every axis — one evaluation per distinct face instead of up to 8.
     // entries [s, e) of one cell (cx, cy, cz): cooperative load, canonical filter (ballot), broadcast
     // reach2 / plo / phi (set per shell below): a regular face whose box is farther than sqrt(reach2) from the box of the
     // wave's unsettled points cannot bring any of them under its certification threshold, so it is not evaluated here —
     // either the lane is settled by a nearer face or it goes to the far path, which is exact.
     float reach2 = INFINITY, plo[3] = {0.f, 0.f, 0.f}, phi[3] = {0.f, 0.f, 0.f};
+    int boxn[3] = {1, 1, 1};                                        // cells per axis of the current search box
+    const int C[3] = {key % kTGMax, (key / kTGMax) % kTGMax, key / (kTGMax * kTGMax)};   // the wave's (clamped) cell
     auto cell_run = [&](const int *__restrict__ lst, int s, int e, bool filter, int cx, int cy, int cz, int bx0, int by0, int bz0) {
         for (int base = s; base < e; base += 64) {
             const int idx = base + lane;
@@ -1151,14 +1153,16 @@ __global__ __launch_bounds__(256) void k_tri_query_coop(const float *__restrict_
             for (int k = 0; k < 9; ++k) fv[k] = have ? face[(size_t)fm * 9 + k] : 0.f;
             bool use = have;
             if (have && filter) {                                     // same cell range as k_tri_face_bin
-                const int fx0 = t_cell(fminf(fv[0], fminf(fv[3], fv[6])) - g.slack[0], g.o[0], g.inv[0], g.g[0]);
-                const int fy0 = t_cell(fminf(fv[1], fminf(fv[4], fv[7])) - g.slack[1], g.o[1], g.inv[1], g.g[1]);
-                const int fz0 = t_cell(fminf(fv[2], fminf(fv[5], fv[8])) - g.slack[2], g.o[2], g.inv[2], g.g[2]);
-                use = cx == max(fx0, bx0) && cy == max(fy0, by0) && cz == max(fz0, bz0);
+                const int cc[3] = {cx, cy, cz}, bb0[3] = {bx0, by0, bz0};
                 float d2 = 0.f;
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     const float flo = fminf(fv[k], fminf(fv[3 + k], fv[6 + k])), fhi = fmaxf(fv[k], fmaxf(fv[3 + k], fv[6 + k]));
+                    const int f0 = t_cell(flo - g.slack[k], g.o[k], g.inv[k], g.g[k]), f1 = t_cell(fhi + g.slack[k], g.o[k], g.inv[k], g.g[k]);
+                    // canonical cell: of the face's cells inside the box, the one NEAREST to the wave's cell on every axis
+                    // (so that a skipped canonical cell implies that all the face's cells are out of reach)
+                    const int lo_k = max(f0, bb0[k]), hi_k = min(f1, bb0[k] + boxn[k] - 1);
+                    use = use && cc[k] == min(max(C[k], lo_k), hi_k);
                     const float d = fmaxf(fmaxf(plo[k] - fhi, flo - phi[k]), 0.f);
                     d2 += d * d;
                 }
@@ -1176,7 +1180,6 @@ __global__ __launch_bounds__(256) void k_tri_query_coop(const float *__restrict_
             }
         }
     };
-    const int C[3] = {key % kTGMax, (key / kTGMax) % kTGMax, key / (kTGMax * kTGMax)};   // the wave's (clamped) cell
     {   // No face within the 3x3x3 coarse cells (4x4x4 cells each) around the wave's cell: the two shells below cannot
         // settle anything — the whole wave goes to the far path at once (the wide list is evaluated there as well).
         bool any_face = false;
@@ -1247,11 +1250,22 @@ __global__ __launch_bounds__(256) void k_tri_query_coop(const float *__restrict_
             }
             reach2 = r2;
         }
+        boxn[0] = bx1 - bx0 + 1; boxn[1] = by1 - by0 + 1; boxn[2] = bz1 - bz0 + 1;
+        // distance^2 from the box of the unsettled points to cell layer c on axis k (wave-uniform values)
+        auto gap2 = [&](int k, int c) -> float {
+            if (!(g.cs[k] < INFINITY)) return 0.f;
+            const float l = g.o[k] + (float)c * g.cs[k] - g.slack[k], h = g.o[k] + (float)(c + 1) * g.cs[k] + g.slack[k];
+            const float d = fmaxf(fmaxf(l - phi[k], plo[k] - h), 0.f);
+            return d * d;
+        };
         for (int z = bz0; z <= bz1; ++z)
             for (int y = by0; y <= by1; ++y) {
+                const float dyz = gap2(1, y) + gap2(2, z);
+                if (__all(dyz * 0.9999f > reach2)) continue;                  // the whole row is out of reach (see cell_run)
                 const int row = (z * g.g[1] + y) * g.g[0];
                 if (cellStart[row + bx0] == cellStart[row + bx1 + 1]) continue;   // nothing in this row of the box: one pair of
                 for (int x = bx0; x <= bx1; ++x) {                             // dependent loads instead of one per cell
+                    if (__all((dyz + gap2(0, x)) * 0.9999f > reach2)) continue;
                     const int s0 = cellStart[row + x], e0 = cellStart[row + x + 1];
                     if (s0 < e0) cell_run(list, s0, e0, true, x, y, z, bx0, by0, bz0);
                 }
