@@ -1096,18 +1096,16 @@ __global__ __launch_bounds__(256) void k_tri_chunks(const unsigned *__restrict__
 
 __device__ __forceinline__ float bcastf(float v, int k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k)); }
 
-__global__ __launch_bounds__(256) void k_tri_query_coop(const float *__restrict__ pts, const float *__restrict__ face,
-                                                        const float *__restrict__ nfb, int P, const TGrid *__restrict__ gp,
-                                                        const int *__restrict__ cellStart, const int *__restrict__ list,
-                                                        const int *__restrict__ wide, const int *__restrict__ nWide, float *closest_d,
-                                                        float *closest_f, int *farFlag, const unsigned *__restrict__ order,
-                                                        const int *__restrict__ ptStart, const int *__restrict__ chunkStart,
-                                                        const int *__restrict__ rep)
+__device__ __forceinline__ void tri_query_chunk(int W, const float *__restrict__ pts, const float *__restrict__ face,
+                                                const float *__restrict__ nfb, int P, const TGrid *__restrict__ gp,
+                                                const int *__restrict__ cellStart, const int *__restrict__ list,
+                                                const int *__restrict__ wide, const int *__restrict__ nWide, float *closest_d,
+                                                float *closest_f, int *farFlag, const unsigned *__restrict__ order,
+                                                const int *__restrict__ ptStart, const int *__restrict__ chunkStart,
+                                                const int *__restrict__ rep)
 {
     constexpr int nKeys = kTGMax * kTGMax * kTGMax;
     const int lane = threadIdx.x & 63;
-    const int W = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (W >= chunkStart[nKeys]) return;
     int lo = 0, hi = nKeys;                                          // largest key with chunkStart[key] <= W
     while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
@@ -1277,6 +1275,23 @@ __global__ __launch_bounds__(256) void k_tri_query_coop(const float *__restrict_
     if (!tame || !done) { farFlag[slot] = 1; return; }              // NaN / Inf / huge points, unresolved ones: the far path
     closest_d[q] = min_d;
     closest_f[q] = (float)min_idx;
+}
+
+// The number of chunks is only known on the device and at most P/64 + (number of cells) = 264 k waves, almost all of
+// them empty: a fixed grid strides over the chunks instead of launching 66 k blocks that exit at once.
+constexpr int kTriQueryBlocks = 2048;
+
+__global__ __launch_bounds__(256) void k_tri_query_coop(const float *__restrict__ pts, const float *__restrict__ face,
+                                                        const float *__restrict__ nfb, int P, const TGrid *__restrict__ gp,
+                                                        const int *__restrict__ cellStart, const int *__restrict__ list,
+                                                        const int *__restrict__ wide, const int *__restrict__ nWide, float *closest_d,
+                                                        float *closest_f, int *farFlag, const unsigned *__restrict__ order,
+                                                        const int *__restrict__ ptStart, const int *__restrict__ chunkStart,
+                                                        const int *__restrict__ rep)
+{
+    const int total = chunkStart[kTGMax * kTGMax * kTGMax];
+    for (int W = blockIdx.x * 4 + (threadIdx.x >> 6); W < total; W += gridDim.x * 4)
+        tri_query_chunk(W, pts, face, nfb, P, gp, cellStart, list, wide, nWide, closest_d, closest_f, farFlag, order, ptStart, chunkStart, rep);
 }
 
 // ---- A9 far path: points the two shells did not settle (a surface still far from the cloud, early in training) ------
@@ -1828,7 +1843,7 @@ extern "C" int deftet_tri_dist_fwd_f32(const float *pts, const float *face, cons
         if (e != hipSuccess) return set_error(DEFTET_ELAUNCH, "exclusive_scan: %s", hipGetErrorString(e));
         {
             const long long maxChunks = (long long)(P + 63) / 64 + (long long)nc;
-            DEFTET_LAUNCH(k_tri_query_coop, dim3((unsigned)((maxChunks + 3) / 4)), dim3(256), st, pb, fb, nb, P, grid, start, list, wide, counters,
+            DEFTET_LAUNCH(k_tri_query_coop, dim3((unsigned)std::min<long long>((maxChunks + 3) / 4, kTriQueryBlocks)), dim3(256), st, pb, fb, nb, P, grid, start, list, wide, counters,
                           closest_d + (size_t)b * P, closest_f + (size_t)b * P, farFlag, (const unsigned *)order,
                           (const int *)ptStart, (const int *)chunkStart, (const int *)rep);
         }
