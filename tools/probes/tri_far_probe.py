@@ -28,3 +28,4 @@ for scale in ([float(a) for a in sys.argv[1:]] or (1.0, 1.1, 1.3, 2.0, 0.5, 0.05
         res[name] = (e0.elapsed_time(e1) / 3, out)
     same = torch.equal(res["grid"][1][0], res["scan"][1][0]) and torch.equal(res["grid"][1][1], res["scan"][1][1])
     print("points at %.2f x the surface radius: grid %.3f ms, scan %.3f ms, identical %s" % (scale, res["grid"][0], res["scan"][0], same))
+
