@@ -860,6 +860,23 @@ __device__ __forceinline__ float min_triangle_distance(const float *a, const flo
     return distance_1 + ret[1];
 }
 
+// The same evaluation with a wave-level early out between its two halves.  Whatever the inside test decides, the value is
+// t^2, t^2 + (a non-negative term) or max_dis >= every best-so-far, i.e. never below the fp32 square of the plane offset t
+// computed first; so when t^2 > best holds for every voting lane the face can neither lower nor tie any of them and the
+// expensive half (three point-line distances, ~350 of ~400 instructions) is skipped.  Bit-identical results.
+// Returns false when skipped.
+__device__ __forceinline__ bool min_triangle_distance_voted(const float *a, const float *b, const float *c, const float *p,
+                                                            float best, bool voter, float &dis)
+{
+    float t, ip[3], ret[3] = {0.f, 0.f, 0.f};
+    plane_project(a, b, c, p, ip, t);
+    const float distance_1 = t * t;
+    if (!__any(voter && distance_1 <= best)) return false;
+    line_distance<false>(a, b, c, ip, ret, 10000.0f);
+    dis = ret[0] == 0 ? distance_1 : (ret[0] < 0 ? 10000.0f : distance_1 + ret[1]);
+    return true;
+}
+
 __global__ __launch_bounds__(256) void k_tri_dist_fwd(const float *__restrict__ pts, const float *__restrict__ face,
                                                       const float *__restrict__ n_face_b, float *closest_d,
                                                       float *closest_f, int P, int Fmax)
@@ -1134,8 +1151,8 @@ __device__ __forceinline__ void tri_query_chunk(int W, int part, unsigned long l
     float min_d = 10000.0f;                                         // for.cu:277
     int min_idx = -1;
     auto eval = [&](int f, const float *fc) {
-        float ret[3] = {0.f, 0.f, 0.f}, ip[3];
-        const float dis = min_triangle_distance<false>(fc, fc + 3, fc + 6, p, ret, ip, 10000.0f);
+        float dis;
+        if (!min_triangle_distance_voted(fc, fc + 3, fc + 6, p, min_d, live, dis)) return;
         if (min_d > dis || (min_d == dis && f < min_idx)) { min_d = dis; min_idx = f; }   // lexicographic (value, index)
     };
     // A face overlapping several cells is listed in each of them: inside a search box it is evaluated
@@ -1215,10 +1232,6 @@ __device__ __forceinline__ void tri_query_chunk(int W, int part, unsigned long l
             return;
         }
     }
-    {
-        const int nw = *nWide;                                      // every wave of the block takes every kTriChunkWaves-th batch
-        for (int s0 = part * 64; s0 < nw; s0 += kTriChunkWaves * 64) cell_run(wide, s0, min(s0 + 64, nw), false, 0, 0, 0, 0, 0, 0);
-    }
     bool done = false;
     for (int r = 1; r <= 2; ++r) {
         if (__all(done || !live || !tame)) break;
@@ -1279,6 +1292,12 @@ __device__ __forceinline__ void tri_query_chunk(int W, int part, unsigned long l
                     if (s0 < e0) cell_run(list, s0, e0, true, x, y, z, bx0, by0, bz0);
                 }
             }
+        if (r == 1) {
+            // the wide list, AFTER the first shell: the lanes' bests are then small and most wide faces (typically the nearly
+            // vertical ones of a grid-like surface, hundreds of them) fail the plane-offset vote of eval() at once
+            const int nw = *nWide;                                  // every wave of the block takes every kTriChunkWaves-th batch
+            for (int s0 = part * 64; s0 < nw; s0 += kTriChunkWaves * 64) cell_run(wide, s0, min(s0 + 64, nw), false, 0, 0, 0, 0, 0, 0);
+        }
         {   // the waves of the block pool their answers: lexicographic (value, index) minimum as one 64-bit word
             s_pack[part][lane] = ((unsigned long long)(unsigned)__float_as_int(min_d) << 32) | (unsigned)min_idx;
             __syncthreads();
@@ -1340,8 +1359,8 @@ struct TriLane {
     int min_idx;
     __device__ __forceinline__ void eval(int f, const float *fc)
     {
-        float ret[3] = {0.f, 0.f, 0.f}, ip[3];
-        const float dis = min_triangle_distance<false>(fc, fc + 3, fc + 6, p, ret, ip, 10000.0f);
+        float dis;
+        if (!min_triangle_distance_voted(fc, fc + 3, fc + 6, p, min_d, true, dis)) return;
         if (min_d > dis || (min_d == dis && f < min_idx)) { min_d = dis; min_idx = f; }   // lexicographic (value, index)
     }
     __device__ __forceinline__ unsigned long long packed() const
