@@ -1,22 +1,28 @@
 """Builds libdeftet_hip.so in-tree with hipcc for gfx950 (no JIT cache, no torch headers).
 
-    python -m deftet_amd.build [--force]
+    python -m deftet_amd.build [--force] [--out PATH] [--swap point_in_tet.hip=OTHER.hip] [--only a.hip,b.cpp] [-DNAME[=V] ...]
+
+Every source is compiled to its own object (in parallel, cached under /tmp by source mtime and flags) and
+the objects are linked into the shared library, so touching one kernel file rebuilds one object.
 """
 from __future__ import annotations
 
+import concurrent.futures
+import hashlib
 import os
 import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJDIR = os.environ.get("DEFTET_BUILD_CACHE") or os.path.join("/tmp", "deftet_amd_build_%d" % os.getuid())   # object cache, outside the tree (the tree is what travels to the GPU box)
 LIB = os.path.join(HERE, "libdeftet_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 # -ffp-contract=off: the integer-valued outputs (tet index, argmin face, NN index) are
 # decided by fp32 sign tests / comparisons that must follow the reference's operation
 # order without fused multiply-adds ("numerics").
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 
 
@@ -24,8 +30,8 @@ def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))
 
 
-def _deps():
-    out = sources() + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
+def _headers():
+    out = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
     out.append(os.path.join(os.path.dirname(HERE), "include", "deftet_hip.h"))
     return out
 
@@ -34,22 +40,64 @@ def needs_build() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(s) > t for s in _deps())
+    return any(os.path.getmtime(s) > t for s in sources() + _headers())
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not needs_build():
+def _obj_for(src, flags):
+    key = hashlib.sha1((src + "\0" + " ".join(flags)).encode()).hexdigest()[:12]
+    return os.path.join(OBJDIR, "%s.%s.o" % (os.path.basename(src), key))
+
+
+def _compile(src, flags, force, verbose):
+    obj = _obj_for(src, flags)
+    newest = max(os.path.getmtime(p) for p in [src] + _headers())
+    if not force and os.path.exists(obj) and os.path.getmtime(obj) >= newest:
+        return obj
+    cmd = [HIPCC] + flags + ["-I", CSRC, "-x", "hip", "-c", src, "-o", obj + ".tmp"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    os.replace(obj + ".tmp", obj)
+    return obj
+
+
+def build(force: bool = False, verbose: bool = False, out: str = LIB, extra_flags=(), swap=None, only=None) -> str:
+    """swap: {basename in csrc: replacement source path}; only: basenames to include (probe builds only)."""
+    if out == LIB and not extra_flags and not swap and not force and not needs_build():
         return LIB
     if not os.path.exists(HIPCC):
         raise RuntimeError("hipcc not found at %s — cannot build libdeftet_hip.so" % HIPCC)
-    srcs = sources()
-    cmd = [HIPCC] + FLAGS + ["-x", "hip"] + srcs + ["-o", LIB + ".tmp"]
+    os.makedirs(OBJDIR, exist_ok=True)
+    flags = FLAGS + list(extra_flags)
+    srcs = [(swap or {}).get(os.path.basename(s), s) for s in sources() if only is None or os.path.basename(s) in only]
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(lambda s: _compile(s, flags, force, verbose), srcs))
+    os.makedirs(os.path.dirname(os.path.abspath(out)), exist_ok=True)
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out + ".tmp"]
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    os.replace(LIB + ".tmp", LIB)
-    return LIB
+    os.replace(out + ".tmp", out)
+    return out
+
+
+def main(argv):
+    force, out, extra, swap, only = False, LIB, [], {}, None
+    it = iter(argv)
+    for a in it:
+        if a == "--force":
+            force = True
+        elif a == "--out":
+            out = next(it)
+        elif a == "--only":
+            only = set(next(it).split(","))
+        elif a == "--swap":
+            k, v = next(it).split("=", 1)
+            swap[k] = os.path.abspath(v)
+        else:
+            extra.append(a)
+    print(build(force=force, verbose=True, out=out, extra_flags=extra, swap=swap or None, only=only))
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    main(sys.argv[1:])

@@ -50,6 +50,16 @@ void prof_end(hipStream_t st);
         DEFTET_LAUNCH_CHECK(#kern);                                            \
     } while (0)
 
+// same, with dynamic LDS bytes
+#define DEFTET_LAUNCH_SHM(kern, grid, block, shm, stream, ...)                 \
+    do {                                                                       \
+        const bool prof_ = deftet::prof_match(#kern);                          \
+        if (prof_) deftet::prof_begin(stream);                                 \
+        hipLaunchKernelGGL(kern, grid, block, shm, stream, __VA_ARGS__);       \
+        if (prof_) deftet::prof_end(stream);                                   \
+        DEFTET_LAUNCH_CHECK(#kern);                                            \
+    } while (0)
+
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // bump allocator over the caller's workspace

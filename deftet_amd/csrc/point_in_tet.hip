@@ -7,15 +7,20 @@
 // operation order WITHOUT fused multiply-add; else -1.
 //
 // Design (tet-centric, not a translation of the one-thread-per-query scan):
-//   1. queries are counting-sorted into a uniform G^3 grid spanning their own bounding box;
-//   2. one lane per tet: the lane computes the tet's four face planes once, visits the
-//      grid cells overlapped by its (slightly enlarged) bounding box and runs the exact
-//      predicate on the queries stored there; hits are combined with atomicMin, which
-//      makes the result independent of evaluation order;
+//   1. queries are counting-sorted into a uniform Gx*G*G grid spanning their own bounding box
+//      (slab = z cell; inside a slab (y cell, x cell) order), with a TRANSPOSED cell-start table
+//      table[cz][cx][cy] so that the bounds of up to four y-adjacent cell runs are one 16-byte load;
+//   2. one lane per tet: the lane computes the tet's four face planes once, walks the z slabs
+//      overlapped by its (slightly enlarged) bounding box, flattens the <= 4 runs of a slab into
+//      one candidate range and runs a certified fused plane filter on them; hits are combined
+//      with atomicMin, which makes the result independent of evaluation order;
 //   3. tets that fail a conditioning test ("irregular": tiny/flat/inverted-inconsistent,
 //      non-finite, huge) are tested against ALL queries, and queries that are
-//      non-finite/huge are tested against ALL tets, by two brute-force side kernels, so
+//      non-finite/huge are tested against ALL tets, by two brute-force side paths, so
 //      the result equals the reference scan for every input, not just for nice meshes.
+//
+// The traversal variants of rounds 1-2 (staged / rows / grouped / LDS / packed) live in
+// tools/probes/legacy/point_in_tet_r02.hip and are built only by tools/probes/build_variant.sh.
 //
 // The whole file is compiled with -ffp-contract=off; the pragma below repeats that.
 #pragma clang fp contract(off)
@@ -28,6 +33,10 @@
 
 #include "common.hpp"
 
+#ifndef PIT_DBG
+#define PIT_DBG 0      // timing experiments only (tools/probes): values != 0 drop one piece of the query sort
+#endif
+
 namespace deftet {
 namespace pit {
 
@@ -36,7 +45,8 @@ constexpr float kTau = 1.0f / 128.0f;        // regular tet: min |6V| >= tau * w
 constexpr float kMargin = 1.0f / 64.0f;      // bounding-box enlargement, in units of w
 constexpr float kWMin = 9.3132257e-10f;      // 2^-30
 constexpr int kMiss = 0x7F7F7F7F;            // result sentinel (> any tet index)
-constexpr int kMaxG = 96;
+constexpr int kMaxG = 112;                   // y/z cells per axis (slab key has 7 bits)
+constexpr int kMaxBins = 15 * 1024;          // (cy, cx) counters of one slab quarter must fit k_slab_sort's LDS (60 KB)
 constexpr int kHitOverflow = -2;            // hits[.].w: this tet has accepted queries that are not recorded
 
 // "hit record" buffer written by the forward and consumed by the backward (int32 words):
@@ -59,14 +69,25 @@ __device__ __forceinline__ void note_overflow(int *counters, int nB, int b, int 
     if (k < kOvfCap) counters[nB * 8 + b * kOvfCap + k] = t;
 }
 
-#ifndef PIT_XFINE
-#define PIT_XFINE 6
+#ifdef PIT_PHASE_TIMING
+// Diagnostic build only (tools/probes/build_variant.sh … -DPIT_PHASE_TIMING): per-phase wall cycles of the traversal
+// kernel.  Lane 0 of every wave adds its s_memtime deltas to a slot of its own (no atomics: same-address atomics from
+// 32 k waves would dominate what is being measured); deftet_debug_phase_read sums the slots.
+constexpr int kPhaseWaves = 1 << 16;
+__device__ unsigned long long g_phase[kPhaseWaves][16];
+#define PHASE_DECL                                                                                      \
+    long long ph_t_ = clock64();                                                                        \
+    const unsigned ph_w_ = (((unsigned)blockIdx.y * gridDim.x + blockIdx.x) * 4u + (threadIdx.x >> 6)) & (kPhaseWaves - 1)
+#define PHASE_MARK(i)                                                                  \
+    do {                                                                               \
+        const long long ph_n_ = clock64();                                             \
+        if ((threadIdx.x & 63) == 0) g_phase[ph_w_][i] += (unsigned long long)(ph_n_ - ph_t_); \
+        ph_t_ = ph_n_;                                                                 \
+    } while (0)
+#else
+#define PHASE_DECL
+#define PHASE_MARK(i)
 #endif
-#ifndef PIT_GDIV
-#define PIT_GDIV 6.0
-#endif
-constexpr int kXFine = PIT_XFINE;           // default: cells are kXFine times finer along x (the run direction)
-constexpr int kMaxXFine = 8;                // upper bound of the runtime override DEFTET_PIT_XFINE (LDS sizing of k_row_fine)
 
 // ------------------------------------------------------------------------------------
 // exact predicate pieces (check_condition_tet_for.cu:105-121, :172-176)
@@ -78,25 +99,43 @@ struct Planes {
     float dv[4];     // dotv4_i
 };
 
+// cross product in the source's operation order (:63-65)
+__device__ __forceinline__ void cross_ref(float r1x, float r1y, float r1z, float r2x, float r2y, float r2z, float *n)
+{
+    n[0] = r1y * r2z - r1z * r2y;
+    n[1] = r1z * r2x - r1x * r2z;
+    n[2] = r1x * r2y - r1y * r2x;
+}
+
+// The four orderings (a,b,c,d),(b,a,d,c),(c,d,a,b),(d,c,b,a) (:172-175) only need the SIX edge vectors of the tet:
+// fl(x - y) = -fl(y - x) exactly, and a product / difference of negated operands is the exact negation (or the same
+// value), so feeding the shared edges with the right signs reproduces every intermediate of the four source-order
+// evaluations bit for bit — with 18 subtractions instead of 36.
 __device__ __forceinline__ void make_planes(const float *v /*12*/, Planes &P)
 {
-    // orderings (a,b,c,d),(b,a,d,c),(c,d,a,b),(d,c,b,a): check_condition_tet_for.cu:172-175
-    constexpr int ord[4][4] = {{0, 1, 2, 3}, {1, 0, 3, 2}, {2, 3, 0, 1}, {3, 2, 1, 0}};
+    const float abx = v[3] - v[0], aby = v[4] - v[1], abz = v[5] - v[2];
+    const float acx = v[6] - v[0], acy = v[7] - v[1], acz = v[8] - v[2];
+    const float adx = v[9] - v[0], ady = v[10] - v[1], adz = v[11] - v[2];
+    const float bcx = v[6] - v[3], bcy = v[7] - v[4], bcz = v[8] - v[5];
+    const float bdx = v[9] - v[3], bdy = v[10] - v[4], bdz = v[11] - v[5];
+    const float cdx = v[9] - v[6], cdy = v[10] - v[7], cdz = v[11] - v[8];
+    // i = 0: a=v0 b=v1 c=v2 d=v3: r1 = ab, r2 = ac, d-a = ad
+    cross_ref(abx, aby, abz, acx, acy, acz, P.n[0]);
+    P.dv[0] = P.n[0][0] * adx + P.n[0][1] * ady + P.n[0][2] * adz;                     // :115
+    // i = 1: a=v1 b=v0 c=v3 d=v2: r1 = -ab, r2 = bd, d-a = bc
+    cross_ref(-abx, -aby, -abz, bdx, bdy, bdz, P.n[1]);
+    P.dv[1] = P.n[1][0] * bcx + P.n[1][1] * bcy + P.n[1][2] * bcz;
+    // i = 2: a=v2 b=v3 c=v0 d=v1: r1 = cd, r2 = -ac, d-a = -bc
+    cross_ref(cdx, cdy, cdz, -acx, -acy, -acz, P.n[2]);
+    P.dv[2] = P.n[2][0] * -bcx + P.n[2][1] * -bcy + P.n[2][2] * -bcz;
+    // i = 3: a=v3 b=v2 c=v1 d=v0: r1 = -cd, r2 = -bd, d-a = -ad
+    cross_ref(-cdx, -cdy, -cdz, -bdx, -bdy, -bdz, P.n[3]);
+    P.dv[3] = P.n[3][0] * -adx + P.n[3][1] * -ady + P.n[3][2] * -adz;
     P.sv = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const float *a = v + 3 * ord[i][0], *b = v + 3 * ord[i][1], *c = v + 3 * ord[i][2], *d = v + 3 * ord[i][3];
-        float r1x = b[0] - a[0], r1y = b[1] - a[1], r1z = b[2] - a[2];        // :111
-        float r2x = c[0] - a[0], r2y = c[1] - a[1], r2z = c[2] - a[2];        // :112
-        float nx = r1y * r2z - r1z * r2y;                                       // :63
-        float ny = r1z * r2x - r1x * r2z;                                       // :64
-        float nz = r1x * r2y - r1y * r2x;                                       // :65
-        float dx = d[0] - a[0], dy = d[1] - a[1], dz = d[2] - a[2];            // :114
-        float dotv4 = nx * dx + ny * dy + nz * dz;                              // :115
-        P.n[i][0] = nx; P.n[i][1] = ny; P.n[i][2] = nz;
-        P.a[i][0] = a[0]; P.a[i][1] = a[1]; P.a[i][2] = a[2];
-        P.dv[i] = dotv4;
-        P.sv |= (dotv4 > 0 ? 1u : 0u) << i;                                     // :119
+        P.a[i][0] = v[3 * i]; P.a[i][1] = v[3 * i + 1]; P.a[i][2] = v[3 * i + 2];
+        P.sv |= (P.dv[i] > 0 ? 1u : 0u) << i;                                           // :119
     }
 }
 
@@ -116,20 +155,18 @@ __device__ __forceinline__ bool accept(const Planes &P, float px, float py, floa
 // ------------------------------------------------------------------------------------
 // grid helpers
 // ------------------------------------------------------------------------------------
-__device__ __forceinline__ int f2ord(float f)
-{
-    int b = __float_as_int(f);
-    return b >= 0 ? b : b ^ 0x7FFFFFFF;
-}
-__device__ __forceinline__ float ord2f(int k) { return __int_as_float(k >= 0 ? k : k ^ 0x7FFFFFFF); }
+constexpr float kErrScale = 4.76837158203125e-07f;      // 8 u = 2^-21
+constexpr float kErrAbs = 7.5231638e-37f;              // 2^-120
+constexpr int kGridWords = 16;                         // floats of grid parameters per shape
 
 struct Grid {
     float o[3], inv[3], lo[3], hi[3];
+    float pe[3];     // kErrScale * max(|lo|, |hi|): the query-side part of the filter's error radius
 };
 constexpr int kBoxBlocks = 64;
 
 // reduce the per-block query boxes of one shape into grid parameters; called by every wave of
-// k_row_count (64 partials, a few shuffles) so that no separate launch is needed
+// k_slab_count (64 partials, a few shuffles) so that no separate launch is needed
 __device__ __forceinline__ Grid reduce_grid(const float *__restrict__ part, int nPart, int G, int Gx)
 {
     const int lane = threadIdx.x & 63;
@@ -161,6 +198,7 @@ __device__ __forceinline__ Grid reduce_grid(const float *__restrict__ part, int 
         g.inv[k] = (ok && ext > 1e-30f) ? (float)(k == 0 ? Gx : G) / ext : 0.f;   // cells per unit
         g.lo[k] = l;
         g.hi[k] = h;
+        g.pe[k] = kErrScale * fmaxf(fabsf(l), fabsf(h));
     }
     return g;
 }
@@ -174,21 +212,31 @@ __device__ __forceinline__ Grid load_grid(const float *__restrict__ gp)
         g.inv[k] = gp[3 + k];
         g.lo[k] = gp[6 + k];
         g.hi[k] = gp[9 + k];
+        g.pe[k] = gp[12 + k];
     }
     return g;
 }
 
-// monotone non-decreasing in x for fixed (o, inv >= 0): rounding, floor and clamp are monotone
+// monotone non-decreasing in x for fixed (o, inv >= 0): rounding, clamp and truncation of a non-negative value are
+// monotone.  (Truncation instead of floor: both give 0 for every value the clamp maps to [0, 1).)
 __device__ __forceinline__ int cell_of(float x, float o, float inv, int G)
 {
-    float f = floorf((x - o) * inv);
-    f = fminf(fmaxf(f, 0.f), (float)(G - 1));
+    const float f = __builtin_amdgcn_fmed3f((x - o) * inv, 0.f, (float)(G - 1));
     return (int)f;
 }
 
 __device__ __forceinline__ bool query_regular(float x, float y, float z)
 {
     return fabsf(x) <= kBig && fabsf(y) <= kBig && fabsf(z) <= kBig;   // NaN fails
+}
+
+// Transposed cell-start table of one shape: entry (cz, cx, cy) = position in sortedQ of the first query of cell
+// (cx, cy, cz); cx = Gx is the end of row (cz, cy); Gp = G + 3 entries per (cz, cx) so that a 4-wide read starting at any
+// cy < G stays inside its (cz, cx) line.
+__host__ __device__ inline int table_pitch(int G) { return G + 3; }
+__device__ __forceinline__ unsigned table_off(int cz, int cx, int cy, int Gx, int Gp)
+{
+    return (unsigned)((cz * (Gx + 1) + cx) * Gp + cy);
 }
 
 // ------------------------------------------------------------------------------------
@@ -214,7 +262,7 @@ __global__ __launch_bounds__(256) void k_query_bbox(const float *__restrict__ pt
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < Q; q += gridDim.x * blockDim.x) {
         float x = p[q * 3], y = p[q * 3 + 1], z = p[q * 3 + 2];
-        if (query_regular(x, y, z)) {                              // irregular queries are listed by k_row_count
+        if (query_regular(x, y, z)) {                              // irregular queries are listed by k_slab_count
             lo[0] = fminf(lo[0], x); lo[1] = fminf(lo[1], y); lo[2] = fminf(lo[2], z);
             hi[0] = fmaxf(hi[0], x); hi[1] = fmaxf(hi[1], y); hi[2] = fmaxf(hi[2], z);
         }
@@ -245,182 +293,289 @@ __global__ __launch_bounds__(256) void k_query_bbox(const float *__restrict__ pt
 // Counting sort of the regular queries into grid cells WITHOUT global atomics.
 // (Round-1 history: one returning global atomicAdd per query = 800 k fabric transactions = 41 us;
 // random-address global atomics run at ~23-26 G/s chip-wide at ANY scope, tools/probes/.)
-// Two levels, both with LDS atomics only:
-//   rows  (cz*G+cy, <= 96^2): k_row_count (per-block LDS histogram + rank inside the block),
-//         k_row_colscan (prefix over blocks per row), k_row_scatter (queries -> row order);
-//   cells (cx inside a row, <= 384): k_row_fine, one wave per row (count, scan, place).
+// Two levels, both with LDS atomics only, two launches:
+//   k_slab_local: every workgroup sorts ITS chunk of <= kRowTile queries by first-level bin (slab cz, y-eighth) into its
+//         own segment of `localQ` and publishes the exclusive bin prefix of the chunk (pre[bin][block]);
+//   k_slab_sort:  one workgroup per (slab, shape) gathers the slab's runs from all chunk segments (a run per chunk,
+//         contiguous), counts per (cy, cx) cell in LDS, scans, writes its plane of the transposed cell-start table with
+//         coalesced stores and places the queries.
+// (Rounds 1-2 sorted into (cz, cy) ROWS with G^2-bin histograms, a column-scan kernel over [nblk][G^2] words, a global
+// scatter and one wave per row: five launches, 44 us at configs[2].  The first slab version of round 3 kept a global
+// scatter between the levels and lost 12 us in it to the column sums of a [nblk][bins] table — a chain of memory
+// latencies; here no workgroup ever needs another one's histogram before the second level.)
 // The order of queries inside a cell is arbitrary (as it was with global atomics); nothing
 // downstream depends on it except which four accepted queries a hit record keeps.
 // ------------------------------------------------------------------------------------
-constexpr int kMaxRowBlocks = 256;   // blocks per shape in k_row_count / k_row_scatter
+constexpr int kMaxRowBlocks = 256;   // chunks per shape (k_slab_sort handles one run per chunk with one thread each)
 #ifndef PIT_ROWTILE
 #define PIT_ROWTILE 2048
 #endif
-constexpr int kRowTile = PIT_ROWTILE;  // smallest query chunk per block
+constexpr int kRowTile = PIT_ROWTILE;  // smallest query chunk per workgroup
+constexpr int kLocalKeep = kRowTile / 256;   // queries a thread keeps in registers between the two passes
+// First-level bins: (slab, y-eighth of the cell rows).  The second level works on y-quarters of a slab (two adjacent
+// sub-bins = one contiguous run per chunk): a quarter's (cy, cx) counters need ~10 KB of LDS, so several workgroups
+// share a compute unit (a whole slab needs 40 KB at configs[2], and only 64 KB per CU are handed out to kernels that do
+// not opt into the large-LDS mode: one workgroup per CU, 17 us instead of 6).
+constexpr int kSub = 8;
+constexpr int kParts = 4;                  // second-level workgroups per slab
+constexpr int kSubPerPart = kSub / kParts;
+constexpr int kMaxBin1 = kMaxG * kSub;     // 896
 
-__global__ __launch_bounds__(256) void k_row_count(const float *__restrict__ pts, int Q, const float *__restrict__ bboxPart,
-                                                   float *gparam, int G, int Gx, int nblk, int chunkQ, int2 *qkey,
-                                                   int *blockHist, int *counters, int *irregQ)
+__global__ __launch_bounds__(256) void k_slab_local(const float *__restrict__ pts, int Q, const float *__restrict__ bboxPart,
+                                                    float *gparam, int G, int Gx, int nblk, int nblkPad, int chunkQ,
+                                                    float4 *localQ, int *pre, int *counters, int *irregQ)
 {
-    __shared__ int hist[kMaxG * kMaxG];
-    const int b = blockIdx.y, blk = blockIdx.x, R = G * G;
+    __shared__ int hist[kMaxBin1 + 1];
+    __shared__ int wtot[4];
+    const int b = blockIdx.y, blk = blockIdx.x, R1 = G * kSub, tid = threadIdx.x;
     const Grid g = reduce_grid(bboxPart + (size_t)b * kBoxBlocks * 6, kBoxBlocks, G, Gx);
-    if (blk == 0 && threadIdx.x < 3) {                             // publish for k_row_fine / k_tet_scan
-        const int k = threadIdx.x;
-        gparam[b * 12 + k] = g.o[k]; gparam[b * 12 + 3 + k] = g.inv[k]; gparam[b * 12 + 6 + k] = g.lo[k]; gparam[b * 12 + 9 + k] = g.hi[k];
+    if (blk == 0 && tid == 0) {                                    // publish for k_slab_sort / the traversal
+        float *gp = gparam + b * kGridWords;                       // (constant indices: a dynamic one sends g through LDS — 13 us)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { gp[k] = g.o[k]; gp[3 + k] = g.inv[k]; gp[6 + k] = g.lo[k]; gp[9 + k] = g.hi[k]; gp[12 + k] = g.pe[k]; }
     }
-    for (int i = threadIdx.x; i < R; i += 256) hist[i] = 0;
+    for (int i = tid; i <= R1; i += 256) hist[i] = 0;
     __syncthreads();
+    const float rcpG = 1.0f / (float)G;
     const int q0 = blk * chunkQ, q1 = min(Q, q0 + chunkQ);
-    for (int qb = q0 + threadIdx.x; qb < q1; qb += 256 * 4) {
-        int row[4];
-        float3 pp[4];
+    const bool keep = chunkQ <= kRowTile;                          // launch-uniform: the chunk fits the register file
+    float3 kp[kLocalKeep];
+    int kbin[kLocalKeep], krank[kLocalKeep];
+    auto bin_of = [&](float x, float y, float z) {                 // (cz, y-eighth of the CELL row: sub = (cy * 8) / G exactly,
+        const int cy = cell_of(y, g.o[1], g.inv[1], G);            //  +0.5 keeps the quotient away from the integers)
+        return cell_of(z, g.o[2], g.inv[2], G) * kSub + (int)(((float)(cy * kSub) + 0.5f) * rcpG);
+    };
+    if (keep) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int q = qb + k * 256;
-            if (q < q1) {
-                const float *p = pts + ((size_t)b * Q + q) * 3;
-                pp[k] = make_float3(p[0], p[1], p[2]);
-            }
+        for (int k = 0; k < kLocalKeep; ++k) {                     // unconditional (clamped) loads: all in flight at once
+            const float *p = pts + ((size_t)b * Q + max(min(q0 + tid + k * 256, q1 - 1), 0)) * 3;
+            kp[k] = make_float3(p[0], p[1], p[2]);
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int q = qb + k * 256;
-            if (q >= q1) continue;
-            int rank = 0;
-            if (query_regular(pp[k].x, pp[k].y, pp[k].z)) {
-                row[k] = cell_of(pp[k].z, g.o[2], g.inv[2], G) * G + cell_of(pp[k].y, g.o[1], g.inv[1], G);
-                rank = atomicAdd(&hist[row[k]], 1);                // LDS
-            } else {                                               // NaN / Inf / huge: tested by every tet lane at the end of k_tet_scan
-                row[k] = -1;
-                irregQ[(size_t)b * Q + atomicAdd(&counters[b * 4 + 1], 1)] = q;
+        for (int k = 0; k < kLocalKeep; ++k) {
+            const int q = q0 + tid + k * 256;
+            kbin[k] = -1;
+            if (q < q1) {
+                if (query_regular(kp[k].x, kp[k].y, kp[k].z)) {
+                    kbin[k] = bin_of(kp[k].x, kp[k].y, kp[k].z);
+                    krank[k] = atomicAdd(&hist[kbin[k]], 1);                          // LDS
+                } else {                                           // NaN / Inf / huge: tested by every tet lane at the end of the traversal
+                    irregQ[(size_t)b * Q + atomicAdd(&counters[b * 4 + 1], 1)] = q;
+                }
             }
-            qkey[(size_t)b * Q + q] = make_int2(row[k], rank);
+        }
+    } else {
+        for (int q = q0 + tid; q < q1; q += 256) {
+            const float *p = pts + ((size_t)b * Q + q) * 3;
+            const float x = p[0], y = p[1], z = p[2];
+            if (query_regular(x, y, z)) atomicAdd(&hist[bin_of(x, y, z)], 1);
+            else irregQ[(size_t)b * Q + atomicAdd(&counters[b * 4 + 1], 1)] = q;
         }
     }
     __syncthreads();
-    int *out = blockHist + ((size_t)b * nblk + blk) * R;
-    for (int i = threadIdx.x; i < R; i += 256) out[i] = hist[i];
-}
-
-// per row: exclusive prefix of the block histograms over the blocks (in place) + row total
-__global__ __launch_bounds__(256) void k_row_colscan(int *blockHist, int nblk, int R, int *rowTotal)
-{
-    const int b = blockIdx.y, row = blockIdx.x * 256 + threadIdx.x;
-    if (row >= R) return;
-    int *p = blockHist + (size_t)b * nblk * R + row;
-    int run = 0, blk = 0;
-    for (; blk + 8 <= nblk; blk += 8) {
-        int v[8];
+    {   // exclusive scan of the R1 counts (<= 4 consecutive bins per thread); hist[R1] = number of regular queries
+        constexpr int kPer = (kMaxBin1 + 255) / 256;               // 4
+        const int per = (R1 + 255) / 256, i0 = tid * per;
+        int n[kPer], sum = 0;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = p[(size_t)(blk + k) * R];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            p[(size_t)(blk + k) * R] = run;
-            run += v[k];
+        for (int j = 0; j < kPer; ++j) {
+            n[j] = (j < per && i0 + j < R1) ? hist[i0 + j] : 0;
+            sum += n[j];
         }
-    }
-    for (; blk < nblk; ++blk) {
-        const int v = p[(size_t)blk * R];
-        p[(size_t)blk * R] = run;
-        run += v;
-    }
-    rowTotal[(size_t)b * R + row] = run;
-}
-
-// queries -> row order.  Every block first rebuilds the row starts (exclusive scan of <= 9216
-// row totals in LDS: cheaper than one more launch); block 0 of a shape publishes them.
-__global__ __launch_bounds__(256) void k_row_scatter(const float *__restrict__ pts, int Q, const int2 *__restrict__ qkey,
-                                                     const int *__restrict__ blockHist, const int *__restrict__ rowTotal,
-                                                     int *rowStart, int G, int nblk, int chunkQ, float4 *rowSorted)
-{
-    __shared__ int rs[kMaxG * kMaxG + 1];
-    __shared__ int wsum[4];
-    const int b = blockIdx.y, blk = blockIdx.x, R = G * G;
-    {
-        const int per = (R + 255) / 256, r0 = threadIdx.x * per, r1 = min(R, r0 + per);
-        const int *rt = rowTotal + (size_t)b * R;
-        int sum = 0;
-        for (int r = r0; r < r1; ++r) sum += rt[r];
         int incl = sum;
-        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        const int lane = tid & 63, w = tid >> 6;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             const int t = __shfl_up(incl, off);
             if (lane >= off) incl += t;
         }
-        if (lane == 63) wsum[w] = incl;
+        if (lane == 63) wtot[w] = incl;
         __syncthreads();
         int run = incl - sum;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            if (k < w) run += wsum[k];
-        for (int r = r0; r < r1; ++r) {
-            rs[r] = run;
-            run += rt[r];
-        }
-        if (r0 < R && r1 == R) rs[R] = run;
-        __syncthreads();
-        if (blk == 0)
-            for (int i = threadIdx.x; i <= R; i += 256) rowStart[(size_t)b * (R + 1) + i] = rs[i];
+            if (k < w) run += wtot[k];
+        int *col = pre + (size_t)b * (R1 + 1) * nblkPad + blk;     // pre[bin][chunk]: a slab workgroup reads rows of it
+#pragma unroll
+        for (int j = 0; j < kPer; ++j)
+            if (j < per && i0 + j < R1) {
+                hist[i0 + j] = run;
+                col[(size_t)(i0 + j) * nblkPad] = run;
+                run += n[j];
+            }
+        if (tid == 255) col[(size_t)R1 * nblkPad] = run;           // thread 255 holds the grand total after its own bins
     }
-    const int *bh = blockHist + ((size_t)b * nblk + blk) * R;
-    const int q0 = blk * chunkQ, q1 = min(Q, q0 + chunkQ);
-    for (int q = q0 + threadIdx.x; q < q1; q += 256) {
-        const int2 k = qkey[(size_t)b * Q + q];
-        if (k.x < 0) continue;
-        const float *p = pts + ((size_t)b * Q + q) * 3;
-        const int pos = rs[k.x] + bh[k.x] + k.y;
-        rowSorted[(size_t)b * Q + pos] = make_float4(p[0], p[1], p[2], __int_as_float(q));
+    __syncthreads();
+    float4 *dst = localQ + (size_t)b * Q + q0;
+    if (keep) {
+#pragma unroll
+        for (int k = 0; k < kLocalKeep; ++k)
+            if (kbin[k] >= 0) dst[hist[kbin[k]] + krank[k]] = make_float4(kp[k].x, kp[k].y, kp[k].z, __int_as_float(q0 + tid + k * 256));
+    } else {
+        for (int q = q0 + tid; q < q1; q += 256) {
+            const float *p = pts + ((size_t)b * Q + q) * 3;
+            const float x = p[0], y = p[1], z = p[2];
+            if (query_regular(x, y, z)) dst[atomicAdd(&hist[bin_of(x, y, z)], 1)] = make_float4(x, y, z, __int_as_float(q));
+        }
     }
 }
 
-// one wave per row: count the row's queries per x-cell, scan, write the cell starts and place the
-// queries in cell order
-__global__ __launch_bounds__(256) void k_row_fine(const float4 *__restrict__ rowSorted, int Q, const float *__restrict__ gparam,
-                                                  int G, int Gx, const int *__restrict__ rowStart, long long cellStride, int *cells,
-                                                  float4 *sortedQ)
+// One workgroup per (slab, y-quarter, shape).  Thread k < nblk owns the part's run in chunk k (pre[.][k] gives its offset
+// and length); the block sums the offsets (= queries in lower bins = the part's start in sortedQ) and scans the lengths.
+// Then: gather, count per (cy, cx) cell in LDS, exclusive scan in (cy, cx) order, placement, and the part's rows of the
+// slab's plane of the transposed cell-start table.  Parts of up to kSortThreads * kSortKeep queries (the usual case) keep
+// their queries, cells and ranks in registers between the counting and the placement pass; larger ones gather twice.
+constexpr int kSortThreads = 256;
+constexpr int kSortKeep = 4;
+static_assert(kMaxRowBlocks <= kSortThreads, "one thread per chunk run");
+__global__ __launch_bounds__(kSortThreads) void k_slab_sort(const float4 *__restrict__ localQ, int Q, const float *__restrict__ gparam,
+                                                            int G, int Gx, const int *__restrict__ pre, int nblk, int nblkPad,
+                                                            int chunkQ, long long cellStride, int *table, float4 *sortedQ)
 {
-    __shared__ int cnt[4][kMaxG * kMaxXFine];
-    const int b = blockIdx.y, wv = threadIdx.x >> 6, lane = threadIdx.x & 63, R = G * G;
-    const int row = blockIdx.x * 4 + wv;
-    const bool live = row < R;
-    const float o = gparam[b * 12 + 0], inv = gparam[b * 12 + 3];
-    int s = 0, e = 0;
-    if (live) {
-        s = rowStart[(size_t)b * (R + 1) + row];
-        e = rowStart[(size_t)b * (R + 1) + row + 1];
+    extern __shared__ __attribute__((aligned(16))) int cnt[];       // [rows of the part][GxP] counts -> starts (-> placement cursors)
+    __shared__ int wsum[kSortThreads / 64], wsum2[kSortThreads / 64];
+    __shared__ int runStart[kMaxRowBlocks + 1], runSrc[kMaxRowBlocks];
+    const int b = blockIdx.y, cz = blockIdx.x / kParts, part = blockIdx.x % kParts, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int GxP = Gx | 1;                                         // odd pitch: the transposed read below is conflict-free
+    // cell rows of this part: (cy * kSub) / G in [part * kSubPerPart, (part + 1) * kSubPerPart)
+    const int cyLo = (part * kSubPerPart * G + kSub - 1) / kSub, cyHi = ((part + 1) * kSubPerPart * G + kSub - 1) / kSub;
+    const int nb = (cyHi - cyLo) * GxP, R1 = G * kSub;
+    const int binLo = cz * kSub + part * kSubPerPart;
+    PHASE_DECL;
+    // runs of this part, one per chunk
+    int a = 0, len = 0;
+    if (tid < nblk) {
+        const int *row = pre + (size_t)b * (R1 + 1) * nblkPad;
+        a = row[(size_t)binLo * nblkPad + tid];
+        len = row[(size_t)(binLo + kSubPerPart) * nblkPad + tid] - a;
     }
-    for (int i = lane; i < Gx; i += 64) cnt[wv][i] = 0;
+    int s0, n;
+    {
+        int ia = a, il = len;                                       // inclusive scans over the threads
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int ta = __shfl_up(ia, off), tl = __shfl_up(il, off);
+            if (lane >= off) { ia += ta; il += tl; }
+        }
+        if (lane == 63) { wsum[w] = ia; wsum2[w] = il; }
+        __syncthreads();
+        int ta = 0, tl = 0, before = 0;
+#pragma unroll
+        for (int k = 0; k < kSortThreads / 64; ++k) {
+            ta += wsum[k];
+            tl += wsum2[k];
+            if (k < w) before += wsum2[k];
+        }
+        s0 = ta;
+        n = tl;
+        if (tid < nblk) {
+            runStart[tid] = before + il - len;
+            runSrc[tid] = tid * chunkQ + a;
+        }
+        if (tid == 0) runStart[nblk] = n;
+    }
+    for (int i = tid; i < ((nb + 3) & ~3); i += kSortThreads) cnt[i] = 0;
     __syncthreads();
-    const float4 *src = rowSorted + (size_t)b * Q;
-    for (int i = s + lane; i < e; i += 64) atomicAdd(&cnt[wv][cell_of(src[i].x, o, inv, Gx)], 1);
+    const float ox = gparam[b * kGridWords + 0], oy = gparam[b * kGridWords + 1];
+    const float ix = gparam[b * kGridWords + 3], iy = gparam[b * kGridWords + 4];
+    const int s1 = s0 + n;
+    const bool keep = n <= kSortThreads * kSortKeep;                // block-uniform
+    const float4 *src = localQ + (size_t)b * Q;
+    auto source_of = [&](int i) {                                   // i-th query of the slab -> position in localQ (binary search over the runs)
+        int lo = 0, hi = nblk;                                      // runStart[lo] <= i < runStart[hi]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (runStart[mid] <= i) lo = mid; else hi = mid;
+        }
+        return min(runSrc[lo] + (i - runStart[lo]), Q - 1);       // (the clamp only matters for the dummy load of an empty slab)
+    };
+    float4 kq[kSortKeep];
+    int kbin[kSortKeep], krank[kSortKeep];
+    if (keep) {
+#pragma unroll
+        for (int k = 0; k < kSortKeep; ++k) kq[k] = src[source_of(max(min(tid + k * kSortThreads, n - 1), 0))];   // clamped, unconditional
+    }
+    PHASE_MARK(8);                                                  // [8] runs + loads issued + LDS cleared
+    if (keep) {
+#pragma unroll
+        for (int k = 0; k < kSortKeep; ++k) {
+            if (tid + k * kSortThreads < n) {
+                kbin[k] = (cell_of(kq[k].y, oy, iy, G) - cyLo) * GxP + cell_of(kq[k].x, ox, ix, Gx);
+                krank[k] = atomicAdd(&cnt[kbin[k]], 1);
+            }
+        }
+    } else {
+        for (int i = tid; i < n; i += kSortThreads) {
+            const float4 q = src[source_of(i)];
+            atomicAdd(&cnt[(cell_of(q.y, oy, iy, G) - cyLo) * GxP + cell_of(q.x, ox, ix, Gx)], 1);
+        }
+    }
     __syncthreads();
-    if (live) {
-        const int per = (Gx + 63) / 64, c0 = lane * per, c1 = min(Gx, c0 + per);
+    PHASE_MARK(9);                                                  // [9] counting pass
+    {   // exclusive scan over the nb words (pad words hold 0), result offset by s0; 16-byte LDS accesses
+        const int nb4 = (nb + 3) >> 2;                              // the dynamic LDS block is sized to a multiple of 16 bytes
+        const int per = (nb4 + kSortThreads - 1) / kSortThreads, i0 = min(nb4, tid * per), i1 = min(nb4, i0 + per);
+        int4 *c4 = reinterpret_cast<int4 *>(cnt);
         int sum = 0;
-        for (int c = c0; c < c1; ++c) sum += cnt[wv][c];
+        for (int i = i0; i < i1; ++i) {
+            const int4 v = c4[i];
+            sum += (v.x + v.y) + (v.z + v.w);
+        }
         int incl = sum;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             const int t = __shfl_up(incl, off);
             if (lane >= off) incl += t;
         }
-        int run = s + incl - sum;
-        int *cb = cells + (size_t)b * cellStride + (size_t)row * Gx;
-        for (int c = c0; c < c1; ++c) {
-            const int n = cnt[wv][c];
-            cnt[wv][c] = run;                                      // becomes the placement cursor
-            cb[c] = run;
-            run += n;
+        __syncthreads();                                            // wsum is reused
+        if (lane == 63) wsum[w] = incl;
+        __syncthreads();
+        int run = s0 + incl - sum;
+#pragma unroll
+        for (int k = 0; k < kSortThreads / 64; ++k)
+            if (k < w) run += wsum[k];
+        for (int i = i0; i < i1; ++i) {
+            const int4 v = c4[i];
+            int4 o;
+            o.x = run; o.y = o.x + v.x; o.z = o.y + v.y; o.w = o.z + v.z;
+            run = o.w + v.w;
+            c4[i] = o;
         }
-        if (row == R - 1 && lane == 0) cb[Gx] = e;                 // end sentinel: cells has Gx*G*G+1 entries
     }
     __syncthreads();
+    PHASE_MARK(10);                                                 // [10] scan
     float4 *dst = sortedQ + (size_t)b * Q;
-    for (int i = s + lane; i < e; i += 64) {
-        const float4 q = src[i];
-        dst[atomicAdd(&cnt[wv][cell_of(q.x, o, inv, Gx)], 1)] = q;
+    if (keep) {                                                     // placement straight from the registers: start + rank
+#pragma unroll
+        for (int k = 0; k < kSortKeep; ++k)
+            if (tid + k * kSortThreads < n) dst[cnt[kbin[k]] + krank[k]] = kq[k];
+    }
+    PHASE_MARK(11);                                                 // [11] placement
+    {   // table[cz][cx][cy] for cy in [cyLo, cyHi) (the last part also writes the padding cy >= G): the threads walk
+        // (cx, cy - cyLo) in order, so every cx line gets one short contiguous store burst
+        const int Gp = table_pitch(G);
+        int *tb = table + (size_t)b * cellStride + (size_t)cz * (Gx + 1) * Gp;
+        const int cyEnd = part == kParts - 1 ? Gp : cyHi, ny = cyEnd - cyLo;
+        const int total = (Gx + 1) * ny, stepx = kSortThreads / ny, stepy = kSortThreads % ny;
+        int cx = tid / ny, ry = tid % ny;
+        for (int i = tid; i < total; i += kSortThreads) {
+            const int cy = cyLo + ry;
+            int v;
+            if (cy >= G) v = s1;                                                        // padding: an empty run at the slab's end
+            else if (cx < Gx) v = cnt[ry * GxP + cx];
+            else v = cy + 1 < cyHi ? cnt[(ry + 1) * GxP] : s1;                          // end of row (cz, cy) = start of the next row
+            tb[cx * Gp + cy] = v;
+            cx += stepx;
+            ry += stepy;
+            if (ry >= ny) { ry -= ny; ++cx; }
+        }
+    }
+    PHASE_MARK(12);                                                 // [12] table plane
+    if (keep) return;
+    __syncthreads();
+    for (int i = tid; i < n; i += kSortThreads) {
+        const float4 q = src[source_of(i)];
+        dst[atomicAdd(&cnt[(cell_of(q.y, oy, iy, G) - cyLo) * GxP + cell_of(q.x, ox, ix, Gx)], 1)] = q;
     }
 }
 
@@ -437,21 +592,40 @@ __device__ __forceinline__ void irregular_queries_tail(const Planes &P, int t, i
     }
 }
 
-// The main kernel: one lane per tet, exact test inline.
-// (A two-phase variant — ballot-compacted candidate ring in LDS + dense exact test — was built
-// and measured in round 1: 14 % fewer VALU instructions but 1.5x slower, because the kernel is
-// bound by vector-memory issue/latency, not by VALU: SQ_WAIT_ANY = 66 % of SQ_WAVE_CYCLES,
-// ~55 gather instructions per wave.  A per-lane LDS candidate queue that defers the exact test so
-// that it is issued max-over-lanes times per wave instead of once per slot was also measured:
-// 133 us vs 114 us — same conclusion.  See DESIGN.md "A1 kernel anatomy" and profiles/.)
 #ifndef PIT_WAVES
 #define PIT_WAVES 6
 #endif
-#ifndef PIT_BATCH
-#define PIT_BATCH 2
-#endif
+
+
+// bounding box of a tet and the classification shared by the traversal kernels.  Every comparison is written so that
+// NaN yields "irregular": a NaN coordinate is dropped by fmin/fmax but poisons all four dotv4 (each involves all four
+// vertices), and |NaN| >= thr is false; Inf and huge values show up in the box.
+struct TetBox {
+    float lo[3], hi[3], w;
+};
+__device__ __forceinline__ bool classify(const float *v, const Planes &P, TetBox &bx)
+{
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        bx.lo[k] = fminf(fminf(v[k], v[3 + k]), fminf(v[6 + k], v[9 + k]));
+        bx.hi[k] = fmaxf(fmaxf(v[k], v[3 + k]), fmaxf(v[6 + k], v[9 + k]));
+    }
+    bx.w = fmaxf(fmaxf(bx.hi[0] - bx.lo[0], bx.hi[1] - bx.lo[1]), bx.hi[2] - bx.lo[2]);
+    const float big = fmaxf(fmaxf(fmaxf(fabsf(bx.lo[0]), fabsf(bx.hi[0])), fmaxf(fabsf(bx.lo[1]), fabsf(bx.hi[1]))),
+                            fmaxf(fabsf(bx.lo[2]), fabsf(bx.hi[2])));
+    const float thr = kTau * ((bx.w * bx.w) * bx.w);
+    const bool cond = fabsf(P.dv[0]) >= thr && fabsf(P.dv[1]) >= thr && fabsf(P.dv[2]) >= thr && fabsf(P.dv[3]) >= thr;
+    // sv == 0 with a zero dotv4 is excluded by |dotv4| >= tau * w^3 > 0
+    return big <= kBig && (P.sv == 0u || P.sv == 15u) && bx.w >= kWMin && cond;
+}
+
+struct CellBox {
+    int cx0, cx1, cy0, cy1, cz0, cz1;
+};
+
+// The round-1 kernel (DEFTET_PIT_EXACT): one lane per tet, box test + the exact predicate on every candidate.
 __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan(const float *__restrict__ tet, int T, int Q,
-                                                  const float *__restrict__ gparam, int G, int Gx, const int *__restrict__ cells,
+                                                  const float *__restrict__ gparam, int G, int Gx, const int *__restrict__ table,
                                                   long long cellStride, const float4 *__restrict__ sortedQ, int *result, int *counters,
                                                   int *irregT, int4 *hits, const float *__restrict__ pts,
                                                   const int *__restrict__ irregQ, int *ucount)
@@ -478,20 +652,8 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan(const float *__rest
     }
     Planes P;
     make_planes(v, P);
-    float lo[3], hi[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        lo[k] = fminf(fminf(v[k], v[3 + k]), fminf(v[6 + k], v[9 + k]));
-        hi[k] = fmaxf(fmaxf(v[k], v[3 + k]), fmaxf(v[6 + k], v[9 + k]));
-    }
-    float w = fmaxf(fmaxf(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]);
-    // conditioning test; every comparison is written so that NaN yields "irregular"
-    bool finite = true;
-#pragma unroll
-    for (int k = 0; k < 12; ++k) finite = finite && (fabsf(v[k]) <= kBig);
-    float mn = fminf(fminf(fabsf(P.dv[0]), fabsf(P.dv[1])), fminf(fabsf(P.dv[2]), fabsf(P.dv[3])));
-    bool regular = finite && (P.sv == 0u || P.sv == 15u) && (w >= kWMin) && (mn >= kTau * ((w * w) * w));
-    // sv==0 with a zero dotv4 is excluded by mn >= tau*w^3 > 0
+    TetBox bx;
+    const bool regular = classify(v, P, bx);
     // hits[b,t] (optional): the queries this tet ACCEPTED (up to 4; w == kHitOverflow marks "more
     // than fit / not recorded") — the backward filters them by condition == t, so no per-hit
     // atomics or linked lists are needed there.
@@ -504,13 +666,13 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan(const float *__rest
         irregular_queries_tail(P, t, b, Q, pts, counters, irregQ, result);
         return;
     }
-    const Grid g = load_grid(gparam + b * 12);
-    const float m = w * kMargin;
+    const Grid g = load_grid(gparam + b * kGridWords);
+    const float m = bx.w * kMargin;
     float elo[3], ehi[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        elo[k] = lo[k] - m;
-        ehi[k] = hi[k] + m;
+        elo[k] = bx.lo[k] - m;
+        ehi[k] = bx.hi[k] + m;
     }
     // no regular query can lie in the enlarged box -> nothing to do
     if (ehi[0] < g.lo[0] || elo[0] > g.hi[0] || ehi[1] < g.lo[1] || elo[1] > g.hi[1] || ehi[2] < g.lo[2] || elo[2] > g.hi[2]) {
@@ -521,51 +683,27 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan(const float *__rest
     const int cx0 = cell_of(elo[0], g.o[0], g.inv[0], Gx), cx1 = cell_of(ehi[0], g.o[0], g.inv[0], Gx);
     const int cy0 = cell_of(elo[1], g.o[1], g.inv[1], G), cy1 = cell_of(ehi[1], g.o[1], g.inv[1], G);
     const int cz0 = cell_of(elo[2], g.o[2], g.inv[2], G), cz1 = cell_of(ehi[2], g.o[2], g.inv[2], G);
-    const int *cb = cells + (size_t)b * cellStride;
+    const int Gp = table_pitch(G);
+    const int *tb = table + (size_t)b * cellStride;
     const float4 *sq = sortedQ + (size_t)b * Q;
     int *res = result + (size_t)b * Q;
-    // Walk the (cz, cy) rows of the cell range; the x-run of a row is contiguous in sortedQ.
-    // Latency hiding per lane: the next row's [start,end) is fetched before the current
-    // row's queries are tested, and queries are fetched PIT_BATCH at a time (measured on the
-    // BASELINE workload: 2 predicated = 104 us, 4 predicated = 135 us, 4 clamped = 113 us, 2 clamped = 118 us).
-    auto test = [&](const float4 &q) {
-        if (q.x >= elo[0] && q.x <= ehi[0] && q.y >= elo[1] && q.y <= ehi[1] && q.z >= elo[2] && q.z <= ehi[2]) {
-            if (accept(P, q.x, q.y, q.z)) {
-                const int qi = __float_as_int(q.w);
-                atomicMin(&res[qi], t);
-                if (hcnt == 0) hrec.x = qi;
-                else if (hcnt == 1) hrec.y = qi;
-                else if (hcnt == 2) hrec.z = qi;
-                else if (hcnt == 3) hrec.w = qi;
-                ++hcnt;
+    for (int cz = cz0; cz <= cz1; ++cz)
+        for (int cy = cy0; cy <= cy1; ++cy) {
+            const int s = tb[table_off(cz, cx0, cy, Gx, Gp)], e = tb[table_off(cz, cx1 + 1, cy, Gx, Gp)];
+            for (int j = s; j < e; ++j) {
+                const float4 q = sq[j];
+                if (q.x >= elo[0] && q.x <= ehi[0] && q.y >= elo[1] && q.y <= ehi[1] && q.z >= elo[2] && q.z <= ehi[2] &&
+                    accept(P, q.x, q.y, q.z)) {
+                    const int qi = __float_as_int(q.w);
+                    atomicMin(&res[qi], t);
+                    if (hcnt == 0) hrec.x = qi;
+                    else if (hcnt == 1) hrec.y = qi;
+                    else if (hcnt == 2) hrec.z = qi;
+                    else if (hcnt == 3) hrec.w = qi;
+                    ++hcnt;
+                }
             }
         }
-    };
-    int cy = cy0, cz = cz0;
-    auto bounds = [&](int row, int &s_, int &e_) {
-        s_ = cb[row + cx0];
-        e_ = cb[row + cx1 + 1];                         // cells has Gx*G*G+1 valid entries
-    };
-    int s, e;
-    bounds((cz * G + cy) * Gx, s, e);
-    for (;;) {
-        int ny = cy + 1, nz = cz;
-        if (ny > cy1) { ny = cy0; nz = cz + 1; }
-        const bool more = nz <= cz1;
-        int s2 = 0, e2 = 0;
-        if (more) bounds((nz * G + ny) * Gx, s2, e2);
-        for (int j = s; j < e; j += PIT_BATCH) {
-            float4 qq[PIT_BATCH];
-#pragma unroll
-            for (int k = 0; k < PIT_BATCH; ++k)
-                if (k == 0 || j + k < e) qq[k] = sq[j + k];     // no clamped duplicate gathers: lane-gathers are the cost
-#pragma unroll
-            for (int k = 0; k < PIT_BATCH; ++k)
-                if (k == 0 || j + k < e) test(qq[k]);
-        }
-        if (!more) break;
-        s = s2; e = e2; cy = ny; cz = nz;
-    }
     if (hits) {
         if (hcnt > 4) {
             hrec.w = kHitOverflow;
@@ -577,34 +715,36 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan(const float *__rest
 }
 
 // ------------------------------------------------------------------------------------
-// k_tet_scan_fma (DEFTET_PIT_FMA / DEFTET_PIT_FMA2): same traversal as k_tet_scan, but the per-candidate work
-// — box test (6 compares) + exact predicate (4 x [3 sub, 3 mul, 2 add, 1 cmp]) — is replaced by a CERTIFIED
-// fused filter: one 3-FMA chain per face plane, one min over the four, two compares.  The exact predicate runs
-// only for candidates the filter cannot decide (a band of a few fp32 ulps around the face planes: ~1e-4 of the
-// candidates on the BASELINE workload), so the result is still bit-exact.  k_tet_scan is bound by VALU issue
-// (44.8 M wave-instructions x 4 cycles = 83 us of its 105 us; profiles/r01_pmc_k_tet_scan_variants.json), and
-// ~80 % of those instructions are the per-candidate tests.
+// k_tet_scan_slab (DEFTET_PIT_AUTO): the per-candidate work — box test (6 compares) + exact predicate
+// (4 x [3 sub, 3 mul, 2 add, 1 cmp]) — is replaced by a CERTIFIED fused filter: one 3-FMA chain per face plane, one
+// min over the four, two compares.  The exact predicate runs only for candidates the filter cannot decide (a band of
+// a few fp32 ulps around the face planes: ~1e-4 of the candidates on the BASELINE workload), so the result is still
+// bit-exact.
 //
-// For a regular tet (see k_tet_scan) with sigma = sign of its four dotv4, the reference accepts p iff
+// For a regular tet (see classify) with sigma = sign of its four dotv4, the reference accepts p iff
 //     sigma * dotp_i(p) > 0  for i = 0..3        (dotp_i = fl(n_i . fl(p - a_i)), source operation order)
 // ("all four false" cannot happen for regular tets).  With D_i = n_i . (p - a_i) in exact
 // arithmetic over the COMPUTED normals:  |dotp_i - D_i| <= 4.0001 u * sum_k |n_ik| (|p_k| + |a_ik|),  u = 2^-24.
 // The filter evaluates  A_i = fma(N_i0, x, fma(N_i1, y, fma(N_i2, z, C_i))),  N_i = sigma n_i,
 // C_i = fl(-sigma c_i - E_i),  c_i = fma(n_i0, a_i0, fma(n_i1, a_i1, n_i2 a_i2)),  which equals
 // sigma D_i - E_i up to  3u sum|n||p| + 7u sum|n||a| + 4u E_i.  With
-//     E_i = 16 u * sum_k |n_ik| (P_k + 2 M_k) + 2^-120,   P_k >= |p_k| for every regular query (grid box),
+//     E_i = 8 u * sum_k |n_ik| (P_k + 2 M_k) + 2^-120,    P_k >= |p_k| for every regular query (grid box),
 //                                                         M_k >= |vertex coordinate k| of this tet,
-// E_i exceeds the sum of both error bounds (7u + 4u on |p|, 11u + 4u... on |a|, with a factor ~2 to spare for the
-// fp32 evaluation of E_i itself), hence
+// the sum of both bounds is (7.0001 u) sum|n|P + (11.0002 u) sum|n|M + 4u E_i, which E_i (1 - 4u) exceeds: 8 > 7.0001 and
+// 16 > 11.0002 leave 12 % / 31 % to spare against the <= 10 u relative error of evaluating E_i itself in fp32 (three FMAs,
+// one addition, S_k = fma(M_k, 16u, 8u P_k) with 8u P_k rounded once).  (Rounds 1-2 used 16 u; halving it halves the
+// undecided band and with it the number of tets that need the exact re-scan.)  Hence
 //     min_i A_i > 0              =>  every sigma * dotp_i > 0        =>  the reference accepts   (certain)
 //     min_i A_i < -2 max_i E_i   =>  some  sigma * dotp_j < 0        =>  the reference rejects   (certain)
 // and anything in between is handed to the exact predicate.  No box test is needed: a point outside the tet
 // violates at least one plane.  2^-120 absorbs products that underflow in either evaluation.
-// PACKED: two candidates per instruction (v_pk_fma_f32).
+//
+// Traversal: the cell box of the tet is walked slab by slab (cz).  The bounds of the <= 4 y-adjacent runs of a slab
+// come from two 16-byte loads of the transposed table (starts at cx0, ends at cx1 + 1); the runs are flattened into
+// one candidate range [0, P4) by their prefix sums, so empty runs cost nothing and a wave-iteration always offers two
+// candidates to every lane that has any left in its slab (rounds 1-2 walked (cz, cy) rows with 2 x 4-byte bounds each:
+// 10.5 wave-iterations for 11.5 candidates per tet at configs[2]; slabs of half-size cells: 7 for 7).
 // ------------------------------------------------------------------------------------
-constexpr float kErrScale = 9.5367431640625e-07f;      // 16 u = 2^-20
-constexpr float kErrAbs = 7.5231638e-37f;              // 2^-120
-
 struct Filter {
     float N[4][3];
     float C[4];
@@ -613,8 +753,8 @@ struct Filter {
 
 // Select with the lane mask in an SGPR pair (VOP3 v_cndmask_b32_e64).  hipcc likes to shrink selects whose mask sits in
 // VCC to the VOP2 form `v_cndmask_b32_e32 …, vcc`, which gfx950 issues ~7.5x slower than an FMA (9.4 vs 1.25 ns per
-// wave-instruction per SIMD, tools/probes/valu_rate_probe.hip; the SGPR-pair form: 1.85 ns).  The traversal loops carry
-// ten selects per iteration, so the form matters more than the count.
+// wave-instruction per SIMD, tools/probes/valu_rate_probe.hip; the SGPR-pair form: 1.85 ns).  The traversal loop carries
+// a dozen selects per iteration, so the form matters more than the count.
 typedef unsigned long long lanemask_t;
 __device__ __forceinline__ int sel(lanemask_t m, int if_set, int if_clear)
 {
@@ -628,25 +768,6 @@ __device__ __forceinline__ unsigned sel(lanemask_t m, unsigned if_set, unsigned 
 }
 __device__ __forceinline__ lanemask_t mask_of(bool c) { return __builtin_amdgcn_ballot_w64(c); }
 
-#ifdef PIT_PHASE_TIMING
-// Diagnostic build only (tools/probes/build_variant.sh … -DPIT_PHASE_TIMING): per-phase wall cycles of the traversal
-// kernels.  Lane 0 of every wave adds its s_memtime deltas to a slot of its own (no atomics: same-address atomics from
-// 32 k waves would dominate what is being measured); deftet_debug_phase_read sums the slots.
-constexpr int kPhaseWaves = 1 << 16;
-__device__ unsigned long long g_phase[kPhaseWaves][16];
-#define PHASE_DECL                                                                                      \
-    long long ph_t_ = clock64();                                                                        \
-    const unsigned ph_w_ = (((unsigned)blockIdx.y * gridDim.x + blockIdx.x) * 4u + (threadIdx.x >> 6)) & (kPhaseWaves - 1)
-#define PHASE_MARK(i)                                                                  \
-    do {                                                                               \
-        const long long ph_n_ = clock64();                                             \
-        if ((threadIdx.x & 63) == 0) g_phase[ph_w_][i] += (unsigned long long)(ph_n_ - ph_t_); \
-        ph_t_ = ph_n_;                                                                 \
-    } while (0)
-#else
-#define PHASE_DECL
-#define PHASE_MARK(i)
-#endif
 
 // load at a 32-bit unsigned BYTE offset from a (wave-uniform) base pointer: scalar-base + vector-offset addressing
 template <typename T>
@@ -654,14 +775,18 @@ __device__ __forceinline__ T ld_off(const void *base, unsigned byte_off)
 {
     return *reinterpret_cast<const T *>(static_cast<const char *>(base) + byte_off);
 }
+// 4-byte-aligned 16-byte load (the table reads start at an arbitrary cy)
+struct __attribute__((packed, aligned(4))) int4u { int x, y, z, w; };
+__device__ __forceinline__ int4u ld_off_u4(const void *base, unsigned byte_off)
+{
+    return *reinterpret_cast<const int4u *>(static_cast<const char *>(base) + byte_off);
+}
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-// Exact re-scan of ONE tet's candidates (box test + reference predicate, as k_tet_scan does), used by k_tet_scan_fma for
-// the rare tets whose traversal met the filter's undecided band or more than four acceptances.  Out of line and called
+// Exact re-scan of ONE tet's candidates (box test + reference predicate, as k_tet_scan does), used by k_tet_scan_slab for
+// the very rare tets that met the filter's undecided band more than twice.  Out of line and called
 // AFTER the traversal loop, so that nothing of it is scheduled (or kept in registers) inside the loop.  Publishes every
 // accepted query with atomicMin (idempotent w.r.t. the ones the filter already accepted) and returns the hit record.
-__device__ __noinline__ int4 exact_rescan(const float *__restrict__ tv, int t, const int *__restrict__ cb, const float4 *__restrict__ sq,
+__device__ __noinline__ int4 exact_rescan(const float *__restrict__ tv, int t, const int *__restrict__ tb, const float4 *__restrict__ sq,
                                           int *res, int G, int Gx, int cx0, int cx1, int cy0, int cy1, int cz0, int cz1,
                                           float m, int *counters, int nB, int b)
 {
@@ -676,12 +801,12 @@ __device__ __noinline__ int4 exact_rescan(const float *__restrict__ tv, int t, c
         elo[k] = fminf(fminf(vv[k], vv[3 + k]), fminf(vv[6 + k], vv[9 + k])) - m;
         ehi[k] = fmaxf(fmaxf(vv[k], vv[3 + k]), fmaxf(vv[6 + k], vv[9 + k])) + m;
     }
+    const int Gp = table_pitch(G);
     int4 hrec = make_int4(-1, -1, -1, -1);
     int hcnt = 0;
     for (int cz = cz0; cz <= cz1; ++cz)
         for (int cy = cy0; cy <= cy1; ++cy) {
-            const int row = (cz * G + cy) * Gx;
-            const int s = cb[row + cx0], e = cb[row + cx1 + 1];
+            const int s = tb[table_off(cz, cx0, cy, Gx, Gp)], e = tb[table_off(cz, cx1 + 1, cy, Gx, Gp)];
             for (int j = s; j < e; ++j) {
                 const float4 q = sq[j];
                 if (q.x >= elo[0] && q.x <= ehi[0] && q.y >= elo[1] && q.y <= ehi[1] && q.z >= elo[2] && q.z <= ehi[2] &&
@@ -703,10 +828,24 @@ __device__ __noinline__ int4 exact_rescan(const float *__restrict__ tv, int t, c
     return hrec;
 }
 
+// The reference predicate for ONE (tet, candidate) pair, used by k_tet_scan_slab for the rare candidates inside the
+// filter's undecided band.  Out of line and re-loading the tet, so that neither the exact planes nor the vertices are
+// kept in registers by the traversal loop.  (For a regular tet the predicate itself is the reference's decision: every
+// point it accepts lies in the enlarged box, DESIGN.md section 3, so no box test is needed.)
+__device__ __noinline__ float exact_accept(const float *__restrict__ tv, float x, float y, float z)
+{
+    float vv[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) vv[k] = tv[k];
+    Planes P;
+    make_planes(vv, P);
+    return accept(P, x, y, z) ? 1.0f : -1.0f;
+}
+
 // irregular queries (NaN / Inf / huge; normally none): re-load the tet so that its vertices need not stay in
 // registers across the traversal loop
-__device__ __noinline__ void fma_irregular_tail_slow(const float *__restrict__ tet, int t, int b, int T, int Q, const float *__restrict__ pts,
-                                                     const int *__restrict__ counters, const int *__restrict__ irregQ, int *result)
+__device__ __noinline__ void irregular_tail_slow(const float *__restrict__ tet, int t, int b, int T, int Q, const float *__restrict__ pts,
+                                                 const int *__restrict__ counters, const int *__restrict__ irregQ, int *result)
 {
     float v[12];
     const float *src = tet + ((size_t)b * T + t) * 12;
@@ -716,31 +855,32 @@ __device__ __noinline__ void fma_irregular_tail_slow(const float *__restrict__ t
     make_planes(v, P);
     irregular_queries_tail(P, t, b, Q, pts, counters, irregQ, result);
 }
-__device__ __forceinline__ void fma_irregular_tail(const float *__restrict__ tet, int t, int b, int T, int Q, const float *__restrict__ pts,
-                                                   const int *__restrict__ counters, const int *__restrict__ irregQ, int *result)
+__device__ __forceinline__ void irregular_tail(const float *__restrict__ tet, int t, int b, int T, int Q, const float *__restrict__ pts,
+                                               const int *__restrict__ counters, const int *__restrict__ irregQ, int *result)
 {
-    if (counters[b * 4 + 1] > 0) fma_irregular_tail_slow(tet, t, b, T, Q, pts, counters, irregQ, result);
+    if (counters[b * 4 + 1] > 0) irregular_tail_slow(tet, t, b, T, Q, pts, counters, irregQ, result);
 }
 
-template <bool PACKED>
-__global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan_fma(const float *__restrict__ tet, int T, int Q,
-                                                  const float *__restrict__ gparam, int G, int Gx, const int *__restrict__ cells,
+#ifndef PIT_BATCH
+#define PIT_BATCH 2
+#endif
+#if PIT_BATCH < 1 || PIT_BATCH > 4
+#error "PIT_BATCH must be 1..4 (a wave-iteration may add at most four acceptances to the four-deep hit register)"
+#endif
+__global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan_slab(const float *__restrict__ tet, int T, int Q,
+                                                  const float *__restrict__ gparam, int G, int Gx, const int *__restrict__ table,
                                                   long long cellStride, const float4 *__restrict__ sortedQ, int *result, int *counters,
                                                   int *irregT, int4 *hits, const float *__restrict__ pts,
-                                                  const int *__restrict__ irregQ, int *ucount, const int *__restrict__ list)
+                                                  const int *__restrict__ irregQ, int *ucount)
 {
     if (ucount && blockIdx.x == 0 && threadIdx.x == 0) ucount[blockIdx.y] = 0;
     const int b = blockIdx.y;
     const int nblk = gridDim.x;
     const int per = (nblk + 7) >> 3;
     const int vb = (blockIdx.x & 7) * per + (blockIdx.x >> 3);        // XCD-aware mapping, see k_tet_scan
-    int t = vb * blockDim.x + threadIdx.x;
+    const int t = vb * blockDim.x + threadIdx.x;
     if (vb >= nblk || t >= T) return;
     PHASE_DECL;
-    if (list) {                                                        // list mode: the tets k_tet_scan_grp deferred (count in counters[.][3])
-        if (t >= counters[b * 4 + 3]) return;
-        t = list[(size_t)b * T + t];
-    }
     float v[12];
     {
         const float4 *src = reinterpret_cast<const float4 *>(tet + ((size_t)b * T + t) * 12);
@@ -749,39 +889,23 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan_fma(const float *__
         v[4] = bq.x; v[5] = bq.y; v[6] = bq.z; v[7] = bq.w;
         v[8] = c.x; v[9] = c.y; v[10] = c.z; v[11] = c.w;
     }
-    float lo[3], hi[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        lo[k] = fminf(fminf(v[k], v[3 + k]), fminf(v[6 + k], v[9 + k]));
-        hi[k] = fmaxf(fmaxf(v[k], v[3 + k]), fmaxf(v[6 + k], v[9 + k]));
-    }
-    const float w = fmaxf(fmaxf(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]);
     Filter F;
-    unsigned sv;
-    float sigma;
-    bool regular;
-    const Grid g = load_grid(gparam + b * 12);
+    TetBox bx;
+    const Grid g = load_grid(gparam + b * kGridWords);
     {
         Planes P;
         make_planes(v, P);
-        bool finite = true;
-#pragma unroll
-        for (int k = 0; k < 12; ++k) finite = finite && (fabsf(v[k]) <= kBig);
-        const float mn = fminf(fminf(fabsf(P.dv[0]), fabsf(P.dv[1])), fminf(fabsf(P.dv[2]), fabsf(P.dv[3])));
-        regular = finite && (P.sv == 0u || P.sv == 15u) && (w >= kWMin) && (mn >= kTau * ((w * w) * w));
-        sv = P.sv;
-        sigma = P.sv == 15u ? 1.0f : -1.0f;
-        if (!regular) {
+        if (!classify(v, P, bx)) {
             int k = atomicAdd(&counters[b * 4 + 0], 1);
             irregT[(size_t)b * T + k] = t;
             if (hits) hits[(size_t)b * T + t] = make_int4(-1, -1, -1, kHitOverflow);
             irregular_queries_tail(P, t, b, Q, pts, counters, irregQ, result);
             return;
         }
+        const float sigma = P.sv == 15u ? 1.0f : -1.0f;
         float S[3];
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
-            S[k] = kErrScale * (fmaxf(fabsf(g.lo[k]), fabsf(g.hi[k])) + 2.0f * fmaxf(fabsf(lo[k]), fabsf(hi[k])));
+        for (int k = 0; k < 3; ++k) S[k] = fmaf(fmaxf(fabsf(bx.lo[k]), fabsf(bx.hi[k])), 2.0f * kErrScale, g.pe[k]);
         float emax = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -794,1103 +918,172 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan_fma(const float *__
         }
         F.twoEmax = 2.0f * emax;
     }
-    const float m = w * kMargin;
+    const float m = bx.w * kMargin;
     float elo[3], ehi[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        elo[k] = lo[k] - m;
-        ehi[k] = hi[k] + m;
+        elo[k] = bx.lo[k] - m;
+        ehi[k] = bx.hi[k] + m;
     }
-    int hcnt = 0;
     if (ehi[0] < g.lo[0] || elo[0] > g.hi[0] || ehi[1] < g.lo[1] || elo[1] > g.hi[1] || ehi[2] < g.lo[2] || elo[2] > g.hi[2]) {
         if (hits) hits[(size_t)b * T + t] = make_int4(-1, -1, -1, -1);
-        fma_irregular_tail(tet, t, b, T, Q, pts, counters, irregQ, result);
+        irregular_tail(tet, t, b, T, Q, pts, counters, irregQ, result);
         return;
     }
     const int cx0 = cell_of(elo[0], g.o[0], g.inv[0], Gx), cx1 = cell_of(ehi[0], g.o[0], g.inv[0], Gx);
     const int cy0 = cell_of(elo[1], g.o[1], g.inv[1], G), cy1 = cell_of(ehi[1], g.o[1], g.inv[1], G);
     const int cz0 = cell_of(elo[2], g.o[2], g.inv[2], G), cz1 = cell_of(ehi[2], g.o[2], g.inv[2], G);
-    const int *cb = cells + (size_t)b * cellStride;
+    const int Gp = table_pitch(G);
+    const int *tb = table + (size_t)b * cellStride;
     const float4 *sq = sortedQ + (size_t)b * Q;
     int *res = result + (size_t)b * Q;
     PHASE_MARK(0);                                                       // [0] load + setup
-    // The loop body is branch-free.  Accepted queries go into a four-deep shift register (h0 = newest) and are
-    // published with atomicMin once, after the traversal.  A candidate in the filter's undecided band, or a fifth
-    // acceptance, only raises a flag; such tets (~1e-4 of them) are re-scanned exactly afterwards.
-    int h0 = -1, h1 = -1, h2 = -1, h3 = -1;
-    float amin = INFINITY;                                             // smallest |filter value| met: <= 2 Emax <=> the undecided band was touched
-    auto decide = [&](float a, int qi, bool live) {
-        const lanemask_t acc = mask_of(live && a > 0.f);
-        amin = fminf(amin, fabsf(a));                                  // a dead second slot repeats the first candidate: no mask needed
-        h3 = sel(acc, h2, h3);
-        h2 = sel(acc, h1, h2);
-        h1 = sel(acc, h0, h1);
-        h0 = sel(acc, qi, h0);
-        hcnt += sel(acc, 1, 0);
-    };
-    // per-lane cursor over (row, position), see k_tet_scan_grp: every wave-iteration each lane takes ITS next two candidates.
-    // All addresses are 32-bit BYTE offsets from wave-uniform bases (scalar base + vector offset addressing: no 64-bit
-    // address arithmetic in the loop); the row offset advances by additions (no integer multiply).
-    const unsigned rowStepB = (unsigned)Gx * 4u;                                        // next cy
-    const unsigned rowWrapB = (unsigned)((G - (cy1 - cy0)) * Gx) * 4u;                 // cy wraps to cy0, cz + 1
-    const unsigned x0B = (unsigned)cx0 * 4u, x1B = (unsigned)(cx1 + 1) * 4u;
-    unsigned rowB = (unsigned)((cz0 * G + cy0) * Gx) * 4u;                              // the row whose bounds sit in (s2, e2)
-    int cy = cy0, cz = cz0;
-    int j = 0, e = 0;
-    int s2 = ld_off<int>(cb, rowB + x0B), e2 = ld_off<int>(cb, rowB + x1B);
+    // Accepted queries go into a four-deep shift register (h0 = newest) and are published with atomicMin once, after the
+    // traversal.  Two rare events are handled by wave-uniform branches inside the loop, so that no tet is ever walked twice
+    // (rounds 1-2 re-scanned such tets after the loop — a serial chain of ~20 memory round trips that kept the whole wave
+    // alive; 1.3e-3 of the tets, 4 us of the launch):
+    //  * a candidate in the filter's undecided band is remembered (two slots) and gets the reference predicate after the
+    //    loop (exact_accept; a third one — never seen on the BASELINE workloads — falls back to the exact re-scan);
+    //  * a lane about to hold more than four acceptances publishes what it holds and marks the tet "overflowed"
+    //    (its hits are then carried by the uncovered list, as before).
+    int h0 = -1, h1 = -1, h2 = -1, h3 = -1, hcnt = 0;
+    bool ovf = false;
+    int pend0 = 0, pend1 = 0, npend = 0;                               // positions in sortedQ of undecided candidates
+    // Slab cursor.  A "slab step" is (cz, chunk of four cy rows); tets that span more than four y cells (rare: needles)
+    // take several chunks per cz.  All table addresses are 32-bit BYTE offsets from the wave-uniform table base.
+    const int ny = cy1 - cy0 + 1;
+    const unsigned lineB = (unsigned)Gp * 4u;                                             // one (cz, cx) line
+    const unsigned slabB = (unsigned)(Gx + 1) * lineB;                                    // one cz plane
+    const unsigned dxB = (unsigned)(cx1 + 1 - cx0) * lineB;                               // start line -> end line
+    unsigned offS = ((unsigned)cz0 * (unsigned)(Gx + 1) + (unsigned)cx0) * lineB + (unsigned)cy0 * 4u;   // bounds of the step held in (nS, nE)
+    int cz = cz0, yoff = 0;                                                              // position of that step
+    int4u nS = ld_off_u4(tb, offS), nE = ld_off_u4(tb, offS + dxB);
     bool haveNext = true;
-    while (j < e || haveNext) {
-        if (j >= e) {                                                   // enter the prefetched row, prefetch the one after it
-            j = s2;
-            e = e2;
-            const lanemask_t wrap = mask_of(cy == cy1);
-            cy = sel(wrap, cy0, cy + 1);
+    int c = 0, P1 = 0, P2 = 0, P3 = 0, P4 = 0, o0 = 0, o1 = 0, o2 = 0, o3 = 0;
+    while (c < P4 || haveNext) {
+        if (c >= P4) {                                                  // enter the prefetched step, prefetch the one after it
+            const int rem = ny - yoff;                                  // rows of this chunk: min(rem, 4)
+            const int n0 = nE.x - nS.x;
+            const int n1 = sel(mask_of(rem > 1), nE.y - nS.y, 0);
+            const int n2 = sel(mask_of(rem > 2), nE.z - nS.z, 0);
+            const int n3 = sel(mask_of(rem > 3), nE.w - nS.w, 0);
+            P1 = n0; P2 = P1 + n1; P3 = P2 + n2; P4 = P3 + n3;
+            o0 = nS.x; o1 = nS.y - P1; o2 = nS.z - P2; o3 = nS.w - P3;
+            c = 0;
+            // pin the eight values here: every use of (nS, nE) then precedes the prefetch below, which can load into the
+            // same registers (without this the compiler sinks the arithmetic below the loads, copies the bounds and waits
+            // for the prefetch right after issuing it)
+            asm volatile("" : "+v"(P1), "+v"(P2), "+v"(P3), "+v"(P4), "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3));
+            const lanemask_t wrap = mask_of(rem <= 4);                  // last chunk of this cz
+            offS += sel(wrap, slabB - (unsigned)yoff * 4u, 16u);
+            yoff = sel(wrap, 0, yoff + 4);
             cz += sel(wrap, 1, 0);
-            rowB += sel(wrap, rowWrapB, rowStepB);
             haveNext = cz <= cz1;
             if (haveNext) {
-                s2 = ld_off<int>(cb, rowB + x0B);
-                e2 = ld_off<int>(cb, rowB + x1B);
+                nS = ld_off_u4(tb, offS);
+                nE = ld_off_u4(tb, offS + dxB);
             }
         }
-        if (j < e) {
-            const bool two = j + 1 < e;
-            const float4 q0 = ld_off<float4>(sq, (unsigned)j * 16u);
-            const float4 q1 = ld_off<float4>(sq, (unsigned)sel(mask_of(two), j + 1, j) * 16u);   // dead slot: the same candidate again (never recorded)
-            if constexpr (PACKED) {
-                const f32x2 X = {q0.x, q1.x}, Y = {q0.y, q1.y}, Z = {q0.z, q1.z};
-                f32x2 A[4];
+        if (c < P4) {
+            // PIT_BATCH candidates per lane and wave-iteration; a dead slot repeats the first candidate (never recorded)
+            int cc[PIT_BATCH], jq[PIT_BATCH];
+            bool live[PIT_BATCH];
+            float4 q[PIT_BATCH];
+            cc[0] = c; live[0] = true;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const f32x2 n0 = {F.N[i][0], F.N[i][0]}, n1 = {F.N[i][1], F.N[i][1]}, n2 = {F.N[i][2], F.N[i][2]}, cc = {F.C[i], F.C[i]};
-                    A[i] = __builtin_elementwise_fma(n0, X, __builtin_elementwise_fma(n1, Y, __builtin_elementwise_fma(n2, Z, cc)));
-                }
-                const float a0 = fminf(fminf(A[0].x, A[1].x), fminf(A[2].x, A[3].x));
-                const float a1 = fminf(fminf(A[0].y, A[1].y), fminf(A[2].y, A[3].y));
-                decide(a0, __float_as_int(q0.w), true);
-                decide(a1, __float_as_int(q1.w), two);
-            } else {
-                float a0, a1;
-                {
-                    float A[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) A[i] = fmaf(F.N[i][0], q0.x, fmaf(F.N[i][1], q0.y, fmaf(F.N[i][2], q0.z, F.C[i])));
-                    a0 = fminf(fminf(A[0], A[1]), fminf(A[2], A[3]));
-                }
-                {
-                    float A[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) A[i] = fmaf(F.N[i][0], q1.x, fmaf(F.N[i][1], q1.y, fmaf(F.N[i][2], q1.z, F.C[i])));
-                    a1 = fminf(fminf(A[0], A[1]), fminf(A[2], A[3]));
-                }
-                decide(a0, __float_as_int(q0.w), true);
-                decide(a1, __float_as_int(q1.w), two);
+            for (int k = 1; k < PIT_BATCH; ++k) {
+                live[k] = c + k < P4;
+                cc[k] = sel(mask_of(live[k]), c + k, c);
             }
-            j += 2;
+#pragma unroll
+            for (int k = 0; k < PIT_BATCH; ++k) {
+                jq[k] = cc[k] + sel(mask_of(cc[k] < P1), o0, sel(mask_of(cc[k] < P2), o1, sel(mask_of(cc[k] < P3), o2, o3)));
+                q[k] = ld_off<float4>(sq, (unsigned)jq[k] * 16u);
+            }
+            __builtin_amdgcn_sched_barrier(0);                         // all gathers in flight before the first filter value is needed
+            float av[PIT_BATCH];
+#pragma unroll
+            for (int k = 0; k < PIT_BATCH; ++k) {
+                float A[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) A[i] = fmaf(F.N[i][0], q[k].x, fmaf(F.N[i][1], q[k].y, fmaf(F.N[i][2], q[k].z, F.C[i])));
+                av[k] = fminf(fminf(A[0], A[1]), fminf(A[2], A[3]));
+            }
+            float am = fabsf(av[0]);                                   // dead slots repeat candidate 0: no mask needed
+#pragma unroll
+            for (int k = 1; k < PIT_BATCH; ++k) am = fminf(am, fabsf(av[k]));
+            if (__builtin_amdgcn_ballot_w64(am <= F.twoEmax) != 0ull) {       // rare: someone met the undecided band
+#pragma unroll
+                for (int k = 0; k < PIT_BATCH; ++k) {                          // remember the candidate; decided after the loop
+                    const lanemask_t bd = mask_of(live[k] && fabsf(av[k]) <= F.twoEmax);
+                    pend1 = sel(bd, pend0, pend1);
+                    pend0 = sel(bd, jq[k], pend0);
+                    npend += sel(bd, 1, 0);
+                    av[k] = __int_as_float(sel(bd, __float_as_int(-1.0f), __float_as_int(av[k])));
+                }
+            }
+            lanemask_t acc[PIT_BATCH];
+            int cnew = hcnt;
+#pragma unroll
+            for (int k = 0; k < PIT_BATCH; ++k) {
+                acc[k] = mask_of(live[k] && av[k] > 0.f);
+                cnew += sel(acc[k], 1, 0);
+            }
+            if (__builtin_amdgcn_ballot_w64(cnew > 4) != 0ull) {              // rare: a fifth acceptance
+                if (cnew > 4) {
+                    if (hcnt > 0) atomicMin(&res[h0], t);
+                    if (hcnt > 1) atomicMin(&res[h1], t);
+                    if (hcnt > 2) atomicMin(&res[h2], t);
+                    if (hcnt > 3) atomicMin(&res[h3], t);
+                    hcnt = 0;
+                    ovf = true;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < PIT_BATCH; ++k) {
+                const int qi = __float_as_int(q[k].w);
+                h3 = sel(acc[k], h2, h3);
+                h2 = sel(acc[k], h1, h2);
+                h1 = sel(acc[k], h0, h1);
+                h0 = sel(acc[k], qi, h0);
+                hcnt += sel(acc[k], 1, 0);
+            }
+            c += PIT_BATCH;
         }
     }
     PHASE_MARK(1);                                                       // [1] traversal loop
-    if (amin <= F.twoEmax || hcnt > 4) {
-        atomicAdd(&counters[gridDim.y * 4 + b * 4 + 1], 1);                   // statistics: tets re-scanned
-        const int4 r = exact_rescan(tet + ((size_t)b * T + t) * 12, t, cb, sq, res, G, Gx, cx0, cx1, cy0, cy1, cz0, cz1, m,
-                                    counters, gridDim.y, b);
-        if (hits) hits[(size_t)b * T + t] = r;
-    } else {
-        if (hcnt > 0) atomicMin(&res[h0], t);
-        if (hcnt > 1) atomicMin(&res[h1], t);
-        if (hcnt > 2) atomicMin(&res[h2], t);
-        if (hcnt > 3) atomicMin(&res[h3], t);
-        if (hits) hits[(size_t)b * T + t] = make_int4(h0, h1, h2, h3);
-    }
-    fma_irregular_tail(tet, t, b, T, Q, pts, counters, irregQ, result);
-    PHASE_MARK(2);                                                       // [2] publish (atomics, record store) / re-scan
-}
-
-// ------------------------------------------------------------------------------------
-// k_tet_scan_grp<NP> (DEFTET_PIT_GRP2/4/6): K = 2*NP CONSECUTIVE tets per lane share one candidate stream.
-//
-// What bounds the one-tet-per-lane kernels is the divergent-gather path: every lane fetches its own row bounds and
-// its own candidate queries, ~20 lane-requests per tet at BASELINE configs[2], and the texture-address unit retires
-// about one divergent lane-request per clock per CU (measured: traversal time = requests / (256 CU x ~2 GHz) within
-// 20 % at configs[1..3]; cutting the VALU work by 40 % with the fused filter moved the time by 7 %,
-// profiles/r02_scan_variants_fma_sweep.jsonl).  Consecutive tets of a mesh are almost always neighbours (the six
-// Kuhn tets of a cube have the same bounding box; in the shipped QuarTet grid the median pair of consecutive tets
-// needs 1.25x the cells of one), so a lane that owns K consecutive tets walks the UNION of their cell ranges once
-// and tests every fetched candidate against all K tets: requests per tet drop by up to K.
-// The K-tet test is where packed fp32 pays: two tets sit in the two halves of a register pair, so the fused filter
-// (see k_tet_scan_fma) costs 12 v_pk_fma_f32 per candidate per PAIR of tets, and the whole per-tet setup (planes,
-// conditioning test, filter coefficients) runs as packed arithmetic too — with the same operation order and
-// rounding per half, so every decision is bit-identical to the one-tet kernels.
-//
-// Accepted (candidate, tet-set) pairs go into an 8-deep shift register per lane (query id | K-bit tet mask); after
-// the traversal each entry is published with ONE atomicMin (the lowest accepting tet of the group is all that can
-// win) and decoded into the per-tet hit records.  Groups whose union range has more cells than the sum of its
-// members' ranges (mesh-order jumps; ~2 % of the groups of the shipped grid) are appended to a list that a second,
-// one-tet-per-lane launch of k_tet_scan_fma processes.  Candidates in the filter's undecided band, or more than
-// eight accepting candidates, send the group to the exact re-scan.
-// ------------------------------------------------------------------------------------
-constexpr int kGrpDepth = 8;
-
-struct TetCells { int cx0, cx1, cy0, cy1, cz0, cz1; };
-
-// Setup of one PAIR of tets in packed arithmetic (.x = first tet, .y = second).  Returns per half: regular, active
-// (regular + live + box meets the query grid), cell range; fills the filter coefficients (zero / -inf for halves that
-// must never accept) and raises twoE to 2 * max E.
-__device__ __forceinline__ void pair_setup(const float *__restrict__ recA, const float *__restrict__ recB, bool liveA, bool liveB,
-                                           const Grid &g, int G, int Gx, f32x2 (&N)[4][3], f32x2 (&C)[4], float &twoE,
-                                           bool (&regular)[2], bool (&active)[2], TetCells (&cells)[2])
-{
-    f32x2 v[12];
-    {
-        const float4 *sa = reinterpret_cast<const float4 *>(recA), *sb = reinterpret_cast<const float4 *>(recB);
-        const float4 a0 = sa[0], a1 = sa[1], a2 = sa[2], b0 = sb[0], b1 = sb[1], b2 = sb[2];
-        v[0] = f32x2{a0.x, b0.x}; v[1] = f32x2{a0.y, b0.y}; v[2] = f32x2{a0.z, b0.z}; v[3] = f32x2{a0.w, b0.w};
-        v[4] = f32x2{a1.x, b1.x}; v[5] = f32x2{a1.y, b1.y}; v[6] = f32x2{a1.z, b1.z}; v[7] = f32x2{a1.w, b1.w};
-        v[8] = f32x2{a2.x, b2.x}; v[9] = f32x2{a2.y, b2.y}; v[10] = f32x2{a2.z, b2.z}; v[11] = f32x2{a2.w, b2.w};
-    }
-    constexpr int ord[4][4] = {{0, 1, 2, 3}, {1, 0, 3, 2}, {2, 3, 0, 1}, {3, 2, 1, 0}};    // check_condition_tet_for.cu:172-175
-    f32x2 n[4][3], dv[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const f32x2 *a = v + 3 * ord[i][0], *b = v + 3 * ord[i][1], *c = v + 3 * ord[i][2], *d = v + 3 * ord[i][3];
-        const f32x2 r1x = b[0] - a[0], r1y = b[1] - a[1], r1z = b[2] - a[2];               // :111
-        const f32x2 r2x = c[0] - a[0], r2y = c[1] - a[1], r2z = c[2] - a[2];               // :112
-        n[i][0] = r1y * r2z - r1z * r2y;                                                     // :63
-        n[i][1] = r1z * r2x - r1x * r2z;                                                     // :64
-        n[i][2] = r1x * r2y - r1y * r2x;                                                     // :65
-        const f32x2 dx = d[0] - a[0], dy = d[1] - a[1], dz = d[2] - a[2];                   // :114
-        dv[i] = n[i][0] * dx + n[i][1] * dy + n[i][2] * dz;                                  // :115
-    }
-    f32x2 lo[3], hi[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        lo[k] = __builtin_elementwise_min(__builtin_elementwise_min(v[k], v[3 + k]), __builtin_elementwise_min(v[6 + k], v[9 + k]));
-        hi[k] = __builtin_elementwise_max(__builtin_elementwise_max(v[k], v[3 + k]), __builtin_elementwise_max(v[6 + k], v[9 + k]));
-    }
-    const f32x2 w = __builtin_elementwise_max(__builtin_elementwise_max(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]);
-    const f32x2 mn = __builtin_elementwise_min(__builtin_elementwise_min(__builtin_elementwise_abs(dv[0]), __builtin_elementwise_abs(dv[1])),
-                                               __builtin_elementwise_min(__builtin_elementwise_abs(dv[2]), __builtin_elementwise_abs(dv[3])));
-    const f32x2 thr = kTau * ((w * w) * w);
-    const f32x2 mg = w * kMargin;
-    f32x2 sigma, S[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const f32x2 M = __builtin_elementwise_max(__builtin_elementwise_abs(lo[k]), __builtin_elementwise_abs(hi[k]));
-        S[k] = kErrScale * (fmaxf(fabsf(g.lo[k]), fabsf(g.hi[k])) + 2.0f * M);
-    }
-    const bool live[2] = {liveA, liveB};
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        bool finite = true;
-#pragma unroll
-        for (int k = 0; k < 12; ++k) finite = finite && (fabsf(v[k][h]) <= kBig);            // NaN fails
-        const unsigned sv = (dv[0][h] > 0 ? 1u : 0u) | (dv[1][h] > 0 ? 2u : 0u) | (dv[2][h] > 0 ? 4u : 0u) | (dv[3][h] > 0 ? 8u : 0u);   // :119
-        regular[h] = finite && (sv == 0u || sv == 15u) && (w[h] >= kWMin) && (mn[h] >= thr[h]);
-        sigma[h] = sv == 15u ? 1.0f : -1.0f;
-        const float elo0 = lo[0][h] - mg[h], ehi0 = hi[0][h] + mg[h], elo1 = lo[1][h] - mg[h], ehi1 = hi[1][h] + mg[h],
-                    elo2 = lo[2][h] - mg[h], ehi2 = hi[2][h] + mg[h];
-        const bool ingrid = !(ehi0 < g.lo[0] || elo0 > g.hi[0] || ehi1 < g.lo[1] || elo1 > g.hi[1] || ehi2 < g.lo[2] || elo2 > g.hi[2]);
-        active[h] = live[h] && regular[h] && ingrid;
-        cells[h].cx0 = cell_of(elo0, g.o[0], g.inv[0], Gx); cells[h].cx1 = cell_of(ehi0, g.o[0], g.inv[0], Gx);
-        cells[h].cy0 = cell_of(elo1, g.o[1], g.inv[1], G);  cells[h].cy1 = cell_of(ehi1, g.o[1], g.inv[1], G);
-        cells[h].cz0 = cell_of(elo2, g.o[2], g.inv[2], G);  cells[h].cz1 = cell_of(ehi2, g.o[2], g.inv[2], G);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const f32x2 *a = v + 3 * ord[i][0];
-        const f32x2 c = __builtin_elementwise_fma(n[i][0], a[0], __builtin_elementwise_fma(n[i][1], a[1], n[i][2] * a[2]));
-        const f32x2 E = __builtin_elementwise_fma(__builtin_elementwise_abs(n[i][0]), S[0],
-                                                  __builtin_elementwise_fma(__builtin_elementwise_abs(n[i][1]), S[1],
-                                                                            __builtin_elementwise_abs(n[i][2]) * S[2])) + kErrAbs;
-        f32x2 Nx = sigma * n[i][0], Ny = sigma * n[i][1], Nz = sigma * n[i][2];
-        f32x2 Cc = -sigma * c - E;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            // inactive half: never accepts, never "undecided" (selects, not branches)
-            Nx[h] = active[h] ? Nx[h] : 0.f; Ny[h] = active[h] ? Ny[h] : 0.f; Nz[h] = active[h] ? Nz[h] : 0.f;
-            Cc[h] = active[h] ? Cc[h] : -INFINITY;
-            twoE = fmaxf(twoE, active[h] ? 2.0f * E[h] : 0.f);
+    if (npend > 0) {                                                      // undecided candidates (rare)
+        const float *tv = tet + ((size_t)b * T + t) * 12;
+        atomicAdd(&counters[gridDim.y * 4 + b * 4 + 1], npend);              // statistics: candidates decided exactly
+        if (npend > 2) {
+            const int4 r = exact_rescan(tv, t, tb, sq, res, G, Gx, cx0, cx1, cy0, cy1, cz0, cz1, m, counters, gridDim.y, b);
+            if (hits) hits[(size_t)b * T + t] = r;
+            irregular_tail(tet, t, b, T, Q, pts, counters, irregQ, result);
+            return;
         }
-        N[i][0] = Nx; N[i][1] = Ny; N[i][2] = Nz; C[i] = Cc;
-    }
-}
-
-// exact re-scan of one tet with its OWN cell range (for the grouped kernel's rare slow path)
-__device__ __noinline__ void exact_rescan_tet(const float *__restrict__ tet, int t, int b, int T, const float *__restrict__ gparam, int G, int Gx,
-                                              const int *__restrict__ cb, const float4 *__restrict__ sq, int *res, int4 *hits, int *counters)
-{
-    const float *tv = tet + ((size_t)b * T + t) * 12;
-    float lo[3], hi[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        lo[k] = fminf(fminf(tv[k], tv[3 + k]), fminf(tv[6 + k], tv[9 + k]));
-        hi[k] = fmaxf(fmaxf(tv[k], tv[3 + k]), fmaxf(tv[6 + k], tv[9 + k]));
-    }
-    const float w = fmaxf(fmaxf(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]);
-    const float m = w * kMargin;
-    const Grid g = load_grid(gparam + b * 12);
-    const int cx0 = cell_of(lo[0] - m, g.o[0], g.inv[0], Gx), cx1 = cell_of(hi[0] + m, g.o[0], g.inv[0], Gx);
-    const int cy0 = cell_of(lo[1] - m, g.o[1], g.inv[1], G), cy1 = cell_of(hi[1] + m, g.o[1], g.inv[1], G);
-    const int cz0 = cell_of(lo[2] - m, g.o[2], g.inv[2], G), cz1 = cell_of(hi[2] + m, g.o[2], g.inv[2], G);
-    const int4 r = exact_rescan(tv, t, cb, sq, res, G, Gx, cx0, cx1, cy0, cy1, cz0, cz1, m, counters, gridDim.y, b);
-    if (hits) hits[(size_t)b * T + t] = r;
-}
-
-template <int NP>
-__global__ __launch_bounds__(256, NP == 1 ? 5 : (NP == 2 ? 4 : 3)) void k_tet_scan_grp(
-    const float *__restrict__ tet, int T, int Q, const float *__restrict__ gparam, int G, int Gx, const int *__restrict__ cells,
-    long long cellStride, const float4 *__restrict__ sortedQ, int *result, int *counters, int *irregT, int4 *hits,
-    const float *__restrict__ pts, const int *__restrict__ irregQ, int *ucount, int *deferT)
-{
-    constexpr int K = 2 * NP;
-    constexpr int kShift = 32 - K;                          // entry = query id | tet mask << kShift   (host guarantees Q < 2^kShift)
-    constexpr unsigned kIdMask = (1u << kShift) - 1u;
-    if (ucount && blockIdx.x == 0 && threadIdx.x == 0) ucount[blockIdx.y] = 0;
-    const int b = blockIdx.y;
-    const int nblk = gridDim.x, per = (nblk + 7) >> 3;
-    const int vb = (blockIdx.x & 7) * per + (blockIdx.x >> 3);        // XCD-aware mapping, see k_tet_scan
-    const long long grp = (long long)vb * blockDim.x + threadIdx.x;
-    const long long t0l = grp * K;
-    if (vb >= nblk || t0l >= T) return;
-    const int t0 = (int)t0l;
-    const Grid g = load_grid(gparam + b * 12);
-    f32x2 N[NP][4][3], C[NP][4];
-    float twoE = 0.f;
-    unsigned regM = 0, actM = 0, liveM = 0;                 // bit k: tet t0 + k is regular / active / exists
-    int ux0 = 0x7FFFFFFF, ux1 = -1, uy0 = 0x7FFFFFFF, uy1 = -1, uz0 = 0x7FFFFFFF, uz1 = -1;
-    long long vsum = 0;
-    int nact = 0;
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-        const int tA = t0 + 2 * p, tB = tA + 1;
-        const bool liveA = tA < T, liveB = tB < T;
-        const float *recA = tet + ((size_t)b * T + (liveA ? tA : t0)) * 12, *recB = tet + ((size_t)b * T + (liveB ? tB : t0)) * 12;
-        bool r2[2], a2[2];
-        TetCells c2[2];
-        pair_setup(recA, recB, liveA, liveB, g, G, Gx, N[p], C[p], twoE, r2, a2, c2);
-        const bool lv[2] = {liveA, liveB};
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int k = 2 * p + h;
-            if (lv[h]) liveM |= 1u << k;
-            if (lv[h] && r2[h]) regM |= 1u << k;
-            if (a2[h]) {
-                actM |= 1u << k;
-                ux0 = min(ux0, c2[h].cx0); ux1 = max(ux1, c2[h].cx1);
-                uy0 = min(uy0, c2[h].cy0); uy1 = max(uy1, c2[h].cy1);
-                uz0 = min(uz0, c2[h].cz0); uz1 = max(uz1, c2[h].cz1);
-                vsum += (long long)(c2[h].cx1 - c2[h].cx0 + 1) * (c2[h].cy1 - c2[h].cy0 + 1) * (c2[h].cz1 - c2[h].cz0 + 1);
-                ++nact;
-            }
-        }
-    }
-    // irregular tets (normally none): listed for k_finalize's brute-force pass, never recorded
-    if (regM != liveM) {
-#pragma unroll 1
-        for (int k = 0; k < K; ++k) {
-            if (((liveM & ~regM) >> k) & 1u) {
-                const int i = atomicAdd(&counters[b * 4 + 0], 1);
-                irregT[(size_t)b * T + i] = t0 + k;
-                if (hits) hits[(size_t)b * T + t0 + k] = make_int4(-1, -1, -1, kHitOverflow);
-            }
-        }
-    }
-    // regular members whose box misses the query grid: empty record
-    if (hits && (regM & ~actM)) {
-#pragma unroll 1
-        for (int k = 0; k < K; ++k)
-            if (((regM & ~actM) >> k) & 1u) hits[(size_t)b * T + t0 + k] = make_int4(-1, -1, -1, -1);
-    }
-    const int *cb = cells + (size_t)b * cellStride;
-    const float4 *sq = sortedQ + (size_t)b * Q;
-    int *res = result + (size_t)b * Q;
-    int e0 = -1, e1 = -1, e2 = -1, e3 = -1, e4 = -1, e5 = -1, e6 = -1, e7 = -1;
-    int cnt = 0, nslow = 0;
-    bool traversed = false;
-    if (nact > 0) {
-        const long long vu = (long long)(ux1 - ux0 + 1) * (uy1 - uy0 + 1) * (uz1 - uz0 + 1);
-        if (vu > vsum) {
-            // a jump in the mesh order inside this group: its members go to the one-tet-per-lane pass
-            const int base = atomicAdd(&counters[b * 4 + 3], nact);
-            int o = 0;
-#pragma unroll 1
-            for (int k = 0; k < K; ++k)
-                if ((actM >> k) & 1u) deferT[(size_t)b * T + base + (o++)] = t0 + k;
-        } else {
-            traversed = true;
-            auto test = [&](const float4 &q, bool live) {
-                unsigned bits = 0;
-                bool unc = false;
-                const f32x2 X = {q.x, q.x}, Y = {q.y, q.y}, Z = {q.z, q.z};
-#pragma unroll
-                for (int p = 0; p < NP; ++p) {
-                    f32x2 A[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        A[i] = __builtin_elementwise_fma(N[p][i][0], X, __builtin_elementwise_fma(N[p][i][1], Y,
-                                                                                                    __builtin_elementwise_fma(N[p][i][2], Z, C[p][i])));
-                    const float ax = fminf(fminf(A[0].x, A[1].x), fminf(A[2].x, A[3].x));
-                    const float ay = fminf(fminf(A[0].y, A[1].y), fminf(A[2].y, A[3].y));
-                    const bool accx = ax > 0.f, accy = ay > 0.f;
-                    unc = unc | ((!accx) & (ax >= -twoE)) | ((!accy) & (ay >= -twoE));   // bitwise on purpose: no branches in this loop
-                    bits = (bits << 2) | (accx ? 2u : 0u) | (accy ? 1u : 0u);           // first tet of the group = most significant bit
-                }
-                nslow += (live & unc) ? 1 : 0;
-                const bool push = live & (bits != 0u);
-                const int entry = (int)(((unsigned)__float_as_int(q.w) & kIdMask) | (bits << kShift));
-                e7 = push ? e6 : e7; e6 = push ? e5 : e6; e5 = push ? e4 : e5; e4 = push ? e3 : e4;
-                e3 = push ? e2 : e3; e2 = push ? e1 : e2; e1 = push ? e0 : e1; e0 = push ? entry : e0;
-                cnt += push ? 1 : 0;
-            };
-            // Per-lane cursor over (row, position): in every wave-iteration each lane takes ITS next two candidates,
-            // wherever they are — a lane whose run is exhausted enters its next row while the others keep testing.
-            // (Looping row by row instead makes the wave spend max-over-lanes iterations on EVERY row: ~30 wave-
-            // iterations for ~6.5 per lane at configs[2], i.e. 20 % lane utilisation and 30 dependent gather round trips.)
-            int cy = uy0, cz = uz0;                                   // the row whose bounds sit in (s2, e2r)
-            int j = 0, e = 0;
-            int s2 = cb[(cz * G + cy) * Gx + ux0], e2r = cb[(cz * G + cy) * Gx + ux1 + 1];
-            bool haveNext = true;
-            while (j < e || haveNext) {
-                if (j >= e) {                                         // enter the prefetched row, prefetch the one after it
-                    j = s2;
-                    e = e2r;
-                    ++cy;
-                    if (cy > uy1) { cy = uy0; ++cz; }
-                    haveNext = cz <= uz1;
-                    if (haveNext) {
-                        const int row2 = (cz * G + cy) * Gx;
-                        s2 = cb[row2 + ux0];
-                        e2r = cb[row2 + ux1 + 1];
-                    }
-                }
-                if (j < e) {
-                    const bool two = j + 1 < e;
-                    const float4 q0 = sq[j];
-                    float4 q1;
-                    q1.x = __builtin_nondeterministic_value(q0.x); q1.y = __builtin_nondeterministic_value(q0.y);
-                    q1.z = __builtin_nondeterministic_value(q0.z); q1.w = __builtin_nondeterministic_value(q0.w);
-                    if (two) q1 = sq[j + 1];
-                    test(q0, true);
-                    test(q1, two);
-                    j += 2;
-                }
-            }
-        }
-    }
-    if (traversed) {
-        if (nslow > 0 || cnt > kGrpDepth) {
-            // undecided band met, or more accepting candidates than the register holds: exact re-scan of every active member
-            atomicAdd(&counters[gridDim.y * 4 + b * 4 + 0], 1);              // statistics: groups re-scanned
-#pragma unroll 1
-            for (int k = 0; k < K; ++k)
-                if ((actM >> k) & 1u) exact_rescan_tet(tet, t0 + k, b, T, gparam, G, Gx, cb, sq, res, hits, counters);
-        } else {
-            const int ent[kGrpDepth] = {e0, e1, e2, e3, e4, e5, e6, e7};
-            // one atomicMin per entry: only the lowest accepting tet of the group can be the query's answer
-#pragma unroll
-            for (int i = 0; i < kGrpDepth; ++i) {
-                if (i < cnt) {
-                    const unsigned bits = (unsigned)ent[i] >> kShift;
-                    const int first = K - 1 - (31 - __clz((int)bits));          // most significant set bit = first tet
-                    atomicMin(&res[(unsigned)ent[i] & kIdMask], t0 + first);
-                }
-            }
-            if (hits) {
-#pragma unroll
-                for (int k = 0; k < K; ++k) {
-                    if (!((actM >> k) & 1u)) continue;
-                    int r0 = -1, r1 = -1, r2 = -1, r3 = -1, c = 0;
-#pragma unroll
-                    for (int i = 0; i < kGrpDepth; ++i) {
-                        const bool has = i < cnt && (((unsigned)ent[i] >> (kShift + K - 1 - k)) & 1u);
-                        const int qi = (int)((unsigned)ent[i] & kIdMask);
-                        r3 = has ? r2 : r3; r2 = has ? r1 : r2; r1 = has ? r0 : r1; r0 = has ? qi : r0;
-                        c += has ? 1 : 0;
-                    }
-                    if (c > 4) {
-                        r3 = kHitOverflow;
-                        note_overflow(counters, gridDim.y, b, t0 + k);
-                    }
-                    hits[(size_t)b * T + t0 + k] = make_int4(r0, r1, r2, r3);
-                }
-            }
-        }
-    }
-    if (counters[b * 4 + 1] > 0) {                                     // irregular queries (normally none)
-#pragma unroll 1
-        for (int k = 0; k < K; ++k)
-            if ((regM >> k) & 1u) fma_irregular_tail_slow(tet, t0 + k, b, T, Q, pts, counters, irregQ, result);
-    }
-}
-
-// ------------------------------------------------------------------------------------
-// k_tet_scan_lds<STAGE_Q> (DEFTET_PIT_LDSB / DEFTET_PIT_LDS): the fused-filter traversal with the block's slice of the
-// grid staged in LDS.  What the one-tet-per-lane kernels pay for is the divergent-gather path: ~8 row-bound loads and ~12
-// candidate loads per tet, each lane with its own address (TA_TA_BUSY ~85 % of the kernel time, profiles/r02_pmc_*).  The
-// 256 consecutive tets of a workgroup are neighbours in any sensibly ordered mesh, so the workgroup
-//   1. reduces its lanes' cell ranges to one union box (six LDS atomics per lane),
-//   2. copies the box's cell starts into LDS with coalesced loads                       (<= kCapB ints), and, with STAGE_Q,
-//   3. the queries of the box's row runs as well: per-row LDS offsets by a block scan   (<= kCapQ queries),
-// after which every lane walks ITS OWN cell range exactly as k_tet_scan_fma does, but out of LDS.  Same candidates, same
-// certified filter, same exact fallback, same records: results are bit-identical.  A workgroup whose box does not fit
-// (incoherent tet order, list mode) keeps the per-lane global loads for whatever did not fit.
-// ------------------------------------------------------------------------------------
-__device__ __forceinline__ int wave_min_i(int v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off));
-    return v;
-}
-__device__ __forceinline__ int wave_max_i(int v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off));
-    return v;
-}
-
-constexpr int kCapB = 2048;        // staged cell starts per workgroup (8 KB)
-constexpr int kCapQ = 1024;        // staged queries per workgroup (16 KB)
-constexpr int kCapRows = 512;      // rows of the union box (2 per thread in the offset scan)
-
-template <bool STAGE_Q>
-__global__ __launch_bounds__(256, 5) void k_tet_scan_lds(const float *__restrict__ tet, int T, int Q,
-                                                  const float *__restrict__ gparam, int G, int Gx, const int *__restrict__ cells,
-                                                  long long cellStride, const float4 *__restrict__ sortedQ, int *result, int *counters,
-                                                  int *irregT, int4 *hits, const float *__restrict__ pts,
-                                                  const int *__restrict__ irregQ, int *ucount)
-{
-    __shared__ int s_box4[24];
-    __shared__ int s_cb[kCapB];
-    __shared__ int s_delta[STAGE_Q ? kCapRows : 1];        // LDS position of a row's first staged query minus its global position
-    __shared__ float4 s_q[STAGE_Q ? kCapQ : 1];
-    __shared__ int s_wsum[5];
-    if (ucount && blockIdx.x == 0 && threadIdx.x == 0) ucount[blockIdx.y] = 0;
-    const int b = blockIdx.y, tid = threadIdx.x;
-    const int nblk = gridDim.x;
-    const int per = (nblk + 7) >> 3;
-    const int vb = (blockIdx.x & 7) * per + (blockIdx.x >> 3);        // XCD-aware mapping, see k_tet_scan
-    if (vb >= nblk || vb * 256 >= T) return;                           // whole workgroup out of range (uniform)
-    const int t = vb * 256 + tid;
-    const bool live = t < T;
-    PHASE_DECL;
-    const Grid g = load_grid(gparam + b * 12);
-    Filter F;
-    bool regular = false, active = false;
-    int cx0 = 0, cx1 = -1, cy0 = 0, cy1 = -1, cz0 = 0, cz1 = -1;
-    float m = 0.f;
-    {
-        float v[12];
-        const float4 *src = reinterpret_cast<const float4 *>(tet + ((size_t)b * T + (live ? t : vb * 256)) * 12);
-        const float4 a = src[0], bq = src[1], c = src[2];
-        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
-        v[4] = bq.x; v[5] = bq.y; v[6] = bq.z; v[7] = bq.w;
-        v[8] = c.x; v[9] = c.y; v[10] = c.z; v[11] = c.w;
-        float lo[3], hi[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            lo[k] = fminf(fminf(v[k], v[3 + k]), fminf(v[6 + k], v[9 + k]));
-            hi[k] = fmaxf(fmaxf(v[k], v[3 + k]), fmaxf(v[6 + k], v[9 + k]));
-        }
-        const float w = fmaxf(fmaxf(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]);
-        Planes P;
-        make_planes(v, P);
-        bool finite = true;
-#pragma unroll
-        for (int k = 0; k < 12; ++k) finite = finite && (fabsf(v[k]) <= kBig);
-        const float mn = fminf(fminf(fabsf(P.dv[0]), fabsf(P.dv[1])), fminf(fabsf(P.dv[2]), fabsf(P.dv[3])));
-        regular = finite && (P.sv == 0u || P.sv == 15u) && (w >= kWMin) && (mn >= kTau * ((w * w) * w));
-        const float sigma = P.sv == 15u ? 1.0f : -1.0f;
-        float S[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-            S[k] = kErrScale * (fmaxf(fabsf(g.lo[k]), fabsf(g.hi[k])) + 2.0f * fmaxf(fabsf(lo[k]), fabsf(hi[k])));
-        float emax = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float n0 = P.n[i][0], n1 = P.n[i][1], n2 = P.n[i][2];
-            const float c2 = fmaf(n0, P.a[i][0], fmaf(n1, P.a[i][1], n2 * P.a[i][2]));
-            const float E = fmaf(fabsf(n0), S[0], fmaf(fabsf(n1), S[1], fabsf(n2) * S[2])) + kErrAbs;
-            F.N[i][0] = sigma * n0; F.N[i][1] = sigma * n1; F.N[i][2] = sigma * n2;
-            F.C[i] = -sigma * c2 - E;
-            emax = fmaxf(emax, E);
-        }
-        F.twoEmax = 2.0f * emax;
-        m = w * kMargin;
-        const float e0 = lo[0] - m, e1 = hi[0] + m, e2 = lo[1] - m, e3 = hi[1] + m, e4 = lo[2] - m, e5 = hi[2] + m;
-        const bool ingrid = !(e1 < g.lo[0] || e0 > g.hi[0] || e3 < g.lo[1] || e2 > g.hi[1] || e5 < g.lo[2] || e4 > g.hi[2]);
-        active = live && regular && ingrid;
-        if (active) {
-            cx0 = cell_of(e0, g.o[0], g.inv[0], Gx); cx1 = cell_of(e1, g.o[0], g.inv[0], Gx);
-            cy0 = cell_of(e2, g.o[1], g.inv[1], G);  cy1 = cell_of(e3, g.o[1], g.inv[1], G);
-            cz0 = cell_of(e4, g.o[2], g.inv[2], G);  cz1 = cell_of(e5, g.o[2], g.inv[2], G);
-        }
-        if (live && !regular) {                                        // irregular tet (normally none): k_finalize tests it against every query
-            const int k = atomicAdd(&counters[b * 4 + 0], 1);
-            irregT[(size_t)b * T + k] = t;
-            if (hits) hits[(size_t)b * T + t] = make_int4(-1, -1, -1, kHitOverflow);
-        }
-        if (live && regular && !ingrid && hits) hits[(size_t)b * T + t] = make_int4(-1, -1, -1, -1);
-    }
-    PHASE_MARK(4);                                                       // [4] load + setup
-    // ---- 1. union box of the workgroup's active lanes: wave butterflies, then four partials per bound through LDS
-    //         (64 lanes hitting one LDS word with an atomic serialise: measured 2x the whole kernel)
-    {
-        constexpr int kBigI = 0x7FFFFFFF;
-        const int m0 = wave_min_i(active ? cx0 : kBigI), m1 = wave_min_i(active ? cy0 : kBigI), m2 = wave_min_i(active ? cz0 : kBigI);
-        const int m3 = wave_max_i(active ? cx1 : -1), m4 = wave_max_i(active ? cy1 : -1), m5 = wave_max_i(active ? cz1 : -1);
-        if ((tid & 63) == 0) {
-            int *dst = s_box4 + (tid >> 6) * 6;
-            dst[0] = m0; dst[1] = m1; dst[2] = m2; dst[3] = m3; dst[4] = m4; dst[5] = m5;
-        }
-    }
-    __syncthreads();
-    const int ux0 = min(min(s_box4[0], s_box4[6]), min(s_box4[12], s_box4[18])), uy0 = min(min(s_box4[1], s_box4[7]), min(s_box4[13], s_box4[19]));
-    const int uz0 = min(min(s_box4[2], s_box4[8]), min(s_box4[14], s_box4[20])), ux1 = max(max(s_box4[3], s_box4[9]), max(s_box4[15], s_box4[21]));
-    const int uy1 = max(max(s_box4[4], s_box4[10]), max(s_box4[16], s_box4[22])), uz1 = max(max(s_box4[5], s_box4[11]), max(s_box4[17], s_box4[23]));
-    const int *cb = cells + (size_t)b * cellStride;
-    const float4 *sq = sortedQ + (size_t)b * Q;
-    int *res = result + (size_t)b * Q;
-    PHASE_MARK(5);                                                       // [5] union box (butterflies + barrier)
-    bool stB = false, stQ = false;
-    int nx1 = 1, ny = 1;
-    if (ux1 >= ux0) {                                                  // some lane is active (uniform)
-        nx1 = ux1 - ux0 + 2;
-        ny = uy1 - uy0 + 1;
-        const int nz = uz1 - uz0 + 1;
-        const long long rowsl = (long long)ny * nz;
-        stB = rowsl <= kCapRows && rowsl * nx1 <= kCapB;
-        if (stB) {
-            // ---- 2. cell starts of the box -> LDS (row r = (cz - uz0) * ny + (cy - uy0), nx1 starts per row)
-            const int rows = (int)rowsl, n = rows * nx1;
-            const float inv_nx1 = 1.0f / (float)nx1, inv_ny = 1.0f / (float)ny;
-            for (int i = tid; i < n; i += 256) {
-                const int r = (int)(((float)i + 0.5f) * inv_nx1), x = i - r * nx1;          // exact for these small integers
-                const int rz = (int)(((float)r + 0.5f) * inv_ny), ry = r - rz * ny;
-                s_cb[i] = cb[((uz0 + rz) * G + (uy0 + ry)) * Gx + ux0 + x];
-            }
-            __syncthreads();
-            PHASE_MARK(6);                                               // [6] cell starts -> LDS (+ barrier)
-            if (STAGE_Q) {
-                // ---- 3. per-row LDS offsets (block exclusive scan of the run lengths, two rows per thread)
-                const int r0 = tid * 2, r1 = r0 + 1;
-                const int st0 = r0 < rows ? s_cb[r0 * nx1] : 0, st1 = r1 < rows ? s_cb[r1 * nx1] : 0;
-                const int len0 = r0 < rows ? s_cb[r0 * nx1 + nx1 - 1] - st0 : 0;
-                const int len1 = r1 < rows ? s_cb[r1 * nx1 + nx1 - 1] - st1 : 0;
-                const int sum = len0 + len1;
-                int incl = sum;
-                const int lane = tid & 63, wv = tid >> 6;
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    const int u = __shfl_up(incl, off);
-                    if (lane >= off) incl += u;
-                }
-                if (lane == 63) s_wsum[wv] = incl;
-                __syncthreads();
-                int base = 0;
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    if (k < wv) base += s_wsum[k];
-                const int total = (s_wsum[0] + s_wsum[1]) + (s_wsum[2] + s_wsum[3]);
-                const int excl = base + incl - sum;
-                stQ = total <= kCapQ;                                   // uniform
-                if (stQ) {
-                    if (r0 < rows) s_delta[r0] = excl - st0;
-                    if (r1 < rows) s_delta[r1] = excl + len0 - st1;
-                }
-                __syncthreads();
-                if (stQ) {
-                    // the queries of the box's row runs -> LDS, eight lanes per row (128 contiguous bytes per step)
-                    for (int r = tid >> 3; r < rows; r += 32) {
-                        const int st = s_cb[r * nx1], nq = s_cb[r * nx1 + nx1 - 1] - st, d = s_delta[r];
-                        for (int k = tid & 7; k < nq; k += 8) s_q[st + k + d] = sq[st + k];
-                    }
-                    __syncthreads();
-                }
-            }
-        }
-    }
-    PHASE_MARK(7);                                                       // [7] offsets scan + queries -> LDS (+ barriers)
-    // ---- traversal (per-lane cursor, see k_tet_scan_grp), operands from LDS where staged.  Three specialisations of
-    //      one loop (MODE 0: bounds and queries from global memory; 1: bounds from LDS; 2: both from LDS), picked by a
-    //      workgroup-uniform branch OUTSIDE the loop.  Row positions advance by additions; selects use SGPR-pair masks.
-    int hcnt = 0;
-    int h0 = -1, h1 = -1, h2 = -1, h3 = -1;
-    float amin = INFINITY;
-    if (active) {
-        auto decide = [&](float a, int qi, bool lv) {
-            const lanemask_t acc = mask_of(lv && a > 0.f);
-            amin = fminf(amin, fabsf(a));                              // a dead second slot repeats the first candidate
-            h3 = sel(acc, h2, h3);
-            h2 = sel(acc, h1, h2);
-            h1 = sel(acc, h0, h1);
-            h0 = sel(acc, qi, h0);
-            hcnt += sel(acc, 1, 0);
-        };
-        auto filter = [&](const float4 &q) {
-            float A[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) A[i] = fmaf(F.N[i][0], q.x, fmaf(F.N[i][1], q.y, fmaf(F.N[i][2], q.z, F.C[i])));
-            return fminf(fminf(A[0], A[1]), fminf(A[2], A[3]));
-        };
-        auto traverse = [&](auto modeTag) {
-            constexpr int MODE = decltype(modeTag)::value;
-            // global addressing (MODE 0): byte offsets from the scalar base, as in k_tet_scan_fma
-            const unsigned rowStepB = (unsigned)Gx * 4u, rowWrapB = (unsigned)((G - (cy1 - cy0)) * Gx) * 4u;
-            const unsigned x0B = (unsigned)cx0 * 4u, x1B = (unsigned)(cx1 + 1) * 4u;
-            unsigned rowB = (unsigned)((cz0 * G + cy0) * Gx) * 4u;
-            // LDS addressing (MODE 1, 2): staged row r = (cz - uz0) * ny + (cy - uy0); its starts sit at s_cb[r * nx1 ...]
-            const int rStep = 1, rWrap = ny - (cy1 - cy0);
-            int r = (cz0 - uz0) * ny + (cy0 - uy0);
-            int rb0 = r * nx1 + (cx0 - ux0), rb1 = r * nx1 + (cx1 + 1 - ux0);          // positions of this lane's two bounds
-            const int rbStep = nx1, rbWrap = rWrap * nx1;
-            int cy = cy0, cz = cz0;                                     // the row whose bounds sit in (s2, e2)
-            int j = 0, e = 0, d = 0, d2 = 0;
-            int s2, e2;
-            if (MODE == 0) {
-                s2 = ld_off<int>(cb, rowB + x0B);
-                e2 = ld_off<int>(cb, rowB + x1B);
-            } else {
-                s2 = s_cb[rb0];
-                e2 = s_cb[rb1];
-                if (MODE == 2) d2 = s_delta[r];
-            }
-            bool haveNext = true;
-            while (j < e || haveNext) {
-                if (j >= e) {                                           // enter the prefetched row, prefetch the one after it
-                    j = s2;
-                    e = e2;
-                    d = d2;
-                    const lanemask_t wrap = mask_of(cy == cy1);
-                    cy = sel(wrap, cy0, cy + 1);
-                    cz += sel(wrap, 1, 0);
-                    haveNext = cz <= cz1;
-                    if (MODE == 0) {
-                        rowB += sel(wrap, rowWrapB, rowStepB);
-                        if (haveNext) {
-                            s2 = ld_off<int>(cb, rowB + x0B);
-                            e2 = ld_off<int>(cb, rowB + x1B);
-                        }
-                    } else {
-                        const int inc = sel(wrap, rbWrap, rbStep);
-                        rb0 += inc;
-                        rb1 += inc;
-                        if (MODE == 2) r += sel(wrap, rWrap, rStep);
-                        if (haveNext) {
-                            s2 = s_cb[rb0];
-                            e2 = s_cb[rb1];
-                            if (MODE == 2) d2 = s_delta[r];
-                        }
-                    }
-                }
-                if (j < e) {
-                    const bool two = j + 1 < e;
-                    const int j1 = sel(mask_of(two), j + 1, j);         // dead slot: the same candidate again (never recorded)
-                    float4 q0, q1;
-                    if (MODE == 2) {
-                        q0 = s_q[j + d];
-                        q1 = s_q[j1 + d];
-                    } else {
-                        q0 = ld_off<float4>(sq, (unsigned)j * 16u);
-                        q1 = ld_off<float4>(sq, (unsigned)j1 * 16u);
-                    }
-                    const float a0 = filter(q0), a1 = filter(q1);
-                    decide(a0, __float_as_int(q0.w), true);
-                    decide(a1, __float_as_int(q1.w), two);
-                    j += 2;
-                }
-            }
-        };
-        if (stQ) traverse(std::integral_constant<int, 2>{});
-        else if (stB) traverse(std::integral_constant<int, 1>{});
-        else traverse(std::integral_constant<int, 0>{});
-        PHASE_MARK(8);                                                   // [8] traversal loop
-        if (amin <= F.twoEmax || hcnt > 4) {
-            atomicAdd(&counters[gridDim.y * 4 + b * 4 + 1], 1);               // statistics: tets re-scanned
-            const int4 r4 = exact_rescan(tet + ((size_t)b * T + t) * 12, t, cb, sq, res, G, Gx, cx0, cx1, cy0, cy1, cz0, cz1, m,
-                                         counters, gridDim.y, b);
-            if (hits) hits[(size_t)b * T + t] = r4;
-        } else {
-            if (hcnt > 0) atomicMin(&res[h0], t);
-            if (hcnt > 1) atomicMin(&res[h1], t);
-            if (hcnt > 2) atomicMin(&res[h2], t);
-            if (hcnt > 3) atomicMin(&res[h3], t);
-            if (hits) hits[(size_t)b * T + t] = make_int4(h0, h1, h2, h3);
-        }
-    }
-    if (live) fma_irregular_tail(tet, t, b, T, Q, pts, counters, irregQ, result);
-    PHASE_MARK(9);                                                       // [9] publish / re-scan
-}
-
-// ------------------------------------------------------------------------------------
-// Wave-cooperative variant of k_tet_scan for spatially coherent tet orders (DEFTET_PIT_STAGED).
-// MEASURED NO FASTER than k_tet_scan on the BASELINE workload (0.322 vs 0.324 ms per step: 37 %
-// fewer vector-memory instructions, 16 % fewer L1 accesses, but 18 % more VALU work for the
-// staging bookkeeping; profiles/r01_pmc_k_tet_scan_variants.json) — kept selectable, not default.
-// The 64 tets of a wave mostly visit the same few cell rows, yet every lane fetches its row
-// bounds and candidate queries with its own gather instructions (~55 per wave, the kernel's
-// bottleneck).  Here a wave first reduces its lanes' cell ranges to one union box; if that box
-// is small (<= 64 rows, <= kSubMax cell bounds, <= kStageQ queries) the wave copies the box's
-// cell bounds and queries into LDS with a handful of full-width loads, and each lane then walks
-// ITS OWN rows out of LDS.  Same candidates, same exact test, same atomicMin — only the source of
-// the operands changes.  Waves whose box is too large (incoherent tet order, or a wave that
-// straddles two grid columns) take the per-lane gather path of k_tet_scan.
-// ------------------------------------------------------------------------------------
-#ifndef PIT_STAGE_BATCH
-#define PIT_STAGE_BATCH 4
-#endif
-constexpr int kSubMax = 448;           // staged cell bounds per wave
-constexpr int kStageQ = 224;           // staged queries per wave
-
-__device__ __forceinline__ void wave_fence()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-#ifndef PIT_STAGE_WAVES
-#define PIT_STAGE_WAVES 5
-#endif
-__global__ __launch_bounds__(256, PIT_STAGE_WAVES) void k_tet_scan_staged(const float *__restrict__ tet, int T, int Q,
-                                                  const float *__restrict__ gparam, int G, int Gx, const int *__restrict__ cells,
-                                                  long long cellStride, const float4 *__restrict__ sortedQ, int *result, int *counters,
-                                                  int *irregT, int4 *hits, const float *__restrict__ pts,
-                                                  const int *__restrict__ irregQ, int *ucount)
-{
-    if (ucount && blockIdx.x == 0 && threadIdx.x == 0) ucount[blockIdx.y] = 0;   // uncovered-hit counter of the hit buffer (k_finalize appends)
-    __shared__ int s_cs[4][kSubMax];
-    __shared__ float4 s_q[4][kStageQ];
-    __shared__ int s_off[4][65];
-    __shared__ int s_rs[4][64];
-    const int b = blockIdx.y;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int nblk = gridDim.x, per = (nblk + 7) >> 3;
-    const int vb = (blockIdx.x & 7) * per + (blockIdx.x >> 3);       // XCD-aware mapping, see k_tet_scan
-    const int t = vb * blockDim.x + threadIdx.x;
-    if (t - lane >= T) return;                                       // whole wave out of range
-    const bool intet = t < T;
-    float v[12];
-    {
-        const float4 *src = reinterpret_cast<const float4 *>(tet + ((size_t)b * T + (intet ? t : t - lane)) * 12);
-        float4 a = src[0], bq = src[1], c = src[2];
-        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
-        v[4] = bq.x; v[5] = bq.y; v[6] = bq.z; v[7] = bq.w;
-        v[8] = c.x; v[9] = c.y; v[10] = c.z; v[11] = c.w;
-    }
-    Planes P;
-    make_planes(v, P);
-    float lo[3], hi[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        lo[k] = fminf(fminf(v[k], v[3 + k]), fminf(v[6 + k], v[9 + k]));
-        hi[k] = fmaxf(fmaxf(v[k], v[3 + k]), fmaxf(v[6 + k], v[9 + k]));
-    }
-    const float w = fmaxf(fmaxf(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]);
-    bool finite = true;
-#pragma unroll
-    for (int k = 0; k < 12; ++k) finite = finite && (fabsf(v[k]) <= kBig);
-    const float mn = fminf(fminf(fabsf(P.dv[0]), fabsf(P.dv[1])), fminf(fabsf(P.dv[2]), fabsf(P.dv[3])));
-    const bool regular = finite && (P.sv == 0u || P.sv == 15u) && (w >= kWMin) && (mn >= kTau * ((w * w) * w));
-    int4 hrec = make_int4(-1, -1, -1, -1);
-    int hcnt = 0;
-    if (intet && !regular) {
-        const int k = atomicAdd(&counters[b * 4 + 0], 1);
-        irregT[(size_t)b * T + k] = t;
-        hrec.w = kHitOverflow;                                       // accepted by k_finalize, not recorded
-    }
-    const Grid g = load_grid(gparam + b * 12);
-    const float m = w * kMargin;
-    float elo[3], ehi[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { elo[k] = lo[k] - m; ehi[k] = hi[k] + m; }
-    const bool active = intet && regular &&
-                        !(ehi[0] < g.lo[0] || elo[0] > g.hi[0] || ehi[1] < g.lo[1] || elo[1] > g.hi[1] || ehi[2] < g.lo[2] || elo[2] > g.hi[2]);
-    const int cx0 = cell_of(elo[0], g.o[0], g.inv[0], Gx), cx1 = cell_of(ehi[0], g.o[0], g.inv[0], Gx);
-    const int cy0 = cell_of(elo[1], g.o[1], g.inv[1], G), cy1 = cell_of(ehi[1], g.o[1], g.inv[1], G);
-    const int cz0 = cell_of(elo[2], g.o[2], g.inv[2], G), cz1 = cell_of(ehi[2], g.o[2], g.inv[2], G);
-    const int *cb = cells + (size_t)b * cellStride;
-    const float4 *sq = sortedQ + (size_t)b * Q;
-    int *res = result + (size_t)b * Q;
-    auto test = [&](const float4 &q) {
-        if (q.x >= elo[0] && q.x <= ehi[0] && q.y >= elo[1] && q.y <= ehi[1] && q.z >= elo[2] && q.z <= ehi[2]) {
-            if (accept(P, q.x, q.y, q.z)) {
+        for (int k = 0; k < npend; ++k) {
+            const float4 q = sq[k == 0 ? pend0 : pend1];
+            if (exact_accept(tv, q.x, q.y, q.z) > 0.f) {
                 const int qi = __float_as_int(q.w);
                 atomicMin(&res[qi], t);
-                if (hcnt == 0) hrec.x = qi;
-                else if (hcnt == 1) hrec.y = qi;
-                else if (hcnt == 2) hrec.z = qi;
-                else if (hcnt == 3) hrec.w = qi;
-                ++hcnt;
-            }
-        }
-    };
-    if (__any(active)) {
-        constexpr int kBigI = 1 << 30;
-        const int ux0 = wave_min_i(active ? cx0 : kBigI), ux1 = wave_max_i(active ? cx1 : -1);
-        const int uy0 = wave_min_i(active ? cy0 : kBigI), uy1 = wave_max_i(active ? cy1 : -1);
-        const int uz0 = wave_min_i(active ? cz0 : kBigI), uz1 = wave_max_i(active ? cz1 : -1);
-        const int nx1 = ux1 - ux0 + 2, ny = uy1 - uy0 + 1, nz = uz1 - uz0 + 1, rows = ny * nz;   // nx1: bounds per row
-        bool staged = rows <= 64 && rows * nx1 <= kSubMax;           // wave-uniform
-        int total = 0;
-        if (staged) {
-            const float inv_nx1 = 1.0f / (float)nx1, inv_ny = 1.0f / (float)ny;
-            for (int i = lane; i < rows * nx1; i += 64) {
-                const int r = (int)(((float)i + 0.5f) * inv_nx1), x = i - r * nx1;      // exact for these small integers
-                const int rz = (int)(((float)r + 0.5f) * inv_ny), ry = r - rz * ny;
-                s_cs[wv][i] = cb[((uz0 + rz) * G + (uy0 + ry)) * Gx + ux0 + x];
-            }
-            wave_fence();
-            const int len = lane < rows ? s_cs[wv][lane * nx1 + nx1 - 1] - s_cs[wv][lane * nx1] : 0;
-            int incl = len;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const int u = __shfl_up(incl, off);
-                if (lane >= off) incl += u;
-            }
-            total = __shfl(incl, 63);
-            s_off[wv][lane] = incl - len;
-            if (lane == 63) s_off[wv][64] = total;
-            if (lane < rows) s_rs[wv][lane] = s_cs[wv][lane * nx1];
-            staged = total <= kStageQ;
-        }
-        if (staged) {
-            wave_fence();
-            for (int i = lane; i < total; i += 64) {
-                int lo_r = 0, hi_r = rows;                              // largest r with s_off[r] <= i
-                while (hi_r - lo_r > 1) {
-                    const int mid = (lo_r + hi_r) >> 1;
-                    if (s_off[wv][mid] <= i) lo_r = mid; else hi_r = mid;
-                }
-                s_q[wv][i] = sq[s_rs[wv][lo_r] + (i - s_off[wv][lo_r])];
-            }
-            wave_fence();
-            if (active) {
-                for (int cz = cz0; cz <= cz1; ++cz)
-                    for (int cy = cy0; cy <= cy1; ++cy) {
-                        const int r = (cz - uz0) * ny + (cy - uy0), base = r * nx1;
-                        const int s = s_cs[wv][base + cx0 - ux0], e = s_cs[wv][base + cx1 + 1 - ux0];
-                        const int l0 = s_off[wv][r] + (s - s_rs[wv][r]), n = e - s;
-                        for (int j = 0; j < n; j += PIT_STAGE_BATCH) {
-                            float4 qq[PIT_STAGE_BATCH];
-#pragma unroll
-                            for (int k = 0; k < PIT_STAGE_BATCH; ++k) qq[k] = s_q[wv][l0 + min(j + k, n - 1)];
-#pragma unroll
-                            for (int k = 0; k < PIT_STAGE_BATCH; ++k)
-                                if (k == 0 || j + k < n) test(qq[k]);
-                        }
-                    }
-            }
-        } else if (active) {
-            // per-lane gather path (identical to k_tet_scan)
-            int cy = cy0, cz = cz0;
-            int s = cb[(cz * G + cy) * Gx + cx0];
-            int e = cb[(cz * G + cy) * Gx + cx1 + 1];
-            for (;;) {
-                int ny2 = cy + 1, nz2 = cz;
-                if (ny2 > cy1) { ny2 = cy0; nz2 = cz + 1; }
-                const bool more = nz2 <= cz1;
-                int s2 = 0, e2 = 0;
-                if (more) {
-                    const int row2 = (nz2 * G + ny2) * Gx;
-                    s2 = cb[row2 + cx0];
-                    e2 = cb[row2 + cx1 + 1];
-                }
-                for (int j = s; j < e; j += PIT_STAGE_BATCH) {
-                    const int last = e - 1;
-                    float4 qq[PIT_STAGE_BATCH];
-#pragma unroll
-                    for (int k = 0; k < PIT_STAGE_BATCH; ++k) qq[k] = sq[min(j + k, last)];
-#pragma unroll
-                    for (int k = 0; k < PIT_STAGE_BATCH; ++k)
-                        if (k == 0 || j + k < e) test(qq[k]);
-                }
-                if (!more) break;
-                s = s2; e = e2; cy = ny2; cz = nz2;
-            }
-        }
-    }
-    if (hits && intet) {
-        if (hcnt > 4) {
-            hrec.w = kHitOverflow;
-            note_overflow(counters, gridDim.y, b, t);
-        }
-        hits[(size_t)b * T + t] = hrec;
-    }
-    if (intet) irregular_queries_tail(P, t, b, Q, pts, counters, irregQ, result);
-}
-
-// ------------------------------------------------------------------------------------
-// Row-balanced variant of k_tet_scan (DEFTET_PIT_ROWS).  In k_tet_scan a lane walks ALL cell rows of
-// its tet, so a wave issues max-over-lanes(rows) x max-over-lanes(batches) gather rounds while the
-// average lane needs 2.25 rows (measured lane utilisation 42 %).  Here the unit of work is one
-// (tet, row) pair: the 64 tets of a wave publish their plane records in LDS, the rows are numbered
-// by a wave prefix sum, and the wave processes them 64 at a time, each lane fetching the planes of
-// the row's owner from LDS.  Same candidates, same exact test, same atomicMin; hit records are
-// collected per tet in LDS.
-// ------------------------------------------------------------------------------------
-constexpr int kRowWords = 33;          // n[12] | a[12] | sv | elo[3] | ehi[3] | cx0,cx1 | cy0,ny,cz0
-
-__global__ __launch_bounds__(256, 4) void k_tet_scan_rows(const float *__restrict__ tet, int T, int Q,
-                                                  const float *__restrict__ gparam, int G, int Gx, const int *__restrict__ cells,
-                                                  long long cellStride, const float4 *__restrict__ sortedQ, int *result, int *counters,
-                                                  int *irregT, int4 *hits, const float *__restrict__ pts,
-                                                  const int *__restrict__ irregQ, int *ucount)
-{
-    if (ucount && blockIdx.x == 0 && threadIdx.x == 0) ucount[blockIdx.y] = 0;   // uncovered-hit counter of the hit buffer (k_finalize appends)
-    __shared__ float s_rec[4][kRowWords][64];
-    __shared__ int s_off[4][65];
-    __shared__ int s_hcnt[4][64];
-    __shared__ int s_hrec[4][4][64];
-    const int b = blockIdx.y;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int nblk = gridDim.x, per = (nblk + 7) >> 3;
-    const int vb = (blockIdx.x & 7) * per + (blockIdx.x >> 3);       // XCD-aware mapping, see k_tet_scan
-    const int t = vb * blockDim.x + threadIdx.x;
-    const int tw = t - lane;                                         // first tet of this wave
-    if (vb >= nblk || tw >= T) return;                               // whole wave out of range
-    const bool intet = t < T;
-    const Grid g = load_grid(gparam + b * 12);
-    int nrows = 0;
-    bool irregularTet = false;
-    {
-        float v[12];
-        const float4 *src = reinterpret_cast<const float4 *>(tet + ((size_t)b * T + (intet ? t : tw)) * 12);
-        float4 a = src[0], bq = src[1], c = src[2];
-        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
-        v[4] = bq.x; v[5] = bq.y; v[6] = bq.z; v[7] = bq.w;
-        v[8] = c.x; v[9] = c.y; v[10] = c.z; v[11] = c.w;
-        Planes P;
-        make_planes(v, P);
-        float lo[3], hi[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            lo[k] = fminf(fminf(v[k], v[3 + k]), fminf(v[6 + k], v[9 + k]));
-            hi[k] = fmaxf(fmaxf(v[k], v[3 + k]), fmaxf(v[6 + k], v[9 + k]));
-        }
-        const float w = fmaxf(fmaxf(hi[0] - lo[0], hi[1] - lo[1]), hi[2] - lo[2]);
-        bool finite = true;
-#pragma unroll
-        for (int k = 0; k < 12; ++k) finite = finite && (fabsf(v[k]) <= kBig);
-        const float mn = fminf(fminf(fabsf(P.dv[0]), fabsf(P.dv[1])), fminf(fabsf(P.dv[2]), fabsf(P.dv[3])));
-        const bool regular = finite && (P.sv == 0u || P.sv == 15u) && (w >= kWMin) && (mn >= kTau * ((w * w) * w));
-        irregularTet = intet && !regular;
-        const float m = w * kMargin;
-        float elo[3], ehi[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { elo[k] = lo[k] - m; ehi[k] = hi[k] + m; }
-        const bool active = intet && regular &&
-                            !(ehi[0] < g.lo[0] || elo[0] > g.hi[0] || ehi[1] < g.lo[1] || elo[1] > g.hi[1] || ehi[2] < g.lo[2] || elo[2] > g.hi[2]);
-        const int cx0 = cell_of(elo[0], g.o[0], g.inv[0], Gx), cx1 = cell_of(ehi[0], g.o[0], g.inv[0], Gx);
-        const int cy0 = cell_of(elo[1], g.o[1], g.inv[1], G), cy1 = cell_of(ehi[1], g.o[1], g.inv[1], G);
-        const int cz0 = cell_of(elo[2], g.o[2], g.inv[2], G), cz1 = cell_of(ehi[2], g.o[2], g.inv[2], G);
-        const int ny = cy1 - cy0 + 1;
-        nrows = active ? ny * (cz1 - cz0 + 1) : 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                s_rec[wv][i * 3 + k][lane] = P.n[i][k];
-                s_rec[wv][12 + i * 3 + k][lane] = P.a[i][k];
-            }
-        s_rec[wv][24][lane] = __int_as_float((int)P.sv);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { s_rec[wv][25 + k][lane] = elo[k]; s_rec[wv][28 + k][lane] = ehi[k]; }
-        s_rec[wv][31][lane] = __int_as_float(cx0 | (cx1 << 16));
-        s_rec[wv][32][lane] = __int_as_float(cy0 | (ny << 8) | (cz0 << 16));
-    }
-    if (irregularTet) irregT[(size_t)b * T + atomicAdd(&counters[b * 4 + 0], 1)] = t;
-    s_hcnt[wv][lane] = 0;
-    // exclusive prefix of the row counts
-    int incl = nrows;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int u = __shfl_up(incl, off);
-        if (lane >= off) incl += u;
-    }
-    const int M = __shfl(incl, 63);
-    s_off[wv][lane] = incl - nrows;
-    if (lane == 63) s_off[wv][64] = M;
-    wave_fence();
-    const int *cb = cells + (size_t)b * cellStride;
-    const float4 *sq = sortedQ + (size_t)b * Q;
-    int *res = result + (size_t)b * Q;
-    for (int base = 0; base < M; base += 64) {
-        const int item = base + lane;
-        if (item < M) {
-            int lo_j = 0, hi_j = 64;                                  // largest j with s_off[j] <= item
-#pragma unroll
-            for (int it = 0; it < 6; ++it) {
-                const int mid = (lo_j + hi_j) >> 1;
-                if (s_off[wv][mid] <= item) lo_j = mid; else hi_j = mid;
-            }
-            const int j = lo_j;
-            int r = item - s_off[wv][j];
-            Planes P;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    P.n[i][k] = s_rec[wv][i * 3 + k][j];
-                    P.a[i][k] = s_rec[wv][12 + i * 3 + k][j];
-                }
-            P.sv = (unsigned)__float_as_int(s_rec[wv][24][j]);
-            float elo[3], ehi[3];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) { elo[k] = s_rec[wv][25 + k][j]; ehi[k] = s_rec[wv][28 + k][j]; }
-            const int pk1 = __float_as_int(s_rec[wv][31][j]), pk2 = __float_as_int(s_rec[wv][32][j]);
-            const int cx0 = pk1 & 0xFFFF, cx1 = pk1 >> 16, cy0 = pk2 & 0xFF, ny = (pk2 >> 8) & 0xFF, cz0 = pk2 >> 16;
-            const int rz = (int)(((float)r + 0.5f) * (1.0f / (float)ny));     // exact for these small integers
-            const int cy = cy0 + (r - rz * ny), cz = cz0 + rz;
-            const int row = (cz * G + cy) * Gx;
-            const int s = cb[row + cx0], e = cb[row + cx1 + 1];
-            const int tg = tw + j;
-            for (int jq = s; jq < e; jq += 2) {
-                float4 qq[2];
-                qq[0] = sq[jq];
-                if (jq + 1 < e) qq[1] = sq[jq + 1];
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    if (k == 1 && jq + 1 >= e) break;
-                    const float4 q = qq[k];
-                    if (q.x >= elo[0] && q.x <= ehi[0] && q.y >= elo[1] && q.y <= ehi[1] && q.z >= elo[2] && q.z <= ehi[2]) {
-                        if (accept(P, q.x, q.y, q.z)) {
-                            const int qi = __float_as_int(q.w);
-                            atomicMin(&res[qi], tg);
-                            const int slot = atomicAdd(&s_hcnt[wv][j], 1);
-                            if (slot < 4) s_hrec[wv][slot][j] = qi;
-                        }
-                    }
+                if (hcnt < 4) {                                              // (already published: only the record needs it)
+                    h3 = h2; h2 = h1; h1 = h0; h0 = qi;
+                    ++hcnt;
+                    atomicMin(&res[h0], t);
+                } else {
+                    ovf = true;
                 }
             }
         }
     }
-    wave_fence();
-    if (hits && intet) {
-        int4 hrec = make_int4(-1, -1, -1, -1);
-        const int hcnt = s_hcnt[wv][lane];
-        if (hcnt > 0) hrec.x = s_hrec[wv][0][lane];
-        if (hcnt > 1) hrec.y = s_hrec[wv][1][lane];
-        if (hcnt > 2) hrec.z = s_hrec[wv][2][lane];
-        if (hcnt > 3) hrec.w = s_hrec[wv][3][lane];
-        if (irregularTet) hrec = make_int4(-1, -1, -1, kHitOverflow);          // accepted by k_finalize, not recorded
-        if (hcnt > 4) {
-            hrec.w = kHitOverflow;
-            note_overflow(counters, gridDim.y, b, t);
-        }
-        hits[(size_t)b * T + t] = hrec;
-    }
-    if (intet && counters[b * 4 + 1] > 0) {                           // irregular queries (normally none)
-        Planes P;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                P.n[i][k] = s_rec[wv][i * 3 + k][lane];
-                P.a[i][k] = s_rec[wv][12 + i * 3 + k][lane];
-            }
-        P.sv = (unsigned)__float_as_int(s_rec[wv][24][lane]);
-        irregular_queries_tail(P, t, b, Q, pts, counters, irregQ, result);
-    }
+    if (hcnt > 0) atomicMin(&res[h0], t);
+    if (hcnt > 1) atomicMin(&res[h1], t);
+    if (hcnt > 2) atomicMin(&res[h2], t);
+    if (hcnt > 3) atomicMin(&res[h3], t);
+    if (ovf) note_overflow(counters, gridDim.y, b, t);
+    if (hits) hits[(size_t)b * T + t] = ovf ? make_int4(-1, -1, -1, kHitOverflow) : make_int4(h0, h1, h2, h3);
+    irregular_tail(tet, t, b, T, Q, pts, counters, irregQ, result);
+    PHASE_MARK(2);                                                       // [2] publish (atomics, record store) / re-scan
 }
 
 // barycentric weights, utils/tet_utils.py:25-45 (same association as the torch expression)
@@ -2400,34 +1593,56 @@ __global__ __launch_bounds__(256) void k_paste_bwd(const float *__restrict__ con
 // ------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------
-static int pick_G(int T, int Q)
+// Grid tunables.  Environment overrides (experiments only) are read ONCE per process, so a prepare and the scan that
+// consumes it always agree on the layout.
+struct Tunables {
+    double gdiv = 6.0;      // tets per coarse cell
+    double qdiv = 2.0;      // queries per coarse cell
+    double yzfine = 2.0;    // y/z cells per coarse cell edge
+    double xfine = 2.0;     // x cells per y/z cell edge (the run direction)
+    Tunables()
+    {
+        auto get = [](const char *name, double lo, double hi, double &dst) {
+            if (const char *e = getenv(name)) {
+                const double v = atof(e);
+                if (v >= lo && v <= hi) dst = v;
+            }
+        };
+        get("DEFTET_PIT_GDIV", 0.25, 4096.0, gdiv);
+        get("DEFTET_PIT_QDIV", 0.03, 4096.0, qdiv);
+        get("DEFTET_PIT_YZFINE", 0.25, 8.0, yzfine);
+        get("DEFTET_PIT_XFINE", 0.25, 16.0, xfine);
+    }
+};
+static const Tunables &tunables()
 {
-    double gdiv = PIT_GDIV;
-    if (const char *e = getenv("DEFTET_PIT_GDIV")) {            // experiments only: tets per cell
-        const double v = atof(e);
-        if (v >= 0.25 && v <= 4096.0) gdiv = v;
-    }
-    double qdiv = 2.0;
-    if (const char *e = getenv("DEFTET_PIT_QDIV")) {            // experiments only: queries per cell
-        const double v = atof(e);
-        if (v >= 0.03 && v <= 4096.0) qdiv = v;
-    }
-    double a = T / gdiv, bq = (Q > 0 ? Q : 1) / qdiv;
-    double m = a < bq ? a : bq;
-    int G = (int)llround(cbrt(m < 1 ? 1 : m));
-    if (G < 1) G = 1;
-    if (G > kMaxG) G = kMaxG;
-    return G;
+    static const Tunables t;
+    return t;
+}
+
+static void pick_grid(int T, int Q, int &G, int &Gx)
+{
+    const Tunables &tn = tunables();
+    const double a = T / tn.gdiv, bq = (Q > 0 ? Q : 1) / tn.qdiv;
+    const double m = a < bq ? a : bq;
+    long long g = llround(tn.yzfine * cbrt(m < 1 ? 1 : m));
+    if (g < 1) g = 1;
+    if (g > kMaxG) g = kMaxG;
+    long long gx = llround(tn.xfine * (double)g);
+    if (gx < 1) gx = 1;
+    while (gx > 1 && (g / 4 + 2) * (gx | 1) > kMaxBins) --gx;       // a slab quarter's (cy, cx) counters must fit k_slab_sort's LDS
+    G = (int)g;
+    Gx = (int)gx;
 }
 
 struct Layout {
     int G, Gx, nRowBlk, chunkQ;
-    long long cellStride;   // padded cells per shape (>= Gx*G*G + 1)
+    long long cellStride;   // padded table words per shape (>= G * (Gx + 1) * (G + 3))
     size_t bytes;
     float *bboxPart;
-    int *counters, *cells, *blockHist, *rowTotal, *rowStart, *result, *irregT, *irregQ, *deferT;
-    int2 *qkey;
-    float4 *rowSorted, *sortedQ;
+    int nblkPad;
+    int *counters, *table, *pre, *result, *irregT, *irregQ;
+    float4 *localQ, *sortedQ;
     float *rec, *gparam;
 };
 
@@ -2439,14 +1654,8 @@ static Layout make_layout(int B, int T, int Q, int algo, void *ws, size_t wsByte
     if (algo == DEFTET_PIT_BRUTE) {
         L.rec = A.take<float>((size_t)B * T * 32);
     } else {
-        L.G = pick_G(T, Q);
-        int xfine = kXFine;
-        if (const char *e = getenv("DEFTET_PIT_XFINE")) {         // experiments only: x-refinement of the cells
-            const int v = atoi(e);
-            if (v >= 1 && v <= kMaxXFine) xfine = v;
-        }
-        L.Gx = L.G * xfine;
-        const long long n = (long long)L.Gx * L.G * L.G + 1, R = (long long)L.G * L.G;
+        pick_grid(T, Q, L.G, L.Gx);
+        const long long n = (long long)L.G * (L.Gx + 1) * table_pitch(L.G);
         L.cellStride = (n + 63) / 64 * 64;
         L.nRowBlk = (Q + kRowTile - 1) / kRowTile;
         if (L.nRowBlk > kMaxRowBlocks) L.nRowBlk = kMaxRowBlocks;
@@ -2454,17 +1663,14 @@ static Layout make_layout(int B, int T, int Q, int algo, void *ws, size_t wsByte
         L.chunkQ = ((Q + L.nRowBlk - 1) / L.nRowBlk + 255) / 256 * 256;
         L.bboxPart = A.take<float>((size_t)B * kBoxBlocks * 6);
         L.counters = A.take<int>((size_t)B * (8 + kOvfCap));  // 4 counters + 4 statistics words per shape, then the overflowed-tet lists
-        L.gparam = A.take<float>((size_t)B * 12);
-        L.cells = A.take<int>((size_t)B * L.cellStride);
-        L.blockHist = A.take<int>((size_t)B * L.nRowBlk * R);
-        L.rowTotal = A.take<int>((size_t)B * R);
-        L.rowStart = A.take<int>((size_t)B * (R + 1));
-        L.qkey = A.take<int2>((size_t)B * Q);
-        L.rowSorted = A.take<float4>((size_t)B * Q);
+        L.gparam = A.take<float>((size_t)B * kGridWords);
+        L.table = A.take<int>((size_t)B * L.cellStride);
+        L.nblkPad = (L.nRowBlk + 15) / 16 * 16;
+        L.pre = A.take<int>((size_t)B * (L.G * kSub + 1) * L.nblkPad);
+        L.localQ = A.take<float4>((size_t)B * Q);
         L.sortedQ = A.take<float4>((size_t)B * Q);
         L.irregT = A.take<int>((size_t)B * T);
         L.irregQ = A.take<int>((size_t)B * Q);
-        L.deferT = A.take<int>((size_t)B * T);
     }
     L.bytes = align_up(A.off, 256);
     return L;
@@ -2488,6 +1694,13 @@ extern "C" size_t deftet_point_in_tet_hits_ints(int B, int T, int Q)
     return hit_list_off(B, T) + (size_t)B * Q;
 }
 
+extern "C" int deftet_point_in_tet_grid_dims(int T, int Q, int *G_yz, int *G_x)
+{
+    DEFTET_CHECK_ARG(T >= 0 && Q >= 0 && G_yz && G_x, "bad argument");
+    pick_grid(T, Q, *G_yz, *G_x);
+    return DEFTET_OK;
+}
+
 static int pit_check(const float *tet, const float *pts, const float *cond, const float *bary, const float *pred, const float *occ,
                      const int32_t *hit_buf, int B, int T, int Q, int algo, const void *workspace)
 {
@@ -2495,10 +1708,7 @@ static int pit_check(const float *tet, const float *pts, const float *cond, cons
     DEFTET_CHECK_ARG((pred == nullptr) == (occ == nullptr), "pred and occ must be given together");
     DEFTET_CHECK_ARG(!occ || T > 0, "paste_occ needs at least one tet");
     DEFTET_CHECK_ARG(B >= 0 && T >= 0 && Q >= 0, "negative size (B=%d T=%d Q=%d)", B, T, Q);
-    DEFTET_CHECK_ARG(algo == DEFTET_PIT_AUTO || algo == DEFTET_PIT_BRUTE || algo == DEFTET_PIT_STAGED || algo == DEFTET_PIT_ROWS ||
-                         algo == DEFTET_PIT_FMA || algo == DEFTET_PIT_FMA2 || algo == DEFTET_PIT_GRP2 || algo == DEFTET_PIT_GRP4 ||
-                         algo == DEFTET_PIT_GRP6 || algo == DEFTET_PIT_LDSB || algo == DEFTET_PIT_LDS || algo == DEFTET_PIT_EXACT,
-                     "unknown algo %d", algo);
+    DEFTET_CHECK_ARG(algo == DEFTET_PIT_AUTO || algo == DEFTET_PIT_BRUTE || algo == DEFTET_PIT_EXACT, "unknown algo %d", algo);
     if (T >= (1 << 24)) return set_error(DEFTET_ELIMIT, "n_tet=%d does not fit a float-encoded index (2^24)", T);
     DEFTET_CHECK_ARG(B <= 65535, "n_batch=%d exceeds the grid-y limit 65535", B);
     if (Q >= (1 << 27)) return set_error(DEFTET_ELIMIT, "n_query=%d: 16-byte query records are addressed with 32-bit byte offsets (limit 2^27)", Q);
@@ -2515,15 +1725,12 @@ static int pit_check(const float *tet, const float *pts, const float *cond, cons
 static int pit_prepare(const Layout &L, const float *pts, int B, int Q, hipStream_t st)
 {
     const dim3 blk(256);
-    const int R = L.G * L.G;
     DEFTET_LAUNCH(k_query_bbox, dim3(kBoxBlocks, B), blk, st, pts, Q, L.bboxPart, L.counters, L.result, B, (long long)B * Q);
-    DEFTET_LAUNCH(k_row_count, dim3(L.nRowBlk, B), blk, st, pts, Q, L.bboxPart, L.gparam, L.G, L.Gx, L.nRowBlk, L.chunkQ, L.qkey,
-                  L.blockHist, L.counters, L.irregQ);
-    DEFTET_LAUNCH(k_row_colscan, dim3((R + 255) / 256, B), blk, st, L.blockHist, L.nRowBlk, R, L.rowTotal);
-    DEFTET_LAUNCH(k_row_scatter, dim3(L.nRowBlk, B), blk, st, pts, Q, L.qkey, L.blockHist, L.rowTotal, L.rowStart, L.G, L.nRowBlk,
-                  L.chunkQ, L.rowSorted);
-    DEFTET_LAUNCH(k_row_fine, dim3((R + 3) / 4, B), blk, st, L.rowSorted, Q, L.gparam, L.G, L.Gx, L.rowStart, L.cellStride, L.cells,
-                  L.sortedQ);
+    DEFTET_LAUNCH(k_slab_local, dim3(L.nRowBlk, B), blk, st, pts, Q, L.bboxPart, L.gparam, L.G, L.Gx, L.nRowBlk, L.nblkPad, L.chunkQ,
+                  L.localQ, L.pre, L.counters, L.irregQ);
+    const size_t shm = align_up((size_t)((L.G + kParts - 1) / kParts + 1) * (L.Gx | 1) * sizeof(int), 16);   // rows of a y-quarter
+    DEFTET_LAUNCH_SHM(k_slab_sort, dim3(L.G * kParts, B), dim3(kSortThreads), shm, st, L.localQ, Q, L.gparam, L.G, L.Gx, L.pre, L.nRowBlk, L.nblkPad,
+                      L.chunkQ, L.cellStride, L.table, L.sortedQ);
     return DEFTET_OK;
 }
 
@@ -2531,50 +1738,16 @@ static int pit_prepare(const Layout &L, const float *pts, int B, int Q, hipStrea
 static int pit_scan(const Layout &L, const float *tet, const float *pts, float *cond, float *bary, const float *pred, float *occ,
                     int32_t *hit_buf, int B, int T, int Q, int algo, hipStream_t st)
 {
-    if ((algo == DEFTET_PIT_GRP2 && Q >= (1 << 30)) || (algo == DEFTET_PIT_GRP4 && Q >= (1 << 28)) || (algo == DEFTET_PIT_GRP6 && Q >= (1 << 26)))
-        algo = DEFTET_PIT_FMA;                                       // query id + tet mask no longer fit one 32-bit entry
     const dim3 blk(256);
     const dim3 gq((Q + 255) / 256, B), gt((((T + 255) / 256 + 7) / 8) * 8, B);   // gt: multiple of 8 for the XCD mapping
     int *ucount = hit_buf ? hit_buf + hit_cnt_off(B, T) : nullptr;
     if (T > 0) {
-        if (algo == DEFTET_PIT_ROWS) {
-            DEFTET_LAUNCH(k_tet_scan_rows, gt, blk, st, tet, T, Q, L.gparam, L.G, L.Gx, L.cells, L.cellStride, L.sortedQ, L.result,
-                          L.counters, L.irregT, (int4 *)hit_buf, pts, L.irregQ, ucount);
-        } else if (algo == DEFTET_PIT_FMA || algo == DEFTET_PIT_AUTO) {
-            DEFTET_LAUNCH(k_tet_scan_fma<false>, gt, blk, st, tet, T, Q, L.gparam, L.G, L.Gx, L.cells, L.cellStride, L.sortedQ, L.result,
-                          L.counters, L.irregT, (int4 *)hit_buf, pts, L.irregQ, ucount, (const int *)nullptr);
-        } else if (algo == DEFTET_PIT_FMA2) {
-            DEFTET_LAUNCH(k_tet_scan_fma<true>, gt, blk, st, tet, T, Q, L.gparam, L.G, L.Gx, L.cells, L.cellStride, L.sortedQ, L.result,
-                          L.counters, L.irregT, (int4 *)hit_buf, pts, L.irregQ, ucount, (const int *)nullptr);
-        } else if (algo == DEFTET_PIT_LDSB) {
-            DEFTET_LAUNCH(k_tet_scan_lds<false>, gt, blk, st, tet, T, Q, L.gparam, L.G, L.Gx, L.cells, L.cellStride, L.sortedQ, L.result,
-                          L.counters, L.irregT, (int4 *)hit_buf, pts, L.irregQ, ucount);
-        } else if (algo == DEFTET_PIT_LDS) {
-            DEFTET_LAUNCH(k_tet_scan_lds<true>, gt, blk, st, tet, T, Q, L.gparam, L.G, L.Gx, L.cells, L.cellStride, L.sortedQ, L.result,
-                          L.counters, L.irregT, (int4 *)hit_buf, pts, L.irregQ, ucount);
-        } else if (algo == DEFTET_PIT_GRP2 || algo == DEFTET_PIT_GRP4 || algo == DEFTET_PIT_GRP6) {
-            const int K = algo == DEFTET_PIT_GRP2 ? 2 : (algo == DEFTET_PIT_GRP4 ? 4 : 6);
-            const int ng = (T + K - 1) / K;
-            const dim3 gg((((ng + 255) / 256 + 7) / 8) * 8, B);
-            if (K == 2) {
-                DEFTET_LAUNCH(k_tet_scan_grp<1>, gg, blk, st, tet, T, Q, L.gparam, L.G, L.Gx, L.cells, L.cellStride, L.sortedQ, L.result,
-                              L.counters, L.irregT, (int4 *)hit_buf, pts, L.irregQ, ucount, L.deferT);
-            } else if (K == 4) {
-                DEFTET_LAUNCH(k_tet_scan_grp<2>, gg, blk, st, tet, T, Q, L.gparam, L.G, L.Gx, L.cells, L.cellStride, L.sortedQ, L.result,
-                              L.counters, L.irregT, (int4 *)hit_buf, pts, L.irregQ, ucount, L.deferT);
-            } else {
-                DEFTET_LAUNCH(k_tet_scan_grp<3>, gg, blk, st, tet, T, Q, L.gparam, L.G, L.Gx, L.cells, L.cellStride, L.sortedQ, L.result,
-                              L.counters, L.irregT, (int4 *)hit_buf, pts, L.irregQ, ucount, L.deferT);
-            }
-            // the groups with a mesh-order jump inside (normally a few per cent, possibly none), one tet per lane
-            DEFTET_LAUNCH(k_tet_scan_fma<false>, gt, blk, st, tet, T, Q, L.gparam, L.G, L.Gx, L.cells, L.cellStride, L.sortedQ, L.result,
-                          L.counters, L.irregT, (int4 *)hit_buf, pts, L.irregQ, (int *)nullptr, (const int *)L.deferT);
-        } else if (algo == DEFTET_PIT_EXACT) {
-            DEFTET_LAUNCH(k_tet_scan, gt, blk, st, tet, T, Q, L.gparam, L.G, L.Gx, L.cells, L.cellStride, L.sortedQ, L.result,
+        if (algo == DEFTET_PIT_EXACT) {
+            DEFTET_LAUNCH(k_tet_scan, gt, blk, st, tet, T, Q, L.gparam, L.G, L.Gx, L.table, L.cellStride, L.sortedQ, L.result,
                           L.counters, L.irregT, (int4 *)hit_buf, pts, L.irregQ, ucount);
         } else {
-            DEFTET_LAUNCH(k_tet_scan_staged, gt, blk, st, tet, T, Q, L.gparam, L.G, L.Gx, L.cells, L.cellStride, L.sortedQ,
-                          L.result, L.counters, L.irregT, (int4 *)hit_buf, pts, L.irregQ, ucount);
+            DEFTET_LAUNCH(k_tet_scan_slab, gt, blk, st, tet, T, Q, L.gparam, L.G, L.Gx, L.table, L.cellStride, L.sortedQ, L.result,
+                          L.counters, L.irregT, (int4 *)hit_buf, pts, L.irregQ, ucount);
         }
     } else if (ucount) {
         DEFTET_HIP(hipMemsetAsync(ucount, 0, (size_t)B * 4, st));
@@ -2618,7 +1791,8 @@ extern "C" int deftet_point_in_tet_prepare_f32(const float *pts, int B, int T, i
                                                size_t workspace_bytes, void *stream_)
 {
     DEFTET_CHECK_ARG(B >= 0 && T >= 0 && Q >= 0 && B <= 65535, "bad size (B=%d T=%d Q=%d)", B, T, Q);
-    DEFTET_CHECK_ARG(algo != DEFTET_PIT_BRUTE && algo >= 0 && algo <= DEFTET_PIT_EXACT, "prepare needs a binned algo (got %d)", algo);
+    DEFTET_CHECK_ARG(algo == DEFTET_PIT_AUTO || algo == DEFTET_PIT_EXACT, "prepare needs a binned algo (got %d)", algo);
+    if (Q >= (1 << 27)) return set_error(DEFTET_ELIMIT, "n_query=%d exceeds 2^27", Q);
     if (B == 0 || Q == 0) return DEFTET_OK;
     DEFTET_CHECK_ARG(pts, "null pts pointer");
     DEFTET_CHECK_ARG(workspace && ((uintptr_t)workspace & 255) == 0, "workspace null or not 256-byte aligned");
@@ -2640,8 +1814,8 @@ extern "C" int deftet_point_in_tet_scan_f32(const float *tet, const float *pts, 
 }
 
 // Diagnostics: copies the 8 int32 words per shape that the last forward on this workspace left behind —
-// [0] irregular tets, [1] irregular queries, [2] hit-record overflow flag, [3] tets deferred by the grouped traversal,
-// [4] groups re-scanned exactly, [5] tets re-scanned exactly (one-tet filter kernel), [6..7] unused — to host memory.
+// [0] irregular tets, [1] irregular queries, [2] hit-record overflow flag, [3] unused,
+// [4] unused, [5] tets re-scanned exactly, [6] overflowed tets, [7] unused — to host memory.
 // Synchronises the stream.
 extern "C" int deftet_point_in_tet_read_stats(const void *workspace, size_t workspace_bytes, int B, int T, int Q, int algo,
                                               int32_t *out_host, void *stream_)

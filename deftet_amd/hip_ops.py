@@ -11,11 +11,8 @@ import torch
 
 from . import _lib
 
-PIT_AUTO, PIT_BRUTE, PIT_STAGED, PIT_ROWS, PIT_FMA, PIT_FMA2, PIT_GRP2, PIT_GRP4, PIT_GRP6, PIT_LDSB, PIT_LDS, PIT_EXACT = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
-_PIT_KERNEL = {PIT_AUTO: "k_tet_scan_fma<false>", PIT_EXACT: "k_tet_scan", PIT_BRUTE: "k_brute", PIT_STAGED: "k_tet_scan_staged", PIT_ROWS: "k_tet_scan_rows",
-               PIT_FMA: "k_tet_scan_fma<false>", PIT_FMA2: "k_tet_scan_fma<true>", PIT_GRP2: "k_tet_scan_grp<1>",
-               PIT_GRP4: "k_tet_scan_grp<2>", PIT_GRP6: "k_tet_scan_grp<3>", PIT_LDSB: "k_tet_scan_lds<false>",
-               PIT_LDS: "k_tet_scan_lds<true>"}
+PIT_AUTO, PIT_BRUTE, PIT_EXACT = 0, 1, 2        # include/deftet_hip.h DEFTET_PIT_*
+_PIT_KERNEL = {PIT_AUTO: "k_tet_scan_slab", PIT_EXACT: "k_tet_scan", PIT_BRUTE: "k_brute"}
 
 
 def pit_kernel_name(algo=PIT_AUTO):
@@ -33,7 +30,7 @@ class PreparedQueries:
     of the tet side — typically on a second stream while the previous step's backward is running:
 
         with torch.cuda.stream(side):
-            pq = hip_ops.prepare_queries(pts_next, n_tet)          # 5 small kernels, no tets needed
+            pq = hip_ops.prepare_queries(pts_next, n_tet)          # 4 small kernels, no tets needed
         ...
         cond, w = hip_ops.point_in_tet(tet, pts_next, want_bary=True, prepared=pq)   # waits for pq's event
 
@@ -116,9 +113,17 @@ def point_in_tet(tet_bxtx4x3, pts_bxqx3, want_bary=False, algo=PIT_AUTO, pred_bx
     return out if len(out) > 1 else cond
 
 
+def point_in_tet_grid(n_tet, n_query):
+    """(y/z cells per axis, x cells) of the query grid the binned algos build for this problem size."""
+    import ctypes
+    g, gx = ctypes.c_int(0), ctypes.c_int(0)
+    _lib.check(_lib.load().deftet_point_in_tet_grid_dims(int(n_tet), int(n_query), ctypes.byref(g), ctypes.byref(gx)), "deftet_point_in_tet_grid_dims")
+    return g.value, gx.value
+
+
 def point_in_tet_stats(B, T, Q, algo, device):
     """Diagnostics of the LAST un-prepared point_in_tet call on this device/stream (it shares the cached workspace):
-    int32 [B,8] = irregular tets, irregular queries, record-overflow flag, deferred tets, groups re-scanned, tets re-scanned, 0, 0."""
+    int32 [B,8] = irregular tets, irregular queries, record-overflow flag, 0, 0, tets re-scanned exactly, overflowed tets, 0."""
     lib = _lib.load()
     dev = torch.device(device)
     out = np.zeros((B, 8), np.int32)

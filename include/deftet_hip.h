@@ -34,18 +34,9 @@ extern "C" {
 #define DEFTET_ELIMIT (-4)   /* size exceeds what the float-encoded index outputs can represent (2^24) */
 
 /* point-in-tet algorithm selector */
-#define DEFTET_PIT_AUTO 0    /* uniform-grid binned, tet-centric, certified fused plane filter (default = DEFTET_PIT_FMA) */
-#define DEFTET_PIT_BRUTE 1   /* LDS/scalar-tiled brute force: the algorithmic equivalent of the reference kernel */
-#define DEFTET_PIT_STAGED 2  /* binned, with wave-cooperative LDS staging of the cell rows (coherent tet orders) */
-#define DEFTET_PIT_ROWS 3    /* binned, (tet,row) pairs balanced across the lanes of a wave through LDS */
-#define DEFTET_PIT_FMA 4     /* binned, certified fused plane filter instead of box test + exact predicate per candidate */
-#define DEFTET_PIT_FMA2 5    /* same, two candidates per packed-fp32 instruction */
-#define DEFTET_PIT_GRP2 6    /* binned, 2 consecutive tets per lane share one candidate stream (packed-fp32 pair) + fused filter */
-#define DEFTET_PIT_GRP4 7    /* same, 4 consecutive tets per lane */
-#define DEFTET_PIT_GRP6 8    /* same, 6 consecutive tets per lane */
-#define DEFTET_PIT_LDSB 9    /* fused filter, the workgroup's cell starts staged in LDS */
-#define DEFTET_PIT_LDS 10    /* fused filter, the workgroup's cell starts AND candidate queries staged in LDS */
-#define DEFTET_PIT_EXACT 11  /* binned, box test + exact predicate on every candidate (the round-1 default, k_tet_scan) */
+#define DEFTET_PIT_AUTO 0    /* uniform-grid binned, tet-centric, slab traversal with the certified fused plane filter (k_tet_scan_slab) */
+#define DEFTET_PIT_BRUTE 1   /* scalar-tiled brute force: the algorithmic equivalent of the reference kernel */
+#define DEFTET_PIT_EXACT 2   /* binned, box test + exact predicate on every candidate (no filter; independent cross-check) */
 
 int deftet_version(void);
 const char *deftet_last_error(void);
@@ -106,9 +97,11 @@ int deftet_point_in_tet_scan_f32(const float *tet, const float *pts, float *cond
  * also needs 64*n_batch floats of workspace); else workspace
  * (deftet_point_in_tet_bwd_workspace_bytes) enables the linked-list gather path; with neither a
  * float-atomic scatter is used. */
-/* Diagnostics (not on the hot path): 8 int32 per shape left in `workspace` by the last forward — irregular tets, irregular
- * queries, hit-record overflow flag, tets deferred by the grouped traversal, groups / tets re-scanned exactly, 2 unused.
- * Copies to host memory and synchronises the stream. */
+/* Diagnostics (not on the hot path): 8 int32 per shape left in `workspace` by the last forward — [0] irregular tets,
+ * [1] irregular queries, [2] hit-record overflow flag, [5] tets re-scanned exactly, [6] overflowed tets, others unused.
+ * Copies to host memory and synchronises the stream.  deftet_point_in_tet_grid_dims reports the cell grid (y/z cells per
+ * axis, x cells) the binned algos use for a problem size. */
+int deftet_point_in_tet_grid_dims(int n_tet, int n_query, int *cells_yz, int *cells_x);
 int deftet_point_in_tet_read_stats(const void *workspace, size_t workspace_bytes, int n_batch, int n_tet, int n_query, int algo,
                                    int32_t *out_host_8xB, void *stream);
 

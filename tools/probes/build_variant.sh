@@ -1,9 +1,16 @@
 #!/bin/bash
 # Builds an alternative libdeftet_hip.so with extra -D flags for A/B runs (load it with DEFTET_HIP_LIB=<path>).
 #   tools/probes/build_variant.sh tools/probes/bin/libdeftet_w8.so -DPIT_WAVES=8
+#   tools/probes/build_variant.sh tools/probes/bin/libdeftet_x.so --pit-only -DPIT_BATCH=3    # 0.3 MB instead of 20 MB
+#   tools/probes/build_variant.sh tools/probes/bin/libdeftet_r02.so --legacy       # the round-2 point-in-tet file with its twelve
+#                                                                                  # traversal variants (tools/probes/legacy/)
 set -e
 out=$1; shift
 cd "$(dirname "$0")/../.."
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -fno-fast-math -Wno-unused-function "$@" \
-    -x hip deftet_amd/csrc/*.hip deftet_amd/csrc/*.cpp -o "$out"
-echo "built $out"
+args=()
+for a in "$@"; do
+    if [ "$a" = "--legacy" ]; then args+=(--swap point_in_tet.hip=tools/probes/legacy/point_in_tet_r02.hip)
+    elif [ "$a" = "--pit-only" ]; then args+=(--only point_in_tet.hip,common.cpp,reduce.hip)    # small library: point-in-tet + row dots only
+    else args+=("$a"); fi
+done
+python -m deftet_amd.build --out "$out" "${args[@]}" | tail -1

@@ -2,7 +2,7 @@
 """Per-phase wall cycles of the traversal kernels (s_memtime deltas summed over waves), from a diagnostic build:
     tools/probes/build_variant.sh tools/probes/bin/libdeftet_phase.so -DPIT_PHASE_TIMING
     DEFTET_HIP_LIB=$PWD/tools/probes/bin/libdeftet_phase.so python tools/probes/phase_probe.py [--config 2]
-Prints average cycles per wave and per phase for algo 0 (k_tet_scan_fma) and 10 (k_tet_scan_lds<true>)."""
+Prints average cycles per wave and per phase of the default traversal kernel."""
 import argparse
 import ctypes
 import json
@@ -25,21 +25,22 @@ raw.deftet_debug_phase_read.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctyp
 dev = torch.device("cuda:0")
 wl = bench.PitWorkload(dict(bench.CONFIGS[a.config], sets=1), 0, dev, 1, None, pipeline=False)
 d = wl.sets[0]
-names = {0: ["load+setup", "loop", "publish"], 10: ["load+setup", "union box", "cell starts->LDS", "offset scan + queries->LDS", "loop", "publish"],
-         9: ["load+setup", "union box", "cell starts->LDS", "(no query staging)", "loop", "publish"]}
-base = {0: 0, 9: 4, 10: 4}
-for algo in (0, 9, 10):
-    for _ in range(2):
-        hip_ops.point_in_tet(d["tet"], d["pts"], want_bary=True, pred_bxt=d["pred"], want_hits=True, algo=algo)
-    torch.cuda.synchronize()
-    buf = (ctypes.c_ulonglong * 16)()
-    raw.deftet_debug_phase_read(buf, 1)
-    reps = 4
-    for _ in range(reps):
-        hip_ops.point_in_tet(d["tet"], d["pts"], want_bary=True, pred_bxt=d["pred"], want_hits=True, algo=algo)
-    torch.cuda.synchronize()
-    raw.deftet_debug_phase_read(buf, 1)
-    n_waves = wl.B * ((wl.T + 63) // 64) * reps
-    vals = [buf[base[algo] + i] / n_waves for i in range(len(names[algo]))]
-    print(json.dumps({"algo": algo, "kernel": hip_ops.pit_kernel_name(algo), "waves_per_launch": n_waves // reps,
-                      "cycles_per_wave": {k: round(v) for k, v in zip(names[algo], vals)}, "total": round(sum(vals))}), flush=True)
+names = ["load+setup", "loop", "publish"]
+for _ in range(2):
+    hip_ops.point_in_tet(d["tet"], d["pts"], want_bary=True, pred_bxt=d["pred"], want_hits=True)
+torch.cuda.synchronize()
+buf = (ctypes.c_ulonglong * 16)()
+raw.deftet_debug_phase_read(buf, 1)
+reps = 4
+for _ in range(reps):
+    hip_ops.point_in_tet(d["tet"], d["pts"], want_bary=True, pred_bxt=d["pred"], want_hits=True)
+torch.cuda.synchronize()
+raw.deftet_debug_phase_read(buf, 1)
+n_waves = wl.B * ((wl.T + 63) // 64) * reps
+vals = [buf[i] / n_waves for i in range(len(names))]
+G = hip_ops.point_in_tet_grid(wl.T, wl.Q)[0]
+n_sort = wl.B * G * 4 * 4 * reps                                    # k_slab_sort: 4 waves per (slab quarter, shape) workgroup
+print(json.dumps({"kernel": "k_slab_sort", "waves_per_launch": n_sort // reps, "cycles_per_wave": {
+    k: round(buf[8 + i] / n_sort) for i, k in enumerate(["loads+clear", "count", "scan", "placement", "table"])}}), flush=True)
+print(json.dumps({"kernel": hip_ops.pit_kernel_name(0), "waves_per_launch": n_waves // reps,
+                  "cycles_per_wave": {k: round(v) for k, v in zip(names, vals)}, "total": round(sum(vals))}), flush=True)
