@@ -54,12 +54,13 @@ CONFIGS = {
 }
 
 ALGO = int(os.environ.get("DEFTET_BENCH_ALGO", "0"))      # A/B switch for the traversal kernel (0 = shipped default)
-PIPELINE = os.environ.get("DEFTET_BENCH_PIPELINE", "1") not in ("", "0")
+PIPELINE = os.environ.get("DEFTET_BENCH_PIPELINE", "0") not in ("", "0")   # cross-step overlap of the query sort: off since round 3 (measured: no gain)
 
 
 def dominant_kernel(algo):
     from deftet_amd import hip_ops
-    return hip_ops.pit_kernel_name(algo).encode()
+    # (DEFTET_BENCH_KERNEL: name of the traversal kernel when DEFTET_HIP_LIB points at a probe build with other kernels)
+    return (os.environ.get("DEFTET_BENCH_KERNEL") or hip_ops.pit_kernel_name(algo)).encode()
 
 
 class PitWorkload:
@@ -399,13 +400,15 @@ def main():
             line["rccl_ranks"] = torch.distributed.get_world_size()
             line["backend"] = backend
         if world == 1:
-            if isinstance(wl, PitWorkload) and wl.pipeline and not args.no_unpipelined:
-                # per-call latency without the cross-step overlap (not the headline; printed beside it)
-                wl.pipeline = False
-                e2, ps2, _, _ = timed(wl, lib, args.steps, 2, 1, barrier=False)
-                line["ms_per_step_unpipelined"] = round(e2 / args.steps * 1e3, 4)
-                line["ms_per_step_unpipelined_median"] = round(statistics.median(ps2), 4)
-                wl.pipeline = True
+            if isinstance(wl, PitWorkload) and not args.no_unpipelined:
+                # the same K steps with the other setting of the cross-step overlap (not the headline; printed beside it)
+                wl.pipeline = not wl.pipeline
+                e2, ps2, km2, kc2 = timed(wl, lib, args.steps, 2, 1, barrier=False)
+                key = "pipelined" if wl.pipeline else "unpipelined"
+                line["ms_per_step_%s" % key] = round(e2 / args.steps * 1e3, 4)
+                line["ms_per_step_%s_median" % key] = round(statistics.median(ps2), 4)
+                line["avg_launch_ms_%s" % key] = round(km2 / max(kc2, 1), 5)
+                wl.pipeline = not wl.pipeline
             if not args.no_cpu_baseline and isinstance(wl, PitWorkload):
                 line["cpu_baseline"] = cpu_baseline(wl)
             if not args.no_other_configs:

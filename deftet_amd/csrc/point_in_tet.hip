@@ -51,12 +51,15 @@ constexpr int kHitOverflow = -2;            // hits[.].w: this tet has accepted 
 
 // "hit record" buffer written by the forward and consumed by the backward (int32 words):
 //   [0, 4*B*T)            int4 per tet: the (<= 4) queries the tet accepted, or w == kHitOverflow
-//   [4*B*T, +pad)         per shape: number of uncovered queries (pad = B rounded up to kHitPad)
+//   [4*B*T, +3*pad)       three words per shape (pad = B rounded up to kHitPad): [0, pad) number of uncovered queries,
+//                         [pad, 2 pad) ticket of the backward's miss-sum reduction (zero between calls),
+//                         [2 pad, 3 pad) flag: some uncovered entry belongs to a NaN/Inf/huge query
 //   [.., + B*Q)           per shape: uncovered queries = hits that are NOT in their tet's record
 //                         (tet overflowed / irregular tet / NaN-Inf-huge query)
 constexpr int kHitPad = 64;
+__host__ __device__ inline int hit_pad(int B) { return (B + kHitPad - 1) / kHitPad * kHitPad; }
 __host__ __device__ inline size_t hit_cnt_off(int B, int T) { return (size_t)B * T * 4; }
-__host__ __device__ inline size_t hit_list_off(int B, int T) { return (size_t)B * T * 4 + (size_t)((B + kHitPad - 1) / kHitPad) * kHitPad; }
+__host__ __device__ inline size_t hit_list_off(int B, int T) { return (size_t)B * T * 4 + (size_t)3 * hit_pad(B); }
 // Tets whose hit record overflowed (> 4 accepted queries; ~1e-4 of the tets at BASELINE configs[2]) are also LISTED, so
 // that k_finalize can tell "this hit is not in its tet's record" from a short wave-uniform list instead of gathering the
 // winning tet's 16-byte record for every query of the shape.  The list lives behind the counter block:
@@ -593,7 +596,7 @@ __device__ __forceinline__ void irregular_queries_tail(const Planes &P, int t, i
 }
 
 #ifndef PIT_WAVES
-#define PIT_WAVES 6
+#define PIT_WAVES 5      // 102 VGPRs: at 6 waves (80) the traversal kernel spills around its publish phase (+15 us)
 #endif
 
 
@@ -628,9 +631,13 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan(const float *__rest
                                                   const float *__restrict__ gparam, int G, int Gx, const int *__restrict__ table,
                                                   long long cellStride, const float4 *__restrict__ sortedQ, int *result, int *counters,
                                                   int *irregT, int4 *hits, const float *__restrict__ pts,
-                                                  const int *__restrict__ irregQ, int *ucount)
+                                                  const int *__restrict__ irregQ, int *ucount, int hpad)
 {
-    if (ucount && blockIdx.x == 0 && threadIdx.x == 0) ucount[blockIdx.y] = 0;   // uncovered-hit counter of the hit buffer (k_finalize appends)
+    if (ucount && blockIdx.x == 0 && threadIdx.x == 0) {               // per-shape words of the hit buffer: uncovered-hit counter
+        ucount[blockIdx.y] = 0;                                        // (k_finalize appends), backward ticket, irregular-query flag
+        ucount[hpad + blockIdx.y] = 0;                                 // (hpad is an argument: deriving it from gridDim.y here made the
+        ucount[2 * hpad + blockIdx.y] = 0;                             //  compiler fetch the dispatch packet with vector loads: +20 us)
+    }
     const int b = blockIdx.y;
     // XCD-aware mapping (workgroup i is observed to run on XCD i % 8, each XCD has a private
     // L2): give every XCD one CONTIGUOUS eighth of the tet range, so a mesh whose tet order is
@@ -782,6 +789,30 @@ __device__ __forceinline__ int4u ld_off_u4(const void *base, unsigned byte_off)
     return *reinterpret_cast<const int4u *>(static_cast<const char *>(base) + byte_off);
 }
 
+// Publish helpers with the addressing fixed in the instruction: wave-uniform base in an SGPR pair, 32-bit byte offset in
+// one VGPR.  (Left to itself the compiler keeps 64-bit per-lane addresses alive across the traversal loop, runs out of
+// its 80 registers and spills them: four scratch reloads in front of the four atomics cost the launch 20 us.)
+__device__ __forceinline__ void atomic_smin_off(int *base, unsigned byte_off, int v)
+{
+    asm volatile("global_atomic_smin %0, %1, %2" ::"v"(byte_off), "v"(v), "s"(base) : "memory");
+}
+// a wave-uniform pointer, re-materialised in scalar registers at the point of use
+template <typename T>
+__device__ __forceinline__ T *uniform_ptr(T *p)
+{
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<T *>(((unsigned long long)hi << 32) | lo);
+}
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_b128_off(void *base, unsigned byte_off, int x, int y, int z, int w)
+{
+    const i32x4 v = {x, y, z, w};
+    // s_nop: a store of more than 64 bits keeps reading its data registers for a few cycles; the compiler pads that
+    // hazard for its own stores, not inside asm (without it the next VALU write clobbered the record of 4 lanes in 16)
+    asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 2" ::"v"(byte_off), "v"(v), "s"(base) : "memory");
+}
+
 // Exact re-scan of ONE tet's candidates (box test + reference predicate, as k_tet_scan does), used by k_tet_scan_slab for
 // the very rare tets that met the filter's undecided band more than twice.  Out of line and called
 // AFTER the traversal loop, so that nothing of it is scheduled (or kept in registers) inside the loop.  Publishes every
@@ -862,7 +893,7 @@ __device__ __forceinline__ void irregular_tail(const float *__restrict__ tet, in
 }
 
 #ifndef PIT_BATCH
-#define PIT_BATCH 2
+#define PIT_BATCH 3
 #endif
 #if PIT_BATCH < 1 || PIT_BATCH > 4
 #error "PIT_BATCH must be 1..4 (a wave-iteration may add at most four acceptances to the four-deep hit register)"
@@ -871,9 +902,13 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan_slab(const float *_
                                                   const float *__restrict__ gparam, int G, int Gx, const int *__restrict__ table,
                                                   long long cellStride, const float4 *__restrict__ sortedQ, int *result, int *counters,
                                                   int *irregT, int4 *hits, const float *__restrict__ pts,
-                                                  const int *__restrict__ irregQ, int *ucount)
+                                                  const int *__restrict__ irregQ, int *ucount, int hpad)
 {
-    if (ucount && blockIdx.x == 0 && threadIdx.x == 0) ucount[blockIdx.y] = 0;
+    if (ucount && blockIdx.x == 0 && threadIdx.x == 0) {               // per-shape words of the hit buffer: uncovered-hit counter
+        ucount[blockIdx.y] = 0;                                        // (k_finalize appends), backward ticket, irregular-query flag
+        ucount[hpad + blockIdx.y] = 0;                                 // (hpad is an argument: deriving it from gridDim.y here made the
+        ucount[2 * hpad + blockIdx.y] = 0;                             //  compiler fetch the dispatch packet with vector loads: +20 us)
+    }
     const int b = blockIdx.y;
     const int nblk = gridDim.x;
     const int per = (nblk + 7) >> 3;
@@ -936,7 +971,6 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan_slab(const float *_
     const int Gp = table_pitch(G);
     const int *tb = table + (size_t)b * cellStride;
     const float4 *sq = sortedQ + (size_t)b * Q;
-    int *res = result + (size_t)b * Q;
     PHASE_MARK(0);                                                       // [0] load + setup
     // Accepted queries go into a four-deep shift register (h0 = newest) and are published with atomicMin once, after the
     // traversal.  Two rare events are handled by wave-uniform branches inside the loop, so that no tet is ever walked twice
@@ -1031,10 +1065,11 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan_slab(const float *_
             }
             if (__builtin_amdgcn_ballot_w64(cnew > 4) != 0ull) {              // rare: a fifth acceptance
                 if (cnew > 4) {
-                    if (hcnt > 0) atomicMin(&res[h0], t);
-                    if (hcnt > 1) atomicMin(&res[h1], t);
-                    if (hcnt > 2) atomicMin(&res[h2], t);
-                    if (hcnt > 3) atomicMin(&res[h3], t);
+                    int *resb = result + (size_t)b * Q;
+                    if (hcnt > 0) atomicMin(&resb[h0], t);
+                    if (hcnt > 1) atomicMin(&resb[h1], t);
+                    if (hcnt > 2) atomicMin(&resb[h2], t);
+                    if (hcnt > 3) atomicMin(&resb[h3], t);
                     hcnt = 0;
                     ovf = true;
                 }
@@ -1056,7 +1091,7 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan_slab(const float *_
         const float *tv = tet + ((size_t)b * T + t) * 12;
         atomicAdd(&counters[gridDim.y * 4 + b * 4 + 1], npend);              // statistics: candidates decided exactly
         if (npend > 2) {
-            const int4 r = exact_rescan(tv, t, tb, sq, res, G, Gx, cx0, cx1, cy0, cy1, cz0, cz1, m, counters, gridDim.y, b);
+            const int4 r = exact_rescan(tv, t, tb, sq, result + (size_t)b * Q, G, Gx, cx0, cx1, cy0, cy1, cz0, cz1, m, counters, gridDim.y, b);
             if (hits) hits[(size_t)b * T + t] = r;
             irregular_tail(tet, t, b, T, Q, pts, counters, irregQ, result);
             return;
@@ -1065,23 +1100,26 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan_slab(const float *_
             const float4 q = sq[k == 0 ? pend0 : pend1];
             if (exact_accept(tv, q.x, q.y, q.z) > 0.f) {
                 const int qi = __float_as_int(q.w);
-                atomicMin(&res[qi], t);
+                atomicMin(&result[(size_t)b * Q + qi], t);
                 if (hcnt < 4) {                                              // (already published: only the record needs it)
                     h3 = h2; h2 = h1; h1 = h0; h0 = qi;
                     ++hcnt;
-                    atomicMin(&res[h0], t);
                 } else {
                     ovf = true;
                 }
             }
         }
     }
-    if (hcnt > 0) atomicMin(&res[h0], t);
-    if (hcnt > 1) atomicMin(&res[h1], t);
-    if (hcnt > 2) atomicMin(&res[h2], t);
-    if (hcnt > 3) atomicMin(&res[h3], t);
+    int *resb = uniform_ptr(result + (size_t)b * Q);
+    if (hcnt > 0) atomic_smin_off(resb, (unsigned)h0 * 4u, t);
+    if (hcnt > 1) atomic_smin_off(resb, (unsigned)h1 * 4u, t);
+    if (hcnt > 2) atomic_smin_off(resb, (unsigned)h2 * 4u, t);
+    if (hcnt > 3) atomic_smin_off(resb, (unsigned)h3 * 4u, t);
     if (ovf) note_overflow(counters, gridDim.y, b, t);
-    if (hits) hits[(size_t)b * T + t] = ovf ? make_int4(-1, -1, -1, kHitOverflow) : make_int4(h0, h1, h2, h3);
+    if (hits) {
+        const lanemask_t o = mask_of(ovf);
+        store_b128_off(uniform_ptr(hits + (size_t)b * T), (unsigned)t * 16u, sel(o, -1, h0), sel(o, -1, h1), sel(o, -1, h2), sel(o, kHitOverflow, h3));
+    }
     irregular_tail(tet, t, b, T, Q, pts, counters, irregQ, result);
     PHASE_MARK(2);                                                       // [2] publish (atomics, record store) / re-scan
 }
@@ -1099,7 +1137,7 @@ __global__ __launch_bounds__(256) void k_finalize(const float *__restrict__ tet,
                                                   int Q, const int *__restrict__ result, float *cond, float *bary,
                                                   const float *__restrict__ pred, float *occ, const int4 *__restrict__ hits,
                                                   int *ucount, int *ulist, const int *__restrict__ counters,
-                                                  const int *__restrict__ irregT)
+                                                  const int *__restrict__ irregT, int hpad)
 {
     const int b = blockIdx.y;
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1144,7 +1182,10 @@ __global__ __launch_bounds__(256) void k_finalize(const float *__restrict__ tet,
                 for (int k = 0; k < nOvf; ++k) covered = covered && ovf[k] != r;
             }
         }
-        if (!covered) ulist[(size_t)b * Q + atomicAdd(&ucount[b], 1)] = q;
+        if (!covered) {
+            ulist[(size_t)b * Q + atomicAdd(&ucount[b], 1)] = q;
+            if (!query_regular(pq[0], pq[1], pq[2])) ucount[2 * hpad + b] = 1;   // its tet's record may be complete: every lane must look
+        }
     }
     if (!bary) return;
     float4 wq = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1446,35 +1487,58 @@ __device__ __forceinline__ void tet_grad_add(const TetGrad &g, const float *pp, 
         for (int k = 0; k < 3; ++k) acc[vtx * 3 + k] += -w[vtx] * G3[k];
 }
 
+// bit-exact read / write of a float at the memory side (device-scope RMW atomics bypass the per-XCD L2s): what the
+// ticket reduction below exchanges between workgroups that may sit on different XCDs
+__device__ __forceinline__ float mem_read_f32(float *p) { return __int_as_float(atomicOr(reinterpret_cast<int *>(p), 0)); }
+__device__ __forceinline__ void mem_write_f32(float *p, float v)
+{
+    const int old = atomicExch(reinterpret_cast<int *>(p), __float_as_int(v));
+    asm volatile("" ::"v"(old));                                   // keep the RETURNING form: its completion is what s_waitcnt observes
+}
+
+constexpr int kMissStride = 80;    // floats of workspace per shape: kMissParts partials + the tet-0 lane's own sum
+
+// One launch for the whole backward:
+//  * every tet lane adds up the (<= 4) hits of its record in ascending query order — no atomics;
+//  * a tet whose record is marked overflowed (or any tet, when the uncovered list holds NaN/Inf/huge queries) gets
+//    its hits from the forward's uncovered list: the WAVE scans the list for the lane (64 entries per step), the
+//    matching lanes evaluate one hit each and a fixed-order butterfly adds them up — no atomics either, so the
+//    whole gradient is bit-reproducible;
+//  * paste_occ sends every miss to tet 0 (deftet.py:133-135), so grad_pred[b,0] also gets the sum of grad_occ over
+//    the misses: the first nMissParts workgroups of a shape each sum a slice of the queries on the side (hidden under
+//    the kernel's own traffic), hand their partial to memory and draw a ticket; the workgroup that draws the last one
+//    adds the partials up in index order, together with the tet-0 lane's own sum, and writes grad_pred[b,0].
+//    (Rounds 1-2 needed a second launch, k_bary_bwd_tail, for the last two items.)
 __global__ __launch_bounds__(256) void k_bary_bwd_hits(const float *__restrict__ tet, const float *__restrict__ pts,
                                                        const float *__restrict__ cond, const float *__restrict__ grad_w,
                                                        const int4 *__restrict__ hits, int T, int Q, float *grad_tet,
                                                        float *grad_pts, int accumulate, const float *__restrict__ gocc,
-                                                       float *grad_pred, float *missPart, int nMissParts)
+                                                       float *grad_pred, float *missPart, int nMissParts, int *hitWords,
+                                                       const int *__restrict__ ulist, int pad)
 {
-    const int b = blockIdx.y;
-    // paste_occ sends every miss to tet 0 (deftet.py:133-135), so grad_pred[b,0] also gets the sum
-    // of grad_occ over the misses.  The first nMissParts blocks of a shape each sum a slice of the
-    // queries on the side (hidden under this kernel's own traffic); k_bary_bwd_tail adds the
-    // partials up in a fixed order.
-    if (grad_pred && (int)blockIdx.x < nMissParts) {
-        __shared__ float wsum[4];
+    __shared__ float wsum[4];
+    __shared__ float s_vals[kMissStride];
+    __shared__ int s_last;
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const bool side = grad_pred && (int)blockIdx.x < nMissParts;   // block-uniform
+    float missPartial = 0.f;
+    if (side) {
         float gm = 0.f;
-        for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < Q; q += nMissParts * blockDim.x)
+        for (int q = blockIdx.x * blockDim.x + tid; q < Q; q += nMissParts * blockDim.x)
             if (cond[(size_t)b * Q + q] < 0.f) gm += gocc[(size_t)b * Q + q];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) gm += __shfl_xor(gm, off);
-        if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = gm;
+        if (lane == 0) wsum[tid >> 6] = gm;
         __syncthreads();
-        if (threadIdx.x == 0) missPart[b * kMissParts + blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+        missPartial = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
     }
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= T) return;
+    const int t = blockIdx.x * blockDim.x + tid;
+    const bool live = t < T;
     float acc[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) acc[k] = 0.f;
     float gp = 0.f;
-    const int4 h = hits[(size_t)b * T + t];
+    const int4 h = live ? hits[(size_t)b * T + t] : make_int4(-1, -1, -1, -1);
     if (h.x >= 0 && h.w != kHitOverflow) {                         // slots fill in order: x < 0 means no accepted query
         TetGrad g;
         tet_grad_setup(tet, (size_t)b * T + t, g);
@@ -1499,52 +1563,83 @@ __global__ __launch_bounds__(256) void k_bary_bwd_hits(const float *__restrict__
             if (grad_pred) gp += gocc[i];
         }
     }
-    if (grad_pred) grad_pred[(size_t)b * T + t] = accumulate ? grad_pred[(size_t)b * T + t] + gp : gp;
-    float4 *dst = reinterpret_cast<float4 *>(grad_tet + ((size_t)b * T + t) * 12);
-    float4 o0 = make_float4(acc[0], acc[1], acc[2], acc[3]), o1 = make_float4(acc[4], acc[5], acc[6], acc[7]),
-           o2 = make_float4(acc[8], acc[9], acc[10], acc[11]);
-    if (accumulate) {
-        float4 p0 = dst[0], p1 = dst[1], p2 = dst[2];
-        o0.x += p0.x; o0.y += p0.y; o0.z += p0.z; o0.w += p0.w;
-        o1.x += p1.x; o1.y += p1.y; o1.z += p1.z; o1.w += p1.w;
-        o2.x += p2.x; o2.y += p2.y; o2.z += p2.z; o2.w += p2.w;
+    // hits that are in no record (overflowed / irregular tets; NaN/Inf/huge queries): the forward listed them
+    const int nU = hitWords[b];
+    if (nU > 0) {                                                  // wave-uniform (scalar load)
+        const bool anyQ = hitWords[2 * pad + b] != 0;              // entries of irregular queries: their tets' records look complete
+        unsigned long long need = __ballot(live && (h.w == kHitOverflow || anyQ));
+        while (need) {
+            const int L = __ffsll((long long)need) - 1;
+            need &= need - 1;
+            const int tL = __shfl(t, L);
+            const float tLf = (float)tL;
+            float part[13];
+#pragma unroll
+            for (int k = 0; k < 13; ++k) part[k] = 0.f;
+            for (int base = 0; base < nU; base += 64) {
+                const int e = base + lane;
+                const int q = e < nU ? ulist[(size_t)b * Q + e] : -1;
+                const size_t i = (size_t)b * Q + (q >= 0 ? q : 0);
+                if (q >= 0 && cond[i] == tLf) {
+                    // a hit recorded by the overflowing tet's own record cannot be here: overflowed records are ignored above
+                    TetGrad g;
+                    tet_grad_setup(tet, (size_t)b * T + tL, g);
+                    float G3[3];
+                    tet_grad_add(g, pts + i * 3, reinterpret_cast<const float4 *>(grad_w)[i], part, G3);
+                    if (grad_pts) { grad_pts[i * 3] = G3[0]; grad_pts[i * 3 + 1] = G3[1]; grad_pts[i * 3 + 2] = G3[2]; }
+                    if (grad_pred) part[12] += gocc[i];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 13; ++k) {
+                float v = part[k];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);      // fixed butterfly: same order on every run
+                part[k] = v;
+            }
+            if (lane == L) {
+#pragma unroll
+                for (int k = 0; k < 12; ++k) acc[k] += part[k];
+                gp += part[12];
+            }
+        }
     }
-    dst[0] = o0; dst[1] = o1; dst[2] = o2;
-}
-
-// After k_bary_bwd_hits, one launch for the two leftovers:
-//  * grad_pred[b,0] += sum of the miss partials (one wave, fixed order -> deterministic);
-//  * the (normally empty) list of hits that are in no tet record: float atomics.
-__global__ __launch_bounds__(256) void k_bary_bwd_tail(const float *__restrict__ tet, const float *__restrict__ pts,
-                                                       const float *__restrict__ cond, const float *__restrict__ grad_w,
-                                                       const int *__restrict__ ucount, const int *__restrict__ ulist, int T,
-                                                       int Q, float *grad_tet, float *grad_pts,
-                                                       const float *__restrict__ gocc, float *grad_pred,
-                                                       const float *__restrict__ missPart, int nMissParts)
-{
-    const int b = blockIdx.y;
-    if (grad_pred && blockIdx.x == 0 && threadIdx.x < 64) {
-        float v = (int)threadIdx.x < nMissParts ? missPart[b * kMissParts + threadIdx.x] : 0.f;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-        if (threadIdx.x == 0) unsafeAtomicAdd(&grad_pred[(size_t)b * T], v);   // atomic only because of the list below
+    if (live) {
+        const bool deferred = grad_pred && t == 0;                 // tet 0 of the shape: written by the ticket winner below
+        if (grad_pred && !deferred) grad_pred[(size_t)b * T + t] = accumulate ? grad_pred[(size_t)b * T + t] + gp : gp;
+        float4 *dst = reinterpret_cast<float4 *>(grad_tet + ((size_t)b * T + t) * 12);
+        float4 o0 = make_float4(acc[0], acc[1], acc[2], acc[3]), o1 = make_float4(acc[4], acc[5], acc[6], acc[7]),
+               o2 = make_float4(acc[8], acc[9], acc[10], acc[11]);
+        if (accumulate) {
+            float4 p0 = dst[0], p1 = dst[1], p2 = dst[2];
+            o0.x += p0.x; o0.y += p0.y; o0.z += p0.z; o0.w += p0.w;
+            o1.x += p1.x; o1.y += p1.y; o1.z += p1.z; o1.w += p1.w;
+            o2.x += p2.x; o2.y += p2.y; o2.z += p2.z; o2.w += p2.w;
+        }
+        dst[0] = o0; dst[1] = o1; dst[2] = o2;
     }
-    const int n = ucount[b];
-    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
-        const int q = ulist[(size_t)b * Q + k];
-        const size_t i = (size_t)b * Q + q;
-        const int t = (int)cond[i];
-        TetGrad g;
-        tet_grad_setup(tet, (size_t)b * T + t, g);
-        float acc[12], G3[3];
-#pragma unroll
-        for (int j = 0; j < 12; ++j) acc[j] = 0.f;
-        tet_grad_add(g, pts + i * 3, reinterpret_cast<const float4 *>(grad_w)[i], acc, G3);
-        float *gt = grad_tet + ((size_t)b * T + t) * 12;
-#pragma unroll
-        for (int j = 0; j < 12; ++j) unsafeAtomicAdd(gt + j, acc[j]);
-        if (grad_pts) { grad_pts[i * 3] = G3[0]; grad_pts[i * 3 + 1] = G3[1]; grad_pts[i * 3 + 2] = G3[2]; }
-        if (grad_pred) unsafeAtomicAdd(&grad_pred[(size_t)b * T + t], gocc[i]);
+    if (!side) return;
+    // miss-sum reduction across the side workgroups: partials and ticket live at the memory side (RMW atomics), so no
+    // cache write-back is needed — a release fence here would flush the whole L2 behind ~100 MB of gradient stores
+    float *mp = missPart + (size_t)b * kMissStride;
+    int *ticket = hitWords + pad + b;
+    if (tid == 0) {
+        mem_write_f32(mp + blockIdx.x, missPartial);
+        if (blockIdx.x == 0) mem_write_f32(mp + kMissParts, gp);   // thread 0 of workgroup 0 is the lane of tet 0
+        __builtin_amdgcn_s_waitcnt(0);                             // both exchanges have returned: they are at the memory side
+        s_last = atomicAdd(ticket, 1) == nMissParts - 1;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (tid <= kMissParts) s_vals[tid] = (tid < nMissParts || tid == kMissParts) ? mem_read_f32(mp + tid) : 0.f;
+    __syncthreads();
+    if (tid == 0) {
+        float tot = 0.f;
+        for (int k = 0; k < kMissParts; ++k) tot += s_vals[k];     // index order: deterministic
+        tot += s_vals[kMissParts];
+        float *dst = grad_pred + (size_t)b * T;
+        *dst = accumulate ? *dst + tot : tot;
+        atomicExch(ticket, 0);                                     // ready for the next backward on this hit buffer
     }
 }
 
@@ -1744,16 +1839,16 @@ static int pit_scan(const Layout &L, const float *tet, const float *pts, float *
     if (T > 0) {
         if (algo == DEFTET_PIT_EXACT) {
             DEFTET_LAUNCH(k_tet_scan, gt, blk, st, tet, T, Q, L.gparam, L.G, L.Gx, L.table, L.cellStride, L.sortedQ, L.result,
-                          L.counters, L.irregT, (int4 *)hit_buf, pts, L.irregQ, ucount);
+                          L.counters, L.irregT, (int4 *)hit_buf, pts, L.irregQ, ucount, hit_pad(B));
         } else {
             DEFTET_LAUNCH(k_tet_scan_slab, gt, blk, st, tet, T, Q, L.gparam, L.G, L.Gx, L.table, L.cellStride, L.sortedQ, L.result,
-                          L.counters, L.irregT, (int4 *)hit_buf, pts, L.irregQ, ucount);
+                          L.counters, L.irregT, (int4 *)hit_buf, pts, L.irregQ, ucount, hit_pad(B));
         }
     } else if (ucount) {
-        DEFTET_HIP(hipMemsetAsync(ucount, 0, (size_t)B * 4, st));
+        DEFTET_HIP(hipMemsetAsync(ucount, 0, (size_t)3 * hit_pad(B) * 4, st));
     }
     DEFTET_LAUNCH(k_finalize, gq, blk, st, tet, pts, T, Q, L.result, cond, bary, pred, occ, (const int4 *)hit_buf, ucount,
-                  hit_buf ? hit_buf + hit_list_off(B, T) : nullptr, L.counters, L.irregT);
+                  hit_buf ? hit_buf + hit_list_off(B, T) : nullptr, L.counters, L.irregT, hit_pad(B));
     return DEFTET_OK;
 }
 
@@ -1774,7 +1869,7 @@ extern "C" int deftet_point_in_tet_f32(const float *tet, const float *pts, float
         }
         DEFTET_LAUNCH(k_brute, gq, blk, st, L.rec, pts, T, Q, L.result);
         DEFTET_LAUNCH(k_finalize, gq, blk, st, tet, pts, T, Q, L.result, cond, bary, pred, occ, (const int4 *)nullptr, (int *)nullptr,
-                      (int *)nullptr, (const int *)nullptr, L.irregT);
+                      (int *)nullptr, (const int *)nullptr, L.irregT, 0);
         return DEFTET_OK;
     }
     rc = pit_prepare(L, pts, B, Q, st);
@@ -1854,7 +1949,9 @@ extern "C" int deftet_debug_phase_read(unsigned long long *out16, int reset)
 extern "C" size_t deftet_point_in_tet_bwd_workspace_bytes(int B, int T, int Q)
 {
     if (B <= 0 || T < 0 || Q < 0) return 0;
-    return align_up((size_t)B * T * 4, 256) + align_up((size_t)B * Q * 4, 256) + align_up((size_t)B * 4, 256);
+    const size_t lists = align_up((size_t)B * T * 4, 256) + align_up((size_t)B * Q * 4, 256) + align_up((size_t)B * 4, 256);
+    const size_t miss = align_up((size_t)B * kMissStride * 4, 256);   // hit-record path: partial sums of the miss gradient
+    return lists > miss ? lists : miss;
 }
 
 extern "C" int deftet_point_in_tet_bwd_f32(const float *tet, const float *pts, const float *cond, const float *grad_w,
@@ -1884,15 +1981,14 @@ extern "C" int deftet_point_in_tet_bwd_f32(const float *tet, const float *pts, c
         DEFTET_CHECK_ARG(((uintptr_t)hit_buf & 15) == 0, "hit_buf must be 16-byte aligned");
         float *missPart = nullptr;
         if (grad_pred) {
-            DEFTET_CHECK_ARG(workspace && workspace_bytes >= (size_t)B * kMissParts * 4, "workspace needed for the miss sums");
+            DEFTET_CHECK_ARG(workspace && workspace_bytes >= (size_t)B * kMissStride * 4, "workspace needed for the miss sums (80 floats per shape)");
             missPart = static_cast<float *>(workspace);
         }
         const int tblocks = (T + 255) / 256, nMissParts = tblocks < kMissParts ? tblocks : kMissParts;
+        int32_t *words = const_cast<int32_t *>(hit_buf) + hit_cnt_off(B, T);    // counters / ticket / flag: the buffer is this library's own
         DEFTET_LAUNCH(k_bary_bwd_hits, dim3(tblocks, B), dim3(256), st, tet, pts, cond, grad_w, (const int4 *)hit_buf, T, Q,
-                      grad_tet, grad_pts, accumulate, grad_occ, grad_pred, missPart, nMissParts);
-        static_assert(kMissParts == 64, "k_bary_bwd_tail sums the partials with one wave");
-        DEFTET_LAUNCH(k_bary_bwd_tail, dim3(64, B), dim3(256), st, tet, pts, cond, grad_w, hit_buf + hit_cnt_off(B, T),
-                      hit_buf + hit_list_off(B, T), T, Q, grad_tet, grad_pts, grad_occ, grad_pred, missPart, nMissParts);
+                      grad_tet, grad_pts, accumulate, grad_occ, grad_pred, missPart, nMissParts, words,
+                      (const int *)(hit_buf + hit_list_off(B, T)), hit_pad(B));
     } else if (workspace) {
         const size_t need = deftet_point_in_tet_bwd_workspace_bytes(B, T, Q);
         DEFTET_CHECK_ARG(workspace_bytes >= need && ((uintptr_t)workspace & 255) == 0,

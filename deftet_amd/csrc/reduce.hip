@@ -1,7 +1,11 @@
 // reduce.hip — per-shape loss scalars: out[r] = sum_c a[r,c] * b[r,c]  (b may be NULL: plain row sum),
 // optionally plus a second term sum_c a2[r,c] * b2[r,c] with its own width (one launch pair for both).
-// Deterministic (fixed reduction tree, no atomics): kParts workgroups per row write partial
-// sums into the caller's workspace, one wave per row adds them up.
+// Deterministic (fixed reduction tree): kParts workgroups per row produce partial sums.  Up to kTicketRows rows take ONE
+// launch: every workgroup hands its partial to the memory side (returning RMW atomics bypass the per-XCD L2s) and draws
+// a ticket; the one that draws the last ticket of its row adds the partials up in index order.  Larger row counts use
+// the two-launch form (partials into the caller's workspace, one wave per row adds them up).
+#include <atomic>
+
 #include "common.hpp"
 
 namespace deftet {
@@ -49,6 +53,45 @@ __global__ __launch_bounds__(256) void k_rowdot_partial(const float *__restrict_
     if (threadIdx.x == 0) part[r * kParts + blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
 }
 
+constexpr int kTicketRows = 1024, kTicketSlots = 32;
+__device__ int g_tickets[kTicketSlots][kTicketRows];               // zero at load; every launch leaves its slot zero again
+
+__global__ __launch_bounds__(256) void k_rowdot_fused(const float *__restrict__ a, const float *__restrict__ b, float *part,
+                                                      long long n_cols, const float *__restrict__ a2, const float *__restrict__ b2,
+                                                      long long n_cols2, float *out, int slot)
+{
+    __shared__ float wsum[4];
+    __shared__ float vals[kParts];
+    __shared__ int s_last;
+    const long long r = blockIdx.y;
+    float acc = rowdot_slice(a, b, r, n_cols);
+    if (a2) acc += rowdot_slice(a2, b2, r, n_cols2);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float v = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+        const int old = atomicExch(reinterpret_cast<int *>(part + r * kParts + blockIdx.x), __float_as_int(v));
+        asm volatile("" ::"v"(old));                               // returning form: complete (at the memory side) once it has returned
+        __builtin_amdgcn_s_waitcnt(0);
+        s_last = atomicAdd(&g_tickets[slot][r], 1) == kParts - 1;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (threadIdx.x < kParts) vals[threadIdx.x] = __int_as_float(atomicOr(reinterpret_cast<int *>(part + r * kParts + threadIdx.x), 0));
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float v = vals[threadIdx.x] + vals[64 + threadIdx.x];      // same tree as k_rowdot_final
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if (threadIdx.x == 0) {
+            out[r] = v;
+            atomicExch(&g_tickets[slot][r], 0);
+        }
+    }
+}
+
 __global__ __launch_bounds__(64) void k_rowdot_final(const float *__restrict__ part, float *out)
 {
     const long long r = blockIdx.x;
@@ -73,6 +116,13 @@ extern "C" int deftet_rowdot2_f32(const float *a, const float *b, long long n_co
     DEFTET_CHECK_ARG(workspace && workspace_bytes >= deftet_rowdot_workspace_bytes(n_rows), "workspace null or too small");
     hipStream_t st = deftet::as_stream(stream_);
     float *part = static_cast<float *>(workspace);
+    if (n_rows <= deftet::red::kTicketRows) {
+        static std::atomic<unsigned> next{0};                       // a slot of tickets per launch in flight
+        const int slot = (int)(next.fetch_add(1) % deftet::red::kTicketSlots);
+        DEFTET_LAUNCH(deftet::red::k_rowdot_fused, dim3(deftet::red::kParts, n_rows), dim3(256), st, a, b, part, n_cols, a2, b2, n_cols2, out,
+                      slot);
+        return DEFTET_OK;
+    }
     DEFTET_LAUNCH(deftet::red::k_rowdot_partial, dim3(deftet::red::kParts, n_rows), dim3(256), st, a, b, part, n_cols, a2, b2, n_cols2);
     DEFTET_LAUNCH(deftet::red::k_rowdot_final, dim3(n_rows), dim3(64), st, part, out);
     return DEFTET_OK;

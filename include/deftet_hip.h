@@ -94,7 +94,7 @@ int deftet_point_in_tet_scan_f32(const float *tet, const float *pts, float *cond
  * grad_occ f32 [B,Q] + grad_pred f32 [B,T] (both or neither): fused backward of the paste_occ
  * gather, grad_pred[b,t] = sum of grad_occ over the queries that pasted from t (misses -> tet 0).
  * hit_buf (from the forward, same tet/pts/cond) selects the fastest path (with grad_pred it
- * also needs 64*n_batch floats of workspace); else workspace
+ * also needs 80*n_batch floats of workspace); else workspace
  * (deftet_point_in_tet_bwd_workspace_bytes) enables the linked-list gather path; with neither a
  * float-atomic scatter is used. */
 /* Diagnostics (not on the hot path): 8 int32 per shape left in `workspace` by the last forward — [0] irregular tets,

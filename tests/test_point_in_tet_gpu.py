@@ -446,3 +446,29 @@ def test_config_full_size_b8(cuda, oracle, res, nq, batch, sub):
         a2 = hip_ops.point_in_tet_bwd(t, p, c2, gw, grad_occ=go, hits=h2)
         assert (a2[0] - b[0]).abs().max() <= 2e-5 * b[0].abs().max()
         assert (a2[2] - b[2]).abs().max() <= 1e-4 * b[2].abs().max()
+
+
+@pytest.mark.parametrize("res,nq", [(8, 150), (8, 1200), (20, 4000)])
+def test_hit_records_equal_between_traversal_kernels(cuda, res, nq):
+    """The per-tet hit records of the default traversal (published with hand-written stores) hold the same query sets
+    as the ones of the exact kernel (plain compiler-generated stores); overflowed records only need to agree on the flag.
+    (Round 3: a missing wait state after a 128-bit store once zeroed the first slot of 4 lanes in 16.)"""
+    from deftet_amd import grids
+    tet, pts, _, _ = grids.make_case(res, nq, 2)
+    t, p = torch.from_numpy(tet).to(cuda), torch.from_numpy(pts).to(cuda)
+    B, T = t.shape[0], t.shape[1]
+    rec = {}
+    for algo in (0, 2):
+        cond, hits = hip_ops.point_in_tet(t, p, want_hits=True, algo=algo)
+        rec[algo] = hits[:4 * B * T].view(B, T, 4).clone()
+    ovf0, ovf2 = rec[0][..., 3] == -2, rec[2][..., 3] == -2
+    assert torch.equal(ovf0, ovf2)
+    a, b = rec[0].sort(-1).values, rec[2].sort(-1).values
+    assert torch.equal(a[~ovf0], b[~ovf0])
+    # and every winner of a non-overflowed tet is in that tet's record
+    c = cond[..., 0].long()
+    for bi in range(B):
+        q = (c[bi] >= 0).nonzero().flatten()
+        tt = c[bi, q]
+        keep = ~ovf0[bi, tt]
+        assert (rec[0][bi, tt[keep]] == q[keep, None].int()).any(-1).all()

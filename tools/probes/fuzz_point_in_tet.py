@@ -45,12 +45,23 @@ while time.time() < t_end:
     gw = torch.randn(B, Q, 4, device=dev, generator=g); go = torch.randn(B, Q, device=dev, generator=g)
     a = hip_ops.point_in_tet_bwd(tet, pts, cond, gw, grad_occ=go, hits=hits)
     b = hip_ops.point_in_tet_bwd(tet, pts, cond, gw, grad_occ=go)
-    for x, y in ((a[0], b[0]), (a[2], b[2])):
+    for name, x, y in (("grad_tet", a[0], b[0]), ("grad_pred", a[2], b[2])):
         f = torch.isfinite(x) & torch.isfinite(y)
         if f.any():
             err = ((x - y)[f]).abs().max().item(); ref_mag = y[f].abs().max().item()
             if err > 2e-3 * max(ref_mag, 1e-30):
-                print("BACKWARD MISMATCH B=%d T=%d Q=%d kind=%d: err %g of %g" % (B, T, Q, kind, err, ref_mag), flush=True)
+                d = torch.where(f, (x - y).abs(), torch.zeros_like(x))
+                at = [int(v) for v in torch.unravel_index(d.argmax(), d.shape)]
+                words = hits[4 * B * T:4 * B * T + 3 * ((B + 63) // 64 * 64)].view(3, -1)[:, :B].tolist()
+                qs = (cond[at[0], :, 0] == at[1]).nonzero().flatten().tolist()
+                nU = words[0][at[0]]
+                ul = hits[4 * B * T + 3 * ((B + 63) // 64 * 64):].view(B, Q)[at[0], :nU].tolist()
+                print("queries won by that tet: %s (coordinates %s); in the uncovered list: %s" % (
+                    qs, pts[at[0], qs].tolist(), [q in ul for q in qs]), flush=True)
+                print("BACKWARD MISMATCH %s B=%d T=%d Q=%d kind=%d: err %g of %g at %s: hits-path %g vs list-path %g; "
+                      "uncovered/ticket/irregular-query words %s; record of that tet %s" % (
+                          name, B, T, Q, kind, err, ref_mag, at, x[tuple(at)].item(), y[tuple(at)].item(), words,
+                          hits[:4 * B * T].view(B, T, 4)[at[0], at[1]].tolist()), flush=True)
                 sys.exit(1)
     n += 1
 print("fuzz ok: %d random cases" % n, flush=True)
