@@ -68,6 +68,9 @@ SIGNATURES = {
     "deftet_tet_energies_bwd_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "deftet_face_edge_adj_workspace_bytes": (_sz, [_i]),
     "deftet_face_edge_adj_f32": (_i, [_vp, _vp, _i, _i, _vp, _sz, _vp]),
+    "deftet_face_edge_adj_ragged_workspace_bytes": (_sz, [_i, _i]),
+    "deftet_face_edge_adj_ragged_f32": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _sz, _vp]),
+    "deftet_nn_index_ragged_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "deftet_tri_dist_workspace_bytes": (_sz, [_i, _i, _i]),
     "deftet_tri_dist_fwd_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "deftet_tri_dist_bwd_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

@@ -1686,35 +1686,29 @@ static int nn_pick_G(int M)
     return G;
 }
 
-extern "C" size_t deftet_nn_index_workspace_bytes(int B, int N, int M)
+static size_t nn_slice_bytes(int N, int M)
 {
     const int G = nn_pick_G(M);
     const size_t nc = (size_t)G * G * G + 1;
     size_t sortTmp = 0;
     (void)rocprim::radix_sort_pairs(nullptr, sortTmp, (unsigned *)nullptr, (unsigned *)nullptr, rocprim::counting_iterator<unsigned>(0),
                                     (unsigned *)nullptr, (size_t)(N > 0 ? N : 0), 0, 25, (hipStream_t) nullptr);
-    return nc * 4 * 3 + (size_t)(M > 0 ? M : 0) * (8 + 16) + (size_t)(N > 0 ? N : 0) * 20 + nc * 8 + nc + 4096 + (size_t)G * G * 4 + sortTmp +
-           ((size_t)2 << 20);
+    return align_up(nc * 4 * 3 + (size_t)(M > 0 ? M : 0) * (8 + 16) + (size_t)(N > 0 ? N : 0) * 20 + nc * 8 + nc + 4096 + (size_t)G * G * 4 + sortTmp +
+                        ((size_t)2 << 20), 256);
 }
 
-// workspace == NULL: the scalar-stream brute force; otherwise the grid search (both exact).
-extern "C" int deftet_nn_index_f32(const float *queries, const float *points, int32_t *result, int B, int N, int M,
-                                   void *workspace, size_t wsb, void *stream_)
+// one workspace slice per shape stream (common.hpp ShapeFork)
+extern "C" size_t deftet_nn_index_workspace_bytes(int B, int N, int M)
 {
-    DEFTET_CHECK_ARG(B >= 0 && N >= 0 && M >= 0 && B <= 65535, "bad size");
-    if (B == 0 || N == 0) return DEFTET_OK;
-    DEFTET_CHECK_ARG(queries && result && (M == 0 || points), "null pointer");
-    DEFTET_CHECK_ARG((long long)M * 3 < 2147483647LL && (long long)N * 3 < 2147483647LL, "too many points per shape");
-    hipStream_t st = as_stream(stream_);
-    if (!workspace || M == 0) {
-        DEFTET_LAUNCH(k_nn, dim3((N + 255) / 256, B), dim3(256), st, queries, points, N, M, result);
-        return DEFTET_OK;
-    }
-    DEFTET_CHECK_ARG(((uintptr_t)workspace & 255) == 0 && wsb >= deftet_nn_index_workspace_bytes(B, N, M),
-                     "workspace misaligned or too small");
+    return nn_slice_bytes(N, M) * (size_t)(B < 1 ? 1 : (B < kShapeStreams ? B : kShapeStreams));
+}
+
+// the grid search for ONE shape on `st` (N queries, M points), workspace slice `ws`
+static int nn_one_shape(const float *qb, const float *pb, int32_t *res, int N, int M, void *ws, size_t wsb, hipStream_t st)
+{
     const int G = nn_pick_G(M), keyBits = nn_far_key_bits(G);
     const size_t nc = (size_t)G * G * G + 1;
-    Arena A(workspace, wsb);
+    Arena A(ws, wsb);
     float *part = A.take<float>(kNNBlocks * 6);
     NNGrid *grid = A.take<NNGrid>(1);
     int *cells = A.take<int>(nc), *start = A.take<int>(nc), *rep = A.take<int>(nc);
@@ -1727,46 +1721,98 @@ extern "C" int deftet_nn_index_f32(const float *queries, const float *points, in
     int *nFar = A.take<int>(4);
     void *tmp = A.base + align_up(A.off, 256);
     const size_t left = wsb - align_up(A.off, 256);
-    for (int b = 0; b < B; ++b) {
-        const float *pb = points + (size_t)b * M * 3, *qb = queries + (size_t)b * N * 3;
-        DEFTET_HIP(hipMemsetAsync(cells, 0, nc * 4, st));
-        DEFTET_HIP(hipMemsetAsync(rep, 0xFF, nc * 4, st));          // -1 = empty coarse cell
-        DEFTET_LAUNCH(k_nn_bbox, dim3(kNNBlocks), dim3(256), st, pb, M, part);
-        DEFTET_LAUNCH(k_nn_grid, dim3(1), dim3(64), st, part, G, grid);
-        DEFTET_LAUNCH(k_nn_bin, dim3((M + 255) / 256), dim3(256), st, pb, M, grid, cells, pcell, rep);
-        size_t need = 0;
-        hipError_t e = rocprim::exclusive_scan(nullptr, need, cells, start, 0, nc, rocprim::plus<int>(), st);
-        if (e != hipSuccess || need > left) return set_error(DEFTET_ELAUNCH, "exclusive_scan temp");
-        e = rocprim::exclusive_scan(tmp, need, cells, start, 0, nc, rocprim::plus<int>(), st);
-        if (e != hipSuccess) return set_error(DEFTET_ELAUNCH, "exclusive_scan: %s", hipGetErrorString(e));
-        DEFTET_LAUNCH(k_nn_scatter, dim3((M + 255) / 256), dim3(256), st, pb, M, pcell, start, sorted);
-        DEFTET_LAUNCH(k_nn_query, dim3((N + 255) / 256), dim3(256), st, qb, N, grid, start, sorted, rep, pb, M,
-                      result + (size_t)b * N, farKey, 1u << keyBits);
-        need = 0;
-        e = rocprim::radix_sort_pairs(nullptr, need, farKey, farKeyS, rocprim::counting_iterator<unsigned>(0), farList, (size_t)N, 0, keyBits + 1, st);
-        if (e != hipSuccess || need > left) return set_error(DEFTET_ELAUNCH, "radix_sort temp");
-        e = rocprim::radix_sort_pairs(tmp, need, farKey, farKeyS, rocprim::counting_iterator<unsigned>(0), farList, (size_t)N, 0, keyBits + 1, st);
-        if (e != hipSuccess) return set_error(DEFTET_ELAUNCH, "radix_sort_pairs: %s", hipGetErrorString(e));
-        const int Gc = (G + kNNCoarse - 1) / kNNCoarse, Gc3 = Gc * Gc * Gc, nt = std::max(Gc3, G * G + 2 * kNNBatch);
-        DEFTET_HIP(hipMemsetAsync(nRep, 0, 16, st));
-        DEFTET_LAUNCH(k_nn_far_tables, dim3((nt + 255) / 256), dim3(256), st, (const int *)rep, pb, Gc3, (const int *)start, G, repList, nRep,
-                      rowStart, sorted);
-        DEFTET_LAUNCH(k_nn_far_pad, dim3(1), dim3(64), st, repList, (const int *)nRep);
-        DEFTET_LAUNCH(k_nn_far_bound, dim3((N + 63) / 64), dim3(kFarWaves * 64), st, qb, grid, start, (const float4 *)sorted,
-                      (const float4 *)repList, (const int *)nRep, pb, N, (const unsigned *)farKeyS, (const unsigned *)farList, bound, nFar,
-                      1u << keyBits);
-        DEFTET_LAUNCH(k_nn_far_rows, dim3((N + 63) / 64, kFarSlices), dim3(kFarWaves * 64), st, qb, grid, start, (const float4 *)sorted,
-                      (const int *)rowStart, (const int *)nFar, (const unsigned *)farList, bound);
-        DEFTET_LAUNCH(k_nn_far_final, dim3((N + 255) / 256), dim3(256), st, (const unsigned long long *)bound, (const int *)nFar,
-                      (const unsigned *)farList, result + (size_t)b * N);
-    }
+    DEFTET_HIP(hipMemsetAsync(cells, 0, nc * 4, st));
+    DEFTET_HIP(hipMemsetAsync(rep, 0xFF, nc * 4, st));          // -1 = empty coarse cell
+    DEFTET_LAUNCH(k_nn_bbox, dim3(kNNBlocks), dim3(256), st, pb, M, part);
+    DEFTET_LAUNCH(k_nn_grid, dim3(1), dim3(64), st, part, G, grid);
+    DEFTET_LAUNCH(k_nn_bin, dim3((M + 255) / 256), dim3(256), st, pb, M, grid, cells, pcell, rep);
+    size_t need = 0;
+    hipError_t e = rocprim::exclusive_scan(nullptr, need, cells, start, 0, nc, rocprim::plus<int>(), st);
+    if (e != hipSuccess || need > left) return set_error(DEFTET_ELAUNCH, "exclusive_scan temp");
+    e = rocprim::exclusive_scan(tmp, need, cells, start, 0, nc, rocprim::plus<int>(), st);
+    if (e != hipSuccess) return set_error(DEFTET_ELAUNCH, "exclusive_scan: %s", hipGetErrorString(e));
+    DEFTET_LAUNCH(k_nn_scatter, dim3((M + 255) / 256), dim3(256), st, pb, M, pcell, start, sorted);
+    DEFTET_LAUNCH(k_nn_query, dim3((N + 255) / 256), dim3(256), st, qb, N, grid, start, sorted, rep, pb, M, res, farKey, 1u << keyBits);
+    need = 0;
+    e = rocprim::radix_sort_pairs(nullptr, need, farKey, farKeyS, rocprim::counting_iterator<unsigned>(0), farList, (size_t)N, 0, keyBits + 1, st);
+    if (e != hipSuccess || need > left) return set_error(DEFTET_ELAUNCH, "radix_sort temp");
+    e = rocprim::radix_sort_pairs(tmp, need, farKey, farKeyS, rocprim::counting_iterator<unsigned>(0), farList, (size_t)N, 0, keyBits + 1, st);
+    if (e != hipSuccess) return set_error(DEFTET_ELAUNCH, "radix_sort_pairs: %s", hipGetErrorString(e));
+    const int Gc = (G + kNNCoarse - 1) / kNNCoarse, Gc3 = Gc * Gc * Gc, nt = std::max(Gc3, G * G + 2 * kNNBatch);
+    DEFTET_HIP(hipMemsetAsync(nRep, 0, 16, st));
+    DEFTET_LAUNCH(k_nn_far_tables, dim3((nt + 255) / 256), dim3(256), st, (const int *)rep, pb, Gc3, (const int *)start, G, repList, nRep,
+                  rowStart, sorted);
+    DEFTET_LAUNCH(k_nn_far_pad, dim3(1), dim3(64), st, repList, (const int *)nRep);
+    DEFTET_LAUNCH(k_nn_far_bound, dim3((N + 63) / 64), dim3(kFarWaves * 64), st, qb, grid, start, (const float4 *)sorted,
+                  (const float4 *)repList, (const int *)nRep, pb, N, (const unsigned *)farKeyS, (const unsigned *)farList, bound, nFar,
+                  1u << keyBits);
+    DEFTET_LAUNCH(k_nn_far_rows, dim3((N + 63) / 64, kFarSlices), dim3(kFarWaves * 64), st, qb, grid, start, (const float4 *)sorted,
+                  (const int *)rowStart, (const int *)nFar, (const unsigned *)farList, bound);
+    DEFTET_LAUNCH(k_nn_far_final, dim3((N + 255) / 256), dim3(256), st, (const unsigned long long *)bound, (const int *)nFar,
+                  (const unsigned *)farList, res);
     return DEFTET_OK;
+}
+
+// n_query_host == NULL: every shape has N queries.  Otherwise shape b has n_query_host[b] <= N queries (rows beyond
+// that are left untouched); the counts are HOST integers (the caller knows its face counts), strides stay N.
+static int nn_index_impl(const float *queries, const float *points, int32_t *result, int B, int N, int M, const int *n_query_host,
+                         void *workspace, size_t wsb, void *stream_)
+{
+    DEFTET_CHECK_ARG(B >= 0 && N >= 0 && M >= 0 && B <= 65535, "bad size");
+    if (B == 0 || N == 0) return DEFTET_OK;
+    DEFTET_CHECK_ARG(queries && result && (M == 0 || points), "null pointer");
+    DEFTET_CHECK_ARG((long long)M * 3 < 2147483647LL && (long long)N * 3 < 2147483647LL, "too many points per shape");
+    if (n_query_host)
+        for (int b = 0; b < B; ++b) DEFTET_CHECK_ARG(n_query_host[b] >= 0 && n_query_host[b] <= N, "n_query[%d]=%d outside [0,%d]", b, n_query_host[b], N);
+    hipStream_t st = as_stream(stream_);
+    if (!workspace || M == 0) {
+        if (!n_query_host) {
+            DEFTET_LAUNCH(k_nn, dim3((N + 255) / 256, B), dim3(256), st, queries, points, N, M, result);
+        } else {
+            for (int b = 0; b < B; ++b)
+                if (n_query_host[b] > 0)
+                    DEFTET_LAUNCH(k_nn, dim3((n_query_host[b] + 255) / 256, 1), dim3(256), st, queries + (size_t)b * N * 3, points + (size_t)b * M * 3,
+                                  n_query_host[b], M, result + (size_t)b * N);
+        }
+        return DEFTET_OK;
+    }
+    DEFTET_CHECK_ARG(((uintptr_t)workspace & 255) == 0 && wsb >= deftet_nn_index_workspace_bytes(B, N, M),
+                     "workspace misaligned or too small");
+    const size_t slice = nn_slice_bytes(N, M);
+    ShapeFork fork(st, B);
+    for (int b = 0; b < B; ++b) {
+        const int Nb = n_query_host ? n_query_host[b] : N;
+        if (Nb == 0) continue;
+        const int rc = nn_one_shape(queries + (size_t)b * N * 3, points + (size_t)b * M * 3, result + (size_t)b * N, Nb, M,
+                                    static_cast<char *>(workspace) + slice * fork.slice(b), slice, fork.stream(b));
+        if (rc != DEFTET_OK) return rc;
+    }
+    return fork.join();
+}
+
+// workspace == NULL: the scalar-stream brute force; otherwise the grid search (both exact).
+extern "C" int deftet_nn_index_f32(const float *queries, const float *points, int32_t *result, int B, int N, int M,
+                                   void *workspace, size_t wsb, void *stream_)
+{
+    return nn_index_impl(queries, points, result, B, N, M, nullptr, workspace, wsb, stream_);
+}
+
+extern "C" int deftet_nn_index_ragged_f32(const float *queries, const float *points, int32_t *result, int B, int N_max, int M,
+                                          const int *n_query_host, void *workspace, size_t wsb, void *stream_)
+{
+    DEFTET_CHECK_ARG(n_query_host || B == 0, "null n_query_host");
+    return nn_index_impl(queries, points, result, B, N_max, M, n_query_host, workspace, wsb, stream_);
 }
 
 extern "C" size_t deftet_face_edge_adj_workspace_bytes(int F)
 {
     const size_t n = (size_t)(F > 0 ? F : 0) * 3;
-    return n * (5 * 8 + 2 * 4 + 3 * 4) + n * 24 + ((size_t)4 << 20);
+    return align_up(n * (5 * 8 + 2 * 4 + 3 * 4) + n * 24 + ((size_t)4 << 20), 256);
+}
+
+extern "C" size_t deftet_face_edge_adj_ragged_workspace_bytes(int B, int F_max)
+{
+    return deftet_face_edge_adj_workspace_bytes(F_max) * (size_t)(B < 1 ? 1 : (B < kShapeStreams ? B : kShapeStreams));
 }
 
 // workspace == NULL (or max_nei > 32): the scalar-stream brute force; otherwise the sort-based path.
@@ -1822,11 +1868,107 @@ extern "C" int deftet_face_edge_adj_f32(const float *face, float *adj, int F, in
     return DEFTET_OK;
 }
 
-extern "C" size_t deftet_tri_dist_workspace_bytes(int B, int P, int Fmax)
+// A8 for a batch of surfaces with different face counts: face f32 [B, F_max, 3, 3], adj f32 [B, F_max, max_nei] (pre-filled
+// with -1 by the caller), shape b has n_face_host[b] <= F_max faces (HOST integers); neighbour indices are local to the
+// shape.  The shapes run side by side on the library's shape streams.
+extern "C" int deftet_face_edge_adj_ragged_f32(const float *face, float *adj, int B, int F_max, const int *n_face_host, int max_nei,
+                                               void *workspace, size_t wsb, void *stream_)
+{
+    DEFTET_CHECK_ARG(B >= 0 && F_max >= 0 && max_nei >= 0 && B <= 65535, "bad size");
+    if (B == 0 || F_max == 0 || max_nei == 0) return DEFTET_OK;
+    DEFTET_CHECK_ARG(face && adj && n_face_host, "null pointer");
+    for (int b = 0; b < B; ++b) DEFTET_CHECK_ARG(n_face_host[b] >= 0 && n_face_host[b] <= F_max, "n_face[%d]=%d outside [0,%d]", b, n_face_host[b], F_max);
+    DEFTET_CHECK_ARG(!workspace || (((uintptr_t)workspace & 255) == 0 && wsb >= deftet_face_edge_adj_ragged_workspace_bytes(B, F_max)),
+                     "workspace misaligned or too small");
+    const size_t slice = deftet_face_edge_adj_workspace_bytes(F_max);
+    ShapeFork fork(as_stream(stream_), B);
+    for (int b = 0; b < B; ++b) {
+        if (n_face_host[b] == 0) continue;
+        const int rc = deftet_face_edge_adj_f32(face + (size_t)b * F_max * 9, adj + (size_t)b * F_max * max_nei, n_face_host[b], max_nei,
+                                                workspace ? static_cast<char *>(workspace) + slice * fork.slice(b) : nullptr, workspace ? slice : 0,
+                                                (void *)fork.stream(b));
+        if (rc != DEFTET_OK) return rc;
+    }
+    return fork.join();
+}
+
+static size_t tri_slice_bytes(int P, int Fmax)
 {
     const size_t nc = (size_t)kTGMax * kTGMax * kTGMax + 1;
     const size_t F = (size_t)(Fmax > 0 ? Fmax : 0), Pn = (size_t)(P > 0 ? P : 0);
-    return nc * 4 * 3 + F * kTMaxCells * 4 + F * 4 + Pn * 4 + Pn * 12 + Pn * 16 + Pn * 16 + nc * 8 + nc * 12 + ((size_t)2 << 20);
+    return align_up(nc * 4 * 3 + F * kTMaxCells * 4 + F * 4 + Pn * 4 + Pn * 12 + Pn * 16 + Pn * 16 + nc * 8 + nc * 12 + ((size_t)2 << 20), 256);
+}
+
+// one workspace slice per shape stream (common.hpp ShapeFork)
+extern "C" size_t deftet_tri_dist_workspace_bytes(int B, int P, int Fmax)
+{
+    return tri_slice_bytes(P, Fmax) * (size_t)(B < 1 ? 1 : (B < kShapeStreams ? B : kShapeStreams));
+}
+
+// the grid search for ONE shape on `st`, workspace slice `ws`
+static int tri_dist_one_shape(const float *pb, const float *fb, const float *nb, float *cd, float *cf, int P, int Fmax, void *ws, size_t wsb,
+                              hipStream_t st)
+{
+    const size_t nc = (size_t)kTGMax * kTGMax * kTGMax + 1;
+    Arena A(ws, wsb);
+    float *part = A.take<float>(kTParts * 8);
+    TGrid *grid = A.take<TGrid>(1);
+    int *cnt = A.take<int>(nc), *start = A.take<int>(nc), *fill = A.take<int>(nc);
+    int *list = A.take<int>((size_t)Fmax * kTMaxCells + 1), *wide = A.take<int>((size_t)Fmax + 1);
+    int *farList = A.take<int>((size_t)P + 1), *counters = A.take<int>(8);
+    int *farFlag = A.take<int>((size_t)P + 1), *farOff = A.take<int>((size_t)P + 1);
+    unsigned long long *bound = A.take<unsigned long long>((size_t)P + 1);
+    int *rep = A.take<int>(kTGc * kTGc * kTGc);
+    unsigned *pkey = A.take<unsigned>((size_t)P + 1), *pskey = A.take<unsigned>((size_t)P + 1), *order = A.take<unsigned>((size_t)P + 1);
+    int *ptStart = A.take<int>(nc + 1), *chunkCount = A.take<int>(nc + 1), *chunkStart = A.take<int>(nc + 1);
+    void *tmp = A.base + align_up(A.off, 256);
+    const size_t left = wsb - align_up(A.off, 256);
+    DEFTET_HIP(hipMemsetAsync(cnt, 0, nc * 4, st));
+    DEFTET_HIP(hipMemsetAsync(fill, 0, nc * 4, st));
+    DEFTET_HIP(hipMemsetAsync(counters, 0, 32, st));
+    DEFTET_HIP(hipMemsetAsync(rep, 0xFF, (size_t)kTGc * kTGc * kTGc * 4, st));   // -1 = no face in the coarse cell
+    DEFTET_LAUNCH(k_tri_face_stats, dim3(kTParts), dim3(256), st, fb, nb, part);
+    DEFTET_LAUNCH(k_tri_grid, dim3(1), dim3(64), st, part, grid);
+    DEFTET_LAUNCH(k_tri_face_bin, dim3((Fmax + 255) / 256), dim3(256), st, fb, nb, grid, 0, cnt, start, fill, list, wide, counters, rep);
+    size_t need = 0;
+    hipError_t e = rocprim::exclusive_scan(nullptr, need, cnt, start, 0, nc, rocprim::plus<int>(), st);
+    if (e != hipSuccess || need > left) return set_error(DEFTET_ELAUNCH, "exclusive_scan temp");
+    e = rocprim::exclusive_scan(tmp, need, cnt, start, 0, nc, rocprim::plus<int>(), st);
+    if (e != hipSuccess) return set_error(DEFTET_ELAUNCH, "exclusive_scan: %s", hipGetErrorString(e));
+    DEFTET_LAUNCH(k_tri_face_bin, dim3((Fmax + 255) / 256), dim3(256), st, fb, nb, grid, 1, cnt, start, fill, list, wide, counters, rep);
+    DEFTET_LAUNCH(k_tri_point_keys, dim3((P + 255) / 256), dim3(256), st, pb, P, grid, pkey);
+    need = 0;
+    e = rocprim::radix_sort_pairs(nullptr, need, pkey, pskey, rocprim::counting_iterator<unsigned>(0), order, (size_t)P, 0, 18, st);
+    if (e != hipSuccess || need > left) return set_error(DEFTET_ELAUNCH, "radix_sort temp");
+    e = rocprim::radix_sort_pairs(tmp, need, pkey, pskey, rocprim::counting_iterator<unsigned>(0), order, (size_t)P, 0, 18, st);
+    if (e != hipSuccess) return set_error(DEFTET_ELAUNCH, "radix_sort_pairs: %s", hipGetErrorString(e));
+    DEFTET_LAUNCH(k_tri_chunks, dim3((unsigned)((nc + 255) / 256)), dim3(256), st, (const unsigned *)pskey, P, ptStart, chunkCount);
+    need = 0;
+    e = rocprim::exclusive_scan(nullptr, need, chunkCount, chunkStart, 0, nc, rocprim::plus<int>(), st);
+    if (e != hipSuccess || need > left) return set_error(DEFTET_ELAUNCH, "exclusive_scan temp");
+    e = rocprim::exclusive_scan(tmp, need, chunkCount, chunkStart, 0, nc, rocprim::plus<int>(), st);
+    if (e != hipSuccess) return set_error(DEFTET_ELAUNCH, "exclusive_scan: %s", hipGetErrorString(e));
+    {
+        const long long maxChunks = (long long)(P + 63) / 64 + (long long)nc;
+        DEFTET_LAUNCH(k_tri_query_coop, dim3((unsigned)std::min<long long>(maxChunks, kTriQueryBlocks)), dim3(kTriChunkWaves * 64), st, pb, fb, nb, P, grid, start, list, wide, counters,
+                      cd, cf, farFlag, (const unsigned *)order,
+                      (const int *)ptStart, (const int *)chunkStart, (const int *)rep);
+    }
+    // the far path (counters: [0] wide faces, [1] far points)
+    need = 0;
+    e = rocprim::exclusive_scan(nullptr, need, farFlag, farOff, 0, (size_t)P, rocprim::plus<int>(), st);
+    if (e != hipSuccess || need > left) return set_error(DEFTET_ELAUNCH, "exclusive_scan temp");
+    e = rocprim::exclusive_scan(tmp, need, farFlag, farOff, 0, (size_t)P, rocprim::plus<int>(), st);
+    if (e != hipSuccess) return set_error(DEFTET_ELAUNCH, "exclusive_scan: %s", hipGetErrorString(e));
+    DEFTET_LAUNCH(k_tri_compact, dim3((P + 255) / 256), dim3(256), st, (const int *)farFlag, (const int *)farOff, (const unsigned *)order, P,
+                  farList, counters + 1);
+    DEFTET_LAUNCH(k_tri_far_bound, dim3((P + 63) / 64), dim3(kTriWaves * 64), st, pb, fb, grid, (const int *)wide, (const int *)counters,
+                  (const int *)rep, (const int *)farList, (const int *)(counters + 1), bound);
+    DEFTET_LAUNCH(k_tri_far_rows, dim3((P + 63) / 64, kTriSlices), dim3(kTriWaves * 64), st, pb, fb, nb, grid, (const int *)start,
+                  (const int *)list, (const int *)farList, (const int *)(counters + 1), bound);
+    DEFTET_LAUNCH(k_tri_far_final, dim3((P + 255) / 256), dim3(256), st, (const unsigned long long *)bound, (const int *)(counters + 1),
+                  (const int *)farList, cd, cf);
+    return DEFTET_OK;
 }
 
 // workspace == NULL: the scalar-stream brute force; otherwise the grid search (both exact).
@@ -1845,69 +1987,15 @@ extern "C" int deftet_tri_dist_fwd_f32(const float *pts, const float *face, cons
     DEFTET_CHECK_ARG(((uintptr_t)workspace & 255) == 0 && wsb >= deftet_tri_dist_workspace_bytes(B, P, Fmax),
                      "workspace misaligned or too small");
     DEFTET_CHECK_ARG((long long)Fmax * kTMaxCells < 2147483647LL && (long long)P * 3 < 2147483647LL, "too many faces / points");
-    const size_t nc = (size_t)kTGMax * kTGMax * kTGMax + 1;
-    Arena A(workspace, wsb);
-    float *part = A.take<float>(kTParts * 8);
-    TGrid *grid = A.take<TGrid>(1);
-    int *cnt = A.take<int>(nc), *start = A.take<int>(nc), *fill = A.take<int>(nc);
-    int *list = A.take<int>((size_t)Fmax * kTMaxCells + 1), *wide = A.take<int>((size_t)Fmax + 1);
-    int *farList = A.take<int>((size_t)P + 1), *counters = A.take<int>(8);
-    int *farFlag = A.take<int>((size_t)P + 1), *farOff = A.take<int>((size_t)P + 1);
-    unsigned long long *bound = A.take<unsigned long long>((size_t)P + 1);
-    int *rep = A.take<int>(kTGc * kTGc * kTGc);
-    unsigned *pkey = A.take<unsigned>((size_t)P + 1), *pskey = A.take<unsigned>((size_t)P + 1), *order = A.take<unsigned>((size_t)P + 1);
-    int *ptStart = A.take<int>(nc + 1), *chunkCount = A.take<int>(nc + 1), *chunkStart = A.take<int>(nc + 1);
-    void *tmp = A.base + align_up(A.off, 256);
-    const size_t left = wsb - align_up(A.off, 256);
+    const size_t slice = tri_slice_bytes(P, Fmax);
+    ShapeFork fork(st, B);                                            // the shapes run side by side on the library's shape streams
     for (int b = 0; b < B; ++b) {
-        const float *pb = pts + (size_t)b * P * 3, *fb = face + (size_t)b * Fmax * 9, *nb = n_face_b + b;
-        DEFTET_HIP(hipMemsetAsync(cnt, 0, nc * 4, st));
-        DEFTET_HIP(hipMemsetAsync(fill, 0, nc * 4, st));
-        DEFTET_HIP(hipMemsetAsync(counters, 0, 32, st));
-        DEFTET_HIP(hipMemsetAsync(rep, 0xFF, (size_t)kTGc * kTGc * kTGc * 4, st));   // -1 = no face in the coarse cell
-        DEFTET_LAUNCH(k_tri_face_stats, dim3(kTParts), dim3(256), st, fb, nb, part);
-        DEFTET_LAUNCH(k_tri_grid, dim3(1), dim3(64), st, part, grid);
-        DEFTET_LAUNCH(k_tri_face_bin, dim3((Fmax + 255) / 256), dim3(256), st, fb, nb, grid, 0, cnt, start, fill, list, wide, counters, rep);
-        size_t need = 0;
-        hipError_t e = rocprim::exclusive_scan(nullptr, need, cnt, start, 0, nc, rocprim::plus<int>(), st);
-        if (e != hipSuccess || need > left) return set_error(DEFTET_ELAUNCH, "exclusive_scan temp");
-        e = rocprim::exclusive_scan(tmp, need, cnt, start, 0, nc, rocprim::plus<int>(), st);
-        if (e != hipSuccess) return set_error(DEFTET_ELAUNCH, "exclusive_scan: %s", hipGetErrorString(e));
-        DEFTET_LAUNCH(k_tri_face_bin, dim3((Fmax + 255) / 256), dim3(256), st, fb, nb, grid, 1, cnt, start, fill, list, wide, counters, rep);
-        DEFTET_LAUNCH(k_tri_point_keys, dim3((P + 255) / 256), dim3(256), st, pb, P, grid, pkey);
-        need = 0;
-        e = rocprim::radix_sort_pairs(nullptr, need, pkey, pskey, rocprim::counting_iterator<unsigned>(0), order, (size_t)P, 0, 18, st);
-        if (e != hipSuccess || need > left) return set_error(DEFTET_ELAUNCH, "radix_sort temp");
-        e = rocprim::radix_sort_pairs(tmp, need, pkey, pskey, rocprim::counting_iterator<unsigned>(0), order, (size_t)P, 0, 18, st);
-        if (e != hipSuccess) return set_error(DEFTET_ELAUNCH, "radix_sort_pairs: %s", hipGetErrorString(e));
-        DEFTET_LAUNCH(k_tri_chunks, dim3((unsigned)((nc + 255) / 256)), dim3(256), st, (const unsigned *)pskey, P, ptStart, chunkCount);
-        need = 0;
-        e = rocprim::exclusive_scan(nullptr, need, chunkCount, chunkStart, 0, nc, rocprim::plus<int>(), st);
-        if (e != hipSuccess || need > left) return set_error(DEFTET_ELAUNCH, "exclusive_scan temp");
-        e = rocprim::exclusive_scan(tmp, need, chunkCount, chunkStart, 0, nc, rocprim::plus<int>(), st);
-        if (e != hipSuccess) return set_error(DEFTET_ELAUNCH, "exclusive_scan: %s", hipGetErrorString(e));
-        {
-            const long long maxChunks = (long long)(P + 63) / 64 + (long long)nc;
-            DEFTET_LAUNCH(k_tri_query_coop, dim3((unsigned)std::min<long long>(maxChunks, kTriQueryBlocks)), dim3(kTriChunkWaves * 64), st, pb, fb, nb, P, grid, start, list, wide, counters,
-                          closest_d + (size_t)b * P, closest_f + (size_t)b * P, farFlag, (const unsigned *)order,
-                          (const int *)ptStart, (const int *)chunkStart, (const int *)rep);
-        }
-        // the far path (counters: [0] wide faces, [1] far points)
-        need = 0;
-        e = rocprim::exclusive_scan(nullptr, need, farFlag, farOff, 0, (size_t)P, rocprim::plus<int>(), st);
-        if (e != hipSuccess || need > left) return set_error(DEFTET_ELAUNCH, "exclusive_scan temp");
-        e = rocprim::exclusive_scan(tmp, need, farFlag, farOff, 0, (size_t)P, rocprim::plus<int>(), st);
-        if (e != hipSuccess) return set_error(DEFTET_ELAUNCH, "exclusive_scan: %s", hipGetErrorString(e));
-        DEFTET_LAUNCH(k_tri_compact, dim3((P + 255) / 256), dim3(256), st, (const int *)farFlag, (const int *)farOff, (const unsigned *)order, P,
-                      farList, counters + 1);
-        DEFTET_LAUNCH(k_tri_far_bound, dim3((P + 63) / 64), dim3(kTriWaves * 64), st, pb, fb, grid, (const int *)wide, (const int *)counters,
-                      (const int *)rep, (const int *)farList, (const int *)(counters + 1), bound);
-        DEFTET_LAUNCH(k_tri_far_rows, dim3((P + 63) / 64, kTriSlices), dim3(kTriWaves * 64), st, pb, fb, nb, grid, (const int *)start,
-                      (const int *)list, (const int *)farList, (const int *)(counters + 1), bound);
-        DEFTET_LAUNCH(k_tri_far_final, dim3((P + 255) / 256), dim3(256), st, (const unsigned long long *)bound, (const int *)(counters + 1),
-                      (const int *)farList, closest_d + (size_t)b * P, closest_f + (size_t)b * P);
+        const int rc = tri_dist_one_shape(pts + (size_t)b * P * 3, face + (size_t)b * Fmax * 9, n_face_b + b, closest_d + (size_t)b * P,
+                                          closest_f + (size_t)b * P, P, Fmax, static_cast<char *>(workspace) + slice * fork.slice(b), slice,
+                                          fork.stream(b));
+        if (rc != DEFTET_OK) return rc;
     }
-    return DEFTET_OK;
+    return fork.join();
 }
 
 extern "C" int deftet_tri_dist_bwd_f32(const float *pts, const float *face, const float *closest_f, const float *dl_dd,

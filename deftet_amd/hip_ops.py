@@ -357,6 +357,47 @@ def face_edge_adj(face_fx3x3, n_max_nei=30, brute=False):
     return adj
 
 
+def _host_counts(counts, B, hi, what):
+    import ctypes
+    c = [int(x) for x in counts]
+    if len(c) != B or any(x < 0 or x > hi for x in c):
+        raise RuntimeError("%s: need %d counts in [0, %d], got %s" % (what, B, hi, c))
+    return (ctypes.c_int * B)(*c)
+
+
+def face_edge_adj_ragged(face_bxfx3x3, n_face, n_max_nei=30, brute=False):
+    """A8 for a batch of surfaces with different face counts: f32 [B, F_max, n_max_nei] (-1 padded), `n_face` = B host
+    integers.  One call; the shapes run side by side on the library's shape streams."""
+    _lib.require_gpu(face_bxfx3x3)
+    lib = _lib.load()
+    face = _f32c(face_bxfx3x3)
+    B, F = face.shape[0], face.shape[1]
+    cnt = _host_counts(n_face, B, F, "face_edge_adj_ragged")
+    adj = torch.full((B, F, n_max_nei), -1.0, device=face.device, dtype=torch.float32)
+    with torch.cuda.device(face.device):
+        ws = None if brute else _lib.workspace(face.device, lib.deftet_face_edge_adj_ragged_workspace_bytes(B, F))
+        _lib.check(lib.deftet_face_edge_adj_ragged_f32(_lib.ptr(face), _lib.ptr(adj), B, F, cnt, n_max_nei, _lib.ptr(ws),
+                                                       ws.numel() if ws is not None else 0, _lib.current_stream(face.device)),
+                   "deftet_face_edge_adj_ragged_f32")
+    return adj
+
+
+def nn_index_ragged(queries_bxnx3, points_bxmx3, n_query, brute=False):
+    """A10 with a per-shape query count (`n_query` = B host integers <= N): int32 [B,N], rows beyond the count stay 0."""
+    _lib.require_gpu(queries_bxnx3, points_bxmx3)
+    lib = _lib.load()
+    q, p = _f32c(queries_bxnx3), _f32c(points_bxmx3)
+    B, N, M = q.shape[0], q.shape[1], p.shape[1]
+    cnt = _host_counts(n_query, B, N, "nn_index_ragged")
+    out = torch.zeros(B, N, device=q.device, dtype=torch.int32)
+    with torch.cuda.device(q.device):
+        ws = None if brute else _lib.workspace(q.device, lib.deftet_nn_index_workspace_bytes(B, N, M))
+        _lib.check(lib.deftet_nn_index_ragged_f32(_lib.ptr(q), _lib.ptr(p), _lib.ptr(out), B, N, M, cnt, _lib.ptr(ws),
+                                                  ws.numel() if ws is not None else 0, _lib.current_stream(q.device)),
+                   "deftet_nn_index_ragged_f32")
+    return out
+
+
 def tri_dist_fwd(pts_bxpx3, face_bxfx3x3, n_face_b, brute=False):
     """(closest_d, closest_f) f32 [B,P,1] — tet_analytic_distance_for.cu:256-307.
     brute=True selects the streaming scan over all faces (kept for cross-checks)."""

@@ -23,17 +23,6 @@ from deftet_amd import hip_ops, surface_losses
 from deftet_amd.layers.DefTet.check_condition_tetrahedron_base.utils import check_condition_f_base, paste_occ
 
 EPS = 1e-10
-MAX_SIDE_STREAMS = 8
-_streams = {}
-
-
-def _side_streams(device, n):
-    """One HIP stream per shape of a batch (at most MAX_SIDE_STREAMS), created once per device."""
-    key = device.index if device.index is not None else torch.cuda.current_device()
-    pool = _streams.setdefault(key, [])
-    while len(pool) < min(n, MAX_SIDE_STREAMS):
-        pool.append(torch.cuda.Stream(device=device))
-    return pool[:max(1, min(n, MAX_SIDE_STREAMS))]
 
 
 class _TetGather(torch.autograd.Function):
@@ -151,29 +140,11 @@ class DefTet(nn.Module):
         boundary = self.get_boundary_index(face_fx3, face_tet_fx2, center_occ.squeeze(dim=-1))
         inv_v = self.inverse_v.to(tet_bxfx4x3.device)
         volume_variance, amips_energy, edge = self.energies(tet_bxfx4x3, inv_v)
-        # The surface terms differ per shape (its own predicted boundary, a different face count), and each is a chain of
-        # ~40 small launches (A8 sort, A9/A10 grid build + search + far path).  The chains are independent, so every
-        # shape gets its own HIP stream: the launches of all shapes interleave on the device instead of queueing behind
-        # each other (the reference's loop, deftet.py:89-103, serialises them on one stream).
-        streams = _side_streams(vertice_pos.device, n_shape)
-        cur = torch.cuda.current_stream(vertice_pos.device)
-        ready = cur.record_event()
-        terms = []
-        for i in range(n_shape):
-            s = streams[i % len(streams)]
-            s.wait_event(ready)
-            with torch.cuda.stream(s):
-                terms.append(self.forward(v_pos_bxnx3=vertice_pos[i:i + 1], tet_bxfx4=tetrahedron_bxfx4[i:i + 1],
-                                          boundary_bxfx3=boundary[i].unsqueeze(dim=0),
-                                          gt_surface_point=gt_surface_points[i:i + 1], inverse_offset=self.inverse_v,
-                                          tet_bxfx4x3=tet_bxfx4x3[i:i + 1], calculate_amips_volume=False))
-        for s in streams[:n_shape]:
-            cur.wait_stream(s)
-        sum_chamfer = sum_analytic = sum_normal = 0.0
-        for chamfer, analytic, normal in terms:
-            sum_chamfer = sum_chamfer + chamfer / n_shape
-            sum_analytic = sum_analytic + analytic / n_shape
-            sum_normal = sum_normal + normal / n_shape
+        # The surface terms differ per shape (its own predicted boundary, a different face count).  The reference loops
+        # over the shapes (deftet.py:89-103); here ONE ragged launch sequence covers the batch: the per-shape chains of
+        # small launches would otherwise be bound by the host (8 shapes x ~150 framework + library calls ~ 25 ms).
+        chamfer, analytic, normal = surface_losses.surface_terms_batched(vertice_pos, boundary, gt_surface_points, per_face=20)
+        sum_chamfer, sum_analytic, sum_normal = chamfer.mean(0, keepdim=True), analytic.mean(0, keepdim=True), normal.mean(0, keepdim=True)
         center_occ = center_occ.squeeze(-1)
         if inference:
             assert point_pos_bxpx3 is not None, 'point_pos_bxpx3 not given'

@@ -56,7 +56,9 @@ def normal_consistency(vertices_bxnx3, faces_bxfx3):
         valid = adj >= 0
         nei = adj.clamp(min=0).long()
     n = unit_normals(tri)                                                     # [B,F,3]
-    cos = (n[:, :, None, :] * n[:, nei]).sum(-1)                              # [B,F,30]
+    # (index_select, not n[:, nei]: the backward of advanced indexing is a sort-based index_put — 31 ms for 120 k entries)
+    nj = torch.index_select(n, 1, nei.reshape(-1)).reshape(B, F, nei.shape[1], 3)
+    cos = (n[:, :, None, :] * nj).sum(-1)                                     # [B,F,30]
     return ((1.0 - cos) * valid).sum(dim=(1, 2)) / valid.sum().clamp(min=1)
 
 
@@ -99,3 +101,47 @@ def surface_terms(vertices_bxnx3, boundary_bxfx3, gt_points_bxmx3, per_face=20, 
     chamfer = cloud_to_cloud(samples, gt).mean(-1)
     analytic = cloud_to_surface(gt, tri).mean(-1).mean(-1)
     return chamfer, analytic, normal
+
+
+def surface_terms_batched(vertices_bxnx3, boundary_list, gt_points_bxmx3, per_face=20, generator=None):
+    """(chamfer [B], analytic [B], normal [B]) for B predicted surfaces with DIFFERENT face counts in one launch
+    sequence — what `DefTet.forward_surface_align` needs per step, where the reference calls `forward` shape by shape
+    (layers/DefTet/deftet.py:89-103).  `boundary_list[b]` = int64 [F_b,3] vertex indices of shape b's surface.
+
+    The faces are padded to F_max (padding = the degenerate triangle of vertex 0, masked out everywhere); the three
+    operators get the per-shape counts: A8 `face_edge_adj_ragged`, A10 `nn_index_ragged` (F_b * per_face samples), A9
+    through its `n_face_b` argument.  A shape with an empty surface yields (1, 1, 1) like `DefTet.forward` (:159-163)."""
+    B, dev = vertices_bxnx3.shape[0], vertices_bxnx3.device
+    counts = [int(f.shape[0]) for f in boundary_list]
+    one = torch.ones(B, device=dev)
+    f_max = max(counts) if counts else 0
+    if f_max == 0:
+        return one, one.clone(), one.clone()
+    faces = torch.nn.utils.rnn.pad_sequence([f.long() for f in boundary_list], batch_first=True)      # [B,F_max,3], zeros beyond F_b
+    n_face = torch.tensor(counts, device=dev)
+    face_ok = torch.arange(f_max, device=dev)[None, :] < n_face[:, None]                           # [B,F_max]
+    empty = n_face == 0
+    tri = corners(vertices_bxnx3, faces)
+    # normal consistency (A8)
+    with torch.no_grad():
+        adj = hip_ops.face_edge_adj_ragged(tri.float(), counts, 30)                                    # [B,F_max,30], local indices
+        pair_ok = adj >= 0
+        nei = adj.clamp(min=0).long()
+    n = unit_normals(tri)
+    nj = torch.gather(n, 1, nei.reshape(B, -1, 1).expand(-1, -1, 3)).reshape(B, f_max, nei.shape[2], 3)
+    cos = (n[:, :, None, :] * nj).sum(-1)
+    normal = ((1.0 - cos) * pair_ok).sum(dim=(1, 2)) / pair_ok.sum(dim=(1, 2)).clamp(min=1)
+    # chamfer: predicted samples -> ground-truth cloud (A10)
+    gt = gt_points_bxmx3.reshape(B, -1, 3)
+    samples = sample_on_faces(tri, per_face, generator).reshape(B, -1, 3)                              # first F_b * per_face rows valid
+    with torch.no_grad():
+        idx = hip_ops.nn_index_ragged(samples, gt, [c * per_face for c in counts]).long()
+    near = torch.gather(gt, 1, idx[..., None].expand(-1, -1, 3))
+    sample_ok = face_ok[:, :, None].expand(-1, -1, per_face).reshape(B, -1)
+    d = torch.sqrt(((samples - near) ** 2).sum(-1) + SQRT_EPS)
+    chamfer = (d * sample_ok).sum(-1) / (n_face * per_face).clamp(min=1)
+    # analytic: ground-truth cloud -> predicted surface (A9)
+    d2, _ = tet_analytic_distance_f_batch(gt, tri, n_face.float())
+    d2 = torch.where(empty[:, None, None], torch.zeros_like(d2), d2)
+    analytic = torch.sqrt(d2 + SQRT_EPS).mean(-1).mean(-1)
+    return (torch.where(empty, one, chamfer), torch.where(empty, one, analytic), torch.where(empty, one, normal))

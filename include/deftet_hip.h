@@ -301,6 +301,14 @@ int deftet_tet_energies_bwd_f32(const float *tet, const float *inv_v, const doub
 size_t deftet_face_edge_adj_workspace_bytes(int n_face);
 int deftet_face_edge_adj_f32(const float *face_fx3x3, float *adj_fxm, int n_face, int n_max_nei,
                              void *workspace, size_t workspace_bytes, void *stream);
+/* The same operator for a BATCH of surfaces with different face counts — what one training step needs, where the
+ * reference loops over the shapes (layers/DefTet/deftet.py:89-103 -> utils/mesh_utils.py:28): face f32 [B,F_max,3,3],
+ * adj f32 [B,F_max,n_max_nei] pre-filled with -1; shape b has n_face_host[b] <= F_max faces (HOST integers: the caller
+ * built the boundary lists); neighbour indices are local to the shape.  One call; the shapes run side by side on
+ * library-owned HIP streams and are joined back into `stream`. */
+size_t deftet_face_edge_adj_ragged_workspace_bytes(int n_batch, int n_face_max);
+int deftet_face_edge_adj_ragged_f32(const float *face_bxfx3x3, float *adj_bxfxm, int n_batch, int n_face_max,
+                                    const int *n_face_host, int n_max_nei, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------
  * A9  point -> triangle-soup squared distance
@@ -325,6 +333,12 @@ size_t deftet_nn_index_workspace_bytes(int n_batch, int n_query, int n_point);
 /* workspace NULL: brute-force scan (scalar-stream); else exact uniform-grid shell search. */
 int deftet_nn_index_f32(const float *queries_bxnx3, const float *points_bxmx3, int32_t *result_bxn,
                         int n_batch, int n_query, int n_point, void *workspace, size_t workspace_bytes, void *stream);
+/* Ragged batch: shape b has n_query_host[b] <= N_max queries (HOST integers; strides stay N_max, rows beyond the count are
+ * left untouched) — the samples of predicted surfaces with different face counts.  Like deftet_tri_dist_fwd_f32 and
+ * deftet_nn_index_f32 themselves, the shapes of a batch run side by side on library-owned HIP streams. */
+int deftet_nn_index_ragged_f32(const float *queries_bxnx3, const float *points_bxmx3, int32_t *result_bxn, int n_batch,
+                               int n_query_max, int n_point, const int *n_query_host, void *workspace, size_t workspace_bytes,
+                               void *stream);
 
 /* ---------------------------------------------------------------------------------
  * A12 differentiable tet rasterizer with the contract of

@@ -360,3 +360,88 @@ def test_surface_terms_vs_reference_mesh_utils_outputs(cuda):
     assert np.array_equal(hip_ops.nn_index(src, dst)[0].cpu().numpy(), g["nn"])   # A10 == fp64 argmin (no ties in this cloud)
     d = SL.cloud_to_cloud(src, dst)
     assert np.abs(d.cpu().numpy() - g["point_point_distance"]).max() <= 1e-6
+
+
+def _sphere_surfaces(cuda, oracle, radii, res=16):
+    """Boundary face lists (different counts) of the tets inside spheres of the given radii, on one jittered grid."""
+    verts, tets = grids.kuhn_grid(res)
+    pos = grids.jittered_positions(verts, res, len(radii))
+    f3, t2, _, _, _ = oracle.tet_to_face(tets, verts.shape[0])
+    out = []
+    for b, r in enumerate(radii):
+        occ = np.linalg.norm(pos[b][tets].mean(1), axis=1) < r
+        o2 = occ[t2]
+        sel = o2.sum(1) == 1
+        bnd = f3[sel].copy()
+        bnd[o2[sel][:, 0]] = bnd[o2[sel][:, 0]][:, ::-1]
+        out.append(torch.from_numpy(bnd.astype(np.int64)).to(cuda))
+    return torch.from_numpy(pos).to(cuda), out
+
+
+def test_ragged_surface_operators_equal_per_shape_calls(cuda, oracle):
+    from deftet_amd import hip_ops
+    """deftet_face_edge_adj_ragged_f32 / deftet_nn_index_ragged_f32 (one call, shapes on the library's shape streams) ==
+    the single-shape operators shape by shape, bit for bit; an empty surface in the batch is tolerated; the batched A9
+    and A10 calls (now shape-parallel inside) == their per-shape calls."""
+    from deftet_amd import surface_losses as SL
+    v, faces = _sphere_surfaces(cuda, oracle, [0.3, 0.0, 0.22, 0.38])
+    counts = [int(f.shape[0]) for f in faces]
+    assert counts[1] == 0 and len(set(counts)) == 4
+    B, fmax = len(faces), max(counts)
+    pad = torch.nn.utils.rnn.pad_sequence(faces, batch_first=True)
+    tri = SL.corners(v, pad).contiguous()
+    adj = hip_ops.face_edge_adj_ragged(tri, counts, 30)
+    assert adj.shape == (B, fmax, 30)
+    for b in range(B):
+        want = hip_ops.face_edge_adj(tri[b, :counts[b]].contiguous(), 30) if counts[b] else adj.new_zeros(0, 30)
+        assert torch.equal(adj[b, :counts[b]], want), b
+        assert (adj[b, counts[b]:] == -1).all()
+    # A10 ragged
+    g = torch.Generator(device=cuda).manual_seed(3)
+    q = (torch.rand(B, fmax * 5, 3, device=cuda, generator=g) - 0.5)
+    pts = (torch.rand(B, 30000, 3, device=cuda, generator=g) - 0.5) * 0.7
+    nq = [c * 5 for c in counts]
+    idx = hip_ops.nn_index_ragged(q, pts, nq)
+    full = hip_ops.nn_index(q, pts)
+    brute = hip_ops.nn_index(q, pts, brute=True)
+    assert torch.equal(full, brute)
+    for b in range(B):
+        assert torch.equal(idx[b, :nq[b]], full[b, :nq[b]]), b
+        assert (idx[b, nq[b]:] == 0).all()
+    # A9 batched (shape-parallel inside) == per-shape == streaming scan
+    nf = torch.tensor(counts, device=cuda, dtype=torch.float32)
+    d, f = hip_ops.tri_dist_fwd(pts[:, :8000].contiguous(), tri, nf)
+    db, fb = hip_ops.tri_dist_fwd(pts[:, :8000].contiguous(), tri, nf, brute=True)
+    assert torch.equal(d, db) and torch.equal(f, fb)
+
+
+def test_surface_terms_batched_equal_per_shape_terms(cuda, oracle):
+    """surface_terms_batched (one ragged launch sequence for the batch) == surface_terms shape by shape: the normal
+    and point-to-surface terms to 1e-5 (no randomness), the chamfer term statistically (other random samples), gradients
+    to the vertices close; an empty surface yields (1, 1, 1) like DefTet.forward."""
+    from deftet_amd import surface_losses as SL
+    v0, faces = _sphere_surfaces(cuda, oracle, [0.3, 0.0, 0.22, 0.38])
+    B = len(faces)
+    d = np.random.default_rng(1).standard_normal((B, 20000, 3))
+    gt = torch.from_numpy((0.3 * d / np.linalg.norm(d, axis=-1, keepdims=True)).astype(np.float32)).to(cuda)
+    v = v0.clone().requires_grad_(True)
+    ch, an, no = SL.surface_terms_batched(v, faces, gt, per_face=20, generator=torch.Generator(device=cuda).manual_seed(0))
+    (ch.sum() + an.sum() + no.sum()).backward()
+    g_batched = v.grad.clone()
+    assert ch[1] == 1 and an[1] == 1 and no[1] == 1
+    g_ref = torch.zeros_like(g_batched)
+    for b in range(B):
+        if faces[b].shape[0] == 0:
+            continue
+        vb = v0[b:b + 1].clone().requires_grad_(True)
+        c1, a1, n1 = SL.surface_terms(vb, faces[b][None], gt[b:b + 1], per_face=20, generator=torch.Generator(device=cuda).manual_seed(7))
+        (c1.sum() + a1.sum() + n1.sum()).backward()
+        g_ref[b] = vb.grad[0]
+        assert abs(a1.item() - an[b].item()) <= 1e-5 * max(1.0, abs(a1.item())), (b, a1.item(), an[b].item())
+        assert abs(n1.item() - no[b].item()) <= 1e-5, (b, n1.item(), no[b].item())
+        assert abs(c1.item() - ch[b].item()) <= 0.03 * c1.item(), (b, c1.item(), ch[b].item())
+    assert torch.isfinite(g_batched).all()
+    assert (g_batched[1] == 0).all()
+    # gradients: the deterministic terms dominate; the sampled term differs by sampling noise only
+    rel = (g_batched - g_ref).norm() / g_ref.norm()
+    assert rel < 0.2, rel

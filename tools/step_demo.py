@@ -8,7 +8,12 @@ forward_surface_align without the networks), end to end on the HIP operators:
     loss.backward(): d/d tets of all of it --gather_bwd--> d/d vertices (no atomics anywhere)
 
 Prints one JSON line with the time of each stage at BASELINE configs[2] sizes.
-    python tools/step_demo.py [--res 70 --batch 8 --queries 100000]"""
+    python tools/step_demo.py [--res 70 --batch 8 --queries 100000] [--surface [--gt-points 100000]]
+
+--surface times the WHOLE geometry side of a training step: `DefTet.forward_surface_align` (gather, check_sign,
+boundary faces, the three energies AND the per-shape surface terms A8 face adjacency / A9 point-to-surface / A10
+nearest neighbour against `--gt-points` ground-truth surface points per shape) plus the occupancy query
+(point-in-tet + weights + paste_occ), and the backward of all of it down to the vertices."""
 import argparse
 import json
 import os
@@ -66,14 +71,64 @@ def run_step(m, pos, idx, f3, t2, gt_verts, gt_faces, pts, inv_v, pred, times=No
     return loss, boundary, cond
 
 
+def run_full_step(m, pos, idxB, f3, t2, gt_verts, gt_faces, pts, inv_v, pred, gt_pts):
+    """forward_surface_align (training branch) + occupancy query + backward."""
+    B = pos.shape[0]
+    m.inverse_v = inv_v
+    out = m.forward_surface_align(pos, pts, tetrahedron_bxfx4=idxB, mesh_list=([gt_verts[None]] * B, [[gt_faces]] * B),
+                                  gt_surface_points=gt_pts, tet_face_bxfx3=f3[None].expand(B, -1, -1),
+                                  tet_face_tet_bx4fx2=t2[None].expand(B, -1, -1))
+    amips, edge, vvar, analytic, normal, center_occ, boundary, chamfer, _ = out
+    tet = m.gather_tet_pos(pos, idxB)
+    cond, w, occ = point_in_tet_occ(tet, pts, pred)
+    loss = ((w * w).sum() + (occ - 0.5).pow(2).sum() + 1e-3 * amips.sum() + 1e-3 * edge.sum() + 1e-6 * vvar.sum()
+            + chamfer.sum() + analytic.sum() + normal.sum())
+    loss.backward()
+    return loss, boundary
+
+
+def surface_main(a, dev):
+    from deftet_amd import surface_losses
+    case = build_case(a.res, a.batch, a.queries, dev)
+    pos0, idx, f3, t2, gt_verts, gt_faces, pts, inv_v = case
+    B = a.batch
+    per_face = max(1, a.gt_points // max(1, gt_faces.shape[0]))
+    tri = gt_verts[gt_faces.long()][None].expand(B, -1, -1, -1)
+    gt_pts = surface_losses.sample_on_faces(tri, per_face, torch.Generator(device=dev).manual_seed(5)).reshape(B, -1, 3).contiguous()
+    pos = pos0.clone().requires_grad_(True)
+    pred = torch.rand(B, idx.shape[0], device=dev, requires_grad=True)
+    m = DefTet(device=dev)
+    idxB = idx[None].expand(B, -1, -1).contiguous()
+    for _ in range(2):
+        pos.grad = None
+        pred.grad = None
+        _, boundary = run_full_step(m, pos, idxB, f3, t2, gt_verts, gt_faces, pts, inv_v, pred, gt_pts)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        pos.grad = None
+        pred.grad = None
+        run_full_step(m, pos, idxB, f3, t2, gt_verts, gt_faces, pts, inv_v, pred, gt_pts)
+    torch.cuda.synchronize()
+    total = (time.perf_counter() - t0) / a.steps
+    print(json.dumps({"op": "DefTet geometry step incl. surface terms (forward_surface_align + point-in-tet occupancy, fwd + bwd to vertices)",
+                      "res": a.res, "batch": B, "n_tet": int(idx.shape[0]), "n_query": a.queries, "n_gt_points": int(gt_pts.shape[1]),
+                      "n_gt_face": int(gt_faces.shape[0]), "n_boundary_face_per_shape": [int(x.shape[0]) for x in boundary],
+                      "surface_streams": min(B, 8), "ms_per_step": round(total * 1e3, 3)}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--res", type=int, default=70)
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--queries", type=int, default=100000)
     ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--surface", action="store_true")
+    ap.add_argument("--gt-points", type=int, default=100000)
     a = ap.parse_args()
     dev = torch.device("cuda:0")
+    if a.surface:
+        return surface_main(a, dev)
     case = build_case(a.res, a.batch, a.queries, dev)
     pos = case[0].clone().requires_grad_(True)
     pred = torch.rand(a.batch, case[1].shape[0], device=dev, requires_grad=True)
