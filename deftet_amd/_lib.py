@@ -71,6 +71,8 @@ SIGNATURES = {
     "deftet_face_edge_adj_ragged_workspace_bytes": (_sz, [_i, _i]),
     "deftet_face_edge_adj_ragged_f32": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _sz, _vp]),
     "deftet_nn_index_ragged_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "deftet_normal_consistency_fwd_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "deftet_normal_consistency_bwd_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "deftet_tri_dist_workspace_bytes": (_sz, [_i, _i, _i]),
     "deftet_tri_dist_fwd_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "deftet_tri_dist_bwd_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

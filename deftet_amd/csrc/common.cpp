@@ -57,61 +57,6 @@ void prof_end(hipStream_t st)
     g_prof.used += 2;
 }
 
-// ---- per-shape streams --------------------------------------------------------------
-namespace {
-struct StreamPool {
-    hipStream_t s[kShapeStreams];
-    hipEvent_t start, done[kShapeStreams];
-    bool ok = false;
-};
-std::mutex g_pool_mu;
-StreamPool *pool_for_current_device()
-{
-    static std::vector<StreamPool *> pools;                     // indexed by device ordinal, created on first use
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    std::lock_guard<std::mutex> lk(g_pool_mu);
-    if ((size_t)dev >= pools.size()) pools.resize((size_t)dev + 1, nullptr);
-    if (!pools[dev]) {
-        StreamPool *p = new StreamPool();
-        p->ok = hipEventCreateWithFlags(&p->start, hipEventDisableTiming) == hipSuccess;
-        for (int i = 0; i < kShapeStreams && p->ok; ++i)
-            p->ok = hipStreamCreateWithFlags(&p->s[i], hipStreamNonBlocking) == hipSuccess &&
-                    hipEventCreateWithFlags(&p->done[i], hipEventDisableTiming) == hipSuccess;
-        pools[dev] = p;
-    }
-    return pools[dev]->ok ? pools[dev] : nullptr;
-}
-}  // namespace
-
-ShapeFork::ShapeFork(hipStream_t parent_, int n_shapes) : parent(parent_), n(1), joined(false)
-{
-    StreamPool *p = n_shapes > 1 ? pool_for_current_device() : nullptr;
-    if (!p || hipEventRecord(p->start, parent) != hipSuccess) return;          // fall back to the caller's stream
-    const int want = n_shapes < kShapeStreams ? n_shapes : kShapeStreams;
-    for (int i = 0; i < want; ++i) {
-        s[i] = p->s[i];
-        if (hipStreamWaitEvent(s[i], p->start, 0) != hipSuccess) return;
-    }
-    n = want;
-}
-
-int ShapeFork::join()
-{
-    if (joined || n <= 1) {
-        joined = true;
-        return DEFTET_OK;
-    }
-    joined = true;
-    StreamPool *p = pool_for_current_device();
-    if (!p) return set_error(DEFTET_ELAUNCH, "stream pool vanished");
-    for (int i = 0; i < n; ++i) {
-        DEFTET_HIP(hipEventRecord(p->done[i], s[i]));
-        DEFTET_HIP(hipStreamWaitEvent(parent, p->done[i], 0));
-    }
-    return DEFTET_OK;
-}
-
 }  // namespace deftet
 
 // select the kernel to time ("" or NULL switches timing off); resets the accumulated samples

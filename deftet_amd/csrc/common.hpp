@@ -79,22 +79,4 @@ struct Arena {
 
 constexpr int kWave = 64;  // CDNA4 wavefront
 
-// Per-shape HIP streams inside ONE library call.  The surface operators (A8-A10) run a chain of ~20 small launches per
-// shape; the chains of different shapes are independent, so a batched call forks them onto up to kShapeStreams
-// library-owned streams (shape b -> stream b % kShapeStreams, which also owns workspace slice b % kShapeStreams) and
-// joins them back into the caller's stream: the caller sees one stream-ordered operation, the device sees the shapes
-// side by side.  ShapeFork must be joined (join() or the destructor) on every path.
-constexpr int kShapeStreams = 8;
-struct ShapeFork {
-    hipStream_t parent;
-    int n;                       // streams in use (min(shapes, kShapeStreams)); 1 = just the parent stream
-    hipStream_t s[kShapeStreams];
-    bool joined;
-    ShapeFork(hipStream_t parent_, int n_shapes);
-    hipStream_t stream(int b) const { return n <= 1 ? parent : s[b % n]; }
-    int slice(int b) const { return n <= 1 ? 0 : b % n; }
-    int join();
-    ~ShapeFork() { (void)join(); }
-};
-
 }  // namespace deftet

@@ -367,7 +367,7 @@ def _host_counts(counts, B, hi, what):
 
 def face_edge_adj_ragged(face_bxfx3x3, n_face, n_max_nei=30, brute=False):
     """A8 for a batch of surfaces with different face counts: f32 [B, F_max, n_max_nei] (-1 padded), `n_face` = B host
-    integers.  One call; the shapes run side by side on the library's shape streams."""
+    integers.  One launch sequence for the whole batch."""
     _lib.require_gpu(face_bxfx3x3)
     lib = _lib.load()
     face = _f32c(face_bxfx3x3)
@@ -396,6 +396,42 @@ def nn_index_ragged(queries_bxnx3, points_bxmx3, n_query, brute=False):
                                                   ws.numel() if ws is not None else 0, _lib.current_stream(q.device)),
                    "deftet_nn_index_ragged_f32")
     return out
+
+
+class _NormalConsistency(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tri, adj, n_face):
+        lib = _lib.load()
+        B, F, K = tri.shape[0], tri.shape[1], adj.shape[2]
+        loss = torch.empty(B, device=tri.device, dtype=torch.float32)
+        nrm = torch.empty(B, F, 3, device=tri.device, dtype=torch.float32)
+        cnt = torch.empty(B, device=tri.device, dtype=torch.float32)
+        with torch.cuda.device(tri.device):
+            _lib.check(lib.deftet_normal_consistency_fwd_f32(_lib.ptr(tri), _lib.ptr(adj), _lib.ptr(n_face), _lib.ptr(loss), _lib.ptr(nrm),
+                                                             _lib.ptr(cnt), B, F, K, _lib.current_stream(tri.device)),
+                       "deftet_normal_consistency_fwd_f32")
+        ctx.save_for_backward(tri, adj, n_face, nrm, cnt)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        tri, adj, n_face, nrm, cnt = ctx.saved_tensors
+        lib = _lib.load()
+        B, F, K = tri.shape[0], tri.shape[1], adj.shape[2]
+        gtri = torch.empty_like(tri)
+        acc = torch.empty(B, F, 3, device=tri.device, dtype=torch.float32)
+        with torch.cuda.device(tri.device):
+            _lib.check(lib.deftet_normal_consistency_bwd_f32(_lib.ptr(tri), _lib.ptr(adj), _lib.ptr(n_face), _lib.ptr(nrm), _lib.ptr(cnt),
+                                                             _lib.ptr(_f32c(g)), _lib.ptr(gtri), _lib.ptr(acc), B, F, K,
+                                                             _lib.current_stream(tri.device)), "deftet_normal_consistency_bwd_f32")
+        return gtri, None, None
+
+
+def normal_consistency(tri_bxfx3x3, adj_bxfxm, n_face_dev):
+    """loss f32 [B] = mean over the valid entries of the A8 table of 1 - <n_i, n_j> (unit normals with the 1e-12 guard of
+    utils/mesh_utils.py:50-51), differentiable w.r.t. the triangle corners; n_face_dev int32 [B] on the device."""
+    _lib.require_gpu(tri_bxfx3x3, adj_bxfxm, n_face_dev)
+    return _NormalConsistency.apply(_f32c(tri_bxfx3x3), _f32c(adj_bxfxm), n_face_dev.to(torch.int32).contiguous())
 
 
 def tri_dist_fwd(pts_bxpx3, face_bxfx3x3, n_face_b, brute=False):

@@ -122,15 +122,10 @@ def surface_terms_batched(vertices_bxnx3, boundary_list, gt_points_bxmx3, per_fa
     face_ok = torch.arange(f_max, device=dev)[None, :] < n_face[:, None]                           # [B,F_max]
     empty = n_face == 0
     tri = corners(vertices_bxnx3, faces)
-    # normal consistency (A8)
+    # normal consistency (A8 table + one fused launch per direction)
     with torch.no_grad():
         adj = hip_ops.face_edge_adj_ragged(tri.float(), counts, 30)                                    # [B,F_max,30], local indices
-        pair_ok = adj >= 0
-        nei = adj.clamp(min=0).long()
-    n = unit_normals(tri)
-    nj = torch.gather(n, 1, nei.reshape(B, -1, 1).expand(-1, -1, 3)).reshape(B, f_max, nei.shape[2], 3)
-    cos = (n[:, :, None, :] * nj).sum(-1)
-    normal = ((1.0 - cos) * pair_ok).sum(dim=(1, 2)) / pair_ok.sum(dim=(1, 2)).clamp(min=1)
+    normal = hip_ops.normal_consistency(tri, adj, n_face)
     # chamfer: predicted samples -> ground-truth cloud (A10)
     gt = gt_points_bxmx3.reshape(B, -1, 3)
     samples = sample_on_faces(tri, per_face, generator).reshape(B, -1, 3)                              # first F_b * per_face rows valid

@@ -304,11 +304,23 @@ int deftet_face_edge_adj_f32(const float *face_fx3x3, float *adj_fxm, int n_face
 /* The same operator for a BATCH of surfaces with different face counts — what one training step needs, where the
  * reference loops over the shapes (layers/DefTet/deftet.py:89-103 -> utils/mesh_utils.py:28): face f32 [B,F_max,3,3],
  * adj f32 [B,F_max,n_max_nei] pre-filled with -1; shape b has n_face_host[b] <= F_max faces (HOST integers: the caller
- * built the boundary lists); neighbour indices are local to the shape.  One call; the shapes run side by side on
- * library-owned HIP streams and are joined back into `stream`. */
+ * built the boundary lists); neighbour indices are local to the shape.  One launch sequence (memset + two kernels)
+ * covers the whole batch. */
 size_t deftet_face_edge_adj_ragged_workspace_bytes(int n_batch, int n_face_max);
 int deftet_face_edge_adj_ragged_f32(const float *face_bxfx3x3, float *adj_bxfxm, int n_batch, int n_face_max,
                                     const int *n_face_host, int n_max_nei, void *workspace, size_t workspace_bytes, void *stream);
+
+/* Normal consistency of B surfaces on their A8 tables: what the reference composes in Python on top of A8
+ * (utils/mesh_utils.py:28-39: unit normals n = c / sqrt(|c|^2 + 1e-12), c = (v1 - v0) x (v2 - v0); pairs from the
+ * adjacency; mean of 1 - <n_i, n_j>) as one fused launch per direction.  loss f32 [B] = mean over the valid table
+ * entries of shape b (0 when there is none); n_face int32 [B] on the DEVICE.  nrm f32 [B,F_max,3] and count f32 [B]
+ * are written by the forward for the backward; grad_tri f32 [B,F_max,3,3] is fully overwritten; acc f32 [B,F_max,3]
+ * is scratch. */
+int deftet_normal_consistency_fwd_f32(const float *tri_bxfx3x3, const float *adj_bxfxm, const int32_t *n_face_dev, float *loss_b,
+                                      float *nrm_bxfx3, float *count_b, int n_batch, int n_face_max, int n_max_nei, void *stream);
+int deftet_normal_consistency_bwd_f32(const float *tri_bxfx3x3, const float *adj_bxfxm, const int32_t *n_face_dev,
+                                      const float *nrm_bxfx3, const float *count_b, const float *grad_loss_b, float *grad_tri,
+                                      float *acc_bxfx3, int n_batch, int n_face_max, int n_max_nei, void *stream);
 
 /* ---------------------------------------------------------------------------------
  * A9  point -> triangle-soup squared distance
@@ -335,7 +347,8 @@ int deftet_nn_index_f32(const float *queries_bxnx3, const float *points_bxmx3, i
                         int n_batch, int n_query, int n_point, void *workspace, size_t workspace_bytes, void *stream);
 /* Ragged batch: shape b has n_query_host[b] <= N_max queries (HOST integers; strides stay N_max, rows beyond the count are
  * left untouched) — the samples of predicted surfaces with different face counts.  Like deftet_tri_dist_fwd_f32 and
- * deftet_nn_index_f32 themselves, the shapes of a batch run side by side on library-owned HIP streams. */
+ * deftet_nn_index_f32 themselves, ONE launch sequence covers (groups of eight shapes of) the batch: every kernel takes
+ * the shape from its grid's y/z dimension. */
 int deftet_nn_index_ragged_f32(const float *queries_bxnx3, const float *points_bxmx3, int32_t *result_bxn, int n_batch,
                                int n_query_max, int n_point, const int *n_query_host, void *workspace, size_t workspace_bytes,
                                void *stream);

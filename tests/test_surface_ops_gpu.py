@@ -445,3 +445,28 @@ def test_surface_terms_batched_equal_per_shape_terms(cuda, oracle):
     # gradients: the deterministic terms dominate; the sampled term differs by sampling noise only
     rel = (g_batched - g_ref).norm() / g_ref.norm()
     assert rel < 0.2, rel
+
+
+def test_normal_consistency_op_vs_torch_autograd(cuda, oracle):
+    """The fused normal-consistency operator (forward value and gradient w.r.t. the corners) == the fp64 torch composition
+    of utils/mesh_utils.py:28-39 on the same A8 table, for a ragged batch with an empty surface."""
+    from deftet_amd import hip_ops, surface_losses as SL
+    v, faces = _sphere_surfaces(cuda, oracle, [0.3, 0.0, 0.22])
+    counts = [int(f.shape[0]) for f in faces]
+    pad = torch.nn.utils.rnn.pad_sequence(faces, batch_first=True)
+    tri = SL.corners(v, pad).contiguous().requires_grad_(True)
+    adj = hip_ops.face_edge_adj_ragged(tri.detach(), counts, 30)
+    n_face = torch.tensor(counts, device=cuda, dtype=torch.int32)
+    loss = hip_ops.normal_consistency(tri, adj, n_face)
+    w = torch.tensor([0.7, 1.3, -0.4], device=cuda)
+    (loss * w).sum().backward()
+    t64 = tri.detach().double().requires_grad_(True)
+    c = torch.linalg.cross(t64[:, :, 1] - t64[:, :, 0], t64[:, :, 2] - t64[:, :, 0], dim=-1)
+    n = c / torch.sqrt((c * c).sum(-1, keepdim=True) + 1e-12)
+    ok = adj >= 0
+    nj = torch.gather(n, 1, adj.clamp(min=0).long().reshape(len(counts), -1, 1).expand(-1, -1, 3)).reshape(len(counts), -1, 30, 3)
+    want = ((1 - (n[:, :, None] * nj).sum(-1)) * ok).sum((1, 2)) / ok.sum((1, 2)).clamp(min=1)
+    (want * w.double()).sum().backward()
+    assert loss[1] == 0 and torch.allclose(loss.double(), want, rtol=1e-5, atol=1e-7)
+    assert (tri.grad[1] == 0).all()
+    assert torch.allclose(tri.grad.double(), t64.grad, rtol=2e-4, atol=1e-6 * t64.grad.abs().max().item())
