@@ -51,6 +51,10 @@ CONFIGS = {
             name="BASELINE configs[3]: res=100 Kuhn tet grid, 200k queries, 8 shapes per GPU (batch=64 over 8 GPUs)"),
     4: dict(kind="raster", res=70, npx=512, knum=64, batch=1, sets=1,
             name="BASELINE configs[4]: tet rasterizer, 512x512 rays x k=64 over the unique faces of the res=70 grid"),
+    # not a BASELINE config: the geometry side of one TRAINING step (layers/DefTet/deftet.py:51-130) — forward_surface_align
+    # incl. the per-shape surface terms A8/A9/A10 + the occupancy query, forward and backward down to the vertices
+    5: dict(kind="geometry", res=70, n_query=100_000, n_gt=100_000, batch=8, sets=1,
+            name="geometry step incl. surface terms: res=70 grid, 100k queries, 100k ground-truth surface points, batch=8"),
 }
 
 ALGO = int(os.environ.get("DEFTET_BENCH_ALGO", "0"))      # A/B switch for the traversal kernel (0 = shipped default)
@@ -195,9 +199,50 @@ class RasterWorkload:
             self.cfg["name"], self.P, self.F, self.k), "n_ray": self.P, "n_face": self.F, "knum": self.k}
 
 
+class GeometryWorkload:
+    """DefTet.forward_surface_align (training branch) + point-in-tet occupancy, fwd + bwd (tools/step_demo.py --surface)."""
+
+    def __init__(self, cfg, rank, device, world, gather=None):
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import step_demo
+        from deftet_amd import surface_losses
+        from deftet_amd.layers.DefTet.deftet import DefTet
+        self.cfg, self.demo = cfg, step_demo
+        B = cfg["batch"]
+        pos0, idx, f3, t2, gt_verts, gt_faces, pts, inv_v = step_demo.build_case(cfg["res"], B, cfg["n_query"], device)
+        per_face = max(1, cfg["n_gt"] // max(1, gt_faces.shape[0]))
+        tri = gt_verts[gt_faces.long()][None].expand(B, -1, -1, -1)
+        self.gt = surface_losses.sample_on_faces(tri, per_face, torch.Generator(device=device).manual_seed(5)).reshape(B, -1, 3).contiguous()
+        self.pos = pos0.clone().requires_grad_(True)
+        self.pred = torch.rand(B, idx.shape[0], device=device, requires_grad=True)
+        self.m = DefTet(device=device)
+        self.args = (idx[None].expand(B, -1, -1).contiguous(), f3, t2, gt_verts, gt_faces, pts, inv_v)
+        self.B, self.T, self.Q = B, idx.shape[0], cfg["n_query"]
+        self.pairs_per_step = float(B)
+        self.unit = "shapes/s"
+        self.dominant = b"k_tri_query_coop"
+        self.dominant_bytes = 0.0
+        self.step_bytes = 0.0
+        self.last = None
+
+    def step(self, i):
+        self.pos.grad = None
+        self.pred.grad = None
+        self.last = self.demo.run_full_step(self.m, self.pos, *self.args, self.pred, self.gt)
+
+    def drain(self):
+        pass
+
+    def describe(self):
+        return {"workload": "%s: T=%d tets, %d GT points and %d queries per shape, DefTet.forward_surface_align (gather, check_sign, boundary "
+                            "faces, energies, ragged A8/A9/A10 surface terms) + occupancy query, fwd + bwd to the vertices; the largest "
+                            "kernel (A9 k_tri_query_coop) is VALU-bound, no HBM roofline is quoted" % (
+                                self.cfg["name"], self.T, self.gt.shape[1], self.Q)}
+
+
 def make_workload(cfg_id, rank, device, world, gather=None, **kw):
     cfg = CONFIGS[cfg_id]
-    return (PitWorkload if cfg["kind"] == "pit" else RasterWorkload)(cfg, rank, device, world, gather, **kw)
+    return {"pit": PitWorkload, "raster": RasterWorkload, "geometry": GeometryWorkload}[cfg["kind"]](cfg, rank, device, world, gather, **kw)
 
 
 def timed(wl, lib, steps, warmup, world, barrier=True):
@@ -308,7 +353,7 @@ def summarize(wl, elapsed, per_step, kern_ms_tot, kern_cnt, steps, world, peak_m
                                  "how": "1 GiB device-to-device copy (read+write bytes) and read-only streaming sum on this GPU, HIP events"}
         roof["frac_of_measured_read"] = round(achieved / peak_measured["read"], 4)
     return {
-        "value": round(world * wl.pairs_per_step * steps / elapsed / 1e6, 1), "unit": wl.unit,
+        "value": round(world * wl.pairs_per_step * steps / elapsed / (1e6 if wl.unit.startswith("M ") else 1.0), 1), "unit": wl.unit,
         "ms_per_step": round(elapsed / steps * 1e3, 4), "ms_per_step_median": round(statistics.median(per_step), 4),
         "roofline": roof,
     }
@@ -421,9 +466,13 @@ def main():
                     w2 = make_workload(cid, 0, device, 1, None)
                     e, ps, km, kc = timed(w2, lib, max(5, args.steps // 2), 2, 1, barrier=False)
                     rec = summarize(w2, e, ps, km, kc, max(5, args.steps // 2), 1, peak)
-                    others.append({"config_id": cid, "config": w2.describe()["workload"], "value": rec["value"], "unit": rec["unit"],
-                                   "ms_per_step": rec["ms_per_step"], "ms_per_step_median": rec["ms_per_step_median"],
-                                   "roofline": {k: rec["roofline"][k] for k in ("kernel", "achieved", "frac", "avg_launch_ms", "whole_step")}})
+                    entry = {"config_id": cid, "config": w2.describe()["workload"], "value": rec["value"], "unit": rec["unit"],
+                             "ms_per_step": rec["ms_per_step"], "ms_per_step_median": rec["ms_per_step_median"]}
+                    if w2.dominant_bytes > 0:
+                        entry["roofline"] = {k: rec["roofline"][k] for k in ("kernel", "achieved", "frac", "avg_launch_ms", "whole_step")}
+                    else:
+                        entry["dominant_kernel"] = {"kernel": rec["roofline"]["kernel"], "avg_launch_ms": rec["roofline"]["avg_launch_ms"]}
+                    others.append(entry)
                     del w2
                     torch.cuda.empty_cache()
                 line["other_configs"] = others

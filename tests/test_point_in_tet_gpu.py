@@ -440,7 +440,13 @@ def test_config_full_size_b8(cuda, oracle, res, nq, batch, sub):
     b = hip_ops.point_in_tet_bwd(t, p, cond, gw, grad_occ=go)
     assert (a[0] - b[0]).abs().max() <= 2e-5 * b[0].abs().max()
     assert (a[2] - b[2]).abs().max() <= 1e-4 * b[2].abs().max()
-    for algo in (2,):                                # grouped / LDS-staged / round-1 traversals: their hit records drive the same backward
+    # backward and weights at FULL size against the fp64 autograd of the reference formula (utils/tet_utils.py:28-45) on the
+    # GPU's own `cond` (already proven equal to the brute-force kernel above): every query of all `batch` shapes
+    w64, gt64 = oracle.point_in_tet_bwd_torch(tet, pts, cond.cpu().numpy(), gw.cpu().numpy())
+    hitn = hit.cpu().numpy()
+    assert np.abs(w.cpu().numpy() - w64)[hitn].max() <= 1e-5 * max(1.0, np.abs(w64[hitn]).max())
+    assert np.abs(a[0].cpu().numpy() - gt64).max() <= 1e-5 * np.abs(gt64).max() * 8
+    for algo in (2,):                                # the exact traversal: its hit records drive the same backward
         c2, w2, o2, h2 = hip_ops.point_in_tet(t, p, want_bary=True, pred_bxt=pred, want_hits=True, algo=algo)
         assert torch.equal(c2, cond) and torch.equal(w2, w) and torch.equal(o2, occ)
         a2 = hip_ops.point_in_tet_bwd(t, p, c2, gw, grad_occ=go, hits=h2)
@@ -453,7 +459,7 @@ def test_hit_records_equal_between_traversal_kernels(cuda, res, nq):
     """The per-tet hit records of the default traversal (published with hand-written stores) hold the same query sets
     as the ones of the exact kernel (plain compiler-generated stores); overflowed records only need to agree on the flag.
     (Round 3: a missing wait state after a 128-bit store once zeroed the first slot of 4 lanes in 16.)"""
-    from deftet_amd import grids
+    from deftet_amd import grids, hip_ops
     tet, pts, _, _ = grids.make_case(res, nq, 2)
     t, p = torch.from_numpy(tet).to(cuda), torch.from_numpy(pts).to(cuda)
     B, T = t.shape[0], t.shape[1]
@@ -472,3 +478,20 @@ def test_hit_records_equal_between_traversal_kernels(cuda, res, nq):
         tt = c[bi, q]
         keep = ~ovf0[bi, tt]
         assert (rec[0][bi, tt[keep]] == q[keep, None].int()).any(-1).all()
+
+
+def test_config3_full_size_b8(cuda, oracle):
+    """BASELINE configs[3] at one GPU's share — res=100 (T = 750,000), 200k queries, EIGHT shapes (what bench.py --config 3
+    times): the binned path == the independent brute-force kernel on every query of every shape, output properties, and the
+    CPU oracle on a subsample."""
+    from deftet_amd import hip_ops
+    tet, pts = cases.jittered(100, 200000, 8)
+    t, p = torch.from_numpy(tet).to(cuda), torch.from_numpy(pts).to(cuda)
+    cond, w = hip_ops.point_in_tet(t, p, want_bary=True)
+    brute = hip_ops.point_in_tet(t, p, algo=1)
+    assert torch.equal(cond, brute)
+    hit = _check_outputs(t, p, cond, w)
+    assert 0.10 < (~hit).float().mean().item() < 0.17
+    pick = np.sort(np.random.default_rng(3).choice(200000, 300, replace=False))
+    want = oracle.point_in_tet(tet, np.ascontiguousarray(pts[:, pick]), omp=True)
+    assert np.array_equal(cond[:, pick].cpu().numpy(), want)
