@@ -324,18 +324,26 @@ def cpu_baseline(wl):
 def traffic_record(kernel):
     """HBM bytes per launch of the dominant kernel from the rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE, corrected as
     MI355X_MICROARCH.md prescribes).  Counters cannot be read from inside the timed process, so this is the figure
-    tools/pmc_traffic.py collected for the same command; its source file is named next to it."""
-    for rel in ("profiles/r02_pmc_traffic.json", "profiles/pmc_traffic.json"):
+    tools/pmc_traffic.py collected for the same command.  It is only quoted while the kernel source it was measured on
+    (sha1 of deftet_amd/csrc/point_in_tet.hip, stored in the file) is still the one in the tree; otherwise null."""
+    import hashlib
+    for rel in ("profiles/r03_pmc_traffic.json",):
         path = os.path.join(ROOT, rel)
-        if os.path.exists(path):
-            try:
-                rec = json.load(open(path))
-            except Exception:
-                continue
-            v = rec.get("%s_hbm_bytes_per_launch" % kernel)
-            if v is not None:
-                return v, rel
-    return None, None
+        if not os.path.exists(path):
+            continue
+        try:
+            rec = json.load(open(path))
+        except Exception:
+            continue
+        src = os.path.join(ROOT, "deftet_amd", "csrc", "point_in_tet.hip")
+        now = hashlib.sha1(open(src, "rb").read()).hexdigest() if os.path.exists(src) else None
+        v = rec.get("%s_hbm_bytes_per_launch" % kernel)
+        if v is None:
+            continue
+        if rec.get("kernel_source_sha1") != now:
+            return None, "%s (STALE: collected on another version of point_in_tet.hip, commit %s)" % (rel, rec.get("commit")), rec.get("commit")
+        return v, rel, rec.get("commit")
+    return None, None, None
 
 
 def summarize(wl, elapsed, per_step, kern_ms_tot, kern_cnt, steps, world, peak_measured=None):
@@ -343,9 +351,9 @@ def summarize(wl, elapsed, per_step, kern_ms_tot, kern_cnt, steps, world, peak_m
     achieved = wl.dominant_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
     step_gbs = wl.step_bytes / (elapsed / steps) / 1e9
     kernel = wl.dominant.decode()
-    traffic, src = traffic_record(kernel)
+    traffic, src, tcommit = traffic_record(kernel)
     roof = {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": src,
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": src, "traffic_commit": tcommit,
             "algorithmic_bytes_per_launch": wl.dominant_bytes, "avg_launch_ms": round(kern_ms, 5), "launches_timed": int(kern_cnt),
             "whole_step": {"algorithmic_bytes": wl.step_bytes, "achieved": round(step_gbs, 1), "frac": round(step_gbs / HBM_PEAK_GBS, 4)}}
     if peak_measured:
@@ -422,10 +430,14 @@ def main():
     gather = sharding.LossGather()
     wl = make_workload(args.config, rank, device, world, gather)
     elapsed, per_step, kms, kcnt = timed(wl, lib, args.steps, args.warmup, world)
+    rank_ms = None
     if world > 1:
+        # the job's time is the slowest rank's; every rank's own time is kept beside it so that a straggler is visible
         t = torch.tensor([elapsed], device="cpu" if shared else device, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+        allt = torch.empty(world, device=t.device, dtype=torch.float64)
+        torch.distributed.all_gather_into_tensor(allt, t)
+        rank_ms = [round(float(x) / args.steps * 1e3, 4) for x in allt.tolist()]
+        elapsed = float(allt.max().item())
 
     if rank == 0:
         peak = measure_bandwidth(device) if (world == 1 and not args.no_bandwidth_probe) else None
@@ -444,6 +456,7 @@ def main():
         if world > 1:
             line["rccl_ranks"] = torch.distributed.get_world_size()
             line["backend"] = backend
+            line["ms_per_step_by_rank"] = {"min": min(rank_ms), "max": max(rank_ms), "all": rank_ms}
         if world == 1:
             if isinstance(wl, PitWorkload) and not args.no_unpipelined:
                 # the same K steps with the other setting of the cross-step overlap (not the headline; printed beside it)

@@ -11,6 +11,7 @@
 #include <cstring>
 
 #include "common.hpp"
+#include <atomic>
 
 #include <rocprim/rocprim.hpp>
 
@@ -77,6 +78,12 @@ __device__ __forceinline__ float ipow(float x, int p)
     for (int i = 0; i < p; ++i) r *= x;
     return r;
 }
+// The same product with the exponent known at compile time (P4: both exponents are the reference's default 4,
+// deftet.py:27): identical multiplication order, no loop.  Kernels take P4 as a template argument.
+template <bool P4>
+__device__ __forceinline__ float ipow_t(float x, int p) { return P4 ? ((x * x) * x) * x : ipow(x, p); }
+template <bool P4>
+__device__ __forceinline__ float ipow_m1_t(float x, int p) { return P4 ? (x * x) * x : ipow(x, p - 1); }
 
 // V = -det([A-D; B-D; C-D]) / 6,  deftet.py:247-253
 __device__ __forceinline__ float tet_volume(const TetV &v, float *a, float *b, float *c)
@@ -146,6 +153,7 @@ __device__ __forceinline__ float tet_amips(const TetV &v, const float *__restric
 }
 
 // sum of the six edge terms of one tet (deftet.py:326-337)
+template <bool P4>
 __device__ __forceinline__ float tet_edges(const TetV &v, float scale, int pw, float *grad, float gscale)
 {
     const float *P[4] = {v.A, v.Bv, v.C, v.D};
@@ -156,9 +164,9 @@ __device__ __forceinline__ float tet_edges(const TetV &v, float scale, int pw, f
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const float d = P[e[i][0]][k] * scale - P[e[i][1]][k] * scale;
-            sum += ipow(d, pw);
+            sum += ipow_t<P4>(d, pw);
             if (grad) {
-                const float g = (float)pw * ipow(d, pw - 1) * scale * gscale;
+                const float g = (float)pw * ipow_m1_t<P4>(d, pw) * scale * gscale;
                 grad[e[i][0] * 3 + k] += g;
                 grad[e[i][1] * 3 + k] -= g;
             }
@@ -166,12 +174,33 @@ __device__ __forceinline__ float tet_edges(const TetV &v, float scale, int pw, f
     return sum;
 }
 
-constexpr int kEParts = 64;
+// The two reduction passes run kEParts workgroups of kEThreads threads per shape: few, large workgroups, because every
+// workgroup ends with one ticket draw on its shape's counter and same-address atomics serialise at the memory side
+// (256 draws per shape cost more than the 8 MB second pass itself; 64 do not show).
+constexpr int kEParts = 64, kEThreads = 1024, kEWaves = kEThreads / 64;
+constexpr int kETicketShapes = 1024, kETicketSlots = 32;
+__device__ int g_energy_tickets[kETicketSlots][2][kETicketShapes];      // zero at load; every launch leaves its slot zero again
 
-template <int N>
-__device__ __forceinline__ void block_reduce_store(double (&v)[N], double *dst)
+// exact 64-bit exchange at the memory side (device-scope RMW atomics bypass the per-XCD L2s): what the ticket reductions
+// below pass between workgroups that may sit on different XCDs
+__device__ __forceinline__ void mem_write_f64(double *p, double v)
 {
-    __shared__ double sh[4][N];
+    const unsigned long long old = atomicExch(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v));
+    asm volatile("" ::"v"(old));                                   // keep the RETURNING form: its completion is what s_waitcnt observes
+}
+__device__ __forceinline__ double mem_read_f64(double *p)
+{
+    return __longlong_as_double((long long)atomicOr(reinterpret_cast<unsigned long long *>(p), 0ull));
+}
+
+// Per-workgroup sums of N doubles -> part[(b * kEParts + blockIdx.x) * N + k].  With slot >= 0 the partials go to the
+// memory side and the workgroup draws a ticket; returns true (to every thread) in the one that drew the last ticket of
+// shape b, which then finishes the reduction itself — no separate launch.  slot < 0: plain stores, returns false.
+template <int N>
+__device__ __forceinline__ bool block_reduce_store(double (&v)[N], double *part, int b, int slot, int phase)
+{
+    __shared__ double sh[kEWaves][N];
+    __shared__ int s_last;
 #pragma unroll
     for (int k = 0; k < N; ++k)
 #pragma unroll
@@ -181,75 +210,60 @@ __device__ __forceinline__ void block_reduce_store(double (&v)[N], double *dst)
 #pragma unroll
         for (int k = 0; k < N; ++k) sh[w][k] = v[k];
     __syncthreads();
-    if (threadIdx.x < N) dst[threadIdx.x] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+    if (threadIdx.x < 64) {                                        // wave 0: one lane per component finishes the sum and hands it over
+        if (threadIdx.x < N) {
+            double sum = 0.0;
+#pragma unroll
+            for (int i = 0; i < kEWaves; ++i) sum += sh[i][threadIdx.x];
+            double *dst = part + ((size_t)b * kEParts + blockIdx.x) * N + threadIdx.x;
+            if (slot >= 0) mem_write_f64(dst, sum);
+            else *dst = sum;
+        }
+        if (slot >= 0) {
+            __builtin_amdgcn_s_waitcnt(0);                         // the N exchanges of this wave have returned
+            if (threadIdx.x == 0) s_last = atomicAdd(&g_energy_tickets[slot][phase][b], 1) == kEParts - 1;
+        }
+    }
+    if (slot < 0) return false;
+    __syncthreads();
+    return s_last != 0;
 }
 
-// pass 1: per-block partial sums of (V, amips, edge)
-__global__ __launch_bounds__(256) void k_energy_pass1(const float *__restrict__ tet, const float *__restrict__ inv_v, int T,
-                                                      float scale, int pow_e, double *part)
+// sum over the kEParts partials of shape b of component k: wave 0 of the workgroup, one partial per lane (the same tree
+// in the fused and the stand-alone form); every thread of wave 0 gets the result
+template <int N>
+__device__ __forceinline__ void sum_parts(double *part, int b, bool at_memory, double (&out)[N])
 {
-    const int b = blockIdx.y;
-    double acc[3] = {0.0, 0.0, 0.0};
-    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < T; t += gridDim.x * blockDim.x) {
-        const TetV v = load_tet(tet, (size_t)b * T + t);
-        float a[3], bb[3], c[3];
-        acc[0] += (double)tet_volume(v, a, bb, c);
-        if (inv_v) acc[1] += (double)tet_amips(v, inv_v + (size_t)t * 9, scale, nullptr, 0.f);
-        acc[2] += (double)tet_edges(v, scale, pow_e, nullptr, 0.f);
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        double *src = part + ((size_t)b * kEParts + (threadIdx.x & 63)) * N + k;
+        double v = at_memory ? mem_read_f64(src) : *src;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        out[k] = v;
     }
-    block_reduce_store<3>(acc, part + ((size_t)b * kEParts + blockIdx.x) * 3);
 }
+static_assert(kEParts == 64, "sum_parts reads one partial per lane of a wave");
 
 // stats[b] = {mean V, amips mean, edge mean, sum (V-mean)^pow, sum pow (V-mean)^(pow-1) / T}
-__global__ __launch_bounds__(64) void k_energy_mean(const double *__restrict__ part, int T, double *stats)
+__device__ __forceinline__ void finish_means(double *part, int b, int T, bool at_memory, double *stats)
 {
-    const int b = blockIdx.x, lane = threadIdx.x;
+    if (threadIdx.x >= 64) return;
     double v[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        v[k] = part[((size_t)b * kEParts + lane) * 3 + k];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_xor(v[k], off);
-    }
-    if (lane == 0) {
+    sum_parts<3>(part, b, at_memory, v);
+    if (threadIdx.x == 0) {
         stats[b * 8 + 0] = v[0] / (double)T;                 // torch.mean(V), :258
         stats[b * 8 + 1] = v[1] / (double)T;                 // torch.mean(energy), :298
         stats[b * 8 + 2] = v[2] / (6.0 * (double)T);         // sum_edge / (6 * T), :338
     }
 }
 
-__global__ __launch_bounds__(256) void k_energy_pass2(const float *__restrict__ tet, int T, int pow_v,
-                                                      const double *__restrict__ stats, double *part)
+__device__ __forceinline__ void finish_energies(double *part2, int b, int T, bool at_memory, double *stats, float *out)
 {
-    const int b = blockIdx.y;
-    const float mean = (float)stats[b * 8 + 0];
-    double acc[2] = {0.0, 0.0};
-    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < T; t += gridDim.x * blockDim.x) {
-        const TetV v = load_tet(tet, (size_t)b * T + t);
-        float a[3], bb[3], c[3];
-        const float d = tet_volume(v, a, bb, c) - mean;
-        if (pow_v == 1) {
-            acc[0] += (double)fabsf(d);                                          // :260
-            acc[1] += (double)(d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
-        } else {
-            acc[0] += (double)ipow(d, pow_v);                                    // :262
-            acc[1] += (double)((float)pow_v * ipow(d, pow_v - 1));
-        }
-    }
-    block_reduce_store<2>(acc, part + ((size_t)b * kEParts + blockIdx.x) * 2);
-}
-
-__global__ __launch_bounds__(64) void k_energy_final(const double *__restrict__ part2, int T, double *stats, float *out)
-{
-    const int b = blockIdx.x, lane = threadIdx.x;
+    if (threadIdx.x >= 64) return;
     double v[2];
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        v[k] = part2[((size_t)b * kEParts + lane) * 2 + k];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_xor(v[k], off);
-    }
-    if (lane == 0) {
+    sum_parts<2>(part2, b, at_memory, v);
+    if (threadIdx.x == 0) {
         stats[b * 8 + 3] = v[0];
         stats[b * 8 + 4] = v[1] / (double)T;                 // mean of d var / d V (enters through mean_v)
         out[b * 3 + 0] = (float)v[0];                        // volume variance
@@ -258,7 +272,60 @@ __global__ __launch_bounds__(64) void k_energy_final(const double *__restrict__ 
     }
 }
 
+// pass 1: per-workgroup partial sums of (V, amips, edge); the volume of every tet is also kept (4 bytes per tet) so that
+// the second pass — sum of (V - mean)^p, which needs the mean first — reads 4 bytes per tet instead of the 48-byte record
+template <bool P4>
+__global__ __launch_bounds__(kEThreads) void k_energy_pass1(const float *__restrict__ tet, const float *__restrict__ inv_v, int T,
+                                                      float scale, int pow_e, double *part, float *vol, double *stats, int slot)
+{
+    const int b = blockIdx.y;
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < T; t += gridDim.x * blockDim.x) {
+        const TetV v = load_tet(tet, (size_t)b * T + t);
+        float a[3], bb[3], c[3];
+        const float V = tet_volume(v, a, bb, c);
+        vol[(size_t)b * T + t] = V;
+        acc[0] += (double)V;
+        if (inv_v) acc[1] += (double)tet_amips(v, inv_v + (size_t)t * 9, scale, nullptr, 0.f);
+        acc[2] += (double)tet_edges<P4>(v, scale, pow_e, nullptr, 0.f);
+    }
+    if (!block_reduce_store<3>(acc, part, b, slot, 0)) return;
+    finish_means(part, b, T, true, stats);
+    if (threadIdx.x == 0) atomicExch(&g_energy_tickets[slot][0][b], 0);
+}
+
+__global__ __launch_bounds__(64) void k_energy_mean(double *part, int T, double *stats) { finish_means(part, blockIdx.x, T, false, stats); }
+
+// pass 2 over the saved volumes (same per-tet values as a second pass over the tets would compute)
+template <bool P4>
+__global__ __launch_bounds__(kEThreads) void k_energy_pass2(const float *__restrict__ vol, int T, int pow_v, double *stats,
+                                                      double *part, float *out, int slot)
+{
+    const int b = blockIdx.y;
+    const float mean = (float)stats[b * 8 + 0];
+    double acc[2] = {0.0, 0.0};
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < T; t += gridDim.x * blockDim.x) {
+        const float d = vol[(size_t)b * T + t] - mean;
+        if (!P4 && pow_v == 1) {
+            acc[0] += (double)fabsf(d);                                          // :260
+            acc[1] += (double)(d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f));
+        } else {
+            acc[0] += (double)ipow_t<P4>(d, pow_v);                              // :262
+            acc[1] += (double)((float)pow_v * ipow_m1_t<P4>(d, pow_v));
+        }
+    }
+    if (!block_reduce_store<2>(acc, part, b, slot, 1)) return;
+    finish_energies(part, b, T, true, stats, out);
+    if (threadIdx.x == 0) atomicExch(&g_energy_tickets[slot][1][b], 0);
+}
+
+__global__ __launch_bounds__(64) void k_energy_final(double *part2, int T, double *stats, float *out)
+{
+    finish_energies(part2, blockIdx.x, T, false, stats, out);
+}
+
 // backward: grad_tet[b,t] = g_var * dvar/dtet + g_amips * damips/dtet + g_edge * dedge/dtet
+template <bool P4>
 __global__ __launch_bounds__(256) void k_energy_bwd(const float *__restrict__ tet, const float *__restrict__ inv_v, int T,
                                                     float scale, int pow_v, int pow_e, const double *__restrict__ stats,
                                                     const float *__restrict__ gout, float *grad_tet)
@@ -274,7 +341,7 @@ __global__ __launch_bounds__(256) void k_energy_bwd(const float *__restrict__ te
     {
         float a[3], bb[3], c[3];
         const float d = tet_volume(v, a, bb, c) - (float)stats[b * 8 + 0];
-        float dvar = pow_v == 1 ? (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) : (float)pow_v * ipow(d, pow_v - 1);
+        float dvar = (!P4 && pow_v == 1) ? (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) : (float)pow_v * ipow_m1_t<P4>(d, pow_v);
         dvar -= (float)stats[b * 8 + 4];                      // through mean_v
         // V = -(a . (b x c)) / 6 with a=A-D, b=B-D, c=C-D
         float bc[3], ca[3], ab[3];
@@ -291,7 +358,7 @@ __global__ __launch_bounds__(256) void k_energy_bwd(const float *__restrict__ te
         }
     }
     if (inv_v) tet_amips(v, inv_v + (size_t)t * 9, scale, g, ga / (float)T);
-    tet_edges(v, scale, pow_e, g, ge / (6.0f * (float)T));
+    tet_edges<P4>(v, scale, pow_e, g, ge / (6.0f * (float)T));
     float4 *dst = reinterpret_cast<float4 *>(grad_tet + ((size_t)b * T + t) * 12);
     dst[0] = make_float4(g[0], g[1], g[2], g[3]);
     dst[1] = make_float4(g[4], g[5], g[6], g[7]);
@@ -337,7 +404,12 @@ extern "C" int deftet_boundary_index_i64(const int64_t *face_fx3, const int64_t 
     return DEFTET_OK;
 }
 
-extern "C" size_t deftet_tet_energies_workspace_bytes(int B) { return (size_t)(B > 0 ? B : 0) * kEParts * 5 * 8 + 256; }
+// B * kEParts * 5 doubles of partial sums (+ with n_tet > 0: one float per tet, the saved volumes of the forward)
+extern "C" size_t deftet_tet_energies_workspace_bytes2(int B, int T)
+{
+    return align_up((size_t)(B > 0 ? B : 0) * kEParts * 5 * 8 + 256, 256) + align_up((size_t)(B > 0 ? B : 0) * (size_t)(T > 0 ? T : 0) * 4, 256);
+}
+extern "C" size_t deftet_tet_energies_workspace_bytes(int B) { return deftet_tet_energies_workspace_bytes2(B, 0); }
 
 // out f32 [B,3] = {volume_variance(pow_v), amips_energy (0 if inv_v == NULL), edge_length(pow_e)};
 // stats f64 [B,8] is kept by the caller for the backward.
@@ -347,13 +419,23 @@ extern "C" int deftet_tet_energies_fwd_f32(const float *tet, const float *inv_v,
     DEFTET_CHECK_ARG(B >= 0 && T > 0 && B <= 65535 && pow_v >= 1 && pow_e >= 1 && pow_v <= 16 && pow_e <= 16, "bad argument");
     if (B == 0) return DEFTET_OK;
     DEFTET_CHECK_ARG(tet && out && stats && ((uintptr_t)tet & 15) == 0, "null or misaligned pointer");
-    DEFTET_CHECK_ARG(workspace && ((uintptr_t)workspace & 255) == 0 && wsb >= deftet_tet_energies_workspace_bytes(B), "workspace");
+    DEFTET_CHECK_ARG(workspace && ((uintptr_t)workspace & 255) == 0 && wsb >= deftet_tet_energies_workspace_bytes2(B, T),
+                     "workspace null, misaligned or smaller than deftet_tet_energies_workspace_bytes2(B, T)");
     hipStream_t st = as_stream(stream_);
     double *part1 = static_cast<double *>(workspace), *part2 = part1 + (size_t)B * kEParts * 3;
-    DEFTET_LAUNCH(k_energy_pass1, dim3(kEParts, B), dim3(256), st, tet, inv_v, T, scale, pow_e, part1);
-    DEFTET_LAUNCH(k_energy_mean, dim3(B), dim3(64), st, part1, T, stats);
-    DEFTET_LAUNCH(k_energy_pass2, dim3(kEParts, B), dim3(256), st, tet, T, pow_v, stats, part2);
-    DEFTET_LAUNCH(k_energy_final, dim3(B), dim3(64), st, part2, T, stats, out);
+    float *vol = reinterpret_cast<float *>(static_cast<char *>(workspace) + deftet_tet_energies_workspace_bytes(B));
+    int slot = -1;                                                 // B <= kETicketShapes: two launches, each pass finishes its own reduction
+    if (B <= kETicketShapes) {
+        static std::atomic<unsigned> next{0};                      // a slot of tickets per forward in flight
+        slot = (int)(next.fetch_add(1, std::memory_order_relaxed) % kETicketSlots);
+    }
+    const bool p4 = pow_v == 4 && pow_e == 4;
+    if (p4) DEFTET_LAUNCH(k_energy_pass1<true>, dim3(kEParts, B), dim3(kEThreads), st, tet, inv_v, T, scale, pow_e, part1, vol, stats, slot);
+    else DEFTET_LAUNCH(k_energy_pass1<false>, dim3(kEParts, B), dim3(kEThreads), st, tet, inv_v, T, scale, pow_e, part1, vol, stats, slot);
+    if (slot < 0) DEFTET_LAUNCH(k_energy_mean, dim3(B), dim3(64), st, part1, T, stats);
+    if (p4) DEFTET_LAUNCH(k_energy_pass2<true>, dim3(kEParts, B), dim3(kEThreads), st, (const float *)vol, T, pow_v, stats, part2, out, slot);
+    else DEFTET_LAUNCH(k_energy_pass2<false>, dim3(kEParts, B), dim3(kEThreads), st, (const float *)vol, T, pow_v, stats, part2, out, slot);
+    if (slot < 0) DEFTET_LAUNCH(k_energy_final, dim3(B), dim3(64), st, part2, T, stats, out);
     return DEFTET_OK;
 }
 
@@ -364,7 +446,11 @@ extern "C" int deftet_tet_energies_bwd_f32(const float *tet, const float *inv_v,
     if (B == 0) return DEFTET_OK;
     DEFTET_CHECK_ARG(tet && stats && grad_out && grad_tet && ((uintptr_t)tet & 15) == 0 && ((uintptr_t)grad_tet & 15) == 0,
                      "null or misaligned pointer");
-    DEFTET_LAUNCH(k_energy_bwd, dim3((T + 255) / 256, B), dim3(256), as_stream(stream_), tet, inv_v, T, scale, pow_v, pow_e,
-                  stats, grad_out, grad_tet);
+    if (pow_v == 4 && pow_e == 4)
+        DEFTET_LAUNCH(k_energy_bwd<true>, dim3((T + 255) / 256, B), dim3(256), as_stream(stream_), tet, inv_v, T, scale, pow_v, pow_e,
+                      stats, grad_out, grad_tet);
+    else
+        DEFTET_LAUNCH(k_energy_bwd<false>, dim3((T + 255) / 256, B), dim3(256), as_stream(stream_), tet, inv_v, T, scale, pow_v, pow_e,
+                      stats, grad_out, grad_tet);
     return DEFTET_OK;
 }

@@ -751,7 +751,7 @@ class _TetEnergies(torch.autograd.Function):
         out = torch.empty(B, 3, device=dev, dtype=torch.float32)
         stats = torch.empty(B, 8, device=dev, dtype=torch.float64)
         with torch.cuda.device(dev):
-            ws = _lib.workspace(dev, lib.deftet_tet_energies_workspace_bytes(B))
+            ws = _lib.workspace(dev, lib.deftet_tet_energies_workspace_bytes2(B, T))
             _lib.check(lib.deftet_tet_energies_fwd_f32(_lib.ptr(tet), _lib.ptr(inv), _lib.ptr(out), _lib.ptr(stats), B, T,
                                                        int(pow_v), int(pow_e), float(scale), _lib.ptr(ws), ws.numel(),
                                                        _lib.current_stream(dev)), "deftet_tet_energies_fwd_f32")

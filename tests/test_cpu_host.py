@@ -358,5 +358,5 @@ def test_bench_self_launch_command(monkeypatch):
     assert 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
     assert cmd[-6:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"] and cmd[-7].endswith("bench.py")
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
-    # every BASELINE configuration has a workload definition
-    assert sorted(bench.CONFIGS) == [1, 2, 3, 4] and bench.CONFIGS[2]["res"] == 70 and bench.CONFIGS[2]["n_query"] == 100_000
+    # every BASELINE configuration has a workload definition (5 = the full geometry step, not a BASELINE entry)
+    assert sorted(bench.CONFIGS) == [1, 2, 3, 4, 5] and bench.CONFIGS[2]["res"] == 70 and bench.CONFIGS[2]["n_query"] == 100_000

@@ -171,3 +171,25 @@ def test_bench_self_launches_two_ranks(cuda):
     assert rec["n_gpus"] == 2 and rec["rccl_ranks"] == 2 and rec["steps"] == 3 and rec["value"] > 0
     assert rec["roofline"]["launches_timed"] == 3 and 0 < rec["roofline"]["frac"] < 1
     assert "cpu_baseline" not in rec                         # rank 0 at N=1 only
+
+
+def test_bench_eight_ranks_config3_shared_gpu(cuda):
+    """`python bench.py --gpus 8 --config 3` — BASELINE configs[3] as the driver launches it on an 8-GPU node (batch 64 =
+    8 shapes per rank) — through bench.py's own launcher with all eight ranks on this box's single GPU (collectives staged
+    over gloo): per-rank seeding, the LossGather flush inside the timed region, the per-rank timing fields and the
+    `rccl_ranks` field are exercised at N = 8."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DEFTET_BENCH_TEST_SHARED_GPU="1", OMP_NUM_THREADS="4")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--config", "3"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 8 and rec["rccl_ranks"] == 8 and rec["steps"] == 2 and rec["value"] > 0
+    assert rec["config"]["n_tet"] == 750000 and rec["config"]["batch_per_gpu"] == 8
+    by = rec["ms_per_step_by_rank"]
+    assert len(by["all"]) == 8 and by["min"] <= by["max"] and abs(by["max"] - rec["ms_per_step"]) < 1e-3

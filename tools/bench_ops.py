@@ -33,6 +33,28 @@ def gpu_time(fn, reps=5, warm=2):
     return float(np.median(ts))
 
 
+def gpu_time_events(fn, reps=20, warm=3):
+    """Device time per call: HIP events around `reps` back-to-back calls (no host sync in between), so launch and
+    synchronisation latency of a single call are not in the figure."""
+    for _ in range(warm):
+        fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps * 1e-3
+
+
+def roof(alg_bytes, seconds, bound):
+    """Roofline fields of a secondary line: the HBM floor of the algorithmic bytes at 8 TB/s, and what fraction of the
+    measured time that floor is; `bound` says what the kernel is limited by when that is not HBM."""
+    floor = alg_bytes / 8e12
+    return dict(algorithmic_mb=round(alg_bytes / 1e6, 2), hbm_floor_ms=round(floor * 1e3, 4), roofline_frac=round(floor / seconds, 4), bound=bound)
+
+
 def cpu_time(fn):
     t0 = time.perf_counter()
     fn()
@@ -77,11 +99,13 @@ def main():
     emit(op="face_edge_adj", n_face=F, gpu_ms=round(tg * 1e3, 3), gpu_brute_ms=round(tgb * 1e3, 3), cpu_ms=round(tc * 1e3, 1), cpu_kind="port (extrapolated from %d faces, O(F^2))" % sub,
          cpu_cores=1, pairs_per_s=round(F * F / tg / 1e9, 2), unit="G face pairs/s")
     tg = gpu_time(lambda: hip_ops.tri_dist_fwd(gt_d, face_d[None], nfb), reps=3)
+    tge = gpu_time_events(lambda: hip_ops.tri_dist_fwd(gt_d, face_d[None], nfb))
     subp = 500
     tc = cpu_time(lambda: O.tri_dist_fwd(gt[None, :subp], face[None], np.array([F], np.float32))) * (100000 / subp)
     tbr = gpu_time(lambda: hip_ops.tri_dist_fwd(gt_d, face_d[None], nfb, brute=True), reps=3)
     emit(op="tri_dist_fwd", n_face=F, n_point=100000, gpu_ms=round(tg * 1e3, 3), gpu_brute_ms=round(tbr * 1e3, 3), cpu_ms=round(tc * 1e3, 1),
-         cpu_kind="port (extrapolated from %d points)" % subp, cpu_cores=1, pairs_per_s=round(F * 1e5 / tg / 1e9, 2), unit="G point-triangle pairs/s")
+         cpu_kind="port (extrapolated from %d points)" % subp, cpu_cores=1, pairs_per_s=round(F * 1e5 / tg / 1e9, 2), unit="G point-triangle pairs/s",
+         device_ms=round(tge * 1e3, 4), **roof(100000 * (12 + 8) + F * 36, tge, "valu (nearest-triangle search: ~60 flop per candidate pair, tens of candidates per point)"))
     far_d = gt_d * 1.3                                                # early training: the cloud 30 % off the predicted surface
     tgf = gpu_time(lambda: hip_ops.tri_dist_fwd(far_d, face_d[None], nfb), reps=3)
     emit(op="tri_dist_fwd", points="30 % outside the surface (far path)", n_face=F, n_point=100000, gpu_ms=round(tgf * 1e3, 3),
@@ -89,7 +113,9 @@ def main():
     dd, ff = hip_ops.tri_dist_fwd(gt_d, face_d[None], nfb)
     gg = torch.ones_like(dd)
     tg = gpu_time(lambda: hip_ops.tri_dist_bwd(gt_d, face_d[None], ff, gg))
-    emit(op="tri_dist_bwd", n_face=F, n_point=100000, gpu_ms=round(tg * 1e3, 3))
+    tge = gpu_time_events(lambda: hip_ops.tri_dist_bwd(gt_d, face_d[None], ff, gg))
+    emit(op="tri_dist_bwd", n_face=F, n_point=100000, gpu_ms=round(tg * 1e3, 3), device_ms=round(tge * 1e3, 4),
+         **roof(100000 * (12 + 4 + 4 + 12) + F * (36 + 36), tge, "hbm + float atomics on the face gradients"))
     nq = 20 * F
     q_d = torch.from_numpy(rng.uniform(-0.3, 0.3, (1, nq, 3)).astype(np.float32)).to(dev)
     tg = gpu_time(lambda: hip_ops.nn_index(q_d, gt_d), reps=3)
@@ -105,8 +131,10 @@ def main():
     qs = surface_losses.sample_on_faces(face_d[None], 20).reshape(1, -1, 3).contiguous()
     tg2 = gpu_time(lambda: hip_ops.nn_index(qs, gt_d), reps=3)
     tb2 = gpu_time(lambda: hip_ops.nn_index(qs, gt_d, brute=True), reps=3)
+    tge = gpu_time_events(lambda: hip_ops.nn_index(qs, gt_d))
     emit(op="nn_index", queries="20 samples per boundary face (training distribution)", n_query=int(qs.shape[1]), n_point=100000,
-         gpu_ms=round(tg2 * 1e3, 3), gpu_brute_ms=round(tb2 * 1e3, 3),
+         gpu_ms=round(tg2 * 1e3, 3), gpu_brute_ms=round(tb2 * 1e3, 3), device_ms=round(tge * 1e3, 4),
+         **roof(int(qs.shape[1]) * (12 + 8) + 100000 * 12, tge, "valu + launch count (cell sort of the cloud, then a ring search per query)"),
          pairs_per_s=round(qs.shape[1] * 1e5 / tg2 / 1e9, 2), unit="G nominal distance evals/s")
 
     # rasterizer, BASELINE configs[4]
@@ -209,8 +237,11 @@ def main():
         return torch.autograd.grad((torch.stack([vv, am, el], -1) * gsel).sum(), tete)
 
     tf_, tt_ = gpu_time(fused, reps=10), gpu_time(torch_ref, reps=5)
-    emit(op="tet_energies fwd+bwd", res=res, batch=Be, n_tet=T, gpu_ms=round(tf_ * 1e3, 3), torch_same_gpu_ms=round(tt_ * 1e3, 3),
-         speedup_vs_torch=round(tt_ / tf_, 1), algorithmic_mb=round(Be * T * 96 / 1e6, 1))
+    tfe = gpu_time_events(fused, reps=30)
+    # forward reads the 48-byte record once (+ 4 B saved volume written and read back); backward reads it and writes 48 B
+    emit(op="tet_energies fwd+bwd", res=res, batch=Be, n_tet=T, gpu_ms=round(tf_ * 1e3, 3), device_ms=round(tfe * 1e3, 4),
+         torch_same_gpu_ms=round(tt_ * 1e3, 3), speedup_vs_torch=round(tt_ / tf_, 1),
+         **roof(Be * T * (48 + 48 + 48) + T * 36 * 2, tfe, "hbm"))
 
     # ---- A1 forward: the binned path against the brute-force HIP formulation (the algorithmic equivalent of the
     # reference kernel: every query meets every tet in index order), BASELINE configs[2]

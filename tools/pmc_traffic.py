@@ -34,9 +34,17 @@ def per_kernel(d, counter):
     return {k: tot[k] / cnt[k] for k in tot}
 
 
+def source_sha1():
+    """sha1 of the kernel source the counters belong to: bench.py prints the traffic figure only while this still matches."""
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    return hashlib.sha1(open(os.path.join(root, "deftet_amd", "csrc", "point_in_tet.hip"), "rb").read()).hexdigest()
+
+
 def main(fetch_dir, write_dir):
     f, w = per_kernel(fetch_dir, "FETCH_SIZE"), per_kernel(write_dir, "WRITE_SIZE")
-    out = {"note": __doc__.split("Corrections", 1)[1].strip().replace("\n", " "), "per_kernel": {}}
+    out = {"note": __doc__.split("Corrections", 1)[1].strip().replace("\n", " "), "kernel_source_sha1": source_sha1(),
+           "commit": os.environ.get("DEFTET_COMMIT", "(fill in: git rev-parse HEAD of the measured tree)"), "per_kernel": {}}
     for k in sorted(set(f) | set(w)):
         if not k.startswith("deftet::"):
             continue
