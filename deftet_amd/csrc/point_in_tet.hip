@@ -33,10 +33,6 @@
 
 #include "common.hpp"
 
-#ifndef PIT_DBG
-#define PIT_DBG 0      // timing experiments only (tools/probes): values != 0 drop one piece of the query sort
-#endif
-
 namespace deftet {
 namespace pit {
 

@@ -27,5 +27,7 @@ for p in "${passes[@]}"; do
     i=$((i+1))
 done
 python $R/tools/pmc_summary.py "${dirs[@]}" --match "$match" > "$R/$out"
+# PMC_TRAFFIC_OUT=<file>: also the per-kernel HBM traffic table bench.py reads (FETCH_SIZE / WRITE_SIZE passes, all kernels)
+if [ -n "${PMC_TRAFFIC_OUT:-}" ]; then python $R/tools/pmc_traffic.py "${dirs[4]}" "${dirs[5]}" > "$R/$PMC_TRAFFIC_OUT"; fi
 for d in "${dirs[@]}"; do rm -rf "$d"; done      # the raw per-dispatch CSVs are large; the summary is what is kept
 echo "wrote $out"

@@ -2,10 +2,10 @@
 # scratch GPU script of the current experiment (overwritten freely)
 set -u
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
-O=gpurun_out/r3f; mkdir -p $O
-timeout 600 python -m pytest tests -q -m gpu -x -k "energ or tet_ops or pipeline or deftet_module" 2>&1 | tail -3
-timeout 300 python tools/probes/energy_probe.py | tee $O/energy_probe.json
-timeout 300 python tools/probes/energy_probe.py --sets 1 | tee $O/energy_probe_warm.json
-timeout 600 rocprofv3 --kernel-trace --stats -d $O/energy_prof -o e --output-format csv -- python tools/probes/energy_probe.py > /dev/null 2>&1
-find $O/energy_prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/energy_kernel_stats.csv; rm -rf $O/energy_prof
-head -4 $O/energy_kernel_stats.csv | cut -c1-200
+O=gpurun_out/r3g; mkdir -p $O
+R=$GRAFT_REPO_ROOT
+PMC_TRAFFIC_OUT=$O/pmc_traffic.json bash tools/pmc_run.sh $O/pmc_traversal.json k_tet_scan_slab -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs --no-bandwidth-probe
+cd $R
+cp $O/pmc_traffic.json profiles/r03_pmc_traffic.json
+timeout 400 python bench.py > $O/bench_line.json 2> $O/bench_err.txt; cut -c1-1500 $O/bench_line.json
+cat $O/pmc_traversal.json | head -60
