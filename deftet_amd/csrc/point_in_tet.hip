@@ -801,6 +801,20 @@ __device__ __forceinline__ T *uniform_ptr(T *p)
     return reinterpret_cast<T *>(((unsigned long long)hi << 32) | lo);
 }
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// streaming accesses (each byte touched once per launch): the nt hint keeps them from evicting the per-query arrays the
+// gathers of k_finalize / k_bary_bwd_hits live on in the 4 MiB L2 of each XCD
+__device__ __forceinline__ void stream_store(float4 *p, const float4 v)
+{
+    const f32x4 x = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(x, reinterpret_cast<f32x4 *>(p));
+}
+__device__ __forceinline__ void stream_store(float *p, float v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ int4 stream_load(const int4 *p)
+{
+    const i32x4 x = __builtin_nontemporal_load(reinterpret_cast<const i32x4 *>(p));
+    return make_int4(x.x, x.y, x.z, x.w);
+}
 __device__ __forceinline__ void store_b128_off(void *base, unsigned byte_off, int x, int y, int z, int w)
 {
     const i32x4 v = {x, y, z, w};
@@ -1158,8 +1172,8 @@ __global__ __launch_bounds__(256) void k_finalize(const float *__restrict__ tet,
         }
     }
     const bool hit = r != kMiss;
-    cond[i] = hit ? (float)r : -1.0f;                               // :177, :149
-    if (occ) occ[i] = pred[(size_t)b * T + (hit ? r : 0)];          // paste_occ: misses alias tet 0 (deftet.py:133-135)
+    stream_store(cond + i, hit ? (float)r : -1.0f);                 // :177, :149
+    if (occ) stream_store(occ + i, pred[(size_t)b * T + (hit ? r : 0)]);   // paste_occ: misses alias tet 0 (deftet.py:133-135)
     if (hits && hit) {
         // is this hit in its tet's record?  (not if the tet overflowed / is irregular, or if the
         // query took the irregular-query side path, which records nothing)
@@ -1203,7 +1217,7 @@ __global__ __launch_bounds__(256) void k_finalize(const float *__restrict__ tet,
         wq.z = triple(vap, vad, vab) * v6;
         wq.w = triple(vap, vab, vac) * v6;
     }
-    reinterpret_cast<float4 *>(bary)[i] = wq;
+    stream_store(reinterpret_cast<float4 *>(bary) + i, wq);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1534,7 +1548,7 @@ __global__ __launch_bounds__(256) void k_bary_bwd_hits(const float *__restrict__
 #pragma unroll
     for (int k = 0; k < 12; ++k) acc[k] = 0.f;
     float gp = 0.f;
-    const int4 h = live ? hits[(size_t)b * T + t] : make_int4(-1, -1, -1, -1);
+    const int4 h = live ? stream_load(hits + (size_t)b * T + t) : make_int4(-1, -1, -1, -1);
     if (h.x >= 0 && h.w != kHitOverflow) {                         // slots fill in order: x < 0 means no accepted query
         TetGrad g;
         tet_grad_setup(tet, (size_t)b * T + t, g);
@@ -1602,7 +1616,7 @@ __global__ __launch_bounds__(256) void k_bary_bwd_hits(const float *__restrict__
     }
     if (live) {
         const bool deferred = grad_pred && t == 0;                 // tet 0 of the shape: written by the ticket winner below
-        if (grad_pred && !deferred) grad_pred[(size_t)b * T + t] = accumulate ? grad_pred[(size_t)b * T + t] + gp : gp;
+        if (grad_pred && !deferred) stream_store(grad_pred + (size_t)b * T + t, accumulate ? grad_pred[(size_t)b * T + t] + gp : gp);
         float4 *dst = reinterpret_cast<float4 *>(grad_tet + ((size_t)b * T + t) * 12);
         float4 o0 = make_float4(acc[0], acc[1], acc[2], acc[3]), o1 = make_float4(acc[4], acc[5], acc[6], acc[7]),
                o2 = make_float4(acc[8], acc[9], acc[10], acc[11]);
@@ -1612,7 +1626,9 @@ __global__ __launch_bounds__(256) void k_bary_bwd_hits(const float *__restrict__
             o1.x += p1.x; o1.y += p1.y; o1.z += p1.z; o1.w += p1.w;
             o2.x += p2.x; o2.y += p2.y; o2.z += p2.z; o2.w += p2.w;
         }
-        dst[0] = o0; dst[1] = o1; dst[2] = o2;
+        stream_store(dst, o0);
+        stream_store(dst + 1, o1);
+        stream_store(dst + 2, o2);
     }
     if (!side) return;
     // miss-sum reduction across the side workgroups: partials and ticket live at the memory side (RMW atomics), so no
