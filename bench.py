@@ -298,6 +298,42 @@ def measure_bandwidth(device):
     return out
 
 
+def graph_replay(wl, steps, warmup=3):
+    """The same K steps replayed from hipGraphs (one captured step per input set; torch.cuda.CUDAGraph is a hipGraph on
+    ROCm): what the launch path costs is then out of the figure.  Reported beside the headline, never as `value`.
+    Returns (ms_per_step, None) or (None, reason)."""
+    if wl.world > 1 or wl.pipeline:
+        return None, "single-GPU, unpipelined steps only"
+    try:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for k in range(len(wl.sets)):                # library workspaces reach their final size outside the capture
+                wl.step(k)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graphs, keep = [], []
+        for k in range(len(wl.sets)):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                wl.step(k)
+            graphs.append(g)
+            keep.append(wl.last)                         # the graph's output buffers
+        for i in range(warmup):
+            graphs[i % len(graphs)].replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            graphs[i % len(graphs)].replay()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        del graphs, keep
+        return round(ms, 4), None
+    except Exception as e:                               # a capture the runtime refuses is reported, not fatal
+        torch.cuda.synchronize()
+        return None, "%s: %s" % (type(e).__name__, str(e)[:200])
+
+
 def cpu_baseline(wl):
     """Oracle (CPU restatement, kind="port") on a bounded sample of the same workload."""
     from oracle import oracle as O
@@ -467,6 +503,10 @@ def main():
                 line["ms_per_step_%s_median" % key] = round(statistics.median(ps2), 4)
                 line["avg_launch_ms_%s" % key] = round(km2 / max(kc2, 1), 5)
                 wl.pipeline = not wl.pipeline
+                gms, why = graph_replay(wl, args.steps)
+                line["ms_per_step_hipgraph"] = gms
+                if why:
+                    line["hipgraph_note"] = why
             if not args.no_cpu_baseline and isinstance(wl, PitWorkload):
                 line["cpu_baseline"] = cpu_baseline(wl)
             if not args.no_other_configs:
@@ -481,6 +521,8 @@ def main():
                     rec = summarize(w2, e, ps, km, kc, max(5, args.steps // 2), 1, peak)
                     entry = {"config_id": cid, "config": w2.describe()["workload"], "value": rec["value"], "unit": rec["unit"],
                              "ms_per_step": rec["ms_per_step"], "ms_per_step_median": rec["ms_per_step_median"]}
+                    if isinstance(w2, PitWorkload):
+                        entry["ms_per_step_hipgraph"] = graph_replay(w2, max(5, args.steps // 2))[0]
                     if w2.dominant_bytes > 0:
                         entry["roofline"] = {k: rec["roofline"][k] for k in ("kernel", "achieved", "frac", "avg_launch_ms", "whole_step")}
                     else:
