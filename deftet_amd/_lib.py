@@ -77,6 +77,8 @@ SIGNATURES = {
     "deftet_tri_dist_workspace_bytes": (_sz, [_i, _i, _i]),
     "deftet_tri_dist_fwd_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "deftet_tri_dist_bwd_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "deftet_tri_dist_fwd_order_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "deftet_tri_dist_bwd_order_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "deftet_nn_index_workspace_bytes": (_sz, [_i, _i, _i]),
     "deftet_nn_index_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "deftet_sparse_render_workspace_bytes": (_sz, [_i, _i, _i, _i]),

@@ -434,32 +434,45 @@ def normal_consistency(tri_bxfx3x3, adj_bxfxm, n_face_dev):
     return _NormalConsistency.apply(_f32c(tri_bxfx3x3), _f32c(adj_bxfxm), n_face_dev.to(torch.int32).contiguous())
 
 
-def tri_dist_fwd(pts_bxpx3, face_bxfx3x3, n_face_b, brute=False):
+def tri_dist_fwd(pts_bxpx3, face_bxfx3x3, n_face_b, brute=False, want_order=False):
     """(closest_d, closest_f) f32 [B,P,1] — tet_analytic_distance_for.cu:256-307.
-    brute=True selects the streaming scan over all faces (kept for cross-checks)."""
+    brute=True selects the streaming scan over all faces (kept for cross-checks).
+    want_order=True also returns the int32 [B,P] order in which the grid search walked the points (None when the grid
+    search did not run: brute, or no faces) — `tri_dist_bwd(order=...)` groups its atomics with it."""
     _lib.require_gpu(pts_bxpx3, face_bxfx3x3, n_face_b)
     lib = _lib.load()
     pts, face, nfb = _f32c(pts_bxpx3), _f32c(face_bxfx3x3), _f32c(n_face_b)
     B, P = pts.shape[0], pts.shape[1]
     d = torch.zeros(B, P, 1, device=pts.device, dtype=torch.float32)                    # utils.py:44-45
     f = torch.zeros(B, P, 1, device=pts.device, dtype=torch.float32)
+    order = None
+    if want_order and not brute and face.shape[1] > 0 and B * P > 0:
+        order = torch.empty(B, P, device=pts.device, dtype=torch.int32)
     with torch.cuda.device(pts.device):
         ws = None if brute else _lib.workspace(pts.device, lib.deftet_tri_dist_workspace_bytes(B, P, face.shape[1]))
-        _lib.check(lib.deftet_tri_dist_fwd_f32(_lib.ptr(pts), _lib.ptr(face), _lib.ptr(nfb), _lib.ptr(d), _lib.ptr(f), B, P,
-                                               face.shape[1], _lib.ptr(ws), ws.numel() if ws is not None else 0,
-                                               _lib.current_stream(pts.device)), "deftet_tri_dist_fwd_f32")
-    return d, f
+        _lib.check(lib.deftet_tri_dist_fwd_order_f32(_lib.ptr(pts), _lib.ptr(face), _lib.ptr(nfb), _lib.ptr(d), _lib.ptr(f),
+                                                     _lib.ptr(order), B, P, face.shape[1], _lib.ptr(ws),
+                                                     ws.numel() if ws is not None else 0, _lib.current_stream(pts.device)),
+                   "deftet_tri_dist_fwd_order_f32")
+    return (d, f, order) if want_order else (d, f)
 
 
-def tri_dist_bwd(pts_bxpx3, face_bxfx3x3, closest_f, dl_dd, deterministic=False):
+def tri_dist_bwd(pts_bxpx3, face_bxfx3x3, closest_f, dl_dd, deterministic=False, order=None):
+    """dL/dface f32 [B,F,3,3] — tet_analytic_distance_back.cu:591-715.  order: the forward's point order (see
+    tri_dist_fwd); with it the atomic path adds up a wavefront's contributions per distinct face first."""
     _lib.require_gpu(pts_bxpx3, face_bxfx3x3, closest_f, dl_dd)
     lib = _lib.load()
     pts, face, cf, g = _f32c(pts_bxpx3), _f32c(face_bxfx3x3), _f32c(closest_f), _f32c(dl_dd)
     B, P, F = pts.shape[0], pts.shape[1], face.shape[1]
     out = torch.zeros(B, F, 3, 3, device=pts.device, dtype=torch.float32)               # utils.py:65
     with torch.cuda.device(pts.device):
-        _lib.check(lib.deftet_tri_dist_bwd_f32(_lib.ptr(pts), _lib.ptr(face), _lib.ptr(cf), _lib.ptr(g), _lib.ptr(out), B, P, F,
-                                               int(deterministic), _lib.current_stream(pts.device)), "deftet_tri_dist_bwd_f32")
+        if order is not None and not deterministic:
+            _lib.check(lib.deftet_tri_dist_bwd_order_f32(_lib.ptr(pts), _lib.ptr(face), _lib.ptr(cf), _lib.ptr(g),
+                                                         _lib.ptr(order.contiguous()), _lib.ptr(out), B, P, F,
+                                                         _lib.current_stream(pts.device)), "deftet_tri_dist_bwd_order_f32")
+        else:
+            _lib.check(lib.deftet_tri_dist_bwd_f32(_lib.ptr(pts), _lib.ptr(face), _lib.ptr(cf), _lib.ptr(g), _lib.ptr(out), B, P, F,
+                                                   int(deterministic), _lib.current_stream(pts.device)), "deftet_tri_dist_bwd_f32")
     return out
 
 

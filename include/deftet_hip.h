@@ -332,6 +332,16 @@ size_t deftet_tri_dist_workspace_bytes(int n_batch, int n_point, int n_max_face)
 int deftet_tri_dist_fwd_f32(const float *pts_bxpx3, const float *face_bxfx3x3, const float *n_face_b,
                             float *closest_d, float *closest_f, int n_batch, int n_point, int n_max_face,
                             void *workspace, size_t workspace_bytes, void *stream);
+/* The same forward, also handing out the order in which the grid search walked the points of every shape (int32 [B,P],
+ * sorted by grid cell; NULL = not wanted; needs a workspace and n_max_face > 0), and the atomic backward that walks the
+ * points in that order: neighbouring points share their closest faces, so a wavefront adds their contributions up first
+ * and issues one set of atomics per distinct face (same sums up to the order of the fp32 additions). */
+int deftet_tri_dist_fwd_order_f32(const float *pts_bxpx3, const float *face_bxfx3x3, const float *n_face_b,
+                                  float *closest_d, float *closest_f, int32_t *order_bxp, int n_batch, int n_point,
+                                  int n_max_face, void *workspace, size_t workspace_bytes, void *stream);
+int deftet_tri_dist_bwd_order_f32(const float *pts_bxpx3, const float *face_bxfx3x3, const float *closest_f,
+                                  const float *dl_dclosest_d, const int32_t *order_bxp, float *dldface, int n_batch,
+                                  int n_point, int n_face, void *stream);
 /* dldface f32 [B,F,3,3] accumulates (zeroed by the wrapper, utils.py:65).  deterministic != 0:
  * contributions are reduced in point order per face instead of by floating-point atomics. */
 int deftet_tri_dist_bwd_f32(const float *pts_bxpx3, const float *face_bxfx3x3, const float *closest_f,

@@ -571,3 +571,39 @@ def test_a8_semantic_pin_integer_edge_adjacency(cuda, oracle):
     for i in range(f.shape[0]):
         row = adj[i][adj[i] >= 0].tolist()
         assert row == sorted(want[i]), i
+
+
+
+def test_tri_dist_backward_with_forward_order_matches_atomic_and_sorted_paths(cuda, oracle):
+    """The grouped backward (atomics per distinct face of a wavefront, points walked in the forward's grid order) gives
+    the same face gradient as the per-point atomic path and the deterministic sorted path, up to fp32 summation order."""
+    from deftet_amd import hip_ops
+    radii = [0.3, 0.22, 0.38]
+    v, faces = _sphere_surfaces(cuda, oracle, radii, res=24)
+    Fmax = max(f.shape[0] for f in faces)
+    face = torch.zeros(len(faces), Fmax, 3, 3, device=cuda)
+    for b, f in enumerate(faces):
+        face[b, : f.shape[0]] = v[b][f]
+    nfb = torch.tensor([float(f.shape[0]) for f in faces], device=cuda)
+    rng = np.random.default_rng(77)
+    d3 = rng.standard_normal((len(radii), 20000, 3))
+    pts = torch.from_numpy((d3 / np.linalg.norm(d3, axis=2, keepdims=True) * np.array(radii)[:, None, None]).astype(np.float32)).to(cuda)
+    d, f, order = hip_ops.tri_dist_fwd(pts, face, nfb, want_order=True)
+    assert order is not None and order.dtype == torch.int32 and order.shape == pts.shape[:2]
+    srt = torch.sort(order.long(), dim=1).values                       # a permutation of the points of every shape
+    assert torch.equal(srt, torch.arange(pts.shape[1], device=cuda).expand_as(srt))
+    d2, f2 = hip_ops.tri_dist_fwd(pts, face, nfb)
+    assert torch.equal(d, d2) and torch.equal(f, f2)
+    g = torch.rand_like(d)
+    a = hip_ops.tri_dist_bwd(pts, face, f, g)
+    s = hip_ops.tri_dist_bwd(pts, face, f, g, deterministic=True)
+    o = hip_ops.tri_dist_bwd(pts, face, f, g, order=order)
+    scale = s.abs().max().item()
+    assert scale > 0
+    assert (o - s).abs().max().item() <= 2e-5 * scale and (a - s).abs().max().item() <= 2e-5 * scale
+    # through the reference-shaped autograd function (which asks for the order when the faces need a gradient)
+    from deftet_amd.layers.DefTet.tet_analytic_distance_batch.utils import tet_analytic_distance_f_batch
+    fr = face.clone().requires_grad_(True)
+    dd, _ = tet_analytic_distance_f_batch(pts, fr, nfb)
+    (dd * g).sum().backward()
+    assert (fr.grad - s).abs().max().item() <= 2e-5 * scale
