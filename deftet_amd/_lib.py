@@ -77,6 +77,9 @@ SIGNATURES = {
     "deftet_tri_dist_workspace_bytes": (_sz, [_i, _i, _i]),
     "deftet_tri_dist_fwd_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "deftet_tri_dist_bwd_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "deftet_face_samples_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "deftet_chamfer_fwd_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "deftet_chamfer_bwd_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "deftet_tri_dist_fwd_order_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "deftet_tri_dist_bwd_order_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "deftet_nn_index_workspace_bytes": (_sz, [_i, _i, _i]),

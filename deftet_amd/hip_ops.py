@@ -398,6 +398,53 @@ def nn_index_ragged(queries_bxnx3, points_bxmx3, n_query, brute=False):
     return out
 
 
+class _ChamferToCloud(torch.autograd.Function):
+    """sum over the valid samples of sqrt(|sample - NN_gt(sample)|^2 + 1e-10), per shape; samples = per_face area-uniform
+    random points per face.  Gradient to `tri` only (the cloud is data)."""
+
+    @staticmethod
+    def forward(ctx, tri, gt, counts, per_face, generator):
+        _lib.require_gpu(tri, gt)
+        lib = _lib.load()
+        tri, gt = _f32c(tri), _f32c(gt)
+        B, F, M, K = tri.shape[0], tri.shape[1], gt.shape[1], int(per_face)
+        dev = tri.device
+        r = torch.rand(2, B, F, K, device=dev, generator=generator)
+        samples = torch.empty(B, F * K, 3, device=dev, dtype=torch.float32)
+        st = _lib.current_stream(dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.deftet_face_samples_f32(_lib.ptr(tri), _lib.ptr(r), _lib.ptr(samples), B, F, K, st), "deftet_face_samples_f32")
+        n_valid = [int(c) * K for c in counts]
+        idx = nn_index_ragged(samples, gt, n_valid)
+        nv = torch.tensor(n_valid, device=dev, dtype=torch.int32)
+        d = torch.empty(B, F * K, device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            _lib.check(lib.deftet_chamfer_fwd_f32(_lib.ptr(samples), _lib.ptr(gt), _lib.ptr(idx), _lib.ptr(nv), _lib.ptr(d), B, F * K, M, st),
+                       "deftet_chamfer_fwd_f32")
+        ctx.save_for_backward(samples, gt, idx, nv, d, r)
+        ctx.dims = (B, F, K, M)
+        return rowdot(d)
+
+    @staticmethod
+    def backward(ctx, grad_sum):
+        samples, gt, idx, nv, d, r = ctx.saved_tensors
+        B, F, K, M = ctx.dims
+        lib = _lib.load()
+        g = _f32c(grad_sum)
+        grad_tri = torch.empty(B, F, 3, 3, device=samples.device, dtype=torch.float32)
+        with torch.cuda.device(samples.device):
+            _lib.check(lib.deftet_chamfer_bwd_f32(_lib.ptr(samples), _lib.ptr(gt), _lib.ptr(idx), _lib.ptr(nv), _lib.ptr(d), _lib.ptr(r),
+                                                  _lib.ptr(g), _lib.ptr(grad_tri), B, F, K, M, _lib.current_stream(samples.device)),
+                       "deftet_chamfer_bwd_f32")
+        return grad_tri, None, None, None, None
+
+
+def chamfer_to_cloud(tri_bxfx3x3, gt_bxmx3, counts, per_face=20, generator=None):
+    """f32 [B]: SUM over shape b's first counts[b] * per_face samples (per_face random points on each of its first
+    counts[b] faces) of their distance to the nearest ground-truth point — differentiable w.r.t. tri."""
+    return _ChamferToCloud.apply(tri_bxfx3x3, gt_bxmx3, counts, per_face, generator)
+
+
 class _NormalConsistency(torch.autograd.Function):
     @staticmethod
     def forward(ctx, tri, adj, n_face):

@@ -119,7 +119,6 @@ def surface_terms_batched(vertices_bxnx3, boundary_list, gt_points_bxmx3, per_fa
         return one, one.clone(), one.clone()
     faces = torch.nn.utils.rnn.pad_sequence([f.long() for f in boundary_list], batch_first=True)      # [B,F_max,3], zeros beyond F_b
     n_face = torch.tensor(counts, device=dev)
-    face_ok = torch.arange(f_max, device=dev)[None, :] < n_face[:, None]                           # [B,F_max]
     empty = n_face == 0
     tri = corners(vertices_bxnx3, faces)
     # normal consistency (A8 table + one fused launch per direction)
@@ -128,13 +127,9 @@ def surface_terms_batched(vertices_bxnx3, boundary_list, gt_points_bxmx3, per_fa
     normal = hip_ops.normal_consistency(tri, adj, n_face)
     # chamfer: predicted samples -> ground-truth cloud (A10)
     gt = gt_points_bxmx3.reshape(B, -1, 3)
-    samples = sample_on_faces(tri, per_face, generator).reshape(B, -1, 3)                              # first F_b * per_face rows valid
-    with torch.no_grad():
-        idx = hip_ops.nn_index_ragged(samples, gt, [c * per_face for c in counts]).long()
-    near = torch.gather(gt, 1, idx[..., None].expand(-1, -1, 3))
-    sample_ok = face_ok[:, :, None].expand(-1, -1, per_face).reshape(B, -1)
-    d = torch.sqrt(((samples - near) ** 2).sum(-1) + SQRT_EPS)
-    chamfer = (d * sample_ok).sum(-1) / (n_face * per_face).clamp(min=1)
+    # (sample placement, distance to the nearest cloud point and the gradient back to the corners: three HIP launches
+    # around the A10 search instead of ~45 elementwise ones)
+    chamfer = hip_ops.chamfer_to_cloud(tri, gt, counts, per_face, generator) / (n_face * per_face).clamp(min=1)
     # analytic: ground-truth cloud -> predicted surface (A9)
     d2, _ = tet_analytic_distance_f_batch(gt, tri, n_face.float())
     d2 = torch.where(empty[:, None, None], torch.zeros_like(d2), d2)

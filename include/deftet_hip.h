@@ -324,6 +324,21 @@ int deftet_normal_consistency_bwd_f32(const float *tri_bxfx3x3, const float *adj
                                       float *acc_bxfx3, int n_batch, int n_face_max, int n_max_nei, void *stream);
 
 /* ---------------------------------------------------------------------------------
+ * Chamfer term of the surface loss (layers/DefTet/deftet.py:174-177 with utils/mesh_utils.py:290-299, :360-374): n_per_face
+ * area-uniform samples per predicted face, each measured against its nearest ground-truth point (A10 finds the index).
+ *   deftet_face_samples_f32  samples f32 [B, F*K, 3] from tri f32 [B,F,3,3] and uniform numbers r f32 [2,B,F,K]
+ *                            (row f*K + j = (1-s) a + s (1-r1) b + s r1 c, s = sqrt(r0): the square-root warp)
+ *   deftet_chamfer_fwd_f32   d f32 [B,N] = sqrt(|sample - gt[idx]|^2 + 1e-10) for the first n_valid[b] rows, 0 beyond
+ *   deftet_chamfer_bwd_f32   grad_tri f32 [B,F,3,3] for dL/d(sum_rows d)[b] = gscale[b] (one lane per face, no atomics) */
+int deftet_face_samples_f32(const float *tri_bxfx3x3, const float *r_2xbxfxk, float *samples_bxnx3, int n_batch, int n_face,
+                            int n_per_face, void *stream);
+int deftet_chamfer_fwd_f32(const float *samples_bxnx3, const float *gt_bxmx3, const int32_t *idx_bxn, const int32_t *n_valid_b,
+                           float *d_bxn, int n_batch, int n_sample, int n_point, void *stream);
+int deftet_chamfer_bwd_f32(const float *samples_bxnx3, const float *gt_bxmx3, const int32_t *idx_bxn, const int32_t *n_valid_b,
+                           const float *d_bxn, const float *r_2xbxfxk, const float *gscale_b, float *grad_tri_bxfx3x3,
+                           int n_batch, int n_face, int n_per_face, int n_point, void *stream);
+
+/* ---------------------------------------------------------------------------------
  * A9  point -> triangle-soup squared distance
  * replaces layers/DefTet/tet_analytic_distance_batch/tet_analytic_distance.cpp ->
  *          tet_analytic_distance_for.cu:256-334 / tet_analytic_distance_back.cu:591-715 */

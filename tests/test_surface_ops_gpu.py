@@ -607,3 +607,39 @@ def test_tri_dist_backward_with_forward_order_matches_atomic_and_sorted_paths(cu
     dd, _ = tet_analytic_distance_f_batch(pts, fr, nfb)
     (dd * g).sum().backward()
     assert (fr.grad - s).abs().max().item() <= 2e-5 * scale
+
+
+def test_chamfer_to_cloud_matches_the_torch_composition(cuda, oracle):
+    """hip_ops.chamfer_to_cloud (sample placement + distance + gradient as three HIP launches around A10) == the same
+    quantity written with torch ops on the same random numbers: sample_on_faces -> nn_index -> gather -> sqrt -> masked
+    sum, value and gradient w.r.t. the corners (fp64 autograd of the torch expression as the gradient reference)."""
+    from deftet_amd import hip_ops
+    from deftet_amd import surface_losses as SL
+    radii = [0.3, 0.22, 0.0, 0.38]                                    # one empty surface
+    v, faces = _sphere_surfaces(cuda, oracle, radii, res=16)
+    counts = [int(f.shape[0]) for f in faces]
+    Fmax, K, B = max(counts), 7, len(faces)
+    idxs = torch.nn.utils.rnn.pad_sequence([f.long() for f in faces], batch_first=True)
+    tri = SL.corners(v, idxs).clone().requires_grad_(True)
+    rng = np.random.default_rng(5)
+    gt = torch.from_numpy((rng.standard_normal((B, 3000, 3)) * 0.2).astype(np.float32)).to(cuda)
+    gen = torch.Generator(device=cuda)
+    gen.manual_seed(1234)
+    out = hip_ops.chamfer_to_cloud(tri, gt, counts, K, gen)
+    w = torch.rand(B, device=cuda) + 0.5
+    (out * w).sum().backward()
+    # the same with torch ops (same generator state -> same r)
+    gen.manual_seed(1234)
+    tri2 = tri.detach().clone().requires_grad_(True)
+    samples = SL.sample_on_faces(tri2, K, gen).reshape(B, -1, 3)
+    idx = hip_ops.nn_index_ragged(samples.detach(), gt, [c * K for c in counts]).long()
+    near = torch.gather(gt, 1, idx[..., None].expand(-1, -1, 3))
+    ok = (torch.arange(Fmax * K, device=cuda)[None, :] < (torch.tensor(counts, device=cuda) * K)[:, None])
+    d = torch.sqrt(((samples - near) ** 2).sum(-1) + 1e-10)
+    ref = (d * ok).sum(-1)
+    (ref * w).sum().backward()
+    assert torch.allclose(out, ref, rtol=2e-6, atol=1e-6)
+    assert out[2].item() == 0.0                                       # the empty surface contributes nothing
+    scale = tri2.grad.abs().max().item()
+    assert scale > 0 and (tri.grad - tri2.grad).abs().max().item() <= 2e-5 * scale
+    assert torch.equal(tri.grad[2], torch.zeros_like(tri.grad[2]))
