@@ -1262,13 +1262,13 @@ __device__ __forceinline__ bool face_regular(const float *fc, float &lox, float 
 // coarse-cell representatives)
 __global__ __launch_bounds__(256) void k_tri_face_stats(const float *__restrict__ face, const float *__restrict__ nfb, float *part,
                                                         size_t slice, int Fmax, int *cnt0, int *fill0, int *counters, int *rep, int nc,
-                                                        int nRepCells)
+                                                        int nRepCells, int *pcnt0)
 {
     __shared__ float sh[4][8];
     const int sb = blockIdx.y;
     face += (size_t)sb * Fmax * 9; nfb += sb;
-    SHAPE(part); SHAPE(cnt0); SHAPE(fill0); SHAPE(counters); SHAPE(rep);
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nc; i += gridDim.x * blockDim.x) { cnt0[i] = 0; fill0[i] = 0; }
+    SHAPE(part); SHAPE(cnt0); SHAPE(fill0); SHAPE(counters); SHAPE(rep); SHAPE(pcnt0);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nc; i += gridDim.x * blockDim.x) { cnt0[i] = 0; fill0[i] = 0; pcnt0[i] = 0; }
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nRepCells; i += gridDim.x * blockDim.x) rep[i] = -1;
     if (blockIdx.x == 0 && threadIdx.x < 8) counters[threadIdx.x] = 0;
     const int nf = (int)nfb[0];
@@ -1429,16 +1429,16 @@ __global__ __launch_bounds__(256) void k_tri_face_bin(const float *__restrict__ 
                 for (int x = x0 / kTCoarse; x <= x1 / kTCoarse; ++x) atomicMax(&rep[(z * kTGc + y) * kTGc + x], f);
 }
 
-// Points keyed by their (clamped) grid cell: after one radix sort the 64 lanes of a wave are
-// neighbours in space, walk (nearly) the same cells and fetch the same face records — the GT point
-// cloud itself comes in arbitrary order.
-__global__ __launch_bounds__(256) void k_tri_point_keys(const float *__restrict__ pts, int P, const TGrid *__restrict__ gp, unsigned *key,
-                                                        size_t slice)
+// Points are sorted by their (clamped) grid cell — a counting sort: count + rank (one returning atomic per point), scan,
+// scatter — so that the 64 lanes of a wave are neighbours in space, walk the same cells and fetch the same face records;
+// the GT point cloud itself comes in arbitrary order.  (Round 2 used a library radix sort: ~20 launches per call.)  The
+// order of the points inside a cell is whatever the atomics gave; no result depends on it.
+__global__ __launch_bounds__(256) void k_tri_point_keys(const float *__restrict__ pts, int P, const TGrid *__restrict__ gp, int *pcount,
+                                                        int2 *prank, size_t slice)
 {
-    // key is ONE array of P keys per shape (outside the slices): all shapes are sorted by one call, shape index above bit 18
     const int sb = blockIdx.y;
-    pts += (size_t)sb * P * 3; key += (size_t)sb * P;
-    SHAPE(gp);
+    pts += (size_t)sb * P * 3;
+    SHAPE(gp); SHAPE(pcount); SHAPE(prank);
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= P) return;
     const TGrid g = *gp;
@@ -1449,7 +1449,23 @@ __global__ __launch_bounds__(256) void k_tri_point_keys(const float *__restrict_
         f = fminf(fmaxf(f, 0.f), (float)(g.g[k] - 1));               // NaN -> 0
         c[k] = (int)f;
     }
-    key[q] = (unsigned)((c[2] * kTGMax + c[1]) * kTGMax + c[0]) | ((unsigned)sb << 18);   // 18 bits + shape
+    const int cell = (c[2] * kTGMax + c[1]) * kTGMax + c[0];         // 18 bits: z, y, x
+    prank[q] = make_int2(cell, atomicAdd(&pcount[cell], 1));
+}
+
+__global__ __launch_bounds__(256) void k_tri_point_scatter(int P, const int2 *__restrict__ prank, const int *__restrict__ pstart,
+                                                           unsigned *order, unsigned *skey, size_t slice)
+{
+    // order / skey: ONE array of P entries per shape (outside the slices)
+    const int sb = blockIdx.y;
+    order += (size_t)sb * P; skey += (size_t)sb * P;
+    SHAPE(prank); SHAPE(pstart);
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= P) return;
+    const int2 r = prank[q];
+    const int slot = pstart[r.x] + r.y;
+    order[slot] = (unsigned)q;
+    skey[slot] = (unsigned)r.x;
 }
 
 // ---- the grid query, wave-cooperative ------------------------------------------------------------
@@ -1467,25 +1483,15 @@ constexpr int kTRows = kTGMax * kTGMax;     // (y, z) rows of the grid
 constexpr int kTFaceBits = 24;              // list entries: face index | x cell << 24 (faces < 2^24 is checked at the boundary)
 constexpr int kTFaceMask = (1 << kTFaceBits) - 1;
 
-__global__ __launch_bounds__(256) void k_tri_chunks(const unsigned *__restrict__ skey, int P, int *ptStart, int *chunkCount, size_t slice)
+__global__ __launch_bounds__(256) void k_tri_chunks(const int *__restrict__ pstart, int *ptStart, int *chunkCount, size_t slice)
 {
     const int sb = blockIdx.y;
-    skey += (size_t)sb * P;
-    SHAPE(ptStart); SHAPE(chunkCount);
-    const unsigned kbase = (unsigned)sb << 18;                         // the shape's keys carry its index above the cell bits
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;               // row = key >> 6
+    SHAPE(pstart); SHAPE(ptStart); SHAPE(chunkCount);
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;               // row = cell >> 6
     if (r > kTRows) return;
-    auto lower = [&](unsigned k) {
-        int lo = 0, hi = P;
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (skey[mid] < k) lo = mid + 1; else hi = mid;
-        }
-        return lo;
-    };
-    const int s0 = lower(kbase + ((unsigned)r << 6));
+    const int s0 = pstart[r << 6];                                     // pstart has 64^3 + 1 entries, the last = P
     ptStart[r] = s0;
-    chunkCount[r] = r < kTRows ? (lower(kbase + ((unsigned)(r + 1) << 6)) - s0 + 63) >> 6 : 0;
+    chunkCount[r] = r < kTRows ? (pstart[(r + 1) << 6] - s0 + 63) >> 6 : 0;
 }
 
 __device__ __forceinline__ float bcastf(float v, int k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k)); }
@@ -2564,19 +2570,44 @@ extern "C" int deftet_chamfer_bwd_f32(const float *samples, const float *gt, con
     return DEFTET_OK;
 }
 
+// the per-shape scratch slice of the grid search: ONE description of the layout, used for the size and for the pointers
+struct TriSlice {
+    float *part; TGrid *grid;
+    int *cnt, *start, *fill, *list, *wide, *farList, *counters, *farFlag, *farOff;
+    unsigned long long *bound;
+    int *rep, *ptStart, *chunkCount, *chunkStart;
+    float4 *sph;
+    int *pcount, *pstart;
+    int2 *prank;
+    size_t lay(void *base, int P, int Fmax)
+    {
+        const size_t nc = (size_t)kTGMax * kTGMax * kTGMax + 1, F = (size_t)(Fmax > 0 ? Fmax : 0), Pn = (size_t)(P > 0 ? P : 0);
+        Arena A(base, ~(size_t)0);
+        part = A.take<float>(kTParts * 8);
+        grid = A.take<TGrid>(1);
+        cnt = A.take<int>(nc); start = A.take<int>(nc); fill = A.take<int>(nc);
+        list = A.take<int>(F * kTMaxCells + 1); wide = A.take<int>(F + 1);
+        farList = A.take<int>(Pn + 1); counters = A.take<int>(8);
+        farFlag = A.take<int>(Pn + 1); farOff = A.take<int>(Pn + 1);
+        bound = A.take<unsigned long long>(Pn + 1);
+        rep = A.take<int>(kTGc * kTGc * kTGc);
+        ptStart = A.take<int>(kTRows + 2); chunkCount = A.take<int>(kTRows + 2); chunkStart = A.take<int>(kTRows + 2);
+        sph = A.take<float4>(F + 1);
+        pcount = A.take<int>(nc); pstart = A.take<int>(nc + 1);
+        prank = A.take<int2>(Pn + 1);
+        return align_up(A.off, 256);
+    }
+};
 static size_t tri_slice_bytes(int P, int Fmax)
 {
-    const size_t nc = (size_t)kTGMax * kTGMax * kTGMax + 1;
-    const size_t F = (size_t)(Fmax > 0 ? Fmax : 0), Pn = (size_t)(P > 0 ? P : 0);
-    return align_up(nc * 4 * 3 + F * kTMaxCells * 4 + F * 4 + F * 16 + Pn * 4 + Pn * 8 + Pn * 8 + nc * 12 + 65536 + ((size_t)1 << 20), 256);
+    TriSlice L;
+    return L.lay(nullptr, P, Fmax);
 }
+// behind the slices: the sorted cell keys and the point order of all shapes of a group (P entries per shape each)
 static size_t tri_sort_bytes(int nShapes, int P)
 {
-    size_t sortTmp = 0;
     const size_t n = (size_t)nShapes * (size_t)(P > 0 ? P : 0);
-    (void)rocprim::radix_sort_pairs(nullptr, sortTmp, (unsigned *)nullptr, (unsigned *)nullptr, (unsigned *)nullptr, (unsigned *)nullptr, n, 0, 32,
-                                    (hipStream_t) nullptr);
-    return align_up(sortTmp, 256) + 4 * align_up(n * 4 + 4, 256) + 1024;
+    return 2 * align_up(n * 4 + 4, 256) + 1024;
 }
 // per-shape scratch slices for a launch group of <= kBatchShapes shapes + the all-shapes point keys and sort scratch
 extern "C" size_t deftet_tri_dist_workspace_bytes(int B, int P, int Fmax)
@@ -2585,53 +2616,39 @@ extern "C" size_t deftet_tri_dist_workspace_bytes(int B, int P, int Fmax)
     return tri_slice_bytes(P, Fmax) * (size_t)g + tri_sort_bytes(g, P);
 }
 
-__global__ __launch_bounds__(256) void k_iota_mod(unsigned *v, long long n, unsigned period)
-{
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) v[i] = (unsigned)(i % period);
-}
-
 // the grid search for a GROUP of nS <= kBatchShapes shapes: one launch per kernel for the whole group
 static int tri_dist_group(const float *pts, const float *face, const float *nfb, float *cd, float *cf, int nS, int P, int Fmax, void *ws,
                           size_t wsb, hipStream_t st, int *order_out)
 {
-    const size_t nc = (size_t)kTGMax * kTGMax * kTGMax + 1, slice = tri_slice_bytes(P, Fmax);
-    Arena A(ws, slice);                                               // layout of slice 0; the kernels rebase to their shape
-    float *part = A.take<float>(kTParts * 8);
-    TGrid *grid = A.take<TGrid>(1);
-    int *cnt = A.take<int>(nc), *start = A.take<int>(nc), *fill = A.take<int>(nc);
-    int *list = A.take<int>((size_t)Fmax * kTMaxCells + 1), *wide = A.take<int>((size_t)Fmax + 1);
-    int *farList = A.take<int>((size_t)P + 1), *counters = A.take<int>(8);
-    int *farFlag = A.take<int>((size_t)P + 1), *farOff = A.take<int>((size_t)P + 1);
-    unsigned long long *bound = A.take<unsigned long long>((size_t)P + 1);
-    int *rep = A.take<int>(kTGc * kTGc * kTGc);
-    int *ptStart = A.take<int>(nc + 1), *chunkCount = A.take<int>(nc + 1), *chunkStart = A.take<int>(nc + 1);
-    float4 *sph = A.take<float4>((size_t)Fmax + 1);
-    if (A.off > slice) return set_error(DEFTET_EINVAL, "tri_dist slice layout exceeds its size");
+    const size_t nc = (size_t)kTGMax * kTGMax * kTGMax + 1;
+    TriSlice L;                                                       // layout of slice 0; the kernels rebase to their shape
+    const size_t slice = L.lay(ws, P, Fmax);
+    float *part = L.part;
+    TGrid *grid = L.grid;
+    int *cnt = L.cnt, *start = L.start, *fill = L.fill, *list = L.list, *wide = L.wide, *farList = L.farList, *counters = L.counters;
+    int *farFlag = L.farFlag, *farOff = L.farOff, *rep = L.rep, *ptStart = L.ptStart, *chunkCount = L.chunkCount, *chunkStart = L.chunkStart;
+    unsigned long long *bound = L.bound;
+    float4 *sph = L.sph;
+    int *pcount = L.pcount, *pstart = L.pstart;
+    int2 *prank = L.prank;
     const size_t nAll = (size_t)nS * P;
+    if (slice * nS + tri_sort_bytes(nS, P) > wsb) return set_error(DEFTET_EINVAL, "tri_dist workspace smaller than its layout");
     Arena T(static_cast<char *>(ws) + slice * nS, wsb - slice * nS);
-    unsigned *pkey = T.take<unsigned>(nAll + 1), *pskey = T.take<unsigned>(nAll + 1), *iota = T.take<unsigned>(nAll + 1), *order = T.take<unsigned>(nAll + 1);
-    void *tmp = T.base + align_up(T.off, 256);
-    const size_t left = (wsb - slice * nS) - align_up(T.off, 256);
+    unsigned *pskey = T.take<unsigned>(nAll + 1), *order = T.take<unsigned>(nAll + 1);
     const dim3 blk(256);
-    DEFTET_LAUNCH(k_tri_face_stats, dim3(kTParts, nS), blk, st, face, nfb, part, slice, Fmax, cnt, fill, counters, rep, (int)nc, kTGc * kTGc * kTGc);
+    DEFTET_LAUNCH(k_tri_face_stats, dim3(kTParts, nS), blk, st, face, nfb, part, slice, Fmax, cnt, fill, counters, rep, (int)nc, kTGc * kTGc * kTGc,
+                  pcount);
     DEFTET_LAUNCH(k_tri_grid, dim3(nS), dim3(64), st, (const float *)part, grid, slice);
     DEFTET_LAUNCH(k_tri_face_bin, dim3((Fmax + 255) / 256, nS), blk, st, face, nfb, (const TGrid *)grid, 0, cnt, (const int *)start, fill, list, wide,
                   counters, rep, slice, Fmax, sph);
     DEFTET_LAUNCH(k_scan_excl, dim3(scan_tiles(nc), nS), dim3(kScanThreads), st, (const int *)cnt, start, (int)nc, slice, 0);
     DEFTET_LAUNCH(k_tri_face_bin, dim3((Fmax + 255) / 256, nS), blk, st, face, nfb, (const TGrid *)grid, 1, cnt, (const int *)start, fill, list, wide,
                   counters, rep, slice, Fmax, sph);
-    DEFTET_LAUNCH(k_tri_point_keys, dim3((P + 255) / 256, nS), blk, st, pts, P, (const TGrid *)grid, pkey, slice);
-    DEFTET_LAUNCH(k_iota_mod, dim3((unsigned)((nAll + 255) / 256)), blk, st, iota, (long long)nAll, (unsigned)P);
-    int shapeBitsN = 0;
-    while ((1 << shapeBitsN) < nS) ++shapeBitsN;
-    size_t need = 0;
-    hipError_t e = rocprim::radix_sort_pairs(nullptr, need, pkey, pskey, iota, order, nAll, 0, 18 + shapeBitsN, st);
-    if (e != hipSuccess || need > left) return set_error(DEFTET_ELAUNCH, "radix_sort temp");
-    e = rocprim::radix_sort_pairs(tmp, need, pkey, pskey, iota, order, nAll, 0, 18 + shapeBitsN, st);
-    if (e != hipSuccess) return set_error(DEFTET_ELAUNCH, "radix_sort_pairs: %s", hipGetErrorString(e));
+    DEFTET_LAUNCH(k_tri_point_keys, dim3((P + 255) / 256, nS), blk, st, pts, P, (const TGrid *)grid, pcount, prank, slice);
+    DEFTET_LAUNCH(k_scan_excl, dim3(scan_tiles(nc), nS), dim3(kScanThreads), st, (const int *)pcount, pstart, (int)nc, slice, 0);
+    DEFTET_LAUNCH(k_tri_point_scatter, dim3((P + 255) / 256, nS), blk, st, P, (const int2 *)prank, (const int *)pstart, order, pskey, slice);
     if (order_out) DEFTET_HIP(hipMemcpyAsync(order_out, order, nAll * 4, hipMemcpyDeviceToDevice, st));   // for the grouped backward
-    DEFTET_LAUNCH(k_tri_chunks, dim3((kTRows + 1 + 255) / 256, nS), blk, st, (const unsigned *)pskey, P, ptStart, chunkCount, slice);
+    DEFTET_LAUNCH(k_tri_chunks, dim3((kTRows + 1 + 255) / 256, nS), blk, st, (const int *)pstart, ptStart, chunkCount, slice);
     DEFTET_LAUNCH(k_scan_excl, dim3(scan_tiles(kTRows + 1), nS), dim3(kScanThreads), st, (const int *)chunkCount, chunkStart, kTRows + 1, slice, 0);
     {
         const long long maxChunks = (long long)(P + 63) / 64 + (long long)kTRows;
