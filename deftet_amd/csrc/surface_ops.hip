@@ -1024,57 +1024,63 @@ __global__ __launch_bounds__(kNCThreads) void k_normal_consistency_fwd(const flo
     }
 }
 
-__global__ __launch_bounds__(kNCThreads) void k_normal_consistency_bwd(const float *__restrict__ tri, const float *__restrict__ adj,
-                                                                       const int *__restrict__ n_face, const float *__restrict__ nrm,
-                                                                       const float *__restrict__ count, const float *__restrict__ gloss,
-                                                                       float *gtri, float *acc, int Fmax, int max_nei)
+// backward, two launches over (faces, shapes) grids (one workgroup per shape, as the forward still is, ran its ~4 faces x 30
+// dependent neighbour loads per thread unhidden: 0.13 ms per 8 shapes):
+//  scatter: G_k = d(sum of 1 - <n_i, n_j>)/d n_k = -(sum over row k of n_j) - (sum over the rows i that list k of n_i),
+//           formed in acc (zeroed by the caller) with float atomics — the table need not be symmetric (rows are cut at
+//           max_nei entries);
+//  final:   chain through the normalisation and the cross product, one lane per face.
+__global__ __launch_bounds__(256) void k_normal_consistency_bwd_scatter(const float *__restrict__ adj, const int *__restrict__ n_face,
+                                                                        const float *__restrict__ nrm, float *acc, int Fmax, int max_nei)
 {
-    const int b = blockIdx.x, F = min(n_face[b], Fmax);
-    const float *tb = tri + (size_t)b * Fmax * 9, *ab = adj + (size_t)b * Fmax * max_nei, *nb = nrm + (size_t)b * Fmax * 3;
-    float *gb = gtri + (size_t)b * Fmax * 9, *accb = acc + (size_t)b * Fmax * 3;
+    const int b = blockIdx.y, F = min(n_face[b], Fmax);
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    const float *ab = adj + ((size_t)b * Fmax + f) * max_nei, *nb = nrm + (size_t)b * Fmax * 3;
+    float *accb = acc + (size_t)b * Fmax * 3;
+    const float n0 = nb[f * 3], n1 = nb[f * 3 + 1], n2 = nb[f * 3 + 2];
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int k = 0; k < max_nei; ++k) {
+        const float a = ab[k];
+        if (a < 0.f) continue;
+        const int j = (int)a;
+        s0 += nb[j * 3]; s1 += nb[j * 3 + 1]; s2 += nb[j * 3 + 2];
+        unsafeAtomicAdd(&accb[j * 3], -n0); unsafeAtomicAdd(&accb[j * 3 + 1], -n1); unsafeAtomicAdd(&accb[j * 3 + 2], -n2);
+    }
+    unsafeAtomicAdd(&accb[f * 3], -s0); unsafeAtomicAdd(&accb[f * 3 + 1], -s1); unsafeAtomicAdd(&accb[f * 3 + 2], -s2);
+}
+
+__global__ __launch_bounds__(256) void k_normal_consistency_bwd_final(const float *__restrict__ tri, const int *__restrict__ n_face,
+                                                                      const float *__restrict__ count, const float *__restrict__ gloss,
+                                                                      const float *__restrict__ acc, float *gtri, int Fmax)
+{
+    const int b = blockIdx.y, F = min(n_face[b], Fmax);
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= Fmax) return;
     const float C = count[b], w = C > 0.f ? gloss[b] / C : 0.f;
-    for (int f = threadIdx.x; f < Fmax * 3; f += kNCThreads) accb[f] = 0.f;
-    __syncthreads();
-    // G_k = d(sum of 1 - <n_i, n_j>)/d n_k = -(sum over row k of n_j) - (sum over the rows i that list k of n_i)
-    for (int f = threadIdx.x; f < F; f += kNCThreads) {
-        const float n0 = nb[f * 3], n1 = nb[f * 3 + 1], n2 = nb[f * 3 + 2];
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-        for (int k = 0; k < max_nei; ++k) {
-            const float a = ab[(size_t)f * max_nei + k];
-            if (a < 0.f) continue;
-            const int j = (int)a;
-            s0 += nb[j * 3]; s1 += nb[j * 3 + 1]; s2 += nb[j * 3 + 2];
-            unsafeAtomicAdd(&accb[j * 3], -n0); unsafeAtomicAdd(&accb[j * 3 + 1], -n1); unsafeAtomicAdd(&accb[j * 3 + 2], -n2);
-        }
-        unsafeAtomicAdd(&accb[f * 3], -s0); unsafeAtomicAdd(&accb[f * 3 + 1], -s1); unsafeAtomicAdd(&accb[f * 3 + 2], -s2);
+    float g[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) g[k] = 0.f;
+    if (f < F) {
+        const float *tb = tri + ((size_t)b * Fmax + f) * 9, *accf = acc + ((size_t)b * Fmax + f) * 3;
+        float t[9], c[3];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) t[k] = tb[k];
+        face_cross(t, c);
+        const float r2 = c[0] * c[0] + c[1] * c[1] + c[2] * c[2] + kNormalEps, r = 1.0f / sqrtf(r2);
+        const float G[3] = {accf[0] * w, accf[1] * w, accf[2] * w};
+        const float cg = (c[0] * G[0] + c[1] * G[1] + c[2] * G[2]) * r * r * r;          // n = c r:  dL/dc = G r - c (c.G) r^3
+        const float dc[3] = {G[0] * r - c[0] * cg, G[1] * r - c[1] * cg, G[2] * r - c[2] * cg};
+        const float e1[3] = {t[3] - t[0], t[4] - t[1], t[5] - t[2]}, e2[3] = {t[6] - t[0], t[7] - t[1], t[8] - t[2]};
+        // c = e1 x e2:  dL/de1 = e2 x dc,  dL/de2 = dc x e1
+        const float d1[3] = {e2[1] * dc[2] - e2[2] * dc[1], e2[2] * dc[0] - e2[0] * dc[2], e2[0] * dc[1] - e2[1] * dc[0]};
+        const float d2[3] = {dc[1] * e1[2] - dc[2] * e1[1], dc[2] * e1[0] - dc[0] * e1[2], dc[0] * e1[1] - dc[1] * e1[0]};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { g[k] = -(d1[k] + d2[k]); g[3 + k] = d1[k]; g[6 + k] = d2[k]; }
     }
-    __syncthreads();
-    for (int f = threadIdx.x; f < Fmax; f += kNCThreads) {
-        float g[9];
+    float *gb = gtri + ((size_t)b * Fmax + f) * 9;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) g[k] = 0.f;
-        if (f < F) {
-            float t[9], c[3];
-#pragma unroll
-            for (int k = 0; k < 9; ++k) t[k] = tb[(size_t)f * 9 + k];
-            face_cross(t, c);
-            const float r2 = c[0] * c[0] + c[1] * c[1] + c[2] * c[2] + kNormalEps, r = 1.0f / sqrtf(r2);
-            // (agent-scope loads: the sums were formed by atomics in L2, the zeroes above may still sit in this CU's L1)
-            const float G[3] = {__hip_atomic_load(&accb[f * 3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * w,
-                                __hip_atomic_load(&accb[f * 3 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * w,
-                                __hip_atomic_load(&accb[f * 3 + 2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * w};
-            const float cg = (c[0] * G[0] + c[1] * G[1] + c[2] * G[2]) * r * r * r;          // n = c r:  dL/dc = G r - c (c.G) r^3
-            const float dc[3] = {G[0] * r - c[0] * cg, G[1] * r - c[1] * cg, G[2] * r - c[2] * cg};
-            const float e1[3] = {t[3] - t[0], t[4] - t[1], t[5] - t[2]}, e2[3] = {t[6] - t[0], t[7] - t[1], t[8] - t[2]};
-            // c = e1 x e2:  dL/de1 = e2 x dc,  dL/de2 = dc x e1
-            const float d1[3] = {e2[1] * dc[2] - e2[2] * dc[1], e2[2] * dc[0] - e2[0] * dc[2], e2[0] * dc[1] - e2[1] * dc[0]};
-            const float d2[3] = {dc[1] * e1[2] - dc[2] * e1[1], dc[2] * e1[0] - dc[0] * e1[2], dc[0] * e1[1] - dc[1] * e1[0]};
-#pragma unroll
-            for (int k = 0; k < 3; ++k) { g[k] = -(d1[k] + d2[k]); g[3 + k] = d1[k]; g[6 + k] = d2[k]; }
-        }
-#pragma unroll
-        for (int k = 0; k < 9; ++k) gb[(size_t)f * 9 + k] = g[k];
-    }
+    for (int k = 0; k < 9; ++k) gb[k] = g[k];
 }
 
 // ---------------------------------------------------------------------------- A9 point -> triangle distance
@@ -1364,11 +1370,11 @@ constexpr int kTGc = kTGMax / kTCoarse;
 __global__ __launch_bounds__(256) void k_tri_face_bin(const float *__restrict__ face, const float *__restrict__ nfb,
                                                       const TGrid *__restrict__ gp, int mode, int *cellCount,
                                                       const int *__restrict__ cellStart, int *cellFill, int *list, int *wide,
-                                                      int *nWide, int *rep, size_t slice, int Fmax, float4 *sph)
+                                                      int *nWide, int *rep, size_t slice, int Fmax, float4 *sph, uint2 *frange)
 {
     const int sb = blockIdx.y;
     face += (size_t)sb * Fmax * 9; nfb += sb;
-    SHAPE(gp); SHAPE(cellCount); SHAPE(cellStart); SHAPE(cellFill); SHAPE(list); SHAPE(wide); SHAPE(nWide); SHAPE(rep); SHAPE(sph);
+    SHAPE(gp); SHAPE(cellCount); SHAPE(cellStart); SHAPE(cellFill); SHAPE(list); SHAPE(wide); SHAPE(nWide); SHAPE(rep); SHAPE(sph); SHAPE(frange);
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= (int)nfb[0]) return;
     const TGrid g = *gp;
@@ -1415,6 +1421,8 @@ __global__ __launch_bounds__(256) void k_tri_face_bin(const float *__restrict__ 
             r2 = fmaxf(r2, dx * dx + dy * dy + dz * dz);
         }
         sph[f] = make_float4(c[0], c[1], c[2], sqrtf(r2) * 1.00001f);
+        // its cell range, six bits per bound: what k_tri_query_coop's canonical-cell rule needs of the face
+        frange[f] = make_uint2((unsigned)x0 | (unsigned)x1 << 6 | (unsigned)y0 << 12 | (unsigned)y1 << 18 | (unsigned)z0 << 24, (unsigned)z1);
     }
     for (int z = z0; z <= z1; ++z)
         for (int y = y0; y <= y1; ++y)
@@ -1506,7 +1514,7 @@ constexpr int kTriChunkWaves = 4;      // waves per chunk of 64 points in k_tri_
 constexpr int kTriCand = 8;            // per-lane candidate slots (LDS) between two drains in k_tri_query_coop
 
 __device__ __forceinline__ void tri_query_chunk(int W, int part, float (*s_lb)[64], int (*s_cf)[64], int *s_q, unsigned long long *s_best,
-                                                const float4 *__restrict__ sph, const unsigned *__restrict__ skey,
+                                                const uint2 *__restrict__ frange, const float4 *__restrict__ sph, const unsigned *__restrict__ skey,
                                                 const float *__restrict__ pts, const float *__restrict__ face,
                                                 const float *__restrict__ nfb, int P, const TGrid *__restrict__ gp,
                                                 const int *__restrict__ cellStart, const int *__restrict__ list,
@@ -1652,31 +1660,42 @@ __device__ __forceinline__ void tri_query_chunk(int W, int part, float (*s_lb)[6
             const bool have = idx < e;
             const int ent = have ? lst[idx] : 0;
             const int fm = ent & kTFaceMask;
-            float fv[9];
-#pragma unroll
-            for (int k = 0; k < 9; ++k) fv[k] = have ? face[(size_t)fm * 9 + k] : 0.f;
+            float fv[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             bool use = have;
-            const float4 sp = have ? sph[fm] : make_float4(0.f, 0.f, 0.f, 0.f);   // regular faces: sphere; wide faces: plane
-            float blo[3] = {0.f, 0.f, 0.f}, bhi[3] = {0.f, 0.f, 0.f};             // the face's bounding box
-            if (have && filter) {                                     // same cell range as k_tri_face_bin
+            float4 sp = make_float4(0.f, 0.f, 0.f, 0.f);             // regular faces: sphere; wide faces: plane
+            float blo[3] = {0.f, 0.f, 0.f}, bhi[3] = {0.f, 0.f, 0.f}; // the face's bounding box
+            if (have && filter) {
+                // canonical cell: of the face's cells (as k_tri_face_bin listed them) inside the box, the one NEAREST to the
+                // chunk's cells on every axis (so that a skipped row implies that all the face's cells are out of reach)
+                const uint2 rg = frange[fm];
+                const int f0[3] = {(int)(rg.x & 63u), (int)(rg.x >> 12 & 63u), (int)(rg.x >> 24 & 63u)};
+                const int f1[3] = {(int)(rg.x >> 6 & 63u), (int)(rg.x >> 18 & 63u), (int)(rg.y & 63u)};
                 const int cc[3] = {(int)((unsigned)ent >> kTFaceBits), cy, cz}, bb0[3] = {bx0, by0, bz0};
-                float d2 = 0.f;
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
-                    const float flo = fminf(fv[k], fminf(fv[3 + k], fv[6 + k])), fhi = fmaxf(fv[k], fmaxf(fv[3 + k], fv[6 + k]));
-                    blo[k] = flo; bhi[k] = fhi;
-                    const int f0 = t_cell(flo - g.slack[k], g.o[k], g.inv[k], g.g[k]), f1 = t_cell(fhi + g.slack[k], g.o[k], g.inv[k], g.g[k]);
-                    // canonical cell: of the face's cells inside the box, the one NEAREST to the chunk's cells on every axis
-                    // (so that a skipped row implies that all the face's cells are out of reach)
-                    const int lo_k = max(f0, bb0[k]), hi_k = min(f1, bb0[k] + boxn[k] - 1);
+                    const int lo_k = max(f0[k], bb0[k]), hi_k = min(f1[k], bb0[k] + boxn[k] - 1);
                     const int canon = lo_k > Chi[k] ? lo_k : (hi_k < Clo[k] ? hi_k : max(lo_k, Clo[k]));
                     use = use && cc[k] == canon;
-                    const float d = fmaxf(fmaxf(plo[k] - fhi, flo - phi[k]), 0.f);
-                    d2 += d * d;
                 }
-                use = use && !(d2 * 0.9999f > reach2);
+                if (use) {                                            // one listing in ~8 survives: only those fetch the record
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) fv[k] = face[(size_t)fm * 9 + k];
+                    sp = sph[fm];
+                    float d2 = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        blo[k] = fminf(fv[k], fminf(fv[3 + k], fv[6 + k]));
+                        bhi[k] = fmaxf(fv[k], fmaxf(fv[3 + k], fv[6 + k]));
+                        const float d = fmaxf(fmaxf(plo[k] - bhi[k], blo[k] - phi[k]), 0.f);
+                        d2 += d * d;
+                    }
+                    use = !(d2 * 0.9999f > reach2);
+                }
             }
             if (have && !filter) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) fv[k] = face[(size_t)fm * 9 + k];
+                sp = sph[fm];
                 // wide face: its plane offset t over the box of the wave's points lies in [tlo, thi] (up to rounding, mag
                 // bounds the operands); when even the smallest |t| squared exceeds every lane's best, the vote below fails
                 // for every lane — decided here for 64 faces at once instead of one broadcast each
@@ -1862,12 +1881,12 @@ __global__ __launch_bounds__(kTriChunkWaves * 64) void k_tri_query_coop(const fl
                                                                          const unsigned *__restrict__ order, const int *__restrict__ ptStart,
                                                                          const int *__restrict__ chunkStart, const int *__restrict__ rep,
                                                                          size_t slice, int Fmax, const float4 *__restrict__ sph,
-                                                                         const unsigned *__restrict__ skey)
+                                                                         const unsigned *__restrict__ skey, const uint2 *__restrict__ frange)
 {
     const int sb = blockIdx.y;
     pts += (size_t)sb * P * 3; face += (size_t)sb * Fmax * 9; nfb += sb; closest_d += (size_t)sb * P; closest_f += (size_t)sb * P;
     order += (size_t)sb * P; skey += (size_t)sb * P;
-    SHAPE(gp); SHAPE(cellStart); SHAPE(list); SHAPE(wide); SHAPE(nWide); SHAPE(farFlag); SHAPE(ptStart); SHAPE(chunkStart); SHAPE(rep); SHAPE(sph);
+    SHAPE(gp); SHAPE(cellStart); SHAPE(list); SHAPE(wide); SHAPE(nWide); SHAPE(farFlag); SHAPE(ptStart); SHAPE(chunkStart); SHAPE(rep); SHAPE(sph); SHAPE(frange);
     // One block per chunk of 64 points, its waves splitting the rows of the search box: one wave per chunk ran its chain of
     // dependent loads (cell starts -> list entries -> vertices) unhidden.
     __shared__ float s_lb[kTriChunkWaves][kTriCand][64];
@@ -1877,7 +1896,7 @@ __global__ __launch_bounds__(kTriChunkWaves * 64) void k_tri_query_coop(const fl
     const int total = chunkStart[kTRows];
     const int part = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     for (int W = blockIdx.x; W < total; W += gridDim.x)
-        tri_query_chunk(W, part, s_lb[part], s_cf[part], s_q[part], s_best, sph, skey, pts, face, nfb, P, gp, cellStart, list, wide, nWide, closest_d,
+        tri_query_chunk(W, part, s_lb[part], s_cf[part], s_q[part], s_best, frange, sph, skey, pts, face, nfb, P, gp, cellStart, list, wide, nWide, closest_d,
                         closest_f, farFlag, order, ptStart, chunkStart, rep);
 }
 
@@ -2530,11 +2549,14 @@ extern "C" int deftet_normal_consistency_bwd_f32(const float *tri, const float *
                                                  const float *count, const float *grad_loss, float *grad_tri, float *acc, int B,
                                                  int F_max, int max_nei, void *stream_)
 {
-    DEFTET_CHECK_ARG(B >= 0 && F_max >= 0 && max_nei >= 0, "bad size");
+    DEFTET_CHECK_ARG(B >= 0 && F_max >= 0 && max_nei >= 0 && B <= 65535, "bad size");
     if (B == 0 || F_max == 0) return DEFTET_OK;
     DEFTET_CHECK_ARG(tri && n_face && nrm && count && grad_loss && grad_tri && acc && (max_nei == 0 || adj), "null pointer");
-    DEFTET_LAUNCH(k_normal_consistency_bwd, dim3(B), dim3(kNCThreads), as_stream(stream_), tri, adj, n_face, nrm, count, grad_loss, grad_tri,
-                  acc, F_max, max_nei);
+    hipStream_t st = as_stream(stream_);
+    DEFTET_HIP(hipMemsetAsync(acc, 0, (size_t)B * F_max * 3 * sizeof(float), st));
+    DEFTET_LAUNCH(k_normal_consistency_bwd_scatter, dim3((F_max + 255) / 256, B), dim3(256), st, adj, n_face, nrm, acc, F_max, max_nei);
+    DEFTET_LAUNCH(k_normal_consistency_bwd_final, dim3((F_max + 255) / 256, B), dim3(256), st, tri, n_face, count, grad_loss, (const float *)acc,
+                  grad_tri, F_max);
     return DEFTET_OK;
 }
 
@@ -2577,6 +2599,7 @@ struct TriSlice {
     unsigned long long *bound;
     int *rep, *ptStart, *chunkCount, *chunkStart;
     float4 *sph;
+    uint2 *frange;
     int *pcount, *pstart;
     int2 *prank;
     size_t lay(void *base, int P, int Fmax)
@@ -2593,6 +2616,7 @@ struct TriSlice {
         rep = A.take<int>(kTGc * kTGc * kTGc);
         ptStart = A.take<int>(kTRows + 2); chunkCount = A.take<int>(kTRows + 2); chunkStart = A.take<int>(kTRows + 2);
         sph = A.take<float4>(F + 1);
+        frange = A.take<uint2>(F + 1);
         pcount = A.take<int>(nc); pstart = A.take<int>(nc + 1);
         prank = A.take<int2>(Pn + 1);
         return align_up(A.off, 256);
@@ -2629,6 +2653,7 @@ static int tri_dist_group(const float *pts, const float *face, const float *nfb,
     int *farFlag = L.farFlag, *farOff = L.farOff, *rep = L.rep, *ptStart = L.ptStart, *chunkCount = L.chunkCount, *chunkStart = L.chunkStart;
     unsigned long long *bound = L.bound;
     float4 *sph = L.sph;
+    uint2 *frange = L.frange;
     int *pcount = L.pcount, *pstart = L.pstart;
     int2 *prank = L.prank;
     const size_t nAll = (size_t)nS * P;
@@ -2640,10 +2665,10 @@ static int tri_dist_group(const float *pts, const float *face, const float *nfb,
                   pcount);
     DEFTET_LAUNCH(k_tri_grid, dim3(nS), dim3(64), st, (const float *)part, grid, slice);
     DEFTET_LAUNCH(k_tri_face_bin, dim3((Fmax + 255) / 256, nS), blk, st, face, nfb, (const TGrid *)grid, 0, cnt, (const int *)start, fill, list, wide,
-                  counters, rep, slice, Fmax, sph);
+                  counters, rep, slice, Fmax, sph, frange);
     DEFTET_LAUNCH(k_scan_excl, dim3(scan_tiles(nc), nS), dim3(kScanThreads), st, (const int *)cnt, start, (int)nc, slice, 0);
     DEFTET_LAUNCH(k_tri_face_bin, dim3((Fmax + 255) / 256, nS), blk, st, face, nfb, (const TGrid *)grid, 1, cnt, (const int *)start, fill, list, wide,
-                  counters, rep, slice, Fmax, sph);
+                  counters, rep, slice, Fmax, sph, frange);
     DEFTET_LAUNCH(k_tri_point_keys, dim3((P + 255) / 256, nS), blk, st, pts, P, (const TGrid *)grid, pcount, prank, slice);
     DEFTET_LAUNCH(k_scan_excl, dim3(scan_tiles(nc), nS), dim3(kScanThreads), st, (const int *)pcount, pstart, (int)nc, slice, 0);
     DEFTET_LAUNCH(k_tri_point_scatter, dim3((P + 255) / 256, nS), blk, st, P, (const int2 *)prank, (const int *)pstart, order, pskey, slice);
@@ -2655,7 +2680,7 @@ static int tri_dist_group(const float *pts, const float *face, const float *nfb,
         DEFTET_LAUNCH(k_tri_query_coop, dim3((unsigned)std::min<long long>(maxChunks, kTriQueryBlocks), nS), dim3(kTriChunkWaves * 64), st, pts,
                       face, nfb, P, (const TGrid *)grid, (const int *)start, (const int *)list, (const int *)wide, (const int *)counters, cd, cf,
                       farFlag, (const unsigned *)order, (const int *)ptStart, (const int *)chunkStart, (const int *)rep, slice, Fmax, (const float4 *)sph,
-                      (const unsigned *)pskey);
+                      (const unsigned *)pskey, (const uint2 *)frange);
     }
     // the far path (counters: [0] wide faces, [1] far points)
     DEFTET_LAUNCH(k_scan_excl, dim3(scan_tiles(P), nS), dim3(kScanThreads), st, (const int *)farFlag, farOff, P, slice, 0);
