@@ -86,6 +86,7 @@ SIGNATURES = {
     "deftet_nn_index_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "deftet_sparse_render_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "deftet_sparse_render_fwd_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _sz, _vp]),
+    "deftet_sparse_render_fwd_policy_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _sz, _vp]),
     "deftet_sparse_render_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "deftet_sparse_render_bwd_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _sz, _vp]),
 }

@@ -9,8 +9,10 @@
 //     k1 = s*q - n*t;  k2 = m*t - s*pp;  k3 = m*q - n*pp
 //     w1 = k1/(k3+eps); w2 = k2/(k3+eps); w0 = 1 - w1 - w2;   covered iff w0,w1,w2 >= 0
 //     z = (w0*az + w1*bz) + w2*cz;                            kept iff zmin <= z <= zmax
-//   per pixel the first `knum` kept faces in ascending face index are recorded, then ordered by
-//   z descending (ties: ascending face index); features = (w0*f0 + w1*f1) + w2*f2.
+//   per pixel at most `knum` kept faces are recorded and ordered by z descending (ties: ascending face
+//   index); which ones when more are kept is the saturation POLICY: the `knum` that come first in that
+//   order (NEAREST, the default — an insertion-sorted list of bounded length) or the first `knum` in
+//   ascending face index (FIRST, rounds 1-2); features = (w0*f0 + w1*f1) + w2*f2.
 //
 // MI355X design (the brute-force formulation is pixels x faces = 1.4e11 tests at 512x512 over a
 // res-70 grid): pixels define a uniform 2-D tile grid; faces are binned into the tiles their
@@ -262,14 +264,16 @@ __global__ __launch_bounds__(256) void k_pix_chunks(const unsigned *__restrict__
 }
 
 struct Hit { int f; float z, w1, w2; };
+constexpr int kPendDepth = 4;          // admitted hits a full lane queues before the wave works the queues off (NEAREST)
 
 // One wave per 64 pixels OF ONE TILE: the face list is then the same for every lane, so the wave
 // loads 64 list entries and their 36 bytes of face data with one coalesced round trip (lane k holds
 // face k) and broadcasts them one after the other with v_readlane — the per-lane formulation spent
 // two dependent gather latencies on every candidate (1.5 ms at configs[4], lists of ~1,700 faces).
-// Faces are visited in ascending index (tile list merged with the wide list), every lane keeps its
-// first `knum` hits, the wave stops when all its lanes are full.  The chunk of NaN/Inf/huge pixels
-// (pseudo-tile nTilesCap) visits every face.
+// FIRST policy: faces are visited in ascending index (tile list merged with the wide list), every lane keeps its first
+// `knum` hits and the wave stops when all its lanes are full.  NEAREST policy: the whole list is visited (from the end
+// whose faces are nearer); a full lane replaces its worst record (smallest z, then largest face index) by a better hit.
+// The chunk of NaN/Inf/huge pixels (pseudo-tile nTilesCap) visits every face.
 __device__ __forceinline__ float bcast(float v, int k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k)); }
 
 __global__ __launch_bounds__(256) void k_pix_raster(const float *__restrict__ pix, const float *__restrict__ rng,
@@ -278,7 +282,7 @@ __global__ __launch_bounds__(256) void k_pix_raster(const float *__restrict__ pi
                                                     const int *__restrict__ list, const int *__restrict__ wide,
                                                     const int *__restrict__ nWide, int F, int knum, float eps, int4 *hits,
                                                     int *nhit, const unsigned *__restrict__ pixOrder,
-                                                    const int *__restrict__ pixStart, const int *__restrict__ chunkStart)
+                                                    const int *__restrict__ pixStart, const int *__restrict__ chunkStart, int nearest)
 {
     const int lane = threadIdx.x & 63;
     const int W = blockIdx.x * 4 + (threadIdx.x >> 6);              // chunk id (wave-uniform)
@@ -301,16 +305,49 @@ __global__ __launch_bounds__(256) void k_pix_raster(const float *__restrict__ pi
     // (A certified wave-level early out before the two divisions — every lane surely outside by the signs of k1, k2 and
     // k1 + k2 - den with rounding margins — was measured: it rarely holds for all 64 pixels and its dozen instructions
     // made the kernel slower, 850 vs 739 us.)
+    // NEAREST: a full lane admits a hit that beats its worst record (smallest z, then largest face index).  Finding the new
+    // worst is a pass over the lane's knum records, and the lanes of a wave saturate at different faces, so admitted hits
+    // wait in a short per-lane queue (LDS) and the wave works the queues off together, every lane replacing its j-th
+    // pending hit in the same pass.  A queued hit is re-tested against the lane's current worst when it is taken out (the
+    // threshold only tightens in between).
+    __shared__ int4 s_pend[4][kPendDepth][64];
+    int4(*pend)[64] = s_pend[threadIdx.x >> 6];
+    float worstZ = INFINITY;                                        // the record a better hit would replace
+    int worstF = -1, worstAt = 0, npend = 0;
+    auto worse = [](float za, int fa, float zb, int fb) { return za < zb || (za == zb && fa > fb); };   // a after b in the output order
+    auto work_off = [&]() {
+        for (int j = 0; j < kPendDepth; ++j) {
+            if (j >= npend) continue;
+            const int4 rec = pend[j][lane];
+            if (!worse(worstZ, worstF, __int_as_float(rec.y), rec.x)) continue;
+            out[worstAt] = rec;
+            worstZ = INFINITY;
+            for (int i = 0; i < knum; ++i) {
+                const int2 o = *reinterpret_cast<const int2 *>(out + i);
+                const float zi = __int_as_float(o.y);
+                if (i == 0 || worse(zi, o.x, worstZ, worstF)) { worstZ = zi; worstF = o.x; worstAt = i; }
+            }
+        }
+        npend = 0;
+    };
     auto test = [&](int f, float ax, float ay, float m, float pp, float n, float q, float den, float az, float bz, float cz) {
-        if (nh >= knum) return;
+        if (nh >= knum && !nearest) return;
         const float s_ = px - ax, t = py - ay;
         const float k1 = s_ * q - n * t, k2 = m * t - s_ * pp;
         const float w1 = k1 / den, w2 = k2 / den, w0 = 1 - w1 - w2;
-        if (!(w0 >= 0 && w1 >= 0 && w2 >= 0)) return;
         const float z = (w0 * az + w1 * bz) + w2 * cz;
-        if (!(z >= zmin && z <= zmax)) return;
-        out[nh] = make_int4(f, __float_as_int(z), __float_as_int(w1), __float_as_int(w2));
-        ++nh;
+        if ((w0 >= 0 && w1 >= 0 && w2 >= 0) && (z >= zmin && z <= zmax)) {
+            const int4 rec = make_int4(f, __float_as_int(z), __float_as_int(w1), __float_as_int(w2));
+            if (nh < knum) {
+                out[nh] = rec;
+                if (nh == 0 || worse(z, f, worstZ, worstF)) { worstZ = z; worstF = f; worstAt = nh; }
+                ++nh;
+            } else if (live && knum > 0 && worse(worstZ, worstF, z, f)) {   // full (dead lanes only count as full)
+                pend[npend][lane] = rec;
+                ++npend;
+            }
+        }
+        if (nearest && __any(npend == kPendDepth)) work_off();
     };
     auto face_terms = [&](float2 a, float2 b, float2 c, float &m, float &pp, float &n, float &q, float &den) {
         m = b.x - a.x; pp = b.y - a.y; n = c.x - a.x; q = c.y - a.y;
@@ -354,21 +391,43 @@ __global__ __launch_bounds__(256) void k_pix_raster(const float *__restrict__ pi
         d.az = fz[f * 3]; d.bz = fz[f * 3 + 1]; d.cz = fz[f * 3 + 2];
         return d;
     };
+    // NEAREST records a set (the order of the visits does not matter), so the batches of the list may be walked from either
+    // end: from the end whose faces are nearer, so that the depth culling below can bite.
+    const int nb = (ie - ib + 63) >> 6;
+    bool rev = false;
+    if (nearest && nb > 1) {
+        const int f0 = allFaces ? ib : list[ib], f1 = allFaces ? ie - 1 : list[ie - 1];
+        const float z0 = fmaxf(fz[f0 * 3], fmaxf(fz[f0 * 3 + 1], fz[f0 * 3 + 2])), z1 = fmaxf(fz[f1 * 3], fmaxf(fz[f1 * 3 + 1], fz[f1 * 3 + 2]));
+        rev = z1 > z0;
+    }
+    auto batch_base = [&](int k) { return ib + ((rev ? nb - 1 - k : k) << 6); };
     int fmCur = -1, fmNext = -1;
     Batch cur = {}, nxt = {};
-    if (ib < ie) {
-        fmCur = load_entry(ib + lane);
+    if (nb > 0) {
+        fmCur = load_entry(batch_base(0) + lane);
         cur = load_faces(fmCur);
-        fmNext = load_entry(ib + 64 + lane);
+        if (nb > 1) fmNext = load_entry(batch_base(1) + lane);
     }
-    for (int base = ib; base < ie; base += 64) {
-        if (__all(nh >= knum)) break;
-        if (base + 64 < ie) nxt = load_faces(fmNext);
-        const int fmAfter = load_entry(base + 128 + lane);
+    for (int kb = 0; kb < nb; ++kb) {
+        if (!nearest && __all(nh >= knum)) break;
+        if (kb + 1 < nb) nxt = load_faces(fmNext);
+        const int fmAfter = kb + 2 < nb ? load_entry(batch_base(kb + 2) + lane) : -1;
         const int fm = fmCur;
         const float2 a = cur.a, b = cur.b, c = cur.c;
         const float az = cur.az, bz = cur.bz, cz = cur.cz;
         bool cand = fm >= 0;
+        if (nearest) {
+            // Depth culling: the interpolated z of a covered pixel is a convex combination of the corner depths (weights in
+            // [0, 1] up to rounding), so it cannot exceed their maximum by more than a few ulps of the largest |depth| — a
+            // face whose corners all lie behind the worst record of EVERY lane of the wave can be admitted by none of them.
+            // (Lanes that are not full yet admit anything: -inf.  The bound is refreshed per batch; a stale one is only
+            // less sharp.)
+            float mw = live ? (nh >= knum ? worstZ : -INFINITY) : INFINITY;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) mw = fminf(mw, __shfl_xor(mw, off));
+            const float zhi = fmaxf(az, fmaxf(bz, cz)), zabs = fmaxf(fabsf(az), fmaxf(fabsf(bz), fabsf(cz)));
+            cand = cand && !(zhi + 1e-5f * zabs < mw);               // NaN depths: tested as before
+        }
         if (cand && !allFaces) {                                    // same enlarged box as face_box()
             const float lox = fminf(a.x, fminf(b.x, c.x)), hix = fmaxf(a.x, fmaxf(b.x, c.x));
             const float loy = fminf(a.y, fminf(b.y, c.y)), hiy = fmaxf(a.y, fmaxf(b.y, c.y));
@@ -383,14 +442,15 @@ __global__ __launch_bounds__(256) void k_pix_raster(const float *__restrict__ pi
             const int k = __ffsll((long long)todo) - 1;
             todo &= todo - 1;
             const int f = __builtin_amdgcn_readlane(fm, k);
-            if (je > 0) wide_before(f);
+            if (je > 0 && !nearest) wide_before(f);                   // FIRST: wide faces merged in face order
             test(f, bcast(a.x, k), bcast(a.y, k), bcast(fm_, k), bcast(fpp, k), bcast(fn, k), bcast(fq, k), bcast(fden, k), bcast(az, k),
                  bcast(bz, k), bcast(cz, k));
-            if ((++since & 7) == 0 && __all(nh >= knum)) break;
+            if (!nearest && (++since & 7) == 0 && __all(nh >= knum)) break;
         }
         fmCur = fmNext; cur = nxt; fmNext = fmAfter;
     }
     if (je > 0) wide_before(0x7FFFFFFF);
+    if (nearest) work_off();
     if (live) nhit[p] = nh;
 }
 
@@ -728,11 +788,13 @@ extern "C" size_t deftet_sparse_render_workspace_bytes(int B, int P, int F, int 
     return make_layout(P, F, knum, nullptr, 0).bytes;      // shapes are processed one after another
 }
 
-extern "C" int deftet_sparse_render_fwd_f32(const float *pix, const float *rng, const float *fz, const float *fxy,
-                                            const float *feat, float *out_feat, int64_t *out_face, float *out_w, int B, int P,
-                                            int F, int D, int knum, float eps, void *workspace, size_t wsb, void *stream_)
+extern "C" int deftet_sparse_render_fwd_policy_f32(const float *pix, const float *rng, const float *fz, const float *fxy,
+                                                   const float *feat, float *out_feat, int64_t *out_face, float *out_w, int B, int P,
+                                                   int F, int D, int knum, float eps, int policy, void *workspace, size_t wsb,
+                                                   void *stream_)
 {
     DEFTET_CHECK_ARG(B >= 0 && P >= 0 && F >= 0 && D >= 0 && knum >= 0, "negative size");
+    DEFTET_CHECK_ARG(policy == DEFTET_RASTER_NEAREST || policy == DEFTET_RASTER_FIRST, "unknown saturation policy %d", policy);
     DEFTET_CHECK_ARG((long long)P * knum < 2147483647LL && (long long)F * kMaxTiles < 2147483647LL, "P*knum or F too large");
     if (B == 0 || P == 0 || knum == 0) return DEFTET_OK;
     DEFTET_CHECK_ARG(pix && rng && out_feat && out_face && (F == 0 || (fz && fxy && feat)), "null pointer");
@@ -781,13 +843,21 @@ extern "C" int deftet_sparse_render_fwd_f32(const float *pix, const float *rng, 
             const long long maxChunks = (long long)(P + 63) / 64 + L.nTiles + 1;     // every tile may end with a partial chunk
             DEFTET_LAUNCH(k_pix_raster, dim3((unsigned)((maxChunks + 3) / 4)), dim3(256), st, pb, rb, zb, xb, P, L.nTiles, L.tileStart,
                           (const int *)L.list, L.wide, L.nWide, F, knum, eps, L.hits, L.nhit, (const unsigned *)L.pixOrder,
-                          (const int *)L.pixStart, (const int *)L.chunkStart);
+                          (const int *)L.pixStart, (const int *)L.chunkStart, policy == DEFTET_RASTER_NEAREST ? 1 : 0);
         }
         DEFTET_LAUNCH(k_pix_emit, dim3((P + 3) / 4), dim3(256), st, L.hits, L.nhit, fb, P, D, knum,
                       out_feat + (size_t)b * P * knum * D, (long long *)out_face + (size_t)b * P * knum,
                       out_w ? out_w + (size_t)b * P * knum * 3 : nullptr);
     }
     return DEFTET_OK;
+}
+
+extern "C" int deftet_sparse_render_fwd_f32(const float *pix, const float *rng, const float *fz, const float *fxy,
+                                            const float *feat, float *out_feat, int64_t *out_face, float *out_w, int B, int P,
+                                            int F, int D, int knum, float eps, void *workspace, size_t wsb, void *stream_)
+{
+    return deftet_sparse_render_fwd_policy_f32(pix, rng, fz, fxy, feat, out_feat, out_face, out_w, B, P, F, D, knum, eps,
+                                               DEFTET_RASTER_NEAREST, workspace, wsb, stream_);
 }
 
 extern "C" size_t deftet_sparse_render_bwd_workspace_bytes(int B, int P, int F, int knum)

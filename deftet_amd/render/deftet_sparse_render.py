@@ -14,13 +14,16 @@ from torch.autograd import Function
 from deftet_amd import _lib
 
 
+NEAREST, FIRST = 0, 1     # saturation policy (include/deftet_hip.h: DEFTET_RASTER_NEAREST / DEFTET_RASTER_FIRST)
+
+
 def _f32c(t):
     return t.contiguous().float()
 
 
 class _SparseRender(Function):
     @staticmethod
-    def forward(ctx, pixel_coords, render_ranges, face_vertices_z, face_vertices_image, face_features, knum, eps):
+    def forward(ctx, pixel_coords, render_ranges, face_vertices_z, face_vertices_image, face_features, knum, eps, policy):
         _lib.require_gpu(pixel_coords, render_ranges, face_vertices_z, face_vertices_image, face_features)
         lib = _lib.load()
         pix, rng = _f32c(pixel_coords), _f32c(render_ranges)
@@ -34,10 +37,10 @@ class _SparseRender(Function):
         face = torch.empty(B, P, knum, device=dev, dtype=torch.int64)
         with torch.cuda.device(dev):
             ws = _lib.workspace(dev, lib.deftet_sparse_render_workspace_bytes(B, P, F, knum))
-            _lib.check(lib.deftet_sparse_render_fwd_f32(_lib.ptr(pix), _lib.ptr(rng), _lib.ptr(fz), _lib.ptr(fxy), _lib.ptr(ff),
-                                                        _lib.ptr(feat), _lib.ptr(face), _lib.ptr(None), B, P, F, D, knum, eps,
-                                                        _lib.ptr(ws), ws.numel(), _lib.current_stream(dev)),
-                       "deftet_sparse_render_fwd_f32")
+            _lib.check(lib.deftet_sparse_render_fwd_policy_f32(_lib.ptr(pix), _lib.ptr(rng), _lib.ptr(fz), _lib.ptr(fxy), _lib.ptr(ff),
+                                                               _lib.ptr(feat), _lib.ptr(face), _lib.ptr(None), B, P, F, D, knum, eps,
+                                                               int(policy), _lib.ptr(ws), ws.numel(), _lib.current_stream(dev)),
+                       "deftet_sparse_render_fwd_policy_f32")
         ctx.save_for_backward(pix, fxy, ff, face)
         ctx.eps = eps
         ctx.mark_non_differentiable(face)
@@ -59,13 +62,15 @@ class _SparseRender(Function):
                                                         _lib.ptr(g), _lib.ptr(gxy), _lib.ptr(gff), B, P, F, D, knum, ctx.eps,
                                                         _lib.ptr(ws), ws.numel(), _lib.current_stream(dev)),
                        "deftet_sparse_render_bwd_f32")
-        return None, None, None, gxy, gff, None, None
+        return None, None, None, gxy, gff, None, None, None
 
 
 def deftet_sparse_render(pixel_coords, render_ranges, face_vertices_z, face_vertices_image, face_features,
-                         knum=300, eps=1e-8):
+                         knum=300, eps=1e-8, policy=NEAREST):
     """(pixel_coords [B,P,2], render_ranges [B,P,2] (min,max depth), face_vertices_z [B,F,3],
     face_vertices_image [B,F,3,2], face_features [B,F,3,D]) ->
-    (features [B,P,knum,D] sorted nearest-first, face_idx int64 [B,P,knum], -1 = empty)."""
+    (features [B,P,knum,D] sorted nearest-first, face_idx int64 [B,P,knum], -1 = empty).
+    policy: which covering faces a pixel with more than knum of them records — NEAREST (default: the knum nearest) or
+    FIRST (the first knum in face order); the same result whenever no pixel saturates, as at the reference's call site."""
     return _SparseRender.apply(pixel_coords, render_ranges, face_vertices_z, face_vertices_image, face_features,
-                               int(knum), float(eps))
+                               int(knum), float(eps), int(policy))

@@ -385,13 +385,28 @@ int deftet_nn_index_ragged_f32(const float *queries_bxnx3, const float *points_b
  * diff_render/diftet_6_subdiv/5_rendereq/deftetrneder.py:97-100 (Kaolin itself is not part
  * of the reference tree: parity unpinned). */
 size_t deftet_sparse_render_workspace_bytes(int n_batch, int n_pixel, int n_face, int knum);
-/* out_w (the barycentric weights of every recorded hit) is optional: NULL skips it. */
+/* Which kept faces a pixel RECORDS when more than knum cover it (the output order is always z descending, ties by
+ * ascending face index).  Nothing in the reference tree settles this; at its call site knum = 300 against ~60 covering
+ * faces, where both give the same images.
+ *   NEAREST (default): the knum faces that come first in the output order — what an insertion-sorted list of bounded
+ *                      length keeps; independent of how the faces are numbered.
+ *   FIRST:             the first knum kept faces in ascending face index (rounds 1-2 of this library). */
+#define DEFTET_RASTER_NEAREST 0
+#define DEFTET_RASTER_FIRST 1
+/* out_w (the barycentric weights of every recorded hit) is optional: NULL skips it.
+ * deftet_sparse_render_fwd_f32 = deftet_sparse_render_fwd_policy_f32 with DEFTET_RASTER_NEAREST. */
 int deftet_sparse_render_fwd_f32(const float *pixel_bxpx2, const float *range_bxpx2,
                                  const float *face_z_bxfx3, const float *face_xy_bxfx3x2,
                                  const float *face_feat_bxfx3xd, float *out_feat_bxpxkxd,
                                  int64_t *out_face_bxpxk, float *out_w_bxpxkx3,
                                  int n_batch, int n_pixel, int n_face, int n_feat, int knum, float eps,
                                  void *workspace, size_t workspace_bytes, void *stream);
+int deftet_sparse_render_fwd_policy_f32(const float *pixel_bxpx2, const float *range_bxpx2,
+                                        const float *face_z_bxfx3, const float *face_xy_bxfx3x2,
+                                        const float *face_feat_bxfx3xd, float *out_feat_bxpxkxd,
+                                        int64_t *out_face_bxpxk, float *out_w_bxpxkx3,
+                                        int n_batch, int n_pixel, int n_face, int n_feat, int knum, float eps, int policy,
+                                        void *workspace, size_t workspace_bytes, void *stream);
 /* backward: gradients to face_vertices_image [B,F,3,2] and face_features [B,F,3,D] (both fully
  * overwritten), none to z / pixels — as Kaolin documents.  Hits are grouped by face with one stable radix
  * sort and reduced by a segmented scan; w_bxpxkx3 is not read (the weights are recomputed from the pixel

@@ -245,7 +245,11 @@ def nn_index(queries_bxnx3, points_bxmx3):
 
 
 # --------------------------------------------------------------------------- rasterizer (parity unpinned)
-def sparse_render_fwd(pixel_bxpx2, range_bxpx2, face_z_bxfx3, face_xy_bxfx3x2, face_feat_bxfx3xd, knum=300, eps=1e-8):
+RASTER_NEAREST, RASTER_FIRST = 0, 1     # which kept faces a saturated pixel records (deftet_oracle_render.c header)
+
+
+def sparse_render_fwd(pixel_bxpx2, range_bxpx2, face_z_bxfx3, face_xy_bxfx3x2, face_feat_bxfx3xd, knum=300, eps=1e-8,
+                      policy=RASTER_NEAREST):
     pix, rng = _c(pixel_bxpx2, np.float32), _c(range_bxpx2, np.float32)
     fz, fxy, ff = _c(face_z_bxfx3, np.float32), _c(face_xy_bxfx3x2, np.float32), _c(face_feat_bxfx3xd, np.float32)
     B, P = pix.shape[:2]
@@ -253,8 +257,9 @@ def sparse_render_fwd(pixel_bxpx2, range_bxpx2, face_z_bxfx3, face_xy_bxfx3x2, f
     feat = np.zeros((B, P, knum, D), np.float32)
     face = np.zeros((B, P, knum), np.int64)
     w = np.zeros((B, P, knum, 3), np.float32)
-    lib().oracle_sparse_render_fwd_f32(_p(pix, _f32p), _p(rng, _f32p), _p(fz, _f32p), _p(fxy, _f32p), _p(ff, _f32p),
-                                       _p(feat, _f32p), _p(face, _i64p), _p(w, _f32p), B, P, F, D, int(knum), C.c_float(eps))
+    lib().oracle_sparse_render_fwd_policy_f32(_p(pix, _f32p), _p(rng, _f32p), _p(fz, _f32p), _p(fxy, _f32p), _p(ff, _f32p),
+                                              _p(feat, _f32p), _p(face, _i64p), _p(w, _f32p), B, P, F, D, int(knum), C.c_float(eps),
+                                              int(policy))
     return feat, face, w
 
 

@@ -290,3 +290,70 @@ def test_n3_rebuild_oracle_matches_reference_outputs(name):
         assert np.array_equal(oracle.delete_tet(t, G["weights"], 0.01), G["kept"])
     assert np.array_equal(oracle.tetweights2tetneighbourweights(G["weights"], G["nei"], 1), G["nw1"], equal_nan=True)
     assert np.array_equal(oracle.tetweights2tetneighbourweights(G["weights"], G["nei"], 2), G["nw2"], equal_nan=True)
+
+
+# ---------------------------------------------------------------------------- render-side glue vs the reference's own functions
+def _render_glue():
+    import os
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "render_glue.npz"))
+
+
+def test_alpha_composite_equals_reference_peel2mask():
+    """deftet_amd.render.alpha_composite == peel2mask (5_rendereq/deftetrneder.py:31-64) on the reference-generated
+    fixture (opacities at 0 and 1 included: the clamp; with and without depth layers)."""
+    import torch
+    from deftet_amd.render import alpha_composite
+    g = _render_glue()
+    ims, dep = torch.from_numpy(g["peel_ims"]), torch.from_numpy(g["peel_depth"])
+    c, v, d = alpha_composite(ims, dep)
+    np.testing.assert_allclose(c.numpy(), g["peel_color"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(v.numpy(), g["peel_vis"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(d.numpy(), g["peel_dep"], rtol=1e-6, atol=2e-6)
+    c2, v2, d2 = alpha_composite(ims)
+    assert d2 is None
+    np.testing.assert_allclose(c2.numpy(), g["peel_color_nodepth"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(v2.numpy(), g["peel_vis_nodepth"], rtol=1e-6, atol=1e-6)
+
+
+def test_face_attributes_and_perspective_equal_the_reference():
+    """face_attributes == vertex2face (4_render/vertex2face.py:12-28, exact: a gather); perspective == cameraop.perspective
+    (3_model/cameraop.py:19-33)."""
+    import torch
+    from deftet_amd.render import face_attributes, perspective
+    g = _render_glue()
+    out = face_attributes(torch.from_numpy(g["v2f_features"]), torch.from_numpy(g["v2f_faces"]))
+    assert np.array_equal(out.numpy(), g["v2f_out"])
+    cam, xy = perspective(torch.from_numpy(g["persp_points"]),
+                          (torch.from_numpy(g["persp_rot"]), torch.from_numpy(g["persp_pos"]), torch.from_numpy(g["persp_proj"])))
+    np.testing.assert_allclose(cam.numpy(), g["persp_cam"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(xy.numpy(), g["persp_xy"], rtol=1e-5, atol=1e-6)
+
+
+def test_render_mesh_color_prepares_the_rasterizer_inputs_like_the_reference_call_site():
+    """render_mesh_color around a rasterizer stub: the five arguments it hands the rasterizer equal the ones the
+    reference's rendermeshcolor (5_rendereq/deftetrneder.py:67-113) handed ITS rasterizer, and the composited outputs for
+    the same returned layers are equal — with and without the depth channel."""
+    import torch
+    from deftet_amd.render import render_mesh_color
+    g = _render_glue()
+    t = lambda k: torch.from_numpy(g[k])                     # noqa: E731
+    for tag, depth in (("d", True), ("n", False)):
+        seen = {}
+
+        def stub(xy, rngs, z, img, feat):
+            seen["args"] = (xy, rngs, z, img, feat)
+            return t("rmc_%s_layers" % tag), None
+
+        feat = t("rmc_feat") if depth else t("rmc_feat")[:, :, 1:]
+        col, msk, dp = render_mesh_color(t("rmc_pix"), t("rmc_ranges"), t("rmc_points3d"), t("rmc_points2d"), feat, t("rmc_faces"),
+                                         depth=depth, rasterizer=stub)
+        xy, rngs, z, img, ff = seen["args"]
+        assert np.array_equal(xy.numpy(), g["rmc_pix"]) and np.array_equal(rngs.numpy(), g["rmc_ranges"])
+        assert np.array_equal(z.numpy(), g["rmc_%s_arg_z" % tag]) and np.array_equal(img.numpy(), g["rmc_%s_arg_img" % tag])
+        np.testing.assert_allclose(ff.numpy(), g["rmc_%s_arg_feat" % tag], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(col.numpy(), g["rmc_%s_color" % tag], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(msk.numpy(), g["rmc_%s_mask" % tag], rtol=1e-6, atol=1e-6)
+        if depth:
+            np.testing.assert_allclose(dp.numpy(), g["rmc_d_depth"], rtol=1e-6, atol=2e-6)
+        else:
+            assert dp is None

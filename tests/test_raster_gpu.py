@@ -23,25 +23,53 @@ def projected_grid(res, **kw):
 pixel_grid = grids.pixel_grid
 
 
-def run(pix, rngs, fz, fxy, ff, knum, dev, eps=1e-8):
+NEAREST, FIRST = 0, 1         # saturation policies (include/deftet_hip.h)
+
+
+def run(pix, rngs, fz, fxy, ff, knum, dev, eps=1e-8, policy=NEAREST):
     from deftet_amd.render import deftet_sparse_render
     t = [torch.from_numpy(x).to(dev) for x in (pix, rngs, fz, fxy, ff)]
-    feat, face = deftet_sparse_render(*t, knum=knum, eps=eps)
+    feat, face = deftet_sparse_render(*t, knum=knum, eps=eps, policy=policy)
     torch.cuda.synchronize()
     return feat, face
 
 
+@pytest.mark.parametrize("policy", [NEAREST, FIRST])
 @pytest.mark.parametrize("knum", [4, 64])
-def test_forward_matches_oracle_projected_grid(cuda, oracle, knum):
+def test_forward_matches_oracle_projected_grid(cuda, oracle, knum, policy):
     fz, fxy, ff = projected_grid(8)
     pix, rngs = pixel_grid(40)
     pix = pix * 0.7
-    wf, wface, ww = oracle.sparse_render_fwd(pix, rngs, fz, fxy, ff, knum=knum)
-    feat, face = run(pix, rngs, fz, fxy, ff, knum, cuda)
+    wf, wface, ww = oracle.sparse_render_fwd(pix, rngs, fz, fxy, ff, knum=knum, policy=policy)
+    feat, face = run(pix, rngs, fz, fxy, ff, knum, cuda, policy=policy)
     assert np.array_equal(face.cpu().numpy(), wface)
     assert np.array_equal(feat.cpu().numpy(), wf)
     nh = (wface >= 0).sum(-1)
-    assert nh.max() == knum if knum == 4 else nh.max() > 20      # knum=4 overflows (first-k-by-face-index rule)
+    assert nh.max() == knum if knum == 4 else nh.max() > 20      # knum=4 overflows: the saturation policy decides
+
+
+def test_saturation_policies_differ_only_where_pixels_saturate(cuda, oracle):
+    """NEAREST keeps the knum nearest covering faces, FIRST the first knum in face order: identical rows wherever a pixel
+    has at most knum covering faces, and on saturated pixels NEAREST's record is the head of the unbounded (knum = F)
+    record while FIRST's is the sorted head of the face-order prefix."""
+    fz, fxy, ff = projected_grid(8)
+    pix, rngs = pixel_grid(40)
+    pix = pix * 0.7
+    k = 12
+    full_feat, full_face = run(pix, rngs, fz, fxy, ff, 120, cuda)             # no pixel has 120 covering faces here
+    n_cover = (full_face >= 0).sum(-1)
+    assert n_cover.max().item() < 120 and (n_cover > k).any() and (n_cover <= k).any()
+    near_feat, near_face = run(pix, rngs, fz, fxy, ff, k, cuda, policy=NEAREST)
+    first_feat, first_face = run(pix, rngs, fz, fxy, ff, k, cuda, policy=FIRST)
+    assert torch.equal(near_face, full_face[..., :k]) and torch.equal(near_feat, full_feat[..., :k, :])
+    unsat = n_cover <= k
+    assert torch.equal(first_face[unsat], near_face[unsat]) and torch.equal(first_feat[unsat], near_feat[unsat])
+    sat = ~unsat
+    # FIRST: the k smallest face indices among the covering faces
+    cover = torch.where(full_face >= 0, full_face, torch.full_like(full_face, 1 << 40))
+    smallest = torch.sort(cover, dim=-1).values[..., :k]
+    assert torch.equal(torch.sort(first_face[sat], dim=-1).values, smallest[sat])
+    assert (first_face[sat] != near_face[sat]).any()
 
 
 def test_forward_matches_oracle_adversarial(cuda, oracle):
@@ -68,10 +96,33 @@ def test_forward_matches_oracle_adversarial(cuda, oracle):
     rngs = np.tile(np.array([-1000.0, 0.0], np.float32), (1, P, 1))
     rngs[0, 200:300] = [-3.0, -2.0]                                                                  # narrow depth window
     for knum in (8, 300):
-        wf, wface, ww = oracle.sparse_render_fwd(pix, rngs, fz, fxy, ff, knum=knum)
-        feat, face = run(pix, rngs, fz, fxy, ff, knum, cuda)
-        assert np.array_equal(face.cpu().numpy(), wface)
-        assert np.array_equal(feat.cpu().numpy(), wf, equal_nan=True)
+        for policy in (NEAREST, FIRST):
+            wf, wface, ww = oracle.sparse_render_fwd(pix, rngs, fz, fxy, ff, knum=knum, policy=policy)
+            feat, face = run(pix, rngs, fz, fxy, ff, knum, cuda, policy=policy)
+            assert np.array_equal(face.cpu().numpy(), wface)
+            assert np.array_equal(feat.cpu().numpy(), wf, equal_nan=True)
+
+
+def test_alpha_composite_on_gpu_equals_reference_peel2mask(cuda):
+    """The compositing step on the GPU against the reference-generated fixture (tests/golden/render_glue.npz: peel2mask of
+    5_rendereq/deftetrneder.py:31-64 run on these layers), value and gradient w.r.t. the layers (fp64 autograd of the same
+    expression as the gradient reference)."""
+    import os
+    from deftet_amd.render import alpha_composite
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "render_glue.npz"))
+    ims = torch.from_numpy(g["peel_ims"]).to(cuda).requires_grad_(True)
+    dep = torch.from_numpy(g["peel_depth"]).to(cuda)
+    c, v, d = alpha_composite(ims, dep)
+    np.testing.assert_allclose(c.detach().cpu().numpy(), g["peel_color"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(v.detach().cpu().numpy(), g["peel_vis"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(d.detach().cpu().numpy(), g["peel_dep"], rtol=1e-6, atol=2e-6)
+    w = torch.rand_like(c)
+    (c * w).sum().backward()
+    i64 = ims.detach().double().requires_grad_(True)
+    c64, _, _ = alpha_composite(i64, dep.double())
+    (c64 * w.double()).sum().backward()
+    # (batch 1 only: batch 0 holds opacities AT the clamp, where 1 - (1 - 1e-10) is 0 in fp32 and 1e-10 in fp64)
+    assert (ims.grad[1].double() - i64.grad[1]).abs().max().item() <= 1e-5 * i64.grad[1].abs().max().item()
 
 
 def test_backward_matches_fp64_autograd(cuda, oracle):
