@@ -184,10 +184,12 @@ class RasterWorkload:
         self.dominant_bytes = self.F * 84.0 + self.P * 16.0 + self.P * self.k * 20.0
         self.step_bytes = 2.0 * self.dominant_bytes
         self.last = None
+        # saturation policy (include/deftet_hip.h): 0 = NEAREST (the library default), 1 = FIRST; DEFTET_BENCH_RASTER_POLICY
+        self.policy = int(os.environ.get("DEFTET_BENCH_RASTER_POLICY", "0"))
 
     def step(self, i):
         from deftet_amd.render import deftet_sparse_render
-        feat, face = deftet_sparse_render(*self.t, knum=self.k)
+        feat, face = deftet_sparse_render(*self.t, knum=self.k, policy=self.policy)
         gxy, gff = torch.autograd.grad(feat, (self.t[3], self.t[4]), self.go)
         self.last = (feat, face, gxy, gff)
 
@@ -195,8 +197,9 @@ class RasterWorkload:
         pass
 
     def describe(self):
-        return {"workload": "%s: %d rays x %d faces, k=%d, fwd+bwd, tile binning included; PARITY UNPINNED (Kaolin absent)" % (
-            self.cfg["name"], self.P, self.F, self.k), "n_ray": self.P, "n_face": self.F, "knum": self.k}
+        return {"workload": "%s: %d rays x %d faces, k=%d (%s saturation policy), fwd+bwd, tile binning included; PARITY UNPINNED "
+                            "(Kaolin absent)" % (self.cfg["name"], self.P, self.F, self.k, ["nearest-k", "first-k"][self.policy]),
+                "n_ray": self.P, "n_face": self.F, "knum": self.k}
 
 
 class GeometryWorkload:

@@ -34,7 +34,13 @@ struct Prof {
 std::mutex g_prof_mu;
 }  // namespace
 
-bool prof_match(const char *name) { return g_prof.on && strcmp(name, g_prof.name) == 0; }
+// the selected name matches a kernel of that name and every template instance of it ("k_pix_raster" selects "k_pix_raster<true>")
+bool prof_match(const char *name)
+{
+    if (!g_prof.on) return false;
+    const size_t n = strlen(g_prof.name);
+    return strncmp(name, g_prof.name, n) == 0 && (name[n] == 0 || name[n] == '<');
+}
 
 void prof_begin(hipStream_t st)
 {

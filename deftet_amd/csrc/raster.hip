@@ -171,29 +171,53 @@ __device__ __forceinline__ FaceBox face_box(const float *__restrict__ xy, int f,
 // construction).  Unused pair slots carry the key kPadKey and sort to the end.
 constexpr unsigned kPadKey = 1u << 18;             // > any tile id (kG2Max^2 = 2^18 tiles at most)
 
-__global__ __launch_bounds__(256) void k_face_span(const float *__restrict__ xy, int F, const Grid2 *__restrict__ gp, float eps,
-                                                   int *span, int *isWide)
+// NEAREST binning order: faces by descending depth of their nearest corner (zhi = largest corner z; the camera looks
+// down -z), so that every tile list comes out near-first and the walk of k_pix_raster can stop at the first batch that lies
+// behind every lane's worst record.  key = order-preserving bits of -zhi (ascending sort = descending zhi); a face with a
+// NaN corner sorts first (its depth bound is unknown).  zAbsMax: the largest finite |corner z| (bits, atomicMax), which
+// scales the rounding margin of that stop test.
+__global__ __launch_bounds__(256) void k_face_depth_keys(const float *__restrict__ fz, int F, unsigned *key, unsigned *val, unsigned *zAbsMax)
 {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= F) return;
+    const float a = fz[f * 3], b = fz[f * 3 + 1], c = fz[f * 3 + 2];
+    const bool nan = !(a == a) || !(b == b) || !(c == c);
+    const float zhi = fmaxf(a, fmaxf(b, c));
+    unsigned u = __float_as_uint(-zhi);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);                  // total order of the floats as unsigned
+    key[f] = nan ? 0u : u;
+    val[f] = (unsigned)f;
+    const float m = fmaxf(fabsf(a), fmaxf(fabsf(b), fabsf(c)));
+    if (m < INFINITY) atomicMax(zAbsMax, __float_as_uint(m));        // non-negative floats order like their bits
+}
+
+__global__ __launch_bounds__(256) void k_face_span(const float *__restrict__ xy, int F, const Grid2 *__restrict__ gp, float eps,
+                                                   const unsigned *__restrict__ perm,
+                                                   int *span, int *isWide)
+{
+    // position i of the binning order holds face perm[i] (NEAREST: faces by descending depth) or face i (perm == NULL)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= F) return;
+    const int f = perm ? (int)perm[i] : i;
     const Grid2 g = *gp;
     const FaceBox fb = face_box(xy, f, g, eps);
-    span[f] = fb.mode == 1 ? (fb.tx1 - fb.tx0 + 1) * (fb.ty1 - fb.ty0 + 1) : 0;
-    isWide[f] = fb.mode == 2 ? 1 : 0;
+    span[i] = fb.mode == 1 ? (fb.tx1 - fb.tx0 + 1) * (fb.ty1 - fb.ty0 + 1) : 0;
+    isWide[i] = fb.mode == 2 ? 1 : 0;
 }
 
 __global__ __launch_bounds__(256) void k_face_pairs(const float *__restrict__ xy, int F, const Grid2 *__restrict__ gp, float eps,
                                                     const int *__restrict__ pairOff, const int *__restrict__ wideOff,
-                                                    unsigned *key, unsigned *val, int *wide, int *nWide, long long cap)
+                                                    unsigned *key, unsigned *val, int *wide, int *nWide, long long cap,
+                                                    const unsigned *__restrict__ perm)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < F) {
-        const int f = (int)i;
+        const int f = perm ? (int)perm[i] : (int)i;                  // pairs come out in binning order: the stable sort by tile keeps it
         const Grid2 g = *gp;
         const FaceBox fb = face_box(xy, f, g, eps);
-        if (fb.mode == 2) wide[wideOff[f]] = f;
+        if (fb.mode == 2) wide[wideOff[i]] = f;
         if (fb.mode == 1) {
-            int o = pairOff[f];
+            int o = pairOff[i];
             for (int ty = fb.ty0; ty <= fb.ty1; ++ty)
                 for (int tx = fb.tx0; tx <= fb.tx1; ++tx) {
                     key[o] = (unsigned)(ty * g.gx + tx);
@@ -201,7 +225,7 @@ __global__ __launch_bounds__(256) void k_face_pairs(const float *__restrict__ xy
                     ++o;
                 }
         }
-        if (f == F - 1) *nWide = wideOff[F];
+        if (i == F - 1) *nWide = wideOff[F];
     }
     // pad the unused tail of the pair arrays (grid covers max(F, cap))
     const int used = pairOff[F];
@@ -264,6 +288,12 @@ __global__ __launch_bounds__(256) void k_pix_chunks(const unsigned *__restrict__
 }
 
 struct Hit { int f; float z, w1, w2; };
+#ifdef RAST_STATS        // probe builds only: where k_pix_raster spends its time under the NEAREST policy
+__device__ unsigned long long g_rast_stats[8];
+#define RAST_STAT(i, v) do { const unsigned long long v_ = (unsigned long long)(v); if (lane == 0) atomicAdd(&g_rast_stats[i], v_); } while (0)
+#else
+#define RAST_STAT(i, v)
+#endif
 constexpr int kPendDepth = 4;          // admitted hits a full lane queues before the wave works the queues off (NEAREST)
 
 // One wave per 64 pixels OF ONE TILE: the face list is then the same for every lane, so the wave
@@ -276,13 +306,65 @@ constexpr int kPendDepth = 4;          // admitted hits a full lane queues befor
 // The chunk of NaN/Inf/huge pixels (pseudo-tile nTilesCap) visits every face.
 __device__ __forceinline__ float bcast(float v, int k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k)); }
 
+// a after b in the output order (z descending, then face index ascending)
+__device__ __forceinline__ bool rast_worse(float za, int fa, float zb, int fb) { return za < zb || (za == zb && fa > fb); }
+
+struct Worst { float z; int f, at; };
+
+// NEAREST: the wave works its lanes' queues of admitted hits off together (see k_pix_raster).  Out of line on purpose:
+// inlined at the three places a hit can be queued it grew the kernel sixfold, and the instruction fetch of the hot loop,
+// not the work, became what a wave waited for (1.98 ms against 0.74 ms for FIRST with the same number of tests).
+__device__ __noinline__ Worst rast_work_off(const int4 (*pend)[64], int npend, Worst w, int4 *hits, int p, int knum, int lane)
+{
+    int4 *out = hits + (size_t)p * knum;
+    for (int j = 0; j < kPendDepth; ++j) {
+        int4 rec = make_int4(0, 0, 0, 0);
+        bool go = false;
+        if (j < npend) {
+            rec = pend[j][lane];
+            go = rast_worse(w.z, w.f, __int_as_float(rec.y), rec.x);
+        }
+        if (go) out[w.at] = rec;
+        unsigned long long need = __ballot(go);
+        // The new worst of a lane that replaced: the WAVE reads that lane's knum records (lane i reads record i: one
+        // coalesced request instead of knum dependent ones from a single lane), the record just replaced comes from
+        // registers, and a butterfly finds the worst.
+        while (need) {
+            const int L = __ffsll((long long)need) - 1;
+            need &= need - 1;
+            const int4 *oL = hits + (size_t)__builtin_amdgcn_readlane(p, L) * knum;
+            const int atL = __builtin_amdgcn_readlane(w.at, L);
+            const int newF = __builtin_amdgcn_readlane(rec.x, L);
+            const float newZ = __int_as_float(__builtin_amdgcn_readlane(rec.y, L));
+            float wz = INFINITY;
+            int wf = -1, wat = -1;
+            for (int i = lane; i < knum; i += 64) {
+                const int2 o = *reinterpret_cast<const int2 *>(oL + i);
+                const float zi = i == atL ? newZ : __int_as_float(o.y);
+                const int fi = i == atL ? newF : o.x;
+                if (wat < 0 || rast_worse(zi, fi, wz, wf)) { wz = zi; wf = fi; wat = i; }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const float oz = __shfl_xor(wz, off);
+                const int of = __shfl_xor(wf, off), oat = __shfl_xor(wat, off);
+                if (oat >= 0 && (wat < 0 || rast_worse(oz, of, wz, wf))) { wz = oz; wf = of; wat = oat; }
+            }
+            if (lane == L) { w.z = wz; w.f = wf; w.at = wat; }
+        }
+    }
+    return w;
+}
+
+template <bool nearest>   // the saturation policy: a template argument, so that FIRST carries none of NEAREST's state
 __global__ __launch_bounds__(256) void k_pix_raster(const float *__restrict__ pix, const float *__restrict__ rng,
                                                     const float *__restrict__ fz, const float *__restrict__ fxy, int P,
                                                     int nTilesCap, const int *__restrict__ tileStart,
                                                     const int *__restrict__ list, const int *__restrict__ wide,
                                                     const int *__restrict__ nWide, int F, int knum, float eps, int4 *hits,
                                                     int *nhit, const unsigned *__restrict__ pixOrder,
-                                                    const int *__restrict__ pixStart, const int *__restrict__ chunkStart, int nearest)
+                                                    const int *__restrict__ pixStart, const int *__restrict__ chunkStart,
+                                                    const unsigned *__restrict__ zAbsMax)
 {
     const int lane = threadIdx.x & 63;
     const int W = blockIdx.x * 4 + (threadIdx.x >> 6);              // chunk id (wave-uniform)
@@ -314,27 +396,25 @@ __global__ __launch_bounds__(256) void k_pix_raster(const float *__restrict__ pi
     int4(*pend)[64] = s_pend[threadIdx.x >> 6];
     float worstZ = INFINITY;                                        // the record a better hit would replace
     int worstF = -1, worstAt = 0, npend = 0;
-    auto worse = [](float za, int fa, float zb, int fb) { return za < zb || (za == zb && fa > fb); };   // a after b in the output order
+    auto worse = [](float za, int fa, float zb, int fb) { return rast_worse(za, fa, zb, fb); };
     auto work_off = [&]() {
-        for (int j = 0; j < kPendDepth; ++j) {
-            if (j >= npend) continue;
-            const int4 rec = pend[j][lane];
-            if (!worse(worstZ, worstF, __int_as_float(rec.y), rec.x)) continue;
-            out[worstAt] = rec;
-            worstZ = INFINITY;
-            for (int i = 0; i < knum; ++i) {
-                const int2 o = *reinterpret_cast<const int2 *>(out + i);
-                const float zi = __int_as_float(o.y);
-                if (i == 0 || worse(zi, o.x, worstZ, worstF)) { worstZ = zi; worstF = o.x; worstAt = i; }
-            }
-        }
+        const Worst w = rast_work_off(pend, npend, Worst{worstZ, worstF, worstAt}, hits, p, knum, lane);
+        worstZ = w.z; worstF = w.f; worstAt = w.at;
         npend = 0;
     };
     auto test = [&](int f, float ax, float ay, float m, float pp, float n, float q, float den, float az, float bz, float cz) {
-        if (nh >= knum && !nearest) return;
+        if (!nearest && nh >= knum) return;
         const float s_ = px - ax, t = py - ay;
         const float k1 = s_ * q - n * t, k2 = m * t - s_ * pp;
         const float w1 = k1 / den, w2 = k2 / den, w0 = 1 - w1 - w2;
+        if (!nearest) {                                               // FIRST: the round-2 body, nothing else
+            if (!(w0 >= 0 && w1 >= 0 && w2 >= 0)) return;
+            const float z = (w0 * az + w1 * bz) + w2 * cz;
+            if (!(z >= zmin && z <= zmax)) return;
+            out[nh] = make_int4(f, __float_as_int(z), __float_as_int(w1), __float_as_int(w2));
+            ++nh;
+            return;
+        }
         const float z = (w0 * az + w1 * bz) + w2 * cz;
         if ((w0 >= 0 && w1 >= 0 && w2 >= 0) && (z >= zmin && z <= zmax)) {
             const int4 rec = make_int4(f, __float_as_int(z), __float_as_int(w1), __float_as_int(w2));
@@ -391,15 +471,13 @@ __global__ __launch_bounds__(256) void k_pix_raster(const float *__restrict__ pi
         d.az = fz[f * 3]; d.bz = fz[f * 3 + 1]; d.cz = fz[f * 3 + 2];
         return d;
     };
-    // NEAREST records a set (the order of the visits does not matter), so the batches of the list may be walked from either
-    // end: from the end whose faces are nearer, so that the depth culling below can bite.
+    // NEAREST: the tile lists are in descending order of the faces' nearest corner depth (k_face_depth_keys), so the walk
+    // stops at the first batch whose first face lies behind every lane's worst record — all later faces do as well.  (With
+    // lists in face order the walk had to cover all ~1,700 faces of a tile, and their gathered 36-byte records, not the
+    // tests, were what bounded the kernel: 1.92 ms against 0.92 ms for FIRST at configs[4].)
     const int nb = (ie - ib + 63) >> 6;
-    bool rev = false;
-    if (nearest && nb > 1) {
-        const int f0 = allFaces ? ib : list[ib], f1 = allFaces ? ie - 1 : list[ie - 1];
-        const float z0 = fmaxf(fz[f0 * 3], fmaxf(fz[f0 * 3 + 1], fz[f0 * 3 + 2])), z1 = fmaxf(fz[f1 * 3], fmaxf(fz[f1 * 3 + 1], fz[f1 * 3 + 2]));
-        rev = z1 > z0;
-    }
+    const bool rev = false;
+    const float zMargin = nearest ? 1e-5f * __uint_as_float(*zAbsMax) : 0.f;
     auto batch_base = [&](int k) { return ib + ((rev ? nb - 1 - k : k) << 6); };
     int fmCur = -1, fmNext = -1;
     Batch cur = {}, nxt = {};
@@ -425,6 +503,11 @@ __global__ __launch_bounds__(256) void k_pix_raster(const float *__restrict__ pi
             float mw = live ? (nh >= knum ? worstZ : -INFINITY) : INFINITY;
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) mw = fminf(mw, __shfl_xor(mw, off));
+            if (!allFaces) {                                         // sorted list: nothing from here on can be admitted
+                const bool nanz = !(az == az) || !(bz == bz) || !(cz == cz);     // such faces sort first: no bound from them
+                const float zfirst = bcast(nanz ? INFINITY : fmaxf(az, fmaxf(bz, cz)), 0);
+                if (zfirst + zMargin < mw) break;                    // (a NaN bound compares false: walk on)
+            }
             const float zhi = fmaxf(az, fmaxf(bz, cz)), zabs = fmaxf(fabsf(az), fmaxf(fabsf(bz), fabsf(cz)));
             cand = cand && !(zhi + 1e-5f * zabs < mw);               // NaN depths: tested as before
         }
@@ -437,6 +520,8 @@ __global__ __launch_bounds__(256) void k_pix_raster(const float *__restrict__ pi
         float fm_, fpp, fn, fq, fden;
         face_terms(a, b, c, fm_, fpp, fn, fq, fden);
         unsigned long long todo = __ballot(cand);
+        RAST_STAT(1, 1);                                                // [1] batches of 64 entries
+        RAST_STAT(2, __popcll(todo));                                   // [2] faces broadcast
         int since = 0;
         while (todo) {
             const int k = __ffsll((long long)todo) - 1;
@@ -451,6 +536,8 @@ __global__ __launch_bounds__(256) void k_pix_raster(const float *__restrict__ pi
     }
     if (je > 0) wide_before(0x7FFFFFFF);
     if (nearest) work_off();
+    RAST_STAT(0, 1);                                                    // [0] wave-chunks
+    RAST_STAT(3, __popcll(__ballot(live)));                             // [3] live lanes
     if (live) nhit[p] = nh;
 }
 
@@ -724,7 +811,7 @@ struct Layout {
     float *part, *fpart;
     Grid2 *grid;
     int *tileStart, *wide, *nWide, *span, *isWide, *pairOff, *wideOff, *nhit;
-    unsigned *pkey, *pval, *skey, *list, *xkey, *xval, *xskey, *pixOrder;
+    unsigned *pkey, *pval, *skey, *list, *xkey, *xval, *xskey, *pixOrder, *perm, *zAbsMax;
     int *pixStart, *chunkCount, *chunkStart;
     long long cap;
     int4 *hits;
@@ -760,12 +847,14 @@ static Layout make_layout(int P, int F, int knum, void *ws, size_t wsb)
     L.chunkCount = A.take<int>((size_t)L.nTiles + 3);
     L.chunkStart = A.take<int>((size_t)L.nTiles + 3);
     L.nhit = A.take<int>((size_t)P + 1);
+    L.perm = A.take<unsigned>((size_t)F + 1);
+    L.zAbsMax = A.take<unsigned>(4);
     L.hits = A.take<int4>((size_t)P * knum + 1);
     {
         size_t a1 = 0, a2 = 0, a3 = 0;
         unsigned *u = nullptr;
         int *ip = nullptr;
-        (void)rocprim::radix_sort_pairs(nullptr, a1, u, u, u, u, (size_t)L.cap, 0, 19, (hipStream_t) nullptr);
+        (void)rocprim::radix_sort_pairs(nullptr, a1, u, u, u, u, (size_t)L.cap, 0, 32, (hipStream_t) nullptr);   // also covers the depth sort (F keys)
         (void)rocprim::radix_sort_pairs(nullptr, a2, u, u, u, u, (size_t)P + 1, 0, 21, (hipStream_t) nullptr);
         (void)rocprim::exclusive_scan(nullptr, a3, ip, ip, 0, (size_t)(F > L.nTiles ? F : L.nTiles) + 3, rocprim::plus<int>(), (hipStream_t) nullptr);
         L.tmpBytes = a1 > a2 ? a1 : a2;
@@ -781,6 +870,18 @@ static Layout make_layout(int P, int F, int knum, void *ws, size_t wsb)
 
 using namespace deftet;
 using namespace deftet::rast;
+
+#ifdef RAST_STATS
+extern "C" int deftet_debug_rast_stats(unsigned long long *out8, int reset)
+{
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_rast_stats), sizeof(g_rast_stats)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[8] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_rast_stats), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 extern "C" size_t deftet_sparse_render_workspace_bytes(int B, int P, int F, int knum)
 {
@@ -817,14 +918,22 @@ extern "C" int deftet_sparse_render_fwd_policy_f32(const float *pix, const float
         e = (call);                                                                                \
         if (e != hipSuccess) return set_error(DEFTET_ELAUNCH, "%s: %s", #call, hipGetErrorString(e)); \
     } while (0)
+        const bool nearest = policy == DEFTET_RASTER_NEAREST;
+        const unsigned *perm = nullptr;
+        DEFTET_HIP(hipMemsetAsync(L.zAbsMax, 0, 4, st));
+        if (F > 0 && nearest) {
+            DEFTET_LAUNCH(k_face_depth_keys, dim3((F + 255) / 256), dim3(256), st, zb, F, L.pkey, L.pval, L.zAbsMax);
+            RAST_RP(rocprim::radix_sort_pairs(L.tmp, need, L.pkey, L.skey, L.pval, L.perm, (size_t)F, 0, 32, st));
+            perm = L.perm;
+        }
         if (F > 0) {
-            DEFTET_LAUNCH(k_face_span, dim3((F + 255) / 256), dim3(256), st, xb, F, L.grid, eps, L.span, L.isWide);
+            DEFTET_LAUNCH(k_face_span, dim3((F + 255) / 256), dim3(256), st, xb, F, L.grid, eps, perm, L.span, L.isWide);
             DEFTET_HIP(hipMemsetAsync(L.span + F, 0, 4, st));
             DEFTET_HIP(hipMemsetAsync(L.isWide + F, 0, 4, st));
             RAST_RP(rocprim::exclusive_scan(L.tmp, need, L.span, L.pairOff, 0, (size_t)F + 1, rocprim::plus<int>(), st));
             RAST_RP(rocprim::exclusive_scan(L.tmp, need, L.isWide, L.wideOff, 0, (size_t)F + 1, rocprim::plus<int>(), st));
             DEFTET_LAUNCH(k_face_pairs, dim3((unsigned)((L.cap + 255) / 256)), dim3(256), st, xb, F, L.grid, eps, L.pairOff, L.wideOff, L.pkey,
-                          L.pval, L.wide, L.nWide, L.cap);
+                          L.pval, L.wide, L.nWide, L.cap, perm);
             RAST_RP(rocprim::radix_sort_pairs(L.tmp, need, L.pkey, L.skey, L.pval, L.list, (size_t)L.cap, 0, 19, st));
             DEFTET_LAUNCH(k_tile_starts, dim3((L.nTiles + 256) / 256), dim3(256), st, L.skey, L.cap, L.nTiles, L.tileStart);
         } else {
@@ -841,9 +950,14 @@ extern "C" int deftet_sparse_render_fwd_policy_f32(const float *pix, const float
         if (e != hipSuccess) return set_error(DEFTET_ELAUNCH, "rocprim::exclusive_scan: %s", hipGetErrorString(e));
         {
             const long long maxChunks = (long long)(P + 63) / 64 + L.nTiles + 1;     // every tile may end with a partial chunk
-            DEFTET_LAUNCH(k_pix_raster, dim3((unsigned)((maxChunks + 3) / 4)), dim3(256), st, pb, rb, zb, xb, P, L.nTiles, L.tileStart,
-                          (const int *)L.list, L.wide, L.nWide, F, knum, eps, L.hits, L.nhit, (const unsigned *)L.pixOrder,
-                          (const int *)L.pixStart, (const int *)L.chunkStart, policy == DEFTET_RASTER_NEAREST ? 1 : 0);
+            if (nearest)
+                DEFTET_LAUNCH(k_pix_raster<true>, dim3((unsigned)((maxChunks + 3) / 4)), dim3(256), st, pb, rb, zb, xb, P, L.nTiles, L.tileStart,
+                              (const int *)L.list, L.wide, L.nWide, F, knum, eps, L.hits, L.nhit, (const unsigned *)L.pixOrder,
+                              (const int *)L.pixStart, (const int *)L.chunkStart, (const unsigned *)L.zAbsMax);
+            else
+                DEFTET_LAUNCH(k_pix_raster<false>, dim3((unsigned)((maxChunks + 3) / 4)), dim3(256), st, pb, rb, zb, xb, P, L.nTiles, L.tileStart,
+                              (const int *)L.list, L.wide, L.nWide, F, knum, eps, L.hits, L.nhit, (const unsigned *)L.pixOrder,
+                              (const int *)L.pixStart, (const int *)L.chunkStart, (const unsigned *)L.zAbsMax);
         }
         DEFTET_LAUNCH(k_pix_emit, dim3((P + 3) / 4), dim3(256), st, L.hits, L.nhit, fb, P, D, knum,
                       out_feat + (size_t)b * P * knum * D, (long long *)out_face + (size_t)b * P * knum,
