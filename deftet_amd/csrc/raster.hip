@@ -179,16 +179,21 @@ constexpr unsigned kPadKey = 1u << 18;             // > any tile id (kG2Max^2 = 
 __global__ __launch_bounds__(256) void k_face_depth_keys(const float *__restrict__ fz, int F, unsigned *key, unsigned *val, unsigned *zAbsMax)
 {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= F) return;
-    const float a = fz[f * 3], b = fz[f * 3 + 1], c = fz[f * 3 + 2];
-    const bool nan = !(a == a) || !(b == b) || !(c == c);
-    const float zhi = fmaxf(a, fmaxf(b, c));
-    unsigned u = __float_as_uint(-zhi);
-    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);                  // total order of the floats as unsigned
-    key[f] = nan ? 0u : u;
-    val[f] = (unsigned)f;
-    const float m = fmaxf(fabsf(a), fmaxf(fabsf(b), fabsf(c)));
-    if (m < INFINITY) atomicMax(zAbsMax, __float_as_uint(m));        // non-negative floats order like their bits
+    float m = 0.f;
+    if (f < F) {
+        const float a = fz[f * 3], b = fz[f * 3 + 1], c = fz[f * 3 + 2];
+        const bool nan = !(a == a) || !(b == b) || !(c == c);
+        const float zhi = fmaxf(a, fmaxf(b, c));
+        unsigned u = __float_as_uint(-zhi);
+        u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);              // total order of the floats as unsigned
+        key[f] = nan ? 0u : u;
+        val[f] = (unsigned)f;
+        m = fmaxf(fabsf(a), fmaxf(fabsf(b), fabsf(c)));
+        if (!(m < INFINITY)) m = 0.f;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(zAbsMax, __float_as_uint(m));   // non-negative floats order like their bits
 }
 
 __global__ __launch_bounds__(256) void k_face_span(const float *__restrict__ xy, int F, const Grid2 *__restrict__ gp, float eps,

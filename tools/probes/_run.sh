@@ -1,7 +1,12 @@
 #!/bin/bash
 set -u
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
-timeout 1200 python -m pytest tests/test_raster_gpu.py -q -x 2>&1 | tail -4
-for pol in 0 1; do
-DEFTET_BENCH_RASTER_POLICY=$pol timeout 300 python bench.py --config 4 --no-cpu-baseline --no-other-configs --no-bandwidth-probe 2>/dev/null | python -c "import sys,json; b=json.loads(sys.stdin.read()); print(b['ms_per_step'], b['roofline']['kernel'], b['roofline']['avg_launch_ms'])"
-done
+O=gpurun_out/r3k; mkdir -p $O
+timeout 1800 python -m pytest tests -q -m gpu -x 2>&1 | tail -4
+timeout 600 python bench.py > $O/bench_line.json 2> $O/bench_err.txt
+python - <<'PY'
+import json
+b=json.load(open('gpurun_out/r3k/bench_line.json'))
+print(b['ms_per_step'], b['roofline']['frac'], b['roofline']['avg_launch_ms'], b.get('ms_per_step_hipgraph'))
+for o in b['other_configs']: print(o['config_id'], o['ms_per_step'], o.get('ms_per_step_hipgraph'))
+PY
