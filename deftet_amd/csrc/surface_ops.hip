@@ -1913,7 +1913,8 @@ __global__ __launch_bounds__(kTriChunkWaves * 64) void k_tri_query_coop(const fl
 // 5.2-5.7 ms against 4.8 ms for the plain scan when the 100 k points sit 30 % off a 4,032-face surface.)
 constexpr int kTriSlices = 8;
 constexpr int kTriWaves = 4;
-constexpr int kTriBitWords = 16384;     // LDS bitset: 524,288 faces; beyond that duplicates are simply evaluated again
+constexpr int kTriBitWords = 4096;      // LDS bitset (16 KB): 131,072 faces; beyond that duplicates are simply evaluated again
+static_assert(kTriBitWords * 4 + kTriWaves * 64 * 8 <= 32 * 1024, "k_tri_far_rows: keep the static LDS of the far path small");
 
 struct TriLane {
     float p[3], min_d;
@@ -2316,17 +2317,18 @@ extern "C" int deftet_debug_tri_stats(unsigned long long *out16, int reset)
 
 static int nn_pick_G(int M)
 {
-    // Cells for ~0.5 points each if the cloud filled its bounding box: the clouds of this operator are SURFACE samples, which
-    // leaves ~5-10 points in an occupied cell (round 2 sized for 4 per cell of a volume: ~35 per occupied cell, and the
-    // 3x3x3 neighbourhood every query scans first held ~300 points).  Measured on the geometry step (8 x 97 k points,
-    // 8 x 80 k queries): 3.49 / 3.32 / 3.27 / 3.22 ms per step at 1 / 1.4 / 1.8 / 2.4 x the old cell count per axis.
-    // DEFTET_NN_GSCALE (read once; experiments) scales the cells per axis.
+    // 1.5x the cells per axis that ~4 points per cell of a VOLUME-filling cloud would give (round 2): the clouds of this
+    // operator are surface samples, which leaves ~10 points in an occupied cell (round 2: ~35, and the 3x3x3 neighbourhood
+    // every query scans first held ~300 points).  Measured on the geometry step (8 x 97 k points, 8 x 80 k queries):
+    // 3.49 / 3.32 / 3.27 / 3.22 ms per step at 1 / 1.4 / 1.8 / 2.4 x; a single shape (one call, 80 k queries) 0.32 / 0.29 /
+    // 0.41 / 0.39 ms — finer grids cost a lone call more in rows visited per query than they save in points per row.
+    // DEFTET_NN_GSCALE (read once; experiments) scales the cells per axis further.
     static const double scale = [] {
         const char *e = std::getenv("DEFTET_NN_GSCALE");
         const double v = e ? std::atof(e) : 1.0;
         return v > 0.1 && v < 10.0 ? v : 1.0;
     }();
-    int G = (int)llround(scale * cbrt(2.0 * (double)(M > 0 ? M : 1)));
+    int G = (int)llround(scale * 1.5 * cbrt((double)(M > 0 ? M : 1) / 4.0));
     if (G < 1) G = 1;
     if (G > 160) G = 160;
     return G;

@@ -52,6 +52,45 @@ class TetTopology:
         return _TetGather.apply(vertice_pos, self.tet_idx, self.csr)
 
 
+# Cache of the incidence CSR, per device and index shape, at MODULE level: nn.DataParallel (train_multigpu.py:138)
+# re-replicates the layer every step and discards whatever a replica stored on itself, and scatters a fresh copy of the
+# index tensor.  Fast path: the very same tensor object, unmodified (a reference is kept, so its storage cannot be
+# recycled for another tensor behind our back).  Otherwise the CONTENT is compared with the cached indices (one small
+# kernel + sync; the CSR rebuild it avoids is 40x that) — never address or shape alone.
+_TOPOLOGIES = {}
+_TOPOLOGIES_MAX = 16
+
+
+def _topology_for(tetrahedron_bxfx4, n_vertex):
+    key = (tetrahedron_bxfx4.device, tuple(tetrahedron_bxfx4.shape), int(n_vertex))
+    hit = _TOPOLOGIES.get(key)
+    if hit is not None:
+        topo, src, version = hit
+        same = src is tetrahedron_bxfx4 and version == tetrahedron_bxfx4._version
+        if not same:
+            same = bool(torch.equal(topo.tet_idx, tetrahedron_bxfx4.long()))
+        if same:
+            _TOPOLOGIES[key] = (topo, tetrahedron_bxfx4, tetrahedron_bxfx4._version)
+            return topo
+    if len(_TOPOLOGIES) >= _TOPOLOGIES_MAX:
+        _TOPOLOGIES.pop(next(iter(_TOPOLOGIES)))
+    topo = TetTopology(tetrahedron_bxfx4, n_vertex)
+    _TOPOLOGIES[key] = (topo, tetrahedron_bxfx4, tetrahedron_bxfx4._version)
+    return topo
+
+
+def save_tet_face(tri_fx3x3, f_name):
+    """Triangle soup as an OBJ file: three `v` lines and one `f a c b` line per triangle, `%f` formatting
+    (utils/mesh_utils.py:258-267)."""
+    lines = []
+    for i, t in enumerate(tri_fx3x3):
+        for k in range(3):
+            lines.append('v %f %f %f\n' % (t[k][0], t[k][1], t[k][2]))
+        lines.append('f %d %d %d\n' % (i * 3 + 1, i * 3 + 3, i * 3 + 2))
+    with open(f_name, 'w') as f:
+        f.write(''.join(lines))
+
+
 class DefTet(nn.Module):
     def __init__(self, device=None):
         super(DefTet, self).__init__()
@@ -63,20 +102,7 @@ class DefTet(nn.Module):
 
     # --- N2: tet_bxfx4x3 from vertex positions (deftet.py:65-68)
     def gather_tet_pos(self, vertice_pos, tetrahedron_bxfx4):
-        # Cache of the incidence CSR.  Fast path: the very same index tensor object, unmodified (a reference is
-        # kept, so its storage cannot be recycled for another tensor behind our back).  Otherwise — e.g.
-        # nn.DataParallel scatters a fresh copy every step — the CONTENT is compared with the cached indices
-        # (one small kernel + sync; the CSR rebuild it avoids is 40x that); never address/shape alone.
-        topo = getattr(self, "_topo", None)
-        same = (topo is not None and topo.n_vertex == vertice_pos.shape[1] and self._topo_src is tetrahedron_bxfx4
-                and self._topo_version == tetrahedron_bxfx4._version)
-        if not same and topo is not None and topo.n_vertex == vertice_pos.shape[1] \
-                and topo.tet_idx.shape == tetrahedron_bxfx4.shape and topo.tet_idx.device == tetrahedron_bxfx4.device:
-            same = bool(torch.equal(topo.tet_idx, tetrahedron_bxfx4.long()))
-        if not same:
-            topo = self._topo = TetTopology(tetrahedron_bxfx4, vertice_pos.shape[1])
-        self._topo_src, self._topo_version = tetrahedron_bxfx4, tetrahedron_bxfx4._version
-        return topo.gather(vertice_pos)
+        return _topology_for(tetrahedron_bxfx4, vertice_pos.shape[1]).gather(vertice_pos)
 
     # --- N1: GT occupancy of the tet centroids (deftet.py:33-49)
     def check_tet_inside_sdfs(self, tet_bxfx4x3, mesh_list):
@@ -131,13 +157,17 @@ class DefTet(nn.Module):
     def forward_surface_align(self, vertice_pos, point_pos_bxpx3, tetrahedron_bxfx4=None, mesh_list=None,
                               gt_surface_points=None, tet_face_bxfx3=None, inference=False, pred_occ=None,
                               tet_face_tet_bx4fx2=None, save=False, save_name=None, inference_threshold=0.4):
-        if save:
-            raise NotImplementedError("save=True writes OBJ files through utils/mesh_utils.py (out of scope here)")
         n_shape = vertice_pos.shape[0]
         tet_bxfx4x3 = self.gather_tet_pos(vertice_pos, tetrahedron_bxfx4)
         center_occ = self.check_tet_inside_sdfs(tet_bxfx4x3, mesh_list)                       # [B,T,1], no grad
         face_fx3, face_tet_fx2 = tet_face_bxfx3[0], tet_face_tet_bx4fx2[0]
         boundary = self.get_boundary_index(face_fx3, face_tet_fx2, center_occ.squeeze(dim=-1))
+        if save:
+            # eval.py --save: the ground-truth-occupancy surface of the first five shapes as triangle-soup OBJ files
+            # (deftet.py:72-80, utils/mesh_utils.py:258-267)
+            for idx in range(min(len(boundary), 5)):
+                tri = vertice_pos[idx][boundary[idx].long()]                               # [F,3,3]
+                save_tet_face(tri.detach().cpu().numpy(), save_name + '_device_%d_%d.obj' % (torch.cuda.current_device(), idx))
         inv_v = self.inverse_v.to(tet_bxfx4x3.device)
         volume_variance, amips_energy, edge = self.energies(tet_bxfx4x3, inv_v)
         # The surface terms differ per shape (its own predicted boundary, a different face count).  The reference loops

@@ -193,3 +193,43 @@ def test_bench_eight_ranks_config3_shared_gpu(cuda):
     assert rec["config"]["n_tet"] == 750000 and rec["config"]["batch_per_gpu"] == 8
     by = rec["ms_per_step_by_rank"]
     assert len(by["all"]) == 8 and by["min"] <= by["max"] and abs(by["max"] - rec["ms_per_step"]) < 1e-3
+
+
+def test_forward_surface_align_save_writes_the_reference_obj_files(cuda, oracle, tmp_path):
+    """save=True (eval.py --save): `<save_name>_device_<d>_<i>.obj` for the first five shapes, three `v` lines and one
+    `f a c b` line per boundary triangle in the reference's `%f` format (layers/DefTet/deftet.py:72-80,
+    utils/mesh_utils.py:258-267); and the vertex->tet topology cache is shared across module instances (what a
+    DataParallel replica is)."""
+    from deftet_amd.layers.DefTet import deftet as D
+    B, Q = 2, 500
+    pos0, idx, f3, t2, gt_verts, gt_faces, pts, inv_v = _case(cuda, B, Q)
+    idxB = idx[None].expand(B, -1, -1).contiguous()
+    m = D.DefTet(device=cuda)
+    m.inverse_v = inv_v
+    d = np.random.default_rng(0).standard_normal((B, 2000, 3))
+    gt_pts = torch.from_numpy((0.3 * d / np.linalg.norm(d, axis=-1, keepdims=True)).astype(np.float32)).to(cuda)
+    kw = dict(tetrahedron_bxfx4=idxB, mesh_list=([gt_verts[None]] * B, [gt_faces[None]] * B), gt_surface_points=gt_pts,
+              tet_face_bxfx3=f3[None].expand(B, -1, -1), tet_face_tet_bx4fx2=t2[None].expand(B, -1, -1))
+    with torch.no_grad():
+        out = m.forward_surface_align(pos0, None, save=True, save_name=str(tmp_path / "shape"), **kw)
+    boundary = out[6]
+    for i in range(B):
+        path = tmp_path / ("shape_device_%d_%d.obj" % (torch.cuda.current_device(), i))
+        lines = path.read_text().splitlines()
+        F = boundary[i].shape[0]
+        assert len(lines) == 4 * F and F > 0
+        tri = pos0[i][boundary[i].long()].cpu().numpy()
+        assert lines[0] == 'v %f %f %f' % tuple(tri[0, 0]) and lines[3] == 'f 1 3 2'
+        assert lines[4 * (F - 1) + 3] == 'f %d %d %d' % (3 * F - 2, 3 * F, 3 * F - 1)
+    # a second module instance (a replica) with a fresh copy of the indices reuses the cached topology
+    before = dict(D._TOPOLOGIES)
+    m2 = D.DefTet(device=cuda)
+    t2_ = m2.gather_tet_pos(pos0, idxB.clone())
+    assert torch.equal(t2_, m.gather_tet_pos(pos0, idxB))
+    assert set(D._TOPOLOGIES) == set(before) and all(D._TOPOLOGIES[k][0] is before[k][0] for k in before)
+    # ... and different indices of the same shape replace the entry instead of hitting it
+    other = idxB.clone()
+    other[:, 0] = other[:, 1]
+    m2.gather_tet_pos(pos0, other)
+    key = (other.device, tuple(other.shape), pos0.shape[1])
+    assert D._TOPOLOGIES[key][0] is not before[key][0]
