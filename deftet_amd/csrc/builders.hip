@@ -15,7 +15,7 @@
 
 #include "common.hpp"
 
-#include <rocprim/rocprim.hpp>
+#include "prims.hpp"
 
 namespace deftet {
 namespace bld {
@@ -494,11 +494,7 @@ static int key_bits(u64 max_key)
     return b;
 }
 
-struct MaxOp {
-    __host__ __device__ int operator()(int a, int b) const { return a > b ? a : b; }
-};
-
-// rocPRIM temporary storage is carved from the tail of the caller's workspace
+// temporary storage of the sorts and scans (prims.hpp) is carved from the tail of the caller's workspace
 struct Ws {
     Arena A;
     Ws(void *p, size_t n) : A(p, n) {}
@@ -506,48 +502,30 @@ struct Ws {
     size_t left() const { return A.cap > A.off ? A.cap - A.off : 0; }
 };
 
-#define RP(call)                                                                                  \
-    do {                                                                                           \
-        hipError_t e_ = (call);                                                                    \
-        if (e_ != hipSuccess) return set_error(DEFTET_ELAUNCH, "%s: %s", #call, hipGetErrorString(e_)); \
-    } while (0)
-
 template <typename V>
 static int sort_pairs(Ws &W, const u64 *kin, u64 *kout, const V *vin, V *vout, size_t n, int bits, hipStream_t st)
 {
-    size_t need = 0;
-    RP(rocprim::radix_sort_pairs(nullptr, need, kin, kout, vin, vout, n, 0, bits, st));
-    if (need > W.left()) return set_error(DEFTET_EINVAL, "workspace too small for the sort (%zu more bytes needed)", need - W.left());
-    RP(rocprim::radix_sort_pairs(W.tail(), need, kin, kout, vin, vout, n, 0, bits, st));
-    return DEFTET_OK;
+    void *tmp = W.tail();
+    return prims::radix_sort<u64, V>(kin, kout, vin, vout, n, bits, tmp, W.left(), st);
 }
 
 static int sort_keys(Ws &W, const u64 *kin, u64 *kout, size_t n, int bits, hipStream_t st)
 {
-    size_t need = 0;
-    RP(rocprim::radix_sort_keys(nullptr, need, kin, kout, n, 0, bits, st));
-    if (need > W.left()) return set_error(DEFTET_EINVAL, "workspace too small for the sort (%zu more bytes needed)", need - W.left());
-    RP(rocprim::radix_sort_keys(W.tail(), need, kin, kout, n, 0, bits, st));
-    return DEFTET_OK;
+    void *tmp = W.tail();
+    return prims::radix_sort_keys<u64>(kin, kout, n, bits, tmp, W.left(), st);
 }
 
 template <typename T>
 static int ex_scan(Ws &W, const T *in, T *out, size_t n, hipStream_t st)
 {
-    size_t need = 0;
-    RP(rocprim::exclusive_scan(nullptr, need, in, out, T(0), n, rocprim::plus<T>(), st));
-    if (need > W.left()) return set_error(DEFTET_EINVAL, "workspace too small for the scan");
-    RP(rocprim::exclusive_scan(W.tail(), need, in, out, T(0), n, rocprim::plus<T>(), st));
-    return DEFTET_OK;
+    void *tmp = W.tail();
+    return prims::scan<T, prims::Plus, true>(in, out, n, T(0), prims::Plus(), tmp, W.left(), st);
 }
 
 static int max_scan(Ws &W, const int *in, int *out, size_t n, hipStream_t st)
 {
-    size_t need = 0;
-    RP(rocprim::inclusive_scan(nullptr, need, in, out, n, MaxOp(), st));
-    if (need > W.left()) return set_error(DEFTET_EINVAL, "workspace too small for the scan");
-    RP(rocprim::inclusive_scan(W.tail(), need, in, out, n, MaxOp(), st));
-    return DEFTET_OK;
+    void *tmp = W.tail();
+    return prims::scan<int, prims::Max, false>(in, out, n, (int)0x80000000, prims::Max(), tmp, W.left(), st);
 }
 
 #define TRY(x)                     \
@@ -634,7 +612,7 @@ using namespace deftet;
 using namespace deftet::bld;
 
 // Upper bound of what any builder needs for (n_point, n_tet): our arrays over 12T records
-// plus rocPRIM's double buffers and histograms.
+// plus the sorts' spare buffers and digit tables (prims.hpp).
 extern "C" size_t deftet_builder_workspace_bytes(int n_point, int n_tet)
 {
     size_t n = (size_t)(n_tet > 0 ? n_tet : 0) * 12 + (size_t)(n_point > 0 ? n_point : 0) + 1024;

@@ -22,7 +22,7 @@
 //    silhouette faces, non-finite or huge ones) and faces spanning more than kMaxSpan cells go to a
 //    per-shape list that every point tests; non-finite / huge points test every face.
 #include <cstring>
-#include <rocprim/rocprim.hpp>
+#include "prims.hpp"
 
 #include "common.hpp"
 
@@ -334,10 +334,8 @@ static Layout make_layout(int B, int F, long long nRec, int algo, void *ws, size
         L.cellFill = A.take<int>(nc);
         L.cellStart = A.take<int>(nc);
         L.list = A.take<int>((size_t)nRec * kMaxSpan);
-        size_t need = 0;
-        (void)rocprim::exclusive_scan(nullptr, need, L.cellCount, L.cellStart, 0, nc, rocprim::plus<int>(), (hipStream_t) nullptr);
-        L.scanTmpBytes = need;
-        L.scanTmp = A.take<char>(need);
+        L.scanTmpBytes = prims::scan_temp_bytes<int>(nc);
+        L.scanTmp = A.take<char>(L.scanTmpBytes);
     }
     L.bytes = align_up(A.off, 256);
     return L;
@@ -388,9 +386,10 @@ static int check_sign_run(const float *verts, const int64_t *faces, const int *v
     const dim3 gf((F + 255) / 256, B);
     DEFTET_LAUNCH(k_bin<0>, gf, blk, st, (const signed char *)L.kind, (const float4 *)L.box, (const float *)L.part, pb, F, L.G, L.dom,
                   L.cellCount, (const int *)nullptr, (int *)nullptr, (int *)nullptr, L.counters, L.irreg, L.kind, fOff);
-    size_t need = L.scanTmpBytes;
-    hipError_t e = rocprim::exclusive_scan(L.scanTmp, need, L.cellCount, L.cellStart, 0, nc, rocprim::plus<int>(), st);
-    if (e != hipSuccess) return set_error(DEFTET_ELAUNCH, "rocprim::exclusive_scan: %s", hipGetErrorString(e));
+    {
+        const int rc = prims::scan<int, prims::Plus, true>(L.cellCount, L.cellStart, nc, 0, prims::Plus(), L.scanTmp, L.scanTmpBytes, st);
+        if (rc != DEFTET_OK) return rc;
+    }
     DEFTET_LAUNCH(k_bin<1>, gf, blk, st, (const signed char *)L.kind, (const float4 *)L.box, (const float *)L.part, pb, F, L.G, L.dom,
                   L.cellCount, (const int *)L.cellStart, L.cellFill, L.list, L.counters, L.irreg, L.kind, fOff);
     DEFTET_LAUNCH(k_query, gn, blk, st, points, (const float4 *)L.rec, N, F, L.G, (const float *)L.dom, (const int *)L.cellStart,

@@ -1,0 +1,304 @@
+// prims.hpp — this library's own device-wide primitives for gfx950: stable LSD radix sort (keys / key-value pairs) and
+// prefix scans.  They replace the rocPRIM calls of the builders, the vertex operators, the boundary extraction and
+// check_sign (rounds 1-2): every instantiated rocPRIM sort brought 1-2 MB of kernels into libdeftet_hip.so (20 MB in
+// round 2), and the sorts are part of what this library is supposed to have written itself.
+//
+//   radix_sort<K, V>(kin, kout, vin, vout, n, bits, tmp, tmp_bytes, stream)      K: u32 / u64, V: 4- or 8-byte values, or
+//   radix_sort_keys<K>(kin, kout, n, bits, tmp, tmp_bytes, stream)               keys only; kin is not modified
+//   scan<T, Op, EXCLUSIVE>(in, out, n, identity, tmp, tmp_bytes, stream)         in == out allowed
+//
+// Sort: 8 bits per pass, (bits + 7) / 8 passes.  Per pass: k_rs_hist (LDS histogram of the digit per 2,048-key tile ->
+// hist[digit][tile]), an exclusive scan of that table (= where the keys of (digit, tile) start), k_rs_scatter.  The
+// scatter is stable without atomics: a tile is four waves x eight rounds x 64 lanes in key order; per round the lanes
+// with equal digits find each other with eight ballots (match-any), the first of them advances the wave's own counter
+// of that digit, so a key's rank among the wave's keys of its digit is known after one walk; one pass over the 4 x 256
+// counters turns them into bases (tile offset + counts of the earlier waves) and the second walk places the keys.
+// Temporary storage: one spare key (and value) array for the ping-pong, the two digit tables and the scan's partials —
+// radix_sort_temp_bytes<K, V>(n).
+#pragma once
+#include "common.hpp"
+
+namespace deftet {
+namespace prims {
+
+constexpr int kTileThreads = 256, kTileItems = 8, kTile = kTileThreads * kTileItems;   // 2,048 elements per workgroup
+
+// ---------------------------------------------------------------------------- scans
+struct Plus {
+    template <typename T>
+    __host__ __device__ T operator()(T a, T b) const { return a + b; }
+};
+struct Max {
+    template <typename T>
+    __host__ __device__ T operator()(T a, T b) const { return a > b ? a : b; }
+};
+
+template <typename T, typename Op>
+__device__ __forceinline__ T wave_incl(T v, Op op, int lane)
+{
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const T t = __shfl_up(v, off);
+        if (lane >= off) v = op(v, t);
+    }
+    return v;
+}
+
+// tile totals: part[tile] = op over the tile's elements
+template <typename T, typename Op>
+__global__ __launch_bounds__(kTileThreads) void k_scan_partials(const T *__restrict__ in, size_t n, T identity, Op op, T *part)
+{
+    __shared__ T sh[kTileThreads / 64];
+    const size_t base = (size_t)blockIdx.x * kTile + (size_t)threadIdx.x * kTileItems;
+    T v = identity;
+#pragma unroll
+    for (int k = 0; k < kTileItems; ++k)
+        if (base + k < n) v = op(v, in[base + k]);
+    const int lane = threadIdx.x & 63;
+    v = wave_incl(v, op, lane);
+    if (lane == 63) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        T t = sh[0];
+        for (int w = 1; w < kTileThreads / 64; ++w) t = op(t, sh[w]);
+        part[blockIdx.x] = t;
+    }
+}
+
+// exclusive scan of the tile totals by ONE workgroup (a few thousand tiles at most for the sizes of this library)
+template <typename T, typename Op>
+__global__ __launch_bounds__(1024) void k_scan_spine(T *part, size_t nt, T identity, Op op)
+{
+    __shared__ T sh[16];
+    __shared__ T s_carry;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = identity;
+    __syncthreads();
+    for (size_t base = 0; base < nt; base += 1024) {
+        const size_t i = base + threadIdx.x;
+        const T x = i < nt ? part[i] : identity;
+        const T incl = wave_incl(x, op, lane);
+        if (lane == 63) sh[w] = incl;
+        __syncthreads();
+        T pre = s_carry, tot = identity;
+        for (int k = 0; k < 16; ++k) {
+            if (k < w) pre = op(pre, sh[k]);
+            tot = op(tot, sh[k]);
+        }
+        // exclusive value of element i: carry + earlier waves + earlier lanes
+        const T before = __shfl_up(incl, 1);
+        if (i < nt) part[i] = lane == 0 ? pre : op(pre, before);
+        __syncthreads();
+        if (threadIdx.x == 0) s_carry = op(s_carry, tot);
+        __syncthreads();
+    }
+}
+
+template <typename T, typename Op, bool EXCLUSIVE>
+__global__ __launch_bounds__(kTileThreads) void k_scan_apply(const T *in, T *out, size_t n, T identity, Op op, const T *__restrict__ part)
+{
+    __shared__ T sh[kTileThreads / 64];
+    const size_t base = (size_t)blockIdx.x * kTile + (size_t)threadIdx.x * kTileItems;
+    T x[kTileItems];
+    T v = identity;
+#pragma unroll
+    for (int k = 0; k < kTileItems; ++k) {
+        x[k] = base + k < n ? in[base + k] : identity;
+        v = op(v, x[k]);
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const T incl = wave_incl(v, op, lane);
+    if (lane == 63) sh[w] = incl;
+    __syncthreads();
+    T run = part[blockIdx.x];
+    for (int k = 0; k < w; ++k) run = op(run, sh[k]);
+    const T before = __shfl_up(incl, 1);
+    if (lane > 0) run = op(run, before);
+#pragma unroll
+    for (int k = 0; k < kTileItems; ++k) {
+        if (EXCLUSIVE) {
+            if (base + k < n) out[base + k] = run;
+            run = op(run, x[k]);
+        } else {
+            run = op(run, x[k]);
+            if (base + k < n) out[base + k] = run;
+        }
+    }
+}
+
+inline size_t scan_tiles(size_t n) { return (n + kTile - 1) / kTile; }
+template <typename T>
+inline size_t scan_temp_bytes(size_t n) { return align_up((scan_tiles(n) + 1) * sizeof(T), 256); }
+
+template <typename T, typename Op, bool EXCLUSIVE>
+int scan(const T *in, T *out, size_t n, T identity, Op op, void *tmp, size_t tmp_bytes, hipStream_t st)
+{
+    if (n == 0) return DEFTET_OK;
+    if (!tmp || tmp_bytes < scan_temp_bytes<T>(n)) return set_error(DEFTET_EINVAL, "scan: temporary storage too small");
+    T *part = static_cast<T *>(tmp);
+    const size_t nt = scan_tiles(n);
+    if (nt > 0x7FFFFFFFull) return set_error(DEFTET_ELIMIT, "scan: too many elements");
+    DEFTET_LAUNCH((k_scan_partials<T, Op>), dim3((unsigned)nt), dim3(kTileThreads), st, in, n, identity, op, part);
+    DEFTET_LAUNCH((k_scan_spine<T, Op>), dim3(1), dim3(1024), st, part, nt, identity, op);
+    DEFTET_LAUNCH((k_scan_apply<T, Op, EXCLUSIVE>), dim3((unsigned)nt), dim3(kTileThreads), st, in, out, n, identity, op, (const T *)part);
+    return DEFTET_OK;
+}
+
+// ---------------------------------------------------------------------------- radix sort
+// where a pass reads its keys / values from: an array, or (first pass only) anything indexable — e.g. keys derived from
+// another tensor, or the identity as values — so that such inputs need not be written out first
+template <typename T>
+struct PtrLoad {
+    const T *p;
+    __device__ __forceinline__ T operator()(size_t i) const { return p[i]; }
+};
+struct IotaLoad {
+    __device__ __forceinline__ unsigned operator()(size_t i) const { return (unsigned)i; }
+};
+
+// n_dev (may be NULL): the number of elements actually present, known on the device only (n is then the capacity the
+// grid is sized for); workgroups beyond it find nothing to do, so the cost follows the real count.
+template <typename K, typename KL>
+__global__ __launch_bounds__(kTileThreads) void k_rs_hist(KL keys, size_t n, int shift, unsigned nblk, unsigned *hist,
+                                                          const int *__restrict__ n_dev)
+{
+    if (n_dev) n = min(n, (size_t)max(*n_dev, 0));
+    __shared__ unsigned h[256];
+    h[threadIdx.x] = 0u;
+    __syncthreads();
+    const size_t base = (size_t)blockIdx.x * kTile;
+#pragma unroll
+    for (int k = 0; k < kTileItems; ++k) {
+        const size_t i = base + (size_t)k * kTileThreads + threadIdx.x;
+        if (i < n) atomicAdd(&h[(unsigned)(keys(i) >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    hist[(size_t)threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];
+}
+
+template <typename K, typename V, bool HAS_V, typename KL, typename VL>
+__global__ __launch_bounds__(kTileThreads) void k_rs_scatter(KL kin, K *kout, VL vin, V *vout, size_t n,
+                                                             int shift, unsigned nblk, const unsigned *__restrict__ offs,
+                                                             const int *__restrict__ n_dev)
+{
+    if (n_dev) n = min(n, (size_t)max(*n_dev, 0));
+    if ((size_t)blockIdx.x * kTile >= n) return;
+    __shared__ unsigned cnt[kTileThreads / 64][256];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < kTileThreads / 64; ++k) cnt[k][threadIdx.x] = 0u;
+    __syncthreads();
+    // wave w owns the tile's keys [w * 512, (w + 1) * 512) in rounds of 64: tile order = (wave, round, lane)
+    const size_t base = (size_t)blockIdx.x * kTile + (size_t)w * (kTileItems * 64);
+    K key[kTileItems];
+    unsigned dig[kTileItems], rank[kTileItems];
+#pragma unroll
+    for (int r = 0; r < kTileItems; ++r) {
+        const size_t i = base + (size_t)r * 64 + lane;
+        const bool valid = i < n;
+        key[r] = valid ? kin(i) : K(0);
+        const unsigned d = (unsigned)(key[r] >> shift) & 255u;
+        dig[r] = d;
+        unsigned long long m = __ballot(valid);                     // lanes of this round with MY digit (match-any by ballots)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const bool bit = (d >> b) & 1u;
+            const unsigned long long bal = __ballot(bit);
+            m &= bit ? bal : ~bal;
+        }
+        const unsigned below = __popcll(m & ((1ull << lane) - 1ull));
+        const unsigned seen = cnt[w][d];                            // keys of digit d in the wave's earlier rounds
+        rank[r] = seen + below;
+        if (valid && below == 0u) cnt[w][d] = seen + (unsigned)__popcll(m);   // one lane per distinct digit, after every lane has read
+    }
+    __syncthreads();
+    {   // counts -> bases: (digit, tile) start from the scanned table, then the earlier waves of the tile
+        const unsigned d = threadIdx.x;
+        unsigned run = offs[(size_t)d * nblk + blockIdx.x];
+#pragma unroll
+        for (int k = 0; k < kTileThreads / 64; ++k) {
+            const unsigned t = cnt[k][d];
+            cnt[k][d] = run;
+            run += t;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kTileItems; ++r) {
+        const size_t i = base + (size_t)r * 64 + lane;
+        if (i < n) {
+            const size_t pos = (size_t)cnt[w][dig[r]] + rank[r];
+            kout[pos] = key[r];
+            if (HAS_V) vout[pos] = vin(i);
+        }
+    }
+}
+
+template <typename K, typename V>
+inline size_t radix_sort_temp_bytes(size_t n, bool has_values = true)
+{
+    const size_t nblk = (n + kTile - 1) / kTile;
+    return align_up(n * sizeof(K), 256) + (has_values ? align_up(n * sizeof(V), 256) : 0) + 2 * align_up(256 * nblk * 4 + 4, 256) +
+           scan_temp_bytes<unsigned>(256 * nblk) + 256;
+}
+
+template <typename K, typename V, bool HAS_V, typename KL, typename VL>
+int radix_sort_impl(KL kin, K *kout, VL vin, V *vout, size_t n, int bits, void *tmp, size_t tmp_bytes, hipStream_t st, const int *n_dev = nullptr)
+{
+    if (n == 0) return DEFTET_OK;
+    if (n > 0xFFFFFFFFull) return set_error(DEFTET_ELIMIT, "radix_sort: more than 2^32 - 1 elements");
+    if (!tmp || ((uintptr_t)tmp & 255) != 0 || tmp_bytes < radix_sort_temp_bytes<K, V>(n, HAS_V))
+        return set_error(DEFTET_EINVAL, "radix_sort: temporary storage missing, misaligned or too small");
+    const int passes = bits <= 0 ? 1 : (bits + 7) / 8;
+    const unsigned nblk = (unsigned)((n + kTile - 1) / kTile);
+    Arena A(tmp, tmp_bytes);
+    K *tk = A.take<K>(n);
+    V *tv = HAS_V ? A.take<V>(n) : nullptr;
+    unsigned *hist = A.take<unsigned>((size_t)256 * nblk + 1), *offs = A.take<unsigned>((size_t)256 * nblk + 1);
+    void *stmp = A.take<char>(scan_temp_bytes<unsigned>((size_t)256 * nblk));
+    const size_t stmp_bytes = scan_temp_bytes<unsigned>((size_t)256 * nblk);
+    const K *sk = nullptr;
+    const V *sv = nullptr;
+    for (int p = 0; p < passes; ++p) {
+        const bool to_out = ((passes - 1 - p) & 1) == 0;            // the last pass lands in kout / vout
+        K *dk = to_out ? kout : tk;
+        V *dv = to_out ? vout : tv;
+        if (p == 0) DEFTET_LAUNCH((k_rs_hist<K, KL>), dim3(nblk), dim3(kTileThreads), st, kin, n, 0, nblk, hist, n_dev);
+        else DEFTET_LAUNCH((k_rs_hist<K, PtrLoad<K>>), dim3(nblk), dim3(kTileThreads), st, PtrLoad<K>{sk}, n, p * 8, nblk, hist, n_dev);
+        const int rc = scan<unsigned, Plus, true>(hist, offs, (size_t)256 * nblk, 0u, Plus(), stmp, stmp_bytes, st);
+        if (rc != DEFTET_OK) return rc;
+        if (p == 0)
+            DEFTET_LAUNCH((k_rs_scatter<K, V, HAS_V, KL, VL>), dim3(nblk), dim3(kTileThreads), st, kin, dk, vin, dv, n, 0, nblk, (const unsigned *)offs,
+                          n_dev);
+        else
+            DEFTET_LAUNCH((k_rs_scatter<K, V, HAS_V, PtrLoad<K>, PtrLoad<V>>), dim3(nblk), dim3(kTileThreads), st, PtrLoad<K>{sk}, dk, PtrLoad<V>{sv},
+                          dv, n, p * 8, nblk, (const unsigned *)offs, n_dev);
+        sk = dk;
+        sv = dv;
+    }
+    return DEFTET_OK;
+}
+
+template <typename K, typename V>
+int radix_sort(const K *kin, K *kout, const V *vin, V *vout, size_t n, int bits, void *tmp, size_t tmp_bytes, hipStream_t st,
+               const int *n_dev = nullptr)
+{
+    static_assert(sizeof(V) == 4 || sizeof(V) == 8, "values of 4 or 8 bytes");
+    return radix_sort_impl<K, V, true>(PtrLoad<K>{kin}, kout, PtrLoad<V>{vin}, vout, n, bits, tmp, tmp_bytes, st, n_dev);
+}
+
+// the same with the first pass reading its keys / values through loaders (see PtrLoad / IotaLoad)
+template <typename K, typename V, typename KL, typename VL>
+int radix_sort_from(KL kin, K *kout, VL vin, V *vout, size_t n, int bits, void *tmp, size_t tmp_bytes, hipStream_t st)
+{
+    return radix_sort_impl<K, V, true, KL, VL>(kin, kout, vin, vout, n, bits, tmp, tmp_bytes, st);
+}
+
+template <typename K>
+int radix_sort_keys(const K *kin, K *kout, size_t n, int bits, void *tmp, size_t tmp_bytes, hipStream_t st)
+{
+    return radix_sort_impl<K, unsigned, false>(PtrLoad<K>{kin}, kout, PtrLoad<unsigned>{nullptr}, (unsigned *)nullptr, n, bits, tmp, tmp_bytes, st);
+}
+
+}  // namespace prims
+}  // namespace deftet

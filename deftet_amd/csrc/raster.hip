@@ -27,7 +27,7 @@
 
 #include "common.hpp"
 
-#include <rocprim/rocprim.hpp>
+#include "prims.hpp"
 
 namespace deftet {
 namespace rast {
@@ -166,7 +166,7 @@ __device__ __forceinline__ FaceBox face_box(const float *__restrict__ xy, int f,
 // Tile lists WITHOUT atomics and without a per-tile sort (round-1 history: atomic count + atomic
 // fill + a bitonic sort per tile = 0.58 + 0.59 + 1.71 ms at configs[4]): every face reports how
 // many tiles it overlaps, an exclusive scan turns that into pair offsets, the (tile, face) pairs
-// are written in ascending face order and ONE stable radix sort by tile (rocPRIM, 19 key bits)
+// are written in ascending face order and ONE stable radix sort by tile (prims.hpp, 19 key bits)
 // leaves every tile's faces ascending.  The wide list is a stream compaction (ascending by
 // construction).  Unused pair slots carry the key kPadKey and sort to the end.
 constexpr unsigned kPadKey = 1u << 18;             // > any tile id (kG2Max^2 = 2^18 tiles at most)
@@ -239,10 +239,12 @@ __global__ __launch_bounds__(256) void k_face_pairs(const float *__restrict__ xy
 
 // tileStart[t] = first sorted position whose key is >= t (binary search, one lane per tile;
 // a boundary scan would leave one lane writing the whole run of empty tiles)
-__global__ __launch_bounds__(256) void k_tile_starts(const unsigned *__restrict__ skey, long long n, int nTilesCap, int *tileStart)
+__global__ __launch_bounds__(256) void k_tile_starts(const unsigned *__restrict__ skey, const int *__restrict__ nUsed, int nTilesCap,
+                                                     int *tileStart)
 {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t > nTilesCap) return;
+    const long long n = *nUsed;                                    // the pairs really produced (only those were sorted)
     long long lo = 0, hi = n;                                      // first i in [0,n] with skey[i] >= t
     while (lo < hi) {
         const long long mid = (lo + hi) >> 1;
@@ -583,9 +585,9 @@ __global__ __launch_bounds__(256) void k_pix_emit(const int4 *__restrict__ hits,
 }
 
 // ---------------------------------------------------------------------------- backward
-// Hits are grouped by face with ONE stable radix sort of (face, slot) pairs: the keys are read straight
-// from face_idx through a transform iterator (empty slots get the padding key F and sort to the end),
-// the values come from a counting iterator.  Then one lane per SORTED hit (k_bwd_sorted): the slot list
+// Hits are grouped by face with ONE stable radix sort of (face, slot) pairs (prims.hpp): the first pass reads its keys
+// straight from face_idx through a loader (empty slots get the padding key F and sort to the end) and takes the slot
+// index as value.  Then one lane per SORTED hit (k_bwd_sorted): the slot list
 // is read coalesced, the hit's pixel and output gradient are the only divergent gathers (the face data of
 // neighbouring lanes coincide), the barycentric weights are recomputed exactly as the forward computed
 // them, and the per-hit contributions are combined by a segmented scan across the wave (DPP moves) and a
@@ -597,12 +599,16 @@ __global__ __launch_bounds__(256) void k_pix_emit(const int4 *__restrict__ hits,
 // + one lane per face chasing them 0.45 + 2.12 ms (a chain of dependent, fully divergent gathers); sorted
 // hits with ds_bpermute shuffles 1.07 ms (LDS pipe); DPP moves 0.89 ms; wave-local runs flushed with 36
 // float atomics per wave -> carried through LDS instead: 0.46 ms.  The sort itself costs 0.49 ms.
-struct FaceKey {
+// first-pass key loader of the hit sort: the face of slot i straight from face_idx (empty slots get the padding key F)
+struct FaceKeyLoad {
+    const long long *face;
     int F;
-    __host__ __device__ unsigned operator()(long long f) const { return (f >= 0 && f < (long long)F) ? (unsigned)f : (unsigned)F; }
+    __device__ __forceinline__ unsigned operator()(size_t i) const
+    {
+        const long long f = face[i];
+        return (f >= 0 && f < (long long)F) ? (unsigned)f : (unsigned)F;
+    }
 };
-using KeyIter = rocprim::transform_iterator<const long long *, FaceKey, unsigned>;
-using ValIter = rocprim::counting_iterator<unsigned>;
 
 constexpr int kDChunk = 4;
 
@@ -803,8 +809,7 @@ static BwdLayout make_bwd_layout(int P, int F, int knum, void *ws, size_t wsb)
     L.sval = A.take<unsigned>(n + 1);
     L.bits = 1;
     while (L.bits < 32 && (1ull << L.bits) <= (unsigned long long)F) ++L.bits;       // keys are 0..F inclusive
-    (void)rocprim::radix_sort_pairs(nullptr, L.tmpBytes, KeyIter(nullptr, FaceKey{F}), (unsigned *)nullptr, ValIter(0u), (unsigned *)nullptr,
-                                    n, 0, L.bits, (hipStream_t) nullptr);
+    L.tmpBytes = prims::radix_sort_temp_bytes<unsigned, unsigned>(n);
     L.tmp = A.take<char>(L.tmpBytes);
     L.bytes = align_up(A.off, 256);
     return L;
@@ -855,13 +860,10 @@ static Layout make_layout(int P, int F, int knum, void *ws, size_t wsb)
     L.perm = A.take<unsigned>((size_t)F + 1);
     L.zAbsMax = A.take<unsigned>(4);
     L.hits = A.take<int4>((size_t)P * knum + 1);
-    {
-        size_t a1 = 0, a2 = 0, a3 = 0;
-        unsigned *u = nullptr;
-        int *ip = nullptr;
-        (void)rocprim::radix_sort_pairs(nullptr, a1, u, u, u, u, (size_t)L.cap, 0, 32, (hipStream_t) nullptr);   // also covers the depth sort (F keys)
-        (void)rocprim::radix_sort_pairs(nullptr, a2, u, u, u, u, (size_t)P + 1, 0, 21, (hipStream_t) nullptr);
-        (void)rocprim::exclusive_scan(nullptr, a3, ip, ip, 0, (size_t)(F > L.nTiles ? F : L.nTiles) + 3, rocprim::plus<int>(), (hipStream_t) nullptr);
+    {   // temporary storage of the sorts and scans (prims.hpp): the largest of them
+        const size_t a1 = prims::radix_sort_temp_bytes<unsigned, unsigned>((size_t)L.cap);
+        const size_t a2 = prims::radix_sort_temp_bytes<unsigned, unsigned>((size_t)P + 1);
+        const size_t a3 = prims::scan_temp_bytes<int>((size_t)(F > L.nTiles ? F : L.nTiles) + 3);
         L.tmpBytes = a1 > a2 ? a1 : a2;
         if (a3 > L.tmpBytes) L.tmpBytes = a3;
     }
@@ -915,44 +917,43 @@ extern "C" int deftet_sparse_render_fwd_policy_f32(const float *pix, const float
         DEFTET_LAUNCH(k_pix_bbox, dim3(kBoxBlocks), dim3(256), st, pb, P, L.part);
         DEFTET_LAUNCH(k_face_stats, dim3(kBoxBlocks), dim3(256), st, xb, F, L.fpart);
         DEFTET_LAUNCH(k_pix_grid, dim3(1), dim3(64), st, L.part, L.fpart, L.grid);
-        size_t need = L.tmpBytes;
-        hipError_t e;
-#define RAST_RP(call)                                                                              \
-    do {                                                                                           \
-        need = L.tmpBytes;                                                                         \
-        e = (call);                                                                                \
-        if (e != hipSuccess) return set_error(DEFTET_ELAUNCH, "%s: %s", #call, hipGetErrorString(e)); \
+#define RAST_TRY(call)                     \
+    do {                                   \
+        const int rc_ = (call);            \
+        if (rc_ != DEFTET_OK) return rc_;  \
     } while (0)
         const bool nearest = policy == DEFTET_RASTER_NEAREST;
         const unsigned *perm = nullptr;
         DEFTET_HIP(hipMemsetAsync(L.zAbsMax, 0, 4, st));
         if (F > 0 && nearest) {
             DEFTET_LAUNCH(k_face_depth_keys, dim3((F + 255) / 256), dim3(256), st, zb, F, L.pkey, L.pval, L.zAbsMax);
-            RAST_RP(rocprim::radix_sort_pairs(L.tmp, need, L.pkey, L.skey, L.pval, L.perm, (size_t)F, 0, 32, st));
+            RAST_TRY((prims::radix_sort<unsigned, unsigned>(L.pkey, L.skey, L.pval, L.perm, (size_t)F, 32, L.tmp, L.tmpBytes, st)));
             perm = L.perm;
         }
         if (F > 0) {
             DEFTET_LAUNCH(k_face_span, dim3((F + 255) / 256), dim3(256), st, xb, F, L.grid, eps, perm, L.span, L.isWide);
             DEFTET_HIP(hipMemsetAsync(L.span + F, 0, 4, st));
             DEFTET_HIP(hipMemsetAsync(L.isWide + F, 0, 4, st));
-            RAST_RP(rocprim::exclusive_scan(L.tmp, need, L.span, L.pairOff, 0, (size_t)F + 1, rocprim::plus<int>(), st));
-            RAST_RP(rocprim::exclusive_scan(L.tmp, need, L.isWide, L.wideOff, 0, (size_t)F + 1, rocprim::plus<int>(), st));
+            RAST_TRY((prims::scan<int, prims::Plus, true>(L.span, L.pairOff, (size_t)F + 1, 0, prims::Plus(), L.tmp, L.tmpBytes, st)));
+            RAST_TRY((prims::scan<int, prims::Plus, true>(L.isWide, L.wideOff, (size_t)F + 1, 0, prims::Plus(), L.tmp, L.tmpBytes, st)));
             DEFTET_LAUNCH(k_face_pairs, dim3((unsigned)((L.cap + 255) / 256)), dim3(256), st, xb, F, L.grid, eps, L.pairOff, L.wideOff, L.pkey,
                           L.pval, L.wide, L.nWide, L.cap, perm);
-            RAST_RP(rocprim::radix_sort_pairs(L.tmp, need, L.pkey, L.skey, L.pval, L.list, (size_t)L.cap, 0, 19, st));
-            DEFTET_LAUNCH(k_tile_starts, dim3((L.nTiles + 256) / 256), dim3(256), st, L.skey, L.cap, L.nTiles, L.tileStart);
+            // stable sort of the (tile, face) pairs by tile — of the pairs really produced (pairOff[F], known on the device
+            // only): the workgroups beyond that count find nothing to do (rounds 1-2 sorted the whole F * 16 capacity)
+            RAST_TRY((prims::radix_sort<unsigned, unsigned>(L.pkey, L.skey, L.pval, L.list, (size_t)L.cap, 19, L.tmp, L.tmpBytes, st,
+                                                            (const int *)(L.pairOff + F))));
+            DEFTET_LAUNCH(k_tile_starts, dim3((L.nTiles + 256) / 256), dim3(256), st, (const unsigned *)L.skey, (const int *)(L.pairOff + F), L.nTiles,
+                          L.tileStart);
         } else {
             DEFTET_HIP(hipMemsetAsync(L.tileStart, 0, ((size_t)L.nTiles + 2) * 4, st));
             DEFTET_HIP(hipMemsetAsync(L.nWide, 0, 16, st));
         }
         DEFTET_LAUNCH(k_pix_keys, dim3((P + 255) / 256), dim3(256), st, pb, P, L.grid, L.xkey, L.xval);
-        RAST_RP(rocprim::radix_sort_pairs(L.tmp, need, L.xkey, L.xskey, L.xval, L.pixOrder, (size_t)P, 0, 21, st));
-#undef RAST_RP
+        RAST_TRY((prims::radix_sort<unsigned, unsigned>(L.xkey, L.xskey, L.xval, L.pixOrder, (size_t)P, 21, L.tmp, L.tmpBytes, st)));
         DEFTET_LAUNCH(k_pix_chunks, dim3((L.nTiles + 2 + 255) / 256), dim3(256), st, (const unsigned *)L.xskey, P, L.nTiles, L.pixStart,
                       L.chunkCount);
-        need = L.tmpBytes;
-        e = rocprim::exclusive_scan(L.tmp, need, L.chunkCount, L.chunkStart, 0, (size_t)L.nTiles + 2, rocprim::plus<int>(), st);
-        if (e != hipSuccess) return set_error(DEFTET_ELAUNCH, "rocprim::exclusive_scan: %s", hipGetErrorString(e));
+        RAST_TRY((prims::scan<int, prims::Plus, true>(L.chunkCount, L.chunkStart, (size_t)L.nTiles + 2, 0, prims::Plus(), L.tmp, L.tmpBytes, st)));
+#undef RAST_TRY
         {
             const long long maxChunks = (long long)(P + 63) / 64 + L.nTiles + 1;     // every tile may end with a partial chunk
             if (nearest)
@@ -1005,10 +1006,11 @@ extern "C" int deftet_sparse_render_bwd_f32(const float *pix, const float *fxy, 
     BwdLayout L = make_bwd_layout(P, F, knum, workspace, wsb);
     DEFTET_CHECK_ARG(L.bytes <= wsb, "backward workspace too small: need %zu bytes, got %zu", L.bytes, wsb);
     for (int b = 0; b < B; ++b) {
-        size_t need = L.tmpBytes;
-        const hipError_t e = rocprim::radix_sort_pairs(L.tmp, need, KeyIter((const long long *)face_idx + (size_t)b * n, FaceKey{F}), L.skey,
-                                                       ValIter(0u), L.sval, (size_t)n, 0, L.bits, st);
-        if (e != hipSuccess) return set_error(DEFTET_ELAUNCH, "rocprim::radix_sort_pairs: %s", hipGetErrorString(e));
+        {
+            const int rc = prims::radix_sort_from<unsigned, unsigned>(FaceKeyLoad{(const long long *)face_idx + (size_t)b * n, F}, L.skey,
+                                                                      prims::IotaLoad(), L.sval, (size_t)n, L.bits, L.tmp, L.tmpBytes, st);
+            if (rc != DEFTET_OK) return rc;
+        }
 #define RAST_BWD(DT)                                                                                                                  \
     DEFTET_LAUNCH(k_bwd_sorted<DT>, dim3((unsigned)((n + kBwdWaves * 64 - 1) / (kBwdWaves * 64))), dim3(kBwdWaves * 64), st, pix + (size_t)b * P * 2, fxy + (size_t)b * F * 6, \
                   feat + (size_t)b * F * 3 * D, gout + (size_t)b * n * D, (const unsigned *)L.skey, (const unsigned *)L.sval, n, F, D,   \

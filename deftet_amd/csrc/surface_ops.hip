@@ -18,7 +18,7 @@
 
 #include "common.hpp"
 
-#include <rocprim/rocprim.hpp>
+#include "prims.hpp"
 
 namespace deftet {
 namespace surf {
@@ -2345,9 +2345,7 @@ static size_t nn_slice_bytes(int N, int M)
 }
 static size_t nn_sort_bytes(int nShapes, int N)
 {
-    size_t sortTmp = 0;
-    (void)rocprim::radix_sort_pairs(nullptr, sortTmp, (unsigned *)nullptr, (unsigned *)nullptr, (unsigned *)nullptr, (unsigned *)nullptr,
-                                    (size_t)nShapes * ((size_t)(N > 0 ? N : 0) + 1), 0, 32, (hipStream_t) nullptr);
+    const size_t sortTmp = prims::radix_sort_temp_bytes<unsigned, unsigned>((size_t)nShapes * ((size_t)(N > 0 ? N : 0) + 1));
     return align_up(sortTmp, 256) + 4 * align_up((size_t)nShapes * ((size_t)(N > 0 ? N : 0) + 1) * 4, 256) + 1024;
 }
 extern "C" size_t deftet_nn_index_workspace_bytes(int B, int N, int M)
@@ -2401,11 +2399,11 @@ static int nn_group(const float *queries, const float *points, int32_t *result, 
     DEFTET_LAUNCH(k_iota, dim3((unsigned)((nAll + 255) / 256)), blk, st, iota, (long long)nAll);
     int shapeBitsN = 0;
     while ((1 << shapeBitsN) < nS) ++shapeBitsN;
-    size_t need = 0;
-    hipError_t e = rocprim::radix_sort_pairs(nullptr, need, farKey, farKeyS, iota, farList, nAll, 0, keyBits + 1 + shapeBitsN, st);
-    if (e != hipSuccess || need > left) return set_error(DEFTET_ELAUNCH, "radix_sort temp");
-    e = rocprim::radix_sort_pairs(tmp, need, farKey, farKeyS, iota, farList, nAll, 0, keyBits + 1 + shapeBitsN, st);
-    if (e != hipSuccess) return set_error(DEFTET_ELAUNCH, "radix_sort_pairs: %s", hipGetErrorString(e));
+    {
+        const int rc = prims::radix_sort<unsigned, unsigned>(farKey, farKeyS, iota, reinterpret_cast<unsigned *>(farList), nAll,
+                                                             keyBits + 1 + shapeBitsN, tmp, left, st);
+        if (rc != DEFTET_OK) return rc;
+    }
     const int Gc = (G + kNNCoarse - 1) / kNNCoarse, Gc3 = Gc * Gc * Gc, nt = std::max(Gc3, G * G + 2 * kNNBatch);
     DEFTET_LAUNCH(k_nn_far_tables, dim3((nt + 255) / 256, nS), blk, st, (const int *)rep, points, Gc3, (const int *)start, G, repList, nRep,
                   rowStart, sorted, slice, M);
@@ -2762,15 +2760,15 @@ extern "C" int deftet_tri_dist_bwd_f32(const float *pts, const float *face, cons
     DEFTET_CHECK_ARG((long long)B * F < 0xFFFFFFFFLL, "too many faces for the deterministic path");
     unsigned long long *key = nullptr, *skey = nullptr;
     void *tmp = nullptr;
-    size_t need = 0;
-    hipError_t e = rocprim::radix_sort_keys(nullptr, need, key, skey, (size_t)n, 0, 64, st);
-    if (e != hipSuccess) return set_error(DEFTET_ELAUNCH, "radix_sort_keys(size): %s", hipGetErrorString(e));
+    const size_t need = prims::radix_sort_temp_bytes<unsigned long long, unsigned>((size_t)n, false);
     DEFTET_HIP(hipMallocAsync((void **)&key, (size_t)n * 8, st));
     DEFTET_HIP(hipMallocAsync((void **)&skey, (size_t)n * 8, st));
-    DEFTET_HIP(hipMallocAsync(&tmp, need ? need : 1, st));
+    DEFTET_HIP(hipMallocAsync(&tmp, need, st));
     DEFTET_LAUNCH(k_bwd_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), st, closest_f, n, P, F, key);
-    e = rocprim::radix_sort_keys(tmp, need, key, skey, (size_t)n, 0, 64, st);
-    if (e != hipSuccess) return set_error(DEFTET_ELAUNCH, "radix_sort_keys: %s", hipGetErrorString(e));
+    {
+        const int rc = prims::radix_sort_keys<unsigned long long>(key, skey, (size_t)n, 64, tmp, need, st);
+        if (rc != DEFTET_OK) return rc;
+    }
     DEFTET_LAUNCH(k_tri_dist_bwd_sorted, dim3((unsigned)((n + 255) / 256)), dim3(256), st, pts, face, dl_dd, skey, n, P, F, dldface);
     DEFTET_HIP(hipFreeAsync(key, st));
     DEFTET_HIP(hipFreeAsync(skey, st));

@@ -13,7 +13,7 @@
 #include "common.hpp"
 #include <atomic>
 
-#include <rocprim/rocprim.hpp>
+#include "prims.hpp"
 
 namespace deftet {
 namespace tops {
@@ -393,12 +393,12 @@ extern "C" int deftet_boundary_index_i64(const int64_t *face_fx3, const int64_t 
     Arena A(workspace, wsb);
     int *flag = A.take<int>(n), *pos = A.take<int>(n);
     void *tmp = A.base + align_up(A.off, 256);
-    size_t left = wsb - align_up(A.off, 256), need = 0;
+    const size_t left = wsb - align_up(A.off, 256);
     DEFTET_LAUNCH(k_bnd_flag, dim3((Fi + 255) / 256, B), dim3(256), st, (const long long *)tetidx_fx2, occ_bxt, T, Fi, mode, flag);
-    hipError_t e = rocprim::exclusive_scan(nullptr, need, flag, pos, 0, n, rocprim::plus<int>(), st);
-    if (e != hipSuccess || need > left) return set_error(DEFTET_ELAUNCH, "exclusive_scan temp");
-    e = rocprim::exclusive_scan(tmp, need, flag, pos, 0, n, rocprim::plus<int>(), st);
-    if (e != hipSuccess) return set_error(DEFTET_ELAUNCH, "exclusive_scan: %s", hipGetErrorString(e));
+    {
+        const int rc = prims::scan<int, prims::Plus, true>(flag, pos, n, 0, prims::Plus(), tmp, left, st);
+        if (rc != DEFTET_OK) return rc;
+    }
     DEFTET_LAUNCH(k_bnd_emit, dim3((Fi + 255) / 256, B), dim3(256), st, (const long long *)face_fx3, (const long long *)tetidx_fx2,
                   occ_bxt, flag, pos, T, Fi, B, mode, (long long *)out_rows, offsets);
     return DEFTET_OK;

@@ -7,7 +7,7 @@
 // incidences per vertex (stable radix sort ⇒ ascending slot order), and the backward is a
 // segmented gather-sum: no atomics, deterministic (fixed summation order, see k_gather_bwd).
 #include <cstring>
-#include <rocprim/rocprim.hpp>
+#include "prims.hpp"
 
 #include "common.hpp"
 
@@ -103,13 +103,7 @@ __global__ __launch_bounds__(256) void k_gather_bwd(const float *__restrict__ gr
     }
 }
 
-static size_t sort_tmp_bytes(size_t n)
-{
-    size_t need = 0;
-    unsigned *k = nullptr;
-    (void)rocprim::radix_sort_pairs(nullptr, need, k, k, k, k, n, 0, 32, (hipStream_t) nullptr);
-    return need;
-}
+static size_t sort_tmp_bytes(size_t n) { return prims::radix_sort_temp_bytes<unsigned, unsigned>(n); }
 
 }  // namespace vtx
 }  // namespace deftet
@@ -158,8 +152,9 @@ extern "C" int deftet_tet_vertex_csr_i32(const int64_t *tet_idx, int32_t *offset
     void *tmp = A.take<char>(tmpBytes);
     const unsigned gb = (unsigned)((n + 255) / 256);
     DEFTET_LAUNCH(vtx::k_csr_keys, dim3(gb), dim3(256), st, tet_idx, n, (long long)T * 4, V, key, val, bad_flag);
-    hipError_t e = rocprim::radix_sort_pairs(tmp, tmpBytes, key, skey, val, reinterpret_cast<unsigned *>(slots), (size_t)n, 0, 32, st);
-    if (e != hipSuccess) return set_error(DEFTET_ELAUNCH, "rocprim::radix_sort_pairs: %s", hipGetErrorString(e));
+    // all 32 key bits: invalid incidences carry the key 0xFFFFFFFF and must sort behind every vertex
+    const int rc = prims::radix_sort<unsigned, unsigned>(key, skey, val, reinterpret_cast<unsigned *>(slots), (size_t)n, 32, tmp, tmpBytes, st);
+    if (rc != DEFTET_OK) return rc;
     DEFTET_LAUNCH(vtx::k_csr_offsets, dim3((unsigned)((n + 256) / 256)), dim3(256), st, skey, n, nKeys, offsets);
     return DEFTET_OK;
 }
