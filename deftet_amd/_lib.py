@@ -84,6 +84,10 @@ SIGNATURES = {
     "deftet_tri_dist_bwd_order_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "deftet_nn_index_workspace_bytes": (_sz, [_i, _i, _i]),
     "deftet_nn_index_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "deftet_radix_sort_workspace_bytes": (_sz, [C.c_longlong, _i, _i]),
+    "deftet_radix_sort": (_i, [_vp, _vp, _vp, _vp, C.c_longlong, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "deftet_scan_workspace_bytes": (_sz, [C.c_longlong, _i]),
+    "deftet_scan": (_i, [_vp, _vp, C.c_longlong, _i, _i, _vp, _sz, _vp]),
     "deftet_sparse_render_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "deftet_sparse_render_fwd_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _sz, _vp]),
     "deftet_sparse_render_fwd_policy_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _sz, _vp]),

@@ -159,7 +159,7 @@ struct IotaLoad {
 // n_dev (may be NULL): the number of elements actually present, known on the device only (n is then the capacity the
 // grid is sized for); workgroups beyond it find nothing to do, so the cost follows the real count.
 template <typename K, typename KL>
-__global__ __launch_bounds__(kTileThreads) void k_rs_hist(KL keys, size_t n, int shift, unsigned nblk, unsigned *hist,
+__global__ __launch_bounds__(kTileThreads) void k_rs_hist(KL keys, size_t n, int shift, unsigned dmask, unsigned nblk, unsigned *hist,
                                                           const int *__restrict__ n_dev)
 {
     if (n_dev) n = min(n, (size_t)max(*n_dev, 0));
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(kTileThreads) void k_rs_hist(KL keys, size_t n, int
 #pragma unroll
     for (int k = 0; k < kTileItems; ++k) {
         const size_t i = base + (size_t)k * kTileThreads + threadIdx.x;
-        if (i < n) atomicAdd(&h[(unsigned)(keys(i) >> shift) & 255u], 1u);
+        if (i < n) atomicAdd(&h[(unsigned)(keys(i) >> shift) & dmask], 1u);
     }
     __syncthreads();
     hist[(size_t)threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(kTileThreads) void k_rs_hist(KL keys, size_t n, int
 
 template <typename K, typename V, bool HAS_V, typename KL, typename VL>
 __global__ __launch_bounds__(kTileThreads) void k_rs_scatter(KL kin, K *kout, VL vin, V *vout, size_t n,
-                                                             int shift, unsigned nblk, const unsigned *__restrict__ offs,
+                                                             int shift, unsigned dmask, unsigned nblk, const unsigned *__restrict__ offs,
                                                              const int *__restrict__ n_dev)
 {
     if (n_dev) n = min(n, (size_t)max(*n_dev, 0));
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(kTileThreads) void k_rs_scatter(KL kin, K *kout, VL
         const size_t i = base + (size_t)r * 64 + lane;
         const bool valid = i < n;
         key[r] = valid ? kin(i) : K(0);
-        const unsigned d = (unsigned)(key[r] >> shift) & 255u;
+        const unsigned d = (unsigned)(key[r] >> shift) & dmask;
         dig[r] = d;
         unsigned long long m = __ballot(valid);                     // lanes of this round with MY digit (match-any by ballots)
 #pragma unroll
@@ -263,16 +263,18 @@ int radix_sort_impl(KL kin, K *kout, VL vin, V *vout, size_t n, int bits, void *
         const bool to_out = ((passes - 1 - p) & 1) == 0;            // the last pass lands in kout / vout
         K *dk = to_out ? kout : tk;
         V *dv = to_out ? vout : tv;
-        if (p == 0) DEFTET_LAUNCH((k_rs_hist<K, KL>), dim3(nblk), dim3(kTileThreads), st, kin, n, 0, nblk, hist, n_dev);
-        else DEFTET_LAUNCH((k_rs_hist<K, PtrLoad<K>>), dim3(nblk), dim3(kTileThreads), st, PtrLoad<K>{sk}, n, p * 8, nblk, hist, n_dev);
+        const int left = bits - p * 8;                               // the last digit may be narrower: bits above `bits` do not count
+        const unsigned dmask = left >= 8 || bits <= 0 ? 255u : (1u << left) - 1u;
+        if (p == 0) DEFTET_LAUNCH((k_rs_hist<K, KL>), dim3(nblk), dim3(kTileThreads), st, kin, n, 0, dmask, nblk, hist, n_dev);
+        else DEFTET_LAUNCH((k_rs_hist<K, PtrLoad<K>>), dim3(nblk), dim3(kTileThreads), st, PtrLoad<K>{sk}, n, p * 8, dmask, nblk, hist, n_dev);
         const int rc = scan<unsigned, Plus, true>(hist, offs, (size_t)256 * nblk, 0u, Plus(), stmp, stmp_bytes, st);
         if (rc != DEFTET_OK) return rc;
         if (p == 0)
-            DEFTET_LAUNCH((k_rs_scatter<K, V, HAS_V, KL, VL>), dim3(nblk), dim3(kTileThreads), st, kin, dk, vin, dv, n, 0, nblk, (const unsigned *)offs,
-                          n_dev);
+            DEFTET_LAUNCH((k_rs_scatter<K, V, HAS_V, KL, VL>), dim3(nblk), dim3(kTileThreads), st, kin, dk, vin, dv, n, 0, dmask, nblk,
+                          (const unsigned *)offs, n_dev);
         else
             DEFTET_LAUNCH((k_rs_scatter<K, V, HAS_V, PtrLoad<K>, PtrLoad<V>>), dim3(nblk), dim3(kTileThreads), st, PtrLoad<K>{sk}, dk, PtrLoad<V>{sv},
-                          dv, n, p * 8, nblk, (const unsigned *)offs, n_dev);
+                          dv, n, p * 8, dmask, nblk, (const unsigned *)offs, n_dev);
         sk = dk;
         sv = dv;
     }

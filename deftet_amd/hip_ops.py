@@ -187,6 +187,46 @@ def paste_occ_bwd(cond_bxqx1, grad_out_bxq, n_tet):
     return gp
 
 
+def radix_sort(keys, values=None, bits=None, n_valid=None):
+    """Stable ascending sort with the library's own LSD radix sort (csrc/prims.hpp).  keys: int32/int64 tensor of
+    NON-NEGATIVE integers (sorted as unsigned on their low `bits` bits; default all bits); values: optional int32/int64/
+    float32 tensor of the same length carried along.  n_valid: optional int32 device tensor with the number of elements
+    that really exist.  Returns (sorted_keys, sorted_values or None)."""
+    _lib.require_gpu(keys, values)
+    lib = _lib.load()
+    k = keys.contiguous()
+    if k.dtype not in (torch.int32, torch.int64):
+        raise RuntimeError("radix_sort: keys must be int32 or int64")
+    kb = k.element_size()
+    n = k.numel()
+    v = values.contiguous() if values is not None else None
+    vb = v.element_size() if v is not None else 0
+    if v is not None and (v.numel() != n or vb not in (4, 8)):
+        raise RuntimeError("radix_sort: values must have the keys' length and 4- or 8-byte elements")
+    ko = torch.empty_like(k)
+    vo = torch.empty_like(v) if v is not None else None
+    with torch.cuda.device(k.device):
+        ws = _lib.workspace(k.device, lib.deftet_radix_sort_workspace_bytes(n, kb, vb))
+        _lib.check(lib.deftet_radix_sort(_lib.ptr(k), _lib.ptr(ko), _lib.ptr(v), _lib.ptr(vo), n, kb, vb, int(bits or kb * 8),
+                                         _lib.ptr(n_valid), _lib.ptr(ws), ws.numel(), _lib.current_stream(k.device)), "deftet_radix_sort")
+    return ko, vo
+
+
+def scan(x, kind="exclusive"):
+    """Prefix scan of a 1-D int32/int64 tensor: "exclusive" / "inclusive" sums or the inclusive running "max"."""
+    _lib.require_gpu(x)
+    lib = _lib.load()
+    t = x.contiguous()
+    if t.dtype not in (torch.int32, torch.int64):
+        raise RuntimeError("scan: int32 or int64")
+    out = torch.empty_like(t)
+    with torch.cuda.device(t.device):
+        ws = _lib.workspace(t.device, lib.deftet_scan_workspace_bytes(t.numel(), t.element_size()))
+        _lib.check(lib.deftet_scan(_lib.ptr(t), _lib.ptr(out), t.numel(), t.element_size(), {"exclusive": 0, "inclusive": 1, "max": 2}[kind],
+                                   _lib.ptr(ws), ws.numel(), _lib.current_stream(t.device)), "deftet_scan")
+    return out
+
+
 def rowdot(a, b=None, a2=None, b2=None):
     """out[r] = sum over the trailing dims of a[r]*b[r] (row sums when b is None), plus the same
     for the optional second pair (a2, b2) of its own width, in one launch pair; f32 [R]."""

@@ -380,6 +380,21 @@ int deftet_nn_index_ragged_f32(const float *queries_bxnx3, const float *points_b
                                void *stream);
 
 /* ---------------------------------------------------------------------------------
+ * Device-wide primitives the operators are built on (deftet_amd/csrc/prims.hpp; nothing in the reference corresponds
+ * to them — its CUDA side gets them from Thrust/CUB through torch): a stable LSD radix sort and prefix scans.
+ * deftet_radix_sort: ascending, stable, on the low `bits` bits of unsigned 4- or 8-byte keys, optionally carrying 4- or
+ * 8-byte values (value_bytes 0 = keys only).  Inputs are not modified, outputs must not alias them.  n_dev (device
+ * pointer or NULL): only the first min(n, *n_dev) elements exist — the cost follows that count, not n.
+ * deftet_scan: kind 0 exclusive sum, 1 inclusive sum, 2 inclusive running maximum over int32 / int64; in == out allowed. */
+size_t deftet_radix_sort_workspace_bytes(long long n, int key_bytes, int value_bytes);
+int deftet_radix_sort(const void *keys_in, void *keys_out, const void *values_in, void *values_out, long long n,
+                      int key_bytes, int value_bytes, int bits, const int32_t *n_dev, void *workspace,
+                      size_t workspace_bytes, void *stream);
+size_t deftet_scan_workspace_bytes(long long n, int elem_bytes);
+int deftet_scan(const void *in, void *out, long long n, int elem_bytes, int kind, void *workspace, size_t workspace_bytes,
+                void *stream);
+
+/* ---------------------------------------------------------------------------------
  * A12 differentiable tet rasterizer with the contract of
  * kaolin.render.mesh.deftet_sparse_render as called at
  * diff_render/diftet_6_subdiv/5_rendereq/deftetrneder.py:97-100 (Kaolin itself is not part
