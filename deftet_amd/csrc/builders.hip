@@ -3,7 +3,7 @@
 // The reference builds these tables on the host with std::map / unordered_set / Python
 // dicts (utils/lib/*/run.cpp, utils/tet_utils.py:208-256).  Here every builder is
 //     key generation (one lane per tet-face / tet-edge incidence)
-//  -> stable LSD radix sort of (key, insertion index)              [rocPRIM device primitive]
+//  -> stable LSD radix sort of (key, insertion index)              [prims.hpp]
 //  -> run detection + prefix sums + ordered emission               [hand-written kernels]
 // which reproduces the reference's output ORDER as well as its content: std::map iterates
 // keys ascending and each key's vector keeps insertion order == a stable sort by key of
