@@ -52,10 +52,18 @@ constexpr int kHitOverflow = -2;            // hits[.].w: this tet has accepted 
 //                         [2 pad, 3 pad) flag: some uncovered entry belongs to a NaN/Inf/huge query
 //   [.., + B*Q)           per shape: uncovered queries = hits that are NOT in their tet's record
 //                         (tet overflowed / irregular tet / NaN-Inf-huge query)
+//   [.., + 4*B*T)         int4 per tet: the SPILL record — a tet that accepts a fifth query writes its first four into
+//                         hits[.] with kHitSpilled set in .x and collects up to four more here; only a ninth acceptance
+//                         makes it "overflowed".  (With four slots only, a dense query set — configs[1]: one query per
+//                         tet on average — overflowed 130 tets per shape, and their ~650 uncovered hits cost k_finalize
+//                         and the backward 20 us each.)  Untouched for tets that never spill.
 constexpr int kHitPad = 64;
 __host__ __device__ inline int hit_pad(int B) { return (B + kHitPad - 1) / kHitPad * kHitPad; }
 __host__ __device__ inline size_t hit_cnt_off(int B, int T) { return (size_t)B * T * 4; }
 __host__ __device__ inline size_t hit_list_off(int B, int T) { return (size_t)B * T * 4 + (size_t)3 * hit_pad(B); }
+// second record of the tets that accepted five to eight queries (k_tet_scan_slab; int4 per tet, 16-byte aligned)
+__host__ __device__ inline size_t hit_spill_off(int B, int T, int Q) { return (hit_list_off(B, T) + (size_t)B * Q + 3) / 4 * 4; }
+constexpr int kHitSpilled = 1 << 30;       // flag in hits[.].x: four more accepted queries (or -1) are in the spill record
 // Tets whose hit record overflowed (> 4 accepted queries; ~1e-4 of the tets at BASELINE configs[2]) are also LISTED, so
 // that k_finalize can tell "this hit is not in its tet's record" from a short wave-uniform list instead of gathering the
 // winning tet's 16-byte record for every query of the shape.  The list lives behind the counter block:
@@ -790,7 +798,12 @@ __device__ __forceinline__ int4u ld_off_u4(const void *base, unsigned byte_off)
 // its 80 registers and spills them: four scratch reloads in front of the four atomics cost the launch 20 us.)
 __device__ __forceinline__ void atomic_smin_off(int *base, unsigned byte_off, int v)
 {
-    asm volatile("global_atomic_smin %0, %1, %2" ::"v"(byte_off), "v"(v), "s"(base) : "memory");
+    // s_nop 4: the scalar base usually comes straight out of v_readfirstlane (uniform_ptr), and a vector-memory instruction
+    // that reads an SGPR written by a VALU instruction needs five wait states in between.  The compiler pads that hazard
+    // for its own instructions but cannot see into an asm block: without the padding the instruction used the OLD
+    // contents of the register pair (round 3: stores to address 0 + offset once the code around the call no longer
+    // happened to put five instructions in between).
+    asm volatile("s_nop 4\n\tglobal_atomic_smin %0, %1, %2" ::"v"(byte_off), "v"(v), "s"(base) : "memory");
 }
 // a wave-uniform pointer, re-materialised in scalar registers at the point of use
 template <typename T>
@@ -820,7 +833,8 @@ __device__ __forceinline__ void store_b128_off(void *base, unsigned byte_off, in
     const i32x4 v = {x, y, z, w};
     // s_nop: a store of more than 64 bits keeps reading its data registers for a few cycles; the compiler pads that
     // hazard for its own stores, not inside asm (without it the next VALU write clobbered the record of 4 lanes in 16)
-    asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 2" ::"v"(byte_off), "v"(v), "s"(base) : "memory");
+    // (leading s_nop 4: VALU-written SGPR base read by a vector-memory instruction, see atomic_smin_off)
+    asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2\n\ts_nop 2" ::"v"(byte_off), "v"(v), "s"(base) : "memory");
 }
 
 // Exact re-scan of ONE tet's candidates (box test + reference predicate, as k_tet_scan does), used by k_tet_scan_slab for
@@ -912,7 +926,7 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan_slab(const float *_
                                                   const float *__restrict__ gparam, int G, int Gx, const int *__restrict__ table,
                                                   long long cellStride, const float4 *__restrict__ sortedQ, int *result, int *counters,
                                                   int *irregT, int4 *hits, const float *__restrict__ pts,
-                                                  const int *__restrict__ irregQ, int *ucount, int hpad)
+                                                  const int *__restrict__ irregQ, int *ucount, int hpad, int4 *spill)
 {
     if (ucount && blockIdx.x == 0 && threadIdx.x == 0) {               // per-shape words of the hit buffer: uncovered-hit counter
         ucount[blockIdx.y] = 0;                                        // (k_finalize appends), backward ticket, irregular-query flag
@@ -988,10 +1002,19 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan_slab(const float *_
     // alive; 1.3e-3 of the tets, 4 us of the launch):
     //  * a candidate in the filter's undecided band is remembered (two slots) and gets the reference predicate after the
     //    loop (exact_accept; a third one — never seen on the BASELINE workloads — falls back to the exact re-scan);
-    //  * a lane about to hold more than four acceptances publishes what it holds and marks the tet "overflowed"
-    //    (its hits are then carried by the uncovered list, as before).
+    //  * a lane about to hold more than four acceptances publishes what it holds; the first time it also writes the four
+    //    into its record (flagged kHitSpilled) and goes on collecting into the spill record, the second time it marks the
+    //    tet "overflowed" (its hits are then carried by the uncovered list).
     int h0 = -1, h1 = -1, h2 = -1, h3 = -1, hcnt = 0;
-    bool ovf = false;
+    int full = 0;                                                      // 0: nothing yet, 1: first four spilled, 2: overflowed
+    auto on_full = [&]() {                                             // the lane holds four PUBLISHED acceptances and gets a fifth
+        // (scalar base + 32-bit offset, like the record store at the end: a 64-bit per-lane address kept alive across the
+        // loop for this rare store was spilt to scratch)
+        if (hits && spill && full == 0) store_b128_off(uniform_ptr(hits + (size_t)b * T), (unsigned)t * 16u, h0 | kHitSpilled, h1, h2, h3);
+        full = (hits && spill) ? min(full + 1, 2) : 2;
+        h0 = -1; h1 = -1; h2 = -1; h3 = -1;
+        hcnt = 0;
+    };
     int pend0 = 0, pend1 = 0, npend = 0;                               // positions in sortedQ of undecided candidates
     // Slab cursor.  A "slab step" is (cz, chunk of four cy rows); tets that span more than four y cells (rare: needles)
     // take several chunks per cz.  All table addresses are 32-bit BYTE offsets from the wave-uniform table base.
@@ -1080,8 +1103,7 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan_slab(const float *_
                     if (hcnt > 1) atomicMin(&resb[h1], t);
                     if (hcnt > 2) atomicMin(&resb[h2], t);
                     if (hcnt > 3) atomicMin(&resb[h3], t);
-                    hcnt = 0;
-                    ovf = true;
+                    on_full();
                 }
             }
 #pragma unroll
@@ -1111,12 +1133,13 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan_slab(const float *_
             if (exact_accept(tv, q.x, q.y, q.z) > 0.f) {
                 const int qi = __float_as_int(q.w);
                 atomicMin(&result[(size_t)b * Q + qi], t);
-                if (hcnt < 4) {                                              // (already published: only the record needs it)
-                    h3 = h2; h2 = h1; h1 = h0; h0 = qi;
-                    ++hcnt;
-                } else {
-                    ovf = true;
+                if (hcnt == 4) {                                             // (the held four are not published yet)
+                    int *resb = result + (size_t)b * Q;
+                    atomicMin(&resb[h0], t); atomicMin(&resb[h1], t); atomicMin(&resb[h2], t); atomicMin(&resb[h3], t);
+                    on_full();
                 }
+                h3 = h2; h2 = h1; h1 = h0; h0 = qi;                          // (qi itself was published above)
+                ++hcnt;
             }
         }
     }
@@ -1125,10 +1148,13 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan_slab(const float *_
     if (hcnt > 1) atomic_smin_off(resb, (unsigned)h1 * 4u, t);
     if (hcnt > 2) atomic_smin_off(resb, (unsigned)h2 * 4u, t);
     if (hcnt > 3) atomic_smin_off(resb, (unsigned)h3 * 4u, t);
-    if (ovf) note_overflow(counters, gridDim.y, b, t);
+    if (full == 2) note_overflow(counters, gridDim.y, b, t);
     if (hits) {
-        const lanemask_t o = mask_of(ovf);
-        store_b128_off(uniform_ptr(hits + (size_t)b * T), (unsigned)t * 16u, sel(o, -1, h0), sel(o, -1, h1), sel(o, -1, h2), sel(o, kHitOverflow, h3));
+        // full == 0: the record; 1: the spill record (the first four are in the record already); 2: overflow marker
+        const lanemask_t o = mask_of(full == 2);
+        const int r0 = sel(o, -1, h0), r1 = sel(o, -1, h1), r2 = sel(o, -1, h2), r3 = sel(o, kHitOverflow, h3);
+        if (full != 1) store_b128_off(uniform_ptr(hits + (size_t)b * T), (unsigned)t * 16u, r0, r1, r2, r3);
+        else store_b128_off(uniform_ptr(spill + (size_t)b * T), (unsigned)t * 16u, r0, r1, r2, r3);
     }
     irregular_tail(tet, t, b, T, Q, pts, counters, irregQ, result);
     PHASE_MARK(2);                                                       // [2] publish (atomics, record store) / re-scan
@@ -1149,15 +1175,16 @@ __global__ __launch_bounds__(256) void k_finalize(const float *__restrict__ tet,
                                                   int *ucount, int *ulist, const int *__restrict__ counters,
                                                   const int *__restrict__ irregT, int hpad)
 {
+    __shared__ int s_cnt[4], s_base;
     const int b = blockIdx.y;
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= Q) return;
-    const size_t i = (size_t)b * Q + q;
-    int r = result[i];
+    const bool live = q < Q;                                        // (no early return: the append below has barriers)
+    const size_t i = (size_t)b * Q + (live ? q : 0);
+    int r = live ? result[i] : kMiss;
     // irregular tets (not certified for the grid filter; normally none) are tested here against
     // every query: query-centric, so no atomics and no extra launch
     const int nIrregT = counters ? counters[b * 4 + 0] : 0;
-    if (nIrregT > 0) {
+    if (nIrregT > 0 && live) {
         const float *p = pts + i * 3;
         const float x = p[0], y = p[1], z = p[2];
         for (int k = 0; k < nIrregT; ++k) {
@@ -1172,8 +1199,11 @@ __global__ __launch_bounds__(256) void k_finalize(const float *__restrict__ tet,
         }
     }
     const bool hit = r != kMiss;
-    stream_store(cond + i, hit ? (float)r : -1.0f);                 // :177, :149
-    if (occ) stream_store(occ + i, pred[(size_t)b * T + (hit ? r : 0)]);   // paste_occ: misses alias tet 0 (deftet.py:133-135)
+    if (live) {
+        stream_store(cond + i, hit ? (float)r : -1.0f);             // :177, :149
+        if (occ) stream_store(occ + i, pred[(size_t)b * T + (hit ? r : 0)]);   // paste_occ: misses alias tet 0 (deftet.py:133-135)
+    }
+    bool uncovered = false;
     if (hits && hit) {
         // is this hit in its tet's record?  (not if the tet overflowed / is irregular, or if the
         // query took the irregular-query side path, which records nothing)
@@ -1193,11 +1223,31 @@ __global__ __launch_bounds__(256) void k_finalize(const float *__restrict__ tet,
             }
         }
         if (!covered) {
-            ulist[(size_t)b * Q + atomicAdd(&ucount[b], 1)] = q;
+            uncovered = true;
             if (!query_regular(pq[0], pq[1], pq[2])) ucount[2 * hpad + b] = 1;   // its tet's record may be complete: every lane must look
         }
     }
-    if (!bary) return;
+    if (hits) {
+        // Append the uncovered hits of this workgroup with ONE atomic: the counter is a single address per shape, and
+        // same-address atomics serialise at the memory side (~50 ns each) — where many tets overflow their four-slot
+        // record (configs[1]: one query per tet on average, ~650 uncovered hits per shape) one atomic per hit made this
+        // kernel 50 us instead of 25.
+        const unsigned long long m = __ballot(uncovered);
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        if (lane == 0) s_cnt[wave] = __popcll(m);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int tot = (s_cnt[0] + s_cnt[1]) + (s_cnt[2] + s_cnt[3]);
+            s_base = tot > 0 ? atomicAdd(&ucount[b], tot) : 0;
+        }
+        __syncthreads();
+        if (uncovered) {
+            int off = s_base + __popcll(m & ((1ull << lane) - 1ull));
+            for (int w = 0; w < wave; ++w) off += s_cnt[w];
+            ulist[(size_t)b * Q + off] = q;
+        }
+    }
+    if (!bary || !live) return;
     float4 wq = make_float4(0.f, 0.f, 0.f, 0.f);
     if (hit) {
         const float4 *src = reinterpret_cast<const float4 *>(tet + ((size_t)b * T + r) * 12);
@@ -1524,7 +1574,7 @@ __global__ __launch_bounds__(256) void k_bary_bwd_hits(const float *__restrict__
                                                        const int4 *__restrict__ hits, int T, int Q, float *grad_tet,
                                                        float *grad_pts, int accumulate, const float *__restrict__ gocc,
                                                        float *grad_pred, float *missPart, int nMissParts, int *hitWords,
-                                                       const int *__restrict__ ulist, int pad)
+                                                       const int *__restrict__ ulist, int pad, const int4 *__restrict__ spill)
 {
     __shared__ float wsum[4];
     __shared__ float s_vals[kMissStride];
@@ -1548,30 +1598,48 @@ __global__ __launch_bounds__(256) void k_bary_bwd_hits(const float *__restrict__
 #pragma unroll
     for (int k = 0; k < 12; ++k) acc[k] = 0.f;
     float gp = 0.f;
-    const int4 h = live ? stream_load(hits + (size_t)b * T + t) : make_int4(-1, -1, -1, -1);
+    int4 h = live ? stream_load(hits + (size_t)b * T + t) : make_int4(-1, -1, -1, -1);
+    const bool spilled = h.w != kHitOverflow && h.x >= 0 && (h.x & kHitSpilled) != 0;   // four more slots in the spill record
+    if (spilled) h.x &= ~kHitSpilled;
     if (h.x >= 0 && h.w != kHitOverflow) {                         // slots fill in order: x < 0 means no accepted query
         TetGrad g;
         tet_grad_setup(tet, (size_t)b * T + t, g);
-        // the record lists the accepted queries in traversal order, which depends on the (arbitrary)
-        // order of queries inside a grid cell: sort the four ids so that the fp32 sums below are
+        // the records list the accepted queries in traversal order, which depends on the (arbitrary)
+        // order of queries inside a grid cell: sort the ids so that the fp32 sums below are
         // added in the same order on every run (empty slots, -1, go last)
-        unsigned hu[4] = {(unsigned)h.x, (unsigned)h.y, (unsigned)h.z, (unsigned)h.w};
-#define DEFTET_CSWAP(a, b) { const unsigned lo_ = min(hu[a], hu[b]), hi_ = max(hu[a], hu[b]); hu[a] = lo_; hu[b] = hi_; }
-        DEFTET_CSWAP(0, 1) DEFTET_CSWAP(2, 3) DEFTET_CSWAP(0, 2) DEFTET_CSWAP(1, 3) DEFTET_CSWAP(1, 2)
-#undef DEFTET_CSWAP
-        const int hq[4] = {(int)hu[0], (int)hu[1], (int)hu[2], (int)hu[3]};
+        unsigned hu[8] = {(unsigned)h.x, (unsigned)h.y, (unsigned)h.z, (unsigned)h.w, ~0u, ~0u, ~0u, ~0u};
         const float tf = (float)t;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int q = hq[k];
-            if (q < 0) continue;
+        auto add_hit = [&](int q) {
+            if (q < 0) return;
             const size_t i = (size_t)b * Q + q;
-            if (cond[i] != tf) continue;                           // accepted here, but a lower-index tet won the query
+            if (cond[i] != tf) return;                             // accepted here, but a lower-index tet won the query
             float G3[3];
             tet_grad_add(g, pts + i * 3, reinterpret_cast<const float4 *>(grad_w)[i], acc, G3);
             if (grad_pts) { grad_pts[i * 3] = G3[0]; grad_pts[i * 3 + 1] = G3[1]; grad_pts[i * 3 + 2] = G3[2]; }
             if (grad_pred) gp += gocc[i];
+        };
+#define DEFTET_CSWAP(a, b) { const unsigned lo_ = min(hu[a], hu[b]), hi_ = max(hu[a], hu[b]); hu[a] = lo_; hu[b] = hi_; }
+        if (!__any(spilled)) {                                       // the usual wave: four slots, five comparators
+            DEFTET_CSWAP(0, 1) DEFTET_CSWAP(2, 3) DEFTET_CSWAP(0, 2) DEFTET_CSWAP(1, 3) DEFTET_CSWAP(1, 2)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) add_hit((int)hu[k]);
+        } else {
+            if (spilled) {
+                const int4 h2 = spill[(size_t)b * T + t];
+                hu[4] = (unsigned)h2.x; hu[5] = (unsigned)h2.y; hu[6] = (unsigned)h2.z; hu[7] = (unsigned)h2.w;
+            }
+            // 19-comparator sorting network for eight keys (empty slots are 0xFFFFFFFF and end up last)
+            DEFTET_CSWAP(0, 1) DEFTET_CSWAP(2, 3) DEFTET_CSWAP(4, 5) DEFTET_CSWAP(6, 7)
+            DEFTET_CSWAP(0, 2) DEFTET_CSWAP(1, 3) DEFTET_CSWAP(4, 6) DEFTET_CSWAP(5, 7)
+            DEFTET_CSWAP(1, 2) DEFTET_CSWAP(5, 6) DEFTET_CSWAP(0, 4) DEFTET_CSWAP(3, 7)
+            DEFTET_CSWAP(1, 5) DEFTET_CSWAP(2, 6)
+            DEFTET_CSWAP(1, 4) DEFTET_CSWAP(3, 6)
+            DEFTET_CSWAP(2, 4) DEFTET_CSWAP(3, 5)
+            DEFTET_CSWAP(3, 4)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) add_hit((int)hu[k]);
         }
+#undef DEFTET_CSWAP
     }
     // hits that are in no record (overflowed / irregular tets; NaN/Inf/huge queries): the forward listed them
     const int nU = hitWords[b];
@@ -1798,7 +1866,7 @@ extern "C" size_t deftet_point_in_tet_workspace_bytes(int B, int T, int Q, int a
 extern "C" size_t deftet_point_in_tet_hits_ints(int B, int T, int Q)
 {
     if (B <= 0 || T < 0 || Q < 0) return 0;
-    return hit_list_off(B, T) + (size_t)B * Q;
+    return hit_spill_off(B, T, Q) + (size_t)B * T * 4;
 }
 
 extern "C" int deftet_point_in_tet_grid_dims(int T, int Q, int *G_yz, int *G_x)
@@ -1854,7 +1922,8 @@ static int pit_scan(const Layout &L, const float *tet, const float *pts, float *
                           L.counters, L.irregT, (int4 *)hit_buf, pts, L.irregQ, ucount, hit_pad(B));
         } else {
             DEFTET_LAUNCH(k_tet_scan_slab, gt, blk, st, tet, T, Q, L.gparam, L.G, L.Gx, L.table, L.cellStride, L.sortedQ, L.result,
-                          L.counters, L.irregT, (int4 *)hit_buf, pts, L.irregQ, ucount, hit_pad(B));
+                          L.counters, L.irregT, (int4 *)hit_buf, pts, L.irregQ, ucount, hit_pad(B),
+                          hit_buf ? (int4 *)(hit_buf + hit_spill_off(B, T, Q)) : (int4 *)nullptr);
         }
     } else if (ucount) {
         DEFTET_HIP(hipMemsetAsync(ucount, 0, (size_t)3 * hit_pad(B) * 4, st));
@@ -2000,7 +2069,7 @@ extern "C" int deftet_point_in_tet_bwd_f32(const float *tet, const float *pts, c
         int32_t *words = const_cast<int32_t *>(hit_buf) + hit_cnt_off(B, T);    // counters / ticket / flag: the buffer is this library's own
         DEFTET_LAUNCH(k_bary_bwd_hits, dim3(tblocks, B), dim3(256), st, tet, pts, cond, grad_w, (const int4 *)hit_buf, T, Q,
                       grad_tet, grad_pts, accumulate, grad_occ, grad_pred, missPart, nMissParts, words,
-                      (const int *)(hit_buf + hit_list_off(B, T)), hit_pad(B));
+                      (const int *)(hit_buf + hit_list_off(B, T)), hit_pad(B), (const int4 *)(hit_buf + hit_spill_off(B, T, Q)));
     } else if (workspace) {
         const size_t need = deftet_point_in_tet_bwd_workspace_bytes(B, T, Q);
         DEFTET_CHECK_ARG(workspace_bytes >= need && ((uintptr_t)workspace & 255) == 0,
