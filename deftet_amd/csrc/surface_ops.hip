@@ -135,6 +135,26 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_excl(const int *in, int *
     if (with_total && tid == 0 && blockIdx.x == gridDim.x - 1) out[n] = carry + tot;
 }
 
+// rank = atomicAdd(&counter[key], 1) for every lane with key >= 0, with ONE atomic per run of consecutive lanes that share
+// a key: point clouds sampled face by face put ~20 consecutive points into the same cell, and returning atomics on a
+// handful of addresses were what the binning kernels spent their time on (k_tri_point_keys 76 us, k_nn_bin 42 us per
+// 8 x 97 k points).  Must be called by all lanes of the wave (key < 0: no count).
+__device__ __forceinline__ int run_atomic_rank(int *counter, int key)
+{
+    const int lane = threadIdx.x & 63;
+    const int prev = __shfl_up(key, 1);
+    const bool head = key >= 0 && (lane == 0 || prev != key);
+    const unsigned long long heads = __ballot(head || key < 0);     // a lane without a key also ends the run before it
+    const unsigned long long upto = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);   // lanes 0..lane
+    const int start = 63 - __clzll((long long)(heads & upto));
+    const unsigned long long above = heads & ~upto;
+    const int end = above ? __ffsll((long long)above) - 1 : 64;
+    int base = 0;
+    if (head) base = atomicAdd(&counter[key], end - start);
+    base = __shfl(base, start);
+    return key >= 0 ? base + (lane - start) : 0;
+}
+
 // --- A10, grid-accelerated (exact) -------------------------------------------------------------------
 // Points are counting-sorted into a uniform G^3 grid over their bounding box; a query walks the
 // cell shells around its own (virtual) cell in increasing Chebyshev radius r and stops as soon as
@@ -233,20 +253,21 @@ __global__ __launch_bounds__(256) void k_nn_bin(const float *__restrict__ pts, i
     pts += (size_t)sb * M * 3;
     SHAPE(gp); SHAPE(cells); SHAPE(pcell); SHAPE(rep);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= M) return;
+    const bool live = i < M;                                       // (no early return: run_atomic_rank is a wave operation)
     const NNGrid g = *gp;
-    const float x = pts[i * 3], y = pts[i * 3 + 1], z = pts[i * 3 + 2];
+    const int ii = live ? i : 0;
+    const float x = pts[ii * 3], y = pts[ii * 3 + 1], z = pts[ii * 3 + 2];
     int2 r = make_int2(-1, 0);
-    if (fabsf(x) < INFINITY && fabsf(y) < INFINITY && fabsf(z) < INFINITY) {
-        const int cx = nn_cell(x, g.o[0], g.inv[0], g.G), cy = nn_cell(y, g.o[1], g.inv[1], g.G), cz = nn_cell(z, g.o[2], g.inv[2], g.G);
-        const int c = (cz * g.G + cy) * g.G + cx;
-        r.x = c;
-        r.y = atomicAdd(&cells[c], 1);
-        // any point of the coarse cell will do as its representative: the first arrival of every fine cell offers itself
-        // (one atomic per occupied fine cell — one per POINT put hundreds of them on the same address: 0.33 ms per 8 shapes)
-        if (r.y == 0) atomicMax(&rep[((cz / kNNCoarse) * g.Gc + cy / kNNCoarse) * g.Gc + cx / kNNCoarse], i);
+    int cx = 0, cy = 0, cz = 0;
+    if (live && fabsf(x) < INFINITY && fabsf(y) < INFINITY && fabsf(z) < INFINITY) {
+        cx = nn_cell(x, g.o[0], g.inv[0], g.G); cy = nn_cell(y, g.o[1], g.inv[1], g.G); cz = nn_cell(z, g.o[2], g.inv[2], g.G);
+        r.x = (cz * g.G + cy) * g.G + cx;
     }
-    pcell[i] = r;                                                  // non-finite points can never be nearest (d is inf/NaN)
+    r.y = run_atomic_rank(cells, r.x);
+    // any point of the coarse cell will do as its representative: the first arrival of every fine cell offers itself
+    // (one atomic per occupied fine cell — one per POINT put hundreds of them on the same address: 0.33 ms per 8 shapes)
+    if (r.x >= 0 && r.y == 0) atomicMax(&rep[((cz / kNNCoarse) * g.Gc + cy / kNNCoarse) * g.Gc + cx / kNNCoarse], i);
+    if (live) pcell[i] = r;                                        // non-finite points can never be nearest (d is inf/NaN)
 }
 
 __global__ __launch_bounds__(256) void k_nn_scatter(const float *__restrict__ pts, int M, const int2 *__restrict__ pcell,
@@ -1448,17 +1469,18 @@ __global__ __launch_bounds__(256) void k_tri_point_keys(const float *__restrict_
     pts += (size_t)sb * P * 3;
     SHAPE(gp); SHAPE(pcount); SHAPE(prank);
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= P) return;
+    const bool live = q < P;                                         // (no early return: run_atomic_rank is a wave operation)
     const TGrid g = *gp;
     int c[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        float f = floorf((pts[q * 3 + k] - g.o[k]) * g.inv[k]);
+        float f = floorf((pts[(live ? q : 0) * 3 + k] - g.o[k]) * g.inv[k]);
         f = fminf(fmaxf(f, 0.f), (float)(g.g[k] - 1));               // NaN -> 0
         c[k] = (int)f;
     }
-    const int cell = (c[2] * kTGMax + c[1]) * kTGMax + c[0];         // 18 bits: z, y, x
-    prank[q] = make_int2(cell, atomicAdd(&pcount[cell], 1));
+    const int cell = live ? (c[2] * kTGMax + c[1]) * kTGMax + c[0] : -1;   // 18 bits: z, y, x
+    const int rank = run_atomic_rank(pcount, cell);                    // one atomic per run of lanes in the same cell
+    if (live) prank[q] = make_int2(cell, rank);
 }
 
 __global__ __launch_bounds__(256) void k_tri_point_scatter(int P, const int2 *__restrict__ prank, const int *__restrict__ pstart,
