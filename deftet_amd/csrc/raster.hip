@@ -77,12 +77,15 @@ __global__ __launch_bounds__(256) void k_pix_bbox(const float *__restrict__ pix,
     }
 }
 
-// mean image-space extent of the finite faces (per-block partials: sum of w, count)
-__global__ __launch_bounds__(256) void k_face_stats(const float *__restrict__ xy, int F, float *part)
+// mean image-space extent of the finite faces and the largest finite |corner depth| (per-block partials: sum of w, count,
+// max |z|; k_pix_grid finishes them)
+__global__ __launch_bounds__(256) void k_face_stats(const float *__restrict__ xy, const float *__restrict__ fz, int F, float *part)
 {
-    __shared__ float sh[4][2];
-    float sw = 0.f, cnt = 0.f;
+    __shared__ float sh[4][3];
+    float sw = 0.f, cnt = 0.f, zm = 0.f;
     for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < F; f += gridDim.x * blockDim.x) {
+        const float m = fmaxf(fabsf(fz[f * 3]), fmaxf(fabsf(fz[f * 3 + 1]), fabsf(fz[f * 3 + 2])));
+        if (m < INFINITY) zm = fmaxf(zm, m);                           // NaN / Inf depths do not scale the margin
         const float2 a = reinterpret_cast<const float2 *>(xy)[f * 3], b = reinterpret_cast<const float2 *>(xy)[f * 3 + 1],
                      c = reinterpret_cast<const float2 *>(xy)[f * 3 + 2];
         const float w = fmaxf(fmaxf(a.x, fmaxf(b.x, c.x)) - fminf(a.x, fminf(b.x, c.x)),
@@ -90,23 +93,27 @@ __global__ __launch_bounds__(256) void k_face_stats(const float *__restrict__ xy
         if (w <= 2.f * kBig && w > 0.f) { sw += w; cnt += 1.f; }      // NaN fails
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { sw += __shfl_xor(sw, off); cnt += __shfl_xor(cnt, off); }
+    for (int off = 32; off > 0; off >>= 1) {
+        sw += __shfl_xor(sw, off); cnt += __shfl_xor(cnt, off);
+        zm = fmaxf(zm, __shfl_xor(zm, off));
+    }
     const int wv = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { sh[wv][0] = sw; sh[wv][1] = cnt; }
+    if ((threadIdx.x & 63) == 0) { sh[wv][0] = sw; sh[wv][1] = cnt; sh[wv][2] = zm; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        part[blockIdx.x * 2] = (sh[0][0] + sh[1][0]) + (sh[2][0] + sh[3][0]);
-        part[blockIdx.x * 2 + 1] = (sh[0][1] + sh[1][1]) + (sh[2][1] + sh[3][1]);
+        part[blockIdx.x * 3] = (sh[0][0] + sh[1][0]) + (sh[2][0] + sh[3][0]);
+        part[blockIdx.x * 3 + 1] = (sh[0][1] + sh[1][1]) + (sh[2][1] + sh[3][1]);
+        part[blockIdx.x * 3 + 2] = fmaxf(fmaxf(sh[0][2], sh[1][2]), fmaxf(sh[2][2], sh[3][2]));
     }
 }
 
 // pixel box + mean face size -> tile grid: tiles are about one mean face extent wide, so a
 // typical face overlaps 2x2..3x3 tiles; never more than kG2Max tiles per axis
-__global__ __launch_bounds__(64) void k_pix_grid(const float *__restrict__ part, const float *__restrict__ fpart, Grid2 *g)
+__global__ __launch_bounds__(64) void k_pix_grid(const float *__restrict__ part, const float *__restrict__ fpart, Grid2 *g, unsigned *zAbsMax)
 {
     const int lane = threadIdx.x;
     float lo[2] = {part[lane * 4], part[lane * 4 + 1]}, hi[2] = {part[lane * 4 + 2], part[lane * 4 + 3]};
-    float sw = fpart[lane * 2], cnt = fpart[lane * 2 + 1];
+    float sw = fpart[lane * 3], cnt = fpart[lane * 3 + 1], zm = fpart[lane * 3 + 2];
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
 #pragma unroll
@@ -116,8 +123,10 @@ __global__ __launch_bounds__(64) void k_pix_grid(const float *__restrict__ part,
         }
         sw += __shfl_xor(sw, off);
         cnt += __shfl_xor(cnt, off);
+        zm = fmaxf(zm, __shfl_xor(zm, off));
     }
     if (lane == 0) {
+        *zAbsMax = __float_as_uint(zm);                             // scales the rounding margin of the NEAREST walk's stop test
         Grid2 r;
         const bool okx = hi[0] >= lo[0], oky = hi[1] >= lo[1];
         r.lox = okx ? lo[0] : 0.f; r.hix = okx ? hi[0] : 0.f;
@@ -174,26 +183,19 @@ constexpr unsigned kPadKey = 1u << 18;             // > any tile id (kG2Max^2 = 
 // NEAREST binning order: faces by descending depth of their nearest corner (zhi = largest corner z; the camera looks
 // down -z), so that every tile list comes out near-first and the walk of k_pix_raster can stop at the first batch that lies
 // behind every lane's worst record.  key = order-preserving bits of -zhi (ascending sort = descending zhi); a face with a
-// NaN corner sorts first (its depth bound is unknown).  zAbsMax: the largest finite |corner z| (bits, atomicMax), which
-// scales the rounding margin of that stop test.
-__global__ __launch_bounds__(256) void k_face_depth_keys(const float *__restrict__ fz, int F, unsigned *key, unsigned *val, unsigned *zAbsMax)
+// NaN corner sorts first (its depth bound is unknown).  (The largest finite |corner z|, which scales the rounding margin of
+// that stop test, comes from k_face_stats / k_pix_grid.)
+__global__ __launch_bounds__(256) void k_face_depth_keys(const float *__restrict__ fz, int F, unsigned *key, unsigned *val)
 {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    float m = 0.f;
-    if (f < F) {
-        const float a = fz[f * 3], b = fz[f * 3 + 1], c = fz[f * 3 + 2];
-        const bool nan = !(a == a) || !(b == b) || !(c == c);
-        const float zhi = fmaxf(a, fmaxf(b, c));
-        unsigned u = __float_as_uint(-zhi);
-        u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);              // total order of the floats as unsigned
-        key[f] = nan ? 0u : u;
-        val[f] = (unsigned)f;
-        m = fmaxf(fabsf(a), fmaxf(fabsf(b), fabsf(c)));
-        if (!(m < INFINITY)) m = 0.f;
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(zAbsMax, __float_as_uint(m));   // non-negative floats order like their bits
+    if (f >= F) return;
+    const float a = fz[f * 3], b = fz[f * 3 + 1], c = fz[f * 3 + 2];
+    const bool nan = !(a == a) || !(b == b) || !(c == c);
+    const float zhi = fmaxf(a, fmaxf(b, c));
+    unsigned u = __float_as_uint(-zhi);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);                  // total order of the floats as unsigned
+    key[f] = nan ? 0u : u;
+    val[f] = (unsigned)f;
 }
 
 __global__ __launch_bounds__(256) void k_face_span(const float *__restrict__ xy, int F, const Grid2 *__restrict__ gp, float eps,
@@ -835,7 +837,7 @@ static Layout make_layout(int P, int F, int knum, void *ws, size_t wsb)
     Arena A(ws, wsb);
     L.nTiles = kG2Max * kG2Max;                              // capacity; the device picks gx*gy <= this
     L.part = A.take<float>(kBoxBlocks * 4);
-    L.fpart = A.take<float>(kBoxBlocks * 2);
+    L.fpart = A.take<float>(kBoxBlocks * 3);
     L.grid = A.take<Grid2>(1);
     L.tileStart = A.take<int>((size_t)L.nTiles + 2);
     L.nWide = A.take<int>(4);
@@ -915,8 +917,8 @@ extern "C" int deftet_sparse_render_fwd_policy_f32(const float *pix, const float
         const float *pb = pix + (size_t)b * P * 2, *rb = rng + (size_t)b * P * 2;
         const float *zb = fz + (size_t)b * F * 3, *xb = fxy + (size_t)b * F * 6, *fb = feat + (size_t)b * F * 3 * D;
         DEFTET_LAUNCH(k_pix_bbox, dim3(kBoxBlocks), dim3(256), st, pb, P, L.part);
-        DEFTET_LAUNCH(k_face_stats, dim3(kBoxBlocks), dim3(256), st, xb, F, L.fpart);
-        DEFTET_LAUNCH(k_pix_grid, dim3(1), dim3(64), st, L.part, L.fpart, L.grid);
+        DEFTET_LAUNCH(k_face_stats, dim3(kBoxBlocks), dim3(256), st, xb, zb, F, L.fpart);
+        DEFTET_LAUNCH(k_pix_grid, dim3(1), dim3(64), st, L.part, L.fpart, L.grid, L.zAbsMax);
 #define RAST_TRY(call)                     \
     do {                                   \
         const int rc_ = (call);            \
@@ -924,9 +926,8 @@ extern "C" int deftet_sparse_render_fwd_policy_f32(const float *pix, const float
     } while (0)
         const bool nearest = policy == DEFTET_RASTER_NEAREST;
         const unsigned *perm = nullptr;
-        DEFTET_HIP(hipMemsetAsync(L.zAbsMax, 0, 4, st));
         if (F > 0 && nearest) {
-            DEFTET_LAUNCH(k_face_depth_keys, dim3((F + 255) / 256), dim3(256), st, zb, F, L.pkey, L.pval, L.zAbsMax);
+            DEFTET_LAUNCH(k_face_depth_keys, dim3((F + 255) / 256), dim3(256), st, zb, F, L.pkey, L.pval);
             RAST_TRY((prims::radix_sort<unsigned, unsigned>(L.pkey, L.skey, L.pval, L.perm, (size_t)F, 32, L.tmp, L.tmpBytes, st)));
             perm = L.perm;
         }
