@@ -12,7 +12,8 @@
 // scatter is stable without atomics: a tile is four waves x eight rounds x 64 lanes in key order; per round the lanes
 // with equal digits find each other with eight ballots (match-any), the first of them advances the wave's own counter
 // of that digit, so a key's rank among the wave's keys of its digit is known after one walk; one pass over the 4 x 256
-// counters turns them into bases (tile offset + counts of the earlier waves) and the second walk places the keys.
+// counters turns them into rank bases inside the tile; the tile is staged in digit order in LDS and written out with
+// consecutive threads on consecutive addresses of every digit's run.
 // Temporary storage: one spare key (and value) array for the ping-pong, the two digit tables and the scan's partials —
 // radix_sort_temp_bytes<K, V>(n).
 #pragma once
@@ -183,20 +184,25 @@ __global__ __launch_bounds__(kTileThreads) void k_rs_scatter(KL kin, K *kout, VL
 {
     if (n_dev) n = min(n, (size_t)max(*n_dev, 0));
     if ((size_t)blockIdx.x * kTile >= n) return;
-    __shared__ unsigned cnt[kTileThreads / 64][256];
+    __shared__ unsigned cnt[kTileThreads / 64][256];                // per wave and digit: count, then rank base inside the tile
+    __shared__ unsigned lbase[256], gbase[256], wtot[kTileThreads / 64];
+    __shared__ K s_key[kTile];
+    __shared__ V s_val[HAS_V ? kTile : 1];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < kTileThreads / 64; ++k) cnt[k][threadIdx.x] = 0u;
     __syncthreads();
     // wave w owns the tile's keys [w * 512, (w + 1) * 512) in rounds of 64: tile order = (wave, round, lane)
-    const size_t base = (size_t)blockIdx.x * kTile + (size_t)w * (kTileItems * 64);
+    const size_t tile0 = (size_t)blockIdx.x * kTile, base = tile0 + (size_t)w * (kTileItems * 64);
     K key[kTileItems];
+    V val[kTileItems];
     unsigned dig[kTileItems], rank[kTileItems];
 #pragma unroll
     for (int r = 0; r < kTileItems; ++r) {
         const size_t i = base + (size_t)r * 64 + lane;
         const bool valid = i < n;
         key[r] = valid ? kin(i) : K(0);
+        if (HAS_V) val[r] = valid ? vin(i) : V(0);
         const unsigned d = (unsigned)(key[r] >> shift) & dmask;
         dig[r] = d;
         unsigned long long m = __ballot(valid);                     // lanes of this round with MY digit (match-any by ballots)
@@ -212,9 +218,24 @@ __global__ __launch_bounds__(kTileThreads) void k_rs_scatter(KL kin, K *kout, VL
         if (valid && below == 0u) cnt[w][d] = seen + (unsigned)__popcll(m);   // one lane per distinct digit, after every lane has read
     }
     __syncthreads();
-    {   // counts -> bases: (digit, tile) start from the scanned table, then the earlier waves of the tile
+    {   // thread d: the tile's keys of digit d start at lbase[d] inside the tile (exclusive scan over the digits) and at gbase[d]
+        // in the output (the scanned table); the wave counters become rank bases inside the tile
         const unsigned d = threadIdx.x;
-        unsigned run = offs[(size_t)d * nblk + blockIdx.x];
+        unsigned tot = 0u;
+#pragma unroll
+        for (int k = 0; k < kTileThreads / 64; ++k) tot += cnt[k][d];
+        unsigned incl = tot;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
+        }
+        if (lane == 63) wtot[w] = incl;
+        __syncthreads();
+        unsigned run = incl - tot;
+        for (int k = 0; k < w; ++k) run += wtot[k];
+        lbase[d] = run;
+        gbase[d] = offs[(size_t)d * nblk + blockIdx.x];
 #pragma unroll
         for (int k = 0; k < kTileThreads / 64; ++k) {
             const unsigned t = cnt[k][d];
@@ -223,13 +244,29 @@ __global__ __launch_bounds__(kTileThreads) void k_rs_scatter(KL kin, K *kout, VL
         }
     }
     __syncthreads();
+    // stage the tile in digit order in LDS (stable), then write it out with consecutive threads on consecutive addresses
+    // inside every digit's run — placing the keys straight from the registers made every lane of a store go to a
+    // different digit's run (4- or 8-byte segments): the 16.8 M-pair sort of the rasterizer's backward took 0.16 ms per pass
 #pragma unroll
     for (int r = 0; r < kTileItems; ++r) {
         const size_t i = base + (size_t)r * 64 + lane;
         if (i < n) {
-            const size_t pos = (size_t)cnt[w][dig[r]] + rank[r];
-            kout[pos] = key[r];
-            if (HAS_V) vout[pos] = vin(i);
+            const unsigned lp = cnt[w][dig[r]] + rank[r];
+            s_key[lp] = key[r];
+            if (HAS_V) s_val[lp] = val[r];
+        }
+    }
+    __syncthreads();
+    const unsigned nTile = (unsigned)min((size_t)kTile, n - tile0);
+#pragma unroll
+    for (int r = 0; r < kTileItems; ++r) {
+        const unsigned j = (unsigned)r * kTileThreads + threadIdx.x;
+        if (j < nTile) {
+            const K k = s_key[j];
+            const unsigned d = (unsigned)(k >> shift) & dmask;
+            const size_t pos = (size_t)gbase[d] + (j - lbase[d]);
+            kout[pos] = k;
+            if (HAS_V) vout[pos] = s_val[j];
         }
     }
 }
