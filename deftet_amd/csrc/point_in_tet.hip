@@ -1569,6 +1569,57 @@ constexpr int kMissStride = 80;    // floats of workspace per shape: kMissParts 
 //    the kernel's own traffic), hand their partial to memory and draw a ticket; the workgroup that draws the last one
 //    adds the partials up in index order, together with the tet-0 lane's own sum, and writes grad_pred[b,0].
 //    (Rounds 1-2 needed a second launch, k_bary_bwd_tail, for the last two items.)
+// The rare part of k_bary_bwd_hits: for every tet of the wave in `need`, the wave walks the shape's list of unrecorded
+// hits and leaves the tet's 12 gradient sums + its grad_pred sum in park[.][tid] of the tet's lane (LDS), to be added
+// after the record's own hits.  It runs BEFORE the kernel's accumulators exist, so that the two phases' registers do
+// not add up: 110 -> 96 VGPRs, 4 -> 5 waves per SIMD, 69.5 -> 63.1 us inside the configs[2] step.  (Out of line with
+// the register budget of 6 waves: the same time, its callee-saved spills cost what the occupancy gains; forcing 6
+// waves on the inlined form spills on the main path: 84 us.)  Returns whether this lane's tet was one of them.
+__device__ __forceinline__ bool bwd_rescan(const float *__restrict__ tet, const float *__restrict__ pts, const float *__restrict__ cond,
+                                        const float *__restrict__ grad_w, const float *__restrict__ gocc, float *grad_pts,
+                                        bool want_pred, const int *__restrict__ ulist, int b, int T, int Q, int nU,
+                                        unsigned long long need, int t, float (*park)[256])
+{
+    const int tid = threadIdx.x, lane = tid & 63;
+    bool parked = false;
+    while (need) {
+        const int L = __ffsll((long long)need) - 1;
+        need &= need - 1;
+        const int tL = __shfl(t, L);
+        const float tLf = (float)tL;
+        float part[13];
+#pragma unroll
+        for (int k = 0; k < 13; ++k) part[k] = 0.f;
+        for (int base = 0; base < nU; base += 64) {
+            const int e = base + lane;
+            const int q = e < nU ? ulist[(size_t)b * Q + e] : -1;
+            const size_t i = (size_t)b * Q + (q >= 0 ? q : 0);
+            if (q >= 0 && cond[i] == tLf) {
+                // a hit recorded by the overflowing tet's own record cannot be here: overflowed records are ignored by the caller
+                TetGrad g;
+                tet_grad_setup(tet, (size_t)b * T + tL, g);
+                float G3[3];
+                tet_grad_add(g, pts + i * 3, reinterpret_cast<const float4 *>(grad_w)[i], part, G3);
+                if (grad_pts) { grad_pts[i * 3] = G3[0]; grad_pts[i * 3 + 1] = G3[1]; grad_pts[i * 3 + 2] = G3[2]; }
+                if (want_pred) part[12] += gocc[i];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 13; ++k) {
+            float v = part[k];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);      // fixed butterfly: same order on every run
+            part[k] = v;
+        }
+        if (lane == L) {                     // parked in LDS until the record's own hits are summed
+#pragma unroll
+            for (int k = 0; k < 13; ++k) park[k][tid] = part[k];
+            parked = true;
+        }
+    }
+    return parked;
+}
+
 __global__ __launch_bounds__(256) void k_bary_bwd_hits(const float *__restrict__ tet, const float *__restrict__ pts,
                                                        const float *__restrict__ cond, const float *__restrict__ grad_w,
                                                        const int4 *__restrict__ hits, int T, int Q, float *grad_tet,
@@ -1579,6 +1630,8 @@ __global__ __launch_bounds__(256) void k_bary_bwd_hits(const float *__restrict__
     __shared__ float wsum[4];
     __shared__ float s_vals[kMissStride];
     __shared__ int s_last;
+    __shared__ float4 s_rows[4][192];
+    __shared__ float s_park[13][256];
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
     const bool side = grad_pred && (int)blockIdx.x < nMissParts;   // block-uniform
     float missPartial = 0.f;
@@ -1594,13 +1647,21 @@ __global__ __launch_bounds__(256) void k_bary_bwd_hits(const float *__restrict__
     }
     const int t = blockIdx.x * blockDim.x + tid;
     const bool live = t < T;
+    int4 h = live ? stream_load(hits + (size_t)b * T + t) : make_int4(-1, -1, -1, -1);
+    const bool spilled = h.w != kHitOverflow && h.x >= 0 && (h.x & kHitSpilled) != 0;   // four more slots in the spill record
+    if (spilled) h.x &= ~kHitSpilled;
+    bool parked = false;
+    // hits that are in no record (overflowed / irregular tets; NaN/Inf/huge queries): the forward listed them
+    const int nU = hitWords[b];
+    if (nU > 0) {                                                  // wave-uniform (scalar load)
+        const bool anyQ = hitWords[2 * pad + b] != 0;              // entries of irregular queries: their tets' records look complete
+        const unsigned long long need = __ballot(live && (h.w == kHitOverflow || anyQ));
+        if (need) parked = bwd_rescan(tet, pts, cond, grad_w, gocc, grad_pts, grad_pred != nullptr, ulist, b, T, Q, nU, need, t, s_park);
+    }
     float acc[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) acc[k] = 0.f;
     float gp = 0.f;
-    int4 h = live ? stream_load(hits + (size_t)b * T + t) : make_int4(-1, -1, -1, -1);
-    const bool spilled = h.w != kHitOverflow && h.x >= 0 && (h.x & kHitSpilled) != 0;   // four more slots in the spill record
-    if (spilled) h.x &= ~kHitSpilled;
     if (h.x >= 0 && h.w != kHitOverflow) {                         // slots fill in order: x < 0 means no accepted query
         TetGrad g;
         tet_grad_setup(tet, (size_t)b * T + t, g);
@@ -1621,8 +1682,11 @@ __global__ __launch_bounds__(256) void k_bary_bwd_hits(const float *__restrict__
 #define DEFTET_CSWAP(a, b) { const unsigned lo_ = min(hu[a], hu[b]), hi_ = max(hu[a], hu[b]); hu[a] = lo_; hu[b] = hi_; }
         if (!__any(spilled)) {                                       // the usual wave: four slots, five comparators
             DEFTET_CSWAP(0, 1) DEFTET_CSWAP(2, 3) DEFTET_CSWAP(0, 2) DEFTET_CSWAP(1, 3) DEFTET_CSWAP(1, 2)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) add_hit((int)hu[k]);
+#pragma unroll 1
+            for (int k = 0; k < 4 && __any(hu[0] != ~0u); ++k) {     // sorted: empty slots are last, most records hold one hit
+                add_hit((int)hu[0]);
+                hu[0] = hu[1]; hu[1] = hu[2]; hu[2] = hu[3]; hu[3] = ~0u;
+            }
         } else {
             if (spilled) {
                 const int4 h2 = spill[(size_t)b * T + t];
@@ -1636,67 +1700,44 @@ __global__ __launch_bounds__(256) void k_bary_bwd_hits(const float *__restrict__
             DEFTET_CSWAP(1, 4) DEFTET_CSWAP(3, 6)
             DEFTET_CSWAP(2, 4) DEFTET_CSWAP(3, 5)
             DEFTET_CSWAP(3, 4)
+#pragma unroll 1
+            for (int k = 0; k < 8 && __any(hu[0] != ~0u); ++k) {
+                add_hit((int)hu[0]);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) add_hit((int)hu[k]);
+                for (int j = 0; j < 7; ++j) hu[j] = hu[j + 1];
+                hu[7] = ~0u;
+            }
         }
 #undef DEFTET_CSWAP
     }
-    // hits that are in no record (overflowed / irregular tets; NaN/Inf/huge queries): the forward listed them
-    const int nU = hitWords[b];
-    if (nU > 0) {                                                  // wave-uniform (scalar load)
-        const bool anyQ = hitWords[2 * pad + b] != 0;              // entries of irregular queries: their tets' records look complete
-        unsigned long long need = __ballot(live && (h.w == kHitOverflow || anyQ));
-        while (need) {
-            const int L = __ffsll((long long)need) - 1;
-            need &= need - 1;
-            const int tL = __shfl(t, L);
-            const float tLf = (float)tL;
-            float part[13];
+    if (parked) {                                                  // the rescan's sums, added after the record's hits as before
 #pragma unroll
-            for (int k = 0; k < 13; ++k) part[k] = 0.f;
-            for (int base = 0; base < nU; base += 64) {
-                const int e = base + lane;
-                const int q = e < nU ? ulist[(size_t)b * Q + e] : -1;
-                const size_t i = (size_t)b * Q + (q >= 0 ? q : 0);
-                if (q >= 0 && cond[i] == tLf) {
-                    // a hit recorded by the overflowing tet's own record cannot be here: overflowed records are ignored above
-                    TetGrad g;
-                    tet_grad_setup(tet, (size_t)b * T + tL, g);
-                    float G3[3];
-                    tet_grad_add(g, pts + i * 3, reinterpret_cast<const float4 *>(grad_w)[i], part, G3);
-                    if (grad_pts) { grad_pts[i * 3] = G3[0]; grad_pts[i * 3 + 1] = G3[1]; grad_pts[i * 3 + 2] = G3[2]; }
-                    if (grad_pred) part[12] += gocc[i];
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < 13; ++k) {
-                float v = part[k];
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);      // fixed butterfly: same order on every run
-                part[k] = v;
-            }
-            if (lane == L) {
-#pragma unroll
-                for (int k = 0; k < 12; ++k) acc[k] += part[k];
-                gp += part[12];
-            }
-        }
+        for (int k = 0; k < 12; ++k) acc[k] += s_park[k][tid];
+        gp += s_park[12][tid];
     }
     if (live) {
         const bool deferred = grad_pred && t == 0;                 // tet 0 of the shape: written by the ticket winner below
         if (grad_pred && !deferred) stream_store(grad_pred + (size_t)b * T + t, accumulate ? grad_pred[(size_t)b * T + t] + gp : gp);
-        float4 *dst = reinterpret_cast<float4 *>(grad_tet + ((size_t)b * T + t) * 12);
-        float4 o0 = make_float4(acc[0], acc[1], acc[2], acc[3]), o1 = make_float4(acc[4], acc[5], acc[6], acc[7]),
-               o2 = make_float4(acc[8], acc[9], acc[10], acc[11]);
-        if (accumulate) {
-            float4 p0 = dst[0], p1 = dst[1], p2 = dst[2];
-            o0.x += p0.x; o0.y += p0.y; o0.z += p0.z; o0.w += p0.w;
-            o1.x += p1.x; o1.y += p1.y; o1.z += p1.z; o1.w += p1.w;
-            o2.x += p2.x; o2.y += p2.y; o2.z += p2.z; o2.w += p2.w;
+    }
+    {   // the 48-byte rows of a wave go through LDS so that every store instruction writes 1 KB of consecutive addresses
+        // (a lane storing its own row wrote 16 bytes every 48: three partial-line streaming stores per line)
+        const int w = tid >> 6;
+        s_rows[w][lane * 3] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        s_rows[w][lane * 3 + 1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+        s_rows[w][lane * 3 + 2] = make_float4(acc[8], acc[9], acc[10], acc[11]);
+        __syncthreads();
+        const int t0 = t - lane;                                    // the wave's first tet
+        float4 *dst = reinterpret_cast<float4 *>(grad_tet + ((size_t)b * T + t0) * 12);
+        const int nRow = min(64, T - t0) * 3;                       // float4 pieces of the wave's live rows (<= 0: none)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int j = k * 64 + lane;
+            if (j < nRow) {
+                float4 o = s_rows[w][j];
+                if (accumulate) { const float4 p = dst[j]; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
+                stream_store(dst + j, o);
+            }
         }
-        stream_store(dst, o0);
-        stream_store(dst + 1, o1);
-        stream_store(dst + 2, o2);
     }
     if (!side) return;
     // miss-sum reduction across the side workgroups: partials and ticket live at the memory side (RMW atomics), so no
