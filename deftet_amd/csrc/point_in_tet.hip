@@ -1169,15 +1169,33 @@ __device__ __forceinline__ float triple(const float *a, const float *b, const fl
     return (a[0] * x0 + a[1] * x1) + a[2] * x2;
 }
 
+// Placement of a (chunk, shape) grid for the kernels whose gathers go to PER-SHAPE arrays in arbitrary order (the
+// queries' coordinates, weights' gradients, winners, predictions): workgroup i is observed to run on XCD i % 8, so
+// with shape = i % B all workgroups of an XCD work on the same shape(s) and the gathered arrays of a shape (3.6 MB in
+// the backward at 100,000 queries) stay in that XCD's 4 MiB L2, instead of every L2 pulling every shape's arrays.
+// Returns (shape, chunk).  Speed only; any placement is correct.
+__device__ __forceinline__ int2 shape_block(int pin)
+{
+    if (!pin) return make_int2(blockIdx.y, blockIdx.x);
+    const int L = blockIdx.y * gridDim.x + blockIdx.x, nB = gridDim.y;
+    return make_int2(L % nB, L / nB);
+}
+// ... when a shape's gathered arrays fit an L2.  Beyond that the shapes are better taken one after the other by the
+// whole chip (the arrays of ONE shape then live in the 256 MiB Infinity Cache; eight at a time do not: configs[3], one
+// million queries per shape, backward 153 -> 165 us with the pinned placement; configs[1]: 33.4 -> 22.1 us, configs[2]:
+// 62.7 -> 60.1 us, k_finalize 30.5 -> 27.5 us).
+static inline int pin_shapes(int Q) { return (size_t)Q * 36 <= ((size_t)4 << 20); }
+
 __global__ __launch_bounds__(256) void k_finalize(const float *__restrict__ tet, const float *__restrict__ pts, int T,
                                                   int Q, const int *__restrict__ result, float *cond, float *bary,
                                                   const float *__restrict__ pred, float *occ, const int4 *__restrict__ hits,
                                                   int *ucount, int *ulist, const int *__restrict__ counters,
-                                                  const int *__restrict__ irregT, int hpad)
+                                                  const int *__restrict__ irregT, int hpad, int pin)
 {
     __shared__ int s_cnt[4], s_base;
-    const int b = blockIdx.y;
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    const int2 sb = shape_block(pin);                                  // shape-per-XCD placement
+    const int b = sb.x;
+    const int q = sb.y * blockDim.x + threadIdx.x;
     const bool live = q < Q;                                        // (no early return: the append below has barriers)
     const size_t i = (size_t)b * Q + (live ? q : 0);
     int r = live ? result[i] : kMiss;
@@ -1625,19 +1643,20 @@ __global__ __launch_bounds__(256) void k_bary_bwd_hits(const float *__restrict__
                                                        const int4 *__restrict__ hits, int T, int Q, float *grad_tet,
                                                        float *grad_pts, int accumulate, const float *__restrict__ gocc,
                                                        float *grad_pred, float *missPart, int nMissParts, int *hitWords,
-                                                       const int *__restrict__ ulist, int pad, const int4 *__restrict__ spill)
+                                                       const int *__restrict__ ulist, int pad, const int4 *__restrict__ spill, int pin)
 {
     __shared__ float wsum[4];
     __shared__ float s_vals[kMissStride];
     __shared__ int s_last;
     __shared__ float4 s_rows[4][192];
     __shared__ float s_park[13][256];
-    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
-    const bool side = grad_pred && (int)blockIdx.x < nMissParts;   // block-uniform
+    const int2 sb = shape_block(pin);                                  // shape-per-XCD placement
+    const int b = sb.x, bx = sb.y, tid = threadIdx.x, lane = tid & 63;
+    const bool side = grad_pred && bx < nMissParts;                // block-uniform
     float missPartial = 0.f;
     if (side) {
         float gm = 0.f;
-        for (int q = blockIdx.x * blockDim.x + tid; q < Q; q += nMissParts * blockDim.x)
+        for (int q = bx * blockDim.x + tid; q < Q; q += nMissParts * blockDim.x)
             if (cond[(size_t)b * Q + q] < 0.f) gm += gocc[(size_t)b * Q + q];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) gm += __shfl_xor(gm, off);
@@ -1645,7 +1664,7 @@ __global__ __launch_bounds__(256) void k_bary_bwd_hits(const float *__restrict__
         __syncthreads();
         missPartial = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
     }
-    const int t = blockIdx.x * blockDim.x + tid;
+    const int t = bx * blockDim.x + tid;
     const bool live = t < T;
     int4 h = live ? stream_load(hits + (size_t)b * T + t) : make_int4(-1, -1, -1, -1);
     const bool spilled = h.w != kHitOverflow && h.x >= 0 && (h.x & kHitSpilled) != 0;   // four more slots in the spill record
@@ -1673,11 +1692,20 @@ __global__ __launch_bounds__(256) void k_bary_bwd_hits(const float *__restrict__
         auto add_hit = [&](int q) {
             if (q < 0) return;
             const size_t i = (size_t)b * Q + q;
-            if (cond[i] != tf) return;                             // accepted here, but a lower-index tet won the query
-            float G3[3];
-            tet_grad_add(g, pts + i * 3, reinterpret_cast<const float4 *>(grad_w)[i], acc, G3);
-            if (grad_pts) { grad_pts[i * 3] = G3[0]; grad_pts[i * 3 + 1] = G3[1]; grad_pts[i * 3 + 2] = G3[2]; }
-            if (grad_pred) gp += gocc[i];
+            // all four gathers leave together: the winner test below only selects (waiting for `cond` before asking for
+            // the rest made every slot two memory latencies long)
+            const float c = cond[i], go = grad_pred ? gocc[i] : 0.f;
+            const float pq[3] = {pts[i * 3], pts[i * 3 + 1], pts[i * 3 + 2]};
+            const float4 gw = reinterpret_cast<const float4 *>(grad_w)[i];
+            const bool won = c == tf;                              // else: accepted here, but a lower-index tet won the query
+            float G3[3], a2[12];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) a2[k] = acc[k];
+            tet_grad_add(g, pq, gw, a2, G3);
+#pragma unroll
+            for (int k = 0; k < 12; ++k) acc[k] = won ? a2[k] : acc[k];
+            if (won && grad_pts) { grad_pts[i * 3] = G3[0]; grad_pts[i * 3 + 1] = G3[1]; grad_pts[i * 3 + 2] = G3[2]; }
+            gp = won ? gp + go : gp;
         };
 #define DEFTET_CSWAP(a, b) { const unsigned lo_ = min(hu[a], hu[b]), hi_ = max(hu[a], hu[b]); hu[a] = lo_; hu[b] = hi_; }
         if (!__any(spilled)) {                                       // the usual wave: four slots, five comparators
@@ -1745,8 +1773,8 @@ __global__ __launch_bounds__(256) void k_bary_bwd_hits(const float *__restrict__
     float *mp = missPart + (size_t)b * kMissStride;
     int *ticket = hitWords + pad + b;
     if (tid == 0) {
-        mem_write_f32(mp + blockIdx.x, missPartial);
-        if (blockIdx.x == 0) mem_write_f32(mp + kMissParts, gp);   // thread 0 of workgroup 0 is the lane of tet 0
+        mem_write_f32(mp + bx, missPartial);
+        if (bx == 0) mem_write_f32(mp + kMissParts, gp);   // thread 0 of workgroup 0 is the lane of tet 0
         __builtin_amdgcn_s_waitcnt(0);                             // both exchanges have returned: they are at the memory side
         s_last = atomicAdd(ticket, 1) == nMissParts - 1;
     }
@@ -1970,7 +1998,7 @@ static int pit_scan(const Layout &L, const float *tet, const float *pts, float *
         DEFTET_HIP(hipMemsetAsync(ucount, 0, (size_t)3 * hit_pad(B) * 4, st));
     }
     DEFTET_LAUNCH(k_finalize, gq, blk, st, tet, pts, T, Q, L.result, cond, bary, pred, occ, (const int4 *)hit_buf, ucount,
-                  hit_buf ? hit_buf + hit_list_off(B, T) : nullptr, L.counters, L.irregT, hit_pad(B));
+                  hit_buf ? hit_buf + hit_list_off(B, T) : nullptr, L.counters, L.irregT, hit_pad(B), pin_shapes(Q));
     return DEFTET_OK;
 }
 
@@ -1991,7 +2019,7 @@ extern "C" int deftet_point_in_tet_f32(const float *tet, const float *pts, float
         }
         DEFTET_LAUNCH(k_brute, gq, blk, st, L.rec, pts, T, Q, L.result);
         DEFTET_LAUNCH(k_finalize, gq, blk, st, tet, pts, T, Q, L.result, cond, bary, pred, occ, (const int4 *)nullptr, (int *)nullptr,
-                      (int *)nullptr, (const int *)nullptr, L.irregT, 0);
+                      (int *)nullptr, (const int *)nullptr, L.irregT, 0, pin_shapes(Q));
         return DEFTET_OK;
     }
     rc = pit_prepare(L, pts, B, Q, st);
@@ -2110,7 +2138,7 @@ extern "C" int deftet_point_in_tet_bwd_f32(const float *tet, const float *pts, c
         int32_t *words = const_cast<int32_t *>(hit_buf) + hit_cnt_off(B, T);    // counters / ticket / flag: the buffer is this library's own
         DEFTET_LAUNCH(k_bary_bwd_hits, dim3(tblocks, B), dim3(256), st, tet, pts, cond, grad_w, (const int4 *)hit_buf, T, Q,
                       grad_tet, grad_pts, accumulate, grad_occ, grad_pred, missPart, nMissParts, words,
-                      (const int *)(hit_buf + hit_list_off(B, T)), hit_pad(B), (const int4 *)(hit_buf + hit_spill_off(B, T, Q)));
+                      (const int *)(hit_buf + hit_list_off(B, T)), hit_pad(B), (const int4 *)(hit_buf + hit_spill_off(B, T, Q)), pin_shapes(Q));
     } else if (workspace) {
         const size_t need = deftet_point_in_tet_bwd_workspace_bytes(B, T, Q);
         DEFTET_CHECK_ARG(workspace_bytes >= need && ((uintptr_t)workspace & 255) == 0,
