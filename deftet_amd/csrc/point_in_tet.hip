@@ -296,6 +296,23 @@ __global__ __launch_bounds__(256) void k_query_bbox(const float *__restrict__ pt
     }
 }
 
+// Placement of a (chunk, shape) grid for the kernels whose gathers go to PER-SHAPE arrays in arbitrary order (the
+// queries' coordinates, weights' gradients, winners, predictions): workgroup i is observed to run on XCD i % 8, so
+// with shape = i % B all workgroups of an XCD work on the same shape(s) and the gathered arrays of a shape (3.6 MB in
+// the backward at 100,000 queries) stay in that XCD's 4 MiB L2, instead of every L2 pulling every shape's arrays.
+// Returns (shape, chunk).  Speed only; any placement is correct.
+__device__ __forceinline__ int2 shape_block(int pin)
+{
+    if (!pin) return make_int2(blockIdx.y, blockIdx.x);
+    const int L = blockIdx.y * gridDim.x + blockIdx.x, nB = gridDim.y;
+    return make_int2(L % nB, L / nB);
+}
+// ... when a shape's gathered arrays fit an L2.  Beyond that the shapes are better taken one after the other by the
+// whole chip (the arrays of ONE shape then live in the 256 MiB Infinity Cache; eight at a time do not: configs[3], one
+// million queries per shape, backward 153 -> 165 us with the pinned placement; configs[1]: 33.4 -> 22.1 us, configs[2]:
+// 62.7 -> 60.1 us, k_finalize 30.5 -> 27.5 us).
+static inline int pin_shapes(int Q) { return (size_t)Q * 36 <= ((size_t)4 << 20); }
+
 // ------------------------------------------------------------------------------------
 // Counting sort of the regular queries into grid cells WITHOUT global atomics.
 // (Round-1 history: one returning global atomicAdd per query = 800 k fabric transactions = 41 us;
@@ -437,12 +454,13 @@ constexpr int kSortKeep = 4;
 static_assert(kMaxRowBlocks <= kSortThreads, "one thread per chunk run");
 __global__ __launch_bounds__(kSortThreads) void k_slab_sort(const float4 *__restrict__ localQ, int Q, const float *__restrict__ gparam,
                                                             int G, int Gx, const int *__restrict__ pre, int nblk, int nblkPad,
-                                                            int chunkQ, long long cellStride, int *table, float4 *sortedQ)
+                                                            int chunkQ, long long cellStride, int *table, float4 *sortedQ, int pin)
 {
     extern __shared__ __attribute__((aligned(16))) int cnt[];       // [rows of the part][GxP] counts -> starts (-> placement cursors)
     __shared__ int wsum[kSortThreads / 64], wsum2[kSortThreads / 64];
     __shared__ int runStart[kMaxRowBlocks + 1], runSrc[kMaxRowBlocks];
-    const int b = blockIdx.y, cz = blockIdx.x / kParts, part = blockIdx.x % kParts, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int2 sb = shape_block(pin);                               // the runs are gathered from all over the shape's localQ
+    const int b = sb.x, cz = sb.y / kParts, part = sb.y % kParts, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int GxP = Gx | 1;                                         // odd pitch: the transposed read below is conflict-free
     // cell rows of this part: (cy * kSub) / G in [part * kSubPerPart, (part + 1) * kSubPerPart)
     const int cyLo = (part * kSubPerPart * G + kSub - 1) / kSub, cyHi = ((part + 1) * kSubPerPart * G + kSub - 1) / kSub;
@@ -1169,22 +1187,6 @@ __device__ __forceinline__ float triple(const float *a, const float *b, const fl
     return (a[0] * x0 + a[1] * x1) + a[2] * x2;
 }
 
-// Placement of a (chunk, shape) grid for the kernels whose gathers go to PER-SHAPE arrays in arbitrary order (the
-// queries' coordinates, weights' gradients, winners, predictions): workgroup i is observed to run on XCD i % 8, so
-// with shape = i % B all workgroups of an XCD work on the same shape(s) and the gathered arrays of a shape (3.6 MB in
-// the backward at 100,000 queries) stay in that XCD's 4 MiB L2, instead of every L2 pulling every shape's arrays.
-// Returns (shape, chunk).  Speed only; any placement is correct.
-__device__ __forceinline__ int2 shape_block(int pin)
-{
-    if (!pin) return make_int2(blockIdx.y, blockIdx.x);
-    const int L = blockIdx.y * gridDim.x + blockIdx.x, nB = gridDim.y;
-    return make_int2(L % nB, L / nB);
-}
-// ... when a shape's gathered arrays fit an L2.  Beyond that the shapes are better taken one after the other by the
-// whole chip (the arrays of ONE shape then live in the 256 MiB Infinity Cache; eight at a time do not: configs[3], one
-// million queries per shape, backward 153 -> 165 us with the pinned placement; configs[1]: 33.4 -> 22.1 us, configs[2]:
-// 62.7 -> 60.1 us, k_finalize 30.5 -> 27.5 us).
-static inline int pin_shapes(int Q) { return (size_t)Q * 36 <= ((size_t)4 << 20); }
 
 __global__ __launch_bounds__(256) void k_finalize(const float *__restrict__ tet, const float *__restrict__ pts, int T,
                                                   int Q, const int *__restrict__ result, float *cond, float *bary,
@@ -1974,7 +1976,7 @@ static int pit_prepare(const Layout &L, const float *pts, int B, int Q, hipStrea
                   L.localQ, L.pre, L.counters, L.irregQ);
     const size_t shm = align_up((size_t)((L.G + kParts - 1) / kParts + 1) * (L.Gx | 1) * sizeof(int), 16);   // rows of a y-quarter
     DEFTET_LAUNCH_SHM(k_slab_sort, dim3(L.G * kParts, B), dim3(kSortThreads), shm, st, L.localQ, Q, L.gparam, L.G, L.Gx, L.pre, L.nRowBlk, L.nblkPad,
-                      L.chunkQ, L.cellStride, L.table, L.sortedQ);
+                      L.chunkQ, L.cellStride, L.table, L.sortedQ, (size_t)Q * 16 <= ((size_t)4 << 20));
     return DEFTET_OK;
 }
 

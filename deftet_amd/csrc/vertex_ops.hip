@@ -74,7 +74,11 @@ __global__ __launch_bounds__(256) void k_gather_bwd(const float *__restrict__ gr
                                                     int idxBatch, int accumulate)
 {
     const int b = blockIdx.y;
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    // XCD-aware placement (workgroup i runs on XCD i % 8, each XCD has its own L2): every XCD takes one CONTIGUOUS eighth of
+    // the vertex range, so the tets shared by vertices of neighbouring workgroups are fetched into one L2 instead of up to
+    // four.  The launch rounds the grid up to a multiple of 8.  Speed only; any placement is correct.
+    const int per = gridDim.x >> 3, vb = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    const int gid = vb * blockDim.x + threadIdx.x;
     const int v = gid >> 2, k = gid & 3;
     float ax = 0.f, ay = 0.f, az = 0.f;
     if (v < V) {
@@ -167,7 +171,7 @@ extern "C" int deftet_tet_gather_bwd_f32(const float *grad_tet, const int32_t *o
     DEFTET_CHECK_ARG(B <= 65535, "n_batch=%d exceeds 65535", B);
     if (B == 0 || V == 0) return DEFTET_OK;
     DEFTET_CHECK_ARG(offsets && grad_pos && (T == 0 || (grad_tet && slots)), "null pointer");
-    DEFTET_LAUNCH(vtx::k_gather_bwd, dim3((V + 63) / 64, B), dim3(256), as_stream(stream_), grad_tet, offsets, slots, grad_pos, V,
+    DEFTET_LAUNCH(vtx::k_gather_bwd, dim3((((V + 63) / 64 + 7) / 8) * 8, B), dim3(256), as_stream(stream_), grad_tet, offsets, slots, grad_pos, V,
                   (long long)T * 4, idx_batch, accumulate);
     return DEFTET_OK;
 }
