@@ -49,6 +49,8 @@ SIGNATURES = {
     "deftet_rowdot_workspace_bytes": (_sz, [_i]),
     "deftet_rowdot_f32": (_i, [_vp, _vp, _vp, _i, _ll, _vp, _sz, _vp]),
     "deftet_rowdot2_f32": (_i, [_vp, _vp, _ll, _vp, _vp, _ll, _vp, _i, _vp, _sz, _vp]),
+    "deftet_sqrt_rowsum_f32": (_i, [_vp, _f, _vp, _i, _ll, _vp, _sz, _vp]),
+    "deftet_sqrt_rowsum_bwd_f32": (_i, [_vp, _f, _vp, _vp, _i, _ll, _vp]),
     "deftet_builder_workspace_bytes": (_sz, [_i, _i]),
     "deftet_tet_adj_share_i32": (_i, [_vp, _vp, _vp, _i, _i, _vp, _sz, _vp]),
     "deftet_tet_adj_share_host": (_i, [_vp, _vp, _vp, _i, _i]),

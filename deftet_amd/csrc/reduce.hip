@@ -13,8 +13,10 @@ namespace red {
 
 constexpr int kParts = 128;
 
+// SQRT: the terms are sqrt(a + eps) instead (b unused) — the surface terms' "mean of sqrt(d^2 + 1e-10)" in one launch
+template <bool SQRT = false>
 __device__ __forceinline__ float rowdot_slice(const float *__restrict__ a, const float *__restrict__ b, long long r,
-                                              long long n_cols)
+                                              long long n_cols, float eps = 0.f)
 {
     const float *pa = a + r * n_cols;
     const float *pb = b ? b + r * n_cols : nullptr;
@@ -25,7 +27,9 @@ __device__ __forceinline__ float rowdot_slice(const float *__restrict__ a, const
         const long long n4 = n_cols / 4;
         for (long long i = tid; i < n4; i += stride) {
             const float4 x = reinterpret_cast<const float4 *>(pa)[i];
-            if (pb) {
+            if (SQRT) {
+                acc += (sqrtf(x.x + eps) + sqrtf(x.y + eps)) + (sqrtf(x.z + eps) + sqrtf(x.w + eps));
+            } else if (pb) {
                 const float4 y = reinterpret_cast<const float4 *>(pb)[i];
                 acc += (x.x * y.x + x.y * y.y) + (x.z * y.z + x.w * y.w);
             } else {
@@ -33,7 +37,7 @@ __device__ __forceinline__ float rowdot_slice(const float *__restrict__ a, const
             }
         }
     } else {
-        for (long long i = tid; i < n_cols; i += stride) acc += pb ? pa[i] * pb[i] : pa[i];
+        for (long long i = tid; i < n_cols; i += stride) acc += SQRT ? sqrtf(pa[i] + eps) : pb ? pa[i] * pb[i] : pa[i];
     }
     return acc;
 }
@@ -56,16 +60,17 @@ __global__ __launch_bounds__(256) void k_rowdot_partial(const float *__restrict_
 constexpr int kTicketRows = 1024, kTicketSlots = 32;
 __device__ int g_tickets[kTicketSlots][kTicketRows];               // zero at load; every launch leaves its slot zero again
 
+template <bool SQRT>
 __global__ __launch_bounds__(256) void k_rowdot_fused(const float *__restrict__ a, const float *__restrict__ b, float *part,
                                                       long long n_cols, const float *__restrict__ a2, const float *__restrict__ b2,
-                                                      long long n_cols2, float *out, int slot)
+                                                      long long n_cols2, float *out, int slot, float eps)
 {
     __shared__ float wsum[4];
     __shared__ float vals[kParts];
     __shared__ int s_last;
     const long long r = blockIdx.y;
-    float acc = rowdot_slice(a, b, r, n_cols);
-    if (a2) acc += rowdot_slice(a2, b2, r, n_cols2);
+    float acc = rowdot_slice<SQRT>(a, b, r, n_cols, eps);
+    if (!SQRT && a2) acc += rowdot_slice(a2, b2, r, n_cols2);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
@@ -101,8 +106,26 @@ __global__ __launch_bounds__(64) void k_rowdot_final(const float *__restrict__ p
     if (threadIdx.x == 0) out[r] = v;
 }
 
+// backward of out[r] = sum_c sqrt(x[r,c] + eps):  gx[r,c] = g[r] * 0.5 / sqrt(x[r,c] + eps)
+__global__ __launch_bounds__(256) void k_sqrt_rowsum_bwd(const float *__restrict__ x, const float *__restrict__ g, float *gx,
+                                                         long long n_cols, float eps)
+{
+    const long long r = blockIdx.y;
+    const float gr = g[r] * 0.5f;
+    const float *px = x + r * n_cols;
+    float *po = gx + r * n_cols;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_cols; i += (long long)gridDim.x * 256) po[i] = gr / sqrtf(px[i] + eps);
+}
+
 }  // namespace red
 }  // namespace deftet
+
+// a slot of tickets per launch in flight (shared by every entry point of this file)
+static int next_ticket_slot()
+{
+    static std::atomic<unsigned> next{0};
+    return (int)(next.fetch_add(1) % deftet::red::kTicketSlots);
+}
 
 extern "C" size_t deftet_rowdot_workspace_bytes(int n_rows) { return (size_t)(n_rows > 0 ? n_rows : 0) * deftet::red::kParts * 4; }
 
@@ -117,10 +140,9 @@ extern "C" int deftet_rowdot2_f32(const float *a, const float *b, long long n_co
     hipStream_t st = deftet::as_stream(stream_);
     float *part = static_cast<float *>(workspace);
     if (n_rows <= deftet::red::kTicketRows) {
-        static std::atomic<unsigned> next{0};                       // a slot of tickets per launch in flight
-        const int slot = (int)(next.fetch_add(1) % deftet::red::kTicketSlots);
-        DEFTET_LAUNCH(deftet::red::k_rowdot_fused, dim3(deftet::red::kParts, n_rows), dim3(256), st, a, b, part, n_cols, a2, b2, n_cols2, out,
-                      slot);
+        const int slot = next_ticket_slot();
+        DEFTET_LAUNCH(deftet::red::k_rowdot_fused<false>, dim3(deftet::red::kParts, n_rows), dim3(256), st, a, b, part, n_cols, a2, b2, n_cols2,
+                      out, slot, 0.f);
         return DEFTET_OK;
     }
     DEFTET_LAUNCH(deftet::red::k_rowdot_partial, dim3(deftet::red::kParts, n_rows), dim3(256), st, a, b, part, n_cols, a2, b2, n_cols2);
@@ -132,4 +154,33 @@ extern "C" int deftet_rowdot_f32(const float *a, const float *b, float *out, int
                                  size_t workspace_bytes, void *stream_)
 {
     return deftet_rowdot2_f32(a, b, n_cols, nullptr, nullptr, 0, out, n_rows, workspace, workspace_bytes, stream_);
+}
+
+// out[r] = sum_c sqrt(x[r,c] + eps) for up to 1,024 rows, one launch (the ticket form of the row sums above); its backward
+// gx[r,c] = g[r] / (2 sqrt(x[r,c] + eps)).  What the surface terms of utils/mesh_utils.py:14 ("sqrt(d^2 + 1e-10)", then
+// the mean over the points) reduce to per shape.
+extern "C" int deftet_sqrt_rowsum_f32(const float *x, float eps, float *out, int n_rows, long long n_cols, void *workspace,
+                                      size_t workspace_bytes, void *stream_)
+{
+    DEFTET_CHECK_ARG(n_rows >= 0 && n_cols >= 0 && n_rows <= deftet::red::kTicketRows, "bad size (at most 1,024 rows)");
+    if (n_rows == 0) return DEFTET_OK;
+    DEFTET_CHECK_ARG(x && out, "null pointer");
+    DEFTET_CHECK_ARG(workspace && workspace_bytes >= deftet_rowdot_workspace_bytes(n_rows), "workspace null or too small");
+    const int slot = next_ticket_slot();
+    DEFTET_LAUNCH(deftet::red::k_rowdot_fused<true>, dim3(deftet::red::kParts, n_rows), dim3(256), deftet::as_stream(stream_), x,
+                  (const float *)nullptr, static_cast<float *>(workspace), n_cols, (const float *)nullptr, (const float *)nullptr, 0LL, out,
+                  slot, eps);
+    return DEFTET_OK;
+}
+
+extern "C" int deftet_sqrt_rowsum_bwd_f32(const float *x, float eps, const float *grad_out, float *grad_x, int n_rows,
+                                          long long n_cols, void *stream_)
+{
+    DEFTET_CHECK_ARG(n_rows >= 0 && n_cols >= 0 && n_rows <= 65535, "bad size");
+    if (n_rows == 0 || n_cols == 0) return DEFTET_OK;
+    DEFTET_CHECK_ARG(x && grad_out && grad_x, "null pointer");
+    const long long blocks = (n_cols + 1023) / 1024;
+    DEFTET_LAUNCH(deftet::red::k_sqrt_rowsum_bwd, dim3((unsigned)(blocks < 1 ? 1 : blocks > 4096 ? 4096 : blocks), n_rows), dim3(256),
+                  deftet::as_stream(stream_), x, grad_out, grad_x, n_cols, eps);
+    return DEFTET_OK;
 }

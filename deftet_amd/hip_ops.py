@@ -255,6 +255,49 @@ def rowdot(a, b=None, a2=None, b2=None):
     return out
 
 
+class _SqrtRowSum(torch.autograd.Function):
+    """out[r] = sum over the trailing dims of sqrt(x[r] + eps): one launch forward, one backward."""
+
+    @staticmethod
+    def forward(ctx, x, eps):
+        _lib.require_gpu(x)
+        lib = _lib.load()
+        x = _f32c(x)
+        R = x.shape[0]
+        if R > 1024:
+            raise RuntimeError("sqrt_rowsum: at most 1024 rows, got %d" % R)
+        ctx.save_for_backward(x)
+        ctx.eps = float(eps)
+        if x.numel() == 0:
+            return torch.zeros(R, device=x.device, dtype=torch.float32)
+        out = torch.empty(R, device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            ws = _lib.workspace(x.device, lib.deftet_rowdot_workspace_bytes(R))
+            _lib.check(lib.deftet_sqrt_rowsum_f32(_lib.ptr(x), float(eps), _lib.ptr(out), R, x.numel() // max(R, 1), _lib.ptr(ws), ws.numel(),
+                                                  _lib.current_stream(x.device)), "deftet_sqrt_rowsum_f32")
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (x,) = ctx.saved_tensors
+        lib = _lib.load()
+        g = _f32c(grad_out)
+        gx = torch.empty_like(x)
+        if x.numel() == 0:
+            return gx, None
+        R = x.shape[0]
+        with torch.cuda.device(x.device):
+            _lib.check(lib.deftet_sqrt_rowsum_bwd_f32(_lib.ptr(x), ctx.eps, _lib.ptr(g), _lib.ptr(gx), R, x.numel() // max(R, 1),
+                                                      _lib.current_stream(x.device)), "deftet_sqrt_rowsum_bwd_f32")
+        return gx, None
+
+
+def sqrt_rowsum(x, eps):
+    """[R] sums of sqrt(x + eps) over everything but the first dimension (differentiable): the tail of the reference's
+    point-to-surface term, `sqrt(d^2 + 1e-10)` then the mean over the points (utils/mesh_utils.py:14)."""
+    return _SqrtRowSum.apply(x, eps)
+
+
 # --------------------------------------------------------------------------------- A2-A6 builders
 def _i32_tets(tet_list, device):
     t = torch.as_tensor(tet_list)

@@ -103,20 +103,21 @@ def surface_terms(vertices_bxnx3, boundary_bxfx3, gt_points_bxmx3, per_face=20, 
     return chamfer, analytic, normal
 
 
-def surface_terms_batched(vertices_bxnx3, boundary_list, gt_points_bxmx3, per_face=20, generator=None):
+def surface_terms_batched(vertices_bxnx3, boundary_list, gt_points_bxmx3, per_face=20, generator=None, stacked=False):
     """(chamfer [B], analytic [B], normal [B]) for B predicted surfaces with DIFFERENT face counts in one launch
     sequence — what `DefTet.forward_surface_align` needs per step, where the reference calls `forward` shape by shape
     (layers/DefTet/deftet.py:89-103).  `boundary_list[b]` = int64 [F_b,3] vertex indices of shape b's surface.
 
     The faces are padded to F_max (padding = the degenerate triangle of vertex 0, masked out everywhere); the three
     operators get the per-shape counts: A8 `face_edge_adj_ragged`, A10 `nn_index_ragged` (F_b * per_face samples), A9
-    through its `n_face_b` argument.  A shape with an empty surface yields (1, 1, 1) like `DefTet.forward` (:159-163)."""
+    through its `n_face_b` argument.  A shape with an empty surface yields (1, 1, 1) like `DefTet.forward` (:159-163).
+    stacked=True returns the three rows as one [3,B] tensor (the caller's means over the batch are then one launch)."""
     B, dev = vertices_bxnx3.shape[0], vertices_bxnx3.device
     counts = [int(f.shape[0]) for f in boundary_list]
     one = torch.ones(B, device=dev)
     f_max = max(counts) if counts else 0
     if f_max == 0:
-        return one, one.clone(), one.clone()
+        return torch.ones(3, B, device=dev) if stacked else (one, one.clone(), one.clone())
     faces = torch.nn.utils.rnn.pad_sequence([f.long() for f in boundary_list], batch_first=True)      # [B,F_max,3], zeros beyond F_b
     n_face = torch.tensor(counts, device=dev)
     empty = n_face == 0
@@ -132,6 +133,10 @@ def surface_terms_batched(vertices_bxnx3, boundary_list, gt_points_bxmx3, per_fa
     chamfer = hip_ops.chamfer_to_cloud(tri, gt, counts, per_face, generator) / (n_face * per_face).clamp(min=1)
     # analytic: ground-truth cloud -> predicted surface (A9)
     d2, _ = tet_analytic_distance_f_batch(gt, tri, n_face.float())
-    d2 = torch.where(empty[:, None, None], torch.zeros_like(d2), d2)
-    analytic = torch.sqrt(d2 + SQRT_EPS).mean(-1).mean(-1)
-    return (torch.where(empty, one, chamfer), torch.where(empty, one, analytic), torch.where(empty, one, normal))
+    if min(counts) == 0:                                                                               # (host-side: no synchronisation)
+        d2 = torch.where(empty[:, None, None], torch.zeros_like(d2), d2)
+    # sqrt(d^2 + 1e-10) and the mean over the points in one launch (one more for the backward) instead of six + six
+    analytic = hip_ops.sqrt_rowsum(d2, SQRT_EPS) / max(d2[0].numel(), 1)
+    terms = torch.stack((chamfer, analytic, normal))                                                   # [3,B]
+    terms = torch.where(empty[None, :], torch.ones_like(terms), terms)
+    return terms if stacked else (terms[0], terms[1], terms[2])

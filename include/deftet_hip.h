@@ -130,6 +130,14 @@ int deftet_rowdot_f32(const float *a, const float *b, float *out, int n_rows, lo
 int deftet_rowdot2_f32(const float *a, const float *b, long long n_cols, const float *a2, const float *b2,
                        long long n_cols2, float *out, int n_rows, void *workspace, size_t workspace_bytes,
                        void *stream);
+/* out[r] = sum_c sqrt(x[r,c] + eps), n_rows <= 1024, one launch (workspace: deftet_rowdot_workspace_bytes), and its
+ * backward grad_x[r,c] = grad_out[r] / (2 sqrt(x[r,c] + eps)).  The reference's surface terms end in
+ * "sqrt(d^2 + 1e-10)" followed by the mean over the points (utils/mesh_utils.py:14, layers/DefTet/deftet.py:168-181):
+ * this is that tail for the point-to-surface term, per shape. */
+int deftet_sqrt_rowsum_f32(const float *x, float eps, float *out, int n_rows, long long n_cols, void *workspace,
+                           size_t workspace_bytes, void *stream);
+int deftet_sqrt_rowsum_bwd_f32(const float *x, float eps, const float *grad_out, float *grad_x, int n_rows,
+                               long long n_cols, void *stream);
 
 /* ---------------------------------------------------------------------------------
  * A2-A6  adjacency builders.  Device variants take device pointers and a caller

@@ -472,6 +472,23 @@ def test_normal_consistency_op_vs_torch_autograd(cuda, oracle):
     assert torch.allclose(tri.grad.double(), t64.grad, rtol=2e-4, atol=1e-6 * t64.grad.abs().max().item())
 
 
+@pytest.mark.parametrize("shape", [(8, 97344, 1), (3, 1001), (1, 7, 5), (5, 0)])
+def test_sqrt_rowsum_vs_torch_autograd(cuda, shape):
+    """hip_ops.sqrt_rowsum (the tail of the point-to-surface term: sqrt(d^2 + 1e-10) summed per shape) == the fp64 torch
+    composition, value and gradient; aligned and unaligned row lengths, an empty row set."""
+    from deftet_amd import hip_ops
+    g = torch.Generator(device=cuda).manual_seed(11)
+    x = (torch.rand(*shape, device=cuda, generator=g) ** 4).requires_grad_(True)          # many values near zero, where the eps matters
+    w = torch.linspace(-1.0, 2.0, shape[0], device=cuda)
+    out = hip_ops.sqrt_rowsum(x, 1e-10)
+    (out * w).sum().backward()
+    x64 = x.detach().double().requires_grad_(True)
+    want = torch.sqrt(x64 + 1e-10).reshape(shape[0], -1).sum(-1)
+    (want * w.double()).sum().backward()
+    assert out.shape == (shape[0],) and torch.allclose(out.double(), want, rtol=1e-5, atol=1e-7)
+    assert torch.allclose(x.grad.double(), x64.grad, rtol=1e-5, atol=1e-9)
+
+
 # ---- independent SEMANTIC pins for the CUDA-only rows (they do not pin the oracle's rounding; they break the loop of one
 # author's transcription being checked against itself: each compares the HIP operator with a different formulation of
 # what the reference kernel is FOR, computed in fp64 / integers with numpy, outside a mask of genuinely ambiguous inputs)
