@@ -233,3 +233,18 @@ def test_forward_surface_align_save_writes_the_reference_obj_files(cuda, oracle,
     m2.gather_tet_pos(pos0, other)
     key = (other.device, tuple(other.shape), pos0.shape[1])
     assert D._TOPOLOGIES[key][0] is not before[key][0]
+    # the same tet list for every shape (what the reference passes) is kept ONCE; lists that differ keep their own copies;
+    # both give torch.gather's values and its gradient
+    assert before[key][0].tet_idx.shape[0] == 1
+    mixed = idxB.clone()
+    mixed[1] = mixed[1].flip(0)
+    for ix, rows in ((idxB, 1), (mixed, B)):
+        p1, p2 = pos0.clone().requires_grad_(True), pos0.clone().requires_grad_(True)
+        got = m2.gather_tet_pos(p1, ix)
+        assert D._TOPOLOGIES[key][0].tet_idx.shape[0] == rows
+        want = torch.gather(p2, 1, ix.long().reshape(B, -1, 1).expand(-1, -1, 3)).reshape(B, -1, 4, 3)
+        assert torch.equal(got, want)
+        w = torch.linspace(0.5, 1.5, got.numel(), device=cuda).reshape(got.shape)
+        (got * w).sum().backward()
+        (want * w).sum().backward()
+        assert torch.allclose(p1.grad, p2.grad, rtol=1e-5, atol=1e-6)
