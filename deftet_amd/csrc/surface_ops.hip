@@ -1919,6 +1919,10 @@ __device__ __forceinline__ void tri_query_chunk(int W, int part, float (*s_lb)[6
 // The number of chunks is only known on the device and at most P/64 + (number of rows); a fixed grid strides over them.
 constexpr int kTriQueryBlocks = 8192;
 
+// (Register budget of FOUR waves per SIMD: the allocator takes 145 VGPRs = three waves when left alone; held to 128 it
+// spills nine dwords and the kernel runs 0.76 -> 0.63 ms at 8 x 97 k points — five waves, 96 VGPRs with 176 bytes of
+// scratch, and six are slower again: geometry step 2.80 / 2.68 / 2.85 / 3.24 ms for 3 / 4 / 5 / 6 waves.)
+__attribute__((amdgpu_waves_per_eu(4, 8)))
 __global__ __launch_bounds__(kTriChunkWaves * 64) void k_tri_query_coop(const float *__restrict__ pts, const float *__restrict__ face,
                                                                          const float *__restrict__ nfb, int P, const TGrid *__restrict__ gp,
                                                                          const int *__restrict__ cellStart, const int *__restrict__ list,
