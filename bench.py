@@ -23,6 +23,7 @@ from __future__ import annotations
 
 import argparse
 import ctypes
+import gc
 import json
 import os
 import socket
@@ -252,15 +253,28 @@ def timed(wl, lib, steps, warmup, world, barrier=True):
     """W untimed warm-up steps, then exactly K steps bracketed by barrier + synchronize on both sides.  Returns the wall
     time, the per-step HIP-event times (ms) and the dominant kernel's (total ms, launches) from the library's own
     events on the launch stream."""
+    # Everything the timed region will allocate lazily is made to exist during the warm-up: the library's launch events
+    # (selected already here, their warm-up samples dropped below), this function's step events (recorded once), and no
+    # cyclic garbage collection inside the region — one timed region of 20 steps was once 45 ms long with a median step
+    # of 0.229 ms (profiles/README.md), i.e. a single host-side stall; the per-step maximum is printed beside the mean
+    # (normally the FIRST step, ~0.15 ms longer than the others: its launches meet an idle GPU after the synchronize).
+    lib.deftet_profile_select(wl.dominant)
     for i in range(warmup):
         wl.step(i)
     wl.drain()
     torch.cuda.synchronize()
+    tot_ms, cnt = ctypes.c_double(0), ctypes.c_longlong(0)
+    lib.deftet_profile_read(ctypes.byref(tot_ms), ctypes.byref(cnt))
     lib.deftet_profile_select(wl.dominant)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    for e in evs:
+        e.record()
+    gc.collect()
     if world > 1 and barrier:
         torch.distributed.barrier()
     torch.cuda.synchronize()
-    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    gc_was_on = gc.isenabled()
+    gc.disable()
     t0 = time.perf_counter()
     for i in range(steps):
         evs[i].record()
@@ -271,6 +285,8 @@ def timed(wl, lib, steps, warmup, world, barrier=True):
     if world > 1 and barrier:
         torch.distributed.barrier()
     elapsed = time.perf_counter() - t0
+    if gc_was_on:
+        gc.enable()
     tot_ms, cnt = ctypes.c_double(0), ctypes.c_longlong(0)
     lib.deftet_profile_read(ctypes.byref(tot_ms), ctypes.byref(cnt))
     lib.deftet_profile_select(b"")
@@ -402,6 +418,7 @@ def summarize(wl, elapsed, per_step, kern_ms_tot, kern_cnt, steps, world, peak_m
     return {
         "value": round(world * wl.pairs_per_step * steps / elapsed / (1e6 if wl.unit.startswith("M ") else 1.0), 1), "unit": wl.unit,
         "ms_per_step": round(elapsed / steps * 1e3, 4), "ms_per_step_median": round(statistics.median(per_step), 4),
+        "ms_per_step_max": round(max(per_step), 4),
         "roofline": roof,
     }
 
@@ -487,6 +504,7 @@ def main():
             "value": main_line["value"], "unit": main_line["unit"],
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": main_line["ms_per_step"], "ms_per_step_median": main_line["ms_per_step_median"],
+            "ms_per_step_max": main_line["ms_per_step_max"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": wl.describe(),

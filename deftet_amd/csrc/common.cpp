@@ -46,11 +46,15 @@ void prof_begin(hipStream_t st)
 {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     if (g_prof.used + 2 > g_prof.ev.size()) {
-        for (int i = 0; i < 2; ++i) {
+        // grow by 64 launches at a time and record every new event once: what the runtime allocates lazily behind an event
+        // then exists after the first (warm-up) launch instead of appearing launch by launch inside a timed region
+        for (int i = 0; i < 128; ++i) {
             hipEvent_t e;
-            if (hipEventCreate(&e) != hipSuccess) return;
+            if (hipEventCreate(&e) != hipSuccess) break;
+            (void)hipEventRecord(e, st);
             g_prof.ev.push_back(e);
         }
+        if (g_prof.used + 2 > g_prof.ev.size()) return;
     }
     (void)hipEventRecord(g_prof.ev[g_prof.used], st);        // timing aid: a failed record only loses a sample
 }
