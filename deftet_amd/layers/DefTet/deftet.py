@@ -144,10 +144,18 @@ class DefTet(nn.Module):
         return hip_ops.tet_energies(tet_bxfx4x3, None, pow_v=pow, pow_e=self.pow)[:, 0]
 
     def amips_energy(self, tet_bxfx4x3, inverse_v, scale=20, center_occ=None, square=False):
-        e = hip_ops.tet_energies(tet_bxfx4x3, inverse_v, pow_v=self.pow, pow_e=self.pow, scale=scale)[:, 1]
         if square:
-            raise NotImplementedError("square=True is never used by the reference (deftet.py:286-287)")
-        return e
+            # never used by the reference's callers (deftet.py:286-287): the per-tet energies squared before the mean.  The
+            # fused operator only hands out the means, so this option is the reference's own torch composition (on the GPU).
+            n_batch = tet_bxfx4x3.shape[0]
+            a, b, c, d = (tet_bxfx4x3[:, :, k, :].unsqueeze(2) * scale for k in range(4))
+            offset_vec = torch.cat([b - a, c - a, d - a], dim=2)
+            jac = torch.bmm(offset_vec.reshape(-1, 3, 3), inverse_v.unsqueeze(0).expand_as(offset_vec).reshape(-1, 3, 3))
+            trace = (jac ** 2).sum(-1).sum(-1)
+            det = (jac[:, 0, :] * torch.linalg.cross(jac[:, 1, :], jac[:, 2, :], dim=-1)).sum(-1)       # utils/matrix_utils.py:42-47
+            energy = trace * torch.pow(det ** 2 + EPS, -1.0 / 3.0) * (det >= 0.0).float()
+            return (energy.reshape(n_batch, -1) ** 2).mean(-1)
+        return hip_ops.tet_energies(tet_bxfx4x3, inverse_v, pow_v=self.pow, pow_e=self.pow, scale=scale)[:, 1]
 
     def edge_length(self, tet_bxfx4x3, pow=2):
         return hip_ops.tet_energies(tet_bxfx4x3, None, pow_v=self.pow, pow_e=pow, scale=20)[:, 2]

@@ -341,14 +341,16 @@ def main():
     vv = D.volume_variance(tg, pow=4)
     am = D.amips_energy(tg, inv_v)
     el = D.edge_length(tg, pow=4)
+    am2 = D.amips_energy(tg, inv_v, square=True)                     # (:286-287; no caller of the reference passes it)
     grads = []
-    for y in (vv, am, el):
+    for y in (vv, am, el, am2):
         (gr,) = torch.autograd.grad(y.sum(), tg, retain_graph=True)
         grads.append(gr.numpy())
     out = dict(tets=tets, verts=verts, tet_bxtx4x3=tet.numpy(), face_fx3=f3, tetidx_fx2=t2, occ=occ.numpy(),
                pred=pred.numpy(), cond=cond.numpy(), cond_after=c2.numpy(), pasted=pasted.numpy(),
                inverse_v=inv_v.numpy(), volume_variance=vv.detach().numpy(), amips=am.detach().numpy(),
-               edge_length=el.detach().numpy(), g_volume_variance=grads[0], g_amips=grads[1], g_edge_length=grads[2])
+               edge_length=el.detach().numpy(), g_volume_variance=grads[0], g_amips=grads[1], g_edge_length=grads[2],
+               amips_square=am2.detach().numpy(), g_amips_square=grads[3])
     for i in range(3):
         out["boundary_%d" % i] = bnd[i].numpy()
         out["internal_%d" % i] = inn[i].numpy()
