@@ -91,9 +91,14 @@ __device__ unsigned long long g_phase[kPhaseWaves][16];
         if ((threadIdx.x & 63) == 0) g_phase[ph_w_][i] += (unsigned long long)(ph_n_ - ph_t_); \
         ph_t_ = ph_n_;                                                                 \
     } while (0)
+#define PHASE_COUNT(i, v)                                                              \
+    do {                                                                               \
+        if ((threadIdx.x & 63) == 0) g_phase[ph_w_][i] += (unsigned long long)(v);     \
+    } while (0)
 #else
 #define PHASE_DECL
 #define PHASE_MARK(i)
+#define PHASE_COUNT(i, v)
 #endif
 
 // ------------------------------------------------------------------------------------
@@ -164,11 +169,12 @@ __device__ __forceinline__ bool accept(const Planes &P, float px, float py, floa
 // ------------------------------------------------------------------------------------
 constexpr float kErrScale = 4.76837158203125e-07f;      // 8 u = 2^-21
 constexpr float kErrAbs = 7.5231638e-37f;              // 2^-120
-constexpr int kGridWords = 16;                         // floats of grid parameters per shape
+constexpr int kGridWords = 20;                         // floats of grid parameters per shape
 
 struct Grid {
     float o[3], inv[3], lo[3], hi[3];
     float pe[3];     // kErrScale * max(|lo|, |hi|): the query-side part of the filter's error radius
+    float cs[3];     // upper bound of a cell's edge (1.001 * extent / cells, >= 1e-30): k_tet_scan_wave's candidate-distance bound
 };
 constexpr int kBoxBlocks = 64;
 
@@ -206,6 +212,9 @@ __device__ __forceinline__ Grid reduce_grid(const float *__restrict__ part, int 
         g.lo[k] = l;
         g.hi[k] = h;
         g.pe[k] = kErrScale * fmaxf(fabsf(l), fabsf(h));
+        // n cells of axis k span at most n * cs[k]: with inv > 0 a cell is ext / cells wide up to the three roundings of
+        // cell_of (<< 0.1 %); with inv == 0 every regular query sits in cell 0 and the box is <= 1e-30 wide
+        g.cs[k] = fmaxf(1.001f * ((h - l) / (float)(k == 0 ? Gx : G)), 1e-30f);
     }
     return g;
 }
@@ -220,6 +229,7 @@ __device__ __forceinline__ Grid load_grid(const float *__restrict__ gp)
         g.lo[k] = gp[6 + k];
         g.hi[k] = gp[9 + k];
         g.pe[k] = gp[12 + k];
+        g.cs[k] = gp[15 + k];
     }
     return g;
 }
@@ -356,7 +366,7 @@ __global__ __launch_bounds__(256) void k_slab_local(const float *__restrict__ pt
     if (blk == 0 && tid == 0) {                                    // publish for k_slab_sort / the traversal
         float *gp = gparam + b * kGridWords;                       // (constant indices: a dynamic one sends g through LDS — 13 us)
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { gp[k] = g.o[k]; gp[3 + k] = g.inv[k]; gp[6 + k] = g.lo[k]; gp[9 + k] = g.hi[k]; gp[12 + k] = g.pe[k]; }
+        for (int k = 0; k < 3; ++k) { gp[k] = g.o[k]; gp[3 + k] = g.inv[k]; gp[6 + k] = g.lo[k]; gp[9 + k] = g.hi[k]; gp[12 + k] = g.pe[k]; gp[15 + k] = g.cs[k]; }
     }
     for (int i = tid; i <= R1; i += 256) hist[i] = 0;
     __syncthreads();
@@ -1178,6 +1188,676 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan_slab(const float *_
     PHASE_MARK(2);                                                       // [2] publish (atomics, record store) / re-scan
 }
 
+// ------------------------------------------------------------------------------------
+// k_tet_scan_wave (DEFTET_PIT_AUTO since round 4).  Same result and hit records as k_tet_scan_slab; three changes:
+//
+//  1. FILTER-ONLY SETUP.  The lane no longer evaluates the reference's four cross products: it builds the filter from
+//     the three faces at v0 (m0 = e1 x e2, m1 = e3 x e1, m2 = e2 x e3, e_i = v_i - v0), the fourth as
+//     m3 = -(m0 + m1 + m2) (exact identity for exact normals) and ONE determinant det = m0 . e3.  With N*_i the exact
+//     normal of the reference's ordering i and D*_i(p) = N*_i . (p - a_i) (exact arithmetic on the fp32 vertices), w_k the
+//     box extents of the tet and G_k = 2 w_l w_m (>= sum of the absolute products of any face normal's component k):
+//       reference:  |dotp_i - D*_i(p)| <= sum_k |p_k - a_k| (4.03 u |N*_k| + 4.02 u G_k) <= 8.05 u sum_k G_k |p_k - a_k|
+//                   (its normal: two rounded products, one difference, rounded edges: 4.01 u G_k per component; the
+//                   dot product: 3.01 u; the rounded p - a: u)
+//       here:       |m_ik - N*_ik| <= 4.01 u G_k for i < 3 (fma form: not worse), <= 15.05 u G_k for the derived one
+//                   (three such errors + two rounded additions of terms <= 2 G_k), base point v0 (faces 0-2) / v1 (face 3)
+//                   lies on the exact plane, so sigma m_i . (p - base) differs from sigma D*_i(p) by <= 15.05 u sum_k G_k |p_k - base_k|;
+//                   evaluating it as A_i = fma(N_i0, x, fma(N_i1, y, fma(N_i2, z, C_i))), C_i = fma(-sigma, c_i, -E_i):
+//                   3.01 u sum|m||p| + 7.02 u sum|m||base| + 4.01 u E_i    (as for k_tet_scan_slab).
+//     Hence  E_i = 24 u sum_k G_k R_k  +  8 u sum_k |m_ik| (P_k + 2 M_k)  + 2^-120   with R_k >= |p_k - vertex_k| for every
+//     candidate this lane is ever offered covers all of it (24 > 23.1, 8 > 7.02; >= 3.7 % to spare against the ~10 u relative
+//     error of evaluating E_i itself), and   min_i A_i > 0 => the reference accepts,  min_i A_i < -2 max_i E_i => it rejects;
+//     in between the reference predicate decides (exact_accept), so the result stays bit-exact.
+//     R_k: the candidates come from grid cells c with c in [first, last] along axis k, a range that contains the cells
+//     of the tet's enlarged box; a vertex and a candidate are then both within (box edge + n cells) of a common point:
+//     R_k = (ehi_k - elo_k) + (n_k + 1) cs_k, n_k = number of cells of that range (the lane's own, or its group's
+//     footprint, see 2), cs_k >= cell edge (Grid::cs).
+//     "Regular" needs the reference's four dotv4 to share a strict sign and |dotv4| >= 2^-7 w^3: |dotv4_i - det| <= 97 u w^3
+//     (same error terms), so |det| >= 2^-7 (1 + 2^-7) w^3 implies it (2^-14 = 1024 u).
+//  2. THE CANDIDATES OF A WAVE ARE STAGED IN LDS.  64 consecutive tets of a spatially coherent mesh share their
+//     neighbourhood.  The wave picks a pivot lane, groups the lanes whose (x, y) cell footprint is within two / one cells
+//     of the pivot's (up to two groups: a wave that straddles two columns of the mesh), reduces the group's cell box
+//     (packed 16-bit max over DPP), reads the bounds of the box's (cz, cy) rows over the group's x range (two 4-byte loads
+//     per row, a wave scan gives their positions in LDS) and copies the rows' queries with coalesced loads, balanced over
+//     the lanes through an owner scan.  A lane's candidates are then ONE contiguous LDS range — all staged rows of its own
+//     z slabs — walked with ds_read_b128 and no addressing arithmetic; acceptances are published at once (atomicMin) and
+//     kept in LDS slots.  Footprints with more queries than a chunk holds are staged slab range by slab range.
+//     Everything here is per wave: no barrier.
+//  3. Lanes that fit no group (incoherent tet order, over-long footprints) walk the global table as k_tet_scan_slab does.
+// ------------------------------------------------------------------------------------
+constexpr int kWvRows = 192;                            // (cz, cy) rows of a staged footprint (three per lane)
+constexpr int kWvCap = 96;                              // staged queries per chunk
+constexpr int kWvSlots = 6;                             // accepted queries a lane keeps: record + half a spill record
+static_assert(kWvRows <= 254 && kWvRows % 64 == 0 && kWvSlots >= 4 && kWvSlots <= 8, "row ids are bytes; the records hold four + four");
+constexpr int kWvMinGroup = 16;                         // lanes a footprint group must have to be worth staging
+constexpr float kRelScale = 2.86102294921875e-06f;      // 48 u = 24 u * (the 2 of G_k = 2 w_l w_m)
+constexpr float kTauSlim = kTau * (1.0f + 1.0f / 128.0f);
+#ifndef PIT_WAVES2
+#define PIT_WAVES2 5
+#endif
+// Diagnostic builds (tools/probes/build_variant.sh ... -DPIT_STOP=n): the kernel ends after stage n with everything computed so
+// far kept alive, so that instruction counters can be read per stage (differences between the builds).
+#ifndef PIT_STOP
+#define PIT_STOP 0
+#endif
+template <typename T>
+__device__ __forceinline__ void keep_alive(T x) { asm volatile("" ::"v"(x)); }
+
+struct __attribute__((aligned(16))) WaveStage {        // 6.6 KB per wave: with the hit slots 32.6 KB per workgroup
+    float4 q[kWvCap + 8];                               // the chunk's queries, rows in (cz, cy) order (+ 8: the last step's dead slots)
+    float4 F[16][4];                                    // filter of the 16 tets of the current block: plane i = (Nx, Ny, Nz, -)
+    float4 Cv[16];                                      // ... and its four plane constants
+    int4 seg[16];                                       // their candidate ranges: (first, end, twoEmax bits, -)
+    int delta[kWvRows];                                 // position of the row's first query in sortedQ - rowBase
+    int cnt[64], pcnt[64], ppend[2][64];                // per tet lane: accepted / undecided candidates so far, the first two undecided
+    unsigned short rowBase[kWvRows + 4];                // exclusive prefix of the row lengths; [R] = total (< 2^16, checked)
+    unsigned char marker[kWvCap];                       // row id + 1 at the LDS position where a non-empty row starts
+};
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp0(int v)             // lanes without a source (or masked rows) read 0
+{
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, true);
+}
+// inclusive scans over the 64 lanes (row_shr 1/2/4/8 inside rows of 16, then row_bcast 15 / 31)
+__device__ __forceinline__ int wave_scan_add(int x)
+{
+    x += dpp0<0x111, 0xf>(x); x += dpp0<0x112, 0xf>(x); x += dpp0<0x114, 0xf>(x); x += dpp0<0x118, 0xf>(x);
+    x += dpp0<0x142, 0xa>(x); x += dpp0<0x143, 0xc>(x);
+    return x;
+}
+__device__ __forceinline__ int wave_scan_max(int x)    // x >= 0
+{
+    x = max(x, dpp0<0x111, 0xf>(x)); x = max(x, dpp0<0x112, 0xf>(x)); x = max(x, dpp0<0x114, 0xf>(x)); x = max(x, dpp0<0x118, 0xf>(x));
+    x = max(x, dpp0<0x142, 0xa>(x)); x = max(x, dpp0<0x143, 0xc>(x));
+    return x;
+}
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk_max(unsigned a, unsigned b)
+{
+    const u16x2 r = __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b));
+    return __builtin_bit_cast(unsigned, r);
+}
+// max of both 16-bit halves over all lanes (max is idempotent: the row masks of a scan are not needed); wave-uniform
+__device__ __forceinline__ unsigned wave_pk_max(unsigned v)
+{
+    v = pk_max(v, (unsigned)dpp0<0x111, 0xf>((int)v)); v = pk_max(v, (unsigned)dpp0<0x112, 0xf>((int)v));
+    v = pk_max(v, (unsigned)dpp0<0x114, 0xf>((int)v)); v = pk_max(v, (unsigned)dpp0<0x118, 0xf>((int)v));
+    v = pk_max(v, (unsigned)dpp0<0x142, 0xf>((int)v)); v = pk_max(v, (unsigned)dpp0<0x143, 0xf>((int)v));
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+// wave-private LDS hand-off between lanes: DS operations of a wave execute in order, the fence keeps the compiler from
+// moving them
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ void atomic_smin_off_nh(int *base, unsigned byte_off, int v)   // base: SGPR pair written long before (no hazard)
+{
+    asm volatile("global_atomic_smin %0, %1, %2" ::"v"(byte_off), "v"(v), "s"(base) : "memory");
+}
+
+__device__ __forceinline__ float sel(lanemask_t m, float if_set, float if_clear)
+{
+    return __int_as_float(sel(m, __float_as_int(if_set), __float_as_int(if_clear)));
+}
+// x + (this lane's bit of m)
+__device__ __forceinline__ int add_bit(int x, lanemask_t m)
+{
+    int d;
+    asm("v_addc_co_u32 %0, vcc, 0, %1, %2" : "=v"(d) : "v"(x), "s"(m) : "vcc");
+    return d;
+}
+// min of the four plane values a matrix instruction left in this lane.  Raw instructions: fminf() on a matrix result makes
+// the compiler quiet each operand first (four extra v_max per candidate).  The leading s_nop covers the wait states a
+// vector instruction needs after the matrix instruction that wrote its operands (the compiler pads that hazard for its own
+// instructions, not across an asm boundary; 4x4x1 f32 takes two passes).
+__device__ __forceinline__ float min4_after_mfma(f32x4 d)
+{
+    float t, r;
+    asm volatile("s_nop 7\n\tv_min_f32 %0, %2, %3\n\tv_min3_f32 %1, %4, %5, %0" : "=&v"(t), "=v"(r) : "v"(d[2]), "v"(d[3]), "v"(d[0]), "v"(d[1]));
+    return r;
+}
+__device__ __forceinline__ float min_abs(float a, float b)
+{
+    float r;
+    asm("v_min_f32 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+__device__ __forceinline__ void cross_fma(float ax, float ay, float az, float bx, float by, float bz, float *n)
+{
+    n[0] = fmaf(ay, bz, -(az * by));
+    n[1] = fmaf(az, bx, -(ax * bz));
+    n[2] = fmaf(ax, by, -(ay * bx));
+}
+
+// irregular tet (flat / needle / non-finite / huge): listed for k_finalize, its hits are not recorded
+__device__ __noinline__ void irregular_tet_slow(const float *__restrict__ tet, int t, int b, int T, int Q, const float *__restrict__ pts,
+                                                int *counters, int *irregT, const int *__restrict__ irregQ, int *result, int4 *hits)
+{
+    const int k = atomicAdd(&counters[b * 4 + 0], 1);
+    irregT[(size_t)b * T + k] = t;
+    if (hits) hits[(size_t)b * T + t] = make_int4(-1, -1, -1, kHitOverflow);
+    if (counters[b * 4 + 1] > 0) irregular_tail_slow(tet, t, b, T, Q, pts, counters, irregQ, result);
+}
+
+// exact re-scan of one tet (more than two undecided candidates: practically never): every accepted query is published
+// and the lane's LDS slots are refilled from scratch; returns the number of accepted queries
+__device__ __noinline__ int exact_rescan_slots(const float *__restrict__ tv, int t, const int *__restrict__ tb, const float4 *__restrict__ sq,
+                                               int *res, int G, int Gx, int cx0, int cx1, int cy0, int cy1, int cz0, int cz1, float m,
+                                               int *slotCol)
+{
+    float vv[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) vv[k] = tv[k];
+    Planes P;
+    make_planes(vv, P);
+    float elo[3], ehi[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        elo[k] = fminf(fminf(vv[k], vv[3 + k]), fminf(vv[6 + k], vv[9 + k])) - m;
+        ehi[k] = fmaxf(fmaxf(vv[k], vv[3 + k]), fmaxf(vv[6 + k], vv[9 + k])) + m;
+    }
+    const int Gp = table_pitch(G);
+    int hcnt = 0;
+    for (int cz = cz0; cz <= cz1; ++cz)
+        for (int cy = cy0; cy <= cy1; ++cy) {
+            const int s = tb[table_off(cz, cx0, cy, Gx, Gp)], e = tb[table_off(cz, cx1 + 1, cy, Gx, Gp)];
+            for (int j = s; j < e; ++j) {
+                const float4 q = sq[j];
+                if (q.x >= elo[0] && q.x <= ehi[0] && q.y >= elo[1] && q.y <= ehi[1] && q.z >= elo[2] && q.z <= ehi[2] &&
+                    accept(P, q.x, q.y, q.z)) {
+                    const int qi = __float_as_int(q.w);
+                    atomicMin(&res[qi], t);
+                    slotCol[min(hcnt, kWvSlots) * 256] = qi;
+                    ++hcnt;
+                }
+            }
+        }
+    return hcnt;
+}
+
+__global__ __launch_bounds__(256, PIT_WAVES2) void k_tet_scan_wave(const float *__restrict__ tet, int T, int Q,
+                                                  const float *__restrict__ gparam, int G, int Gx, const int *__restrict__ table,
+                                                  long long cellStride, const float4 *__restrict__ sortedQ, int *result, int *counters,
+                                                  int *irregT, int4 *hits, const float *__restrict__ pts,
+                                                  const int *__restrict__ irregQ, int *ucount, int hpad, int4 *spill)
+{
+    __shared__ WaveStage s_w[4];
+    __shared__ int s_hit[kWvSlots + 1][256];                           // [slot][thread]; slot kWvSlots swallows the overflow
+    if (ucount && blockIdx.x == 0 && threadIdx.x == 0) {               // per-shape words of the hit buffer, see k_tet_scan_slab
+        ucount[blockIdx.y] = 0;
+        ucount[hpad + blockIdx.y] = 0;
+        ucount[2 * hpad + blockIdx.y] = 0;
+    }
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    WaveStage &W = s_w[tid >> 6];
+    W.cnt[lane] = 0;
+    W.pcnt[lane] = 0;
+    const int nblk = gridDim.x;
+    const int per = (nblk + 7) >> 3;
+    const int vb = (blockIdx.x & 7) * per + (blockIdx.x >> 3);        // XCD-aware mapping, see k_tet_scan
+    const int t = vb * blockDim.x + tid;
+    const bool valid = vb < nblk && t < T;
+    if (__builtin_amdgcn_ballot_w64(valid) == 0ull) return;           // (every other lane stays: the wave works together)
+    PHASE_DECL;
+    float v[12];
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(tet + ((size_t)b * T + (valid ? t : T - 1)) * 12);
+        float4 a = src[0], bq = src[1], c = src[2];
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+        v[4] = bq.x; v[5] = bq.y; v[6] = bq.z; v[7] = bq.w;
+        v[8] = c.x; v[9] = c.y; v[10] = c.z; v[11] = c.w;
+    }
+    const Grid g = load_grid(gparam + b * kGridWords);
+    // --- filter-only setup -------------------------------------------------------------------------------------------
+    // Everything that does not depend on the lane's group is finished here, so that the vertices and normals are dead
+    // before the wave-level part starts: N_i, cE_i = fl(-sigma c_i - Eabs_i), max Eabs; the group-dependent part of the
+    // radius is subtracted afterwards (C_i = fl(cE_i - erel): one more rounding of <= u (|c_i| + E_i), covered by the
+    // 16 u of the |base| term where 8.02 u are needed).
+    Filter F;
+    float eabsMax, mrg, wk[3];
+    bool regular, ingrid;
+    int cx0, cx1, cy0, cy1, cz0, cz1;
+    {
+        float mN[4][3], det;
+        {
+            const float e1x = v[3] - v[0], e1y = v[4] - v[1], e1z = v[5] - v[2];
+            const float e2x = v[6] - v[0], e2y = v[7] - v[1], e2z = v[8] - v[2];
+            const float e3x = v[9] - v[0], e3y = v[10] - v[1], e3z = v[11] - v[2];
+            cross_fma(e1x, e1y, e1z, e2x, e2y, e2z, mN[0]);            // face (v0 v1 v2): the reference's ordering 0
+            cross_fma(e3x, e3y, e3z, e1x, e1y, e1z, mN[1]);            // face (v1 v0 v3): ordering 1
+            cross_fma(e2x, e2y, e2z, e3x, e3y, e3z, mN[2]);            // face (v2 v3 v0): ordering 2
+#pragma unroll
+            for (int k = 0; k < 3; ++k) mN[3][k] = -((mN[0][k] + mN[1][k]) + mN[2][k]);   // face (v3 v2 v1): ordering 3
+            det = fmaf(mN[0][0], e3x, fmaf(mN[0][1], e3y, mN[0][2] * e3z));
+        }
+        float blo[3], bhi[3], mx[3];                                   // box; largest |coordinate| per axis
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            blo[k] = fminf(fminf(v[k], v[3 + k]), fminf(v[6 + k], v[9 + k]));
+            bhi[k] = fmaxf(fmaxf(v[k], v[3 + k]), fmaxf(v[6 + k], v[9 + k]));
+            wk[k] = bhi[k] - blo[k];
+            mx[k] = fmaxf(fabsf(blo[k]), fabsf(bhi[k]));
+        }
+        const float w = fmaxf(fmaxf(wk[0], wk[1]), wk[2]);
+        // every comparison is written so that NaN yields "irregular" (NaN poisons det; Inf / huge values show up in mx)
+        regular = fmaxf(fmaxf(mx[0], mx[1]), mx[2]) <= kBig && w >= kWMin && fabsf(det) >= kTauSlim * ((w * w) * w);
+        mrg = w * kMargin;
+        float elo[3], ehi[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            elo[k] = blo[k] - mrg;
+            ehi[k] = bhi[k] + mrg;
+        }
+        // no regular query can lie in the enlarged box -> nothing to traverse
+        ingrid = !(ehi[0] < g.lo[0] || elo[0] > g.hi[0] || ehi[1] < g.lo[1] || elo[1] > g.hi[1] || ehi[2] < g.lo[2] || elo[2] > g.hi[2]);
+        cx0 = cell_of(elo[0], g.o[0], g.inv[0], Gx); cx1 = cell_of(ehi[0], g.o[0], g.inv[0], Gx);
+        cy0 = cell_of(elo[1], g.o[1], g.inv[1], G); cy1 = cell_of(ehi[1], g.o[1], g.inv[1], G);
+        cz0 = cell_of(elo[2], g.o[2], g.inv[2], G); cz1 = cell_of(ehi[2], g.o[2], g.inv[2], G);
+        const float sigma = det > 0.f ? 1.0f : -1.0f;
+        float S[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) S[k] = fmaf(mx[k], 2.0f * kErrScale, g.pe[k]);                 // 8 u P_k + 16 u M_k
+        eabsMax = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float n0 = mN[i][0], n1 = mN[i][1], n2 = mN[i][2];
+            const float *a = i < 3 ? v : v + 3;                        // a point of the face: v0 (faces 0-2), v1 (face 3)
+            const float c = fmaf(n0, a[0], fmaf(n1, a[1], n2 * a[2]));
+            const float E = fmaf(fabsf(n0), S[0], fmaf(fabsf(n1), S[1], fabsf(n2) * S[2]));
+            F.N[i][0] = sigma * n0; F.N[i][1] = sigma * n1; F.N[i][2] = sigma * n2;
+            F.C[i] = fmaf(-sigma, c, -E);
+            eabsMax = fmaxf(eabsMax, E);
+        }
+    }
+    const bool work = valid && regular && ingrid;
+    const int Gp = table_pitch(G);
+    const int *tb = table + (size_t)b * cellStride;
+    const float4 *sq = sortedQ + (size_t)b * Q;
+    if (PIT_STOP == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { keep_alive(F.N[i][0]); keep_alive(F.N[i][1]); keep_alive(F.N[i][2]); keep_alive(F.C[i]); }
+        keep_alive(eabsMax); keep_alive(mrg); keep_alive(wk[0]); keep_alive(wk[1]); keep_alive(wk[2]);
+        keep_alive(cx0); keep_alive(cx1); keep_alive(cy0); keep_alive(cy1); keep_alive(cz0); keep_alive(cz1); keep_alive((int)work);
+        return;
+    }
+    // --- footprint groups (wave-uniform scalars) ------------------------------------------------------------------------
+    // group g: cell box [gx0, gx1] x [gy0, gy0 + gny) x [gz0, gz0 + gnz).  Its rows are numbered (slab << gsh) + y with a
+    // power-of-two y pitch (ids with y >= gny are empty rows) and take whole blocks of 64 ids: group 0 the first gK0 blocks
+    int gx0[2], gx1[2], gy0[2], gz0[2], gny[2], gnz[2], gsh[2];
+    int gid = -1;                                                      // the lane's group
+    int ncx = cx1 - cx0 + 1, ncy = cy1 - cy0 + 1;                      // cells of the lane's candidate source along x / y
+    int nBlk = 0, gK0 = 0;                                             // blocks of 64 row ids in use; of them group 0's
+    {
+        lanemask_t rem = __builtin_amdgcn_ballot_w64(work);
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            gx0[p] = gx1[p] = gy0[p] = gz0[p] = 0;
+            gny[p] = gnz[p] = gsh[p] = 0;
+            if (__popcll(rem) < kWvMinGroup) continue;
+            const int pl = __ffsll((long long)rem) - 1;
+            const int px0 = __builtin_amdgcn_readlane(cx0, pl), px1 = __builtin_amdgcn_readlane(cx1, pl);
+            const int py0 = __builtin_amdgcn_readlane(cy0, pl), py1 = __builtin_amdgcn_readlane(cy1, pl);
+            // (unsigned compare of the shifted difference: one instruction per bound)
+            const bool in = ((rem >> lane) & 1ull) != 0ull && (unsigned)(cx0 - px0 + 2) <= 4u && (unsigned)(cx1 - px1 + 2) <= 4u &&
+                            (unsigned)(cy0 - py0 + 1) <= 2u && (unsigned)(cy1 - py1 + 1) <= 2u;
+            const lanemask_t gm = __builtin_amdgcn_ballot_w64(in);
+            if (__popcll(gm) < kWvMinGroup) { rem = 0ull; continue; }  // incoherent order: everything left walks the global table
+            const unsigned ax = wave_pk_max(in ? ((unsigned)cx1 | ((0xFFFFu - (unsigned)cx0) << 16)) : 0u);
+            const unsigned ay = wave_pk_max(in ? ((unsigned)cy1 | ((0xFFFFu - (unsigned)cy0) << 16)) : 0u);
+            const unsigned az = wave_pk_max(in ? ((unsigned)cz1 | ((0xFFFFu - (unsigned)cz0) << 16)) : 0u);
+            rem &= ~gm;
+            const int ux0 = (int)(0xFFFFu - (ax >> 16)), uy0 = (int)(0xFFFFu - (ay >> 16)), uz0 = (int)(0xFFFFu - (az >> 16));
+            const int ny = (int)(ay & 0xFFFFu) - uy0 + 1, nz = (int)(az & 0xFFFFu) - uz0 + 1;
+            const int sh = ny <= 1 ? 0 : 32 - __builtin_clz((unsigned)(ny - 1));              // pitch 2^sh >= ny
+            const int blocks = ((nz << sh) + 63) >> 6;
+            if (nBlk + blocks > kWvRows / 64) continue;                // too many rows: its lanes walk the global table
+            gx0[p] = ux0; gx1[p] = (int)(ax & 0xFFFFu); gy0[p] = uy0; gz0[p] = uz0; gny[p] = ny; gnz[p] = nz; gsh[p] = sh;
+            if (p == 0) gK0 = blocks;
+            else if (nBlk == 0) gK0 = 0;                               // (group 0 was dropped: group 1 starts at row 0)
+            nBlk += blocks;
+            if (in) { gid = p; ncx = gx1[p] - ux0 + 1; ncy = ny; }
+        }
+    }
+    // --- the group-dependent part of the error radius ---------------------------------------------------------------------
+    {
+        // |candidate - vertex| per axis: box edge + the cells the candidates may come from (+ 1 for the roundings of cell_of)
+        const float R0 = fmaf(2.0f, mrg, wk[0]) + (float)(ncx + 1) * g.cs[0];
+        const float R1 = fmaf(2.0f, mrg, wk[1]) + (float)(ncy + 1) * g.cs[1];
+        const float R2 = fmaf(2.0f, mrg, wk[2]) + (float)(cz1 - cz0 + 2) * g.cs[2];
+        const float erel = fmaf(kRelScale, fmaf(wk[1] * wk[2], R0, fmaf(wk[0] * wk[2], R1, (wk[0] * wk[1]) * R2)), kErrAbs);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) F.C[i] -= erel;
+        F.twoEmax = 2.0f * (eabsMax + erel);
+    }
+    if (PIT_STOP == 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { keep_alive(F.N[i][0]); keep_alive(F.N[i][1]); keep_alive(F.N[i][2]); keep_alive(F.C[i]); }
+        keep_alive(F.twoEmax); keep_alive(gid); keep_alive(nBlk); keep_alive(gK0);
+        keep_alive(cx0); keep_alive(cx1); keep_alive(cy0); keep_alive(cy1); keep_alive(cz0); keep_alive(cz1); keep_alive((int)work);
+        return;
+    }
+    PHASE_MARK(0);                                                       // [0] load + setup + grouping
+    int *resb = uniform_ptr(result + (size_t)b * Q);
+    asm volatile("s_nop 4" ::: "memory");                               // VALU-written SGPR base -> vector memory: five wait states, paid once
+    int hcnt = 0;                                                       // accepted so far
+    int pend0 = -1, pend1 = -1, npend = 0;                              // query ids of undecided candidates
+    const unsigned slotB = (unsigned)tid * 4u;
+    auto test = [&](const float4 q) {
+        const float A0 = fmaf(F.N[0][0], q.x, fmaf(F.N[0][1], q.y, fmaf(F.N[0][2], q.z, F.C[0])));
+        const float A1 = fmaf(F.N[1][0], q.x, fmaf(F.N[1][1], q.y, fmaf(F.N[1][2], q.z, F.C[1])));
+        const float A2 = fmaf(F.N[2][0], q.x, fmaf(F.N[2][1], q.y, fmaf(F.N[2][2], q.z, F.C[2])));
+        const float A3 = fmaf(F.N[3][0], q.x, fmaf(F.N[3][1], q.y, fmaf(F.N[3][2], q.z, F.C[3])));
+        const float av = fminf(fminf(A0, A1), fminf(A2, A3));
+        const int qi = __float_as_int(q.w);
+        if (av > F.twoEmax) {                                           // certain (twoEmax >= 0): kept in the lane's LDS slots, published
+            // after the loops (an atomic per acceptance here is a vector-memory instruction with one or two live lanes in
+            // most wave-iterations: 28 of them per wave kept the address unit as busy as the round-3 gathers did)
+            *reinterpret_cast<int *>(reinterpret_cast<char *>(&s_hit[0][0]) + (unsigned)min(hcnt, kWvSlots) * 1024u + slotB) = qi;
+            hcnt += 1;
+        }
+        const bool band = fabsf(av) <= F.twoEmax;                       // rare: decided by the reference predicate after the loops
+        if (__builtin_amdgcn_ballot_w64(band) != 0ull) {                // (wave-uniform branch: the selects stay out of the common path)
+            pend1 = band ? pend0 : pend1;
+            pend0 = band ? qi : pend0;
+            npend = band ? npend + 1 : npend;
+        }
+    };
+    // --- the groups' rows and queries are staged together, the lanes of both groups walk their ranges in one loop --------
+    if (nBlk > 0) {
+        int gS[3], len[3], base[3];
+        // row id r = 64 k + lane: (slab, y) of a footprint; bounds of its part over the group's x range.  A block of ids
+        // belongs to ONE group, so everything but the lane's (slab, y) is scalar
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            gS[k] = 0; len[k] = 0; base[k] = 0;
+            if (k < nBlk) {
+                const bool second = k >= gK0;                           // wave-uniform
+                const int sh = second ? gsh[1] : gsh[0], ny = second ? gny[1] : gny[0], nz = second ? gnz[1] : gnz[0];
+                const int zb = second ? gz0[1] : gz0[0], yb = second ? gy0[1] : gy0[0];
+                const unsigned xa = (unsigned)(second ? gx0[1] : gx0[0]) * (unsigned)Gp, xe = (unsigned)((second ? gx1[1] : gx1[0]) + 1) * (unsigned)Gp;
+                const int rl = lane + 64 * (second ? k - gK0 : k);
+                const int rz = rl >> sh, ry = rl & ((1 << sh) - 1);
+                const bool ok = rz < nz && ry < ny;
+                const unsigned line = ((unsigned)(zb + (ok ? rz : 0)) * (unsigned)(Gx + 1)) * (unsigned)Gp + (unsigned)(yb + (ok ? ry : 0));
+                const int a = ld_off<int>(tb, (line + xa) * 4u), e = ld_off<int>(tb, (line + xe) * 4u);
+                gS[k] = a;
+                len[k] = ok ? e - a : 0;
+            }
+        }
+        int N = 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (k < nBlk) {
+                const int incl = wave_scan_add(len[k]);
+                base[k] = N + incl - len[k];
+                N += __builtin_amdgcn_readlane(incl, 63);
+            }
+        const int Rtot = nBlk * 64;
+        // a row that does not fit a chunk by itself (very dense queries): nothing is staged, everybody walks the global table
+        const bool fitsRows = __builtin_amdgcn_ballot_w64(max(max(len[0], len[1]), len[2]) > kWvCap) == 0ull && N < 65536;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (k < nBlk) {
+                W.rowBase[lane + 64 * k] = (unsigned short)base[k];
+                W.delta[lane + 64 * k] = gS[k] - base[k];
+            }
+        if (lane == 0) W.rowBase[Rtot] = (unsigned short)N;
+        wave_sync();
+        if (PIT_STOP == 3) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { keep_alive(F.N[i][0]); keep_alive(F.N[i][1]); keep_alive(F.N[i][2]); keep_alive(F.C[i]); }
+            keep_alive(F.twoEmax); keep_alive(gid); keep_alive(N); keep_alive(len[0] + len[1] + len[2]); keep_alive(base[0] + base[1] + base[2]);
+            keep_alive(cx0); keep_alive(cx1); keep_alive(cy0); keep_alive(cy1); keep_alive(cz0); keep_alive(cz1); keep_alive((int)work);
+            return;
+        }
+        PHASE_MARK(4);                                                   // [4] row bounds, scan
+        // the lane's rows: the slabs [cz0, cz1] of its group's footprint, all of the footprint's y rows
+        const bool mine2 = gid == 1;
+        const int rowOff = mine2 ? gK0 * 64 : 0, gz = mine2 ? gz0[1] : gz0[0], gs = mine2 ? gsh[1] : gsh[0];
+        int rn = rowOff + ((cz0 - gz) << gs);                          // next row to walk
+        const int re = rowOff + ((cz1 + 1 - gz) << gs);
+        if (!fitsRows) gid = -1;
+        int r0 = fitsRows ? 0 : Rtot;
+#pragma unroll 1
+        while (r0 < Rtot) {                                              // chunks of whole rows
+            const int B0 = __builtin_amdgcn_readfirstlane(W.rowBase[r0]);
+            int r1 = Rtot;
+            if (N - B0 > kWvCap) {
+                r1 = r0;
+#pragma unroll 1
+                for (int j = 0; j < 3; ++j) {
+                    const int rc = r0 + 1 + lane + 64 * j;
+                    const int cnt = rc <= Rtot ? W.rowBase[rc] - B0 : 0x7FFFFFFF;
+                    const lanemask_t fits = __builtin_amdgcn_ballot_w64(cnt <= kWvCap);  // a prefix of the lanes (counts are monotone)
+                    if (fits == ~0ull) { r1 += 64; continue; }
+                    r1 += __ffsll((long long)~fits) - 1;
+                    break;
+                }
+            }
+            const int Nc = __builtin_amdgcn_readfirstlane(W.rowBase[r1]) - B0;
+            // owner of every staged position: non-empty rows mark their first position, a max-scan spreads the marks
+            for (int i = lane; i < Nc; i += 64) W.marker[i] = 0;
+            wave_sync();
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                if (k < nBlk) {
+                    const int r = lane + 64 * k;
+                    if (len[k] > 0 && r >= r0 && r < r1) W.marker[base[k] - B0] = (unsigned char)(r + 1);
+                }
+            wave_sync();
+            int carry = 0;
+#pragma unroll
+            for (int j = 0; j < (kWvCap + 63) / 64; ++j)
+                if (j * 64 < Nc) {
+                    const int i = lane + 64 * j;
+                    const int own = max(wave_scan_max(i < Nc ? W.marker[i] : 0), carry);
+                    carry = __builtin_amdgcn_readlane(own, 63);
+                    if (i < Nc) W.q[i] = ld_off<float4>(sq, (unsigned)(B0 + i + W.delta[own - 1]) * 16u);
+                }
+            wave_sync();
+            PHASE_MARK(5);                                               // [5] owners, copy
+            PHASE_COUNT(7, Nc);
+            PHASE_COUNT(15, 1);
+            // The lane's rows inside the chunk are one contiguous range [cs, ce) of staged queries.  The tests run on the
+            // matrix pipe: 16 tets at a time, four lanes per tet; v_mfma_f32_4x4x1 (16 blocks of 4x4 += 4x1 . 1x4) takes plane
+            // i's coefficient from lane (tet, i) and candidate j's coordinate from lane (tet, j), and leaves the four plane
+            // values of candidate j in lane (tet, j): 64 (tet, candidate) pairs per step for four matrix instructions (C, z, y, x:
+            // the fma chain of the vector form, bit for bit) and a handful of vector ones.
+            const int lo = max(rn, r0), hi = min(re, r1);
+            int cs = 0, ce = 0;
+            if (PIT_STOP != 4 && gid >= 0 && lo < hi) {
+                cs = W.rowBase[lo] - B0;
+                ce = W.rowBase[hi] - B0;
+                rn = hi;
+            }
+            PHASE_COUNT(13, ce - cs);
+#pragma unroll 1
+            for (int blk = 0; blk < 4; ++blk) {
+                const bool mineBlk = (lane >> 4) == blk;
+                if (__builtin_amdgcn_ballot_w64(mineBlk && cs < ce) == 0ull) continue;     // no candidates for these 16 tets
+                if (mineBlk) {
+                    const int l16 = lane & 15;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) W.F[l16][i] = make_float4(F.N[i][0], F.N[i][1], F.N[i][2], 0.f);
+                    W.Cv[l16] = make_float4(F.C[0], F.C[1], F.C[2], F.C[3]);
+                    W.seg[l16] = make_int4(cs, ce, __float_as_int(F.twoEmax), 0);
+                }
+                wave_sync();
+                const int tl = lane >> 2, pj = lane & 3;                // tet of the block, plane (A operand) / candidate slot (B operand, result)
+                const float4 row = W.F[tl][pj];
+                const float4 cv = W.Cv[tl];
+                const f32x4 cacc = {cv.x, cv.y, cv.z, cv.w};
+                const int4 sg = W.seg[tl];
+                const float twoE = __int_as_float(sg.z);
+                const int tetLane = blk * 16 + tl, hitCol = (tid & ~63) + tetLane, ce4 = sg.y;
+                int c = sg.x + pj;
+                // accepted queries of this lane (a quarter of its tet's candidates) wait in two registers and are handed to
+                // the tet's slots with ONE returning LDS atomic at the end of the block (one per acceptance inside the loop
+                // made every step wait for an LDS round trip)
+                int a0 = -1, a1 = -1, na = 0;
+                lanemask_t m0 = mask_of(c < ce4);
+#pragma unroll 1
+                while (m0 != 0ull) {                                     // eight candidates per tet and step: two chains in flight
+                    const lanemask_t m1 = mask_of(c + 4 < ce4);
+                    const float4 q0 = W.q[c], q1 = W.q[c + 4];
+                    f32x4 d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(row.z, q0.z, cacc, 0, 0, 0);
+                    f32x4 d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(row.z, q1.z, cacc, 0, 0, 0);
+                    d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(row.y, q0.y, d0, 0, 0, 0);
+                    d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(row.y, q1.y, d1, 0, 0, 0);
+                    d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(row.x, q0.x, d0, 0, 0, 0);
+                    d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(row.x, q1.x, d1, 0, 0, 0);
+                    // dead slots (past the tet's range) neither accept nor hesitate
+                    const float av0 = sel(m0, min4_after_mfma(d0), -INFINITY), av1 = sel(m1, min4_after_mfma(d1), -INFINITY);
+                    const lanemask_t h0 = mask_of(av0 > twoE), h1 = mask_of(av1 > twoE);   // certain
+                    int nn = add_bit(add_bit(na, h0), h1);
+                    if (mask_of(nn > 2) != 0ull) {                       // rare: a third acceptance of one lane: empty the registers first
+                        if (na > 0) {
+                            const int slot = atomicAdd(&W.cnt[tetLane], na);
+                            if (slot < kWvSlots) s_hit[slot][hitCol] = a0;
+                            if (na > 1 && slot + 1 < kWvSlots) s_hit[slot + 1][hitCol] = a1;
+                        }
+                        nn -= na;
+                    }
+                    a1 = sel(h0, a0, a1); a0 = sel(h0, __float_as_int(q0.w), a0);
+                    a1 = sel(h1, a0, a1); a0 = sel(h1, __float_as_int(q1.w), a0);
+                    na = nn;
+                    if (mask_of(min_abs(av0, av1) <= twoE) != 0ull) {    // rare: undecided
+                        if (fabsf(av0) <= twoE) {
+                            const int k = atomicAdd(&W.pcnt[tetLane], 1);
+                            if (k < 2) W.ppend[k][tetLane] = __float_as_int(q0.w);
+                        }
+                        if (fabsf(av1) <= twoE) {
+                            const int k = atomicAdd(&W.pcnt[tetLane], 1);
+                            if (k < 2) W.ppend[k][tetLane] = __float_as_int(q1.w);
+                        }
+                    }
+                    c += 8;
+                    m0 = mask_of(c < ce4);
+                }
+                if (na > 0) {
+                    const int slot = atomicAdd(&W.cnt[tetLane], na);
+                    if (slot < kWvSlots) s_hit[slot][hitCol] = a0;
+                    if (na > 1 && slot + 1 < kWvSlots) s_hit[slot + 1][hitCol] = a1;
+                }
+                wave_sync();
+            }
+            wave_sync();
+            PHASE_MARK(6);                                               // [6] traversal of the chunk
+            r0 = r1;
+        }
+    }
+    PHASE_COUNT(14, __popcll(__builtin_amdgcn_ballot_w64(work && gid < 0)));
+    PHASE_MARK(1);                                                       // [1] staged traversal
+    // --- global walk for the lanes (slabs) no group covered: the slab cursor of k_tet_scan_slab ---------------------------
+    if (work && gid < 0) {
+        const int czn = cz0;
+        const int ny = cy1 - cy0 + 1;
+        const unsigned lineB = (unsigned)Gp * 4u;
+        const unsigned slabB = (unsigned)(Gx + 1) * lineB;
+        const unsigned dxB = (unsigned)(cx1 + 1 - cx0) * lineB;
+        unsigned offS = ((unsigned)czn * (unsigned)(Gx + 1) + (unsigned)cx0) * lineB + (unsigned)cy0 * 4u;
+        int cz = czn, yoff = 0;
+        int4u nS = ld_off_u4(tb, offS), nE = ld_off_u4(tb, offS + dxB);
+        bool haveNext = true;
+        int c = 0, P1 = 0, P2 = 0, P3 = 0, P4 = 0, o0 = 0, o1 = 0, o2 = 0, o3 = 0;
+        while (c < P4 || haveNext) {
+            if (c >= P4) {
+                const int rem = ny - yoff;
+                const int n0 = nE.x - nS.x;
+                const int n1 = rem > 1 ? nE.y - nS.y : 0;
+                const int n2 = rem > 2 ? nE.z - nS.z : 0;
+                const int n3 = rem > 3 ? nE.w - nS.w : 0;
+                P1 = n0; P2 = P1 + n1; P3 = P2 + n2; P4 = P3 + n3;
+                o0 = nS.x; o1 = nS.y - P1; o2 = nS.z - P2; o3 = nS.w - P3;
+                c = 0;
+                asm volatile("" : "+v"(P1), "+v"(P2), "+v"(P3), "+v"(P4), "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3));
+                const bool wrap = rem <= 4;
+                offS += wrap ? slabB - (unsigned)yoff * 4u : 16u;
+                yoff = wrap ? 0 : yoff + 4;
+                cz += wrap ? 1 : 0;
+                haveNext = cz <= cz1;
+                if (haveNext) {
+                    nS = ld_off_u4(tb, offS);
+                    nE = ld_off_u4(tb, offS + dxB);
+                }
+            }
+            if (c < P4) {
+                const int jq = c + (c < P1 ? o0 : c < P2 ? o1 : c < P3 ? o2 : o3);
+                test(ld_off<float4>(sq, (unsigned)jq * 16u));
+                ++c;
+            }
+        }
+    }
+    PHASE_MARK(2);                                                       // [2] global walk
+    {   // what the matrix-pipe blocks collected for this lane's tet (a lane is either staged or walks the global table)
+        const int np = W.pcnt[lane];
+        hcnt += W.cnt[lane];
+        if (np > 0) {
+            npend = np;
+            pend0 = W.ppend[0][lane];
+            pend1 = W.ppend[1][lane];
+        }
+    }
+    if (!valid) return;
+    if (!regular) {                                                      // (out-of-line call placed where almost nothing is live)
+        irregular_tet_slow(tet, t, b, T, Q, pts, counters, irregT, irregQ, result, hits);
+        return;
+    }
+    if (npend > 0) {                                                     // undecided candidates (rare)
+        const float *tv = tet + ((size_t)b * T + t) * 12;
+        atomicAdd(&counters[gridDim.y * 4 + b * 4 + 1], npend);         // statistics: candidates decided exactly
+        if (npend > 2) {
+            hcnt = exact_rescan_slots(tv, t, tb, sq, result + (size_t)b * Q, G, Gx, cx0, cx1, cy0, cy1, cz0, cz1, mrg, &s_hit[0][tid]);
+        } else {
+            for (int k = 0; k < npend; ++k) {
+                const int qi = k == 0 ? pend0 : pend1;
+                const float *pq = pts + ((size_t)b * Q + qi) * 3;
+                if (exact_accept(tv, pq[0], pq[1], pq[2]) > 0.f) {
+                    atomicMin(&result[(size_t)b * Q + qi], t);
+                    s_hit[min(hcnt, kWvSlots)][tid] = qi;
+                    ++hcnt;
+                }
+            }
+        }
+    }
+    if (hcnt > kWvSlots) {                                               // more acceptances than slots (dense queries): the out-of-line exact
+        const float *tv = tet + ((size_t)b * T + t) * 12;               // walk publishes every one of them
+        hcnt = exact_rescan_slots(tv, t, tb, sq, result + (size_t)b * Q, G, Gx, cx0, cx1, cy0, cy1, cz0, cz1, mrg, &s_hit[0][tid]);
+    }
+#pragma unroll 1
+    for (int i = 0; i < kWvSlots; ++i) {                                 // publish: one atomic instruction per slot level in use
+        if (__builtin_amdgcn_ballot_w64(hcnt > i) == 0ull) break;
+        if (hcnt > i) atomic_smin_off_nh(resb, (unsigned)s_hit[i][tid] * 4u, t);
+    }
+    if (hits) {
+        // <= 4 accepted: the record; 5..kWvSlots: the record (flagged) + the spill record; more: overflow marker (the hits are
+        // then carried by the uncovered list, see k_finalize)
+        int h[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) h[i] = -1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (i < hcnt) h[i] = s_hit[i][tid];
+        const bool spilled = hcnt > 4 && hcnt <= kWvSlots && spill != nullptr;
+        const bool over = hcnt > 4 && !spilled;
+        if (spilled) {
+#pragma unroll
+            for (int i = 4; i < kWvSlots; ++i)
+                if (i < hcnt) h[i] = s_hit[i][tid];
+            spill[(size_t)b * T + t] = make_int4(h[4], h[5], h[6], h[7]);
+            h[0] |= kHitSpilled;
+        }
+        if (over) note_overflow(counters, gridDim.y, b, t);
+        hits[(size_t)b * T + t] = over ? make_int4(-1, -1, -1, kHitOverflow) : make_int4(h[0], h[1], h[2], h[3]);
+    }
+    irregular_tail(tet, t, b, T, Q, pts, counters, irregQ, result);
+    PHASE_MARK(3);                                                       // [3] exact decisions, records
+}
+
 // barycentric weights, utils/tet_utils.py:25-45 (same association as the torch expression)
 __device__ __forceinline__ float triple(const float *a, const float *b, const float *c)
 {
@@ -1954,7 +2634,7 @@ static int pit_check(const float *tet, const float *pts, const float *cond, cons
     DEFTET_CHECK_ARG((pred == nullptr) == (occ == nullptr), "pred and occ must be given together");
     DEFTET_CHECK_ARG(!occ || T > 0, "paste_occ needs at least one tet");
     DEFTET_CHECK_ARG(B >= 0 && T >= 0 && Q >= 0, "negative size (B=%d T=%d Q=%d)", B, T, Q);
-    DEFTET_CHECK_ARG(algo == DEFTET_PIT_AUTO || algo == DEFTET_PIT_BRUTE || algo == DEFTET_PIT_EXACT, "unknown algo %d", algo);
+    DEFTET_CHECK_ARG(algo == DEFTET_PIT_AUTO || algo == DEFTET_PIT_BRUTE || algo == DEFTET_PIT_EXACT || algo == DEFTET_PIT_SLAB, "unknown algo %d", algo);
     if (T >= (1 << 24)) return set_error(DEFTET_ELIMIT, "n_tet=%d does not fit a float-encoded index (2^24)", T);
     DEFTET_CHECK_ARG(B <= 65535, "n_batch=%d exceeds the grid-y limit 65535", B);
     if (Q >= (1 << 27)) return set_error(DEFTET_ELIMIT, "n_query=%d: 16-byte query records are addressed with 32-bit byte offsets (limit 2^27)", Q);
@@ -1991,8 +2671,12 @@ static int pit_scan(const Layout &L, const float *tet, const float *pts, float *
         if (algo == DEFTET_PIT_EXACT) {
             DEFTET_LAUNCH(k_tet_scan, gt, blk, st, tet, T, Q, L.gparam, L.G, L.Gx, L.table, L.cellStride, L.sortedQ, L.result,
                           L.counters, L.irregT, (int4 *)hit_buf, pts, L.irregQ, ucount, hit_pad(B));
-        } else {
+        } else if (algo == DEFTET_PIT_SLAB) {
             DEFTET_LAUNCH(k_tet_scan_slab, gt, blk, st, tet, T, Q, L.gparam, L.G, L.Gx, L.table, L.cellStride, L.sortedQ, L.result,
+                          L.counters, L.irregT, (int4 *)hit_buf, pts, L.irregQ, ucount, hit_pad(B),
+                          hit_buf ? (int4 *)(hit_buf + hit_spill_off(B, T, Q)) : (int4 *)nullptr);
+        } else {
+            DEFTET_LAUNCH(k_tet_scan_wave, gt, blk, st, tet, T, Q, L.gparam, L.G, L.Gx, L.table, L.cellStride, L.sortedQ, L.result,
                           L.counters, L.irregT, (int4 *)hit_buf, pts, L.irregQ, ucount, hit_pad(B),
                           hit_buf ? (int4 *)(hit_buf + hit_spill_off(B, T, Q)) : (int4 *)nullptr);
         }
@@ -2038,7 +2722,7 @@ extern "C" int deftet_point_in_tet_prepare_f32(const float *pts, int B, int T, i
                                                size_t workspace_bytes, void *stream_)
 {
     DEFTET_CHECK_ARG(B >= 0 && T >= 0 && Q >= 0 && B <= 65535, "bad size (B=%d T=%d Q=%d)", B, T, Q);
-    DEFTET_CHECK_ARG(algo == DEFTET_PIT_AUTO || algo == DEFTET_PIT_EXACT, "prepare needs a binned algo (got %d)", algo);
+    DEFTET_CHECK_ARG(algo == DEFTET_PIT_AUTO || algo == DEFTET_PIT_EXACT || algo == DEFTET_PIT_SLAB, "prepare needs a binned algo (got %d)", algo);
     if (Q >= (1 << 27)) return set_error(DEFTET_ELIMIT, "n_query=%d exceeds 2^27", Q);
     if (B == 0 || Q == 0) return DEFTET_OK;
     DEFTET_CHECK_ARG(pts, "null pts pointer");

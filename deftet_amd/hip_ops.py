@@ -11,8 +11,8 @@ import torch
 
 from . import _lib
 
-PIT_AUTO, PIT_BRUTE, PIT_EXACT = 0, 1, 2        # include/deftet_hip.h DEFTET_PIT_*
-_PIT_KERNEL = {PIT_AUTO: "k_tet_scan_slab", PIT_EXACT: "k_tet_scan", PIT_BRUTE: "k_brute"}
+PIT_AUTO, PIT_BRUTE, PIT_EXACT, PIT_SLAB = 0, 1, 2, 3        # include/deftet_hip.h DEFTET_PIT_*
+_PIT_KERNEL = {PIT_AUTO: "k_tet_scan_wave", PIT_EXACT: "k_tet_scan", PIT_BRUTE: "k_brute", PIT_SLAB: "k_tet_scan_slab"}
 
 
 def pit_kernel_name(algo=PIT_AUTO):

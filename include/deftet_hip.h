@@ -34,9 +34,10 @@ extern "C" {
 #define DEFTET_ELIMIT (-4)   /* size exceeds what the float-encoded index outputs can represent (2^24) */
 
 /* point-in-tet algorithm selector */
-#define DEFTET_PIT_AUTO 0    /* uniform-grid binned, tet-centric, slab traversal with the certified fused plane filter (k_tet_scan_slab) */
+#define DEFTET_PIT_AUTO 0    /* uniform-grid binned, tet-centric; a wave stages its candidates in LDS, certified fused plane filter (k_tet_scan_wave) */
 #define DEFTET_PIT_BRUTE 1   /* scalar-tiled brute force: the algorithmic equivalent of the reference kernel */
 #define DEFTET_PIT_EXACT 2   /* binned, box test + exact predicate on every candidate (no filter; independent cross-check) */
+#define DEFTET_PIT_SLAB 3    /* the round-3 traversal (per-lane walk of the global cell table, k_tet_scan_slab): A/B and cross-check */
 
 int deftet_version(void);
 const char *deftet_last_error(void);

@@ -16,7 +16,9 @@ passes=(
  "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum"
  "FETCH_SIZE"
  "WRITE_SIZE"
+ "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_FLAT SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC"
 )
+if [ -n "${PMC_PASSES:-}" ]; then sel=(); for i in $PMC_PASSES; do sel+=("${passes[$i]}"); done; passes=("${sel[@]}"); fi
 dirs=()
 i=0
 for p in "${passes[@]}"; do
@@ -28,6 +30,6 @@ for p in "${passes[@]}"; do
 done
 python $R/tools/pmc_summary.py "${dirs[@]}" --match "$match" > "$R/$out"
 # PMC_TRAFFIC_OUT=<file>: also the per-kernel HBM traffic table bench.py reads (FETCH_SIZE / WRITE_SIZE passes, all kernels)
-if [ -n "${PMC_TRAFFIC_OUT:-}" ]; then python $R/tools/pmc_traffic.py "${dirs[4]}" "${dirs[5]}" > "$R/$PMC_TRAFFIC_OUT"; fi
+if [ -n "${PMC_TRAFFIC_OUT:-}" ] && [ -z "${PMC_PASSES:-}" ]; then python $R/tools/pmc_traffic.py "${dirs[4]}" "${dirs[5]}" > "$R/$PMC_TRAFFIC_OUT"; fi
 for d in "${dirs[@]}"; do rm -rf "$d"; done      # the raw per-dispatch CSVs are large; the summary is what is kept
 echo "wrote $out"

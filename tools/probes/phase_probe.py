@@ -18,6 +18,7 @@ from deftet_amd import _lib, hip_ops  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--config", type=int, default=2)
+ap.add_argument("--algo", type=int, default=0)
 a = ap.parse_args()
 lib = _lib.load()
 raw = ctypes.CDLL(_lib.LIB_PATH)
@@ -25,15 +26,15 @@ raw.deftet_debug_phase_read.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctyp
 dev = torch.device("cuda:0")
 wl = bench.PitWorkload(dict(bench.CONFIGS[a.config], sets=1), 0, dev, 1, None, pipeline=False)
 d = wl.sets[0]
-names = ["load+setup", "loop", "publish"]
+names = ["load+setup", "loop", "publish"] if a.algo == 3 else ["setup+groups", "staged(rest)", "global walk", "exact+records", "bounds+scan", "owners+copy", "traverse", "sum_Nc", "s8", "s9", "s10", "s11", "s12", "lane0_cands", "fallback_lanes", "chunks"]
 for _ in range(2):
-    hip_ops.point_in_tet(d["tet"], d["pts"], want_bary=True, pred_bxt=d["pred"], want_hits=True)
+    hip_ops.point_in_tet(d["tet"], d["pts"], want_bary=True, pred_bxt=d["pred"], want_hits=True, algo=a.algo)
 torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * 16)()
 raw.deftet_debug_phase_read(buf, 1)
 reps = 4
 for _ in range(reps):
-    hip_ops.point_in_tet(d["tet"], d["pts"], want_bary=True, pred_bxt=d["pred"], want_hits=True)
+    hip_ops.point_in_tet(d["tet"], d["pts"], want_bary=True, pred_bxt=d["pred"], want_hits=True, algo=a.algo)
 torch.cuda.synchronize()
 raw.deftet_debug_phase_read(buf, 1)
 n_waves = wl.B * ((wl.T + 63) // 64) * reps
@@ -42,5 +43,5 @@ G = hip_ops.point_in_tet_grid(wl.T, wl.Q)[0]
 n_sort = wl.B * G * 4 * 4 * reps                                    # k_slab_sort: 4 waves per (slab quarter, shape) workgroup
 print(json.dumps({"kernel": "k_slab_sort", "waves_per_launch": n_sort // reps, "cycles_per_wave": {
     k: round(buf[8 + i] / n_sort) for i, k in enumerate(["loads+clear", "count", "scan", "placement", "table"])}}), flush=True)
-print(json.dumps({"kernel": hip_ops.pit_kernel_name(0), "waves_per_launch": n_waves // reps,
-                  "cycles_per_wave": {k: round(v) for k, v in zip(names, vals)}, "total": round(sum(vals))}), flush=True)
+print(json.dumps({"kernel": hip_ops.pit_kernel_name(a.algo), "waves_per_launch": n_waves // reps,
+                  "cycles_per_wave": {k: round(v, 2) for k, v in zip(names, vals)}, "total": round(sum(vals[:7]))}), flush=True)
