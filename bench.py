@@ -62,10 +62,10 @@ ALGO = int(os.environ.get("DEFTET_BENCH_ALGO", "0"))      # A/B switch for the t
 PIPELINE = os.environ.get("DEFTET_BENCH_PIPELINE", "0") not in ("", "0")   # cross-step overlap of the query sort: off since round 3 (measured: no gain)
 
 
-def dominant_kernel(algo):
+def dominant_kernel(algo, n_tet, n_query):
     from deftet_amd import hip_ops
     # (DEFTET_BENCH_KERNEL: name of the traversal kernel when DEFTET_HIP_LIB points at a probe build with other kernels)
-    return (os.environ.get("DEFTET_BENCH_KERNEL") or hip_ops.pit_kernel_name(algo)).encode()
+    return (os.environ.get("DEFTET_BENCH_KERNEL") or hip_ops.pit_kernel_name(algo, n_tet, n_query)).encode()
 
 
 class PitWorkload:
@@ -100,7 +100,7 @@ class PitWorkload:
         self.B, self.T, self.Q = B, self.sets[0]["tet"].shape[1], Q
         self.pairs_per_step = float(B) * self.T * Q
         self.unit = "M tet-point tests/s"
-        self.dominant = dominant_kernel(algo)
+        self.dominant = dominant_kernel(algo, self.T, Q)
         # SURVEY.md 8(d), A1 fwd: B*(48*T + 12*Q + 4*Q) algorithmic bytes per call — what the traversal kernel must
         # touch once (48-byte tet records, 16-byte sorted queries); its per-tet hit records and the result atomics are
         # overhead of THIS design and are not counted

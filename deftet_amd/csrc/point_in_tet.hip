@@ -1243,13 +1243,9 @@ constexpr float kTauSlim = kTau * (1.0f + 1.0f / 128.0f);
 template <typename T>
 __device__ __forceinline__ void keep_alive(T x) { asm volatile("" ::"v"(x)); }
 
-struct __attribute__((aligned(16))) WaveStage {        // 6.6 KB per wave: with the hit slots 32.6 KB per workgroup
-    float4 q[kWvCap + 8];                               // the chunk's queries, rows in (cz, cy) order (+ 8: the last step's dead slots)
-    float4 F[16][4];                                    // filter of the 16 tets of the current block: plane i = (Nx, Ny, Nz, -)
-    float4 Cv[16];                                      // ... and its four plane constants
-    int4 seg[16];                                       // their candidate ranges: (first, end, twoEmax bits, -)
+struct __attribute__((aligned(16))) WaveStage {        // 2.8 KB per wave: with the hit slots 19.4 KB per workgroup, eight workgroups per CU
+    float4 q[kWvCap];                                   // the chunk's queries, rows in (cz, cy) order
     int delta[kWvRows];                                 // position of the row's first query in sortedQ - rowBase
-    int cnt[64], pcnt[64], ppend[2][64];                // per tet lane: accepted / undecided candidates so far, the first two undecided
     unsigned short rowBase[kWvRows + 4];                // exclusive prefix of the row lengths; [R] = total (< 2^16, checked)
     unsigned char marker[kWvCap];                       // row id + 1 at the LDS position where a non-empty row starts
 };
@@ -1302,30 +1298,6 @@ __device__ __forceinline__ float sel(lanemask_t m, float if_set, float if_clear)
 {
     return __int_as_float(sel(m, __float_as_int(if_set), __float_as_int(if_clear)));
 }
-// x + (this lane's bit of m)
-__device__ __forceinline__ int add_bit(int x, lanemask_t m)
-{
-    int d;
-    asm("v_addc_co_u32 %0, vcc, 0, %1, %2" : "=v"(d) : "v"(x), "s"(m) : "vcc");
-    return d;
-}
-// min of the four plane values a matrix instruction left in this lane.  Raw instructions: fminf() on a matrix result makes
-// the compiler quiet each operand first (four extra v_max per candidate).  The leading s_nop covers the wait states a
-// vector instruction needs after the matrix instruction that wrote its operands (the compiler pads that hazard for its own
-// instructions, not across an asm boundary; 4x4x1 f32 takes two passes).
-__device__ __forceinline__ float min4_after_mfma(f32x4 d)
-{
-    float t, r;
-    asm volatile("s_nop 7\n\tv_min_f32 %0, %2, %3\n\tv_min3_f32 %1, %4, %5, %0" : "=&v"(t), "=v"(r) : "v"(d[2]), "v"(d[3]), "v"(d[0]), "v"(d[1]));
-    return r;
-}
-__device__ __forceinline__ float min_abs(float a, float b)
-{
-    float r;
-    asm("v_min_f32 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-
 __device__ __forceinline__ void cross_fma(float ax, float ay, float az, float bx, float by, float bz, float *n)
 {
     n[0] = fmaf(ay, bz, -(az * by));
@@ -1386,7 +1358,7 @@ __global__ __launch_bounds__(256, PIT_WAVES2) void k_tet_scan_wave(const float *
                                                   const int *__restrict__ irregQ, int *ucount, int hpad, int4 *spill)
 {
     __shared__ WaveStage s_w[4];
-    __shared__ int s_hit[kWvSlots + 1][256];                           // [slot][thread]; slot kWvSlots swallows the overflow
+    __shared__ int s_hit[kWvSlots + 2][256];                           // [slot][thread]; the last two rows swallow the overflow
     if (ucount && blockIdx.x == 0 && threadIdx.x == 0) {               // per-shape words of the hit buffer, see k_tet_scan_slab
         ucount[blockIdx.y] = 0;
         ucount[hpad + blockIdx.y] = 0;
@@ -1394,8 +1366,6 @@ __global__ __launch_bounds__(256, PIT_WAVES2) void k_tet_scan_wave(const float *
     }
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
     WaveStage &W = s_w[tid >> 6];
-    W.cnt[lane] = 0;
-    W.pcnt[lane] = 0;
     const int nblk = gridDim.x;
     const int per = (nblk + 7) >> 3;
     const int vb = (blockIdx.x & 7) * per + (blockIdx.x >> 3);        // XCD-aware mapping, see k_tet_scan
@@ -1543,9 +1513,11 @@ __global__ __launch_bounds__(256, PIT_WAVES2) void k_tet_scan_wave(const float *
     PHASE_MARK(0);                                                       // [0] load + setup + grouping
     int *resb = uniform_ptr(result + (size_t)b * Q);
     asm volatile("s_nop 4" ::: "memory");                               // VALU-written SGPR base -> vector memory: five wait states, paid once
-    int hcnt = 0;                                                       // accepted so far
+    // accepted queries go to the lane's LDS slots: `slotA` is the byte address of the next one, saturating two rows past the
+    // last real slot (so that "more than kWvSlots" stays visible); they are published after the loops
+    const unsigned slot0 = (unsigned)tid * 4u, slotEnd = slot0 + (unsigned)(kWvSlots + 1) * 1024u;   // byte offsets into s_hit
+    unsigned slotA = slot0;
     int pend0 = -1, pend1 = -1, npend = 0;                              // query ids of undecided candidates
-    const unsigned slotB = (unsigned)tid * 4u;
     auto test = [&](const float4 q) {
         const float A0 = fmaf(F.N[0][0], q.x, fmaf(F.N[0][1], q.y, fmaf(F.N[0][2], q.z, F.C[0])));
         const float A1 = fmaf(F.N[1][0], q.x, fmaf(F.N[1][1], q.y, fmaf(F.N[1][2], q.z, F.C[1])));
@@ -1556,11 +1528,12 @@ __global__ __launch_bounds__(256, PIT_WAVES2) void k_tet_scan_wave(const float *
         if (av > F.twoEmax) {                                           // certain (twoEmax >= 0): kept in the lane's LDS slots, published
             // after the loops (an atomic per acceptance here is a vector-memory instruction with one or two live lanes in
             // most wave-iterations: 28 of them per wave kept the address unit as busy as the round-3 gathers did)
-            *reinterpret_cast<int *>(reinterpret_cast<char *>(&s_hit[0][0]) + (unsigned)min(hcnt, kWvSlots) * 1024u + slotB) = qi;
-            hcnt += 1;
+            *reinterpret_cast<int *>(reinterpret_cast<char *>(&s_hit[0][0]) + slotA) = qi;
+            slotA = min(slotA + 1024u, slotEnd);
         }
         const bool band = fabsf(av) <= F.twoEmax;                       // rare: decided by the reference predicate after the loops
         if (__builtin_amdgcn_ballot_w64(band) != 0ull) {                // (wave-uniform branch: the selects stay out of the common path)
+            asm volatile("" ::: "memory");                              // (... and the compiler from turning the branch into selects)
             pend1 = band ? pend0 : pend1;
             pend0 = band ? qi : pend0;
             npend = band ? npend + 1 : npend;
@@ -1662,88 +1635,32 @@ __global__ __launch_bounds__(256, PIT_WAVES2) void k_tet_scan_wave(const float *
             PHASE_MARK(5);                                               // [5] owners, copy
             PHASE_COUNT(7, Nc);
             PHASE_COUNT(15, 1);
-            // The lane's rows inside the chunk are one contiguous range [cs, ce) of staged queries.  The tests run on the
-            // matrix pipe: 16 tets at a time, four lanes per tet; v_mfma_f32_4x4x1 (16 blocks of 4x4 += 4x1 . 1x4) takes plane
-            // i's coefficient from lane (tet, i) and candidate j's coordinate from lane (tet, j), and leaves the four plane
-            // values of candidate j in lane (tet, j): 64 (tet, candidate) pairs per step for four matrix instructions (C, z, y, x:
-            // the fma chain of the vector form, bit for bit) and a handful of vector ones.
+            // the lane's rows inside the chunk: one contiguous range of staged queries.  Two candidates per trip of the
+            // source loop, each in its own registers, so that the next one is on its way while this one is tested and nothing
+            // has to be moved.
+            // (A matrix-pipe version of this loop — 16 tets at a time, four lanes per tet, v_mfma_f32_4x4x1 giving the four plane
+            // values of a candidate to one lane — was measured: the vector instructions around the matrix ones (dead-slot masks,
+            // minima, acceptance bookkeeping, the transposition through LDS) are as many as the 14 it replaces: 94 vs 82 us.)
             const int lo = max(rn, r0), hi = min(re, r1);
-            int cs = 0, ce = 0;
             if (PIT_STOP != 4 && gid >= 0 && lo < hi) {
-                cs = W.rowBase[lo] - B0;
-                ce = W.rowBase[hi] - B0;
+                unsigned c = (unsigned)(W.rowBase[lo] - B0) * 16u;      // byte offsets into W.q
+                const unsigned e = (unsigned)(W.rowBase[hi] - B0) * 16u;
+                PHASE_COUNT(13, (e - c) >> 4);
                 rn = hi;
-            }
-            PHASE_COUNT(13, ce - cs);
-#pragma unroll 1
-            for (int blk = 0; blk < 4; ++blk) {
-                const bool mineBlk = (lane >> 4) == blk;
-                if (__builtin_amdgcn_ballot_w64(mineBlk && cs < ce) == 0ull) continue;     // no candidates for these 16 tets
-                if (mineBlk) {
-                    const int l16 = lane & 15;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) W.F[l16][i] = make_float4(F.N[i][0], F.N[i][1], F.N[i][2], 0.f);
-                    W.Cv[l16] = make_float4(F.C[0], F.C[1], F.C[2], F.C[3]);
-                    W.seg[l16] = make_int4(cs, ce, __float_as_int(F.twoEmax), 0);
-                }
-                wave_sync();
-                const int tl = lane >> 2, pj = lane & 3;                // tet of the block, plane (A operand) / candidate slot (B operand, result)
-                const float4 row = W.F[tl][pj];
-                const float4 cv = W.Cv[tl];
-                const f32x4 cacc = {cv.x, cv.y, cv.z, cv.w};
-                const int4 sg = W.seg[tl];
-                const float twoE = __int_as_float(sg.z);
-                const int tetLane = blk * 16 + tl, hitCol = (tid & ~63) + tetLane, ce4 = sg.y;
-                int c = sg.x + pj;
-                // accepted queries of this lane (a quarter of its tet's candidates) wait in two registers and are handed to
-                // the tet's slots with ONE returning LDS atomic at the end of the block (one per acceptance inside the loop
-                // made every step wait for an LDS round trip)
-                int a0 = -1, a1 = -1, na = 0;
-                lanemask_t m0 = mask_of(c < ce4);
-#pragma unroll 1
-                while (m0 != 0ull) {                                     // eight candidates per tet and step: two chains in flight
-                    const lanemask_t m1 = mask_of(c + 4 < ce4);
-                    const float4 q0 = W.q[c], q1 = W.q[c + 4];
-                    f32x4 d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(row.z, q0.z, cacc, 0, 0, 0);
-                    f32x4 d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(row.z, q1.z, cacc, 0, 0, 0);
-                    d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(row.y, q0.y, d0, 0, 0, 0);
-                    d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(row.y, q1.y, d1, 0, 0, 0);
-                    d0 = __builtin_amdgcn_mfma_f32_4x4x1f32(row.x, q0.x, d0, 0, 0, 0);
-                    d1 = __builtin_amdgcn_mfma_f32_4x4x1f32(row.x, q1.x, d1, 0, 0, 0);
-                    // dead slots (past the tet's range) neither accept nor hesitate
-                    const float av0 = sel(m0, min4_after_mfma(d0), -INFINITY), av1 = sel(m1, min4_after_mfma(d1), -INFINITY);
-                    const lanemask_t h0 = mask_of(av0 > twoE), h1 = mask_of(av1 > twoE);   // certain
-                    int nn = add_bit(add_bit(na, h0), h1);
-                    if (mask_of(nn > 2) != 0ull) {                       // rare: a third acceptance of one lane: empty the registers first
-                        if (na > 0) {
-                            const int slot = atomicAdd(&W.cnt[tetLane], na);
-                            if (slot < kWvSlots) s_hit[slot][hitCol] = a0;
-                            if (na > 1 && slot + 1 < kWvSlots) s_hit[slot + 1][hitCol] = a1;
-                        }
-                        nn -= na;
+                const char *qb0 = reinterpret_cast<const char *>(&W.q[0]);
+                if (c < e) {
+                    float4 qa = *reinterpret_cast<const float4 *>(qb0 + c);
+                    for (;;) {
+                        const float4 qb = *reinterpret_cast<const float4 *>(qb0 + c + 16);   // (one entry past the range: harmless)
+                        test(qa);
+                        c += 16;
+                        if (c >= e) break;
+                        qa = *reinterpret_cast<const float4 *>(qb0 + c + 16);
+                        test(qb);
+                        c += 16;
+                        if (c >= e) break;
                     }
-                    a1 = sel(h0, a0, a1); a0 = sel(h0, __float_as_int(q0.w), a0);
-                    a1 = sel(h1, a0, a1); a0 = sel(h1, __float_as_int(q1.w), a0);
-                    na = nn;
-                    if (mask_of(min_abs(av0, av1) <= twoE) != 0ull) {    // rare: undecided
-                        if (fabsf(av0) <= twoE) {
-                            const int k = atomicAdd(&W.pcnt[tetLane], 1);
-                            if (k < 2) W.ppend[k][tetLane] = __float_as_int(q0.w);
-                        }
-                        if (fabsf(av1) <= twoE) {
-                            const int k = atomicAdd(&W.pcnt[tetLane], 1);
-                            if (k < 2) W.ppend[k][tetLane] = __float_as_int(q1.w);
-                        }
-                    }
-                    c += 8;
-                    m0 = mask_of(c < ce4);
                 }
-                if (na > 0) {
-                    const int slot = atomicAdd(&W.cnt[tetLane], na);
-                    if (slot < kWvSlots) s_hit[slot][hitCol] = a0;
-                    if (na > 1 && slot + 1 < kWvSlots) s_hit[slot + 1][hitCol] = a1;
-                }
-                wave_sync();
             }
             wave_sync();
             PHASE_MARK(6);                                               // [6] traversal of the chunk
@@ -1793,15 +1710,7 @@ __global__ __launch_bounds__(256, PIT_WAVES2) void k_tet_scan_wave(const float *
         }
     }
     PHASE_MARK(2);                                                       // [2] global walk
-    {   // what the matrix-pipe blocks collected for this lane's tet (a lane is either staged or walks the global table)
-        const int np = W.pcnt[lane];
-        hcnt += W.cnt[lane];
-        if (np > 0) {
-            npend = np;
-            pend0 = W.ppend[0][lane];
-            pend1 = W.ppend[1][lane];
-        }
-    }
+    int hcnt = (int)((slotA - slot0) >> 10);                            // accepted (kWvSlots + 1 stands for "more than kWvSlots")
     if (!valid) return;
     if (!regular) {                                                      // (out-of-line call placed where almost nothing is live)
         irregular_tet_slow(tet, t, b, T, Q, pts, counters, irregT, irregQ, result, hits);
@@ -2546,6 +2455,16 @@ static const Tunables &tunables()
     return t;
 }
 
+// DEFTET_PIT_AUTO: the wave-staged traversal pays for its staging (union box, row bounds, copy) with a walk that costs a
+// third per candidate; with about one query per tet or more (BASELINE configs[1]) the candidates dominate either way and
+// the round-3 walk, which takes three of them per wave-iteration, is faster (measured: 35 vs 53 us at configs[1], 83 vs 80
+// at configs[2], 204 vs 185 at configs[3]).
+static int resolve_auto(int algo, int T, int Q)
+{
+    if (algo != DEFTET_PIT_AUTO) return algo;
+    return (double)Q <= 0.6 * (double)T ? DEFTET_PIT_WAVE : DEFTET_PIT_SLAB;
+}
+
 static void pick_grid(int T, int Q, int &G, int &Gx)
 {
     const Tunables &tn = tunables();
@@ -2620,6 +2539,8 @@ extern "C" size_t deftet_point_in_tet_hits_ints(int B, int T, int Q)
     return hit_spill_off(B, T, Q) + (size_t)B * T * 4;
 }
 
+extern "C" int deftet_point_in_tet_resolve_algo(int algo, int T, int Q) { return resolve_auto(algo, T, Q); }
+
 extern "C" int deftet_point_in_tet_grid_dims(int T, int Q, int *G_yz, int *G_x)
 {
     DEFTET_CHECK_ARG(T >= 0 && Q >= 0 && G_yz && G_x, "bad argument");
@@ -2634,7 +2555,7 @@ static int pit_check(const float *tet, const float *pts, const float *cond, cons
     DEFTET_CHECK_ARG((pred == nullptr) == (occ == nullptr), "pred and occ must be given together");
     DEFTET_CHECK_ARG(!occ || T > 0, "paste_occ needs at least one tet");
     DEFTET_CHECK_ARG(B >= 0 && T >= 0 && Q >= 0, "negative size (B=%d T=%d Q=%d)", B, T, Q);
-    DEFTET_CHECK_ARG(algo == DEFTET_PIT_AUTO || algo == DEFTET_PIT_BRUTE || algo == DEFTET_PIT_EXACT || algo == DEFTET_PIT_SLAB, "unknown algo %d", algo);
+    DEFTET_CHECK_ARG(algo == DEFTET_PIT_AUTO || algo == DEFTET_PIT_BRUTE || algo == DEFTET_PIT_EXACT || algo == DEFTET_PIT_SLAB || algo == DEFTET_PIT_WAVE, "unknown algo %d", algo);
     if (T >= (1 << 24)) return set_error(DEFTET_ELIMIT, "n_tet=%d does not fit a float-encoded index (2^24)", T);
     DEFTET_CHECK_ARG(B <= 65535, "n_batch=%d exceeds the grid-y limit 65535", B);
     if (Q >= (1 << 27)) return set_error(DEFTET_ELIMIT, "n_query=%d: 16-byte query records are addressed with 32-bit byte offsets (limit 2^27)", Q);
@@ -2671,7 +2592,7 @@ static int pit_scan(const Layout &L, const float *tet, const float *pts, float *
         if (algo == DEFTET_PIT_EXACT) {
             DEFTET_LAUNCH(k_tet_scan, gt, blk, st, tet, T, Q, L.gparam, L.G, L.Gx, L.table, L.cellStride, L.sortedQ, L.result,
                           L.counters, L.irregT, (int4 *)hit_buf, pts, L.irregQ, ucount, hit_pad(B));
-        } else if (algo == DEFTET_PIT_SLAB) {
+        } else if (resolve_auto(algo, T, Q) == DEFTET_PIT_SLAB) {
             DEFTET_LAUNCH(k_tet_scan_slab, gt, blk, st, tet, T, Q, L.gparam, L.G, L.Gx, L.table, L.cellStride, L.sortedQ, L.result,
                           L.counters, L.irregT, (int4 *)hit_buf, pts, L.irregQ, ucount, hit_pad(B),
                           hit_buf ? (int4 *)(hit_buf + hit_spill_off(B, T, Q)) : (int4 *)nullptr);
@@ -2722,7 +2643,7 @@ extern "C" int deftet_point_in_tet_prepare_f32(const float *pts, int B, int T, i
                                                size_t workspace_bytes, void *stream_)
 {
     DEFTET_CHECK_ARG(B >= 0 && T >= 0 && Q >= 0 && B <= 65535, "bad size (B=%d T=%d Q=%d)", B, T, Q);
-    DEFTET_CHECK_ARG(algo == DEFTET_PIT_AUTO || algo == DEFTET_PIT_EXACT || algo == DEFTET_PIT_SLAB, "prepare needs a binned algo (got %d)", algo);
+    DEFTET_CHECK_ARG(algo == DEFTET_PIT_AUTO || algo == DEFTET_PIT_EXACT || algo == DEFTET_PIT_SLAB || algo == DEFTET_PIT_WAVE, "prepare needs a binned algo (got %d)", algo);
     if (Q >= (1 << 27)) return set_error(DEFTET_ELIMIT, "n_query=%d exceeds 2^27", Q);
     if (B == 0 || Q == 0) return DEFTET_OK;
     DEFTET_CHECK_ARG(pts, "null pts pointer");

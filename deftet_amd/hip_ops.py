@@ -11,13 +11,14 @@ import torch
 
 from . import _lib
 
-PIT_AUTO, PIT_BRUTE, PIT_EXACT, PIT_SLAB = 0, 1, 2, 3        # include/deftet_hip.h DEFTET_PIT_*
-_PIT_KERNEL = {PIT_AUTO: "k_tet_scan_wave", PIT_EXACT: "k_tet_scan", PIT_BRUTE: "k_brute", PIT_SLAB: "k_tet_scan_slab"}
+PIT_AUTO, PIT_BRUTE, PIT_EXACT, PIT_SLAB, PIT_WAVE = 0, 1, 2, 3, 4        # include/deftet_hip.h DEFTET_PIT_*
+_PIT_KERNEL = {PIT_WAVE: "k_tet_scan_wave", PIT_EXACT: "k_tet_scan", PIT_BRUTE: "k_brute", PIT_SLAB: "k_tet_scan_slab"}
 
 
-def pit_kernel_name(algo=PIT_AUTO):
-    """Name of the traversal kernel an `algo` value launches (what deftet_profile_select / rocprofv3 show)."""
-    return _PIT_KERNEL[int(algo)]
+def pit_kernel_name(algo=PIT_AUTO, n_tet=257250, n_query=100000):
+    """Name of the traversal kernel an `algo` value launches (what deftet_profile_select / rocprofv3 show); PIT_AUTO
+    depends on the problem size (default: BASELINE configs[2])."""
+    return _PIT_KERNEL[int(_lib.load().deftet_point_in_tet_resolve_algo(int(algo), int(n_tet), int(n_query)))]
 
 
 def _f32c(t):

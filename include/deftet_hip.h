@@ -34,10 +34,12 @@ extern "C" {
 #define DEFTET_ELIMIT (-4)   /* size exceeds what the float-encoded index outputs can represent (2^24) */
 
 /* point-in-tet algorithm selector */
-#define DEFTET_PIT_AUTO 0    /* uniform-grid binned, tet-centric; a wave stages its candidates in LDS, certified fused plane filter (k_tet_scan_wave) */
+#define DEFTET_PIT_AUTO 0    /* uniform-grid binned, tet-centric, certified fused plane filter: DEFTET_PIT_WAVE for sparse query sets
+                              * (n_query <= 0.6 n_tet), DEFTET_PIT_SLAB otherwise (deftet_point_in_tet_resolve_algo) */
 #define DEFTET_PIT_BRUTE 1   /* scalar-tiled brute force: the algorithmic equivalent of the reference kernel */
 #define DEFTET_PIT_EXACT 2   /* binned, box test + exact predicate on every candidate (no filter; independent cross-check) */
-#define DEFTET_PIT_SLAB 3    /* the round-3 traversal (per-lane walk of the global cell table, k_tet_scan_slab): A/B and cross-check */
+#define DEFTET_PIT_SLAB 3    /* per-lane walk of the global cell table, three candidates per wave-iteration (k_tet_scan_slab) */
+#define DEFTET_PIT_WAVE 4    /* a wave stages the candidates of its 64 tets in LDS, filter-only per-tet setup (k_tet_scan_wave) */
 
 int deftet_version(void);
 const char *deftet_last_error(void);
@@ -103,6 +105,8 @@ int deftet_point_in_tet_scan_f32(const float *tet, const float *pts, float *cond
  * Copies to host memory and synchronises the stream.  deftet_point_in_tet_grid_dims reports the cell grid (y/z cells per
  * axis, x cells) the binned algos use for a problem size. */
 int deftet_point_in_tet_grid_dims(int n_tet, int n_query, int *cells_yz, int *cells_x);
+/* the algorithm `algo` runs for a problem size (resolves DEFTET_PIT_AUTO; any other id is returned unchanged) */
+int deftet_point_in_tet_resolve_algo(int algo, int n_tet, int n_query);
 int deftet_point_in_tet_read_stats(const void *workspace, size_t workspace_bytes, int n_batch, int n_tet, int n_query, int algo,
                                    int32_t *out_host_8xB, void *stream);
 

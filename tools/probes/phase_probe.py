@@ -43,5 +43,5 @@ G = hip_ops.point_in_tet_grid(wl.T, wl.Q)[0]
 n_sort = wl.B * G * 4 * 4 * reps                                    # k_slab_sort: 4 waves per (slab quarter, shape) workgroup
 print(json.dumps({"kernel": "k_slab_sort", "waves_per_launch": n_sort // reps, "cycles_per_wave": {
     k: round(buf[8 + i] / n_sort) for i, k in enumerate(["loads+clear", "count", "scan", "placement", "table"])}}), flush=True)
-print(json.dumps({"kernel": hip_ops.pit_kernel_name(a.algo), "waves_per_launch": n_waves // reps,
+print(json.dumps({"kernel": hip_ops.pit_kernel_name(a.algo, wl.T, wl.Q), "waves_per_launch": n_waves // reps,
                   "cycles_per_wave": {k: round(v, 2) for k, v in zip(names, vals)}, "total": round(sum(vals[:7]))}), flush=True)

@@ -94,7 +94,7 @@ def main():
     if a.order:
         cfg["order"] = a.order
     wl = bench.PitWorkload(cfg, 0, dev, 1, None, pipeline=False)
-    kernel = a.kernel or hip_ops.pit_kernel_name(a.algo)
+    kernel = a.kernel or hip_ops.pit_kernel_name(a.algo, wl.T, wl.Q)
     outs, g, k_us, fwd_us, bwd_us, stats = run(wl, lib, a.algo, a.reps, kernel)
     step_k_us, step_us = run_steplike(wl, lib, a.algo, a.reps, kernel)
     rec = {"config": a.config, "mesh": (a.mesh or "kuhn") + ("/" + a.order if a.order else ""), "n_tet": wl.T, "algo": a.algo, "kernel": kernel,
