@@ -66,7 +66,6 @@ SIGNATURES = {
     "deftet_tet_neighbours_i64": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "deftet_boundary_index_workspace_bytes": (_sz, [_i, _i]),
     "deftet_boundary_index_i64": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
-    "deftet_tet_energies_workspace_bytes": (_sz, [_i]),
     "deftet_tet_energies_workspace_bytes2": (_sz, [_i, _i]),
     "deftet_tet_energies_fwd_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _sz, _vp]),
     "deftet_tet_energies_bwd_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),

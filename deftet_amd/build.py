@@ -2,20 +2,23 @@
 
     python -m deftet_amd.build [--force] [--out PATH] [--swap point_in_tet.hip=OTHER.hip] [--only a.hip,b.cpp] [-DNAME[=V] ...]
 
-Every source is compiled to its own object (in parallel, cached under /tmp by source mtime and flags) and
+Every source is compiled to its own object (in parallel, cached in a private per-user directory by source mtime and flags) and
 the objects are linked into the shared library, so touching one kernel file rebuilds one object.
 """
 from __future__ import annotations
 
 import concurrent.futures
+import fcntl
 import hashlib
 import os
+import stat
 import subprocess
 import sys
+import tempfile
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OBJDIR = os.environ.get("DEFTET_BUILD_CACHE") or os.path.join("/tmp", "deftet_amd_build_%d" % os.getuid())   # object cache, outside the tree (the tree is what travels to the GPU box)
+_OBJDIR = None
 LIB = os.path.join(HERE, "libdeftet_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
@@ -43,9 +46,28 @@ def needs_build() -> bool:
     return any(os.path.getmtime(s) > t for s in sources() + _headers())
 
 
+def objdir():
+    """Object cache, outside the tree (the tree is what travels to the GPU box): DEFTET_BUILD_CACHE, else a per-user directory
+    under the temp dir.  The objects in it are linked into the library this process loads, so the directory must be ours and
+    closed to everybody else: created 0700; an existing one is only used if it belongs to this user, is a real directory
+    (not a link) and is not writable by group / others — otherwise a fresh private directory is made for this run."""
+    global _OBJDIR
+    if _OBJDIR:
+        return _OBJDIR
+    path = os.environ.get("DEFTET_BUILD_CACHE") or os.path.join(tempfile.gettempdir(), "deftet_amd_build_%d" % os.getuid())
+    try:
+        os.makedirs(path, mode=0o700, exist_ok=True)
+        st = os.lstat(path)
+        ok = stat.S_ISDIR(st.st_mode) and st.st_uid == os.getuid() and not (st.st_mode & (stat.S_IWGRP | stat.S_IWOTH))
+    except OSError:
+        ok = False
+    _OBJDIR = path if ok else tempfile.mkdtemp(prefix="deftet_amd_build_")
+    return _OBJDIR
+
+
 def _obj_for(src, flags):
     key = hashlib.sha1((src + "\0" + " ".join(flags)).encode()).hexdigest()[:12]
-    return os.path.join(OBJDIR, "%s.%s.o" % (os.path.basename(src), key))
+    return os.path.join(objdir(), "%s.%s.o" % (os.path.basename(src), key))
 
 
 def _compile(src, flags, force, verbose):
@@ -53,11 +75,12 @@ def _compile(src, flags, force, verbose):
     newest = max(os.path.getmtime(p) for p in [src] + _headers())
     if not force and os.path.exists(obj) and os.path.getmtime(obj) >= newest:
         return obj
-    cmd = [HIPCC] + flags + ["-I", CSRC, "-x", "hip", "-c", src, "-o", obj + ".tmp"]
+    tmp = "%s.%d.tmp" % (obj, os.getpid())                  # ranks that build at the same time never share a temporary
+    cmd = [HIPCC] + flags + ["-I", CSRC, "-x", "hip", "-c", src, "-o", tmp]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    os.replace(obj + ".tmp", obj)
+    os.replace(tmp, obj)
     return obj
 
 
@@ -67,17 +90,19 @@ def build(force: bool = False, verbose: bool = False, out: str = LIB, extra_flag
         return LIB
     if not os.path.exists(HIPCC):
         raise RuntimeError("hipcc not found at %s — cannot build libdeftet_hip.so" % HIPCC)
-    os.makedirs(OBJDIR, exist_ok=True)
     flags = FLAGS + list(extra_flags)
     srcs = [(swap or {}).get(os.path.basename(s), s) for s in sources() if only is None or os.path.basename(s) in only]
     with concurrent.futures.ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 1)) as ex:
         objs = list(ex.map(lambda s: _compile(s, flags, force, verbose), srcs))
     os.makedirs(os.path.dirname(os.path.abspath(out)), exist_ok=True)
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out + ".tmp"]
+    tmp = "%s.%d.tmp" % (out, os.getpid())
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", tmp]
     if verbose:
         print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
-    os.replace(out + ".tmp", out)
+    with open(os.path.join(objdir(), ".link.lock"), "w") as lock:   # one linker at a time per cache (several ranks, one tree)
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        subprocess.check_call(cmd)
+        os.replace(tmp, out)
     return out
 
 

@@ -67,6 +67,21 @@ void prof_end(hipStream_t st)
     g_prof.used += 2;
 }
 
+int ticket_slot_for_stream(hipStream_t st, int n_slots)
+{
+    struct Key { int dev; hipStream_t st; };
+    static std::mutex mu;
+    static std::vector<Key> keys;                             // index = slot
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    std::lock_guard<std::mutex> lk(mu);
+    for (size_t i = 0; i < keys.size(); ++i)
+        if (keys[i].dev == dev && keys[i].st == st) return (int)i;
+    if ((int)keys.size() >= n_slots) return -1;
+    keys.push_back(Key{dev, st});
+    return (int)keys.size() - 1;
+}
+
 }  // namespace deftet
 
 // select the kernel to time ("" or NULL switches timing off); resets the accumulated samples
@@ -98,7 +113,7 @@ extern "C" int deftet_profile_read(double *total_ms, long long *count)
     return DEFTET_OK;
 }
 
-extern "C" int deftet_version(void) { return 100; }
+extern "C" int deftet_version(void) { return 200; }
 
 extern "C" const char *deftet_last_error(void) { return deftet::err_buf(); }
 

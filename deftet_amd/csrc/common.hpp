@@ -79,4 +79,10 @@ struct Arena {
 
 constexpr int kWave = 64;  // CDNA4 wavefront
 
+// Ticket reductions (reduce.hip, tet_ops.hip) finish inside one launch by counting workgroups on device-global counters.
+// Two launches may only share a set of counters if they cannot run at the same time: launches on ONE stream are ordered, so
+// every (device, stream) pair gets its own slot of counters, at most `n_slots` of them per process; -1 when they are used up
+// (the caller then takes its multi-launch form, which needs no counters).
+int ticket_slot_for_stream(hipStream_t st, int n_slots);
+
 }  // namespace deftet

@@ -2,9 +2,9 @@
 // optionally plus a second term sum_c a2[r,c] * b2[r,c] with its own width (one launch pair for both).
 // Deterministic (fixed reduction tree): kParts workgroups per row produce partial sums.  Up to kTicketRows rows take ONE
 // launch: every workgroup hands its partial to the memory side (returning RMW atomics bypass the per-XCD L2s) and draws
-// a ticket; the one that draws the last ticket of its row adds the partials up in index order.  Larger row counts use
-// the two-launch form (partials into the caller's workspace, one wave per row adds them up).
-#include <atomic>
+// a ticket; the one that draws the last ticket of its row adds the partials up in index order.  Larger row counts (and
+// processes that use more than kTicketSlots streams) use the two-launch form (partials into the caller's workspace, one
+// wave per row adds them up).
 
 #include "common.hpp"
 
@@ -42,14 +42,15 @@ __device__ __forceinline__ float rowdot_slice(const float *__restrict__ a, const
     return acc;
 }
 
+template <bool SQRT>
 __global__ __launch_bounds__(256) void k_rowdot_partial(const float *__restrict__ a, const float *__restrict__ b,
                                                         float *part, long long n_cols, const float *__restrict__ a2,
-                                                        const float *__restrict__ b2, long long n_cols2)
+                                                        const float *__restrict__ b2, long long n_cols2, float eps)
 {
     __shared__ float wsum[4];
     const long long r = blockIdx.y;
-    float acc = rowdot_slice(a, b, r, n_cols);
-    if (a2) acc += rowdot_slice(a2, b2, r, n_cols2);
+    float acc = rowdot_slice<SQRT>(a, b, r, n_cols, eps);
+    if (!SQRT && a2) acc += rowdot_slice(a2, b2, r, n_cols2);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
@@ -58,7 +59,9 @@ __global__ __launch_bounds__(256) void k_rowdot_partial(const float *__restrict_
 }
 
 constexpr int kTicketRows = 1024, kTicketSlots = 32;
-__device__ int g_tickets[kTicketSlots][kTicketRows];               // zero at load; every launch leaves its slot zero again
+// zero at load; every launch leaves its slot zero again.  A slot belongs to one (device, stream) pair
+// (ticket_slot_for_stream): launches that share it are ordered by their stream.
+__device__ int g_tickets[kTicketSlots][kTicketRows];
 
 template <bool SQRT>
 __global__ __launch_bounds__(256) void k_rowdot_fused(const float *__restrict__ a, const float *__restrict__ b, float *part,
@@ -120,13 +123,6 @@ __global__ __launch_bounds__(256) void k_sqrt_rowsum_bwd(const float *__restrict
 }  // namespace red
 }  // namespace deftet
 
-// a slot of tickets per launch in flight (shared by every entry point of this file)
-static int next_ticket_slot()
-{
-    static std::atomic<unsigned> next{0};
-    return (int)(next.fetch_add(1) % deftet::red::kTicketSlots);
-}
-
 extern "C" size_t deftet_rowdot_workspace_bytes(int n_rows) { return (size_t)(n_rows > 0 ? n_rows : 0) * deftet::red::kParts * 4; }
 
 extern "C" int deftet_rowdot2_f32(const float *a, const float *b, long long n_cols, const float *a2, const float *b2,
@@ -139,13 +135,13 @@ extern "C" int deftet_rowdot2_f32(const float *a, const float *b, long long n_co
     DEFTET_CHECK_ARG(workspace && workspace_bytes >= deftet_rowdot_workspace_bytes(n_rows), "workspace null or too small");
     hipStream_t st = deftet::as_stream(stream_);
     float *part = static_cast<float *>(workspace);
-    if (n_rows <= deftet::red::kTicketRows) {
-        const int slot = next_ticket_slot();
+    const int slot = n_rows <= deftet::red::kTicketRows ? deftet::ticket_slot_for_stream(st, deftet::red::kTicketSlots) : -1;
+    if (slot >= 0) {
         DEFTET_LAUNCH(deftet::red::k_rowdot_fused<false>, dim3(deftet::red::kParts, n_rows), dim3(256), st, a, b, part, n_cols, a2, b2, n_cols2,
                       out, slot, 0.f);
         return DEFTET_OK;
     }
-    DEFTET_LAUNCH(deftet::red::k_rowdot_partial, dim3(deftet::red::kParts, n_rows), dim3(256), st, a, b, part, n_cols, a2, b2, n_cols2);
+    DEFTET_LAUNCH(deftet::red::k_rowdot_partial<false>, dim3(deftet::red::kParts, n_rows), dim3(256), st, a, b, part, n_cols, a2, b2, n_cols2, 0.f);
     DEFTET_LAUNCH(deftet::red::k_rowdot_final, dim3(n_rows), dim3(64), st, part, out);
     return DEFTET_OK;
 }
@@ -156,20 +152,27 @@ extern "C" int deftet_rowdot_f32(const float *a, const float *b, float *out, int
     return deftet_rowdot2_f32(a, b, n_cols, nullptr, nullptr, 0, out, n_rows, workspace, workspace_bytes, stream_);
 }
 
-// out[r] = sum_c sqrt(x[r,c] + eps) for up to 1,024 rows, one launch (the ticket form of the row sums above); its backward
+// out[r] = sum_c sqrt(x[r,c] + eps), one launch for up to 1,024 rows (the ticket form of the row sums above); its backward
 // gx[r,c] = g[r] / (2 sqrt(x[r,c] + eps)).  What the surface terms of utils/mesh_utils.py:14 ("sqrt(d^2 + 1e-10)", then
 // the mean over the points) reduce to per shape.
 extern "C" int deftet_sqrt_rowsum_f32(const float *x, float eps, float *out, int n_rows, long long n_cols, void *workspace,
                                       size_t workspace_bytes, void *stream_)
 {
-    DEFTET_CHECK_ARG(n_rows >= 0 && n_cols >= 0 && n_rows <= deftet::red::kTicketRows, "bad size (at most 1,024 rows)");
+    DEFTET_CHECK_ARG(n_rows >= 0 && n_cols >= 0 && n_rows <= 65535, "bad size");
     if (n_rows == 0) return DEFTET_OK;
     DEFTET_CHECK_ARG(x && out, "null pointer");
     DEFTET_CHECK_ARG(workspace && workspace_bytes >= deftet_rowdot_workspace_bytes(n_rows), "workspace null or too small");
-    const int slot = next_ticket_slot();
-    DEFTET_LAUNCH(deftet::red::k_rowdot_fused<true>, dim3(deftet::red::kParts, n_rows), dim3(256), deftet::as_stream(stream_), x,
-                  (const float *)nullptr, static_cast<float *>(workspace), n_cols, (const float *)nullptr, (const float *)nullptr, 0LL, out,
-                  slot, eps);
+    hipStream_t st = deftet::as_stream(stream_);
+    float *part = static_cast<float *>(workspace);
+    const int slot = n_rows <= deftet::red::kTicketRows ? deftet::ticket_slot_for_stream(st, deftet::red::kTicketSlots) : -1;
+    if (slot >= 0) {
+        DEFTET_LAUNCH(deftet::red::k_rowdot_fused<true>, dim3(deftet::red::kParts, n_rows), dim3(256), st, x, (const float *)nullptr, part, n_cols,
+                      (const float *)nullptr, (const float *)nullptr, 0LL, out, slot, eps);
+        return DEFTET_OK;
+    }
+    DEFTET_LAUNCH(deftet::red::k_rowdot_partial<true>, dim3(deftet::red::kParts, n_rows), dim3(256), st, x, (const float *)nullptr, part, n_cols,
+                  (const float *)nullptr, (const float *)nullptr, 0LL, eps);
+    DEFTET_LAUNCH(deftet::red::k_rowdot_final, dim3(n_rows), dim3(64), st, part, out);
     return DEFTET_OK;
 }
 

@@ -1044,7 +1044,7 @@ __global__ __launch_bounds__(kNCThreads) void k_normal_consistency_fwd(const flo
         for (int i = threadIdx.x; i < nPair; i += kNCThreads) {
             const int f = i / max_nei;
             const float a = ab[i];
-            const bool valid = a >= 0.f;
+            const bool valid = a >= 0.f && a < (float)F;            // (entries outside [0, F) — or NaN — count as "no neighbour")
             const int j = valid ? (int)a : f;
             const float d = s_n[f * 3] * s_n[j * 3] + s_n[f * 3 + 1] * s_n[j * 3 + 1] + s_n[f * 3 + 2] * s_n[j * 3 + 2];
             s += valid ? 1.0f - d : 0.f;
@@ -1055,7 +1055,7 @@ __global__ __launch_bounds__(kNCThreads) void k_normal_consistency_fwd(const flo
             const float n0 = nb[f * 3], n1 = nb[f * 3 + 1], n2 = nb[f * 3 + 2];
             for (int k = 0; k < max_nei; ++k) {
                 const float a = ab[(size_t)f * max_nei + k];
-                if (a < 0.f) continue;
+                if (!(a >= 0.f && a < (float)F)) continue;
                 const int j = (int)a;
                 s += 1.0f - (n0 * nb[j * 3] + n1 * nb[j * 3 + 1] + n2 * nb[j * 3 + 2]);
                 cnt += 1.0f;
@@ -1087,7 +1087,7 @@ __global__ __launch_bounds__(256) void k_normal_consistency_bwd_scatter(const fl
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
     for (int k = 0; k < max_nei; ++k) {
         const float a = ab[k];
-        if (a < 0.f) continue;
+        if (!(a >= 0.f && a < (float)F)) continue;                  // same validity rule as the forward
         const int j = (int)a;
         s0 += nb[j * 3]; s1 += nb[j * 3 + 1]; s2 += nb[j * 3 + 2];
         unsafeAtomicAdd(&accb[j * 3], -n0); unsafeAtomicAdd(&accb[j * 3 + 1], -n1); unsafeAtomicAdd(&accb[j * 3 + 2], -n2);

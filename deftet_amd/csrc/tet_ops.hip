@@ -179,7 +179,8 @@ __device__ __forceinline__ float tet_edges(const TetV &v, float scale, int pw, f
 // (256 draws per shape cost more than the 8 MB second pass itself; 64 do not show).
 constexpr int kEParts = 64, kEThreads = 1024, kEWaves = kEThreads / 64;
 constexpr int kETicketShapes = 1024, kETicketSlots = 32;
-__device__ int g_energy_tickets[kETicketSlots][2][kETicketShapes];      // zero at load; every launch leaves its slot zero again
+// zero at load; every launch leaves its slot zero again; one slot per (device, stream) pair (ticket_slot_for_stream)
+__device__ int g_energy_tickets[kETicketSlots][2][kETicketShapes];
 
 // exact 64-bit exchange at the memory side (device-scope RMW atomics bypass the per-XCD L2s): what the ticket reductions
 // below pass between workgroups that may sit on different XCDs
@@ -410,7 +411,7 @@ extern "C" size_t deftet_tet_energies_workspace_bytes2(int B, int T)
 {
     return align_up((size_t)(B > 0 ? B : 0) * kEParts * 5 * 8 + 256, 256) + align_up((size_t)(B > 0 ? B : 0) * (size_t)(T > 0 ? T : 0) * 4, 256);
 }
-extern "C" size_t deftet_tet_energies_workspace_bytes(int B) { return deftet_tet_energies_workspace_bytes2(B, 0); }
+static size_t energies_partials_bytes(int B) { return deftet_tet_energies_workspace_bytes2(B, 0); }
 
 // out f32 [B,3] = {volume_variance(pow_v), amips_energy (0 if inv_v == NULL), edge_length(pow_e)};
 // stats f64 [B,8] is kept by the caller for the backward.
@@ -424,12 +425,9 @@ extern "C" int deftet_tet_energies_fwd_f32(const float *tet, const float *inv_v,
                      "workspace null, misaligned or smaller than deftet_tet_energies_workspace_bytes2(B, T)");
     hipStream_t st = as_stream(stream_);
     double *part1 = static_cast<double *>(workspace), *part2 = part1 + (size_t)B * kEParts * 3;
-    float *vol = reinterpret_cast<float *>(static_cast<char *>(workspace) + deftet_tet_energies_workspace_bytes(B));
-    int slot = -1;                                                 // B <= kETicketShapes: two launches, each pass finishes its own reduction
-    if (B <= kETicketShapes) {
-        static std::atomic<unsigned> next{0};                      // a slot of tickets per forward in flight
-        slot = (int)(next.fetch_add(1, std::memory_order_relaxed) % kETicketSlots);
-    }
+    float *vol = reinterpret_cast<float *>(static_cast<char *>(workspace) + energies_partials_bytes(B));
+    // B <= kETicketShapes: two launches, each pass finishes its own reduction on the counters of this stream's slot
+    const int slot = B <= kETicketShapes ? ticket_slot_for_stream(st, kETicketSlots) : -1;
     const bool p4 = pow_v == 4 && pow_e == 4;
     if (p4) DEFTET_LAUNCH(k_energy_pass1<true>, dim3(kEParts, B), dim3(kEThreads), st, tet, inv_v, T, scale, pow_e, part1, vol, stats, slot);
     else DEFTET_LAUNCH(k_energy_pass1<false>, dim3(kEParts, B), dim3(kEThreads), st, tet, inv_v, T, scale, pow_e, part1, vol, stats, slot);

@@ -193,7 +193,9 @@ def radix_sort(keys, values=None, bits=None, n_valid=None):
     NON-NEGATIVE integers (sorted as unsigned on their low `bits` bits; default all bits); values: optional int32/int64/
     float32 tensor of the same length carried along.  n_valid: optional int32 device tensor with the number of elements
     that really exist.  Returns (sorted_keys, sorted_values or None)."""
-    _lib.require_gpu(keys, values)
+    _lib.require_gpu(keys, values, n_valid)
+    if n_valid is not None and (n_valid.dtype != torch.int32 or n_valid.device != keys.device or n_valid.numel() < 1):
+        raise RuntimeError("radix_sort: n_valid must be an int32 tensor on the keys' device")
     lib = _lib.load()
     k = keys.contiguous()
     if k.dtype not in (torch.int32, torch.int64):
@@ -488,9 +490,7 @@ class _ChamferToCloud(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, tri, gt, counts, per_face, generator):
-        _lib.require_gpu(tri, gt)
         lib = _lib.load()
-        tri, gt = _f32c(tri), _f32c(gt)
         B, F, M, K = tri.shape[0], tri.shape[1], gt.shape[1], int(per_face)
         dev = tri.device
         r = torch.rand(2, B, F, K, device=dev, generator=generator)
@@ -526,7 +526,13 @@ class _ChamferToCloud(torch.autograd.Function):
 def chamfer_to_cloud(tri_bxfx3x3, gt_bxmx3, counts, per_face=20, generator=None):
     """f32 [B]: SUM over shape b's first counts[b] * per_face samples (per_face random points on each of its first
     counts[b] faces) of their distance to the nearest ground-truth point — differentiable w.r.t. tri."""
-    return _ChamferToCloud.apply(tri_bxfx3x3, gt_bxmx3, counts, per_face, generator)
+    _lib.require_gpu(tri_bxfx3x3, gt_bxmx3)
+    if gt_bxmx3.shape[1] == 0:
+        raise RuntimeError("chamfer_to_cloud: the ground-truth cloud is empty (no nearest neighbour exists)")
+    if len(counts) != tri_bxfx3x3.shape[0] or any(int(c) < 0 or int(c) > tri_bxfx3x3.shape[1] for c in counts):
+        raise RuntimeError("chamfer_to_cloud: counts must hold one face count in [0, F] per shape")
+    # (cast outside the autograd.Function, so that a non-f32 `tri` gets its gradient in its own dtype through the cast)
+    return _ChamferToCloud.apply(_f32c(tri_bxfx3x3), _f32c(gt_bxmx3), counts, per_face, generator)
 
 
 class _NormalConsistency(torch.autograd.Function):

@@ -16,6 +16,8 @@
                                                              arguments, same tuple order as the reference
     laplacian_sparse                          (:340-343)  torch.sparse.mm (vendor SpMM)
 """
+import collections
+import threading
 import torch
 import torch.nn as nn
 
@@ -63,25 +65,39 @@ class TetTopology:
 # index tensor.  Fast path: the very same tensor object, unmodified (a reference is kept, so its storage cannot be
 # recycled for another tensor behind our back).  Otherwise the CONTENT is compared with the cached indices (one small
 # kernel + sync; the CSR rebuild it avoids is 40x that) — never address or shape alone.
-_TOPOLOGIES = {}
+# nn.DataParallel runs the replicas' forward in threads of one process: the cache is shared by them, so every access is
+# under a lock; least-recently-used entries go first (at most _TOPOLOGIES_MAX (device, shape, n_vertex) keys stay pinned in
+# GPU memory; clear_topology_cache() drops them all).
+_TOPOLOGIES = collections.OrderedDict()
 _TOPOLOGIES_MAX = 16
+_TOPOLOGIES_LOCK = threading.Lock()
+
+
+def clear_topology_cache():
+    with _TOPOLOGIES_LOCK:
+        _TOPOLOGIES.clear()
 
 
 def _topology_for(tetrahedron_bxfx4, n_vertex):
     key = (tetrahedron_bxfx4.device, tuple(tetrahedron_bxfx4.shape), int(n_vertex))
-    hit = _TOPOLOGIES.get(key)
+    with _TOPOLOGIES_LOCK:
+        hit = _TOPOLOGIES.get(key)
     if hit is not None:
         topo, src, version = hit
         same = src is tetrahedron_bxfx4 and version == tetrahedron_bxfx4._version
         if not same:
             same = bool((tetrahedron_bxfx4 == topo.tet_idx).all())     # (broadcasts over the batch when one shared copy is kept)
         if same:
-            _TOPOLOGIES[key] = (topo, tetrahedron_bxfx4, tetrahedron_bxfx4._version)
+            with _TOPOLOGIES_LOCK:
+                _TOPOLOGIES[key] = (topo, tetrahedron_bxfx4, tetrahedron_bxfx4._version)
+                _TOPOLOGIES.move_to_end(key)
             return topo
-    if len(_TOPOLOGIES) >= _TOPOLOGIES_MAX:
-        _TOPOLOGIES.pop(next(iter(_TOPOLOGIES)))
-    topo = TetTopology(tetrahedron_bxfx4, n_vertex)
-    _TOPOLOGIES[key] = (topo, tetrahedron_bxfx4, tetrahedron_bxfx4._version)
+    topo = TetTopology(tetrahedron_bxfx4, n_vertex)                   # (built outside the lock: a host sync and a few launches)
+    with _TOPOLOGIES_LOCK:
+        _TOPOLOGIES[key] = (topo, tetrahedron_bxfx4, tetrahedron_bxfx4._version)
+        _TOPOLOGIES.move_to_end(key)
+        while len(_TOPOLOGIES) > _TOPOLOGIES_MAX:
+            _TOPOLOGIES.popitem(last=False)
     return topo
 
 

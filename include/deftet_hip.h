@@ -41,6 +41,9 @@ extern "C" {
 #define DEFTET_PIT_SLAB 3    /* per-lane walk of the global cell table, three candidates per wave-iteration (k_tet_scan_slab) */
 #define DEFTET_PIT_WAVE 4    /* a wave stages the candidates of its 64 tets in LDS, filter-only per-tet setup (k_tet_scan_wave) */
 
+/* 200: round 4.  (deftet_tet_energies_workspace_bytes(B) is gone: the forward needs ..._bytes2(B, T).  Algorithm ids other
+ * than the DEFTET_PIT_* values above — the STAGED / ROWS / ... ids 2-11 of the round-2 library — are rejected with
+ * DEFTET_EINVAL, never silently mapped.) */
 int deftet_version(void);
 const char *deftet_last_error(void);
 /* number of HIP devices visible; negative code on failure */
@@ -299,7 +302,6 @@ int deftet_tet_gather_bwd_f32(const float *grad_tet, const int32_t *offsets, con
  * {volume_variance(pow_v), amips_energy(inv_v f32 [T,3,3]; 0 when NULL), edge_length(pow_e)};
  * stats f64 [B,8] is produced by the forward and consumed by the backward, which writes
  * grad_tet f32 [B,T,4,3] = sum_k grad_out[b,k] * d out[b,k] / d tet (fully overwritten). */
-size_t deftet_tet_energies_workspace_bytes(int n_batch);              /* partial sums only (kept for older callers) */
 size_t deftet_tet_energies_workspace_bytes2(int n_batch, int n_tet); /* what deftet_tet_energies_fwd_f32 needs: + one float per tet */
 int deftet_tet_energies_fwd_f32(const float *tet, const float *inv_v, float *out, double *stats, int n_batch, int n_tet,
                                 int pow_v, int pow_e, float scale, void *workspace, size_t workspace_bytes, void *stream);
