@@ -295,14 +295,19 @@ def timed(wl, lib, steps, warmup, world, barrier=True):
 
 
 def measure_bandwidth(device):
-    """What this box's HBM actually delivers: device-to-device copy (read + write) and a read-only streaming sum
-    (the library's rowdot kernel) over 1 GiB, HIP-event timed.  Quoted beside the 8 TB/s spec figure."""
-    from deftet_amd import hip_ops
-    n = 1 << 28
-    src = torch.empty(n, device=device, dtype=torch.float32).uniform_()
+    """What this box's HBM delivers to a plain streaming kernel (deftet_bandwidth_probe: float4, nontemporal, 32 KB per
+    workgroup): a 1 GiB device-to-device copy (read + write bytes) and a read-only pass, HIP-event timed.  Quoted beside
+    the 8 TB/s datasheet figure; MI355X_MICROARCH.md measures 6.29 TB/s for a float4 copy on this part."""
+    from deftet_amd import _lib
+    lib = _lib.load()
+    n = 1 << 30
+    src = torch.empty(n // 4, device=device, dtype=torch.float32).uniform_()
     dst = torch.empty_like(src)
+    st = _lib.current_stream(device)
     out = {}
-    for name, fn, nbytes in (("copy", lambda: dst.copy_(src), 8.0 * n), ("read", lambda: hip_ops.rowdot(src.view(256, -1)), 4.0 * n)):
+    for name, mode, nbytes in (("copy", 0, 2.0 * n), ("read", 1, 1.0 * n)):
+        def fn():
+            _lib.check(lib.deftet_bandwidth_probe(_lib.ptr(src), _lib.ptr(dst), n, mode, None, st), "deftet_bandwidth_probe")
         for _ in range(3):
             fn()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -315,6 +320,27 @@ def measure_bandwidth(device):
         out[name] = nbytes * reps / (a.elapsed_time(b) * 1e-3) / 1e9
     del src, dst
     return out
+
+
+def brute_force_comparator(wl, step_ms):
+    """north_star's "10x the brute-force path": the library's own brute-force kernel (DEFTET_PIT_BRUTE: every query meets every
+    tet in index order, the algorithmic equivalent of check_condition_tet_for.cu:124-189 written for CDNA4) on input set 0 of
+    this workload — the whole batch, as the step has it — outside the timed region, HIP-event timed.  The ratio compares its
+    FORWARD ALONE with the whole binned forward + backward step, i.e. it is a lower bound of the speed-up."""
+    from deftet_amd import hip_ops
+    d = wl.sets[0]
+    hip_ops.point_in_tet(d["tet"][:1].contiguous(), d["pts"][:1].contiguous(), algo=hip_ops.PIT_BRUTE)      # (loads the kernel)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    ref = hip_ops.point_in_tet(d["tet"], d["pts"], algo=hip_ops.PIT_BRUTE)
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b)
+    same = bool(torch.equal(ref, hip_ops.point_in_tet(d["tet"], d["pts"], algo=wl.algo)))
+    return {"kernel": "k_brute", "ms_fwd_batch": round(ms, 2), "M_tests_per_s_fwd": round(wl.pairs_per_step / (ms * 1e-3) / 1e6, 1),
+            "speedup_of_binned_fwd_bwd_step_over_brute_fwd": round(ms / step_ms, 1), "same_result_as_binned": same,
+            "how": "DEFTET_PIT_BRUTE forward on input set 0 (all %d shapes) after the timed region, one launch sequence, HIP events; "
+                   "compared with the WHOLE binned fwd+bwd step" % wl.B}
 
 
 def graph_replay(wl, steps, warmup=3):
@@ -413,7 +439,7 @@ def summarize(wl, elapsed, per_step, kern_ms_tot, kern_cnt, steps, world, peak_m
             "whole_step": {"algorithmic_bytes": wl.step_bytes, "achieved": round(step_gbs, 1), "frac": round(step_gbs / HBM_PEAK_GBS, 4)}}
     if peak_measured:
         roof["peak_measured"] = {"copy_GBs": round(peak_measured["copy"], 1), "read_GBs": round(peak_measured["read"], 1),
-                                 "how": "1 GiB device-to-device copy (read+write bytes) and read-only streaming sum on this GPU, HIP events"}
+                                 "how": "1 GiB float4 streaming kernel of the library (copy: read+write bytes; read-only pass) on this GPU, HIP events"}
         roof["frac_of_measured_read"] = round(achieved / peak_measured["read"], 4)
     return {
         "value": round(world * wl.pairs_per_step * steps / elapsed / (1e6 if wl.unit.startswith("M ") else 1.0), 1), "unit": wl.unit,
@@ -449,6 +475,7 @@ def main():
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true")
+    ap.add_argument("--no-brute-force", action="store_true", help="skip the brute-force HIP comparator (one shape, ~50 ms at configs[2])")
     ap.add_argument("--no-unpipelined", action="store_true", help="skip the extra un-overlapped timing loop (profiling runs: every traversal launch in the kernel table is then a timed-region launch)")
     ap.add_argument("--no-bandwidth-probe", action="store_true", help="skip the 1 GiB copy/read probe (profiling runs: keeps its launches out of the kernel table)")
     args = ap.parse_args()
@@ -528,6 +555,8 @@ def main():
                 line["ms_per_step_hipgraph"] = gms
                 if why:
                     line["hipgraph_note"] = why
+            if isinstance(wl, PitWorkload) and not args.no_brute_force:
+                line["brute_force_hip"] = brute_force_comparator(wl, main_line["ms_per_step"])
             if not args.no_cpu_baseline and isinstance(wl, PitWorkload):
                 line["cpu_baseline"] = cpu_baseline(wl)
             if not args.no_other_configs:
@@ -538,12 +567,13 @@ def main():
                     if cid == args.config:
                         continue
                     w2 = make_workload(cid, 0, device, 1, None)
-                    e, ps, km, kc = timed(w2, lib, max(5, args.steps // 2), 2, 1, barrier=False)
-                    rec = summarize(w2, e, ps, km, kc, max(5, args.steps // 2), 1, peak)
-                    entry = {"config_id": cid, "config": w2.describe()["workload"], "value": rec["value"], "unit": rec["unit"],
+                    k2 = max(20, args.steps)                      # (ten steps let the first, idle-GPU step weigh 17 % of the mean)
+                    e, ps, km, kc = timed(w2, lib, k2, 3, 1, barrier=False)
+                    rec = summarize(w2, e, ps, km, kc, k2, 1, peak)
+                    entry = {"config_id": cid, "config": w2.describe()["workload"], "value": rec["value"], "unit": rec["unit"], "steps": k2,
                              "ms_per_step": rec["ms_per_step"], "ms_per_step_median": rec["ms_per_step_median"]}
                     if isinstance(w2, PitWorkload):
-                        entry["ms_per_step_hipgraph"] = graph_replay(w2, max(5, args.steps // 2))[0]
+                        entry["ms_per_step_hipgraph"] = graph_replay(w2, k2)[0]
                     if w2.dominant_bytes > 0:
                         entry["roofline"] = {k: rec["roofline"][k] for k in ("kernel", "achieved", "frac", "avg_launch_ms", "whole_step")}
                     else:

@@ -18,6 +18,7 @@ _vp, _i, _sz, _ll, _f = C.c_void_p, C.c_int, C.c_size_t, C.c_longlong, C.c_float
 # name -> (restype, argtypes); must list every symbol of include/deftet_hip.h
 SIGNATURES = {
     "deftet_version": (_i, []),
+    "deftet_bandwidth_probe": (_i, [_vp, _vp, _sz, _i, C.POINTER(_sz), _vp]),
     "deftet_last_error": (C.c_char_p, []),
     "deftet_device_count": (_i, []),
     "deftet_profile_select": (_i, [C.c_char_p]),

@@ -45,6 +45,9 @@ extern "C" {
  * than the DEFTET_PIT_* values above — the STAGED / ROWS / ... ids 2-11 of the round-2 library — are rejected with
  * DEFTET_EINVAL, never silently mapped.) */
 int deftet_version(void);
+/* Measurement aid (bench.py): streams n_bytes (rounded down to 32 KB) with a plain float4 kernel — mode 0 copies src to dst,
+ * mode 1 only reads src (dst then needs one float per 32 KB).  *done (optional) = bytes streamed per direction. */
+int deftet_bandwidth_probe(const void *src, void *dst, size_t n_bytes, int mode, size_t *done, void *stream);
 const char *deftet_last_error(void);
 /* number of HIP devices visible; negative code on failure */
 int deftet_device_count(void);

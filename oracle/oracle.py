@@ -13,6 +13,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libdeftet_oracle.so")
+LIB_FMA_PATH = os.path.join(HERE, "libdeftet_oracle_fma.so")    # same source, -mfma -ffp-contract=fast (flip counting only)
 REF_DIR = os.path.join(HERE, "_ref")
 
 _f32p = C.POINTER(C.c_float)
@@ -24,8 +25,8 @@ _f64p = C.POINTER(C.c_double)
 def build(force: bool = False) -> None:
     """Compile the restatement and (when /root/reference is present) oracle/_ref."""
     src = [os.path.join(HERE, f) for f in ("deftet_oracle.c", "deftet_oracle_surface.c", "deftet_oracle_render.c", "deftet_oracle_sign.c", "Makefile")]
-    stale = (not os.path.exists(LIB_PATH) or
-             any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in src))
+    stale = (not os.path.exists(LIB_PATH) or not os.path.exists(LIB_FMA_PATH) or
+             any(os.path.getmtime(s) > min(os.path.getmtime(LIB_PATH), os.path.getmtime(LIB_FMA_PATH)) for s in src))
     need_ref = os.path.isdir("/root/reference/utils/lib") and not all(
         os.path.exists(os.path.join(REF_DIR, n + "_run.so"))
         for n in ("tet_adj_share", "tet_face_adj", "tet_point_adj", "colaps_v"))
@@ -43,6 +44,18 @@ def lib():
         _lib = C.CDLL(LIB_PATH)
         _lib.oracle_point_in_tet_f32_omp.restype = C.c_int
     return _lib
+
+
+_lib_fma = None
+
+
+def lib_fma():
+    global _lib_fma
+    if _lib_fma is None:
+        build()
+        _lib_fma = C.CDLL(LIB_FMA_PATH)
+        _lib_fma.oracle_point_in_tet_f32_omp.restype = C.c_int
+    return _lib_fma
 
 
 def _p(a, t):
@@ -66,6 +79,16 @@ def point_in_tet(tet_bxtx4x3, pts_bxqx3, omp=False, return_executed=False):
     ex = C.c_longlong(0)
     lib().oracle_point_in_tet_f32(_p(tet, _f32p), _p(pts, _f32p), _p(out, _f32p), B, T, Q, C.byref(ex))
     return (out, ex.value) if return_executed else out
+
+
+def point_in_tet_contracted(tet_bxtx4x3, pts_bxqx3):
+    """The scan of point_in_tet(omp=True) from the build with fused multiply-adds (what nvcc's default contraction does to
+    check_condition_tet_for.cu:105-121).  For counting flipped decisions; NOT the parity oracle."""
+    tet = _c(tet_bxtx4x3, np.float32)
+    pts = _c(pts_bxqx3, np.float32)
+    out = np.empty((tet.shape[0], pts.shape[1], 1), np.float32)
+    lib_fma().oracle_point_in_tet_f32_omp(_p(tet, _f32p), _p(pts, _f32p), _p(out, _f32p), tet.shape[0], tet.shape[1], pts.shape[1])
+    return out
 
 
 def point_in_tet_margin(tet_tx4x3, pts_qx3):

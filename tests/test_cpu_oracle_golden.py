@@ -357,3 +357,21 @@ def test_render_mesh_color_prepares_the_rasterizer_inputs_like_the_reference_cal
             np.testing.assert_allclose(dp.numpy(), g["rmc_d_depth"], rtol=1e-6, atol=2e-6)
         else:
             assert dp is None
+
+
+def test_fma_contraction_flips_no_decision_on_a_configs2_sample(oracle):
+    """the reference's real CUDA build ran with nvcc's default contraction (a * b + c fused), the parity
+    oracle follows the source text without it.  The second oracle build (-mfma -ffp-contract=fast, same source) counts how
+    many decisions the contraction flips on BASELINE configs[2]'s own data: shape 0 of the res-70 jittered grid against a
+    bounded sample of its uniform queries.  (tools/fma_flip_count.py runs all 100,000 queries of several shapes on a box
+    with more cores; DESIGN.md section 2 quotes its count.)  A flip needs a query within a few ulps of a face plane: of the
+    order of 1e-5 of the queries, so the assertion is a generous bound, not the figure."""
+    from tests import cases
+    tet, pts = cases.jittered(70, 100_000, 1)
+    sample = np.ascontiguousarray(pts[:, :1500])
+    plain = oracle.point_in_tet(tet, sample, omp=True)
+    fused = oracle.point_in_tet_contracted(tet, sample)
+    flips = int((plain != fused).sum())
+    assert flips <= 3, flips
+    # where the two builds disagree the query sits on a face: the other build's answer is a face neighbour or a miss
+    assert ((plain >= 0) == (fused >= 0)).mean() > 0.998
