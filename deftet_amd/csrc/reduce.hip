@@ -6,6 +6,8 @@
 // processes that use more than kTicketSlots streams) use the two-launch form (partials into the caller's workspace, one
 // wave per row adds them up).
 
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace deftet {
@@ -22,10 +24,28 @@ __device__ __forceinline__ float rowdot_slice(const float *__restrict__ a, const
     const float *pb = b ? b + r * n_cols : nullptr;
     float acc = 0.f;
     const bool vec = (n_cols % 4 == 0) && (((uintptr_t)pa & 15) == 0) && (!pb || ((uintptr_t)pb & 15) == 0);
-    const long long tid = (long long)blockIdx.x * 256 + threadIdx.x, stride = (long long)kParts * 256;
+    const long long tid = (long long)blockIdx.x * 256 + threadIdx.x, stride = (long long)gridDim.x * 256;
     if (vec) {
         const long long n4 = n_cols / 4;
-        for (long long i = tid; i < n4; i += stride) {
+        // four strided items per trip, all loads issued before the first is used (one load per trip left the row's
+        // three trips as three memory latencies in a row); the items are added in index order, trip by trip
+        long long i = tid;
+        for (; i + 3 * stride < n4; i += 4 * stride) {
+            float4 x[4], y[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) x[k] = reinterpret_cast<const float4 *>(pa)[i + k * stride];
+            if (!SQRT && pb) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) y[k] = reinterpret_cast<const float4 *>(pb)[i + k * stride];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (SQRT) acc += (sqrtf(x[k].x + eps) + sqrtf(x[k].y + eps)) + (sqrtf(x[k].z + eps) + sqrtf(x[k].w + eps));
+                else if (pb) acc += (x[k].x * y[k].x + x[k].y * y[k].y) + (x[k].z * y[k].z + x[k].w * y[k].w);
+                else acc += (x[k].x + x[k].y) + (x[k].z + x[k].w);
+            }
+        }
+        for (; i < n4; i += stride) {
             const float4 x = reinterpret_cast<const float4 *>(pa)[i];
             if (SQRT) {
                 acc += (sqrtf(x.x + eps) + sqrtf(x.y + eps)) + (sqrtf(x.z + eps) + sqrtf(x.w + eps));
@@ -56,6 +76,7 @@ __global__ __launch_bounds__(256) void k_rowdot_partial(const float *__restrict_
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) part[r * kParts + blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+    if (blockIdx.x == 0 && threadIdx.x < kParts && threadIdx.x >= gridDim.x) part[r * kParts + threadIdx.x] = 0.f;   // k_rowdot_final adds all kParts
 }
 
 constexpr int kTicketRows = 1024, kTicketSlots = 32;
@@ -83,11 +104,12 @@ __global__ __launch_bounds__(256) void k_rowdot_fused(const float *__restrict__ 
         const int old = atomicExch(reinterpret_cast<int *>(part + r * kParts + blockIdx.x), __float_as_int(v));
         asm volatile("" ::"v"(old));                               // returning form: complete (at the memory side) once it has returned
         __builtin_amdgcn_s_waitcnt(0);
-        s_last = atomicAdd(&g_tickets[slot][r], 1) == kParts - 1;
+        s_last = atomicAdd(&g_tickets[slot][r], 1) == (int)gridDim.x - 1;
     }
     __syncthreads();
     if (!s_last) return;
-    if (threadIdx.x < kParts) vals[threadIdx.x] = __int_as_float(atomicOr(reinterpret_cast<int *>(part + r * kParts + threadIdx.x), 0));
+    if (threadIdx.x < kParts)                                      // (fewer workgroups than kParts: the missing partials are zeros)
+        vals[threadIdx.x] = threadIdx.x < gridDim.x ? __int_as_float(atomicOr(reinterpret_cast<int *>(part + r * kParts + threadIdx.x), 0)) : 0.f;
     __syncthreads();
     if (threadIdx.x < 64) {
         float v = vals[threadIdx.x] + vals[64 + threadIdx.x];      // same tree as k_rowdot_final
@@ -123,6 +145,15 @@ __global__ __launch_bounds__(256) void k_sqrt_rowsum_bwd(const float *__restrict
 }  // namespace red
 }  // namespace deftet
 
+// Workgroups per row: all kParts.  (Measured at 8 rows x 4 MB: 16 / 32 / 64 / 128 workgroups per row take 35 / 22 / 18 / 17 us —
+// the streams, not the 128 same-address ticket draws per row, are what the launch waits for.  DEFTET_ROWDOT_PARTS: experiments.)
+static int parts_for(long long n_cols, long long n_cols2)
+{
+    static const int forced = [] { const char *e = getenv("DEFTET_ROWDOT_PARTS"); return e ? atoi(e) : 0; }();
+    (void)n_cols; (void)n_cols2;
+    return forced >= 1 && forced <= deftet::red::kParts ? forced : deftet::red::kParts;
+}
+
 extern "C" size_t deftet_rowdot_workspace_bytes(int n_rows) { return (size_t)(n_rows > 0 ? n_rows : 0) * deftet::red::kParts * 4; }
 
 extern "C" int deftet_rowdot2_f32(const float *a, const float *b, long long n_cols, const float *a2, const float *b2,
@@ -137,11 +168,11 @@ extern "C" int deftet_rowdot2_f32(const float *a, const float *b, long long n_co
     float *part = static_cast<float *>(workspace);
     const int slot = n_rows <= deftet::red::kTicketRows ? deftet::ticket_slot_for_stream(st, deftet::red::kTicketSlots) : -1;
     if (slot >= 0) {
-        DEFTET_LAUNCH(deftet::red::k_rowdot_fused<false>, dim3(deftet::red::kParts, n_rows), dim3(256), st, a, b, part, n_cols, a2, b2, n_cols2,
+        DEFTET_LAUNCH(deftet::red::k_rowdot_fused<false>, dim3(parts_for(n_cols, n_cols2), n_rows), dim3(256), st, a, b, part, n_cols, a2, b2, n_cols2,
                       out, slot, 0.f);
         return DEFTET_OK;
     }
-    DEFTET_LAUNCH(deftet::red::k_rowdot_partial<false>, dim3(deftet::red::kParts, n_rows), dim3(256), st, a, b, part, n_cols, a2, b2, n_cols2, 0.f);
+    DEFTET_LAUNCH(deftet::red::k_rowdot_partial<false>, dim3(parts_for(n_cols, n_cols2), n_rows), dim3(256), st, a, b, part, n_cols, a2, b2, n_cols2, 0.f);
     DEFTET_LAUNCH(deftet::red::k_rowdot_final, dim3(n_rows), dim3(64), st, part, out);
     return DEFTET_OK;
 }
@@ -166,11 +197,11 @@ extern "C" int deftet_sqrt_rowsum_f32(const float *x, float eps, float *out, int
     float *part = static_cast<float *>(workspace);
     const int slot = n_rows <= deftet::red::kTicketRows ? deftet::ticket_slot_for_stream(st, deftet::red::kTicketSlots) : -1;
     if (slot >= 0) {
-        DEFTET_LAUNCH(deftet::red::k_rowdot_fused<true>, dim3(deftet::red::kParts, n_rows), dim3(256), st, x, (const float *)nullptr, part, n_cols,
+        DEFTET_LAUNCH(deftet::red::k_rowdot_fused<true>, dim3(parts_for(n_cols, 0), n_rows), dim3(256), st, x, (const float *)nullptr, part, n_cols,
                       (const float *)nullptr, (const float *)nullptr, 0LL, out, slot, eps);
         return DEFTET_OK;
     }
-    DEFTET_LAUNCH(deftet::red::k_rowdot_partial<true>, dim3(deftet::red::kParts, n_rows), dim3(256), st, x, (const float *)nullptr, part, n_cols,
+    DEFTET_LAUNCH(deftet::red::k_rowdot_partial<true>, dim3(parts_for(n_cols, 0), n_rows), dim3(256), st, x, (const float *)nullptr, part, n_cols,
                   (const float *)nullptr, (const float *)nullptr, 0LL, eps);
     DEFTET_LAUNCH(deftet::red::k_rowdot_final, dim3(n_rows), dim3(64), st, part, out);
     return DEFTET_OK;
