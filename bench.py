@@ -85,8 +85,29 @@ class PitWorkload:
             idx = np.arange(n * n * n * 6).reshape(n, n, n, 6)       # [ix, iy, iz, k] -> current position
             tets = tets[idx.transpose(2, 1, 0, 3).reshape(-1)]       # new position ((iz*n + iy)*n + ix)*6 + k
         self.sets, self.host = [], None
+        # N > 1: the sets are generated ON THE GPU (same distributions, torch generators seeded per rank and set): eight
+        # ranks x several sets of res-100 numpy jitter + gathers on one host are minutes of CPU before the first step.  N = 1
+        # keeps the numpy generators of deftet_amd.grids (bit-identical to the parity tests' inputs, and the CPU baseline needs
+        # a host copy).
+        on_gpu = world > 1 and cfg.get("generate", "auto") != "host"
+        verts_d = torch.from_numpy(verts).to(device) if on_gpu else None
+        tets_d = torch.from_numpy(tets.astype(np.int64)).to(device) if on_gpu else None
         for s in range(cfg["sets"]):
             base = rank * B + s * 100_000                 # distinct seeds per rank and per set
+            if on_gpu:
+                g = torch.Generator(device=device).manual_seed(1000 + base)
+                h = 2.0 / res
+                interior = ((verts_d > 0) & (verts_d < 1)).to(torch.float64)
+                d = (torch.rand((B,) + tuple(verts_d.shape), device=device, dtype=torch.float64, generator=g) * 0.2 - 0.1) * h
+                pos = (verts_d[None] - 0.5 + d * interior[None]).to(torch.float32)
+                T = tets_d.shape[0]
+                dset = dict(tet=pos[:, tets_d, :].contiguous(),
+                            pts=(1.05 * (torch.rand(B, Q, 3, device=device, dtype=torch.float64, generator=g) - 0.5)).to(torch.float32),
+                            gw=torch.randn(B, Q, 4, device=device, generator=g), pred=torch.rand(B, T, device=device, generator=g),
+                            gout=torch.randn(B, Q, device=device, generator=g))
+                del pos, d
+                self.sets.append(dset)
+                continue
             pos = grids.jittered_positions(verts, res, B, 0.1, seed0=1000 + base)
             tet = grids.gather_tets(pos, tets)
             pts = grids.random_queries(B, Q, seed0=2000 + base)
@@ -97,6 +118,7 @@ class PitWorkload:
             if s == 0:
                 self.host = dict(tet=tet[:1].copy(), pts=pts[:1].copy())
             self.sets.append({k: torch.from_numpy(v).to(device) for k, v in dict(tet=tet, pts=pts, gw=gw, pred=pred, gout=gout).items()})
+        self.generated_on = "gpu" if on_gpu else "host"
         self.B, self.T, self.Q = B, self.sets[0]["tet"].shape[1], Q
         self.pairs_per_step = float(B) * self.T * Q
         self.unit = "M tet-point tests/s"
@@ -160,6 +182,7 @@ class PitWorkload:
                             "fwd+bwd, grid build included, %d rotating input sets" % (self.cfg["name"], self.T, self.Q, self.B, len(self.sets)),
                 "res": self.cfg["res"], "n_tet": self.T, "n_query": self.Q, "batch_per_gpu": self.B, "input_sets": len(self.sets),
                 "sharding": "shapes sharded by rank; all-gather of %d loss scalars" % (self.world * self.B),
+                "inputs_generated_on": self.generated_on,
                 "pipelining": ("query sort of step i+1 enqueued on a second stream during step i" if self.pipeline else "none")}
 
 
@@ -449,6 +472,27 @@ def summarize(wl, elapsed, per_step, kern_ms_tot, kern_cnt, steps, world, peak_m
     }
 
 
+def pin_to_gpu_numa_node(dev_index):
+    """Best effort: restrict this rank's CPU threads to the cores of its GPU's NUMA node (eight ranks that all start on node 0
+    share its memory controllers while they build their inputs and launch).  Returns a short description for the line."""
+    try:
+        pr = torch.cuda.get_device_properties(dev_index)
+        bdf = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        node = int(open("/sys/bus/pci/devices/%s/numa_node" % bdf).read())
+        if node < 0:
+            return {"pci": bdf, "numa_node": None}
+        cpus = set()
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if cpus:
+            os.sched_setaffinity(0, cpus)
+        return {"pci": bdf, "numa_node": node, "cpus": len(cpus)}
+    except Exception as e:                                # no sysfs entry, no permission, an older torch: not fatal
+        return {"pci": None, "numa_node": None, "note": "%s: %s" % (type(e).__name__, str(e)[:80])}
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -498,15 +542,38 @@ def main():
         raise SystemExit("rank %d wants cuda:%d but only %d device(s) are visible" % (rank, dev_index, torch.cuda.device_count()))
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    backend = None
+    backend, placement, identities = None, None, None
     if world > 1:
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if shared:
-            torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-        backend = torch.distributed.get_backend()
+        placement = pin_to_gpu_numa_node(dev_index)
+        limit = datetime.timedelta(seconds=int(os.environ.get("DEFTET_BENCH_INIT_TIMEOUT", "180")))
+        try:
+            if shared:
+                torch.distributed.init_process_group("gloo", rank=rank, world_size=world, timeout=limit)
+            else:
+                torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=device, timeout=limit)
+            backend = torch.distributed.get_backend()
+            # first collective = the transport check: a failure (or a hang, cut by the timeout) surfaces HERE with a clear
+            # message, not as a stalled timed region
+            probe = torch.ones(1, device="cpu" if shared else device)
+            torch.distributed.all_reduce(probe)
+            if int(probe.item()) != world:
+                raise RuntimeError("all_reduce over %d ranks returned %s" % (world, probe.item()))
+            me = {"rank": rank, "host": socket.gethostname(), "device": dev_index, "pci": (placement or {}).get("pci"),
+                  "numa_node": (placement or {}).get("numa_node")}
+            identities = [None] * world
+            torch.distributed.all_gather_object(identities, me)
+        except Exception as e:
+            raise SystemExit("rank %d/%d: process group (%s over %s:%s) could not be set up within %s: %s: %s — check that every rank sees "
+                             "its GPU (HIP_VISIBLE_DEVICES), that HSA_ENABLE_IPC_MODE_LEGACY=0 is exported and that MASTER_ADDR resolves"
+                             % (rank, world, "gloo" if shared else "nccl(RCCL)", os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT"),
+                                limit, type(e).__name__, str(e)[:300]))
+        if not shared:
+            seen = {(i["host"], i["device"]) for i in identities}
+            if len(seen) != world:
+                raise SystemExit("the %d ranks do not sit on %d distinct GPUs: %s" % (world, world, identities))
 
     from deftet_amd import _lib, sharding
     lib = _lib.load()
@@ -539,7 +606,11 @@ def main():
         }
         if world > 1:
             line["rccl_ranks"] = torch.distributed.get_world_size()
+            if line["rccl_ranks"] != args.gpus:
+                raise SystemExit("process group has %d ranks, --gpus %d" % (line["rccl_ranks"], args.gpus))
             line["backend"] = backend
+            line["ranks"] = identities                    # rank -> (host, device, PCI address, NUMA node its threads were pinned to)
+            line["distinct_devices"] = len({(i["host"], i["device"]) for i in identities})
             line["ms_per_step_by_rank"] = {"min": min(rank_ms), "max": max(rank_ms), "all": rank_ms}
         if world == 1:
             if isinstance(wl, PitWorkload) and not args.no_unpipelined:

@@ -489,11 +489,12 @@ class _ChamferToCloud(torch.autograd.Function):
     random points per face.  Gradient to `tri` only (the cloud is data)."""
 
     @staticmethod
-    def forward(ctx, tri, gt, counts, per_face, generator):
+    def forward(ctx, tri, gt, counts, per_face, generator, uv=None):
         lib = _lib.load()
         B, F, M, K = tri.shape[0], tri.shape[1], gt.shape[1], int(per_face)
         dev = tri.device
-        r = torch.rand(2, B, F, K, device=dev, generator=generator)
+        # uv (optional, tests): the two uniform numbers per sample drawn by the caller instead of here
+        r = torch.rand(2, B, F, K, device=dev, generator=generator) if uv is None else _f32c(uv).reshape(2, B, F, K)
         samples = torch.empty(B, F * K, 3, device=dev, dtype=torch.float32)
         st = _lib.current_stream(dev)
         with torch.cuda.device(dev):
@@ -520,10 +521,10 @@ class _ChamferToCloud(torch.autograd.Function):
             _lib.check(lib.deftet_chamfer_bwd_f32(_lib.ptr(samples), _lib.ptr(gt), _lib.ptr(idx), _lib.ptr(nv), _lib.ptr(d), _lib.ptr(r),
                                                   _lib.ptr(g), _lib.ptr(grad_tri), B, F, K, M, _lib.current_stream(samples.device)),
                        "deftet_chamfer_bwd_f32")
-        return grad_tri, None, None, None, None
+        return grad_tri, None, None, None, None, None
 
 
-def chamfer_to_cloud(tri_bxfx3x3, gt_bxmx3, counts, per_face=20, generator=None):
+def chamfer_to_cloud(tri_bxfx3x3, gt_bxmx3, counts, per_face=20, generator=None, uv=None):
     """f32 [B]: SUM over shape b's first counts[b] * per_face samples (per_face random points on each of its first
     counts[b] faces) of their distance to the nearest ground-truth point — differentiable w.r.t. tri."""
     _lib.require_gpu(tri_bxfx3x3, gt_bxmx3)
@@ -532,7 +533,7 @@ def chamfer_to_cloud(tri_bxfx3x3, gt_bxmx3, counts, per_face=20, generator=None)
     if len(counts) != tri_bxfx3x3.shape[0] or any(int(c) < 0 or int(c) > tri_bxfx3x3.shape[1] for c in counts):
         raise RuntimeError("chamfer_to_cloud: counts must hold one face count in [0, F] per shape")
     # (cast outside the autograd.Function, so that a non-f32 `tri` gets its gradient in its own dtype through the cast)
-    return _ChamferToCloud.apply(_f32c(tri_bxfx3x3), _f32c(gt_bxmx3), counts, per_face, generator)
+    return _ChamferToCloud.apply(_f32c(tri_bxfx3x3), _f32c(gt_bxmx3), counts, per_face, generator, uv)
 
 
 class _NormalConsistency(torch.autograd.Function):

@@ -203,7 +203,8 @@ class DefTet(nn.Module):
         # The surface terms differ per shape (its own predicted boundary, a different face count).  The reference loops
         # over the shapes (deftet.py:89-103); here ONE ragged launch sequence covers the batch: the per-shape chains of
         # small launches would otherwise be bound by the host (8 shapes x ~150 framework + library calls ~ 25 ms).
-        terms = surface_losses.surface_terms_batched(vertice_pos, boundary, gt_surface_points, per_face=20, stacked=True)   # [3,B]
+        terms = surface_losses.surface_terms_batched(vertice_pos, boundary, gt_surface_points, per_face=20, stacked=True,
+                                                     uv=getattr(self, "sample_uv", None))             # [3,B] (sample_uv: tests only)
         sum_chamfer, sum_analytic, sum_normal = terms.mean(1, keepdim=True)                          # three [1] tensors (:104-110)
         center_occ = center_occ.squeeze(-1)
         if inference:

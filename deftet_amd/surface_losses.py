@@ -103,7 +103,7 @@ def surface_terms(vertices_bxnx3, boundary_bxfx3, gt_points_bxmx3, per_face=20, 
     return chamfer, analytic, normal
 
 
-def surface_terms_batched(vertices_bxnx3, boundary_list, gt_points_bxmx3, per_face=20, generator=None, stacked=False):
+def surface_terms_batched(vertices_bxnx3, boundary_list, gt_points_bxmx3, per_face=20, generator=None, stacked=False, uv=None):
     """(chamfer [B], analytic [B], normal [B]) for B predicted surfaces with DIFFERENT face counts in one launch
     sequence — what `DefTet.forward_surface_align` needs per step, where the reference calls `forward` shape by shape
     (layers/DefTet/deftet.py:89-103).  `boundary_list[b]` = int64 [F_b,3] vertex indices of shape b's surface.
@@ -111,7 +111,9 @@ def surface_terms_batched(vertices_bxnx3, boundary_list, gt_points_bxmx3, per_fa
     The faces are padded to F_max (padding = the degenerate triangle of vertex 0, masked out everywhere); the three
     operators get the per-shape counts: A8 `face_edge_adj_ragged`, A10 `nn_index_ragged` (F_b * per_face samples), A9
     through its `n_face_b` argument.  A shape with an empty surface yields (1, 1, 1) like `DefTet.forward` (:159-163).
-    stacked=True returns the three rows as one [3,B] tensor (the caller's means over the batch are then one launch)."""
+    stacked=True returns the three rows as one [3,B] tensor (the caller's means over the batch are then one launch).
+    uv (tests): f32 [2,B,F_max,per_face] uniform numbers for the surface samples instead of fresh ones — with the numbers
+    the reference drew (sqrt-warp on uv[0], mesh_utils.py:296-298) the sample points are the reference's."""
     B, dev = vertices_bxnx3.shape[0], vertices_bxnx3.device
     counts = [int(f.shape[0]) for f in boundary_list]
     one = torch.ones(B, device=dev)
@@ -130,7 +132,7 @@ def surface_terms_batched(vertices_bxnx3, boundary_list, gt_points_bxmx3, per_fa
     gt = gt_points_bxmx3.reshape(B, -1, 3)
     # (sample placement, distance to the nearest cloud point and the gradient back to the corners: three HIP launches
     # around the A10 search instead of ~45 elementwise ones)
-    chamfer = hip_ops.chamfer_to_cloud(tri, gt, counts, per_face, generator) / (n_face * per_face).clamp(min=1)
+    chamfer = hip_ops.chamfer_to_cloud(tri, gt, counts, per_face, generator, uv) / (n_face * per_face).clamp(min=1)
     # analytic: ground-truth cloud -> predicted surface (A9)
     d2, _ = tet_analytic_distance_f_batch(gt, tri, n_face.float())
     if min(counts) == 0:                                                                               # (host-side: no synchronisation)

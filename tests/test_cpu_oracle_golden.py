@@ -375,3 +375,26 @@ def test_fma_contraction_flips_no_decision_on_a_configs2_sample(oracle):
     assert flips <= 3, flips
     # where the two builds disagree the query sits on a face: the other build's answer is a face neighbour or a miss
     assert ((plain >= 0) == (fused >= 0)).mean() > 0.998
+
+
+def test_forward_composition_fixture_is_selfconsistent():
+    """tests/golden/forward_composition.npz (generated by running the reference's DefTet.forward_surface_align,
+    deftet.py:51-130, on the CPU with the L1 operators replaced by oracle calls): the batch terms are the per-shape terms of
+    DefTet.forward (:138-184) divided by the batch size and summed (:104-110), lap_v_loss is zero, both branches see the same
+    geometry terms, and the recorded random numbers have the shapes sample_surf_point_batch(., 20) draws."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "forward_composition.npz"))
+    ps = g["per_shape_terms"]                                            # [B, (chamfer, analytic, normal)]
+    B = ps.shape[0]
+    for col, name in enumerate(("sum_chamfer_distance", "sum_analytic_distance", "sum_normal_loss")):
+        want = np.float32(0)
+        for i in range(B):
+            want = np.float32(want + np.float32(ps[i, col]) / np.float32(B))
+        assert np.allclose(g["train_" + name], want, rtol=2e-6, atol=0), name
+    assert (g["train_lap_v_loss"] == 0).all() and g["train_sum_normal_loss"].shape == (1,)
+    for name in ("amips_energy", "edge", "volume_variance", "center_occ", "sum_analytic_distance", "sum_normal_loss"):
+        assert np.array_equal(g["train_" + name], g["infer_" + name]), name        # no randomness in these
+    for i in range(B):
+        F = g["train_boundary_%d" % i].shape[0]
+        assert g["rand_sqrt_u_%d" % i].shape == (1, F, 20, 1) and g["rand_v_%d" % i].shape == (1, F, 20, 1)
+        assert np.array_equal(g["train_boundary_%d" % i], g["infer_boundary_%d" % i])
+    assert g["infer_condition"].shape == (B, 200, 1) and g["train_center_occ"].shape == (B, g["tets"].shape[0])

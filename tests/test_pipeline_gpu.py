@@ -194,6 +194,10 @@ def test_bench_eight_ranks_config3_shared_gpu(cuda):
     assert rec["config"]["n_tet"] == 750000 and rec["config"]["batch_per_gpu"] == 8
     by = rec["ms_per_step_by_rank"]
     assert len(by["all"]) == 8 and by["min"] <= by["max"] and abs(by["max"] - rec["ms_per_step"]) < 1e-3
+    # what a first-time RCCL run relies on: inputs generated on the GPU, every rank identified in the line (a shared-GPU
+    # test run has ONE distinct device; a real run asserts eight), the transport probe passed before the timed region
+    assert rec["config"]["inputs_generated_on"] == "gpu"
+    assert [r["rank"] for r in rec["ranks"]] == list(range(8)) and rec["distinct_devices"] == 1 and rec["backend"] == "gloo"
 
 
 def test_forward_surface_align_save_writes_the_reference_obj_files(cuda, oracle, tmp_path):
@@ -249,3 +253,63 @@ def test_forward_surface_align_save_writes_the_reference_obj_files(cuda, oracle,
         (got * w).sum().backward()
         (want * w).sum().backward()
         assert torch.allclose(p1.grad, p2.grad, rtol=1e-5, atol=1e-6)
+
+
+def test_forward_surface_align_equals_the_reference_composition(cuda):
+    """The opt-in DefTet module against tests/golden/forward_composition.npz — the reference's own
+    DefTet.forward_surface_align (layers/DefTet/deftet.py:51-130) and per-shape DefTet.forward (:138-184) run on the CPU
+    with the L1 operators replaced by oracle calls: the order and weighting of the per-shape terms, the 20 samples per face
+    (replayed with the reference's own random numbers), the means and the return tuples of both branches."""
+    import os
+    from deftet_amd.layers.DefTet.deftet import DefTet
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "forward_composition.npz"))
+    B = g["pos"].shape[0]
+    t = lambda a, dt=None: torch.from_numpy(np.ascontiguousarray(a)).to(cuda) if dt is None else torch.from_numpy(np.ascontiguousarray(a)).to(cuda).to(dt)
+    pos = t(g["pos"])
+    tet_b = t(g["tets"], torch.int64)[None].expand(B, -1, -1).contiguous()
+    mesh_list = ([t(g["gt_verts_%d" % i])[None] for i in range(B)], [t(g["gt_faces_%d" % i], torch.int64)[None] for i in range(B)])
+    m = DefTet(device=cuda)
+    m.inverse_v = t(g["inverse_v"])
+    common = dict(tetrahedron_bxfx4=tet_b, mesh_list=mesh_list, gt_surface_points=t(g["gt_points"]),
+                  tet_face_bxfx3=t(g["face_fx3"], torch.int64)[None], tet_face_tet_bx4fx2=t(g["tetidx_fx2"], torch.int64)[None])
+
+    def uv_of(prefix):
+        fmax = max(g["train_boundary_%d" % i].shape[0] for i in range(B))
+        uv = torch.zeros(2, B, fmax, 20)
+        for i in range(B):
+            F = g["train_boundary_%d" % i].shape[0]
+            uv[0, i, :F] = torch.from_numpy(g[prefix % ("sqrt_u", i)][0, :, :, 0])
+            uv[1, i, :F] = torch.from_numpy(g[prefix % ("v", i)][0, :, :, 0])
+        return uv.to(cuda)
+
+    close = lambda got, want, tol=2e-5: np.allclose(got.detach().cpu().numpy().reshape(np.shape(want)), want, rtol=tol, atol=tol * np.abs(want).max())
+    # --- training branch: (amips, edge, volume variance, analytic, normal, center_occ, boundary, chamfer, lap_v_loss)
+    m.sample_uv = uv_of("rand_%s_%d")
+    out = m.forward_surface_align(pos, None, inference=False, **common)
+    assert len(out) == 9
+    for k, name in ((0, "amips_energy"), (1, "edge"), (2, "volume_variance"), (3, "sum_analytic_distance"), (4, "sum_normal_loss"),
+                    (7, "sum_chamfer_distance"), (8, "lap_v_loss")):
+        assert close(out[k], g["train_" + name]), (name, out[k], g["train_" + name])
+        assert tuple(out[k].shape) == g["train_" + name].shape, name
+    assert np.array_equal(out[5].cpu().numpy(), g["train_center_occ"])
+    for i in range(B):
+        assert np.array_equal(out[6][i].cpu().numpy(), g["train_boundary_%d" % i])
+    # the per-shape terms the batch terms are made of (DefTet.forward, one shape at a time; fresh samples: only the two
+    # sample-free terms are compared)
+    for i in range(B):
+        bnd = t(g["train_boundary_%d" % i], torch.int64)[None]
+        ch, an, no = m.forward(v_pos_bxnx3=pos[i:i + 1], tet_bxfx4=tet_b[i:i + 1], boundary_bxfx3=bnd, gt_surface_point=common["gt_surface_points"][i:i + 1],
+                               inverse_offset=m.inverse_v, calculate_amips_volume=False)
+        assert close(an, g["per_shape_terms"][i, 1]) and close(no, g["per_shape_terms"][i, 2], 5e-5), (i, an, no, g["per_shape_terms"][i])
+        assert abs(float(ch) - g["per_shape_terms"][i, 0]) < 0.25 * g["per_shape_terms"][i, 0]          # other samples, same surface
+    # --- inference branch: (..., center_occ, condition, boundary, pred_surface_face, chamfer)
+    m.sample_uv = uv_of("rand_%s_infer_%d")
+    out = m.forward_surface_align(pos, t(g["queries"]), inference=True, pred_occ=t(g["pred_occ"]), **common)
+    assert len(out) == 10
+    for k, name in ((0, "amips_energy"), (1, "edge"), (2, "volume_variance"), (3, "sum_analytic_distance"), (4, "sum_normal_loss"),
+                    (9, "sum_chamfer_distance")):
+        assert close(out[k], g["infer_" + name]), (name, out[k], g["infer_" + name])
+    assert np.array_equal(out[5].cpu().numpy(), g["infer_center_occ"]) and np.array_equal(out[6].cpu().numpy(), g["infer_condition"])
+    for i in range(B):
+        assert np.array_equal(out[7][i].cpu().numpy(), g["infer_boundary_%d" % i])
+        assert np.array_equal(out[8][i].cpu().numpy(), g["infer_pred_surface_%d" % i])
