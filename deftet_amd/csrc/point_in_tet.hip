@@ -1233,7 +1233,7 @@ constexpr int kWvMinGroup = 16;                         // lanes a footprint gro
 constexpr float kRelScale = 2.86102294921875e-06f;      // 48 u = 24 u * (the 2 of G_k = 2 w_l w_m)
 constexpr float kTauSlim = kTau * (1.0f + 1.0f / 128.0f);
 #ifndef PIT_WAVES2
-#define PIT_WAVES2 5
+#define PIT_WAVES2 6     // 80 registers: one 8-byte spill outside the loops; 78.5 vs 81 us at five waves (96 registers)
 #endif
 // Diagnostic builds (tools/probes/build_variant.sh ... -DPIT_STOP=n): the kernel ends after stage n with everything computed so
 // far kept alive, so that instruction counters can be read per stage (differences between the builds).
@@ -1315,17 +1315,39 @@ __device__ __noinline__ void irregular_tet_slow(const float *__restrict__ tet, i
     if (counters[b * 4 + 1] > 0) irregular_tail_slow(tet, t, b, T, Q, pts, counters, irregQ, result);
 }
 
-// exact re-scan of one tet (more than two undecided candidates: practically never): every accepted query is published
-// and the lane's LDS slots are refilled from scratch; returns the number of accepted queries
+// The cell box of a regular tet, from its vertices: the same operations, in the same order, as the setup of
+// k_tet_scan_wave (so the same cells).  The kernel does not keep its cells across the staged loop — the few lanes that need
+// them afterwards (global walk, exact re-scan) recompute them from the reloaded tet: six registers less in the loop.
+__device__ __forceinline__ void tet_cell_box(const float *__restrict__ tv, const Grid &g, int G, int Gx, CellBox &cb, float &mrg)
+{
+    float blo[3], bhi[3], wk[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        blo[k] = fminf(fminf(tv[k], tv[3 + k]), fminf(tv[6 + k], tv[9 + k]));
+        bhi[k] = fmaxf(fmaxf(tv[k], tv[3 + k]), fmaxf(tv[6 + k], tv[9 + k]));
+        wk[k] = bhi[k] - blo[k];
+    }
+    const float w = fmaxf(fmaxf(wk[0], wk[1]), wk[2]);
+    mrg = w * kMargin;
+    cb.cx0 = cell_of(blo[0] - mrg, g.o[0], g.inv[0], Gx); cb.cx1 = cell_of(bhi[0] + mrg, g.o[0], g.inv[0], Gx);
+    cb.cy0 = cell_of(blo[1] - mrg, g.o[1], g.inv[1], G); cb.cy1 = cell_of(bhi[1] + mrg, g.o[1], g.inv[1], G);
+    cb.cz0 = cell_of(blo[2] - mrg, g.o[2], g.inv[2], G); cb.cz1 = cell_of(bhi[2] + mrg, g.o[2], g.inv[2], G);
+}
+
+// exact re-scan of one tet (more than two undecided candidates, or more acceptances than slots: practically never): every
+// accepted query is published and the lane's LDS slots are refilled from scratch; returns the number of accepted queries
 __device__ __noinline__ int exact_rescan_slots(const float *__restrict__ tv, int t, const int *__restrict__ tb, const float4 *__restrict__ sq,
-                                               int *res, int G, int Gx, int cx0, int cx1, int cy0, int cy1, int cz0, int cz1, float m,
-                                               int *slotCol)
+                                               int *res, const float *__restrict__ gp, int G, int Gx, int *slotCol)
 {
     float vv[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) vv[k] = tv[k];
     Planes P;
     make_planes(vv, P);
+    const Grid g = load_grid(gp);
+    CellBox cb;
+    float m;
+    tet_cell_box(vv, g, G, Gx, cb, m);
     float elo[3], ehi[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -1334,9 +1356,9 @@ __device__ __noinline__ int exact_rescan_slots(const float *__restrict__ tv, int
     }
     const int Gp = table_pitch(G);
     int hcnt = 0;
-    for (int cz = cz0; cz <= cz1; ++cz)
-        for (int cy = cy0; cy <= cy1; ++cy) {
-            const int s = tb[table_off(cz, cx0, cy, Gx, Gp)], e = tb[table_off(cz, cx1 + 1, cy, Gx, Gp)];
+    for (int cz = cb.cz0; cz <= cb.cz1; ++cz)
+        for (int cy = cb.cy0; cy <= cb.cy1; ++cy) {
+            const int s = tb[table_off(cz, cb.cx0, cy, Gx, Gp)], e = tb[table_off(cz, cb.cx1 + 1, cy, Gx, Gp)];
             for (int j = s; j < e; ++j) {
                 const float4 q = sq[j];
                 if (q.x >= elo[0] && q.x <= ehi[0] && q.y >= elo[1] && q.y <= ehi[1] && q.z >= elo[2] && q.z <= ehi[2] &&
@@ -1456,11 +1478,12 @@ __global__ __launch_bounds__(256, PIT_WAVES2) void k_tet_scan_wave(const float *
     }
     // --- footprint groups (wave-uniform scalars) ------------------------------------------------------------------------
     // group g: cell box [gx0, gx1] x [gy0, gy0 + gny) x [gz0, gz0 + gnz).  Its rows are numbered (slab << gsh) + y with a
-    // power-of-two y pitch (ids with y >= gny are empty rows) and take whole blocks of 64 ids: group 0 the first gK0 blocks
+    // power-of-two y pitch <= 4 (ids with y >= gny are empty rows); group 1's follow group 0's.  One LANE per slab reads
+    // the slab's row bounds below (one 16-byte load per column), so the two groups have at most 64 slabs together.
     int gx0[2], gx1[2], gy0[2], gz0[2], gny[2], gnz[2], gsh[2];
     int gid = -1;                                                      // the lane's group
     int ncx = cx1 - cx0 + 1, ncy = cy1 - cy0 + 1;                      // cells of the lane's candidate source along x / y
-    int nBlk = 0, gK0 = 0;                                             // blocks of 64 row ids in use; of them group 0's
+    int rowsTot = 0, rowOff1 = 0, slabsTot = 0;                        // row ids in use; first id of group 1; slabs of both groups
     {
         lanemask_t rem = __builtin_amdgcn_ballot_w64(work);
 #pragma unroll
@@ -1483,12 +1506,11 @@ __global__ __launch_bounds__(256, PIT_WAVES2) void k_tet_scan_wave(const float *
             const int ux0 = (int)(0xFFFFu - (ax >> 16)), uy0 = (int)(0xFFFFu - (ay >> 16)), uz0 = (int)(0xFFFFu - (az >> 16));
             const int ny = (int)(ay & 0xFFFFu) - uy0 + 1, nz = (int)(az & 0xFFFFu) - uz0 + 1;
             const int sh = ny <= 1 ? 0 : 32 - __builtin_clz((unsigned)(ny - 1));              // pitch 2^sh >= ny
-            const int blocks = ((nz << sh) + 63) >> 6;
-            if (nBlk + blocks > kWvRows / 64) continue;                // too many rows: its lanes walk the global table
+            if (sh > 2 || slabsTot + nz > 64 || rowsTot + (nz << sh) > kWvRows) continue;   // too many rows: its lanes walk the global table
             gx0[p] = ux0; gx1[p] = (int)(ax & 0xFFFFu); gy0[p] = uy0; gz0[p] = uz0; gny[p] = ny; gnz[p] = nz; gsh[p] = sh;
-            if (p == 0) gK0 = blocks;
-            else if (nBlk == 0) gK0 = 0;                               // (group 0 was dropped: group 1 starts at row 0)
-            nBlk += blocks;
+            if (p == 1) rowOff1 = rowsTot;
+            rowsTot += nz << sh;
+            slabsTot += nz;
             if (in) { gid = p; ncx = gx1[p] - ux0 + 1; ncy = ny; }
         }
     }
@@ -1506,7 +1528,7 @@ __global__ __launch_bounds__(256, PIT_WAVES2) void k_tet_scan_wave(const float *
     if (PIT_STOP == 2) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) { keep_alive(F.N[i][0]); keep_alive(F.N[i][1]); keep_alive(F.N[i][2]); keep_alive(F.C[i]); }
-        keep_alive(F.twoEmax); keep_alive(gid); keep_alive(nBlk); keep_alive(gK0);
+        keep_alive(F.twoEmax); keep_alive(gid); keep_alive(rowsTot); keep_alive(rowOff1);
         keep_alive(cx0); keep_alive(cx1); keep_alive(cy0); keep_alive(cy1); keep_alive(cz0); keep_alive(cz1); keep_alive((int)work);
         return;
     }
@@ -1540,57 +1562,61 @@ __global__ __launch_bounds__(256, PIT_WAVES2) void k_tet_scan_wave(const float *
         }
     };
     // --- the groups' rows and queries are staged together, the lanes of both groups walk their ranges in one loop --------
-    if (nBlk > 0) {
-        int gS[3], len[3], base[3];
-        // row id r = 64 k + lane: (slab, y) of a footprint; bounds of its part over the group's x range.  A block of ids
-        // belongs to ONE group, so everything but the lane's (slab, y) is scalar
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            gS[k] = 0; len[k] = 0; base[k] = 0;
-            if (k < nBlk) {
-                const bool second = k >= gK0;                           // wave-uniform
-                const int sh = second ? gsh[1] : gsh[0], ny = second ? gny[1] : gny[0], nz = second ? gnz[1] : gnz[0];
-                const int zb = second ? gz0[1] : gz0[0], yb = second ? gy0[1] : gy0[0];
-                const unsigned xa = (unsigned)(second ? gx0[1] : gx0[0]) * (unsigned)Gp, xe = (unsigned)((second ? gx1[1] : gx1[0]) + 1) * (unsigned)Gp;
-                const int rl = lane + 64 * (second ? k - gK0 : k);
-                const int rz = rl >> sh, ry = rl & ((1 << sh) - 1);
-                const bool ok = rz < nz && ry < ny;
-                const unsigned line = ((unsigned)(zb + (ok ? rz : 0)) * (unsigned)(Gx + 1)) * (unsigned)Gp + (unsigned)(yb + (ok ? ry : 0));
-                const int a = ld_off<int>(tb, (line + xa) * 4u), e = ld_off<int>(tb, (line + xe) * 4u);
-                gS[k] = a;
-                len[k] = ok ? e - a : 0;
-            }
+    if (rowsTot > 0) {
+        // One lane per slab of a footprint: the bounds of the slab's (<= 8) y rows over the group's x range are two 16-byte
+        // loads of the transposed table per four rows (start column, end column) — 50 addresses per wave where one lane
+        // per ROW fetched 200 four-byte words, and that fetch, not arithmetic, was the longest stage of the kernel (stage
+        // timing, DESIGN.md section 3: 26 of 80 us).  Group 1's slabs follow group 0's (when group 0 was dropped: none of it).
+        const int nzA = gnz[0];
+        const bool second = lane >= nzA, slabLane = lane < slabsTot;
+        const lanemask_t m2 = mask_of(second);
+        const int zl = sel(m2, lane - nzA, lane), sh = sel(m2, gsh[1], gsh[0]), ny = sel(m2, gny[1], gny[0]);
+        const int rowId0 = sel(m2, rowOff1, 0) + (zl << sh);
+        int a[4], len[4];
+        {
+            const unsigned zrow = (unsigned)(sel(m2, gz0[1], gz0[0]) + (slabLane ? zl : 0)) * (unsigned)(Gx + 1);
+            const unsigned la = ((zrow + (unsigned)sel(m2, gx0[1], gx0[0])) * (unsigned)Gp + (unsigned)sel(m2, gy0[1], gy0[0])) * 4u;
+            const unsigned le = ((zrow + (unsigned)sel(m2, gx1[1], gx1[0]) + 1u) * (unsigned)Gp + (unsigned)sel(m2, gy0[1], gy0[0])) * 4u;
+            const int4u a0 = ld_off_u4(tb, la), e0 = ld_off_u4(tb, le);
+            a[0] = a0.x; a[1] = a0.y; a[2] = a0.z; a[3] = a0.w;
+            len[0] = e0.x - a0.x; len[1] = e0.y - a0.y; len[2] = e0.z - a0.z; len[3] = e0.w - a0.w;
         }
-        int N = 0;
+        int pre[5];                                                     // exclusive prefix of the slab's rows
+        pre[0] = 0;
+        int lmax = 0;
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
-            if (k < nBlk) {
-                const int incl = wave_scan_add(len[k]);
-                base[k] = N + incl - len[k];
-                N += __builtin_amdgcn_readlane(incl, 63);
-            }
-        const int Rtot = nBlk * 64;
+        for (int y = 0; y < 4; ++y) {
+            len[y] = sel(mask_of(slabLane && y < ny), len[y], 0);
+            pre[y + 1] = pre[y] + len[y];
+            lmax = max(lmax, len[y]);
+        }
+        const int incl = wave_scan_add(pre[4]);
+        const int lb = incl - pre[4];                                   // staged position of the slab's first query
+        const int N = __builtin_amdgcn_readlane(incl, 63);
+        const int Rtot = rowsTot;
         // a row that does not fit a chunk by itself (very dense queries): nothing is staged, everybody walks the global table
-        const bool fitsRows = __builtin_amdgcn_ballot_w64(max(max(len[0], len[1]), len[2]) > kWvCap) == 0ull && N < 65536;
+        const bool fitsRows = __builtin_amdgcn_ballot_w64(lmax > kWvCap) == 0ull && N < 65536;
+        if (slabLane) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
-            if (k < nBlk) {
-                W.rowBase[lane + 64 * k] = (unsigned short)base[k];
-                W.delta[lane + 64 * k] = gS[k] - base[k];
-            }
+            for (int y = 0; y < 4; ++y)
+                if (y < (1 << sh)) {                                    // (ids past the footprint's height: empty rows at the slab's end)
+                    W.rowBase[rowId0 + y] = (unsigned short)(lb + pre[y]);
+                    W.delta[rowId0 + y] = a[y] - (lb + pre[y]);
+                }
+        }
         if (lane == 0) W.rowBase[Rtot] = (unsigned short)N;
         wave_sync();
         if (PIT_STOP == 3) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) { keep_alive(F.N[i][0]); keep_alive(F.N[i][1]); keep_alive(F.N[i][2]); keep_alive(F.C[i]); }
-            keep_alive(F.twoEmax); keep_alive(gid); keep_alive(N); keep_alive(len[0] + len[1] + len[2]); keep_alive(base[0] + base[1] + base[2]);
+            keep_alive(F.twoEmax); keep_alive(gid); keep_alive(N); keep_alive(pre[4]); keep_alive(lb);
             keep_alive(cx0); keep_alive(cx1); keep_alive(cy0); keep_alive(cy1); keep_alive(cz0); keep_alive(cz1); keep_alive((int)work);
             return;
         }
         PHASE_MARK(4);                                                   // [4] row bounds, scan
         // the lane's rows: the slabs [cz0, cz1] of its group's footprint, all of the footprint's y rows
         const bool mine2 = gid == 1;
-        const int rowOff = mine2 ? gK0 * 64 : 0, gz = mine2 ? gz0[1] : gz0[0], gs = mine2 ? gsh[1] : gsh[0];
+        const int rowOff = mine2 ? rowOff1 : 0, gz = mine2 ? gz0[1] : gz0[0], gs = mine2 ? gsh[1] : gsh[0];
         int rn = rowOff + ((cz0 - gz) << gs);                          // next row to walk
         const int re = rowOff + ((cz1 + 1 - gz) << gs);
         if (!fitsRows) gid = -1;
@@ -1615,12 +1641,17 @@ __global__ __launch_bounds__(256, PIT_WAVES2) void k_tet_scan_wave(const float *
             // owner of every staged position: non-empty rows mark their first position, a max-scan spreads the marks
             for (int i = lane; i < Nc; i += 64) W.marker[i] = 0;
             wave_sync();
+            if (slabLane) {                                              // (row bounds re-read from LDS: 17 registers less across the loop)
+                int p0 = W.rowBase[rowId0];
 #pragma unroll
-            for (int k = 0; k < 3; ++k)
-                if (k < nBlk) {
-                    const int r = lane + 64 * k;
-                    if (len[k] > 0 && r >= r0 && r < r1) W.marker[base[k] - B0] = (unsigned char)(r + 1);
+                for (int y = 0; y < 4; ++y) {
+                    if (y < (1 << sh)) {
+                        const int r = rowId0 + y, p1 = W.rowBase[r + 1];
+                        if (p1 > p0 && r >= r0 && r < r1) W.marker[p0 - B0] = (unsigned char)(r + 1);
+                        p0 = p1;
+                    }
                 }
+            }
             wave_sync();
             int carry = 0;
 #pragma unroll
@@ -1671,7 +1702,15 @@ __global__ __launch_bounds__(256, PIT_WAVES2) void k_tet_scan_wave(const float *
     PHASE_MARK(1);                                                       // [1] staged traversal
     // --- global walk for the lanes (slabs) no group covered: the slab cursor of k_tet_scan_slab ---------------------------
     if (work && gid < 0) {
-        const int czn = cz0;
+        CellBox cb;
+        {
+            float tv[12], mrg2;
+            const float *src = tet + ((size_t)b * T + t) * 12;
+#pragma unroll
+            for (int k = 0; k < 12; ++k) tv[k] = src[k];
+            tet_cell_box(tv, g, G, Gx, cb, mrg2);
+        }
+        const int cx0 = cb.cx0, cx1 = cb.cx1, cy0 = cb.cy0, cy1 = cb.cy1, cz1 = cb.cz1, czn = cb.cz0;
         const int ny = cy1 - cy0 + 1;
         const unsigned lineB = (unsigned)Gp * 4u;
         const unsigned slabB = (unsigned)(Gx + 1) * lineB;
@@ -1712,21 +1751,25 @@ __global__ __launch_bounds__(256, PIT_WAVES2) void k_tet_scan_wave(const float *
     PHASE_MARK(2);                                                       // [2] global walk
     int hcnt = (int)((slotA - slot0) >> 10);                            // accepted (kWvSlots + 1 stands for "more than kWvSlots")
     if (!valid) return;
+    // (the addresses of this lane's tet, record, ... are formed from `te` HERE: hoisted to the top of the kernel they are
+    // six more live registers across the staged loop — the difference between five and six waves per SIMD)
+    int te = t;
+    asm volatile("" : "+v"(te));
     if (!regular) {                                                      // (out-of-line call placed where almost nothing is live)
-        irregular_tet_slow(tet, t, b, T, Q, pts, counters, irregT, irregQ, result, hits);
+        irregular_tet_slow(tet, te, b, T, Q, pts, counters, irregT, irregQ, result, hits);
         return;
     }
     if (npend > 0) {                                                     // undecided candidates (rare)
-        const float *tv = tet + ((size_t)b * T + t) * 12;
+        const float *tv = tet + ((size_t)b * T + te) * 12;
         atomicAdd(&counters[gridDim.y * 4 + b * 4 + 1], npend);         // statistics: candidates decided exactly
         if (npend > 2) {
-            hcnt = exact_rescan_slots(tv, t, tb, sq, result + (size_t)b * Q, G, Gx, cx0, cx1, cy0, cy1, cz0, cz1, mrg, &s_hit[0][tid]);
+            hcnt = exact_rescan_slots(tv, te, tb, sq, result + (size_t)b * Q, gparam + b * kGridWords, G, Gx, &s_hit[0][tid]);
         } else {
             for (int k = 0; k < npend; ++k) {
                 const int qi = k == 0 ? pend0 : pend1;
                 const float *pq = pts + ((size_t)b * Q + qi) * 3;
                 if (exact_accept(tv, pq[0], pq[1], pq[2]) > 0.f) {
-                    atomicMin(&result[(size_t)b * Q + qi], t);
+                    atomicMin(&result[(size_t)b * Q + qi], te);
                     s_hit[min(hcnt, kWvSlots)][tid] = qi;
                     ++hcnt;
                 }
@@ -1734,13 +1777,13 @@ __global__ __launch_bounds__(256, PIT_WAVES2) void k_tet_scan_wave(const float *
         }
     }
     if (hcnt > kWvSlots) {                                               // more acceptances than slots (dense queries): the out-of-line exact
-        const float *tv = tet + ((size_t)b * T + t) * 12;               // walk publishes every one of them
-        hcnt = exact_rescan_slots(tv, t, tb, sq, result + (size_t)b * Q, G, Gx, cx0, cx1, cy0, cy1, cz0, cz1, mrg, &s_hit[0][tid]);
+        const float *tv = tet + ((size_t)b * T + te) * 12;               // walk publishes every one of them
+        hcnt = exact_rescan_slots(tv, te, tb, sq, result + (size_t)b * Q, gparam + b * kGridWords, G, Gx, &s_hit[0][tid]);
     }
 #pragma unroll 1
     for (int i = 0; i < kWvSlots; ++i) {                                 // publish: one atomic instruction per slot level in use
         if (__builtin_amdgcn_ballot_w64(hcnt > i) == 0ull) break;
-        if (hcnt > i) atomic_smin_off_nh(resb, (unsigned)s_hit[i][tid] * 4u, t);
+        if (hcnt > i) atomic_smin_off_nh(resb, (unsigned)s_hit[i][tid] * 4u, te);
     }
     if (hits) {
         // <= 4 accepted: the record; 5..kWvSlots: the record (flagged) + the spill record; more: overflow marker (the hits are
@@ -1757,13 +1800,13 @@ __global__ __launch_bounds__(256, PIT_WAVES2) void k_tet_scan_wave(const float *
 #pragma unroll
             for (int i = 4; i < kWvSlots; ++i)
                 if (i < hcnt) h[i] = s_hit[i][tid];
-            spill[(size_t)b * T + t] = make_int4(h[4], h[5], h[6], h[7]);
+            spill[(size_t)b * T + te] = make_int4(h[4], h[5], h[6], h[7]);
             h[0] |= kHitSpilled;
         }
-        if (over) note_overflow(counters, gridDim.y, b, t);
-        hits[(size_t)b * T + t] = over ? make_int4(-1, -1, -1, kHitOverflow) : make_int4(h[0], h[1], h[2], h[3]);
+        if (over) note_overflow(counters, gridDim.y, b, te);
+        hits[(size_t)b * T + te] = over ? make_int4(-1, -1, -1, kHitOverflow) : make_int4(h[0], h[1], h[2], h[3]);
     }
-    irregular_tail(tet, t, b, T, Q, pts, counters, irregQ, result);
+    irregular_tail(tet, te, b, T, Q, pts, counters, irregQ, result);
     PHASE_MARK(3);                                                       // [3] exact decisions, records
 }
 

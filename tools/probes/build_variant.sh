@@ -2,15 +2,12 @@
 # Builds an alternative libdeftet_hip.so with extra -D flags for A/B runs (load it with DEFTET_HIP_LIB=<path>).
 #   tools/probes/build_variant.sh tools/probes/bin/libdeftet_w8.so -DPIT_WAVES=8
 #   tools/probes/build_variant.sh tools/probes/bin/libdeftet_x.so --pit-only -DPIT_BATCH=3    # 0.3 MB instead of 20 MB
-#   tools/probes/build_variant.sh tools/probes/bin/libdeftet_r02.so --legacy       # the round-2 point-in-tet file with its twelve
-#                                                                                  # traversal variants (tools/probes/legacy/)
 set -e
 out=$1; shift
 cd "$(dirname "$0")/../.."
 args=()
 for a in "$@"; do
-    if [ "$a" = "--legacy" ]; then args+=(--swap point_in_tet.hip=tools/probes/legacy/point_in_tet_r02.hip)
-    elif [ "$a" = "--pit-only" ]; then args+=(--only point_in_tet.hip,common.cpp,reduce.hip)    # small library: point-in-tet + row dots only
+    if [ "$a" = "--pit-only" ]; then args+=(--only point_in_tet.hip,common.cpp,reduce.hip,probe.hip)    # small library: point-in-tet + row dots only
     else args+=("$a"); fi
 done
 python -m deftet_amd.build --out "$out" "${args[@]}" | tail -1

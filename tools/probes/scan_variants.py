@@ -7,8 +7,8 @@ when --check is given.
     python tools/probes/scan_variants.py [--config 2] [--reps 10] [--algo 0] [--kernel NAME] [--check]
 
 Grid tunables are read ONCE per process (DEFTET_PIT_YZFINE / _XFINE / _GDIV / _QDIV), so a sweep is a shell loop over
-processes; DEFTET_HIP_LIB=<path> times another build of the library (tools/probes/build_variant.sh; `--legacy` builds
-the round-2 traversal kernels, whose default is --kernel 'k_tet_scan_fma<false>').
+processes; DEFTET_HIP_LIB=<path> times another build of the library (tools/probes/build_variant.sh); --algo 3 / 4 are the
+round-3 / round-4 traversal kernels of the product library (A/B inside one build).
 Prints one JSON line."""
 import argparse
 import ctypes
