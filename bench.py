@@ -431,7 +431,7 @@ def traffic_record(kernel):
     tools/pmc_traffic.py collected for the same command.  It is only quoted while the kernel source it was measured on
     (sha1 of deftet_amd/csrc/point_in_tet.hip, stored in the file) is still the one in the tree; otherwise null."""
     import hashlib
-    for rel in ("profiles/r03_pmc_traffic.json",):
+    for rel in ("profiles/r04_pmc_traffic.json", "profiles/r03_pmc_traffic.json"):
         path = os.path.join(ROOT, rel)
         if not os.path.exists(path):
             continue

@@ -665,10 +665,14 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan(const float *__rest
                                                   int *irregT, int4 *hits, const float *__restrict__ pts,
                                                   const int *__restrict__ irregQ, int *ucount, int hpad)
 {
-    if (ucount && blockIdx.x == 0 && threadIdx.x == 0) {               // per-shape words of the hit buffer: uncovered-hit counter
-        ucount[blockIdx.y] = 0;                                        // (k_finalize appends), backward ticket, irregular-query flag
-        ucount[hpad + blockIdx.y] = 0;                                 // (hpad is an argument: deriving it from gridDim.y here made the
-        ucount[2 * hpad + blockIdx.y] = 0;                             //  compiler fetch the dispatch packet with vector loads: +20 us)
+    // per-shape words of the hit buffer: uncovered-hit counter (k_finalize appends), backward ticket, irregular-query flag.
+    // (hpad is an argument: deriving it from gridDim.y here made the compiler fetch the dispatch packet with vector loads:
+    // +20 us.  The branch is WAVE-UNIFORM — all lanes of the first wave store the same zeros: behind a one-thread branch the
+    // compiler carried the shape index, and the pointers derived from it, in VGPRs through the whole kernel.)
+    if (ucount && blockIdx.x == 0 && __builtin_amdgcn_readfirstlane(threadIdx.x) == 0) {
+        ucount[blockIdx.y] = 0;
+        ucount[hpad + blockIdx.y] = 0;
+        ucount[2 * hpad + blockIdx.y] = 0;
     }
     const int b = blockIdx.y;
     // XCD-aware mapping (workgroup i is observed to run on XCD i % 8, each XCD has a private
@@ -956,10 +960,14 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan_slab(const float *_
                                                   int *irregT, int4 *hits, const float *__restrict__ pts,
                                                   const int *__restrict__ irregQ, int *ucount, int hpad, int4 *spill)
 {
-    if (ucount && blockIdx.x == 0 && threadIdx.x == 0) {               // per-shape words of the hit buffer: uncovered-hit counter
-        ucount[blockIdx.y] = 0;                                        // (k_finalize appends), backward ticket, irregular-query flag
-        ucount[hpad + blockIdx.y] = 0;                                 // (hpad is an argument: deriving it from gridDim.y here made the
-        ucount[2 * hpad + blockIdx.y] = 0;                             //  compiler fetch the dispatch packet with vector loads: +20 us)
+    // per-shape words of the hit buffer: uncovered-hit counter (k_finalize appends), backward ticket, irregular-query flag.
+    // (hpad is an argument: deriving it from gridDim.y here made the compiler fetch the dispatch packet with vector loads:
+    // +20 us.  The branch is WAVE-UNIFORM — all lanes of the first wave store the same zeros: behind a one-thread branch the
+    // compiler carried the shape index, and the pointers derived from it, in VGPRs through the whole kernel.)
+    if (ucount && blockIdx.x == 0 && __builtin_amdgcn_readfirstlane(threadIdx.x) == 0) {
+        ucount[blockIdx.y] = 0;
+        ucount[hpad + blockIdx.y] = 0;
+        ucount[2 * hpad + blockIdx.y] = 0;
     }
     const int b = blockIdx.y;
     const int nblk = gridDim.x;
@@ -1233,7 +1241,7 @@ constexpr int kWvMinGroup = 16;                         // lanes a footprint gro
 constexpr float kRelScale = 2.86102294921875e-06f;      // 48 u = 24 u * (the 2 of G_k = 2 w_l w_m)
 constexpr float kTauSlim = kTau * (1.0f + 1.0f / 128.0f);
 #ifndef PIT_WAVES2
-#define PIT_WAVES2 6     // 80 registers: one 8-byte spill outside the loops; 78.5 vs 81 us at five waves (96 registers)
+#define PIT_WAVES2 7     // 72 registers, scratch only on the rare exact-decision path; 69.0 us (six waves, 76 registers: 72.2; eight, 64: 70.5)
 #endif
 // Diagnostic builds (tools/probes/build_variant.sh ... -DPIT_STOP=n): the kernel ends after stage n with everything computed so
 // far kept alive, so that instruction counters can be read per stage (differences between the builds).
@@ -1381,10 +1389,10 @@ __global__ __launch_bounds__(256, PIT_WAVES2) void k_tet_scan_wave(const float *
 {
     __shared__ WaveStage s_w[4];
     __shared__ int s_hit[kWvSlots + 2][256];                           // [slot][thread]; the last two rows swallow the overflow
-    if (ucount && blockIdx.x == 0 && threadIdx.x == 0) {               // per-shape words of the hit buffer, see k_tet_scan_slab
-        ucount[blockIdx.y] = 0;
-        ucount[hpad + blockIdx.y] = 0;
-        ucount[2 * hpad + blockIdx.y] = 0;
+    if (ucount && blockIdx.x == 0 && __builtin_amdgcn_readfirstlane(threadIdx.x) == 0) {   // per-shape words of the hit buffer
+        ucount[blockIdx.y] = 0;                                        // (wave-uniform branch, see k_tet_scan_slab: behind a
+        ucount[hpad + blockIdx.y] = 0;                                 // one-thread branch: 80 registers and an 8-byte scratch store
+        ucount[2 * hpad + blockIdx.y] = 0;                             // per lane = 16 MB of HBM writes per launch; so: 76, none)
     }
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
     WaveStage &W = s_w[tid >> 6];
@@ -1540,12 +1548,16 @@ __global__ __launch_bounds__(256, PIT_WAVES2) void k_tet_scan_wave(const float *
     const unsigned slot0 = (unsigned)tid * 4u, slotEnd = slot0 + (unsigned)(kWvSlots + 1) * 1024u;   // byte offsets into s_hit
     unsigned slotA = slot0;
     int pend0 = -1, pend1 = -1, npend = 0;                              // query ids of undecided candidates
+    // the four planes as two packed pairs: v_pk_fma_f32 evaluates two of them per instruction (six instructions per
+    // candidate where twelve v_fma_f32 stood; every half is the same IEEE fma in the same order, so A_i is unchanged)
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 Px01 = {F.N[0][0], F.N[1][0]}, Py01 = {F.N[0][1], F.N[1][1]}, Pz01 = {F.N[0][2], F.N[1][2]}, Pc01 = {F.C[0], F.C[1]};
+    const f32x2 Px23 = {F.N[2][0], F.N[3][0]}, Py23 = {F.N[2][1], F.N[3][1]}, Pz23 = {F.N[2][2], F.N[3][2]}, Pc23 = {F.C[2], F.C[3]};
     auto test = [&](const float4 q) {
-        const float A0 = fmaf(F.N[0][0], q.x, fmaf(F.N[0][1], q.y, fmaf(F.N[0][2], q.z, F.C[0])));
-        const float A1 = fmaf(F.N[1][0], q.x, fmaf(F.N[1][1], q.y, fmaf(F.N[1][2], q.z, F.C[1])));
-        const float A2 = fmaf(F.N[2][0], q.x, fmaf(F.N[2][1], q.y, fmaf(F.N[2][2], q.z, F.C[2])));
-        const float A3 = fmaf(F.N[3][0], q.x, fmaf(F.N[3][1], q.y, fmaf(F.N[3][2], q.z, F.C[3])));
-        const float av = fminf(fminf(A0, A1), fminf(A2, A3));
+        const f32x2 qx = {q.x, q.x}, qy = {q.y, q.y}, qz = {q.z, q.z};
+        const f32x2 A01 = __builtin_elementwise_fma(Px01, qx, __builtin_elementwise_fma(Py01, qy, __builtin_elementwise_fma(Pz01, qz, Pc01)));
+        const f32x2 A23 = __builtin_elementwise_fma(Px23, qx, __builtin_elementwise_fma(Py23, qy, __builtin_elementwise_fma(Pz23, qz, Pc23)));
+        const float av = fminf(fminf(A01.x, A01.y), fminf(A23.x, A23.y));
         const int qi = __float_as_int(q.w);
         if (av > F.twoEmax) {                                           // certain (twoEmax >= 0): kept in the lane's LDS slots, published
             // after the loops (an atomic per acceptance here is a vector-memory instruction with one or two live lanes in
