@@ -272,37 +272,42 @@ def make_workload(cfg_id, rank, device, world, gather=None, **kw):
     return {"pit": PitWorkload, "raster": RasterWorkload, "geometry": GeometryWorkload}[cfg["kind"]](cfg, rank, device, world, gather, **kw)
 
 
-def timed(wl, lib, steps, warmup, world, barrier=True):
+def timed(wl, lib, steps, warmup, world, barrier=True, step_events=False):
     """W untimed warm-up steps, then exactly K steps bracketed by barrier + synchronize on both sides.  Returns the wall
-    time, the per-step HIP-event times (ms) and the dominant kernel's (total ms, launches) from the library's own
-    events on the launch stream."""
-    # Everything the timed region will allocate lazily is made to exist during the warm-up: the library's launch events
-    # (selected already here, their warm-up samples dropped below), this function's step events (recorded once), and no
-    # cyclic garbage collection inside the region — one timed region of 20 steps was once 45 ms long with a median step
-    # of 0.229 ms (profiles/README.md), i.e. a single host-side stall; the per-step maximum is printed beside the mean
-    # (normally the FIRST step, ~0.15 ms longer than the others: its launches meet an idle GPU after the synchronize).
+    time, the per-step HIP-event times (ms; empty unless step_events) and the dominant kernel's (total ms, launches)
+    from the library's own events on the launch stream."""
+    # Everything the timed region would otherwise do lazily is done BEFORE the warm-up: the step events exist and have
+    # been recorded once, the cyclic garbage collector has run and is off (one timed region of 20 steps was once 45 ms
+    # long with a median step of 0.229 ms, profiles/README.md: a single host-side stall), and the library's launch events
+    # exist (selected for the warm-up already, those samples dropped below).  Between the last warm-up step and the first
+    # timed one there is then nothing but the barrier and the synchronize the contract asks for: rounds 1-3 created the
+    # events and collected garbage THERE, the GPU sat idle for milliseconds and the first timed step ran 0.15 ms longer
+    # than the others (7 us per step of a 20-step mean).
+    # step_events: an event after every step gives the median / maximum, but every event record is a barrier packet in
+    # the queue (3-4 us per step at configs[2]); the headline region is timed without them, a second region with.
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)] if step_events else []
+    for e in evs:
+        e.record()
+    gc.collect()
+    gc_was_on = gc.isenabled()
+    gc.disable()
     lib.deftet_profile_select(wl.dominant)
     for i in range(warmup):
         wl.step(i)
     wl.drain()
+    if world > 1 and barrier:
+        torch.distributed.barrier()
     torch.cuda.synchronize()
     tot_ms, cnt = ctypes.c_double(0), ctypes.c_longlong(0)
     lib.deftet_profile_read(ctypes.byref(tot_ms), ctypes.byref(cnt))
     lib.deftet_profile_select(wl.dominant)
-    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
-    for e in evs:
-        e.record()
-    gc.collect()
-    if world > 1 and barrier:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    gc_was_on = gc.isenabled()
-    gc.disable()
     t0 = time.perf_counter()
     for i in range(steps):
-        evs[i].record()
+        if step_events:
+            evs[i].record()
         wl.step(warmup + i)
-    evs[steps].record()
+    if step_events:
+        evs[steps].record()
     wl.drain()
     torch.cuda.synchronize()
     if world > 1 and barrier:
@@ -313,7 +318,7 @@ def timed(wl, lib, steps, warmup, world, barrier=True):
     tot_ms, cnt = ctypes.c_double(0), ctypes.c_longlong(0)
     lib.deftet_profile_read(ctypes.byref(tot_ms), ctypes.byref(cnt))
     lib.deftet_profile_select(b"")
-    per_step = [evs[i].elapsed_time(evs[i + 1]) for i in range(steps)]
+    per_step = [evs[i].elapsed_time(evs[i + 1]) for i in range(steps)] if step_events else []
     return elapsed, per_step, tot_ms.value, cnt.value
 
 
@@ -466,8 +471,9 @@ def summarize(wl, elapsed, per_step, kern_ms_tot, kern_cnt, steps, world, peak_m
         roof["frac_of_measured_read"] = round(achieved / peak_measured["read"], 4)
     return {
         "value": round(world * wl.pairs_per_step * steps / elapsed / (1e6 if wl.unit.startswith("M ") else 1.0), 1), "unit": wl.unit,
-        "ms_per_step": round(elapsed / steps * 1e3, 4), "ms_per_step_median": round(statistics.median(per_step), 4),
-        "ms_per_step_max": round(max(per_step), 4),
+        "ms_per_step": round(elapsed / steps * 1e3, 4),
+        "ms_per_step_median": round(statistics.median(per_step), 4) if per_step else None,
+        "ms_per_step_max": round(max(per_step), 4) if per_step else None,
         "roofline": roof,
     }
 
@@ -579,7 +585,9 @@ def main():
     lib = _lib.load()
     gather = sharding.LossGather()
     wl = make_workload(args.config, rank, device, world, gather)
-    elapsed, per_step, kms, kcnt = timed(wl, lib, args.steps, args.warmup, world)
+    elapsed, _, kms, kcnt = timed(wl, lib, args.steps, args.warmup, world)
+    # median / maximum step: a second region of the same K steps with an event after every step (not the headline)
+    _, per_step, _, _ = timed(wl, lib, args.steps, 2, world, step_events=True)
     rank_ms = None
     if world > 1:
         # the job's time is the slowest rank's; every rank's own time is kept beside it so that a straggler is visible
@@ -599,6 +607,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": main_line["ms_per_step"], "ms_per_step_median": main_line["ms_per_step_median"],
             "ms_per_step_max": main_line["ms_per_step_max"],
+            "median_max_from": "a second region of the same K steps with a HIP event after every step",
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": wl.describe(),
@@ -616,7 +625,7 @@ def main():
             if isinstance(wl, PitWorkload) and not args.no_unpipelined:
                 # the same K steps with the other setting of the cross-step overlap (not the headline; printed beside it)
                 wl.pipeline = not wl.pipeline
-                e2, ps2, km2, kc2 = timed(wl, lib, args.steps, 2, 1, barrier=False)
+                e2, ps2, km2, kc2 = timed(wl, lib, args.steps, 2, 1, barrier=False, step_events=True)
                 key = "pipelined" if wl.pipeline else "unpipelined"
                 line["ms_per_step_%s" % key] = round(e2 / args.steps * 1e3, 4)
                 line["ms_per_step_%s_median" % key] = round(statistics.median(ps2), 4)
@@ -639,7 +648,7 @@ def main():
                         continue
                     w2 = make_workload(cid, 0, device, 1, None)
                     k2 = max(20, args.steps)                      # (ten steps let the first, idle-GPU step weigh 17 % of the mean)
-                    e, ps, km, kc = timed(w2, lib, k2, 3, 1, barrier=False)
+                    e, ps, km, kc = timed(w2, lib, k2, 3, 1, barrier=False, step_events=True)
                     rec = summarize(w2, e, ps, km, kc, k2, 1, peak)
                     entry = {"config_id": cid, "config": w2.describe()["workload"], "value": rec["value"], "unit": rec["unit"], "steps": k2,
                              "ms_per_step": rec["ms_per_step"], "ms_per_step_median": rec["ms_per_step_median"]}

@@ -28,7 +28,9 @@ __device__ __forceinline__ float rowdot_slice(const float *__restrict__ a, const
     if (vec) {
         const long long n4 = n_cols / 4;
         // four strided items per trip, all loads issued before the first is used (one load per trip left the row's
-        // three trips as three memory latencies in a row); the items are added in index order, trip by trip
+        // three trips as three memory latencies in a row); the items are added in index order, trip by trip.  (Batching
+        // the tail trips as well — clamped indices, items past the end not added — measured slower: 16 -> 21 us at
+        // 8 rows x 100,000 x (4 + 1) columns, where most threads have three items.)
         long long i = tid;
         for (; i + 3 * stride < n4; i += 4 * stride) {
             float4 x[4], y[4];

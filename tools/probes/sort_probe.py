@@ -12,7 +12,7 @@ a = ap.parse_args()
 lib = _lib.load(); dev = torch.device("cuda:0")
 wl = bench.PitWorkload(dict(bench.CONFIGS[a.config]), 0, dev, 1, None, pipeline=False)
 out = {}
-for k in ("k_query_bbox", "k_slab_local", "k_slab_sort", hip_ops.pit_kernel_name(0, wl.T, wl.Q), "k_finalize", "k_bary_bwd_hits", "k_rowdot_fused"):
+for k in ("k_query_bbox", "k_slab_local", "k_slab_sort", hip_ops.pit_kernel_name(0, wl.T, wl.Q), "k_finalize", "k_bary_bwd_hits", "deftet::red::k_rowdot_fused"):
     for i in range(3): wl.step(i)
     torch.cuda.synchronize()
     lib.deftet_profile_select(k.encode())
