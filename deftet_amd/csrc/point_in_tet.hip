@@ -1256,12 +1256,15 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan_slab(const float *_
 //  2. THE CANDIDATES OF A WAVE ARE STAGED IN LDS.  64 consecutive tets of a spatially coherent mesh share their
 //     neighbourhood.  The wave picks a pivot lane, groups the lanes whose (x, y) cell footprint is within two / one cells
 //     of the pivot's (up to two groups: a wave that straddles two columns of the mesh), reduces the group's cell box
-//     (packed 16-bit max over DPP), reads the bounds of the box's (cz, cy) rows over the group's x range (two 4-byte loads
-//     per row, a wave scan gives their positions in LDS) and copies the rows' queries with coalesced loads, balanced over
-//     the lanes through an owner scan.  A lane's candidates are then ONE contiguous LDS range — all staged rows of its own
-//     z slabs — walked with ds_read_b128 and no addressing arithmetic; acceptances are published at once (atomicMin) and
-//     kept in LDS slots.  Footprints with more queries than a chunk holds are staged slab range by slab range.
-//     Everything here is per wave: no barrier.
+//     (packed 16-bit max over DPP), reads the bounds of the box's (cz, cy) rows over the group's x range — one LANE per
+//     slab, two 16-byte loads of the transposed table (start column, end column) for the slab's <= 4 rows; a wave scan
+//     gives the rows' positions in LDS — and copies the rows' queries with coalesced loads, balanced over the lanes
+//     through an owner scan.  A lane's candidates are then ONE contiguous LDS range — all staged rows of its own z slabs —
+//     walked with ds_read_b128, two candidates per trip, the four planes as two packed pairs (v_pk_fma_f32: six
+//     instructions per candidate).  Accepted queries are kept in the lane's LDS slots (kWvSlots) and published after the
+//     loops with one atomicMin instruction per slot level (an atomic per acceptance inside the loop was a vector-memory
+//     instruction with one or two live lanes: 101 vs 84 us).  Footprints with more queries than a chunk holds are staged
+//     slab range by slab range.  Everything here is per wave: no barrier.
 //  3. Lanes that fit no group (incoherent tet order, over-long footprints) walk the global table as k_tet_scan_slab does.
 // ------------------------------------------------------------------------------------
 constexpr int kWvRows = 192;                            // (cz, cy) rows of a staged footprint (three per lane)
