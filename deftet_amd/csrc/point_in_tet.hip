@@ -1044,6 +1044,9 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan_slab(const float *_
         }
         F.twoEmax = 2.0f * emax;
     }
+    typedef float pk2 __attribute__((ext_vector_type(2)));
+    const pk2 Px01 = {F.N[0][0], F.N[1][0]}, Py01 = {F.N[0][1], F.N[1][1]}, Pz01 = {F.N[0][2], F.N[1][2]}, Pc01 = {F.C[0], F.C[1]};
+    const pk2 Px23 = {F.N[2][0], F.N[3][0]}, Py23 = {F.N[2][1], F.N[3][1]}, Pz23 = {F.N[2][2], F.N[3][2]}, Pc23 = {F.C[2], F.C[3]};
     const float m = bx.w * kMargin;
     float elo[3], ehi[3];
 #pragma unroll
@@ -1137,11 +1140,11 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan_slab(const float *_
             __builtin_amdgcn_sched_barrier(0);                         // all gathers in flight before the first filter value is needed
             float av[PIT_BATCH];
 #pragma unroll
-            for (int k = 0; k < PIT_BATCH; ++k) {
-                float A[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) A[i] = fmaf(F.N[i][0], q[k].x, fmaf(F.N[i][1], q[k].y, fmaf(F.N[i][2], q[k].z, F.C[i])));
-                av[k] = fminf(fminf(A[0], A[1]), fminf(A[2], A[3]));
+            for (int k = 0; k < PIT_BATCH; ++k) {                       // two planes per v_pk_fma_f32 (same fmas, same order)
+                const pk2 qx = {q[k].x, q[k].x}, qy = {q[k].y, q[k].y}, qz = {q[k].z, q[k].z};
+                const pk2 A01 = __builtin_elementwise_fma(Px01, qx, __builtin_elementwise_fma(Py01, qy, __builtin_elementwise_fma(Pz01, qz, Pc01)));
+                const pk2 A23 = __builtin_elementwise_fma(Px23, qx, __builtin_elementwise_fma(Py23, qy, __builtin_elementwise_fma(Pz23, qz, Pc23)));
+                av[k] = fminf(fminf(A01.x, A01.y), fminf(A23.x, A23.y));
             }
             float am = fabsf(av[0]);                                   // dead slots repeat candidate 0: no mask needed
 #pragma unroll
