@@ -8,7 +8,9 @@
 //   scan<T, Op, EXCLUSIVE>(in, out, n, identity, tmp, tmp_bytes, stream)         in == out allowed
 //
 // Sort: 8 bits per pass, (bits + 7) / 8 passes.  Per pass: k_rs_hist (LDS histogram of the digit per 2,048-key tile ->
-// hist[digit][tile]), an exclusive scan of that table (= where the keys of (digit, tile) start), k_rs_scatter.  The
+// hist[digit][tile]), an exclusive scan of that table (= where the keys of (digit, tile) start), k_rs_scatter.  Sorts of up
+// to kFusedTiles tiles (1 M keys) skip the scan launches: the table is written tile-major and every scatter workgroup sums
+// the rows of the earlier tiles itself (two launches per pass instead of three to five).  The
 // scatter is stable without atomics: a tile is four waves x eight rounds x 64 lanes in key order; per round the lanes
 // with equal digits find each other with eight ballots (match-any), the first of them advances the wave's own counter
 // of that digit, so a key's rank among the wave's keys of its digit is known after one walk; one pass over the 4 x 256
@@ -23,6 +25,10 @@ namespace deftet {
 namespace prims {
 
 constexpr int kTileThreads = 256, kTileItems = 8, kTile = kTileThreads * kTileItems;   // 2,048 elements per workgroup
+#ifndef PRIMS_FUSED_TILES
+#define PRIMS_FUSED_TILES 512
+#endif
+constexpr unsigned kFusedTiles = PRIMS_FUSED_TILES;       // sorts of up to this many tiles (1 M keys) run two launches per pass (no scan)
 
 // ---------------------------------------------------------------------------- scans
 struct Plus {
@@ -210,9 +216,11 @@ struct IotaLoad {
 
 // n_dev (may be NULL): the number of elements actually present, known on the device only (n is then the capacity the
 // grid is sized for); workgroups beyond it find nothing to do, so the cost follows the real count.
+// by_tile: the table is hist[tile][digit] (read by the FUSED scatter, which sums the earlier tiles' rows itself) instead of
+// hist[digit][tile] (what the scan of the three-launch form wants)
 template <typename K, typename KL>
 __global__ __launch_bounds__(kTileThreads) void k_rs_hist(KL keys, size_t n, int shift, unsigned dmask, unsigned nblk, unsigned *hist,
-                                                          const int *__restrict__ n_dev)
+                                                          const int *__restrict__ n_dev, int by_tile)
 {
     if (n_dev) n = min(n, (size_t)max(*n_dev, 0));
     __shared__ unsigned h[256];
@@ -225,18 +233,18 @@ __global__ __launch_bounds__(kTileThreads) void k_rs_hist(KL keys, size_t n, int
         if (i < n) atomicAdd(&h[(unsigned)(keys(i) >> shift) & dmask], 1u);
     }
     __syncthreads();
-    hist[(size_t)threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];
+    hist[by_tile ? (size_t)blockIdx.x * 256 + threadIdx.x : (size_t)threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];
 }
 
 template <typename K, typename V, bool HAS_V, typename KL, typename VL>
 __global__ __launch_bounds__(kTileThreads) void k_rs_scatter(KL kin, K *kout, VL vin, V *vout, size_t n,
                                                              int shift, unsigned dmask, unsigned nblk, const unsigned *__restrict__ offs,
-                                                             const int *__restrict__ n_dev)
+                                                             const int *__restrict__ n_dev, int fused)
 {
     if (n_dev) n = min(n, (size_t)max(*n_dev, 0));
     if ((size_t)blockIdx.x * kTile >= n) return;
     __shared__ unsigned cnt[kTileThreads / 64][256];                // per wave and digit: count, then rank base inside the tile
-    __shared__ unsigned lbase[256], gbase[256], wtot[kTileThreads / 64];
+    __shared__ unsigned lbase[256], gbase[256], wtot[kTileThreads / 64], wtot2[kTileThreads / 64];
     __shared__ K s_key[kTile];
     __shared__ V s_val[HAS_V ? kTile : 1];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -281,12 +289,45 @@ __global__ __launch_bounds__(kTileThreads) void k_rs_scatter(KL kin, K *kout, VL
             const unsigned t = __shfl_up(incl, off);
             if (lane >= off) incl += t;
         }
+        // fused: `offs` is the UNSCANNED table hist[tile][digit] of k_rs_hist: thread d sums its column over the earlier tiles
+        // (where the tile's keys of digit d start inside the digit's run) and over all tiles (the digit's total); an exclusive
+        // scan of the totals over the digits gives the run's start.  A few hundred coalesced 1 KB rows from L2 per workgroup
+        // instead of three scan launches per pass (small sorts: the launches were most of the pass).
+        unsigned below = 0u, total = 0u, gincl = 0u;
+        if (fused) {
+            const unsigned ntile = (unsigned)((n + kTile - 1) / kTile);          // tiles that hold keys (n is the device-side count)
+            constexpr unsigned kInFlight = 32;                                   // rows per trip, all loads issued before the first is used
+            for (unsigned j0 = 0; j0 < ntile; j0 += kInFlight) {
+                unsigned a[kInFlight];
+#pragma unroll
+                for (unsigned k = 0; k < kInFlight; ++k) a[k] = offs[(size_t)min(j0 + k, ntile - 1u) * 256 + d];   // clamped, unconditional
+#pragma unroll
+                for (unsigned k = 0; k < kInFlight; ++k) {
+                    const unsigned v = j0 + k < ntile ? a[k] : 0u;
+                    total += v;
+                    below += j0 + k < blockIdx.x ? v : 0u;
+                }
+            }
+            gincl = total;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned t = __shfl_up(gincl, off);
+                if (lane >= off) gincl += t;
+            }
+            if (lane == 63) wtot2[w] = gincl;
+        }
         if (lane == 63) wtot[w] = incl;
         __syncthreads();
         unsigned run = incl - tot;
         for (int k = 0; k < w; ++k) run += wtot[k];
         lbase[d] = run;
-        gbase[d] = offs[(size_t)d * nblk + blockIdx.x];
+        if (fused) {
+            unsigned g = gincl - total + below;
+            for (int k = 0; k < w; ++k) g += wtot2[k];
+            gbase[d] = g;
+        } else {
+            gbase[d] = offs[(size_t)d * nblk + blockIdx.x];
+        }
 #pragma unroll
         for (int k = 0; k < kTileThreads / 64; ++k) {
             const unsigned t = cnt[k][d];
@@ -347,22 +388,28 @@ int radix_sort_impl(KL kin, K *kout, VL vin, V *vout, size_t n, int bits, void *
     const size_t stmp_bytes = scan_temp_bytes<unsigned>((size_t)256 * nblk);
     const K *sk = nullptr;
     const V *sv = nullptr;
+    // sorts of up to kFusedTiles tiles skip the scan: the scatter sums the histogram table itself (see k_rs_scatter)
+    const int fused = nblk <= kFusedTiles ? 1 : 0;
     for (int p = 0; p < passes; ++p) {
         const bool to_out = ((passes - 1 - p) & 1) == 0;            // the last pass lands in kout / vout
         K *dk = to_out ? kout : tk;
         V *dv = to_out ? vout : tv;
         const int left = bits - p * 8;                               // the last digit may be narrower: bits above `bits` do not count
         const unsigned dmask = left >= 8 || bits <= 0 ? 255u : (1u << left) - 1u;
-        if (p == 0) DEFTET_LAUNCH((k_rs_hist<K, KL>), dim3(nblk), dim3(kTileThreads), st, kin, n, 0, dmask, nblk, hist, n_dev);
-        else DEFTET_LAUNCH((k_rs_hist<K, PtrLoad<K>>), dim3(nblk), dim3(kTileThreads), st, PtrLoad<K>{sk}, n, p * 8, dmask, nblk, hist, n_dev);
-        const int rc = scan<unsigned, Plus, true>(hist, offs, (size_t)256 * nblk, 0u, Plus(), stmp, stmp_bytes, st);
-        if (rc != DEFTET_OK) return rc;
+        if (p == 0) DEFTET_LAUNCH((k_rs_hist<K, KL>), dim3(nblk), dim3(kTileThreads), st, kin, n, 0, dmask, nblk, hist, n_dev, fused);
+        else DEFTET_LAUNCH((k_rs_hist<K, PtrLoad<K>>), dim3(nblk), dim3(kTileThreads), st, PtrLoad<K>{sk}, n, p * 8, dmask, nblk, hist, n_dev, fused);
+        const unsigned *table = hist;
+        if (!fused) {
+            const int rc = scan<unsigned, Plus, true>(hist, offs, (size_t)256 * nblk, 0u, Plus(), stmp, stmp_bytes, st);
+            if (rc != DEFTET_OK) return rc;
+            table = offs;
+        }
         if (p == 0)
             DEFTET_LAUNCH((k_rs_scatter<K, V, HAS_V, KL, VL>), dim3(nblk), dim3(kTileThreads), st, kin, dk, vin, dv, n, 0, dmask, nblk,
-                          (const unsigned *)offs, n_dev);
+                          table, n_dev, fused);
         else
             DEFTET_LAUNCH((k_rs_scatter<K, V, HAS_V, PtrLoad<K>, PtrLoad<V>>), dim3(nblk), dim3(kTileThreads), st, PtrLoad<K>{sk}, dk, PtrLoad<V>{sv},
-                          dv, n, p * 8, dmask, nblk, (const unsigned *)offs, n_dev);
+                          dv, n, p * 8, dmask, nblk, table, n_dev, fused);
         sk = dk;
         sv = dv;
     }

@@ -651,7 +651,8 @@ def check_sign(verts_bxvx3, faces_fx3, points_bxnx3, brute=False, return_count=F
                                              algo, _lib.ptr(ws), ws.numel(), _lib.current_stream(dev)), "deftet_check_sign_f32")
     if check and int(bad.item()):
         raise IndexError("check_sign: face index outside [0, %d)" % V)
-    return (out.bool(), cnt) if return_count else out.bool()
+    inside = out.view(torch.bool)                            # 0 / 1 bytes: a reinterpretation, not a conversion launch
+    return (inside, cnt) if return_count else inside
 
 
 def check_sign_ragged(verts_list, faces_list, points_bxnx3, brute=False, return_count=False, check=False):
@@ -681,7 +682,8 @@ def check_sign_ragged(verts_list, faces_list, points_bxnx3, brute=False, return_
                                                     ws.numel(), _lib.current_stream(dev)), "deftet_check_sign_ragged_f32")
     if check and int(bad.item()):
         raise IndexError("check_sign_ragged: face index outside its mesh")
-    return (out.bool(), cnt) if return_count else out.bool()
+    inside = out.view(torch.bool)                            # 0 / 1 bytes: a reinterpretation, not a conversion launch
+    return (inside, cnt) if return_count else inside
 
 
 # --------------------------------------------------------------------------------- N3 render-side rebuilds

@@ -247,7 +247,7 @@ class DefTet(nn.Module):
         det_m = (torch.abs(torch.det(T)) < 1e-10).float()                     # :215
         iden_m = torch.eye(T.shape[-1], dtype=torch.float, device=T.device).unsqueeze(0).expand(T.shape[0], -1, -1)
         tmp_m = T * (1 - det_m.unsqueeze(-1).unsqueeze(-1)) + iden_m * det_m.unsqueeze(-1).unsqueeze(-1)
-        return torch.inverse(tmp_m), 1 - det_m
+        return torch.inverse(tmp_m).contiguous(), 1 - det_m              # (row-major: the energies would copy it per call)
 
     def tet_inverse_v(self, init_tet_pos, init_tet_fx4, scale=20):
         vertice_pos = init_tet_pos.float()
