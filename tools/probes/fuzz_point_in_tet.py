@@ -14,19 +14,40 @@ t_end = time.time() + budget
 n = 0
 while time.time() < t_end:
     B = int(rng.integers(1, 5)); T = int(rng.choice([1, 2, 5, 63, 64, 65, 300, 1000, 3000, 20000])); Q = int(rng.choice([1, 2, 63, 64, 65, 255, 256, 257, 2047, 2048, 2049, 6000, 30000]))
-    kind = rng.integers(0, 5)
+    kind = rng.integers(0, 8)
     scale = float(rng.choice([1e-3, 1.0, 1.0, 1.0, 50.0]))
-    c = torch.rand(B, T, 1, 3, device=dev, generator=g) - 0.5
     size = float(rng.choice([0.02, 0.1, 0.4, 1.5]))
-    tet = (c + size * (torch.rand(B, T, 4, 3, device=dev, generator=g) - 0.5)) * scale
+    if kind >= 5:
+        # a COHERENT mesh (what the wave-staged traversal groups): jittered Kuhn grid in cube-major order, sometimes with
+        # stretches of it reversed or rotated, jitter from mild to inverting; kinds 6 / 7 make the query set dense
+        # (several staged chunks per footprint, rows that do not fit a chunk)
+        from deftet_amd import grids
+        res = int(rng.choice([2, 4, 6, 10, 16, 24]))
+        verts, tets = grids.kuhn_grid(res)
+        T = tets.shape[0]
+        amp = float(rng.choice([0.0, 0.1, 0.3, 0.9]))
+        v = torch.from_numpy(verts.astype(np.float32)).to(dev)[None].repeat(B, 1, 1) - 0.5
+        v = v + amp / res * (torch.rand(v.shape, device=dev, generator=g) - 0.5)
+        idx = torch.from_numpy(tets.astype(np.int64)).to(dev)
+        if rng.random() < 0.5:
+            k0 = int(rng.integers(0, T)); k1 = int(rng.integers(k0, T + 1))
+            idx = torch.cat([idx[:k0], idx[k0:k1].flip(0), idx[k1:]])
+        if rng.random() < 0.3:
+            idx = idx.roll(int(rng.integers(0, T)), 0)
+        tet = (v[:, idx] * scale).contiguous()
+    else:
+        c = torch.rand(B, T, 1, 3, device=dev, generator=g) - 0.5
+        tet = (c + size * (torch.rand(B, T, 4, 3, device=dev, generator=g) - 0.5)) * scale
     if kind == 1:                                        # degenerate / non-finite tets mixed in
         m = torch.rand(B, T, device=dev, generator=g)
         tet[m < 0.05] = tet[m < 0.05][:, :1].expand(-1, 4, -1)            # collapsed
         tet[(m > 0.05) & (m < 0.07)] = float("nan")
         tet[(m > 0.07) & (m < 0.09)] *= 1e7
     pts = (torch.rand(B, Q, 3, device=dev, generator=g) - 0.5) * scale * 1.1
-    if kind == 2:
+    if kind == 2 or kind == 6:
         pts = pts * 1e-3 + 0.1 * scale                   # one cell
+    if kind == 7:
+        pts[:, : Q // 2] = pts[:, : Q // 2] * 0.05 + 0.2 * scale    # half of them in a small box: dense rows next to sparse ones
     if kind == 3:
         pts[..., int(rng.integers(0, 3))] = 0.03 * scale  # a plane
     if kind == 4:
@@ -40,7 +61,8 @@ while time.time() < t_end:
             print("MISMATCH algo=%d B=%d T=%d Q=%d kind=%d scale=%g size=%g at %s: %s vs %s" % (algo, B, T, Q, kind, scale, size, bad, got[tuple(bad)].item(), ref[tuple(bad)].item()), flush=True)
             sys.exit(1)
     pred = torch.rand(B, T, device=dev, generator=g)
-    cond, w, occ, hits = hip_ops.point_in_tet(tet, pts, want_bary=True, pred_bxt=pred, want_hits=True, algo=int(rng.choice([0, 2, 3, 4])))
+    falgo = int(rng.choice([0, 2, 3, 4]))
+    cond, w, occ, hits = hip_ops.point_in_tet(tet, pts, want_bary=True, pred_bxt=pred, want_hits=True, algo=falgo)
     assert torch.equal(cond, ref)
     gw = torch.randn(B, Q, 4, device=dev, generator=g); go = torch.randn(B, Q, device=dev, generator=g)
     a = hip_ops.point_in_tet_bwd(tet, pts, cond, gw, grad_occ=go, hits=hits)
@@ -55,9 +77,11 @@ while time.time() < t_end:
                 words = hits[4 * B * T:4 * B * T + 3 * ((B + 63) // 64 * 64)].view(3, -1)[:, :B].tolist()
                 qs = (cond[at[0], :, 0] == at[1]).nonzero().flatten().tolist()
                 nU = words[0][at[0]]
-                ul = hits[4 * B * T + 3 * ((B + 63) // 64 * 64):].view(B, Q)[at[0], :nU].tolist()
+                l0 = 4 * B * T + 3 * ((B + 63) // 64 * 64)
+                ul = hits[l0:l0 + B * Q].view(B, Q)[at[0], :nU].tolist()
                 print("queries won by that tet: %s (coordinates %s); in the uncovered list: %s" % (
                     qs, pts[at[0], qs].tolist(), [q in ul for q in qs]), flush=True)
+                print("forward algo %d; scale %g size %g" % (falgo, scale, size), flush=True)
                 print("BACKWARD MISMATCH %s B=%d T=%d Q=%d kind=%d: err %g of %g at %s: hits-path %g vs list-path %g; "
                       "uncovered/ticket/irregular-query words %s; record of that tet %s" % (
                           name, B, T, Q, kind, err, ref_mag, at, x[tuple(at)].item(), y[tuple(at)].item(), words,
