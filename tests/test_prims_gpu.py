@@ -6,7 +6,9 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-SIZES = [0, 1, 63, 64, 65, 2047, 2048, 2049, 4096 + 17, 100_003, 1_000_000]
+# 512 tiles of 2,048 keys is where the sort changes its pass structure (two launches per pass with the scatter summing the
+# tile-major table itself below, hist + scan + scatter above): both sides of 1,048,576 and a size well above it
+SIZES = [0, 1, 63, 64, 65, 2047, 2048, 2049, 4096 + 17, 100_003, 1_000_000, 512 * 2048, 512 * 2048 + 1, 2_500_003]
 
 
 @pytest.mark.parametrize("n", SIZES)
@@ -44,6 +46,14 @@ def test_radix_sort_ignores_bits_above_the_requested_ones_and_honours_a_device_s
     ko, vo = hip_ops.radix_sort(k, v, bits=30, n_valid=cnt)          # the tail beyond the count is not touched / defined
     order = np.argsort(keys[:used], kind="stable")
     assert np.array_equal(ko.cpu().numpy()[:used], keys[:used][order]) and np.array_equal(vo.cpu().numpy()[:used], vals[:used][order])
+    # the same with a capacity above 512 tiles (the scan form of the pass) of which only a few tiles hold keys
+    n2, used2 = 1_300_000, 5_001
+    keys2 = rng.integers(0, 1 << 19, n2, dtype=np.int64).astype(np.int32)
+    k2 = torch.from_numpy(keys2).to(cuda)
+    v2 = torch.arange(n2, device=cuda, dtype=torch.int32)
+    ko, vo = hip_ops.radix_sort(k2, v2, bits=19, n_valid=torch.tensor([used2], device=cuda, dtype=torch.int32))
+    order = np.argsort(keys2[:used2], kind="stable")
+    assert np.array_equal(ko.cpu().numpy()[:used2], keys2[:used2][order]) and np.array_equal(vo.cpu().numpy()[:used2], order.astype(np.int32))
 
 
 @pytest.mark.parametrize("n", SIZES)
