@@ -1274,7 +1274,13 @@ constexpr int kWvRows = 192;                            // (cz, cy) rows of a st
 constexpr int kWvCap = 96;                              // staged queries per chunk
 constexpr int kWvSlots = 6;                             // accepted queries a lane keeps: record + half a spill record
 static_assert(kWvRows <= 254 && kWvRows % 64 == 0 && kWvSlots >= 4 && kWvSlots <= 8, "row ids are bytes; the records hold four + four");
-constexpr int kWvMinGroup = 16;                         // lanes a footprint group must have to be worth staging
+#ifndef PIT_TOLX
+#define PIT_TOLX 2          // x cells a lane's footprint may differ from the pivot's
+#endif
+#ifndef PIT_MINGROUP
+#define PIT_MINGROUP 4      // 16: 68.7 us at configs[2], 150 at configs[3]; 8: 66.2 / 148; 4: 65.2 / 143; 2, 1: the same
+#endif
+constexpr int kWvMinGroup = PIT_MINGROUP;               // lanes a footprint group must have to be worth staging
 constexpr float kRelScale = 2.86102294921875e-06f;      // 48 u = 24 u * (the 2 of G_k = 2 w_l w_m)
 constexpr float kTauSlim = kTau * (1.0f + 1.0f / 128.0f);
 #ifndef PIT_WAVES2
@@ -1540,7 +1546,7 @@ __global__ __launch_bounds__(256, PIT_WAVES2) void k_tet_scan_wave(const float *
             const int px0 = __builtin_amdgcn_readlane(cx0, pl), px1 = __builtin_amdgcn_readlane(cx1, pl);
             const int py0 = __builtin_amdgcn_readlane(cy0, pl), py1 = __builtin_amdgcn_readlane(cy1, pl);
             // (unsigned compare of the shifted difference: one instruction per bound)
-            const bool in = ((rem >> lane) & 1ull) != 0ull && (unsigned)(cx0 - px0 + 2) <= 4u && (unsigned)(cx1 - px1 + 2) <= 4u &&
+            const bool in = ((rem >> lane) & 1ull) != 0ull && (unsigned)(cx0 - px0 + PIT_TOLX) <= 2u * PIT_TOLX && (unsigned)(cx1 - px1 + PIT_TOLX) <= 2u * PIT_TOLX &&
                             (unsigned)(cy0 - py0 + 1) <= 2u && (unsigned)(cy1 - py1 + 1) <= 2u;
             const lanemask_t gm = __builtin_amdgcn_ballot_w64(in);
             if (__popcll(gm) < kWvMinGroup) { rem = 0ull; continue; }  // incoherent order: everything left walks the global table
