@@ -1271,7 +1271,10 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan_slab(const float *_
 //  3. Lanes that fit no group (incoherent tet order, over-long footprints) walk the global table as k_tet_scan_slab does.
 // ------------------------------------------------------------------------------------
 constexpr int kWvRows = 192;                            // (cz, cy) rows of a staged footprint (three per lane)
-constexpr int kWvCap = 96;                              // staged queries per chunk
+#ifndef PIT_WVCAP
+#define PIT_WVCAP 96
+#endif
+constexpr int kWvCap = PIT_WVCAP;                       // staged queries per chunk
 constexpr int kWvSlots = 6;                             // accepted queries a lane keeps: record + half a spill record
 static_assert(kWvRows <= 254 && kWvRows % 64 == 0 && kWvSlots >= 4 && kWvSlots <= 8, "row ids are bytes; the records hold four + four");
 #ifndef PIT_TOLX
