@@ -69,7 +69,7 @@ int deftet_profile_read(double *total_ms, long long *count);
  *      utils/tet_utils.py:28-45 (zeros for misses).
  * pred f32 [B,T] + occ f32 [B,Q] (both or neither): fused DefTet.paste_occ gather
  *      occ[b,q] = pred[b, max(index,0)] (layers/DefTet/deftet.py:132-136); cond keeps its -1s.
- * hit_buf int32 [deftet_point_in_tet_hits_ints(B,T,Q)] or NULL (DEFTET_PIT_AUTO only): opaque
+ * hit_buf int32 [deftet_point_in_tet_hits_ints(B,T,Q)], 16-byte aligned, or NULL (every algo but DEFTET_PIT_BRUTE): opaque
  *      per-tet records of the accepted queries; handing it to deftet_point_in_tet_bwd_f32 makes
  *      the backward free of atomics, lists and memsets.
  * ------------------------------------------------------------------------------- */
