@@ -236,11 +236,14 @@ __global__ __launch_bounds__(kTileThreads) void k_rs_hist(KL keys, size_t n, int
     hist[by_tile ? (size_t)blockIdx.x * 256 + threadIdx.x : (size_t)threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];
 }
 
-template <typename K, typename V, bool HAS_V, typename KL, typename VL>
+// FUSED is a template argument: the 32 rows its column sums keep in flight are 32 more registers (100 instead of 68), which
+// as a run-time branch cost the large sorts — the 16.8 M-pair hit sort of the rasterizer's backward — a workgroup per CU
+template <typename K, typename V, bool HAS_V, typename KL, typename VL, bool FUSED>
 __global__ __launch_bounds__(kTileThreads) void k_rs_scatter(KL kin, K *kout, VL vin, V *vout, size_t n,
                                                              int shift, unsigned dmask, unsigned nblk, const unsigned *__restrict__ offs,
-                                                             const int *__restrict__ n_dev, int fused)
+                                                             const int *__restrict__ n_dev)
 {
+    constexpr bool fused = FUSED;
     if (n_dev) n = min(n, (size_t)max(*n_dev, 0));
     if ((size_t)blockIdx.x * kTile >= n) return;
     __shared__ unsigned cnt[kTileThreads / 64][256];                // per wave and digit: count, then rank base inside the tile
@@ -404,12 +407,18 @@ int radix_sort_impl(KL kin, K *kout, VL vin, V *vout, size_t n, int bits, void *
             if (rc != DEFTET_OK) return rc;
             table = offs;
         }
-        if (p == 0)
-            DEFTET_LAUNCH((k_rs_scatter<K, V, HAS_V, KL, VL>), dim3(nblk), dim3(kTileThreads), st, kin, dk, vin, dv, n, 0, dmask, nblk,
-                          table, n_dev, fused);
+        if (p == 0 && fused)
+            DEFTET_LAUNCH((k_rs_scatter<K, V, HAS_V, KL, VL, true>), dim3(nblk), dim3(kTileThreads), st, kin, dk, vin, dv, n, 0, dmask, nblk,
+                          table, n_dev);
+        else if (p == 0)
+            DEFTET_LAUNCH((k_rs_scatter<K, V, HAS_V, KL, VL, false>), dim3(nblk), dim3(kTileThreads), st, kin, dk, vin, dv, n, 0, dmask, nblk,
+                          table, n_dev);
+        else if (fused)
+            DEFTET_LAUNCH((k_rs_scatter<K, V, HAS_V, PtrLoad<K>, PtrLoad<V>, true>), dim3(nblk), dim3(kTileThreads), st, PtrLoad<K>{sk}, dk,
+                          PtrLoad<V>{sv}, dv, n, p * 8, dmask, nblk, table, n_dev);
         else
-            DEFTET_LAUNCH((k_rs_scatter<K, V, HAS_V, PtrLoad<K>, PtrLoad<V>>), dim3(nblk), dim3(kTileThreads), st, PtrLoad<K>{sk}, dk, PtrLoad<V>{sv},
-                          dv, n, p * 8, dmask, nblk, table, n_dev, fused);
+            DEFTET_LAUNCH((k_rs_scatter<K, V, HAS_V, PtrLoad<K>, PtrLoad<V>, false>), dim3(nblk), dim3(kTileThreads), st, PtrLoad<K>{sk}, dk,
+                          PtrLoad<V>{sv}, dv, n, p * 8, dmask, nblk, table, n_dev);
         sk = dk;
         sv = dv;
     }
