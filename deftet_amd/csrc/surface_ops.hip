@@ -2172,11 +2172,18 @@ __global__ __launch_bounds__(256) void k_tri_far_final(const unsigned long long 
 
 // per-point gradient contributions of the backward kernel (back.cu:591-686): up to 9 values
 // for up to 3 vertices of the saved face.  Returns the number of (slot,value) pairs written.
-__device__ __forceinline__ int tri_dist_point_grad(const float *fc, const float *p, float gp, int *slot, float *val)
+// Gradient of one point's value with respect to the nine coordinates of its nearest face: g9[s], and the mask of the
+// entries the reference's backward ADDS to (it also adds the zeros of the far edge endpoint, which matter only when the
+// incoming gradient is not finite).  Everything is indexed statically — a (slot, value) list walked with a run-time count
+// and corners addressed as fc + i * 3 put the lists and the corner array into scratch memory (48 bytes per lane, and 81
+// compares per point to undo the list) in all three backward kernels.
+__device__ __forceinline__ unsigned tri_dist_point_grad9(const float *fc, const float *p, float gp, float *g9)
 {
     float ret[3] = {0.f, 0.f, 0.f}, ip[3];
     min_triangle_distance<true>(fc, fc + 3, fc + 6, p, ret, ip, 9999999.0f);     // back.cu:628
-    int n = 0;
+#pragma unroll
+    for (int s = 0; s < 9; ++s) g9[s] = 0.f;
+    auto corner = [&](int c, int k) { return c == 0 ? fc[k] : (c == 1 ? fc[3 + k] : fc[6 + k]); };
     if (ret[0] == 0) {                                              // :630-651, cuda_gradient_triangle_distance :439-483
         const float *a = fc, *b = fc + 3, *c = fc + 6;
         float ip2[3], t;
@@ -2195,34 +2202,39 @@ __device__ __forceinline__ int tri_dist_point_grad(const float *fc, const float 
             }
         }
 #pragma unroll
-        for (int k = 0; k < 9; ++k) { slot[n] = k; val[n] = gp * grad[k]; ++n; }
-    } else if (ret[0] == 1) {                                       // :652-670
+        for (int k = 0; k < 9; ++k) g9[k] = gp * grad[k];
+        return 0x1FFu;
+    }
+    if (ret[0] == 1) {                                              // :652-670
         const int i1 = (int)ret[2], i2 = (i1 + 1) % 3;
-        const float *A = fc + i1 * 3, *B = fc + i2 * 3;
         // cuda_gradient_line_distance (:291-317): the second assignment of grad[0..2] wins, grad[3..5] stays 0
-        float PA[3], BA[3];
+        float A[3], B[3], PA[3], BA[3], v[3];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { PA[k] = p[k] - A[k]; BA[k] = B[k] - A[k]; }
+        for (int k = 0; k < 3; ++k) { A[k] = corner(i1, k); B[k] = corner(i2, k); PA[k] = p[k] - A[k]; BA[k] = B[k] - A[k]; }
         const float t = dot3(PA, BA) / divide_non_zero(dot3(BA, BA));
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const float tmp = B[k] * t;
             float ipk = A[k] * (1 - t);
             ipk = ipk + tmp;
-            slot[n] = i1 * 3 + k; val[n] = gp * (2 * (ipk - p[k]) * (t)); ++n;
+            v[k] = gp * (2 * (ipk - p[k]) * (t));
         }
+        const float z = gp * 0.0f;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { slot[n] = i2 * 3 + k; val[n] = gp * 0.0f; ++n; }
-    } else if (ret[0] == 2) {                                       // :671-685
+        for (int s = 0; s < 9; ++s) g9[s] = s / 3 == i1 ? v[s % 3] : (s / 3 == i2 ? z : 0.f);
+        return (7u << (3 * i1)) | (7u << (3 * i2));
+    }
+    if (ret[0] == 2) {                                              // :671-685
         const int iv = (int)ret[2];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            float gl = fc[iv * 3 + k] - p[k];
+        for (int s = 0; s < 9; ++s) {
+            float gl = corner(s / 3, s % 3) - p[s % 3];
             gl = gl * 1.0f;
-            slot[n] = iv * 3 + k; val[n] = 2 * gp * gl; ++n;
+            g9[s] = s / 3 == iv ? 2 * gp * gl : 0.f;
         }
+        return 7u << (3 * iv);
     }
-    return n;
+    return 0u;
 }
 
 __global__ __launch_bounds__(256) void k_tri_dist_bwd_atomic(const float *__restrict__ pts, const float *__restrict__ face,
@@ -2240,11 +2252,12 @@ __global__ __launch_bounds__(256) void k_tri_dist_bwd_atomic(const float *__rest
 #pragma unroll
     for (int k = 0; k < 9; ++k) fc[k] = src[k];
     const float p[3] = {pts[i * 3], pts[i * 3 + 1], pts[i * 3 + 2]};
-    int slot[9];
-    float val[9];
-    const int n = tri_dist_point_grad(fc, p, dl_dd[i], slot, val);
+    float g9[9];
+    const unsigned touched = tri_dist_point_grad9(fc, p, dl_dd[i], g9);
     float *g = dldface + ((size_t)b * F + fi) * 9;
-    for (int k = 0; k < n; ++k) unsafeAtomicAdd(g + slot[k], val[k]);           // back.cu:640-683
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+        if (touched >> k & 1u) unsafeAtomicAdd(g + k, g9[k]);                   // back.cu:640-683
 }
 
 // The same, walking the points in the FORWARD's order (sorted by grid cell): the 64 points of a wave are neighbours in
@@ -2268,13 +2281,11 @@ __global__ __launch_bounds__(256) void k_tri_dist_bwd_grouped(const float *__res
 #pragma unroll
         for (int k = 0; k < 9; ++k) fc[k] = src[k];
         const float p[3] = {pts[i * 3], pts[i * 3 + 1], pts[i * 3 + 2]};
-        int slotk[9];
-        float val[9];
-        const int n = tri_dist_point_grad(fc, p, dl_dd[i], slotk, val);
-        for (int k = 0; k < n; ++k)
+        float g9[9];
+        const unsigned touched = tri_dist_point_grad9(fc, p, dl_dd[i], g9);
 #pragma unroll
-            for (int s = 0; s < 9; ++s)
-                if (slotk[k] == s) gsum[s] += val[k];
+        for (int s = 0; s < 9; ++s)
+            if (touched >> s & 1u) gsum[s] += g9[s];
     }
     unsigned long long todo = __ballot(fi >= 0);
     while (todo) {
@@ -2334,14 +2345,11 @@ __global__ __launch_bounds__(256) void k_tri_dist_bwd_sorted(const float *__rest
     for (long long y = i; y < n && (skey[y] >> 32) == fkey; ++y) {
         const size_t pi = (size_t)b * P + (size_t)(skey[y] & 0xFFFFFFFFull);
         const float p[3] = {pts[pi * 3], pts[pi * 3 + 1], pts[pi * 3 + 2]};
-        int slot[9];
-        float val[9];
-        const int m = tri_dist_point_grad(fc, p, dl_dd[pi], slot, val);
-        for (int j = 0; j < m; ++j) {
+        float g9[9];
+        const unsigned touched = tri_dist_point_grad9(fc, p, dl_dd[pi], g9);
 #pragma unroll
-            for (int s = 0; s < 9; ++s)
-                if (slot[j] == s) acc[s] += val[j];
-        }
+        for (int s = 0; s < 9; ++s)
+            if (touched >> s & 1u) acc[s] += g9[s];
     }
 #pragma unroll
     for (int j = 0; j < 9; ++j) g[j] = acc[j];
