@@ -406,12 +406,12 @@ __global__ __launch_bounds__(256) void k_pix_raster(const float *__restrict__ pi
     float worstZ = INFINITY;                                        // the record a better hit would replace
     int worstF = -1, worstAt = 0, npend = 0;
     auto worse = [](float za, int fa, float zb, int fb) { return rast_worse(za, fa, zb, fb); };
-    auto work_off = [&]() {
+    auto work_off = [&]() __attribute__((always_inline)) {
         const Worst w = rast_work_off(pend, npend, Worst{worstZ, worstF, worstAt}, hits, p, knum, lane);
         worstZ = w.z; worstF = w.f; worstAt = w.at;
         npend = 0;
     };
-    auto test = [&](int f, float ax, float ay, float m, float pp, float n, float q, float den, float az, float bz, float cz) {
+    auto test = [&](int f, float ax, float ay, float m, float pp, float n, float q, float den, float az, float bz, float cz) __attribute__((always_inline)) {
         if (!nearest && nh >= knum) return;
         const float s_ = px - ax, t = py - ay;
         const float k1 = s_ * q - n * t, k2 = m * t - s_ * pp;
@@ -425,17 +425,23 @@ __global__ __launch_bounds__(256) void k_pix_raster(const float *__restrict__ pi
             return;
         }
         const float z = (w0 * az + w1 * bz) + w2 * cz;
+        // (the two counters advance OUTSIDE the branches: written as ++nh / ++npend inside them the compiler merges the two
+        // increments into one store through a selected address, which puts both counters into scratch memory — a scratch
+        // load, a dependent scratch store and another load with s_waitcnt vmcnt(0) in every iteration of the face loop)
+        int dnh = 0, dnp = 0;
         if ((w0 >= 0 && w1 >= 0 && w2 >= 0) && (z >= zmin && z <= zmax)) {
             const int4 rec = make_int4(f, __float_as_int(z), __float_as_int(w1), __float_as_int(w2));
             if (nh < knum) {
                 out[nh] = rec;
                 if (nh == 0 || worse(z, f, worstZ, worstF)) { worstZ = z; worstF = f; worstAt = nh; }
-                ++nh;
+                dnh = 1;
             } else if (live && knum > 0 && worse(worstZ, worstF, z, f)) {   // full (dead lanes only count as full)
                 pend[npend][lane] = rec;
-                ++npend;
+                dnp = 1;
             }
         }
+        nh += dnh;
+        npend += dnp;
         if (nearest && __any(npend == kPendDepth)) work_off();
     };
     auto face_terms = [&](float2 a, float2 b, float2 c, float &m, float &pp, float &n, float &q, float &den) {
@@ -447,7 +453,7 @@ __global__ __launch_bounds__(256) void k_pix_raster(const float *__restrict__ pi
     const int ib = allFaces ? 0 : tileStart[tile], ie = allFaces ? F : tileStart[tile + 1];
     int j = 0;
     const int je = allFaces ? 0 : *nWide;
-    auto wide_before = [&](int fLimit) {                            // wide faces with index < fLimit (normally none)
+    auto wide_before = [&](int fLimit) __attribute__((always_inline)) {                            // wide faces with index < fLimit (normally none)
         while (j < je) {
             const int f = wide[j];
             if (f >= fLimit) break;
