@@ -8,7 +8,8 @@
 //   scan<T, Op, EXCLUSIVE>(in, out, n, identity, tmp, tmp_bytes, stream)         in == out allowed
 //
 // Sort: 8 bits per pass, (bits + 7) / 8 passes.  Per pass: k_rs_hist (LDS histogram of the digit per 2,048-key tile ->
-// hist[digit][tile]), an exclusive scan of that table (= where the keys of (digit, tile) start), k_rs_scatter.  Sorts of up
+// hist[tile][digit]), an exclusive scan of that table in (digit, tile) order (= where the keys of (digit, tile) start;
+// k_cs_partials / k_cs_spine / k_cs_apply: coalesced rows only), k_rs_scatter.  Sorts of up
 // to kFusedTiles tiles (1 M keys) skip the scan launches: the table is written tile-major and every scatter workgroup sums
 // the rows of the earlier tiles itself (two launches per pass instead of three to five).  The
 // scatter is stable without atomics: a tile is four waves x eight rounds x 64 lanes in key order; per round the lanes
@@ -216,11 +217,12 @@ struct IotaLoad {
 
 // n_dev (may be NULL): the number of elements actually present, known on the device only (n is then the capacity the
 // grid is sized for); workgroups beyond it find nothing to do, so the cost follows the real count.
-// by_tile: the table is hist[tile][digit] (read by the FUSED scatter, which sums the earlier tiles' rows itself) instead of
-// hist[digit][tile] (what the scan of the three-launch form wants)
+// The table is tile-major, hist[tile][digit]: a workgroup writes ONE 1 KB row.  (Rounds 3-4 wrote hist[digit][tile] for a flat
+// scan: 256 four-byte stores per workgroup, each to another line — 2.1 M scattered stores per pass of the 16.8 M-pair sort,
+// which took 50 us to read 67 MB — and the scatter read its 256 offsets back the same way.)
 template <typename K, typename KL>
 __global__ __launch_bounds__(kTileThreads) void k_rs_hist(KL keys, size_t n, int shift, unsigned dmask, unsigned nblk, unsigned *hist,
-                                                          const int *__restrict__ n_dev, int by_tile)
+                                                          const int *__restrict__ n_dev)
 {
     if (n_dev) n = min(n, (size_t)max(*n_dev, 0));
     __shared__ unsigned h[256];
@@ -233,7 +235,89 @@ __global__ __launch_bounds__(kTileThreads) void k_rs_hist(KL keys, size_t n, int
         if (i < n) atomicAdd(&h[(unsigned)(keys(i) >> shift) & dmask], 1u);
     }
     __syncthreads();
-    hist[by_tile ? (size_t)blockIdx.x * 256 + threadIdx.x : (size_t)threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];
+    hist[(size_t)blockIdx.x * 256 + threadIdx.x] = h[threadIdx.x];
+}
+
+// Exclusive scan of the tile-major table in (digit, tile) order — where the keys of (digit, tile) start in the output — with
+// coalesced rows only.  Thread d owns column d everywhere: chunk sums of kColChunk rows, one workgroup that turns the
+// chunk sums into chunk bases (exclusive over the chunks of a digit, plus the exclusive scan of the digits' totals),
+// and the rows of every chunk rewritten as running offsets.
+constexpr unsigned kColChunk = 64;
+static __global__ __launch_bounds__(256) void k_cs_partials(const unsigned *__restrict__ hist, unsigned nblk, unsigned *part)
+{
+    const unsigned t0 = blockIdx.x * kColChunk, t1 = min(nblk, t0 + kColChunk), d = threadIdx.x;
+    unsigned sum = 0u;
+    for (unsigned j0 = t0; j0 < t1; j0 += 16) {
+        unsigned a[16];
+#pragma unroll
+        for (unsigned k = 0; k < 16; ++k) a[k] = hist[(size_t)min(j0 + k, t1 - 1u) * 256 + d];      // clamped, unconditional
+#pragma unroll
+        for (unsigned k = 0; k < 16; ++k) sum += j0 + k < t1 ? a[k] : 0u;
+    }
+    part[(size_t)blockIdx.x * 256 + d] = sum;
+}
+// one workgroup of 1,024 threads: thread (q, d) owns a quarter of the chunks of digit d (reads and writes in batches of 16,
+// all loads of a batch in flight; a plain loop of read-modify-writes over 128 chunks took 14 us)
+static __global__ __launch_bounds__(1024) void k_cs_spine(unsigned *part, unsigned nchunk)
+{
+    __shared__ unsigned qsum[4][256], wtot[4];
+    const unsigned d = threadIdx.x & 255u, q = threadIdx.x >> 8, lane = threadIdx.x & 63u;
+    const unsigned per = (nchunk + 3u) / 4u, c0 = min(nchunk, q * per), c1 = min(nchunk, c0 + per);
+    unsigned total = 0u;
+    for (unsigned j0 = c0; j0 < c1; j0 += 16) {
+        unsigned a[16];
+#pragma unroll
+        for (unsigned k = 0; k < 16; ++k) a[k] = part[(size_t)min(j0 + k, c1 - 1u) * 256 + d];
+#pragma unroll
+        for (unsigned k = 0; k < 16; ++k) total += j0 + k < c1 ? a[k] : 0u;
+    }
+    qsum[q][d] = total;
+    __syncthreads();
+    unsigned before = 0u, dtot = 0u;                                // earlier quarters of this digit; the digit's total
+#pragma unroll
+    for (unsigned k = 0; k < 4; ++k) {
+        const unsigned v = qsum[k][d];
+        before += k < q ? v : 0u;
+        dtot += v;
+    }
+    unsigned incl = dtot;                                           // exclusive scan of the totals over the digits (every quarter
+#pragma unroll                                                      // computes it: waves 0-3 of a quarter hold digits 0-255)
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned t = __shfl_up(incl, off);
+        if (lane >= (unsigned)off) incl += t;
+    }
+    if (q == 0 && lane == 63u) wtot[d >> 6] = incl;
+    __syncthreads();
+    unsigned run = incl - dtot + before;
+    for (unsigned k = 0; k < (d >> 6); ++k) run += wtot[k];
+    for (unsigned j0 = c0; j0 < c1; j0 += 16) {
+        unsigned a[16];
+#pragma unroll
+        for (unsigned k = 0; k < 16; ++k) a[k] = part[(size_t)min(j0 + k, c1 - 1u) * 256 + d];
+#pragma unroll
+        for (unsigned k = 0; k < 16; ++k)
+            if (j0 + k < c1) {
+                part[(size_t)(j0 + k) * 256 + d] = run;             // (own column, own quarter: read above, nobody else touches it)
+                run += a[k];
+            }
+    }
+}
+static __global__ __launch_bounds__(256) void k_cs_apply(const unsigned *__restrict__ hist, unsigned nblk, const unsigned *__restrict__ part,
+                                                  unsigned *offs)
+{
+    const unsigned t0 = blockIdx.x * kColChunk, t1 = min(nblk, t0 + kColChunk), d = threadIdx.x;
+    unsigned run = part[(size_t)blockIdx.x * 256 + d];
+    for (unsigned j0 = t0; j0 < t1; j0 += 16) {
+        unsigned a[16];
+#pragma unroll
+        for (unsigned k = 0; k < 16; ++k) a[k] = hist[(size_t)min(j0 + k, t1 - 1u) * 256 + d];
+#pragma unroll
+        for (unsigned k = 0; k < 16; ++k)
+            if (j0 + k < t1) {
+                offs[(size_t)(j0 + k) * 256 + d] = run;
+                run += a[k];
+            }
+    }
 }
 
 // FUSED is a template argument: the 32 rows its column sums keep in flight are 32 more registers (100 instead of 68), which
@@ -329,7 +413,7 @@ __global__ __launch_bounds__(kTileThreads) void k_rs_scatter(KL kin, K *kout, VL
             for (int k = 0; k < w; ++k) g += wtot2[k];
             gbase[d] = g;
         } else {
-            gbase[d] = offs[(size_t)d * nblk + blockIdx.x];
+            gbase[d] = offs[(size_t)blockIdx.x * 256 + d];           // the column scan's table is tile-major as well
         }
 #pragma unroll
         for (int k = 0; k < kTileThreads / 64; ++k) {
@@ -371,7 +455,7 @@ inline size_t radix_sort_temp_bytes(size_t n, bool has_values = true)
 {
     const size_t nblk = (n + kTile - 1) / kTile;
     return align_up(n * sizeof(K), 256) + (has_values ? align_up(n * sizeof(V), 256) : 0) + 2 * align_up(256 * nblk * 4 + 4, 256) +
-           scan_temp_bytes<unsigned>(256 * nblk) + 256;
+           align_up(256 * ((nblk + kColChunk - 1) / kColChunk + 1) * 4, 256) + 256;
 }
 
 template <typename K, typename V, bool HAS_V, typename KL, typename VL>
@@ -387,8 +471,8 @@ int radix_sort_impl(KL kin, K *kout, VL vin, V *vout, size_t n, int bits, void *
     K *tk = A.take<K>(n);
     V *tv = HAS_V ? A.take<V>(n) : nullptr;
     unsigned *hist = A.take<unsigned>((size_t)256 * nblk + 1), *offs = A.take<unsigned>((size_t)256 * nblk + 1);
-    void *stmp = A.take<char>(scan_temp_bytes<unsigned>((size_t)256 * nblk));
-    const size_t stmp_bytes = scan_temp_bytes<unsigned>((size_t)256 * nblk);
+    const unsigned nchunk = (nblk + kColChunk - 1) / kColChunk;
+    unsigned *part = A.take<unsigned>((size_t)256 * (nchunk + 1));
     const K *sk = nullptr;
     const V *sv = nullptr;
     // sorts of up to kFusedTiles tiles skip the scan: the scatter sums the histogram table itself (see k_rs_scatter)
@@ -399,12 +483,13 @@ int radix_sort_impl(KL kin, K *kout, VL vin, V *vout, size_t n, int bits, void *
         V *dv = to_out ? vout : tv;
         const int left = bits - p * 8;                               // the last digit may be narrower: bits above `bits` do not count
         const unsigned dmask = left >= 8 || bits <= 0 ? 255u : (1u << left) - 1u;
-        if (p == 0) DEFTET_LAUNCH((k_rs_hist<K, KL>), dim3(nblk), dim3(kTileThreads), st, kin, n, 0, dmask, nblk, hist, n_dev, fused);
-        else DEFTET_LAUNCH((k_rs_hist<K, PtrLoad<K>>), dim3(nblk), dim3(kTileThreads), st, PtrLoad<K>{sk}, n, p * 8, dmask, nblk, hist, n_dev, fused);
+        if (p == 0) DEFTET_LAUNCH((k_rs_hist<K, KL>), dim3(nblk), dim3(kTileThreads), st, kin, n, 0, dmask, nblk, hist, n_dev);
+        else DEFTET_LAUNCH((k_rs_hist<K, PtrLoad<K>>), dim3(nblk), dim3(kTileThreads), st, PtrLoad<K>{sk}, n, p * 8, dmask, nblk, hist, n_dev);
         const unsigned *table = hist;
         if (!fused) {
-            const int rc = scan<unsigned, Plus, true>(hist, offs, (size_t)256 * nblk, 0u, Plus(), stmp, stmp_bytes, st);
-            if (rc != DEFTET_OK) return rc;
+            DEFTET_LAUNCH(k_cs_partials, dim3(nchunk), dim3(256), st, (const unsigned *)hist, nblk, part);
+            DEFTET_LAUNCH(k_cs_spine, dim3(1), dim3(1024), st, part, nchunk);
+            DEFTET_LAUNCH(k_cs_apply, dim3(nchunk), dim3(256), st, (const unsigned *)hist, nblk, (const unsigned *)part, offs);
             table = offs;
         }
         if (p == 0 && fused)
