@@ -186,9 +186,13 @@ class DefTet(nn.Module):
     #     batch; only the surface terms loop over shapes (a different predicted surface per shape)
     def forward_surface_align(self, vertice_pos, point_pos_bxpx3, tetrahedron_bxfx4=None, mesh_list=None,
                               gt_surface_points=None, tet_face_bxfx3=None, inference=False, pred_occ=None,
-                              tet_face_tet_bx4fx2=None, save=False, save_name=None, inference_threshold=0.4):
+                              tet_face_tet_bx4fx2=None, save=False, save_name=None, inference_threshold=0.4, tet_bxfx4x3=None):
+        # tet_bxfx4x3 (not in the reference's signature; its `forward` has the same optional argument, deftet.py:140): a
+        # caller that has gathered the tet positions already — e.g. for the occupancy query of the same step — hands them
+        # in instead of having them gathered (and their gradient scattered) a second time
         n_shape = vertice_pos.shape[0]
-        tet_bxfx4x3 = self.gather_tet_pos(vertice_pos, tetrahedron_bxfx4)
+        if tet_bxfx4x3 is None:
+            tet_bxfx4x3 = self.gather_tet_pos(vertice_pos, tetrahedron_bxfx4)
         center_occ = self.check_tet_inside_sdfs(tet_bxfx4x3, mesh_list)                       # [B,T,1], no grad
         face_fx3, face_tet_fx2 = tet_face_bxfx3[0], tet_face_tet_bx4fx2[0]
         boundary = self.get_boundary_index(face_fx3, face_tet_fx2, center_occ.squeeze(dim=-1))

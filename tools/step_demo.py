@@ -76,11 +76,11 @@ def run_full_step(m, pos, idxB, f3, t2, gt_verts, gt_faces, pts, inv_v, pred, gt
     """forward_surface_align (training branch) + occupancy query + backward."""
     B = pos.shape[0]
     m.inverse_v = inv_v
+    tet = m.gather_tet_pos(pos, idxB)                                  # once: the module and the occupancy query share it
     out = m.forward_surface_align(pos, pts, tetrahedron_bxfx4=idxB, mesh_list=([gt_verts[None]] * B, [[gt_faces]] * B),
                                   gt_surface_points=gt_pts, tet_face_bxfx3=f3[None].expand(B, -1, -1),
-                                  tet_face_tet_bx4fx2=t2[None].expand(B, -1, -1))
+                                  tet_face_tet_bx4fx2=t2[None].expand(B, -1, -1), tet_bxfx4x3=tet)
     amips, edge, vvar, analytic, normal, center_occ, boundary, chamfer, _ = out
-    tet = m.gather_tet_pos(pos, idxB)
     cond, w, occ = point_in_tet_occ(tet, pts, pred)
     loss = standin_loss(w, occ, amips, edge, vvar, chamfer, analytic, normal)
     loss.backward()
