@@ -84,6 +84,11 @@ class PitWorkload:
             n = res // 2
             idx = np.arange(n * n * n * 6).reshape(n, n, n, 6)       # [ix, iy, iz, k] -> current position
             tets = tets[idx.transpose(2, 1, 0, 3).reshape(-1)]       # new position ((iz*n + iy)*n + ix)*6 + k
+        if cfg.get("mesh") == "shuffled":                 # probe use: the same grid, its tet list in random order
+            tets = tets[np.random.default_rng(7).permutation(tets.shape[0])]
+        # traversal order handed to the operator: "auto" (what the autograd ops pass: decided once per grid), "native" (none),
+        # "sorted" (the computed column order, unconditionally) — DEFTET_BENCH_TET_ORDER / cfg["tet_order"]; never changes a result
+        self.order_mode = cfg.get("tet_order") or os.environ.get("DEFTET_BENCH_TET_ORDER", "auto")
         self.sets, self.host = [], None
         # N > 1: the sets are generated ON THE GPU (same distributions, torch generators seeded per rank and set): eight
         # ranks x several sets of res-100 numpy jitter + gathers on one host are minutes of CPU before the first step.  N = 1
@@ -132,6 +137,13 @@ class PitWorkload:
         self._side = None
         self._pq = {}
         self.last = None
+        from deftet_amd import hip_ops
+        if self.order_mode == "sorted":
+            self.order = hip_ops.tet_spatial_order(self.sets[0]["tet"][0])
+        elif self.order_mode == "auto":
+            self.order = hip_ops.auto_tet_order(self.sets[0]["tet"])       # resolved here: the steps pass a tensor or None
+        else:
+            self.order = None
 
     def side_stream(self):
         if self._side is None:
@@ -156,7 +168,7 @@ class PitWorkload:
             if pq is None:
                 pq = hip_ops.prepare_queries(d["pts"], self.T, algo=self.algo)
             cond, w, occ, hits = hip_ops.point_in_tet(d["tet"], d["pts"], want_bary=True, pred_bxt=d["pred"], want_hits=True,
-                                                      algo=self.algo, prepared=pq)
+                                                      algo=self.algo, prepared=pq, order=self.order)
             nxt = self.sets[(i + 1) % len(self.sets)]
             # (making the side stream wait for this step's forward, so that the sort overlaps the HBM-bound backward instead
             # of the traversal, was measured: 0.257-0.259 vs 0.247-0.248 ms/step)
@@ -164,7 +176,7 @@ class PitWorkload:
                 self._pq = {i + 1: hip_ops.prepare_queries(nxt["pts"], self.T, algo=self.algo)}
         else:
             cond, w, occ, hits = hip_ops.point_in_tet(d["tet"], d["pts"], want_bary=True, pred_bxt=d["pred"], want_hits=True,
-                                                      algo=self.algo)
+                                                      algo=self.algo, order=self.order)
         g_tet, _, g_pred = hip_ops.point_in_tet_bwd(d["tet"], d["pts"], cond, d["gw"], grad_occ=d["gout"], hits=hits)
         loss = hip_ops.rowdot(w, d["gw"], occ, d["gout"])         # [B] per-shape loss scalars
         if self.world > 1:
@@ -183,6 +195,7 @@ class PitWorkload:
                 "res": self.cfg["res"], "n_tet": self.T, "n_query": self.Q, "batch_per_gpu": self.B, "input_sets": len(self.sets),
                 "sharding": "shapes sharded by rank; all-gather of %d loss scalars" % (self.world * self.B),
                 "inputs_generated_on": self.generated_on,
+                "tet_order": "%s -> %s" % (self.order_mode, "the caller's numbering" if self.order is None else "computed column order"),
                 "pipelining": ("query sort of step i+1 enqueued on a second stream during step i" if self.pipeline else "none")}
 
 
@@ -364,7 +377,7 @@ def brute_force_comparator(wl, step_ms):
     b.record()
     torch.cuda.synchronize()
     ms = a.elapsed_time(b)
-    same = bool(torch.equal(ref, hip_ops.point_in_tet(d["tet"], d["pts"], algo=wl.algo)))
+    same = bool(torch.equal(ref, hip_ops.point_in_tet(d["tet"], d["pts"], algo=wl.algo, order=wl.order)))
     return {"kernel": "k_brute", "ms_fwd_batch": round(ms, 2), "M_tests_per_s_fwd": round(wl.pairs_per_step / (ms * 1e-3) / 1e6, 1),
             "speedup_of_binned_fwd_bwd_step_over_brute_fwd": round(ms / step_ms, 1), "same_result_as_binned": same,
             "how": "DEFTET_PIT_BRUTE forward on input set 0 (all %d shapes) after the timed region, one launch sequence, HIP events; "
@@ -418,12 +431,31 @@ def cpu_baseline(wl):
     t1 = time.perf_counter() - t0
     qn = min(wl.Q, max(2000, 1200 * ncpu))
     t0 = time.perf_counter()
-    _, nthreads = O.point_in_tet(tet, pts[:1, :qn], omp=True, return_executed=True)
+    cond, nthreads = O.point_in_tet(tet, pts[:1, :qn], omp=True, return_executed=True)
     tn = time.perf_counter() - t0
     T = tet.shape[1]
+    # the backward half of the metric on the same sample: weights (oracle_bary_f32) + dL/dtet (oracle_bary_bwd_f32, a plain
+    # scatter-add), single-threaded as written — next to the all-pairs scan they are noise, which is the point of quoting them
+    gw = np.random.default_rng(4000).standard_normal((1, qn, 4)).astype(np.float32)
+    t0 = time.perf_counter()
+    O.bary(tet, pts[:1, :qn], cond)
+    O.bary_bwd(tet, pts[:1, :qn], cond, gw)
+    tb = time.perf_counter() - t0
+    model = "?"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     return {
         "value": round(T * qn / tn / 1e6, 2), "unit": "M tet-point tests/s (fwd only)", "cores": int(nthreads),
-        "kind": "port",
+        "kind": "port", "covers": "fwd",
+        "covers_note": "the reference's own autograd backward for this op returns (None, None) "
+                       "(check_condition_tetrahedron_base/utils.py:55-58); value_fwd_bwd adds this build's A1b backward on the CPU",
+        "value_fwd_bwd": round(T * qn / (tn + tb) / 1e6, 2), "bwd_seconds_on_sample": round(tb, 4), "fwd_seconds_on_sample": round(tn, 3),
+        "cpu_model": model, "nproc": ncpu,
         "sample": "oracle/deftet_oracle.c brute-force scan, 1 shape res=%d (T=%d), first %d queries, OpenMP over "
                   "queries; single-core on %d queries: %.2f M/s" % (wl.cfg["res"], T, qn, q1, T * q1 / t1 / 1e6),
         "value_1core": round(T * q1 / t1 / 1e6, 2),

@@ -54,14 +54,31 @@ def objdir():
     global _OBJDIR
     if _OBJDIR:
         return _OBJDIR
-    path = os.environ.get("DEFTET_BUILD_CACHE") or os.path.join(tempfile.gettempdir(), "deftet_amd_build_%d" % os.getuid())
+    explicit = os.environ.get("DEFTET_BUILD_CACHE")
+    path = explicit or os.path.join(tempfile.gettempdir(), "deftet_amd_build_%d" % os.getuid())
+    why = None
     try:
         os.makedirs(path, mode=0o700, exist_ok=True)
         st = os.lstat(path)
-        ok = stat.S_ISDIR(st.st_mode) and st.st_uid == os.getuid() and not (st.st_mode & (stat.S_IWGRP | stat.S_IWOTH))
-    except OSError:
-        ok = False
-    _OBJDIR = path if ok else tempfile.mkdtemp(prefix="deftet_amd_build_")
+        if not stat.S_ISDIR(st.st_mode):
+            why = "it is not a real directory"
+        elif st.st_uid != os.getuid():
+            why = "it belongs to uid %d" % st.st_uid
+        elif st.st_mode & (stat.S_IWGRP | stat.S_IWOTH):
+            why = "it is writable by group / others (mode %o)" % stat.S_IMODE(st.st_mode)
+    except OSError as e:
+        why = "it cannot be created or read (%s)" % e
+    if why is None:
+        _OBJDIR = path
+        return _OBJDIR
+    if explicit:                                              # set on purpose: say so instead of silently recompiling every run
+        raise RuntimeError("DEFTET_BUILD_CACHE=%s is not usable as the object cache: %s" % (path, why))
+    import atexit
+    import shutil
+    _OBJDIR = tempfile.mkdtemp(prefix="deftet_amd_build_")
+    atexit.register(shutil.rmtree, _OBJDIR, True)             # one-run cache: removed with the process (objects, link lock)
+    print("deftet_amd.build: object cache %s rejected (%s); using a private directory for this run only (full recompile): %s"
+          % (path, why, _OBJDIR), file=sys.stderr, flush=True)
     return _OBJDIR
 
 

@@ -74,6 +74,17 @@ int ticket_slot_for_stream(hipStream_t st, int n_slots)
     static std::vector<Key> keys;                             // index = slot
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return -1;
+    // A launch that is being CAPTURED into a hipGraph is not ordered by the stream it was captured on: two graphs captured on
+    // one stream may be replayed concurrently on different streams and would then share that stream's counters (a row sum
+    // corrupted, an output left unwritten).  Captured launches therefore take the counter-free multi-launch form.
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess) {
+        (void)hipGetLastError();                                  // (not this launch's error: keep it out of the launch check)
+        return -1;
+    }
+    if (cap != hipStreamCaptureStatusNone) return -1;
+    // Slots are never recycled (a stream handle cannot be observed dying): after n_slots distinct (device, stream) pairs of a
+    // process every further stream gets -1 for good, i.e. the multi-launch form — slower by one launch, never wrong.
     std::lock_guard<std::mutex> lk(mu);
     for (size_t i = 0; i < keys.size(); ++i)
         if (keys[i].dev == dev && keys[i].st == st) return (int)i;

@@ -985,11 +985,16 @@ __device__ __forceinline__ void irregular_tail(const float *__restrict__ tet, in
 #if PIT_BATCH < 1 || PIT_BATCH > 4
 #error "PIT_BATCH must be 1..4 (a wave-iteration may add at most four acceptances to the four-deep hit register)"
 #endif
+// ORD: the lane at position p of the launch works on tet order[p] (a permutation of [0, T) shared by the shapes of the batch,
+// deftet_tet_spatial_order_f32) and publishes / records under that ORIGINAL index, so every output is the same as without
+// the permutation; a template argument, so that the unordered instance is the round-4 kernel unchanged.
+template <bool ORD>
 __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan_slab(const float *__restrict__ tet, int T, int Q,
                                                   const float *__restrict__ gparam, int G, int Gx, const int *__restrict__ table,
                                                   long long cellStride, const float4 *__restrict__ sortedQ, int *result, int *counters,
                                                   int *irregT, int4 *hits, const float *__restrict__ pts,
-                                                  const int *__restrict__ irregQ, int *ucount, int hpad, int4 *spill)
+                                                  const int *__restrict__ irregQ, int *ucount, int hpad, int4 *spill,
+                                                  const int *__restrict__ order)
 {
     // per-shape words of the hit buffer: uncovered-hit counter (k_finalize appends), backward ticket, irregular-query flag.
     // (hpad is an argument: deriving it from gridDim.y here made the compiler fetch the dispatch packet with vector loads:
@@ -1004,8 +1009,9 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan_slab(const float *_
     const int nblk = gridDim.x;
     const int per = (nblk + 7) >> 3;
     const int vb = (blockIdx.x & 7) * per + (blockIdx.x >> 3);        // XCD-aware mapping, see k_tet_scan
-    const int t = vb * blockDim.x + threadIdx.x;
-    if (vb >= nblk || t >= T) return;
+    const int pos = vb * blockDim.x + threadIdx.x;
+    if (vb >= nblk || pos >= T) return;
+    const int t = ORD ? order[pos] : pos;
     PHASE_DECL;
     float v[12];
     {
@@ -1427,11 +1433,13 @@ __device__ __noinline__ int exact_rescan_slots(const float *__restrict__ tv, int
     return hcnt;
 }
 
+template <bool ORD>                                                    // see k_tet_scan_slab
 __global__ __launch_bounds__(256, PIT_WAVES2) void k_tet_scan_wave(const float *__restrict__ tet, int T, int Q,
                                                   const float *__restrict__ gparam, int G, int Gx, const int *__restrict__ table,
                                                   long long cellStride, const float4 *__restrict__ sortedQ, int *result, int *counters,
                                                   int *irregT, int4 *hits, const float *__restrict__ pts,
-                                                  const int *__restrict__ irregQ, int *ucount, int hpad, int4 *spill)
+                                                  const int *__restrict__ irregQ, int *ucount, int hpad, int4 *spill,
+                                                  const int *__restrict__ order)
 {
     __shared__ WaveStage s_w[4];
     __shared__ int s_hit[kWvSlots + 2][256];                           // [slot][thread]; the last two rows swallow the overflow
@@ -1445,13 +1453,15 @@ __global__ __launch_bounds__(256, PIT_WAVES2) void k_tet_scan_wave(const float *
     const int nblk = gridDim.x;
     const int per = (nblk + 7) >> 3;
     const int vb = (blockIdx.x & 7) * per + (blockIdx.x >> 3);        // XCD-aware mapping, see k_tet_scan
-    const int t = vb * blockDim.x + tid;
+    const int t = vb * blockDim.x + tid;                                // position in the launch; the tet is tet_id()
     const bool valid = vb < nblk && t < T;
     if (__builtin_amdgcn_ballot_w64(valid) == 0ull) return;           // (every other lane stays: the wave works together)
+    // (ORD: re-read where it is needed instead of kept in a register across the staged loop)
+    auto tet_id = [&]() -> int { return ORD ? order[valid ? t : T - 1] : t; };
     PHASE_DECL;
     float v[12];
     {
-        const float4 *src = reinterpret_cast<const float4 *>(tet + ((size_t)b * T + (valid ? t : T - 1)) * 12);
+        const float4 *src = reinterpret_cast<const float4 *>(tet + ((size_t)b * T + (valid ? tet_id() : T - 1)) * 12);
         float4 a = src[0], bq = src[1], c = src[2];
         v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
         v[4] = bq.x; v[5] = bq.y; v[6] = bq.z; v[7] = bq.w;
@@ -1763,7 +1773,7 @@ __global__ __launch_bounds__(256, PIT_WAVES2) void k_tet_scan_wave(const float *
         CellBox cb;
         {
             float tv[12], mrg2;
-            const float *src = tet + ((size_t)b * T + t) * 12;
+            const float *src = tet + ((size_t)b * T + tet_id()) * 12;
 #pragma unroll
             for (int k = 0; k < 12; ++k) tv[k] = src[k];
             tet_cell_box(tv, g, G, Gx, cb, mrg2);
@@ -1811,7 +1821,7 @@ __global__ __launch_bounds__(256, PIT_WAVES2) void k_tet_scan_wave(const float *
     if (!valid) return;
     // (the addresses of this lane's tet, record, ... are formed from `te` HERE: hoisted to the top of the kernel they are
     // six more live registers across the staged loop — the difference between five and six waves per SIMD)
-    int te = t;
+    int te = tet_id();
     asm volatile("" : "+v"(te));
     if (!regular) {                                                      // (out-of-line call placed where almost nothing is live)
         irregular_tet_slow(tet, te, b, T, Q, pts, counters, irregT, irregQ, result, hits);
@@ -2684,7 +2694,7 @@ static int pit_prepare(const Layout &L, const float *pts, int B, int Q, hipStrea
 
 // tet side: traversal + finalize; consumes the prepared state (result sentinels, counters)
 static int pit_scan(const Layout &L, const float *tet, const float *pts, float *cond, float *bary, const float *pred, float *occ,
-                    int32_t *hit_buf, int B, int T, int Q, int algo, hipStream_t st)
+                    int32_t *hit_buf, int B, int T, int Q, int algo, hipStream_t st, const int32_t *order = nullptr)
 {
     const dim3 blk(256);
     const dim3 gq((Q + 255) / 256, B), gt((((T + 255) / 256 + 7) / 8) * 8, B);   // gt: multiple of 8 for the XCD mapping
@@ -2693,14 +2703,16 @@ static int pit_scan(const Layout &L, const float *tet, const float *pts, float *
         if (algo == DEFTET_PIT_EXACT) {
             DEFTET_LAUNCH(k_tet_scan, gt, blk, st, tet, T, Q, L.gparam, L.G, L.Gx, L.table, L.cellStride, L.sortedQ, L.result,
                           L.counters, L.irregT, (int4 *)hit_buf, pts, L.irregQ, ucount, hit_pad(B));
-        } else if (resolve_auto(algo, T, Q) == DEFTET_PIT_SLAB) {
-            DEFTET_LAUNCH(k_tet_scan_slab, gt, blk, st, tet, T, Q, L.gparam, L.G, L.Gx, L.table, L.cellStride, L.sortedQ, L.result,
-                          L.counters, L.irregT, (int4 *)hit_buf, pts, L.irregQ, ucount, hit_pad(B),
-                          hit_buf ? (int4 *)(hit_buf + hit_spill_off(B, T, Q)) : (int4 *)nullptr);
         } else {
-            DEFTET_LAUNCH(k_tet_scan_wave, gt, blk, st, tet, T, Q, L.gparam, L.G, L.Gx, L.table, L.cellStride, L.sortedQ, L.result,
-                          L.counters, L.irregT, (int4 *)hit_buf, pts, L.irregQ, ucount, hit_pad(B),
-                          hit_buf ? (int4 *)(hit_buf + hit_spill_off(B, T, Q)) : (int4 *)nullptr);
+            int4 *spill = hit_buf ? (int4 *)(hit_buf + hit_spill_off(B, T, Q)) : (int4 *)nullptr;
+            const bool slab = resolve_auto(algo, T, Q) == DEFTET_PIT_SLAB;
+#define PIT_SCAN_ARGS tet, T, Q, L.gparam, L.G, L.Gx, L.table, L.cellStride, L.sortedQ, L.result, L.counters, L.irregT, (int4 *)hit_buf, pts, \
+                      L.irregQ, ucount, hit_pad(B), spill, (const int *)order
+            if (slab && order) DEFTET_LAUNCH(k_tet_scan_slab<true>, gt, blk, st, PIT_SCAN_ARGS);
+            else if (slab) DEFTET_LAUNCH(k_tet_scan_slab<false>, gt, blk, st, PIT_SCAN_ARGS);
+            else if (order) DEFTET_LAUNCH(k_tet_scan_wave<true>, gt, blk, st, PIT_SCAN_ARGS);
+            else DEFTET_LAUNCH(k_tet_scan_wave<false>, gt, blk, st, PIT_SCAN_ARGS);
+#undef PIT_SCAN_ARGS
         }
     } else if (ucount) {
         DEFTET_HIP(hipMemsetAsync(ucount, 0, (size_t)3 * hit_pad(B) * 4, st));
@@ -2710,9 +2722,8 @@ static int pit_scan(const Layout &L, const float *tet, const float *pts, float *
     return DEFTET_OK;
 }
 
-extern "C" int deftet_point_in_tet_f32(const float *tet, const float *pts, float *cond, float *bary, const float *pred,
-                                       float *occ, int32_t *hit_buf, int B, int T, int Q, int algo, void *workspace,
-                                       size_t workspace_bytes, void *stream_)
+static int pit_forward(const float *tet, const float *pts, float *cond, float *bary, const float *pred, float *occ, int32_t *hit_buf,
+                       int B, int T, int Q, int algo, void *workspace, size_t workspace_bytes, void *stream_, const int32_t *order)
 {
     int rc = pit_check(tet, pts, cond, bary, pred, occ, hit_buf, B, T, Q, algo, workspace);
     if (rc != DEFTET_OK || B == 0 || Q == 0) return rc;
@@ -2732,7 +2743,24 @@ extern "C" int deftet_point_in_tet_f32(const float *tet, const float *pts, float
     }
     rc = pit_prepare(L, pts, B, Q, st);
     if (rc != DEFTET_OK) return rc;
-    return pit_scan(L, tet, pts, cond, bary, pred, occ, hit_buf, B, T, Q, algo, st);
+    return pit_scan(L, tet, pts, cond, bary, pred, occ, hit_buf, B, T, Q, algo, st, order);
+}
+
+extern "C" int deftet_point_in_tet_f32(const float *tet, const float *pts, float *cond, float *bary, const float *pred,
+                                       float *occ, int32_t *hit_buf, int B, int T, int Q, int algo, void *workspace,
+                                       size_t workspace_bytes, void *stream_)
+{
+    return pit_forward(tet, pts, cond, bary, pred, occ, hit_buf, B, T, Q, algo, workspace, workspace_bytes, stream_, nullptr);
+}
+
+// The same with a traversal order (int32 [T] on the device, a permutation of [0, T) — deftet_tet_spatial_order_f32 — shared by
+// the shapes of the batch; NULL = the caller's own order).  Outputs are identical with and without it: the filter kernels
+// (DEFTET_PIT_AUTO / _SLAB / _WAVE) walk the tets in that order and publish the original indices; the other ids ignore it.
+extern "C" int deftet_point_in_tet_ordered_f32(const float *tet, const float *pts, float *cond, float *bary, const float *pred,
+                                               float *occ, int32_t *hit_buf, int B, int T, int Q, int algo, const int32_t *tet_order,
+                                               void *workspace, size_t workspace_bytes, void *stream_)
+{
+    return pit_forward(tet, pts, cond, bary, pred, occ, hit_buf, B, T, Q, algo, workspace, workspace_bytes, stream_, tet_order);
 }
 
 // The same operator in two calls: the QUERY side (bounding box + counting sort: depends on pts and on
@@ -2754,16 +2782,29 @@ extern "C" int deftet_point_in_tet_prepare_f32(const float *pts, int B, int T, i
     return pit_prepare(L, pts, B, Q, as_stream(stream_));
 }
 
-extern "C" int deftet_point_in_tet_scan_f32(const float *tet, const float *pts, float *cond, float *bary, const float *pred,
-                                            float *occ, int32_t *hit_buf, int B, int T, int Q, int algo, void *workspace,
-                                            size_t workspace_bytes, void *stream_)
+static int pit_scan_entry(const float *tet, const float *pts, float *cond, float *bary, const float *pred, float *occ, int32_t *hit_buf,
+                          int B, int T, int Q, int algo, void *workspace, size_t workspace_bytes, void *stream_, const int32_t *order)
 {
     DEFTET_CHECK_ARG(algo != DEFTET_PIT_BRUTE, "scan needs a binned algo");
     int rc = pit_check(tet, pts, cond, bary, pred, occ, hit_buf, B, T, Q, algo, workspace);
     if (rc != DEFTET_OK || B == 0 || Q == 0) return rc;
     Layout L = make_layout(B, T, Q, algo, workspace, workspace_bytes);
     DEFTET_CHECK_ARG(L.bytes <= workspace_bytes, "workspace too small: need %zu bytes, got %zu", L.bytes, workspace_bytes);
-    return pit_scan(L, tet, pts, cond, bary, pred, occ, hit_buf, B, T, Q, algo, as_stream(stream_));
+    return pit_scan(L, tet, pts, cond, bary, pred, occ, hit_buf, B, T, Q, algo, as_stream(stream_), order);
+}
+
+extern "C" int deftet_point_in_tet_scan_f32(const float *tet, const float *pts, float *cond, float *bary, const float *pred,
+                                            float *occ, int32_t *hit_buf, int B, int T, int Q, int algo, void *workspace,
+                                            size_t workspace_bytes, void *stream_)
+{
+    return pit_scan_entry(tet, pts, cond, bary, pred, occ, hit_buf, B, T, Q, algo, workspace, workspace_bytes, stream_, nullptr);
+}
+
+extern "C" int deftet_point_in_tet_scan_ordered_f32(const float *tet, const float *pts, float *cond, float *bary, const float *pred,
+                                                    float *occ, int32_t *hit_buf, int B, int T, int Q, int algo,
+                                                    const int32_t *tet_order, void *workspace, size_t workspace_bytes, void *stream_)
+{
+    return pit_scan_entry(tet, pts, cond, bary, pred, occ, hit_buf, B, T, Q, algo, workspace, workspace_bytes, stream_, tet_order);
 }
 
 // Diagnostics: copies the 8 int32 words per shape that the last forward on this workspace left behind —

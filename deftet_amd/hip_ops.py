@@ -15,10 +15,13 @@ PIT_AUTO, PIT_BRUTE, PIT_EXACT, PIT_SLAB, PIT_WAVE = 0, 1, 2, 3, 4        # incl
 _PIT_KERNEL = {PIT_WAVE: "k_tet_scan_wave", PIT_EXACT: "k_tet_scan", PIT_BRUTE: "k_brute", PIT_SLAB: "k_tet_scan_slab"}
 
 
-def pit_kernel_name(algo=PIT_AUTO, n_tet=257250, n_query=100000):
-    """Name of the traversal kernel an `algo` value launches (what deftet_profile_select / rocprofv3 show); PIT_AUTO
-    depends on the problem size (default: BASELINE configs[2])."""
-    return _PIT_KERNEL[int(_lib.load().deftet_point_in_tet_resolve_algo(int(algo), int(n_tet), int(n_query)))]
+def pit_kernel_name(algo, n_tet=None, n_query=None):
+    """Name of the traversal kernel an `algo` value launches (what deftet_profile_select / rocprofv3 show).  PIT_AUTO depends
+    on the problem size, so n_tet and n_query are required for it (no silent default: a wrong guess selects a kernel that
+    never runs, and deftet_profile_read then returns zero samples)."""
+    if int(algo) == PIT_AUTO and (n_tet is None or n_query is None):
+        raise ValueError("pit_kernel_name(PIT_AUTO, ...) needs n_tet and n_query: the kernel AUTO runs depends on them")
+    return _PIT_KERNEL[int(_lib.load().deftet_point_in_tet_resolve_algo(int(algo), int(n_tet or 0), int(n_query or 0)))]
 
 
 def _f32c(t):
@@ -65,12 +68,66 @@ def prepare_queries(pts_bxqx3, n_tet, algo=PIT_AUTO):
     return pq
 
 
-def point_in_tet(tet_bxtx4x3, pts_bxqx3, want_bary=False, algo=PIT_AUTO, pred_bxt=None, want_hits=False, prepared=None):
+def tet_spatial_order(tet_tx4x3, want_breaks=False):
+    """int32 [T] permutation that walks the tets of ONE shape column by column ((x, y) columns one mean tet extent wide,
+    ascending z inside a column): the traversal order deftet_point_in_tet_ordered_f32 takes.  Static topology => computed once
+    (from any positions of the grid) and reused for every step and every shape of a batch.  want_breaks also returns the
+    int32 [2] device tensor (breaks of the caller's order, breaks of the computed one) the C entry point describes."""
+    _lib.require_gpu(tet_tx4x3)
+    lib = _lib.load()
+    tet = _f32c(tet_tx4x3)
+    if tet.dim() != 3 or tet.shape[1:] != (4, 3):
+        raise RuntimeError("tet_tx4x3 must be [T,4,3] (one shape), got %s" % (tuple(tet.shape),))
+    T, dev = tet.shape[0], tet.device
+    order = torch.empty(T, device=dev, dtype=torch.int32)
+    breaks = torch.zeros(2, device=dev, dtype=torch.int32)
+    with torch.cuda.device(dev):
+        ws = _lib.workspace(dev, max(lib.deftet_tet_spatial_order_workspace_bytes(T), 256))
+        _lib.check(lib.deftet_tet_spatial_order_f32(_lib.ptr(tet), T, _lib.ptr(order), _lib.ptr(breaks), _lib.ptr(ws), ws.numel(),
+                                                    _lib.current_stream(dev)), "deftet_tet_spatial_order_f32")
+    return (order, breaks) if want_breaks else order
+
+
+# Traversal orders chosen automatically, one per (device, number of tets): decided at the first call from the positions it was
+# handed (one host read of two integers), then reused — the topology of a DefTet grid is static, and the order is a matter of
+# speed only, so a stale or unlucky choice can never change a result.  DEFTET_PIT_ORDER=off|force overrides the decision.
+_order_cache = {}
+_order_lock = __import__("threading").Lock()
+
+
+def auto_tet_order(tet_bxtx4x3):
+    """The cached traversal order for this grid, or None when its own numbering is coherent enough (or the grid is tiny)."""
+    import os
+    mode = os.environ.get("DEFTET_PIT_ORDER", "auto")
+    T, dev = tet_bxtx4x3.shape[1], tet_bxtx4x3.device
+    if mode == "off" or T < 4096:
+        return None
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), T)
+    with _order_lock:
+        if key in _order_cache:
+            return _order_cache[key]
+    order, breaks = tet_spatial_order(tet_bxtx4x3[0], want_breaks=True)
+    native, sorted_ = (int(x) for x in breaks.tolist())              # one-time synchronisation per topology
+    # the caller's numbering is kept unless it breaks runs clearly more often than the column order does (a group of 64 tets
+    # that changes column once or twice is what the kernel is built for: T / 64 groups, a quarter of a break each, is noise)
+    use = mode == "force" or native > 2 * sorted_ + T // 256
+    with _order_lock:
+        _order_cache[key] = order if use else None
+    return _order_cache[key]
+
+
+def clear_tet_order_cache():
+    with _order_lock:
+        _order_cache.clear()
+
+
+def point_in_tet(tet_bxtx4x3, pts_bxqx3, want_bary=False, algo=PIT_AUTO, pred_bxt=None, want_hits=False, prepared=None, order=None):
     """cond f32 [B,Q,1] (lowest containing tet index or -1); with want_bary also the barycentric
     weights f32 [B,Q,4] of the hit tet; with pred_bxt also occ f32 [B,Q] = the fused
     DefTet.paste_occ gather pred[b, max(index, 0)].  Returns cond | (cond, bary) | (cond, bary, occ)
     | (cond, occ) depending on what was asked for; want_hits appends the opaque int32 hit-record
-    buffer that makes point_in_tet_bwd atomic-free."""
+    buffer that makes point_in_tet_bwd atomic-free.  order: None (the caller's tet numbering), an int32 [T] permutation from
+    tet_spatial_order, or "auto" (auto_tet_order: decided once per grid size and device); never changes a result."""
     _lib.require_gpu(tet_bxtx4x3, pts_bxqx3, pred_bxt)
     lib = _lib.load()
     tet, pts = _f32c(tet_bxtx4x3), _f32c(pts_bxqx3)
@@ -89,6 +146,14 @@ def point_in_tet(tet_bxtx4x3, pts_bxqx3, want_bary=False, algo=PIT_AUTO, pred_bx
     hits = None
     if want_hits and algo != PIT_BRUTE:
         hits = torch.empty(max(lib.deftet_point_in_tet_hits_ints(B, T, Q), 4), device=dev, dtype=torch.int32)
+    if isinstance(order, str):
+        if order != "auto":
+            raise RuntimeError("order must be None, 'auto' or an int32 [T] permutation")
+        order = auto_tet_order(tet) if (B > 0 and algo in (PIT_AUTO, PIT_SLAB, PIT_WAVE)) else None
+    if order is not None:
+        _lib.require_gpu(order)
+        if order.dtype != torch.int32 or order.shape != (T,) or not order.is_contiguous() or order.device != dev:
+            raise RuntimeError("order must be a contiguous int32 [T] tensor on the tets' device")
     with torch.cuda.device(dev):
         if prepared is not None:
             if prepared.consumed or prepared.algo != algo or prepared.n_tet != T or prepared.pts.data_ptr() != pts.data_ptr() \
@@ -101,15 +166,15 @@ def point_in_tet(tet_bxtx4x3, pts_bxqx3, want_bary=False, algo=PIT_AUTO, pred_bx
             ws = prepared.workspace
             ws.record_stream(cur)
             prepared.consumed = True
-            _lib.check(lib.deftet_point_in_tet_scan_f32(_lib.ptr(tet), _lib.ptr(pts), _lib.ptr(cond), _lib.ptr(bary), _lib.ptr(pred),
-                                                        _lib.ptr(occ), _lib.ptr(hits), B, T, Q, algo, _lib.ptr(ws), ws.numel(),
-                                                        _lib.current_stream(dev)), "deftet_point_in_tet_scan_f32")
+            _lib.check(lib.deftet_point_in_tet_scan_ordered_f32(_lib.ptr(tet), _lib.ptr(pts), _lib.ptr(cond), _lib.ptr(bary), _lib.ptr(pred),
+                                                                _lib.ptr(occ), _lib.ptr(hits), B, T, Q, algo, _lib.ptr(order), _lib.ptr(ws),
+                                                                ws.numel(), _lib.current_stream(dev)), "deftet_point_in_tet_scan_ordered_f32")
         else:
             nbytes = lib.deftet_point_in_tet_workspace_bytes(B, T, Q, algo)
             ws = _lib.workspace(dev, nbytes)
-            _lib.check(lib.deftet_point_in_tet_f32(_lib.ptr(tet), _lib.ptr(pts), _lib.ptr(cond), _lib.ptr(bary), _lib.ptr(pred),
-                                                   _lib.ptr(occ), _lib.ptr(hits), B, T, Q, algo, _lib.ptr(ws), ws.numel(),
-                                                   _lib.current_stream(dev)), "deftet_point_in_tet_f32")
+            _lib.check(lib.deftet_point_in_tet_ordered_f32(_lib.ptr(tet), _lib.ptr(pts), _lib.ptr(cond), _lib.ptr(bary), _lib.ptr(pred),
+                                                           _lib.ptr(occ), _lib.ptr(hits), B, T, Q, algo, _lib.ptr(order), _lib.ptr(ws),
+                                                           ws.numel(), _lib.current_stream(dev)), "deftet_point_in_tet_ordered_f32")
     out = (cond,) + ((bary,) if want_bary else ()) + ((occ,) if pred is not None else ()) + ((hits,) if want_hits else ())
     return out if len(out) > 1 else cond
 

@@ -94,6 +94,27 @@ int deftet_point_in_tet_scan_f32(const float *tet, const float *pts, float *cond
                                  int n_batch, int n_tet, int n_query, int algo,
                                  void *workspace, size_t workspace_bytes, void *stream);
 
+/* Traversal order (no reference counterpart: the reference scans all tets for every query, in index order).
+ * The filter kernels stage the candidates of 64 CONSECUTIVE tets, so their speed — never their result — depends on how
+ * coherently the caller's tet list is numbered.  The topology of a DefTet grid is static (layers/DefTet/deftet.py:65-68), so
+ * a caller computes ONCE, from any positions of one shape, a permutation that walks the tets column by column
+ * (deftet_tet_spatial_order_f32: tet f32 [T,4,3] -> order int32 [T]; breaks int32 [2] on the device, may be NULL, receives
+ * how often the column changes or z jumps inside a group of 64 consecutive tets of the caller's order ([0]) and of the
+ * computed one ([1]) — when [0] is not much larger than [1] the list is coherent as it is and NULL should be passed on) and
+ * hands it to the *_ordered_* variants below.  Every output (cond, bary, occ, hit_buf) is identical with and without it:
+ * "lowest tet index" (check_condition_tet_for.cu:176-178) is decided on the original indices. */
+size_t deftet_tet_spatial_order_workspace_bytes(int n_tet);
+int deftet_tet_spatial_order_f32(const float *tet, int n_tet, int32_t *order, int32_t *breaks,
+                                 void *workspace, size_t workspace_bytes, void *stream);
+int deftet_point_in_tet_ordered_f32(const float *tet, const float *pts, float *cond, float *bary,
+                                    const float *pred, float *occ, int32_t *hit_buf,
+                                    int n_batch, int n_tet, int n_query, int algo, const int32_t *tet_order,
+                                    void *workspace, size_t workspace_bytes, void *stream);
+int deftet_point_in_tet_scan_ordered_f32(const float *tet, const float *pts, float *cond, float *bary,
+                                         const float *pred, float *occ, int32_t *hit_buf,
+                                         int n_batch, int n_tet, int n_query, int algo, const int32_t *tet_order,
+                                         void *workspace, size_t workspace_bytes, void *stream);
+
 /* A1b  backward of the weights (the reference's own backward,
  * check_condition_tetrahedron_base/utils.py:55-58, returns None).
  * grad_w f32 [B,Q,4] -> grad_tet f32 [B,T,4,3] = d(sum grad_w*w)/d tet; grad_pts f32 [B,Q,3]

@@ -183,6 +183,51 @@ void oracle_bary_f32(const float *tet_bxtx4x3, const float *pts_bxqx3, const flo
 }
 
 /* ------------------------------------------------------------------------------------
+ * A1b backward, plain C (bench.py's CPU fwd+bwd figure; checked against the torch-autograd oracle in
+ * tests/test_cpu_oracle_golden.py).  The weights of utils/tet_utils.py:28-45 are affine in p, w_i(p) = s_i . (p - base_i) / v,
+ * with gradients  grad_p w_a = (vbd x vbc)/v, w_b: (vac x vad)/v, w_c: (vad x vab)/v, w_d: (vab x vac)/v;  from
+ * p = sum_i w_i v_i, sum_i w_i = 1:   dL/dv_k = -w_k G,  G = sum_i g_i grad_p w_i.   A scatter-add in query order.
+ * grad_tet must be zeroed by the caller.  Misses (cond < 0) contribute nothing.
+ * ---------------------------------------------------------------------------------- */
+static void cross3(const float *b, const float *c, float *x)
+{
+    x[0] = b[1] * c[2] - b[2] * c[1];
+    x[1] = b[2] * c[0] - b[0] * c[2];
+    x[2] = b[0] * c[1] - b[1] * c[0];
+}
+
+void oracle_bary_bwd_f32(const float *tet_bxtx4x3, const float *pts_bxqx3, const float *cond_bxq, const float *grad_w_bxqx4,
+                         float *grad_tet_bxtx4x3, int n_batch, int n_tet, int n_query)
+{
+    for (long long i = 0; i < (long long)n_batch * n_query; ++i) {
+        int b = (int)(i / n_query);
+        int t = (int)cond_bxq[i];
+        if (t < 0) continue;
+        const float *A = tet_bxtx4x3 + ((size_t)b * n_tet + t) * 12, *B = A + 3, *C = A + 6, *D = A + 9;
+        const float *p = pts_bxqx3 + i * 3, *g = grad_w_bxqx4 + i * 4;
+        float vap[3], vbp[3], vab[3], vac[3], vad[3], vbc[3], vbd[3];
+        for (int k = 0; k < 3; ++k) {
+            vap[k] = p[k] - A[k]; vbp[k] = p[k] - B[k];
+            vab[k] = B[k] - A[k]; vac[k] = C[k] - A[k]; vad[k] = D[k] - A[k];
+            vbc[k] = C[k] - B[k]; vbd[k] = D[k] - B[k];
+        }
+        float na[3], nb[3], nc[3], nd[3];
+        cross3(vbd, vbc, na); cross3(vac, vad, nb); cross3(vad, vab, nc); cross3(vab, vac, nd);
+        float v6 = 1.0f / ((vab[0] * nb[0] + vab[1] * nb[1]) + vab[2] * nb[2]);      /* triple(vab, vac, vad) */
+        float w[4];
+        w[0] = ((vbp[0] * na[0] + vbp[1] * na[1]) + vbp[2] * na[2]) * v6;
+        w[1] = ((vap[0] * nb[0] + vap[1] * nb[1]) + vap[2] * nb[2]) * v6;
+        w[2] = ((vap[0] * nc[0] + vap[1] * nc[1]) + vap[2] * nc[2]) * v6;
+        w[3] = ((vap[0] * nd[0] + vap[1] * nd[1]) + vap[2] * nd[2]) * v6;
+        float G[3];
+        for (int k = 0; k < 3; ++k) G[k] = (g[0] * na[k] + g[1] * nb[k] + g[2] * nc[k] + g[3] * nd[k]) * v6;
+        float *gt = grad_tet_bxtx4x3 + ((size_t)b * n_tet + t) * 12;
+        for (int v = 0; v < 4; ++v)
+            for (int k = 0; k < 3; ++k) gt[v * 3 + k] -= w[v] * G[k];
+    }
+}
+
+/* ------------------------------------------------------------------------------------
  * Builders.  Shared local-face table (utils/lib/tet_adj_share/run.cpp:42-45,
  * utils/tet_utils.py:160-163).
  * ---------------------------------------------------------------------------------- */

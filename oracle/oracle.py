@@ -25,8 +25,9 @@ _f64p = C.POINTER(C.c_double)
 def build(force: bool = False) -> None:
     """Compile the restatement and (when /root/reference is present) oracle/_ref."""
     src = [os.path.join(HERE, f) for f in ("deftet_oracle.c", "deftet_oracle_surface.c", "deftet_oracle_render.c", "deftet_oracle_sign.c", "Makefile")]
-    stale = (not os.path.exists(LIB_PATH) or not os.path.exists(LIB_FMA_PATH) or
-             any(os.path.getmtime(s) > min(os.path.getmtime(LIB_PATH), os.path.getmtime(LIB_FMA_PATH)) for s in src))
+    # (the FMA variant is a diagnostic: it is built along with the oracle when the compiler can, and its absence — a host
+    # without -mfma — neither makes the oracle stale nor fails the build; lib_fma() says so)
+    stale = not os.path.exists(LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in src)
     need_ref = os.path.isdir("/root/reference/utils/lib") and not all(
         os.path.exists(os.path.join(REF_DIR, n + "_run.so"))
         for n in ("tet_adj_share", "tet_face_adj", "tet_point_adj", "colaps_v"))
@@ -49,10 +50,30 @@ def lib():
 _lib_fma = None
 
 
+class FmaOracleUnavailable(RuntimeError):
+    """the -mfma build of the restatement (a flip-counting diagnostic, never the parity oracle) cannot be used on this host"""
+
+
+def _cpu_has_fma():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("flags"):
+                return " fma " in line + " "
+    except OSError:
+        pass
+    return True                                               # unknown: let the loader decide
+
+
 def lib_fma():
     global _lib_fma
     if _lib_fma is None:
         build()
+        if not os.path.exists(LIB_FMA_PATH) or os.path.getmtime(LIB_FMA_PATH) < os.path.getmtime(os.path.join(HERE, "deftet_oracle.c")):
+            subprocess.call(["make", "-s", "-C", HERE, "fma"])
+        if not os.path.exists(LIB_FMA_PATH):
+            raise FmaOracleUnavailable("libdeftet_oracle_fma.so could not be built on this host (needs -mfma)")
+        if not _cpu_has_fma():
+            raise FmaOracleUnavailable("this CPU has no FMA instructions: libdeftet_oracle_fma.so would fault")
         _lib_fma = C.CDLL(LIB_FMA_PATH)
         _lib_fma.oracle_point_in_tet_f32_omp.restype = C.c_int
     return _lib_fma
@@ -107,6 +128,18 @@ def bary(tet_bxtx4x3, pts_bxqx3, cond_bxq):
     out = np.empty(pts.shape[:2] + (4,), np.float32)
     lib().oracle_bary_f32(_p(tet, _f32p), _p(pts, _f32p), _p(cond, _f32p), _p(out, _f32p),
                           tet.shape[0], tet.shape[1], pts.shape[1])
+    return out
+
+
+def bary_bwd(tet_bxtx4x3, pts_bxqx3, cond_bxq, grad_w_bxqx4):
+    """dL/dtet [B,T,4,3] in plain fp32 C (scatter-add in query order): the CPU leg of bench.py's fwd+bwd figure."""
+    tet = _c(tet_bxtx4x3, np.float32)
+    pts = _c(pts_bxqx3, np.float32)
+    cond = _c(cond_bxq, np.float32).reshape(pts.shape[0], pts.shape[1])
+    gw = _c(grad_w_bxqx4, np.float32)
+    out = np.zeros(tet.shape, np.float32)
+    lib().oracle_bary_bwd_f32(_p(tet, _f32p), _p(pts, _f32p), _p(cond, _f32p), _p(gw, _f32p), _p(out, _f32p),
+                              tet.shape[0], tet.shape[1], pts.shape[1])
     return out
 
 

@@ -4,6 +4,7 @@ import pytest
 import torch
 
 from tests import cases
+from tests.tol import check_close
 
 pytestmark = pytest.mark.gpu
 
@@ -403,8 +404,8 @@ def test_config0_res20_10k_b1_vs_oracle(cuda, oracle):
     g = hip_ops.point_in_tet_bwd(t, p, cond, gw, hits=hits)[0].cpu().numpy()
     w64, gt64 = oracle.point_in_tet_bwd_torch(tet, pts, want, gw.cpu().numpy())
     hit = want[..., 0] >= 0
-    assert np.abs(w.cpu().numpy() - w64)[hit].max() <= 1e-5 * max(1.0, np.abs(w64).max())
-    assert np.abs(g - gt64).max() <= 1e-5 * np.abs(gt64).max() * 8
+    check_close("A1b weights, configs[0] res20 10k B1 vs fp64", w.cpu().numpy()[hit], w64[hit], 1e-5)
+    check_close("A1b grad_tet, configs[0] res20 10k B1 vs fp64 autograd", g, gt64, 8e-5)
 
 
 @pytest.mark.parametrize("res,nq,batch,sub", [(40, 50000, 8, 4000), (70, 100000, 8, 2000)])
@@ -444,8 +445,8 @@ def test_config_full_size_b8(cuda, oracle, res, nq, batch, sub):
     # GPU's own `cond` (already proven equal to the brute-force kernel above): every query of all `batch` shapes
     w64, gt64 = oracle.point_in_tet_bwd_torch(tet, pts, cond.cpu().numpy(), gw.cpu().numpy())
     hitn = hit.cpu().numpy()
-    assert np.abs(w.cpu().numpy() - w64)[hitn].max() <= 1e-5 * max(1.0, np.abs(w64[hitn]).max())
-    assert np.abs(a[0].cpu().numpy() - gt64).max() <= 1e-5 * np.abs(gt64).max() * 8
+    check_close("A1b weights, res%d %dk B%d vs fp64" % (res, nq // 1000, batch), w.cpu().numpy()[hitn], w64[hitn], 1e-5)
+    check_close("A1b grad_tet, res%d %dk B%d vs fp64 autograd" % (res, nq // 1000, batch), a[0], gt64, 8e-5)
     for algo in (2, 3, 4):                              # the other traversals: their hit records drive the same backward
         c2, w2, o2, h2 = hip_ops.point_in_tet(t, p, want_bary=True, pred_bxt=pred, want_hits=True, algo=algo)
         assert torch.equal(c2, cond) and torch.equal(w2, w) and torch.equal(o2, occ)
@@ -532,3 +533,101 @@ def test_config3_full_size_b8(cuda, oracle):
     pick = np.sort(np.random.default_rng(3).choice(200000, 300, replace=False))
     want = oracle.point_in_tet(tet, np.ascontiguousarray(pts[:, pick]), omp=True)
     assert np.array_equal(cond[:, pick].cpu().numpy(), want)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# traversal order (round 5): the result must not depend on how the tets are numbered, nor on the permutation they are
+# traversed in
+# ---------------------------------------------------------------------------------------------------------------------
+def test_spatial_order_is_a_permutation_and_groups_columns(cuda):
+    from deftet_amd import grids, hip_ops
+    tet, _, _, _ = grids.make_case(20, 10, 1)
+    rng = np.random.default_rng(3)
+    shuffled = np.ascontiguousarray(tet[0][rng.permutation(tet.shape[1])])
+    for arr, coherent in ((tet[0], True), (shuffled, False)):
+        order, breaks = hip_ops.tet_spatial_order(torch.from_numpy(arr).to(cuda), want_breaks=True)
+        o = order.cpu().numpy()
+        assert np.array_equal(np.sort(o), np.arange(arr.shape[0]))
+        native, srt = breaks.tolist()
+        if coherent:
+            assert native <= 2 * srt + arr.shape[0] // 256             # the Kuhn enumeration is kept as it is
+        else:
+            assert native > 8 * srt                                     # a shuffled list is not
+        # consecutive tets of the computed order are neighbours: the mean centroid step is a small fraction of the grid
+        c = arr[o].mean(1)
+        assert np.abs(np.diff(c, axis=0)).sum(1).mean() < 0.2
+    # non-finite tets go to the end, the rest is still a permutation
+    bad = shuffled.copy()
+    bad[5, 2, 1] = np.nan
+    bad[77] = np.inf
+    o = hip_ops.tet_spatial_order(torch.from_numpy(bad).to(cuda)).cpu().numpy()
+    assert np.array_equal(np.sort(o), np.arange(bad.shape[0])) and set(o[-2:]) == {5, 77}
+
+
+@pytest.mark.parametrize("algo", [0, 3, 4])
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_ordered_traversal_bit_exact_adversarial(cuda, oracle, algo, seed):
+    """Every special class (irregular tets, NaN queries, duplicates where the LOWEST index must win) through the ordered
+    instances of the filter kernels, with the computed order and with a random permutation."""
+    from deftet_amd import hip_ops
+    tet, pts = cases.adversarial(seed)
+    want = oracle.point_in_tet(tet, pts)
+    t, p = torch.from_numpy(tet).to(cuda), torch.from_numpy(pts).to(cuda)
+    T = tet.shape[1]
+    perm = torch.from_numpy(np.random.default_rng(seed).permutation(T).astype(np.int32)).to(cuda)
+    for order in (hip_ops.tet_spatial_order(t[0]), perm):
+        got = hip_ops.point_in_tet(t, p, algo=algo, order=order)
+        assert np.array_equal(got.cpu().numpy(), want)
+
+
+def test_shuffled_tets_configs2_size_bit_exact_vs_brute(cuda):
+    """BASELINE configs[2] size (res 70, 100k queries; two shapes), the tet list randomly shuffled: the caller's order, the
+    computed traversal order and order="auto" all give the brute-force kernel's answer, the same weights and the same
+    gradients."""
+    from deftet_amd import grids, hip_ops
+    tet, pts, _, _ = grids.make_case(70, 100_000, 2)
+    rng = np.random.default_rng(11)
+    tet = np.ascontiguousarray(tet[:, rng.permutation(tet.shape[1])])
+    t, p = torch.from_numpy(tet).to(cuda), torch.from_numpy(pts).to(cuda)
+    brute = hip_ops.point_in_tet(t, p, algo=hip_ops.PIT_BRUTE)
+    order, breaks = hip_ops.tet_spatial_order(t[0], want_breaks=True)
+    native, srt = breaks.tolist()
+    assert native > 8 * srt
+    hip_ops.clear_tet_order_cache()
+    assert hip_ops.auto_tet_order(t) is not None                       # the automatic choice takes the computed order here
+    gw = torch.randn(2, 100_000, 4, device=cuda, generator=torch.Generator(device=cuda).manual_seed(0))
+    for algo in (hip_ops.PIT_WAVE, hip_ops.PIT_SLAB):
+        ref = None
+        for o in (None, order, "auto"):
+            cond, w, hits = hip_ops.point_in_tet(t, p, want_bary=True, want_hits=True, algo=algo, order=o)
+            assert torch.equal(cond, brute), (algo, o is None)
+            g = hip_ops.point_in_tet_bwd(t, p, cond, gw, hits=hits)[0]
+            if ref is None:
+                ref = (w, g)
+            assert torch.equal(w, ref[0]) and torch.equal(g, ref[1])   # recorded hits are summed in ascending query order
+    hip_ops.clear_tet_order_cache()
+
+
+def test_wave_kernel_clamped_footprints_and_degenerate_axis(cuda, oracle):
+    """Directed at k_tet_scan_wave's radius bound: most tets straddle or lie outside the query bounding
+    box (their cell footprints are clamped), and in a second case all queries share one x coordinate (inv == 0 on that axis).
+    Compared bit-exact against the exact binned kernel, the brute kernel and the oracle."""
+    from deftet_amd import grids, hip_ops
+    tet, _, _, _ = grids.make_case(16, 10, 2)
+    rng = np.random.default_rng(5)
+    for case in range(3):
+        if case == 0:       # queries in a small box in the middle: most tets are outside, many straddle its faces
+            pts = (rng.random((2, 6000, 3)).astype(np.float32) - 0.5) * 0.22 + 0.03
+        elif case == 1:     # coplanar queries: the x extent of their box is zero
+            pts = (rng.random((2, 6000, 3)).astype(np.float32) - 0.5) * 0.9
+            pts[..., 0] = 0.0625
+        else:               # collinear queries (two degenerate axes), crossing the whole grid and leaving it
+            pts = np.zeros((2, 3000, 3), np.float32)
+            pts[..., 2] = np.linspace(-0.7, 0.7, 3000, dtype=np.float32)
+            pts[..., 0] = 0.03125
+            pts[..., 1] = -0.125
+        want = oracle.point_in_tet(tet, pts)
+        t, p = torch.from_numpy(tet).to(cuda), torch.from_numpy(pts).to(cuda)
+        for algo in (1, 2, 3, 4):
+            assert np.array_equal(hip_ops.point_in_tet(t, p, algo=algo).cpu().numpy(), want), (case, algo)
+        assert (want >= 0).any()

@@ -147,10 +147,10 @@ def test_backward_matches_fp64_autograd(cuda, oracle):
     g = torch.Generator(device=cuda).manual_seed(0)
     wts = torch.rand(color.shape, device=cuda, generator=g).cpu().double()
     ((c64 * wts).sum() + (v64 ** 2).sum()).backward()
-    for got, want in ((txy.grad.cpu().double(), xy64.grad), (tff.grad.cpu().double(), ff64.grad)):
-        scale = want.abs().max().item()
-        assert scale > 0
-        assert (got - want).abs().max().item() <= 2e-4 * scale
+    from tests.tol import check_close
+    for nm, got, want in (("xy", txy.grad, xy64.grad), ("feat", tff.grad, ff64.grad)):
+        assert want.abs().max().item() > 0
+        check_close("A12 grad_%s through compositing, res6 24x24 k48 vs fp64 autograd" % nm, got, want, 2e-4)
     # faces that no pixel hit get exactly zero gradient
     hit = torch.zeros(fxy.shape[1], dtype=torch.bool)
     hit[face.cpu()[face.cpu() >= 0]] = True
@@ -178,8 +178,9 @@ def test_backward_other_feature_widths_and_batches(cuda, oracle, D, B):
     ff64 = tff.detach().double().requires_grad_(True)
     feat64 = oracle.sparse_render_torch(tp.double(), xy64, ff64, face)
     wxy, wff = torch.autograd.grad(feat64, (xy64, ff64), go.double())
-    for got, want in ((gxy, wxy), (gff, wff)):
-        assert (got.double() - want).abs().max().item() <= 2e-4 * want.abs().max().item()
+    from tests.tol import check_close
+    for nm, got, want in (("xy", gxy, wxy), ("feat", gff, wff)):
+        check_close("A12 grad_%s, D=%d B=%d vs fp64 autograd" % (nm, D, B), got, want, 2e-4)
     assert (face >= 0).sum().item() > 1000 * B
 
 
@@ -238,7 +239,8 @@ def test_backward_baseline_config_fp64(cuda, oracle):
         err = (got.double() - want).abs().reshape(want.shape[1], -1).max(-1).values
         big = mag > 1e-3 * mag.max()
         assert (err[big] / mag[big]).max().item() < 2e-3
-        assert err.max().item() <= 2e-4 * want.abs().max().item()
+        from tests.tol import check_close
+        check_close("A12 grad (%s), configs[4] 512x512 k64 vs fp64 autograd" % ("xy" if got is gxy else "feat"), got, want, 2e-4)
         # run-to-run: only faces whose hits straddle three or more waves may differ, and only by rounding
         assert (again.double() - got.double()).abs().max().item() <= 1e-5 * want.abs().max().item()
     hit = torch.zeros(fxy.shape[1], dtype=torch.bool, device=cuda)

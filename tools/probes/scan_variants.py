@@ -30,7 +30,7 @@ def run_steplike(wl, lib, algo, reps, kernel):
     the average step time."""
     def step(i):
         d = wl.sets[i % len(wl.sets)]
-        outs = hip_ops.point_in_tet(d["tet"], d["pts"], want_bary=True, pred_bxt=d["pred"], want_hits=True, algo=algo)
+        outs = hip_ops.point_in_tet(d["tet"], d["pts"], want_bary=True, pred_bxt=d["pred"], want_hits=True, algo=algo, order=wl.order)
         hip_ops.point_in_tet_bwd(d["tet"], d["pts"], outs[0], d["gw"], grad_occ=d["gout"], hits=outs[3])
         return outs
     for i in range(3):
@@ -53,13 +53,13 @@ def run(wl, lib, algo, reps, kernel):
     d = wl.sets[0]
     outs = None
     for _ in range(2):
-        outs = hip_ops.point_in_tet(d["tet"], d["pts"], want_bary=True, pred_bxt=d["pred"], want_hits=True, algo=algo)
+        outs = hip_ops.point_in_tet(d["tet"], d["pts"], want_bary=True, pred_bxt=d["pred"], want_hits=True, algo=algo, order=wl.order)
     torch.cuda.synchronize()
     lib.deftet_profile_select(kernel.encode())
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(reps):
-        outs = hip_ops.point_in_tet(d["tet"], d["pts"], want_bary=True, pred_bxt=d["pred"], want_hits=True, algo=algo)
+        outs = hip_ops.point_in_tet(d["tet"], d["pts"], want_bary=True, pred_bxt=d["pred"], want_hits=True, algo=algo, order=wl.order)
     b.record()
     torch.cuda.synchronize()
     tot, cnt = ctypes.c_double(0), ctypes.c_longlong(0)
@@ -82,7 +82,8 @@ def main():
     ap.add_argument("--algo", type=int, default=0)
     ap.add_argument("--kernel", default=None, help="traversal kernel name to time (default: the one `algo` launches in the product library)")
     ap.add_argument("--order", default=None, help="xfast: enumerate the Kuhn cubes with x fastest instead of z fastest")
-    ap.add_argument("--mesh", default=None, help="cube40: the shipped QuarTet grid (res 40 sizes) instead of the Kuhn grid")
+    ap.add_argument("--mesh", default=None, help="cube40: the shipped QuarTet grid (res 40 sizes) instead of the Kuhn grid; shuffled: the Kuhn grid's tet list in random order")
+    ap.add_argument("--tet-order", default="auto", choices=["auto", "native", "sorted"], help="traversal order handed to the operator")
     ap.add_argument("--check", action="store_true", help="compare cond with the brute-force kernel (slow at configs[2..3])")
     ap.add_argument("--sets", type=int, default=3, help="input sets of the step-like timing (1 = everything stays in the Infinity Cache)")
     a = ap.parse_args()
@@ -93,11 +94,13 @@ def main():
         cfg["mesh"] = a.mesh
     if a.order:
         cfg["order"] = a.order
+    cfg["tet_order"] = a.tet_order
     wl = bench.PitWorkload(cfg, 0, dev, 1, None, pipeline=False)
     kernel = a.kernel or hip_ops.pit_kernel_name(a.algo, wl.T, wl.Q)
     outs, g, k_us, fwd_us, bwd_us, stats = run(wl, lib, a.algo, a.reps, kernel)
     step_k_us, step_us = run_steplike(wl, lib, a.algo, a.reps, kernel)
     rec = {"config": a.config, "mesh": (a.mesh or "kuhn") + ("/" + a.order if a.order else ""), "n_tet": wl.T, "algo": a.algo, "kernel": kernel,
+           "tet_order": a.tet_order + ("" if a.tet_order != "auto" else (" -> native" if wl.order is None else " -> sorted")),
            "lib": os.environ.get("DEFTET_HIP_LIB", "product"),
            "env": {k: os.environ[k] for k in ("DEFTET_PIT_YZFINE", "DEFTET_PIT_XFINE", "DEFTET_PIT_GDIV", "DEFTET_PIT_QDIV") if k in os.environ},
            "traversal_us_in_step": round(step_k_us, 2), "step_us": round(step_us, 1),
