@@ -85,7 +85,8 @@ class PitWorkload:
             idx = np.arange(n * n * n * 6).reshape(n, n, n, 6)       # [ix, iy, iz, k] -> current position
             tets = tets[idx.transpose(2, 1, 0, 3).reshape(-1)]       # new position ((iz*n + iy)*n + ix)*6 + k
         if cfg.get("mesh") == "shuffled":                 # probe use: the same grid, its tet list in random order
-            tets = tets[np.random.default_rng(7).permutation(tets.shape[0])]
+            self.shuffle_perm = np.random.default_rng(7).permutation(tets.shape[0])
+            tets = tets[self.shuffle_perm]
         # traversal order handed to the operator: "auto" (what the autograd ops pass: decided once per grid), "native" (none),
         # "sorted" (the computed column order, unconditionally) — DEFTET_BENCH_TET_ORDER / cfg["tet_order"]; never changes a result
         self.order_mode = cfg.get("tet_order") or os.environ.get("DEFTET_BENCH_TET_ORDER", "auto")
@@ -141,7 +142,11 @@ class PitWorkload:
         if self.order_mode == "sorted":
             self.order = hip_ops.tet_spatial_order(self.sets[0]["tet"][0])
         elif self.order_mode == "auto":
-            self.order = hip_ops.auto_tet_order(self.sets[0]["tet"])       # resolved here: the steps pass a tensor or None
+            self.order = hip_ops.auto_tet_order(self.sets[0]["tet"], self.sets[0]["pts"], algo)   # resolved here: the steps pass a tensor or None
+        elif self.order_mode == "identity":               # probe: the ordered kernel instance on the caller's own order
+            self.order = torch.arange(self.T, device=device, dtype=torch.int32)
+        elif self.order_mode == "ideal":                  # probe (mesh "shuffled"): the permutation that undoes the shuffle
+            self.order = torch.from_numpy(np.argsort(self.shuffle_perm).astype(np.int32)).to(device)
         else:
             self.order = None
 

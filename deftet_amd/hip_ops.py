@@ -88,32 +88,60 @@ def tet_spatial_order(tet_tx4x3, want_breaks=False):
     return (order, breaks) if want_breaks else order
 
 
-# Traversal orders chosen automatically, one per (device, number of tets): decided at the first call from the positions it was
-# handed (one host read of two integers), then reused — the topology of a DefTet grid is static, and the order is a matter of
-# speed only, so a stale or unlucky choice can never change a result.  DEFTET_PIT_ORDER=off|force overrides the decision.
+# Traversal orders chosen automatically, one per (device, number of tets, kernel): decided at the first call by MEASURING the
+# forward on the tensors it was handed — the caller's numbering against the computed column order, a few launches each, ~1 ms
+# once — then reused: the topology of a DefTet grid is static (layers/DefTet/deftet.py:65-68), and the order is a matter of
+# speed only, so a stale or unlucky choice can never change a result.  (A static coherence measure was tried first — the
+# `breaks` counts of deftet_tet_spatial_order_f32 — and chose wrongly for the shipped QuarTet grid, whose own order is the
+# faster one although it looks less regular.)  DEFTET_PIT_ORDER=off|force overrides the decision.
 _order_cache = {}
 _order_lock = __import__("threading").Lock()
 
 
-def auto_tet_order(tet_bxtx4x3):
-    """The cached traversal order for this grid, or None when its own numbering is coherent enough (or the grid is tiny)."""
+def auto_tet_order(tet_bxtx4x3, pts_bxqx3, algo=PIT_AUTO):
+    """The cached traversal order for this grid, or None when its own numbering is at least as fast (or the grid is tiny)."""
     import os
     mode = os.environ.get("DEFTET_PIT_ORDER", "auto")
-    T, dev = tet_bxtx4x3.shape[1], tet_bxtx4x3.device
-    if mode == "off" or T < 4096:
+    B, T, dev = tet_bxtx4x3.shape[0], tet_bxtx4x3.shape[1], tet_bxtx4x3.device
+    Q = pts_bxqx3.shape[1]
+    if mode == "off" or T < 4096 or B == 0 or Q == 0:
         return None
-    key = (dev.index if dev.index is not None else torch.cuda.current_device(), T)
+    kernel = int(_lib.load().deftet_point_in_tet_resolve_algo(int(algo), T, Q))
+    if kernel not in (PIT_SLAB, PIT_WAVE):
+        return None
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), T, kernel)
     with _order_lock:
         if key in _order_cache:
-            return _order_cache[key]
-    order, breaks = tet_spatial_order(tet_bxtx4x3[0], want_breaks=True)
-    native, sorted_ = (int(x) for x in breaks.tolist())              # one-time synchronisation per topology
-    # the caller's numbering is kept unless it breaks runs clearly more often than the column order does (a group of 64 tets
-    # that changes column once or twice is what the kernel is built for: T / 64 groups, a quarter of a break each, is noise)
-    use = mode == "force" or native > 2 * sorted_ + T // 256
+            return _order_cache[key][0]
+    if torch.cuda.is_current_stream_capturing():                     # no timing inside a graph capture: decide at an eager call
+        return None
+    order = tet_spatial_order(tet_bxtx4x3[0])
+    if mode == "force":
+        choice, times = order, None
+    else:
+        def run(o, n):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            best = float("inf")
+            for i in range(n + 1):                                     # (the first run of each candidate is a warm-up)
+                a.record()
+                point_in_tet(tet_bxtx4x3, pts_bxqx3, algo=algo, order=o)
+                b.record()
+                b.synchronize()
+                if i:
+                    best = min(best, a.elapsed_time(b))
+            return best
+        t_native, t_sorted = run(None, 3), run(order, 3)
+        choice = order if t_sorted < 0.92 * t_native else None         # the caller's numbering unless the other is clearly faster
+        times = (t_native, t_sorted)
     with _order_lock:
-        _order_cache[key] = order if use else None
-    return _order_cache[key]
+        _order_cache[key] = (choice, times)
+    return choice
+
+
+def tet_order_decisions():
+    """{(device, n_tet, kernel id): (chosen "sorted" | "native", (ms native, ms sorted) | None)} — what auto_tet_order decided."""
+    with _order_lock:
+        return {k: ("native" if v[0] is None else "sorted", v[1]) for k, v in _order_cache.items()}
 
 
 def clear_tet_order_cache():
@@ -149,7 +177,7 @@ def point_in_tet(tet_bxtx4x3, pts_bxqx3, want_bary=False, algo=PIT_AUTO, pred_bx
     if isinstance(order, str):
         if order != "auto":
             raise RuntimeError("order must be None, 'auto' or an int32 [T] permutation")
-        order = auto_tet_order(tet) if (B > 0 and algo in (PIT_AUTO, PIT_SLAB, PIT_WAVE)) else None
+        order = auto_tet_order(tet, pts, algo) if algo in (PIT_AUTO, PIT_SLAB, PIT_WAVE) else None
     if order is not None:
         _lib.require_gpu(order)
         if order.dtype != torch.int32 or order.shape != (T,) or not order.is_contiguous() or order.device != dev:

@@ -83,7 +83,7 @@ def main():
     ap.add_argument("--kernel", default=None, help="traversal kernel name to time (default: the one `algo` launches in the product library)")
     ap.add_argument("--order", default=None, help="xfast: enumerate the Kuhn cubes with x fastest instead of z fastest")
     ap.add_argument("--mesh", default=None, help="cube40: the shipped QuarTet grid (res 40 sizes) instead of the Kuhn grid; shuffled: the Kuhn grid's tet list in random order")
-    ap.add_argument("--tet-order", default="auto", choices=["auto", "native", "sorted"], help="traversal order handed to the operator")
+    ap.add_argument("--tet-order", default="auto", choices=["auto", "native", "sorted", "identity", "ideal"], help="traversal order handed to the operator")
     ap.add_argument("--check", action="store_true", help="compare cond with the brute-force kernel (slow at configs[2..3])")
     ap.add_argument("--sets", type=int, default=3, help="input sets of the step-like timing (1 = everything stays in the Infinity Cache)")
     a = ap.parse_args()
