@@ -95,7 +95,15 @@ __device__ unsigned long long g_phase[kPhaseWaves][16];
     do {                                                                               \
         if ((threadIdx.x & 63) == 0) g_phase[ph_w_][i] += (unsigned long long)(v);     \
     } while (0)
+// why lanes end up outside every footprint group (lanes per reason, summed over the waves of all launches)
+__device__ unsigned long long g_reason[8];
+#define REASON_COUNT(i, mask)                                                                                        \
+    do {                                                                                                             \
+        const unsigned long long rm_ = (mask);                                                                       \
+        if (rm_ != 0ull && (threadIdx.x & 63) == 0) atomicAdd(&g_reason[i], (unsigned long long)__popcll(rm_));     \
+    } while (0)
 #else
+#define REASON_COUNT(i, mask)
 #define PHASE_DECL
 #define PHASE_MARK(i)
 #define PHASE_COUNT(i, v)
@@ -1282,7 +1290,22 @@ constexpr int kWvRows = 192;                            // (cz, cy) rows of a st
 #endif
 constexpr int kWvCap = PIT_WVCAP;                       // staged queries per chunk
 constexpr int kWvSlots = 6;                             // accepted queries a lane keeps: record + half a spill record
-static_assert(kWvRows <= 254 && kWvRows % 64 == 0 && kWvSlots >= 4 && kWvSlots <= 8, "row ids are bytes; the records hold four + four");
+static_assert(kWvRows % 64 == 0 && kWvSlots >= 4 && kWvSlots <= 8, "whole waves of row ids; the records hold four + four");
+// two tets per lane (k_tet_scan_pair): the wave's footprint holds the rows and queries of 128 tets
+#ifndef PIT_WVCAP_PAIR
+#define PIT_WVCAP_PAIR 128
+#endif
+constexpr int kWvCapPair = PIT_WVCAP_PAIR, kWvRowsPair = 256;
+// timing experiments only (wrong results when 0): leave out the global walk of the lanes no group covers / the exact decisions
+#ifndef PIT_DBG_WALK
+#define PIT_DBG_WALK 1
+#endif
+#ifndef PIT_DBG_PEND
+#define PIT_DBG_PEND 1
+#endif
+#ifndef PIT_WAVES_PAIR
+#define PIT_WAVES_PAIR 5
+#endif
 #ifndef PIT_TOLX
 #define PIT_TOLX 2          // x cells a lane's footprint may differ from the pivot's
 #endif
@@ -1290,24 +1313,22 @@ static_assert(kWvRows <= 254 && kWvRows % 64 == 0 && kWvSlots >= 4 && kWvSlots <
 #define PIT_MINGROUP 4      // 16: 68.7 us at configs[2], 150 at configs[3]; 8: 66.2 / 148; 4: 65.2 / 143; 2, 1: the same
 #endif
 constexpr int kWvMinGroup = PIT_MINGROUP;               // lanes a footprint group must have to be worth staging
+#ifndef PIT_ZREACH
+#define PIT_ZREACH 24
+#endif
+constexpr int kWvZReach = PIT_ZREACH;                    // slabs a lane's first slab may lie from its pivot's (two groups of 2 * 24 + a few slabs fit 64 lanes... mostly)
 constexpr float kRelScale = 2.86102294921875e-06f;      // 48 u = 24 u * (the 2 of G_k = 2 w_l w_m)
 constexpr float kTauSlim = kTau * (1.0f + 1.0f / 128.0f);
 #ifndef PIT_WAVES2
 #define PIT_WAVES2 7     // 72 registers, scratch only on the rare exact-decision path; 69.0 us (six waves, 76 registers: 72.2; eight, 64: 70.5)
 #endif
-// Diagnostic builds (tools/probes/build_variant.sh ... -DPIT_STOP=n): the kernel ends after stage n with everything computed so
-// far kept alive, so that instruction counters can be read per stage (differences between the builds).
-#ifndef PIT_STOP
-#define PIT_STOP 0
-#endif
-template <typename T>
-__device__ __forceinline__ void keep_alive(T x) { asm volatile("" ::"v"(x)); }
-
-struct __attribute__((aligned(16))) WaveStage {        // 2.8 KB per wave: with the hit slots 19.4 KB per workgroup, eight workgroups per CU
-    float4 q[kWvCap];                                   // the chunk's queries, rows in (cz, cy) order
-    int delta[kWvRows];                                 // position of the row's first query in sortedQ - rowBase
-    unsigned short rowBase[kWvRows + 4];                // exclusive prefix of the row lengths; [R] = total (< 2^16, checked)
-    unsigned char marker[kWvCap];                       // row id + 1 at the LDS position where a non-empty row starts
+template <int CAP, int ROWS>
+struct __attribute__((aligned(16))) WaveStageT {       // one tet per lane: 2.8 KB per wave, with the hit slots 19.4 KB per workgroup
+    typedef typename std::conditional<(ROWS <= 254), unsigned char, unsigned short>::type marker_t;
+    float4 q[CAP];                                      // the chunk's queries, rows in (cz, cy) order
+    int delta[ROWS];                                    // position of the row's first query in sortedQ - rowBase
+    unsigned short rowBase[ROWS + 4];                   // exclusive prefix of the row lengths; [R] = total (< 2^16, checked)
+    marker_t marker[CAP];                               // row id + 1 at the LDS position where a non-empty row starts
 };
 
 template <int CTRL, int ROW_MASK>
@@ -1433,51 +1454,64 @@ __device__ __noinline__ int exact_rescan_slots(const float *__restrict__ tv, int
     return hcnt;
 }
 
-template <bool ORD>                                                    // see k_tet_scan_slab
-__global__ __launch_bounds__(256, PIT_WAVES2) void k_tet_scan_wave(const float *__restrict__ tet, int T, int Q,
+// NT tets per lane (1: k_tet_scan_wave, 2: k_tet_scan_pair).  With two, the lane owns the tets at positions 2p and 2p + 1 — in a
+// coherent list neighbours, usually with the same candidates — and everything that is done once per WAVE (footprint groups,
+// row bounds, scan, staging: 59 % of the instructions of the one-tet kernel at configs[2]) serves 128 tets instead of 64:
+// the lane's footprint is the union of its two cell boxes, every staged candidate is tested against both filters (one LDS
+// read, 2 x 6 packed FMAs), each tet has its own slots, record and publish.  A tet of the pair that has nothing to traverse
+// (irregular, outside the query box, past the end of the list) gets a filter that rejects everything.
+template <bool ORD, int NT>                                             // ORD: see k_tet_scan_slab
+__device__ __forceinline__ void tet_scan_wave_body(const float *__restrict__ tet, int T, int Q,
                                                   const float *__restrict__ gparam, int G, int Gx, const int *__restrict__ table,
                                                   long long cellStride, const float4 *__restrict__ sortedQ, int *result, int *counters,
                                                   int *irregT, int4 *hits, const float *__restrict__ pts,
                                                   const int *__restrict__ irregQ, int *ucount, int hpad, int4 *spill,
                                                   const int *__restrict__ order)
 {
-    __shared__ WaveStage s_w[4];
-    __shared__ int s_hit[kWvSlots + 2][256];                           // [slot][thread]; the last two rows swallow the overflow
+    constexpr int CAP = NT == 1 ? kWvCap : kWvCapPair, ROWS = NT == 1 ? kWvRows : kWvRowsPair;
+    typedef WaveStageT<CAP, ROWS> Stage;
+    __shared__ Stage s_w[4];
+    __shared__ int s_hit[NT][kWvSlots + 2][256];                       // [tet of the lane][slot][thread]; the last two rows swallow the overflow
     if (ucount && blockIdx.x == 0 && __builtin_amdgcn_readfirstlane(threadIdx.x) == 0) {   // per-shape words of the hit buffer
         ucount[blockIdx.y] = 0;                                        // (wave-uniform branch, see k_tet_scan_slab: behind a
         ucount[hpad + blockIdx.y] = 0;                                 // one-thread branch: 80 registers and an 8-byte scratch store
         ucount[2 * hpad + blockIdx.y] = 0;                             // per lane = 16 MB of HBM writes per launch; so: 76, none)
     }
     const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
-    WaveStage &W = s_w[tid >> 6];
+    Stage &W = s_w[tid >> 6];
     const int nblk = gridDim.x;
     const int per = (nblk + 7) >> 3;
     const int vb = (blockIdx.x & 7) * per + (blockIdx.x >> 3);        // XCD-aware mapping, see k_tet_scan
-    const int t = vb * blockDim.x + tid;                                // position in the launch; the tet is tet_id()
-    const bool valid = vb < nblk && t < T;
+    const int t = vb * blockDim.x + tid;                                // the lane's position in the launch: tets at NT * t + k
+    const bool valid = vb < nblk && t < (T + NT - 1) / NT;
     if (__builtin_amdgcn_ballot_w64(valid) == 0ull) return;           // (every other lane stays: the wave works together)
-    // (ORD: re-read where it is needed instead of kept in a register across the staged loop)
-    auto tet_id = [&]() -> int { return ORD ? order[valid ? t : T - 1] : t; };
+    // (re-read where it is needed instead of kept in a register across the staged loop; clamped for the lanes past the end)
+    auto tet_id = [&](int k) -> int {
+        const int p = min(NT * t + k, T - 1);
+        return ORD ? order[p] : p;
+    };
+    auto tet_exists = [&](int k) -> bool { return valid && (NT == 1 || NT * t + k < T); };
     PHASE_DECL;
-    float v[12];
-    {
-        const float4 *src = reinterpret_cast<const float4 *>(tet + ((size_t)b * T + (valid ? tet_id() : T - 1)) * 12);
-        float4 a = src[0], bq = src[1], c = src[2];
-        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
-        v[4] = bq.x; v[5] = bq.y; v[6] = bq.z; v[7] = bq.w;
-        v[8] = c.x; v[9] = c.y; v[10] = c.z; v[11] = c.w;
-    }
     const Grid g = load_grid(gparam + b * kGridWords);
     // --- filter-only setup -------------------------------------------------------------------------------------------
     // Everything that does not depend on the lane's group is finished here, so that the vertices and normals are dead
     // before the wave-level part starts: N_i, cE_i = fl(-sigma c_i - Eabs_i), max Eabs; the group-dependent part of the
     // radius is subtracted afterwards (C_i = fl(cE_i - erel): one more rounding of <= u (|c_i| + E_i), covered by the
     // 16 u of the |base| term where 8.02 u are needed).
-    Filter F;
-    float eabsMax, mrg, wk[3];
-    bool regular, ingrid;
-    int cx0, cx1, cy0, cy1, cz0, cz1;
-    {
+    Filter F[NT];
+    float eabsMax[NT], mrg[NT], wk[NT][3];
+    bool regular[NT], works[NT];
+    int cx0 = 0x7FFF, cx1 = 0, cy0 = 0x7FFF, cy1 = 0, cz0 = 0x7FFF, cz1 = 0;   // the lane's cell box: the union over its working tets
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+        float v[12];
+        {
+            const float4 *src = reinterpret_cast<const float4 *>(tet + ((size_t)b * T + tet_id(k)) * 12);
+            float4 a = src[0], bq = src[1], c = src[2];
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+            v[4] = bq.x; v[5] = bq.y; v[6] = bq.z; v[7] = bq.w;
+            v[8] = c.x; v[9] = c.y; v[10] = c.z; v[11] = c.w;
+        }
         float mN[4][3], det;
         {
             const float e1x = v[3] - v[0], e1y = v[4] - v[1], e1z = v[5] - v[2];
@@ -1487,59 +1521,62 @@ __global__ __launch_bounds__(256, PIT_WAVES2) void k_tet_scan_wave(const float *
             cross_fma(e3x, e3y, e3z, e1x, e1y, e1z, mN[1]);            // face (v1 v0 v3): ordering 1
             cross_fma(e2x, e2y, e2z, e3x, e3y, e3z, mN[2]);            // face (v2 v3 v0): ordering 2
 #pragma unroll
-            for (int k = 0; k < 3; ++k) mN[3][k] = -((mN[0][k] + mN[1][k]) + mN[2][k]);   // face (v3 v2 v1): ordering 3
+            for (int j = 0; j < 3; ++j) mN[3][j] = -((mN[0][j] + mN[1][j]) + mN[2][j]);   // face (v3 v2 v1): ordering 3
             det = fmaf(mN[0][0], e3x, fmaf(mN[0][1], e3y, mN[0][2] * e3z));
         }
         float blo[3], bhi[3], mx[3];                                   // box; largest |coordinate| per axis
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            blo[k] = fminf(fminf(v[k], v[3 + k]), fminf(v[6 + k], v[9 + k]));
-            bhi[k] = fmaxf(fmaxf(v[k], v[3 + k]), fmaxf(v[6 + k], v[9 + k]));
-            wk[k] = bhi[k] - blo[k];
-            mx[k] = fmaxf(fabsf(blo[k]), fabsf(bhi[k]));
+        for (int j = 0; j < 3; ++j) {
+            blo[j] = fminf(fminf(v[j], v[3 + j]), fminf(v[6 + j], v[9 + j]));
+            bhi[j] = fmaxf(fmaxf(v[j], v[3 + j]), fmaxf(v[6 + j], v[9 + j]));
+            wk[k][j] = bhi[j] - blo[j];
+            mx[j] = fmaxf(fabsf(blo[j]), fabsf(bhi[j]));
         }
-        const float w = fmaxf(fmaxf(wk[0], wk[1]), wk[2]);
+        const float w = fmaxf(fmaxf(wk[k][0], wk[k][1]), wk[k][2]);
         // every comparison is written so that NaN yields "irregular" (NaN poisons det; Inf / huge values show up in mx)
-        regular = fmaxf(fmaxf(mx[0], mx[1]), mx[2]) <= kBig && w >= kWMin && fabsf(det) >= kTauSlim * ((w * w) * w);
-        mrg = w * kMargin;
+        regular[k] = fmaxf(fmaxf(mx[0], mx[1]), mx[2]) <= kBig && w >= kWMin && fabsf(det) >= kTauSlim * ((w * w) * w);
+        mrg[k] = w * kMargin;
         float elo[3], ehi[3];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            elo[k] = blo[k] - mrg;
-            ehi[k] = bhi[k] + mrg;
+        for (int j = 0; j < 3; ++j) {
+            elo[j] = blo[j] - mrg[k];
+            ehi[j] = bhi[j] + mrg[k];
         }
         // no regular query can lie in the enlarged box -> nothing to traverse
-        ingrid = !(ehi[0] < g.lo[0] || elo[0] > g.hi[0] || ehi[1] < g.lo[1] || elo[1] > g.hi[1] || ehi[2] < g.lo[2] || elo[2] > g.hi[2]);
-        cx0 = cell_of(elo[0], g.o[0], g.inv[0], Gx); cx1 = cell_of(ehi[0], g.o[0], g.inv[0], Gx);
-        cy0 = cell_of(elo[1], g.o[1], g.inv[1], G); cy1 = cell_of(ehi[1], g.o[1], g.inv[1], G);
-        cz0 = cell_of(elo[2], g.o[2], g.inv[2], G); cz1 = cell_of(ehi[2], g.o[2], g.inv[2], G);
+        const bool ingrid = !(ehi[0] < g.lo[0] || elo[0] > g.hi[0] || ehi[1] < g.lo[1] || elo[1] > g.hi[1] || ehi[2] < g.lo[2] || elo[2] > g.hi[2]);
+        works[k] = tet_exists(k) && regular[k] && ingrid;
+        {
+            const int ax0 = cell_of(elo[0], g.o[0], g.inv[0], Gx), ax1 = cell_of(ehi[0], g.o[0], g.inv[0], Gx);
+            const int ay0 = cell_of(elo[1], g.o[1], g.inv[1], G), ay1 = cell_of(ehi[1], g.o[1], g.inv[1], G);
+            const int az0 = cell_of(elo[2], g.o[2], g.inv[2], G), az1 = cell_of(ehi[2], g.o[2], g.inv[2], G);
+            if (NT == 1) {
+                cx0 = ax0; cx1 = ax1; cy0 = ay0; cy1 = ay1; cz0 = az0; cz1 = az1;
+            } else if (works[k]) {
+                cx0 = min(cx0, ax0); cx1 = max(cx1, ax1); cy0 = min(cy0, ay0); cy1 = max(cy1, ay1); cz0 = min(cz0, az0); cz1 = max(cz1, az1);
+            }
+        }
         const float sigma = det > 0.f ? 1.0f : -1.0f;
         float S[3];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) S[k] = fmaf(mx[k], 2.0f * kErrScale, g.pe[k]);                 // 8 u P_k + 16 u M_k
-        eabsMax = 0.f;
+        for (int j = 0; j < 3; ++j) S[j] = fmaf(mx[j], 2.0f * kErrScale, g.pe[j]);                 // 8 u P_k + 16 u M_k
+        eabsMax[k] = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const float n0 = mN[i][0], n1 = mN[i][1], n2 = mN[i][2];
             const float *a = i < 3 ? v : v + 3;                        // a point of the face: v0 (faces 0-2), v1 (face 3)
             const float c = fmaf(n0, a[0], fmaf(n1, a[1], n2 * a[2]));
             const float E = fmaf(fabsf(n0), S[0], fmaf(fabsf(n1), S[1], fabsf(n2) * S[2]));
-            F.N[i][0] = sigma * n0; F.N[i][1] = sigma * n1; F.N[i][2] = sigma * n2;
-            F.C[i] = fmaf(-sigma, c, -E);
-            eabsMax = fmaxf(eabsMax, E);
+            F[k].N[i][0] = sigma * n0; F[k].N[i][1] = sigma * n1; F[k].N[i][2] = sigma * n2;
+            F[k].C[i] = fmaf(-sigma, c, -E);
+            eabsMax[k] = fmaxf(eabsMax[k], E);
         }
     }
-    const bool work = valid && regular && ingrid;
+    bool work = works[0];
+#pragma unroll
+    for (int k = 1; k < NT; ++k) work = work || works[k];
     const int Gp = table_pitch(G);
     const int *tb = table + (size_t)b * cellStride;
     const float4 *sq = sortedQ + (size_t)b * Q;
-    if (PIT_STOP == 1) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { keep_alive(F.N[i][0]); keep_alive(F.N[i][1]); keep_alive(F.N[i][2]); keep_alive(F.C[i]); }
-        keep_alive(eabsMax); keep_alive(mrg); keep_alive(wk[0]); keep_alive(wk[1]); keep_alive(wk[2]);
-        keep_alive(cx0); keep_alive(cx1); keep_alive(cy0); keep_alive(cy1); keep_alive(cz0); keep_alive(cz1); keep_alive((int)work);
-        return;
-    }
     // --- footprint groups (wave-uniform scalars) ------------------------------------------------------------------------
     // group g: cell box [gx0, gx1] x [gy0, gy0 + gny) x [gz0, gz0 + gnz).  Its rows are numbered (slab << gsh) + y with a
     // power-of-two y pitch <= 4 (ids with y >= gny are empty rows); group 1's follow group 0's.  One LANE per slab reads
@@ -1549,84 +1586,129 @@ __global__ __launch_bounds__(256, PIT_WAVES2) void k_tet_scan_wave(const float *
     int ncx = cx1 - cx0 + 1, ncy = cy1 - cy0 + 1;                      // cells of the lane's candidate source along x / y
     int rowsTot = 0, rowOff1 = 0, slabsTot = 0;                        // row ids in use; first id of group 1; slabs of both groups
     {
+        // Up to three pivots for up to two groups.  A pivot's group holds the lanes whose (x, y) footprint is within PIT_TOLX /
+        // one cell of the pivot's AND whose first slab is within kWvZReach of the pivot's: without the z condition the last
+        // tets of one mesh column and the first of the next (y-adjacent: their footprints can differ by a single cell when the
+        // jitter falls that way) formed ONE group spanning the whole z range — five rows, or more than 64 slabs, or more rows
+        // than the stage holds — which was dropped as a whole, and all its lanes walked the global table by themselves:
+        // 61,000 of 2.06 M lanes per launch at configs[2], 212,000 of 6 M at configs[3], whole waves of them, 8 of 68 us.
+        // A pivot whose group is too small to be worth staging (the last one or two tets of a column at the head of a wave)
+        // gives up only ITS lanes; the others get the next pivot (it used to send the whole rest of the wave to the global walk).
         lanemask_t rem = __builtin_amdgcn_ballot_w64(work);
+        int ng = 0;                                                    // groups accepted so far (wave-uniform)
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             gx0[p] = gx1[p] = gy0[p] = gz0[p] = 0;
             gny[p] = gnz[p] = gsh[p] = 0;
-            if (__popcll(rem) < kWvMinGroup) continue;
+        }
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            if (ng == 2 || __popcll(rem) < kWvMinGroup) break;         // (lanes left over walk the global table)
             const int pl = __ffsll((long long)rem) - 1;
             const int px0 = __builtin_amdgcn_readlane(cx0, pl), px1 = __builtin_amdgcn_readlane(cx1, pl);
             const int py0 = __builtin_amdgcn_readlane(cy0, pl), py1 = __builtin_amdgcn_readlane(cy1, pl);
+            const int pz0 = __builtin_amdgcn_readlane(cz0, pl);
             // (unsigned compare of the shifted difference: one instruction per bound)
             const bool in = ((rem >> lane) & 1ull) != 0ull && (unsigned)(cx0 - px0 + PIT_TOLX) <= 2u * PIT_TOLX && (unsigned)(cx1 - px1 + PIT_TOLX) <= 2u * PIT_TOLX &&
-                            (unsigned)(cy0 - py0 + 1) <= 2u && (unsigned)(cy1 - py1 + 1) <= 2u;
+                            (unsigned)(cy0 - py0 + 1) <= 2u && (unsigned)(cy1 - py1 + 1) <= 2u && (unsigned)(cz0 - pz0 + kWvZReach) <= 2u * kWvZReach;
             const lanemask_t gm = __builtin_amdgcn_ballot_w64(in);
-            if (__popcll(gm) < kWvMinGroup) { rem = 0ull; continue; }  // incoherent order: everything left walks the global table
+            rem &= ~gm;
+            if (__popcll(gm) < kWvMinGroup) { REASON_COUNT(2, gm); continue; }   // its few lanes walk the global table; the rest gets the next pivot
             const unsigned ax = wave_pk_max(in ? ((unsigned)cx1 | ((0xFFFFu - (unsigned)cx0) << 16)) : 0u);
             const unsigned ay = wave_pk_max(in ? ((unsigned)cy1 | ((0xFFFFu - (unsigned)cy0) << 16)) : 0u);
             const unsigned az = wave_pk_max(in ? ((unsigned)cz1 | ((0xFFFFu - (unsigned)cz0) << 16)) : 0u);
-            rem &= ~gm;
             const int ux0 = (int)(0xFFFFu - (ax >> 16)), uy0 = (int)(0xFFFFu - (ay >> 16)), uz0 = (int)(0xFFFFu - (az >> 16));
             const int ny = (int)(ay & 0xFFFFu) - uy0 + 1, nz = (int)(az & 0xFFFFu) - uz0 + 1;
             const int sh = ny <= 1 ? 0 : 32 - __builtin_clz((unsigned)(ny - 1));              // pitch 2^sh >= ny
-            if (sh > 2 || slabsTot + nz > 64 || rowsTot + (nz << sh) > kWvRows) continue;   // too many rows: its lanes walk the global table
-            gx0[p] = ux0; gx1[p] = (int)(ax & 0xFFFFu); gy0[p] = uy0; gz0[p] = uz0; gny[p] = ny; gnz[p] = nz; gsh[p] = sh;
-            if (p == 1) rowOff1 = rowsTot;
+            if (sh > 2 || slabsTot + nz > 64 || rowsTot + (nz << sh) > ROWS) {              // too many rows: its lanes walk the global table
+                REASON_COUNT(sh > 2 ? 3 : slabsTot + nz > 64 ? 4 : 5, gm);
+                continue;
+            }
+            const bool second = ng != 0;                                // (static indices, wave-uniform selects)
+            gx0[0] = second ? gx0[0] : ux0; gx1[0] = second ? gx1[0] : (int)(ax & 0xFFFFu); gy0[0] = second ? gy0[0] : uy0; gz0[0] = second ? gz0[0] : uz0;
+            gny[0] = second ? gny[0] : ny; gnz[0] = second ? gnz[0] : nz; gsh[0] = second ? gsh[0] : sh;
+            gx0[1] = second ? ux0 : 0; gx1[1] = second ? (int)(ax & 0xFFFFu) : 0; gy0[1] = second ? uy0 : 0; gz0[1] = second ? uz0 : 0;
+            gny[1] = second ? ny : 0; gnz[1] = second ? nz : 0; gsh[1] = second ? sh : 0;
+            if (second) rowOff1 = rowsTot;
             rowsTot += nz << sh;
             slabsTot += nz;
-            if (in) { gid = p; ncx = gx1[p] - ux0 + 1; ncy = ny; }
+            if (in) { gid = ng; ncx = (int)(ax & 0xFFFFu) - ux0 + 1; ncy = ny; }
+            ++ng;
         }
+        REASON_COUNT(6, rem);                                            // [6]: left over after the last pivot
     }
     // --- the group-dependent part of the error radius ---------------------------------------------------------------------
-    {
-        // |candidate - vertex| per axis: box edge + the cells the candidates may come from (+ 1 for the roundings of cell_of)
-        const float R0 = fmaf(2.0f, mrg, wk[0]) + (float)(ncx + 1) * g.cs[0];
-        const float R1 = fmaf(2.0f, mrg, wk[1]) + (float)(ncy + 1) * g.cs[1];
-        const float R2 = fmaf(2.0f, mrg, wk[2]) + (float)(cz1 - cz0 + 2) * g.cs[2];
-        const float erel = fmaf(kRelScale, fmaf(wk[1] * wk[2], R0, fmaf(wk[0] * wk[2], R1, (wk[0] * wk[1]) * R2)), kErrAbs);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) F.C[i] -= erel;
-        F.twoEmax = 2.0f * (eabsMax + erel);
-    }
-    if (PIT_STOP == 2) {
+    for (int k = 0; k < NT; ++k) {
+        // |candidate - vertex| per axis: box edge + the cells the candidates may come from (+ 1 for the roundings of cell_of);
+        // with two tets per lane the cells are those of the lane's UNION box, which contains the tet's own
+        const float R0 = fmaf(2.0f, mrg[k], wk[k][0]) + (float)(ncx + 1) * g.cs[0];
+        const float R1 = fmaf(2.0f, mrg[k], wk[k][1]) + (float)(ncy + 1) * g.cs[1];
+        const float R2 = fmaf(2.0f, mrg[k], wk[k][2]) + (float)(cz1 - cz0 + 2) * g.cs[2];
+        const float erel = fmaf(kRelScale, fmaf(wk[k][1] * wk[k][2], R0, fmaf(wk[k][0] * wk[k][2], R1, (wk[k][0] * wk[k][1]) * R2)), kErrAbs);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { keep_alive(F.N[i][0]); keep_alive(F.N[i][1]); keep_alive(F.N[i][2]); keep_alive(F.C[i]); }
-        keep_alive(F.twoEmax); keep_alive(gid); keep_alive(rowsTot); keep_alive(rowOff1);
-        keep_alive(cx0); keep_alive(cx1); keep_alive(cy0); keep_alive(cy1); keep_alive(cz0); keep_alive(cz1); keep_alive((int)work);
-        return;
+        for (int i = 0; i < 4; ++i) F[k].C[i] -= erel;
+        F[k].twoEmax = 2.0f * (eabsMax[k] + erel);
+        if (NT > 1 && !works[k]) {                                      // nothing to traverse for this tet: A_i = -inf, never accepted, never in the band
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { F[k].N[i][0] = F[k].N[i][1] = F[k].N[i][2] = 0.f; F[k].C[i] = -INFINITY; }
+            F[k].twoEmax = 0.f;
+        }
     }
     PHASE_MARK(0);                                                       // [0] load + setup + grouping
     int *resb = uniform_ptr(result + (size_t)b * Q);
     asm volatile("s_nop 4" ::: "memory");                               // VALU-written SGPR base -> vector memory: five wait states, paid once
-    // accepted queries go to the lane's LDS slots: `slotA` is the byte address of the next one, saturating two rows past the
+    // accepted queries go to the tet's LDS slots: `slotA` is the byte address of the next one, saturating two rows past the
     // last real slot (so that "more than kWvSlots" stays visible); they are published after the loops
-    const unsigned slot0 = (unsigned)tid * 4u, slotEnd = slot0 + (unsigned)(kWvSlots + 1) * 1024u;   // byte offsets into s_hit
-    unsigned slotA = slot0;
-    int pend0 = -1, pend1 = -1, npend = 0;                              // query ids of undecided candidates
+    unsigned slot0[NT], slotEnd[NT], slotA[NT];                         // byte offsets into s_hit
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+        slot0[k] = (unsigned)(k * (kWvSlots + 2) * 256 + tid) * 4u;
+        slotEnd[k] = slot0[k] + (unsigned)(kWvSlots + 1) * 1024u;
+        slotA[k] = slot0[k];
+    }
+    int pend0 = -1, pend1 = -1, npend = 0;                              // undecided candidates: query id, tet of the lane in bit 30
     // the four planes as two packed pairs: v_pk_fma_f32 evaluates two of them per instruction (six instructions per
     // candidate where twelve v_fma_f32 stood; every half is the same IEEE fma in the same order, so A_i is unchanged)
     typedef float f32x2 __attribute__((ext_vector_type(2)));
-    const f32x2 Px01 = {F.N[0][0], F.N[1][0]}, Py01 = {F.N[0][1], F.N[1][1]}, Pz01 = {F.N[0][2], F.N[1][2]}, Pc01 = {F.C[0], F.C[1]};
-    const f32x2 Px23 = {F.N[2][0], F.N[3][0]}, Py23 = {F.N[2][1], F.N[3][1]}, Pz23 = {F.N[2][2], F.N[3][2]}, Pc23 = {F.C[2], F.C[3]};
+    f32x2 Px01[NT], Py01[NT], Pz01[NT], Pc01[NT], Px23[NT], Py23[NT], Pz23[NT], Pc23[NT];
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+        Px01[k] = f32x2{F[k].N[0][0], F[k].N[1][0]}; Py01[k] = f32x2{F[k].N[0][1], F[k].N[1][1]};
+        Pz01[k] = f32x2{F[k].N[0][2], F[k].N[1][2]}; Pc01[k] = f32x2{F[k].C[0], F[k].C[1]};
+        Px23[k] = f32x2{F[k].N[2][0], F[k].N[3][0]}; Py23[k] = f32x2{F[k].N[2][1], F[k].N[3][1]};
+        Pz23[k] = f32x2{F[k].N[2][2], F[k].N[3][2]}; Pc23[k] = f32x2{F[k].C[2], F[k].C[3]};
+    }
     auto test = [&](const float4 q) {
         const f32x2 qx = {q.x, q.x}, qy = {q.y, q.y}, qz = {q.z, q.z};
-        const f32x2 A01 = __builtin_elementwise_fma(Px01, qx, __builtin_elementwise_fma(Py01, qy, __builtin_elementwise_fma(Pz01, qz, Pc01)));
-        const f32x2 A23 = __builtin_elementwise_fma(Px23, qx, __builtin_elementwise_fma(Py23, qy, __builtin_elementwise_fma(Pz23, qz, Pc23)));
-        const float av = fminf(fminf(A01.x, A01.y), fminf(A23.x, A23.y));
         const int qi = __float_as_int(q.w);
-        if (av > F.twoEmax) {                                           // certain (twoEmax >= 0): kept in the lane's LDS slots, published
-            // after the loops (an atomic per acceptance here is a vector-memory instruction with one or two live lanes in
-            // most wave-iterations: 28 of them per wave kept the address unit as busy as the round-3 gathers did)
-            *reinterpret_cast<int *>(reinterpret_cast<char *>(&s_hit[0][0]) + slotA) = qi;
-            slotA = min(slotA + 1024u, slotEnd);
+        float av[NT];
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+            const f32x2 A01 = __builtin_elementwise_fma(Px01[k], qx, __builtin_elementwise_fma(Py01[k], qy, __builtin_elementwise_fma(Pz01[k], qz, Pc01[k])));
+            const f32x2 A23 = __builtin_elementwise_fma(Px23[k], qx, __builtin_elementwise_fma(Py23[k], qy, __builtin_elementwise_fma(Pz23[k], qz, Pc23[k])));
+            av[k] = fminf(fminf(A01.x, A01.y), fminf(A23.x, A23.y));
         }
-        const bool band = fabsf(av) <= F.twoEmax;                       // rare: decided by the reference predicate after the loops
+#pragma unroll
+        for (int k = 0; k < NT; ++k)
+            if (av[k] > F[k].twoEmax) {                                 // certain (twoEmax >= 0): kept in the tet's LDS slots, published
+                // after the loops (an atomic per acceptance here is a vector-memory instruction with one or two live lanes in
+                // most wave-iterations: 28 of them per wave kept the address unit as busy as the round-3 gathers did)
+                *reinterpret_cast<int *>(reinterpret_cast<char *>(&s_hit[0][0][0]) + slotA[k]) = qi;
+                slotA[k] = min(slotA[k] + 1024u, slotEnd[k]);
+            }
+        bool band = fabsf(av[0]) <= F[0].twoEmax;                       // rare: decided by the reference predicate after the loops
+#pragma unroll
+        for (int k = 1; k < NT; ++k) band = band || fabsf(av[k]) <= F[k].twoEmax;
         if (__builtin_amdgcn_ballot_w64(band) != 0ull) {                // (wave-uniform branch: the selects stay out of the common path)
             asm volatile("" ::: "memory");                              // (... and the compiler from turning the branch into selects)
-            pend1 = band ? pend0 : pend1;
-            pend0 = band ? qi : pend0;
-            npend = band ? npend + 1 : npend;
+#pragma unroll
+            for (int k = 0; k < NT; ++k) {
+                const bool bk = fabsf(av[k]) <= F[k].twoEmax;
+                pend1 = bk ? pend0 : pend1;
+                pend0 = bk ? (qi | (k << 30)) : pend0;
+                npend = bk ? npend + 1 : npend;
+            }
         }
     };
     // --- the groups' rows and queries are staged together, the lanes of both groups walk their ranges in one loop --------
@@ -1663,7 +1745,7 @@ __global__ __launch_bounds__(256, PIT_WAVES2) void k_tet_scan_wave(const float *
         const int N = __builtin_amdgcn_readlane(incl, 63);
         const int Rtot = rowsTot;
         // a row that does not fit a chunk by itself (very dense queries): nothing is staged, everybody walks the global table
-        const bool fitsRows = __builtin_amdgcn_ballot_w64(lmax > kWvCap) == 0ull && N < 65536;
+        const bool fitsRows = __builtin_amdgcn_ballot_w64(lmax > CAP) == 0ull && N < 65536;
         if (slabLane) {
 #pragma unroll
             for (int y = 0; y < 4; ++y)
@@ -1674,32 +1756,25 @@ __global__ __launch_bounds__(256, PIT_WAVES2) void k_tet_scan_wave(const float *
         }
         if (lane == 0) W.rowBase[Rtot] = (unsigned short)N;
         wave_sync();
-        if (PIT_STOP == 3) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { keep_alive(F.N[i][0]); keep_alive(F.N[i][1]); keep_alive(F.N[i][2]); keep_alive(F.C[i]); }
-            keep_alive(F.twoEmax); keep_alive(gid); keep_alive(N); keep_alive(pre[4]); keep_alive(lb);
-            keep_alive(cx0); keep_alive(cx1); keep_alive(cy0); keep_alive(cy1); keep_alive(cz0); keep_alive(cz1); keep_alive((int)work);
-            return;
-        }
         PHASE_MARK(4);                                                   // [4] row bounds, scan
         // the lane's rows: the slabs [cz0, cz1] of its group's footprint, all of the footprint's y rows
         const bool mine2 = gid == 1;
         const int rowOff = mine2 ? rowOff1 : 0, gz = mine2 ? gz0[1] : gz0[0], gs = mine2 ? gsh[1] : gsh[0];
         int rn = rowOff + ((cz0 - gz) << gs);                          // next row to walk
         const int re = rowOff + ((cz1 + 1 - gz) << gs);
-        if (!fitsRows) gid = -1;
+        if (!fitsRows) { REASON_COUNT(7, __builtin_amdgcn_ballot_w64(gid >= 0)); gid = -1; }
         int r0 = fitsRows ? 0 : Rtot;
 #pragma unroll 1
         while (r0 < Rtot) {                                              // chunks of whole rows
             const int B0 = __builtin_amdgcn_readfirstlane(W.rowBase[r0]);
             int r1 = Rtot;
-            if (N - B0 > kWvCap) {
+            if (N - B0 > CAP) {
                 r1 = r0;
 #pragma unroll 1
-                for (int j = 0; j < 3; ++j) {
+                for (int j = 0; j < ROWS / 64; ++j) {
                     const int rc = r0 + 1 + lane + 64 * j;
                     const int cnt = rc <= Rtot ? W.rowBase[rc] - B0 : 0x7FFFFFFF;
-                    const lanemask_t fits = __builtin_amdgcn_ballot_w64(cnt <= kWvCap);  // a prefix of the lanes (counts are monotone)
+                    const lanemask_t fits = __builtin_amdgcn_ballot_w64(cnt <= CAP);  // a prefix of the lanes (counts are monotone)
                     if (fits == ~0ull) { r1 += 64; continue; }
                     r1 += __ffsll((long long)~fits) - 1;
                     break;
@@ -1715,7 +1790,7 @@ __global__ __launch_bounds__(256, PIT_WAVES2) void k_tet_scan_wave(const float *
                 for (int y = 0; y < 4; ++y) {
                     if (y < (1 << sh)) {
                         const int r = rowId0 + y, p1 = W.rowBase[r + 1];
-                        if (p1 > p0 && r >= r0 && r < r1) W.marker[p0 - B0] = (unsigned char)(r + 1);
+                        if (p1 > p0 && r >= r0 && r < r1) W.marker[p0 - B0] = (typename Stage::marker_t)(r + 1);
                         p0 = p1;
                     }
                 }
@@ -1723,7 +1798,7 @@ __global__ __launch_bounds__(256, PIT_WAVES2) void k_tet_scan_wave(const float *
             wave_sync();
             int carry = 0;
 #pragma unroll
-            for (int j = 0; j < (kWvCap + 63) / 64; ++j)
+            for (int j = 0; j < (CAP + 63) / 64; ++j)
                 if (j * 64 < Nc) {
                     const int i = lane + 64 * j;
                     const int own = max(wave_scan_max(i < Nc ? W.marker[i] : 0), carry);
@@ -1741,7 +1816,7 @@ __global__ __launch_bounds__(256, PIT_WAVES2) void k_tet_scan_wave(const float *
             // values of a candidate to one lane — was measured: the vector instructions around the matrix ones (dead-slot masks,
             // minima, acceptance bookkeeping, the transposition through LDS) are as many as the 14 it replaces: 94 vs 82 us.)
             const int lo = max(rn, r0), hi = min(re, r1);
-            if (PIT_STOP != 4 && gid >= 0 && lo < hi) {
+            if (gid >= 0 && lo < hi) {
                 unsigned c = (unsigned)(W.rowBase[lo] - B0) * 16u;      // byte offsets into W.q
                 const unsigned e = (unsigned)(W.rowBase[hi] - B0) * 16u;
                 PHASE_COUNT(13, (e - c) >> 4);
@@ -1769,14 +1844,23 @@ __global__ __launch_bounds__(256, PIT_WAVES2) void k_tet_scan_wave(const float *
     PHASE_COUNT(14, __popcll(__builtin_amdgcn_ballot_w64(work && gid < 0)));
     PHASE_MARK(1);                                                       // [1] staged traversal
     // --- global walk for the lanes (slabs) no group covered: the slab cursor of k_tet_scan_slab ---------------------------
-    if (work && gid < 0) {
+    if (PIT_DBG_WALK && work && gid < 0) {
         CellBox cb;
         {
-            float tv[12], mrg2;
-            const float *src = tet + ((size_t)b * T + tet_id()) * 12;
+            cb.cx0 = cb.cy0 = cb.cz0 = 0x7FFF;
+            cb.cx1 = cb.cy1 = cb.cz1 = 0;
 #pragma unroll
-            for (int k = 0; k < 12; ++k) tv[k] = src[k];
-            tet_cell_box(tv, g, G, Gx, cb, mrg2);
+            for (int k = 0; k < NT; ++k) {
+                if (NT > 1 && !works[k]) continue;
+                float tv[12], mrg2;
+                const float *src = tet + ((size_t)b * T + tet_id(k)) * 12;
+#pragma unroll
+                for (int j = 0; j < 12; ++j) tv[j] = src[j];
+                CellBox c1;
+                tet_cell_box(tv, g, G, Gx, c1, mrg2);
+                cb.cx0 = min(cb.cx0, c1.cx0); cb.cx1 = max(cb.cx1, c1.cx1); cb.cy0 = min(cb.cy0, c1.cy0); cb.cy1 = max(cb.cy1, c1.cy1);
+                cb.cz0 = min(cb.cz0, c1.cz0); cb.cz1 = max(cb.cz1, c1.cz1);
+            }
         }
         const int cx0 = cb.cx0, cx1 = cb.cx1, cy0 = cb.cy0, cy1 = cb.cy1, cz1 = cb.cz1, czn = cb.cz0;
         const int ny = cy1 - cy0 + 1;
@@ -1817,66 +1901,98 @@ __global__ __launch_bounds__(256, PIT_WAVES2) void k_tet_scan_wave(const float *
         }
     }
     PHASE_MARK(2);                                                       // [2] global walk
-    int hcnt = (int)((slotA - slot0) >> 10);                            // accepted (kWvSlots + 1 stands for "more than kWvSlots")
     if (!valid) return;
-    // (the addresses of this lane's tet, record, ... are formed from `te` HERE: hoisted to the top of the kernel they are
-    // six more live registers across the staged loop — the difference between five and six waves per SIMD)
-    int te = tet_id();
-    asm volatile("" : "+v"(te));
-    if (!regular) {                                                      // (out-of-line call placed where almost nothing is live)
-        irregular_tet_slow(tet, te, b, T, Q, pts, counters, irregT, irregQ, result, hits);
-        return;
-    }
-    if (npend > 0) {                                                     // undecided candidates (rare)
-        const float *tv = tet + ((size_t)b * T + te) * 12;
+    int hcnt[NT];                                                        // accepted (kWvSlots + 1 stands for "more than kWvSlots")
+#pragma unroll
+    for (int k = 0; k < NT; ++k) hcnt[k] = (int)((slotA[k] - slot0[k]) >> 10);
+    if (PIT_DBG_PEND && npend > 0) {                                     // undecided candidates (rare)
         atomicAdd(&counters[gridDim.y * 4 + b * 4 + 1], npend);         // statistics: candidates decided exactly
         if (npend > 2) {
-            hcnt = exact_rescan_slots(tv, te, tb, sq, result + (size_t)b * Q, gparam + b * kGridWords, G, Gx, &s_hit[0][tid]);
+#pragma unroll
+            for (int k = 0; k < NT; ++k)
+                if (works[k]) {
+                    const int te = tet_id(k);
+                    hcnt[k] = exact_rescan_slots(tet + ((size_t)b * T + te) * 12, te, tb, sq, result + (size_t)b * Q, gparam + b * kGridWords, G, Gx,
+                                                 &s_hit[k][0][tid]);
+                }
         } else {
-            for (int k = 0; k < npend; ++k) {
-                const int qi = k == 0 ? pend0 : pend1;
-                const float *pq = pts + ((size_t)b * Q + qi) * 3;
-                if (exact_accept(tv, pq[0], pq[1], pq[2]) > 0.f) {
+            for (int j = 0; j < npend; ++j) {
+                const int pq = j == 0 ? pend0 : pend1;
+                const int k = NT == 1 ? 0 : (pq >> 30) & 1, qi = pq & 0x3FFFFFFF;
+                const int te = tet_id(k);
+                const float *pp = pts + ((size_t)b * Q + qi) * 3;
+                if (exact_accept(tet + ((size_t)b * T + te) * 12, pp[0], pp[1], pp[2]) > 0.f) {
                     atomicMin(&result[(size_t)b * Q + qi], te);
-                    s_hit[min(hcnt, kWvSlots)][tid] = qi;
-                    ++hcnt;
+                    if (NT == 1 || k == 0) { s_hit[0][min(hcnt[0], kWvSlots)][tid] = qi; ++hcnt[0]; }
+                    else { s_hit[NT - 1][min(hcnt[NT - 1], kWvSlots)][tid] = qi; ++hcnt[NT - 1]; }
                 }
             }
         }
     }
-    if (hcnt > kWvSlots) {                                               // more acceptances than slots (dense queries): the out-of-line exact
-        const float *tv = tet + ((size_t)b * T + te) * 12;               // walk publishes every one of them
-        hcnt = exact_rescan_slots(tv, te, tb, sq, result + (size_t)b * Q, gparam + b * kGridWords, G, Gx, &s_hit[0][tid]);
-    }
-#pragma unroll 1
-    for (int i = 0; i < kWvSlots; ++i) {                                 // publish: one atomic instruction per slot level in use
-        if (__builtin_amdgcn_ballot_w64(hcnt > i) == 0ull) break;
-        if (hcnt > i) atomic_smin_off_nh(resb, (unsigned)s_hit[i][tid] * 4u, te);
-    }
-    if (hits) {
-        // <= 4 accepted: the record; 5..kWvSlots: the record (flagged) + the spill record; more: overflow marker (the hits are
-        // then carried by the uncovered list, see k_finalize)
-        int h[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) h[i] = -1;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (i < hcnt) h[i] = s_hit[i][tid];
-        const bool spilled = hcnt > 4 && hcnt <= kWvSlots && spill != nullptr;
-        const bool over = hcnt > 4 && !spilled;
-        if (spilled) {
-#pragma unroll
-            for (int i = 4; i < kWvSlots; ++i)
-                if (i < hcnt) h[i] = s_hit[i][tid];
-            spill[(size_t)b * T + te] = make_int4(h[4], h[5], h[6], h[7]);
-            h[0] |= kHitSpilled;
+    for (int k = 0; k < NT; ++k) {
+        if (NT > 1 && !tet_exists(k)) continue;                          // (odd list: the last lane has one tet)
+        // (the addresses of this tet, its record, ... are formed from `te` HERE: hoisted to the top of the kernel they are
+        // six more live registers across the staged loop — the difference between five and six waves per SIMD)
+        int te = tet_id(k);
+        asm volatile("" : "+v"(te));
+        if (!regular[k]) {                                               // (out-of-line call placed where almost nothing is live)
+            irregular_tet_slow(tet, te, b, T, Q, pts, counters, irregT, irregQ, result, hits);
+            continue;
         }
-        if (over) note_overflow(counters, gridDim.y, b, te);
-        hits[(size_t)b * T + te] = over ? make_int4(-1, -1, -1, kHitOverflow) : make_int4(h[0], h[1], h[2], h[3]);
+        int hc = hcnt[k];
+        if (hc > kWvSlots) {                                             // more acceptances than slots (dense queries): the out-of-line exact
+            const float *tv = tet + ((size_t)b * T + te) * 12;           // walk publishes every one of them
+            hc = exact_rescan_slots(tv, te, tb, sq, result + (size_t)b * Q, gparam + b * kGridWords, G, Gx, &s_hit[k][0][tid]);
+        }
+#pragma unroll 1
+        for (int i = 0; i < kWvSlots; ++i) {                             // publish: one atomic instruction per slot level in use
+            if (__builtin_amdgcn_ballot_w64(hc > i) == 0ull) break;
+            if (hc > i) atomic_smin_off_nh(resb, (unsigned)s_hit[k][i][tid] * 4u, te);
+        }
+        if (hits) {
+            // <= 4 accepted: the record; 5..kWvSlots: the record (flagged) + the spill record; more: overflow marker (the hits are
+            // then carried by the uncovered list, see k_finalize)
+            int h[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) h[i] = -1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i < hc) h[i] = s_hit[k][i][tid];
+            const bool spilled = hc > 4 && hc <= kWvSlots && spill != nullptr;
+            const bool over = hc > 4 && !spilled;
+            if (spilled) {
+#pragma unroll
+                for (int i = 4; i < kWvSlots; ++i)
+                    if (i < hc) h[i] = s_hit[k][i][tid];
+                spill[(size_t)b * T + te] = make_int4(h[4], h[5], h[6], h[7]);
+                h[0] |= kHitSpilled;
+            }
+            if (over) note_overflow(counters, gridDim.y, b, te);
+            hits[(size_t)b * T + te] = over ? make_int4(-1, -1, -1, kHitOverflow) : make_int4(h[0], h[1], h[2], h[3]);
+        }
+        irregular_tail(tet, te, b, T, Q, pts, counters, irregQ, result);
     }
-    irregular_tail(tet, te, b, T, Q, pts, counters, irregQ, result);
     PHASE_MARK(3);                                                       // [3] exact decisions, records
 }
+
+#define PIT_SCAN_PARAMS                                                                                                               \
+    const float *__restrict__ tet, int T, int Q, const float *__restrict__ gparam, int G, int Gx, const int *__restrict__ table,      \
+        long long cellStride, const float4 *__restrict__ sortedQ, int *result, int *counters, int *irregT, int4 *hits,                \
+        const float *__restrict__ pts, const int *__restrict__ irregQ, int *ucount, int hpad, int4 *spill, const int *__restrict__ order
+#define PIT_SCAN_FWD tet, T, Q, gparam, G, Gx, table, cellStride, sortedQ, result, counters, irregT, hits, pts, irregQ, ucount, hpad, spill, order
+template <bool ORD>
+__global__ __launch_bounds__(256, PIT_WAVES2) void k_tet_scan_wave(PIT_SCAN_PARAMS)
+{
+    tet_scan_wave_body<ORD, 1>(PIT_SCAN_FWD);
+}
+template <bool ORD>
+__global__ __launch_bounds__(256, PIT_WAVES_PAIR) void k_tet_scan_pair(PIT_SCAN_PARAMS)
+{
+    tet_scan_wave_body<ORD, 2>(PIT_SCAN_FWD);
+}
+#undef PIT_SCAN_PARAMS
+#undef PIT_SCAN_FWD
 
 // barycentric weights, utils/tet_utils.py:25-45 (same association as the torch expression)
 __device__ __forceinline__ float triple(const float *a, const float *b, const float *c)
@@ -2573,6 +2689,8 @@ static const Tunables &tunables()
 static int resolve_auto(int algo, int T, int Q)
 {
     if (algo != DEFTET_PIT_AUTO) return algo;
+    // (DEFTET_PIT_PAIR, two tets per lane, executes 4 % fewer instructions but lives at five waves per SIMD with waves that
+    // take 1.5x as long: 79-89 against 63-67 us at configs[2], 173-187 against 141-153 at configs[3]; round 5)
     return (double)Q <= 0.6 * (double)T ? DEFTET_PIT_WAVE : DEFTET_PIT_SLAB;
 }
 
@@ -2666,7 +2784,7 @@ static int pit_check(const float *tet, const float *pts, const float *cond, cons
     DEFTET_CHECK_ARG((pred == nullptr) == (occ == nullptr), "pred and occ must be given together");
     DEFTET_CHECK_ARG(!occ || T > 0, "paste_occ needs at least one tet");
     DEFTET_CHECK_ARG(B >= 0 && T >= 0 && Q >= 0, "negative size (B=%d T=%d Q=%d)", B, T, Q);
-    DEFTET_CHECK_ARG(algo == DEFTET_PIT_AUTO || algo == DEFTET_PIT_BRUTE || algo == DEFTET_PIT_EXACT || algo == DEFTET_PIT_SLAB || algo == DEFTET_PIT_WAVE, "unknown algo %d", algo);
+    DEFTET_CHECK_ARG(algo == DEFTET_PIT_AUTO || algo == DEFTET_PIT_BRUTE || algo == DEFTET_PIT_EXACT || algo == DEFTET_PIT_SLAB || algo == DEFTET_PIT_WAVE || algo == DEFTET_PIT_PAIR, "unknown algo %d", algo);
     if (T >= (1 << 24)) return set_error(DEFTET_ELIMIT, "n_tet=%d does not fit a float-encoded index (2^24)", T);
     DEFTET_CHECK_ARG(B <= 65535, "n_batch=%d exceeds the grid-y limit 65535", B);
     if (Q >= (1 << 27)) return set_error(DEFTET_ELIMIT, "n_query=%d: 16-byte query records are addressed with 32-bit byte offsets (limit 2^27)", Q);
@@ -2705,11 +2823,15 @@ static int pit_scan(const Layout &L, const float *tet, const float *pts, float *
                           L.counters, L.irregT, (int4 *)hit_buf, pts, L.irregQ, ucount, hit_pad(B));
         } else {
             int4 *spill = hit_buf ? (int4 *)(hit_buf + hit_spill_off(B, T, Q)) : (int4 *)nullptr;
-            const bool slab = resolve_auto(algo, T, Q) == DEFTET_PIT_SLAB;
+            const int kern = resolve_auto(algo, T, Q);
+            const bool slab = kern == DEFTET_PIT_SLAB;
+            const dim3 gp(((((T + 1) / 2 + 255) / 256 + 7) / 8) * 8, B);                  // two tets per lane
 #define PIT_SCAN_ARGS tet, T, Q, L.gparam, L.G, L.Gx, L.table, L.cellStride, L.sortedQ, L.result, L.counters, L.irregT, (int4 *)hit_buf, pts, \
                       L.irregQ, ucount, hit_pad(B), spill, (const int *)order
             if (slab && order) DEFTET_LAUNCH(k_tet_scan_slab<true>, gt, blk, st, PIT_SCAN_ARGS);
             else if (slab) DEFTET_LAUNCH(k_tet_scan_slab<false>, gt, blk, st, PIT_SCAN_ARGS);
+            else if (kern == DEFTET_PIT_PAIR && order) DEFTET_LAUNCH(k_tet_scan_pair<true>, gp, blk, st, PIT_SCAN_ARGS);
+            else if (kern == DEFTET_PIT_PAIR) DEFTET_LAUNCH(k_tet_scan_pair<false>, gp, blk, st, PIT_SCAN_ARGS);
             else if (order) DEFTET_LAUNCH(k_tet_scan_wave<true>, gt, blk, st, PIT_SCAN_ARGS);
             else DEFTET_LAUNCH(k_tet_scan_wave<false>, gt, blk, st, PIT_SCAN_ARGS);
 #undef PIT_SCAN_ARGS
@@ -2772,7 +2894,7 @@ extern "C" int deftet_point_in_tet_prepare_f32(const float *pts, int B, int T, i
                                                size_t workspace_bytes, void *stream_)
 {
     DEFTET_CHECK_ARG(B >= 0 && T >= 0 && Q >= 0 && B <= 65535, "bad size (B=%d T=%d Q=%d)", B, T, Q);
-    DEFTET_CHECK_ARG(algo == DEFTET_PIT_AUTO || algo == DEFTET_PIT_EXACT || algo == DEFTET_PIT_SLAB || algo == DEFTET_PIT_WAVE, "prepare needs a binned algo (got %d)", algo);
+    DEFTET_CHECK_ARG(algo == DEFTET_PIT_AUTO || algo == DEFTET_PIT_EXACT || algo == DEFTET_PIT_SLAB || algo == DEFTET_PIT_WAVE || algo == DEFTET_PIT_PAIR, "prepare needs a binned algo (got %d)", algo);
     if (Q >= (1 << 27)) return set_error(DEFTET_ELIMIT, "n_query=%d exceeds 2^27", Q);
     if (B == 0 || Q == 0) return DEFTET_OK;
     DEFTET_CHECK_ARG(pts, "null pts pointer");
@@ -2830,6 +2952,15 @@ extern "C" int deftet_point_in_tet_read_stats(const void *workspace, size_t work
 }
 
 #ifdef PIT_PHASE_TIMING
+extern "C" int deftet_debug_reason_read(unsigned long long *out8, int reset)
+{
+    DEFTET_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(deftet::pit::g_reason), 64));
+    if (reset) {
+        unsigned long long z[8] = {0};
+        DEFTET_HIP(hipMemcpyToSymbol(HIP_SYMBOL(deftet::pit::g_reason), z, 64));
+    }
+    return DEFTET_OK;
+}
 extern "C" int deftet_debug_phase_read(unsigned long long *out16, int reset)
 {
     std::vector<unsigned long long> h((size_t)kPhaseWaves * 16);

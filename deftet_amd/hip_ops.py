@@ -11,8 +11,8 @@ import torch
 
 from . import _lib
 
-PIT_AUTO, PIT_BRUTE, PIT_EXACT, PIT_SLAB, PIT_WAVE = 0, 1, 2, 3, 4        # include/deftet_hip.h DEFTET_PIT_*
-_PIT_KERNEL = {PIT_WAVE: "k_tet_scan_wave", PIT_EXACT: "k_tet_scan", PIT_BRUTE: "k_brute", PIT_SLAB: "k_tet_scan_slab"}
+PIT_AUTO, PIT_BRUTE, PIT_EXACT, PIT_SLAB, PIT_WAVE, PIT_PAIR = 0, 1, 2, 3, 4, 5        # include/deftet_hip.h DEFTET_PIT_*
+_PIT_KERNEL = {PIT_WAVE: "k_tet_scan_wave", PIT_EXACT: "k_tet_scan", PIT_BRUTE: "k_brute", PIT_SLAB: "k_tet_scan_slab", PIT_PAIR: "k_tet_scan_pair"}
 
 
 def pit_kernel_name(algo, n_tet=None, n_query=None):
@@ -107,7 +107,7 @@ def auto_tet_order(tet_bxtx4x3, pts_bxqx3, algo=PIT_AUTO):
     if mode == "off" or T < 4096 or B == 0 or Q == 0:
         return None
     kernel = int(_lib.load().deftet_point_in_tet_resolve_algo(int(algo), T, Q))
-    if kernel not in (PIT_SLAB, PIT_WAVE):
+    if kernel not in (PIT_SLAB, PIT_WAVE, PIT_PAIR):
         return None
     key = (dev.index if dev.index is not None else torch.cuda.current_device(), T, kernel)
     with _order_lock:
@@ -177,7 +177,7 @@ def point_in_tet(tet_bxtx4x3, pts_bxqx3, want_bary=False, algo=PIT_AUTO, pred_bx
     if isinstance(order, str):
         if order != "auto":
             raise RuntimeError("order must be None, 'auto' or an int32 [T] permutation")
-        order = auto_tet_order(tet, pts, algo) if algo in (PIT_AUTO, PIT_SLAB, PIT_WAVE) else None
+        order = auto_tet_order(tet, pts, algo) if algo in (PIT_AUTO, PIT_SLAB, PIT_WAVE, PIT_PAIR) else None
     if order is not None:
         _lib.require_gpu(order)
         if order.dtype != torch.int32 or order.shape != (T,) or not order.is_contiguous() or order.device != dev:

@@ -40,6 +40,7 @@ extern "C" {
 #define DEFTET_PIT_EXACT 2   /* binned, box test + exact predicate on every candidate (no filter; independent cross-check) */
 #define DEFTET_PIT_SLAB 3    /* per-lane walk of the global cell table, three candidates per wave-iteration (k_tet_scan_slab) */
 #define DEFTET_PIT_WAVE 4    /* a wave stages the candidates of its 64 tets in LDS, filter-only per-tet setup (k_tet_scan_wave) */
+#define DEFTET_PIT_PAIR 5    /* the same with two tets per lane: a wave stages once for 128 tets (k_tet_scan_pair; measured slower, never AUTO) */
 
 /* 200: round 4.  (deftet_tet_energies_workspace_bytes(B) is gone: the forward needs ..._bytes2(B, T).  Algorithm ids other
  * than the DEFTET_PIT_* values above — the STAGED / ROWS / ... ids 2-11 of the round-2 library — are rejected with

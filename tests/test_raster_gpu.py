@@ -150,7 +150,7 @@ def test_backward_matches_fp64_autograd(cuda, oracle):
     from tests.tol import check_close
     for nm, got, want in (("xy", txy.grad, xy64.grad), ("feat", tff.grad, ff64.grad)):
         assert want.abs().max().item() > 0
-        check_close("A12 grad_%s through compositing, res6 24x24 k48 vs fp64 autograd" % nm, got, want, 2e-4)
+        check_close("A12 grad_%s through compositing, res6 24x24 k48 vs fp64 autograd" % nm, got, want, 6e-7, elem_rel=1.5e-4)
     # faces that no pixel hit get exactly zero gradient
     hit = torch.zeros(fxy.shape[1], dtype=torch.bool)
     hit[face.cpu()[face.cpu() >= 0]] = True
@@ -180,7 +180,7 @@ def test_backward_other_feature_widths_and_batches(cuda, oracle, D, B):
     wxy, wff = torch.autograd.grad(feat64, (xy64, ff64), go.double())
     from tests.tol import check_close
     for nm, got, want in (("xy", gxy, wxy), ("feat", gff, wff)):
-        check_close("A12 grad_%s, D=%d B=%d vs fp64 autograd" % (nm, D, B), got, want, 2e-4)
+        check_close("A12 grad_%s, D=%d B=%d vs fp64 autograd" % (nm, D, B), got, want, 6e-7, elem_rel=3e-5)
     assert (face >= 0).sum().item() > 1000 * B
 
 
@@ -208,10 +208,11 @@ def test_backward_face_with_thousands_of_hits(cuda, oracle):
     ff64 = tff.detach().double().requires_grad_(True)
     feat64 = oracle.sparse_render_torch(tp.double(), xy64, ff64, face)
     wxy, wff = torch.autograd.grad(feat64, (xy64, ff64), go.double())
-    for got, want in ((gxy, wxy), (gff, wff)):
+    from tests.tol import check_close
+    for nm, got, want in (("xy", gxy, wxy), ("feat", gff, wff)):
         for f in (150, 151):
-            assert (got[0, f].double() - want[0, f]).abs().max().item() <= 1e-4 * want[0, f].abs().max().item()
-        assert (got.double() - want).abs().max().item() <= 2e-4 * want.abs().max().item()
+            check_close("A12 grad_%s of a face with 9,216 hits vs fp64 autograd" % nm, got[0, f], want[0, f], 1e-4)
+        check_close("A12 grad_%s, 96x96 pixels, two faces with 9,216 hits vs fp64 autograd" % nm, got, want, 2e-4)
 
 
 def test_backward_baseline_config_fp64(cuda, oracle):
@@ -240,7 +241,10 @@ def test_backward_baseline_config_fp64(cuda, oracle):
         big = mag > 1e-3 * mag.max()
         assert (err[big] / mag[big]).max().item() < 2e-3
         from tests.tol import check_close
-        check_close("A12 grad (%s), configs[4] 512x512 k64 vs fp64 autograd" % ("xy" if got is gxy else "feat"), got, want, 2e-4)
+        # (xy: a face's gradient is the sum of up to a few hundred per-hit terms of mixed sign, each ~1/extent large: fp32
+        # accumulation error relative to the LARGEST entry is sqrt(hits) * u * sum|terms| / max — measured 3.6e-5; feat: 4e-7)
+        check_close("A12 grad (%s), configs[4] 512x512 k64 vs fp64 autograd" % ("xy" if got is gxy else "feat"), got, want,
+                    8e-5 if got is gxy else 1e-6)
         # run-to-run: only faces whose hits straddle three or more waves may differ, and only by rounding
         assert (again.double() - got.double()).abs().max().item() <= 1e-5 * want.abs().max().item()
     hit = torch.zeros(fxy.shape[1], dtype=torch.bool, device=cuda)

@@ -101,4 +101,4 @@ def test_module_autograd_chain(cuda, oracle):
     wc = torch.stack(oracle.bary_torch(sel[:, :, 0], sel[:, :, 1], sel[:, :, 2], sel[:, :, 3], pq), dim=-1) * hit[..., None]
     (wc * gw.cpu().double()).sum().backward()
     from tests.tol import check_close
-    check_close("N2 module chain grad_pos (gather + A1b backward), res8 vs fp64 autograd", p.grad, pc.grad, 1e-4)
+    check_close("N2 module chain grad_pos (gather + A1b backward), res8 vs fp64 autograd", p.grad, pc.grad, 5e-7, elem_rel=1e-4)

@@ -54,14 +54,14 @@ while time.time() < t_end:
         k = max(1, Q // 20)
         pts[:, :k] = float("nan"); pts[:, k:2 * k] = 3e6 * scale
     ref = hip_ops.point_in_tet(tet, pts, algo=1)
-    for algo in (0, 2, 3, 4):
+    for algo in (0, 2, 3, 4, 5):
         got = hip_ops.point_in_tet(tet, pts, algo=algo)
         if not torch.equal(got, ref):
             bad = (got != ref).nonzero()[0].tolist()
             print("MISMATCH algo=%d B=%d T=%d Q=%d kind=%d scale=%g size=%g at %s: %s vs %s" % (algo, B, T, Q, kind, scale, size, bad, got[tuple(bad)].item(), ref[tuple(bad)].item()), flush=True)
             sys.exit(1)
     pred = torch.rand(B, T, device=dev, generator=g)
-    falgo = int(rng.choice([0, 2, 3, 4]))
+    falgo = int(rng.choice([0, 2, 3, 4, 5]))
     cond, w, occ, hits = hip_ops.point_in_tet(tet, pts, want_bary=True, pred_bxt=pred, want_hits=True, algo=falgo)
     assert torch.equal(cond, ref)
     gw = torch.randn(B, Q, 4, device=dev, generator=g); go = torch.randn(B, Q, device=dev, generator=g)

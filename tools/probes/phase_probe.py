@@ -32,6 +32,9 @@ for _ in range(2):
 torch.cuda.synchronize()
 buf = (ctypes.c_ulonglong * 16)()
 raw.deftet_debug_phase_read(buf, 1)
+rbuf = (ctypes.c_ulonglong * 8)()
+if hasattr(raw, "deftet_debug_reason_read"):
+    raw.deftet_debug_reason_read(rbuf, 1)
 reps = 4
 for _ in range(reps):
     hip_ops.point_in_tet(d["tet"], d["pts"], want_bary=True, pred_bxt=d["pred"], want_hits=True, algo=a.algo)
@@ -45,3 +48,7 @@ print(json.dumps({"kernel": "k_slab_sort", "waves_per_launch": n_sort // reps, "
     k: round(buf[8 + i] / n_sort) for i, k in enumerate(["loads+clear", "count", "scan", "placement", "table"])}}), flush=True)
 print(json.dumps({"kernel": hip_ops.pit_kernel_name(a.algo, wl.T, wl.Q), "waves_per_launch": n_waves // reps,
                   "cycles_per_wave": {k: round(v, 2) for k, v in zip(names, vals)}, "total": round(sum(vals[:7]))}), flush=True)
+if hasattr(raw, "deftet_debug_reason_read"):
+    raw.deftet_debug_reason_read(rbuf, 1)
+    print(json.dumps({"ungrouped_lanes_per_launch": dict(zip(["few_left_p0", "few_left_p1", "small_pivot_group(all remaining)", "five_rows", "slabs>64", "rows>cap",
+                                                               "left_after_two_groups", "row_longer_than_chunk"], [int(rbuf[i]) // reps for i in range(8)]))}), flush=True)
