@@ -222,6 +222,7 @@ class RasterWorkload:
         self.pairs_per_step = float(self.P) * self.F
         self.unit = "M ray-face tests/s"
         self.dominant = b"k_pix_raster"
+        self.valu_files = ("profiles/r05_pmc_raster.json",)       # (counters of THIS round's kernel only)
         # SURVEY 8(d) A12 fwd: F*(12+24+48) + P*(8+8) + P*k*(16+4)
         self.dominant_bytes = self.F * 84.0 + self.P * 16.0 + self.P * self.k * 20.0
         self.step_bytes = 2.0 * self.dominant_bytes
@@ -266,6 +267,7 @@ class GeometryWorkload:
         self.pairs_per_step = float(B)
         self.unit = "shapes/s"
         self.dominant = b"k_tri_query_coop"
+        self.valu_files = ("profiles/r05_pmc_geometry.json",)
         self.dominant_bytes = 0.0
         self.step_bytes = 0.0
         self.last = None
@@ -281,7 +283,7 @@ class GeometryWorkload:
     def describe(self):
         return {"workload": "%s: T=%d tets, %d GT points and %d queries per shape, DefTet.forward_surface_align (gather, check_sign, boundary "
                             "faces, energies, ragged A8/A9/A10 surface terms) + occupancy query, fwd + bwd to the vertices; the largest "
-                            "kernel (A9 k_tri_query_coop) is VALU-bound, no HBM roofline is quoted" % (
+                            "kernel (A9 k_tri_query_coop) is VALU-bound: its roofline is the issue fraction" % (
                                 self.cfg["name"], self.T, self.gt.shape[1], self.Q)}
 
 
@@ -473,7 +475,7 @@ def traffic_record(kernel):
     tools/pmc_traffic.py collected for the same command.  It is only quoted while the kernel source it was measured on
     (sha1 of deftet_amd/csrc/point_in_tet.hip, stored in the file) is still the one in the tree; otherwise null."""
     import hashlib
-    for rel in ("profiles/r04_pmc_traffic.json", "profiles/r03_pmc_traffic.json"):
+    for rel in ("profiles/r05_pmc_traffic.json", "profiles/r04_pmc_traffic.json", "profiles/r03_pmc_traffic.json"):
         path = os.path.join(ROOT, rel)
         if not os.path.exists(path):
             continue
@@ -492,6 +494,26 @@ def traffic_record(kernel):
     return None, None, None
 
 
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 4.0            # G wave-instructions/s: 1,024 SIMDs, one 64-lane VALU instruction per 4 cycles at 2.4 GHz
+
+
+def valu_record(kernel, files):
+    """SQ_INSTS_VALU per launch of `kernel` from a tools/pmc_run.sh summary (counters cannot be read from inside the timed
+    process: the same rule as traffic_record — quoted with its source file, null when there is none)."""
+    for rel in files:
+        path = os.path.join(ROOT, rel)
+        if not os.path.exists(path):
+            continue
+        try:
+            rec = json.load(open(path))
+        except Exception:
+            continue
+        for name, c in rec.items():
+            if isinstance(c, dict) and kernel in name and "SQ_INSTS_VALU" in c:
+                return c["SQ_INSTS_VALU"], rel
+    return None, None
+
+
 def summarize(wl, elapsed, per_step, kern_ms_tot, kern_cnt, steps, world, peak_measured=None):
     kern_ms = kern_ms_tot / max(kern_cnt, 1)
     achieved = wl.dominant_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
@@ -502,6 +524,17 @@ def summarize(wl, elapsed, per_step, kern_ms_tot, kern_cnt, steps, world, peak_m
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": src, "traffic_commit": tcommit,
             "algorithmic_bytes_per_launch": wl.dominant_bytes, "avg_launch_ms": round(kern_ms, 5), "launches_timed": int(kern_cnt),
             "whole_step": {"algorithmic_bytes": wl.step_bytes, "achieved": round(step_gbs, 1), "frac": round(step_gbs / HBM_PEAK_GBS, 4)}}
+    if getattr(wl, "valu_files", None):
+        # a VALU-bound kernel gets a VALU figure: wave-instructions per launch (rocprofv3 --pmc SQ_INSTS_VALU) over the launch's
+        # duration measured HERE, against the chip's issue rate — next to the HBM fraction (rasterizer) or instead of it (A9 query)
+        insts, src = valu_record(kernel, wl.valu_files)
+        if insts and kern_ms > 0:
+            ach = insts / (kern_ms * 1e-3) / 1e9
+            roof["valu"] = {"bound": "valu", "achieved": round(ach, 1), "peak": round(VALU_PEAK_GINST, 1), "unit": "G wave-instructions/s",
+                            "frac": round(ach / VALU_PEAK_GINST, 4), "insts_per_launch": insts, "insts_source": src}
+            if wl.dominant_bytes <= 0:
+                roof.update({"bound": "valu", "achieved": roof["valu"]["achieved"], "peak": roof["valu"]["peak"], "unit": roof["valu"]["unit"],
+                             "frac": roof["valu"]["frac"]})
     if peak_measured:
         roof["peak_measured"] = {"copy_GBs": round(peak_measured["copy"], 1), "read_GBs": round(peak_measured["read"], 1),
                                  "how": "1 GiB float4 streaming kernel of the library (copy: read+write bytes; read-only pass) on this GPU, HIP events"}
@@ -693,6 +726,10 @@ def main():
                         entry["ms_per_step_hipgraph"] = graph_replay(w2, k2)[0]
                     if w2.dominant_bytes > 0:
                         entry["roofline"] = {k: rec["roofline"][k] for k in ("kernel", "achieved", "frac", "avg_launch_ms", "whole_step")}
+                        if "valu" in rec["roofline"]:
+                            entry["roofline"]["valu"] = rec["roofline"]["valu"]
+                    elif "valu" in rec["roofline"]:
+                        entry["roofline"] = dict(rec["roofline"]["valu"], kernel=rec["roofline"]["kernel"], avg_launch_ms=rec["roofline"]["avg_launch_ms"])
                     else:
                         entry["dominant_kernel"] = {"kernel": rec["roofline"]["kernel"], "avg_launch_ms": rec["roofline"]["avg_launch_ms"]}
                     others.append(entry)

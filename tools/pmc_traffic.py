@@ -51,7 +51,8 @@ def main(fetch_dir, write_dir):
         out["per_kernel"][k] = {"FETCH_SIZE_bytes_raw": round(f.get(k, 0.0)), "fetch_bytes_corrected_x2": round(2 * f.get(k, 0.0)),
                                 "WRITE_SIZE_bytes": round(w.get(k, 0.0))}
     for k, v in out["per_kernel"].items():                      # "<short kernel name>_hbm_bytes_per_launch" (bench.py reads the dominant kernel's)
-        out["%s_hbm_bytes_per_launch" % k.split("::")[-1]] = v["fetch_bytes_corrected_x2"] + v["WRITE_SIZE_bytes"]
+        short = re.sub(r"<.*", "", k.split("::")[-1])              # template instances share their kernel's key (k_tet_scan_wave<false>)
+        out["%s_hbm_bytes_per_launch" % short] = out.get("%s_hbm_bytes_per_launch" % short, 0) or (v["fetch_bytes_corrected_x2"] + v["WRITE_SIZE_bytes"])
     step = sum(v["fetch_bytes_corrected_x2"] + v["WRITE_SIZE_bytes"] for v in out["per_kernel"].values())
     out["whole_step_hbm_bytes"] = step
     print(json.dumps(out, indent=1))
