@@ -90,6 +90,10 @@ class PitWorkload:
         # traversal order handed to the operator: "auto" (what the autograd ops pass: decided once per grid), "native" (none),
         # "sorted" (the computed column order, unconditionally) — DEFTET_BENCH_TET_ORDER / cfg["tet_order"]; never changes a result
         self.order_mode = cfg.get("tet_order") or os.environ.get("DEFTET_BENCH_TET_ORDER", "auto")
+        # query grid box: "track" (what the autograd ops pass: the box the previous step's queries measured, one launch fewer;
+        # the steps rotate over input sets with DIFFERENT queries) or "measure" (every step measures its own) — DEFTET_BENCH_QUERY_BOX
+        qb = cfg.get("query_box") or os.environ.get("DEFTET_BENCH_QUERY_BOX", "track")
+        self.query_box = "track" if qb == "track" else None
         self.sets, self.host = [], None
         # N > 1: the sets are generated ON THE GPU (same distributions, torch generators seeded per rank and set): eight
         # ranks x several sets of res-100 numpy jitter + gathers on one host are minutes of CPU before the first step.  N = 1
@@ -171,17 +175,17 @@ class PitWorkload:
             # step i's traversal has been launched; every step still does all of its work (K sorts in K timed steps)
             pq = self._pq.pop(i, None)
             if pq is None:
-                pq = hip_ops.prepare_queries(d["pts"], self.T, algo=self.algo)
+                pq = hip_ops.prepare_queries(d["pts"], self.T, algo=self.algo, query_box=self.query_box)
             cond, w, occ, hits = hip_ops.point_in_tet(d["tet"], d["pts"], want_bary=True, pred_bxt=d["pred"], want_hits=True,
                                                       algo=self.algo, prepared=pq, order=self.order)
             nxt = self.sets[(i + 1) % len(self.sets)]
             # (making the side stream wait for this step's forward, so that the sort overlaps the HBM-bound backward instead
             # of the traversal, was measured: 0.257-0.259 vs 0.247-0.248 ms/step)
             with torch.cuda.stream(self.side_stream()):
-                self._pq = {i + 1: hip_ops.prepare_queries(nxt["pts"], self.T, algo=self.algo)}
+                self._pq = {i + 1: hip_ops.prepare_queries(nxt["pts"], self.T, algo=self.algo, query_box=self.query_box)}
         else:
             cond, w, occ, hits = hip_ops.point_in_tet(d["tet"], d["pts"], want_bary=True, pred_bxt=d["pred"], want_hits=True,
-                                                      algo=self.algo, order=self.order)
+                                                      algo=self.algo, order=self.order, query_box=self.query_box)
         g_tet, _, g_pred = hip_ops.point_in_tet_bwd(d["tet"], d["pts"], cond, d["gw"], grad_occ=d["gout"], hits=hits)
         loss = hip_ops.rowdot(w, d["gw"], occ, d["gout"])         # [B] per-shape loss scalars
         if self.world > 1:
@@ -201,6 +205,8 @@ class PitWorkload:
                 "sharding": "shapes sharded by rank; all-gather of %d loss scalars" % (self.world * self.B),
                 "inputs_generated_on": self.generated_on,
                 "tet_order": "%s -> %s" % (self.order_mode, "the caller's numbering" if self.order is None else "computed column order"),
+                "query_box": ("tracked: the grid of a step spans the box the previous step's (different) queries measured; queries outside it "
+                              "take the exact side path" if self.query_box else "measured by every step"),
                 "pipelining": ("query sort of step i+1 enqueued on a second stream during step i" if self.pipeline else "none")}
 
 

@@ -186,27 +186,9 @@ struct Grid {
 };
 constexpr int kBoxBlocks = 64;
 
-// reduce the per-block query boxes of one shape into grid parameters; called by every wave of
-// k_slab_count (64 partials, a few shuffles) so that no separate launch is needed
-__device__ __forceinline__ Grid reduce_grid(const float *__restrict__ part, int nPart, int G, int Gx)
+// grid parameters from the box of the regular queries (lo > hi: none seen)
+__device__ __forceinline__ Grid make_grid(const float *lo, const float *hi, int G, int Gx)
 {
-    const int lane = threadIdx.x & 63;
-    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int i = lane; i < nPart; i += 64) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            lo[k] = fminf(lo[k], part[(size_t)i * 6 + k]);
-            hi[k] = fmaxf(hi[k], part[(size_t)i * 6 + 3 + k]);
-        }
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            lo[k] = fminf(lo[k], __shfl_xor(lo[k], off));
-            hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off));
-        }
-    }
     Grid g;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -225,6 +207,60 @@ __device__ __forceinline__ Grid reduce_grid(const float *__restrict__ part, int 
         g.cs[k] = fmaxf(1.001f * ((h - l) / (float)(k == 0 ? Gx : G)), 1e-30f);
     }
     return g;
+}
+
+// reduce the per-block query boxes of one shape into grid parameters; called by every wave of
+// k_slab_count (64 partials, a few shuffles) so that no separate launch is needed
+__device__ __forceinline__ void reduce_box(const float *__restrict__ part, int nPart, float *lo, float *hi)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { lo[k] = INFINITY; hi[k] = -INFINITY; }
+    for (int i = lane; i < nPart; i += 64) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = fminf(lo[k], part[(size_t)i * 6 + k]);
+            hi[k] = fmaxf(hi[k], part[(size_t)i * 6 + 3 + k]);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = fminf(lo[k], __shfl_xor(lo[k], off));
+            hi[k] = fmaxf(hi[k], __shfl_xor(hi[k], off));
+        }
+    }
+}
+__device__ __forceinline__ Grid reduce_grid(const float *__restrict__ part, int nPart, int G, int Gx)
+{
+    float lo[3], hi[3];
+    reduce_box(part, nPart, lo, hi);
+    return make_grid(lo, hi, G, Gx);
+}
+
+// The grid of a call that was handed a box instead of measuring its queries' own (query_box_in of the *_ex_* entry points: the
+// sampler's box, or the box an earlier call measured).  The box is a HINT: it is enlarged by 1/32 of its extent per side, the
+// grid spans it, and a query outside it is not binned but listed with the NaN / Inf / huge ones and tested against every tet
+// by the side path, so the result is exact for any box — a box that fits saves the launch that measures (k_query_bbox),
+// one that does not costs time.  A box that is not a box (NaN, lo > hi) holds no query.
+__device__ __forceinline__ Grid hint_grid(const float *__restrict__ box, int G, int Gx)
+{
+    float lo[3], hi[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float l = box[k], h = box[3 + k];
+        const float e = (h - l) * (1.0f / 32.0f);
+        const bool ok = h >= l && fabsf(l) <= kBig && fabsf(h) <= kBig;      // (NaN fails)
+        lo[k] = ok ? fmaxf(l - e, -kBig) : INFINITY;
+        hi[k] = ok ? fminf(h + e, kBig) : -INFINITY;
+    }
+    return make_grid(lo, hi, G, Gx);
+}
+// a query the grid bins: regular coordinates inside the grid's box (always true for the box measured from the queries themselves)
+__device__ __forceinline__ bool query_binned(float x, float y, float z, const Grid &g)
+{
+    return x >= g.lo[0] && x <= g.hi[0] && y >= g.lo[1] && y <= g.hi[1] && z >= g.lo[2] && z <= g.hi[2];
 }
 
 __device__ __forceinline__ Grid load_grid(const float *__restrict__ gp)
@@ -375,12 +411,21 @@ constexpr int kParts = 4;                  // second-level workgroups per slab
 constexpr int kSubPerPart = kSub / kParts;
 constexpr int kMaxBin1 = kMaxG * kSub;     // 896
 
+// HINT (query_box_in given): the grid comes from the box the caller handed in (hint_grid) and k_query_bbox is not launched,
+// so this kernel also does what that launch did besides measuring — the result sentinels of its chunk — and measures for
+// the NEXT call: the box of its chunk's regular queries goes to partOut[chunk], k_slab_sort reduces the chunks' boxes into
+// query_box_out.  Queries the grid does not bin (outside the hint, NaN / Inf / huge) are listed per chunk without a global
+// counter (nobody has zeroed one): irregQ[q0 + i], i < irrCnt[chunk]; k_slab_sort compacts the lists and sets the counters.
+template <bool HINT>
 __global__ __launch_bounds__(256) void k_slab_local(const float *__restrict__ pts, int Q, const float *__restrict__ bboxPart,
                                                     float *gparam, int G, int Gx, int nblk, int nblkPad, int chunkQ,
-                                                    float4 *localQ, int *pre, int *counters, int *irregQ)
+                                                    float4 *localQ, int *pre, int *counters, int *irregQ,
+                                                    const float *__restrict__ boxIn, float *partOut, int *irrCnt, int *result)
 {
     __shared__ int hist[kMaxBin1 + 1];
     __shared__ int wtot[4];
+    __shared__ int s_irr;
+    __shared__ float s_box[4][6];
     const int b = blockIdx.y, blk = blockIdx.x, R1 = G * kSub, tid = threadIdx.x;
     const int q0 = blk * chunkQ, q1 = min(Q, q0 + chunkQ);
     const bool keep = chunkQ <= kRowTile;                          // launch-uniform: the chunk fits the register file
@@ -392,7 +437,24 @@ __global__ __launch_bounds__(256) void k_slab_local(const float *__restrict__ pt
             kp[k] = make_float3(p[0], p[1], p[2]);
         }
     }
-    const Grid g = reduce_grid(bboxPart + (size_t)b * kBoxBlocks * 6, kBoxBlocks, G, Gx);
+    if (HINT) {
+        for (int q = q0 + tid; q < q1; q += 256) result[(size_t)b * Q + q] = kMiss;
+        if (tid == 0) s_irr = 0;
+    }
+    const Grid g = HINT ? hint_grid(boxIn + (size_t)b * 6, G, Gx) : reduce_grid(bboxPart + (size_t)b * kBoxBlocks * 6, kBoxBlocks, G, Gx);
+    float blo[3] = {INFINITY, INFINITY, INFINITY}, bhi[3] = {-INFINITY, -INFINITY, -INFINITY};   // HINT: box of this chunk's regular queries
+    auto box_add = [&](float x, float y, float z) {
+        if (HINT && query_regular(x, y, z)) {
+            blo[0] = fminf(blo[0], x); blo[1] = fminf(blo[1], y); blo[2] = fminf(blo[2], z);
+            bhi[0] = fmaxf(bhi[0], x); bhi[1] = fmaxf(bhi[1], y); bhi[2] = fmaxf(bhi[2], z);
+        }
+    };
+    // a query the grid does not bin: with a measured box that is a NaN / Inf / huge one, with a hint also one outside the hint
+    auto binned = [&](float x, float y, float z) { return HINT ? query_binned(x, y, z, g) : query_regular(x, y, z); };
+    auto list_irregular = [&](int q) {
+        if (HINT) irregQ[(size_t)b * Q + q0 + atomicAdd(&s_irr, 1)] = q;                      // LDS counter, the chunk's own segment
+        else irregQ[(size_t)b * Q + atomicAdd(&counters[b * 4 + 1], 1)] = q;
+    };
     if (blk == 0 && tid == 0) {                                    // publish for k_slab_sort / the traversal
         float *gp = gparam + b * kGridWords;                       // (constant indices: a dynamic one sends g through LDS — 13 us)
 #pragma unroll
@@ -412,11 +474,12 @@ __global__ __launch_bounds__(256) void k_slab_local(const float *__restrict__ pt
             const int q = q0 + tid + k * 256;
             kbin[k] = -1;
             if (q < q1) {
-                if (query_regular(kp[k].x, kp[k].y, kp[k].z)) {
+                box_add(kp[k].x, kp[k].y, kp[k].z);
+                if (binned(kp[k].x, kp[k].y, kp[k].z)) {
                     kbin[k] = bin_of(kp[k].x, kp[k].y, kp[k].z);
                     krank[k] = atomicAdd(&hist[kbin[k]], 1);                          // LDS
-                } else {                                           // NaN / Inf / huge: tested by every tet lane at the end of the traversal
-                    irregQ[(size_t)b * Q + atomicAdd(&counters[b * 4 + 1], 1)] = q;
+                } else {                                           // NaN / Inf / huge (/ outside the hint): tested by every tet lane at the end of the traversal
+                    list_irregular(q);
                 }
             }
         }
@@ -424,11 +487,34 @@ __global__ __launch_bounds__(256) void k_slab_local(const float *__restrict__ pt
         for (int q = q0 + tid; q < q1; q += 256) {
             const float *p = pts + ((size_t)b * Q + q) * 3;
             const float x = p[0], y = p[1], z = p[2];
-            if (query_regular(x, y, z)) atomicAdd(&hist[bin_of(x, y, z)], 1);
-            else irregQ[(size_t)b * Q + atomicAdd(&counters[b * 4 + 1], 1)] = q;
+            box_add(x, y, z);
+            if (binned(x, y, z)) atomicAdd(&hist[bin_of(x, y, z)], 1);
+            else list_irregular(q);
+        }
+    }
+    if (HINT) {                                                    // the chunk's box for the next call's hint
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                blo[k] = fminf(blo[k], __shfl_xor(blo[k], off));
+                bhi[k] = fmaxf(bhi[k], __shfl_xor(bhi[k], off));
+            }
+        }
+        if ((tid & 63) == 0) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { s_box[tid >> 6][k] = blo[k]; s_box[tid >> 6][3 + k] = bhi[k]; }
         }
     }
     __syncthreads();
+    if (HINT) {
+        if (tid < 6) {
+            float v = s_box[0][tid];
+            for (int i = 1; i < 4; ++i) v = tid < 3 ? fminf(v, s_box[i][tid]) : fmaxf(v, s_box[i][tid]);
+            partOut[((size_t)b * kMaxRowBlocks + blk) * 6 + tid] = v;
+        }
+        if (tid == 0) irrCnt[b * kMaxRowBlocks + blk] = s_irr;
+    }
     {   // exclusive scan of the R1 counts (<= 4 consecutive bins per thread); hist[R1] = number of regular queries
         constexpr int kPer = (kMaxBin1 + 255) / 256;               // 4
         const int per = (R1 + 255) / 256, i0 = tid * per;
@@ -471,7 +557,7 @@ __global__ __launch_bounds__(256) void k_slab_local(const float *__restrict__ pt
         for (int q = q0 + tid; q < q1; q += 256) {
             const float *p = pts + ((size_t)b * Q + q) * 3;
             const float x = p[0], y = p[1], z = p[2];
-            if (query_regular(x, y, z)) dst[atomicAdd(&hist[bin_of(x, y, z)], 1)] = make_float4(x, y, z, __int_as_float(q));
+            if (binned(x, y, z)) dst[atomicAdd(&hist[bin_of(x, y, z)], 1)] = make_float4(x, y, z, __int_as_float(q));
         }
     }
 }
@@ -488,10 +574,38 @@ constexpr int kSortThreads = PIT_SORT_THREADS;
 constexpr int kSortKeep = 1024 / kSortThreads;                        // queries a thread keeps in registers
 constexpr int kRunsPer = kMaxRowBlocks / kSortThreads;               // chunk runs per thread (consecutive chunks)
 static_assert(kRunsPer * kSortThreads == kMaxRowBlocks && kSortThreads % 64 == 0, "every chunk run has a thread");
+// boxPart / boxOut (query_box_out): the workgroup of a shape's first slab part also reduces the nPart per-block boxes of the
+// queries (k_query_bbox's, or k_slab_local<true>'s) into the box the caller gets back.  hint: k_slab_local<true> ran instead
+// of k_query_bbox — the same workgroup compacts the chunks' lists of unbinned queries (forward copy: a list's place in the
+// compact list never lies behind its own segment) and sets the counters the traversal and k_finalize read.
 __global__ __launch_bounds__(kSortThreads) void k_slab_sort(const float4 *__restrict__ localQ, int Q, const float *__restrict__ gparam,
                                                             int G, int Gx, const int *__restrict__ pre, int nblk, int nblkPad,
-                                                            int chunkQ, long long cellStride, int *table, float4 *sortedQ, int pin)
+                                                            int chunkQ, long long cellStride, int *table, float4 *sortedQ, int pin,
+                                                            const float *__restrict__ boxPart, int nPart, int partStride, float *boxOut,
+                                                            int hint, const int *__restrict__ irrCnt, int *irregQ, int *counters)
 {
+    if (shape_block(pin).y == 0 && (boxOut || hint)) {               // (block-uniform; before the sort proper: nothing below depends on it)
+        const int b0 = shape_block(pin).x, nB = gridDim.y;
+        if (boxOut && threadIdx.x < 64) {
+            float lo[3], hi[3];
+            reduce_box(boxPart + (size_t)b0 * partStride * 6, nPart, lo, hi);
+            if (threadIdx.x == 0) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { boxOut[b0 * 6 + k] = lo[k]; boxOut[b0 * 6 + 3 + k] = hi[k]; }   // lo > hi: no regular query
+            }
+        }
+        if (hint && threadIdx.x == 0) {
+            int n = 0;
+            for (int c = 0; c < nblk; ++c) {
+                const int cnt = irrCnt[b0 * kMaxRowBlocks + c];
+                const int *src = irregQ + (size_t)b0 * Q + (size_t)c * chunkQ;
+                for (int i = 0; i < cnt; ++i) irregQ[(size_t)b0 * Q + n++] = src[i];
+            }
+            counters[b0 * 4 + 0] = 0; counters[b0 * 4 + 1] = n; counters[b0 * 4 + 2] = 0; counters[b0 * 4 + 3] = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) counters[nB * 4 + b0 * 4 + k] = 0;
+        }
+    }
     extern __shared__ __attribute__((aligned(16))) int cnt[];       // [rows of the part][GxP] counts -> starts (-> placement cursors)
     __shared__ int wsum[kSortThreads / 64], wsum2[kSortThreads / 64];
     __shared__ int runStart[kMaxRowBlocks + 1], runSrc[kMaxRowBlocks];
@@ -2008,7 +2122,7 @@ __global__ __launch_bounds__(256) void k_finalize(const float *__restrict__ tet,
                                                   int Q, const int *__restrict__ result, float *cond, float *bary,
                                                   const float *__restrict__ pred, float *occ, const int4 *__restrict__ hits,
                                                   int *ucount, int *ulist, const int *__restrict__ counters,
-                                                  const int *__restrict__ irregT, int hpad, int pin)
+                                                  const int *__restrict__ irregT, int hpad, int pin, const float *__restrict__ gparam)
 {
     __shared__ int s_cnt[4], s_base;
     const int2 sb = shape_block(pin);                                  // shape-per-XCD placement
@@ -2046,7 +2160,11 @@ __global__ __launch_bounds__(256) void k_finalize(const float *__restrict__ tet,
         const float *pq = pts + i * 3;
         // records are complete unless some tet is irregular or overflowed (wave-uniform test: the
         // per-hit gather of the record is skipped for ordinary meshes)
+        // (a query the grid did not bin — NaN / Inf / huge, or outside the box the grid was given — took the side path, which
+        // records nothing; with the box measured from the queries themselves the second test is true for every regular query)
         bool covered = query_regular(pq[0], pq[1], pq[2]);
+        if (gparam) covered = covered && query_binned(pq[0], pq[1], pq[2], load_grid(gparam + b * kGridWords));
+        const bool sidePath = !covered;
         if (counters) {
             const int nB = gridDim.y, nOvf = counters[nB * 4 + b * 4 + 2];
             if (counters[b * 4 + 0] > 0 || nOvf > kOvfCap) {
@@ -2060,7 +2178,7 @@ __global__ __launch_bounds__(256) void k_finalize(const float *__restrict__ tet,
         }
         if (!covered) {
             uncovered = true;
-            if (!query_regular(pq[0], pq[1], pq[2])) ucount[2 * hpad + b] = 1;   // its tet's record may be complete: every lane must look
+            if (sidePath) ucount[2 * hpad + b] = 1;                  // its tet's record may be complete: every lane must look
         }
     }
     if (hits) {
@@ -2713,7 +2831,8 @@ struct Layout {
     int G, Gx, nRowBlk, chunkQ;
     long long cellStride;   // padded table words per shape (>= G * (Gx + 1) * (G + 3))
     size_t bytes;
-    float *bboxPart;
+    float *bboxPart, *chunkBox;
+    int *irrCnt;
     int nblkPad;
     int *counters, *table, *pre, *result, *irregT, *irregQ;
     float4 *localQ, *sortedQ;
@@ -2736,6 +2855,8 @@ static Layout make_layout(int B, int T, int Q, int algo, void *ws, size_t wsByte
         if (L.nRowBlk < 1) L.nRowBlk = 1;
         L.chunkQ = ((Q + L.nRowBlk - 1) / L.nRowBlk + 255) / 256 * 256;
         L.bboxPart = A.take<float>((size_t)B * kBoxBlocks * 6);
+        L.chunkBox = A.take<float>((size_t)B * kMaxRowBlocks * 6);  // k_slab_local<true>: the chunks' boxes, the chunks' unbinned counts
+        L.irrCnt = A.take<int>((size_t)B * kMaxRowBlocks);
         L.counters = A.take<int>((size_t)B * (8 + kOvfCap));  // 4 counters + 4 statistics words per shape, then the overflowed-tet lists
         L.gparam = A.take<float>((size_t)B * kGridWords);
         L.table = A.take<int>((size_t)B * L.cellStride);
@@ -2798,15 +2919,22 @@ static int pit_check(const float *tet, const float *pts, const float *cond, cons
 }
 
 // query side: resets + bounding box + counting sort of the queries into grid cells (depends on pts, B, T, Q only)
-static int pit_prepare(const Layout &L, const float *pts, int B, int Q, hipStream_t st)
+static int pit_prepare(const Layout &L, const float *pts, int B, int Q, hipStream_t st, const float *boxIn = nullptr, float *boxOut = nullptr)
 {
     const dim3 blk(256);
-    DEFTET_LAUNCH(k_query_bbox, dim3(kBoxBlocks, B), blk, st, pts, Q, L.bboxPart, L.counters, L.result, B, (long long)B * Q);
-    DEFTET_LAUNCH(k_slab_local, dim3(L.nRowBlk, B), blk, st, pts, Q, L.bboxPart, L.gparam, L.G, L.Gx, L.nRowBlk, L.nblkPad, L.chunkQ,
-                  L.localQ, L.pre, L.counters, L.irregQ);
+    if (boxIn) {                                                         // two launches: the grid spans the box handed in
+        DEFTET_LAUNCH(k_slab_local<true>, dim3(L.nRowBlk, B), blk, st, pts, Q, L.bboxPart, L.gparam, L.G, L.Gx, L.nRowBlk, L.nblkPad, L.chunkQ,
+                      L.localQ, L.pre, L.counters, L.irregQ, boxIn, L.chunkBox, L.irrCnt, L.result);
+    } else {
+        DEFTET_LAUNCH(k_query_bbox, dim3(kBoxBlocks, B), blk, st, pts, Q, L.bboxPart, L.counters, L.result, B, (long long)B * Q);
+        DEFTET_LAUNCH(k_slab_local<false>, dim3(L.nRowBlk, B), blk, st, pts, Q, L.bboxPart, L.gparam, L.G, L.Gx, L.nRowBlk, L.nblkPad, L.chunkQ,
+                      L.localQ, L.pre, L.counters, L.irregQ, (const float *)nullptr, (float *)nullptr, (int *)nullptr, (int *)nullptr);
+    }
     const size_t shm = align_up((size_t)((L.G + kParts - 1) / kParts + 1) * (L.Gx | 1) * sizeof(int), 16);   // rows of a y-quarter
     DEFTET_LAUNCH_SHM(k_slab_sort, dim3(L.G * kParts, B), dim3(kSortThreads), shm, st, L.localQ, Q, L.gparam, L.G, L.Gx, L.pre, L.nRowBlk, L.nblkPad,
-                      L.chunkQ, L.cellStride, L.table, L.sortedQ, (size_t)Q * 16 <= ((size_t)4 << 20));
+                      L.chunkQ, L.cellStride, L.table, L.sortedQ, (size_t)Q * 16 <= ((size_t)4 << 20),
+                      (const float *)(boxIn ? L.chunkBox : L.bboxPart), boxIn ? L.nRowBlk : kBoxBlocks, boxIn ? kMaxRowBlocks : kBoxBlocks, boxOut,
+                      boxIn ? 1 : 0, (const int *)L.irrCnt, L.irregQ, L.counters);
     return DEFTET_OK;
 }
 
@@ -2840,12 +2968,13 @@ static int pit_scan(const Layout &L, const float *tet, const float *pts, float *
         DEFTET_HIP(hipMemsetAsync(ucount, 0, (size_t)3 * hit_pad(B) * 4, st));
     }
     DEFTET_LAUNCH(k_finalize, gq, blk, st, tet, pts, T, Q, L.result, cond, bary, pred, occ, (const int4 *)hit_buf, ucount,
-                  hit_buf ? hit_buf + hit_list_off(B, T) : nullptr, L.counters, L.irregT, hit_pad(B), pin_shapes(Q));
+                  hit_buf ? hit_buf + hit_list_off(B, T) : nullptr, L.counters, L.irregT, hit_pad(B), pin_shapes(Q), (const float *)L.gparam);
     return DEFTET_OK;
 }
 
 static int pit_forward(const float *tet, const float *pts, float *cond, float *bary, const float *pred, float *occ, int32_t *hit_buf,
-                       int B, int T, int Q, int algo, void *workspace, size_t workspace_bytes, void *stream_, const int32_t *order)
+                       int B, int T, int Q, int algo, void *workspace, size_t workspace_bytes, void *stream_, const int32_t *order,
+                       const float *boxIn = nullptr, float *boxOut = nullptr)
 {
     int rc = pit_check(tet, pts, cond, bary, pred, occ, hit_buf, B, T, Q, algo, workspace);
     if (rc != DEFTET_OK || B == 0 || Q == 0) return rc;
@@ -2860,10 +2989,10 @@ static int pit_forward(const float *tet, const float *pts, float *cond, float *b
         }
         DEFTET_LAUNCH(k_brute, gq, blk, st, L.rec, pts, T, Q, L.result);
         DEFTET_LAUNCH(k_finalize, gq, blk, st, tet, pts, T, Q, L.result, cond, bary, pred, occ, (const int4 *)nullptr, (int *)nullptr,
-                      (int *)nullptr, (const int *)nullptr, L.irregT, 0, pin_shapes(Q));
+                      (int *)nullptr, (const int *)nullptr, L.irregT, 0, pin_shapes(Q), (const float *)nullptr);
         return DEFTET_OK;
     }
-    rc = pit_prepare(L, pts, B, Q, st);
+    rc = pit_prepare(L, pts, B, Q, st, boxIn, boxOut);
     if (rc != DEFTET_OK) return rc;
     return pit_scan(L, tet, pts, cond, bary, pred, occ, hit_buf, B, T, Q, algo, st, order);
 }
@@ -2877,12 +3006,21 @@ extern "C" int deftet_point_in_tet_f32(const float *tet, const float *pts, float
 
 // The same with a traversal order (int32 [T] on the device, a permutation of [0, T) — deftet_tet_spatial_order_f32 — shared by
 // the shapes of the batch; NULL = the caller's own order).  Outputs are identical with and without it: the filter kernels
-// (DEFTET_PIT_AUTO / _SLAB / _WAVE) walk the tets in that order and publish the original indices; the other ids ignore it.
-extern "C" int deftet_point_in_tet_ordered_f32(const float *tet, const float *pts, float *cond, float *bary, const float *pred,
-                                               float *occ, int32_t *hit_buf, int B, int T, int Q, int algo, const int32_t *tet_order,
-                                               void *workspace, size_t workspace_bytes, void *stream_)
+// (DEFTET_PIT_AUTO / _SLAB / _WAVE / _PAIR) walk the tets in that order and publish the original indices; the other ids ignore it.
+// ... and with a box for the query grid (query_box_in, f32 [B,6] = lo xyz, hi xyz on the device, or NULL): the grid spans that box
+// (enlarged by 1/32 per side) instead of the measured box of this call's queries, which saves the measuring launch.  The box is
+// a hint: queries outside it are answered exactly by the side path that handles NaN / Inf / huge queries, at brute-force cost
+// each — hand in the sampler's box, or the box an earlier call with the same query distribution measured: query_box_out
+// (f32 [B,6] or NULL, must not alias query_box_in) receives the box of THIS call's regular queries (lo > hi when there is none).
+// The brute-force algorithm ignores both.
+extern "C" int deftet_point_in_tet_ex_f32(const float *tet, const float *pts, float *cond, float *bary, const float *pred,
+                                          float *occ, int32_t *hit_buf, int B, int T, int Q, int algo, const int32_t *tet_order,
+                                          const float *query_box_in, float *query_box_out,
+                                          void *workspace, size_t workspace_bytes, void *stream_)
 {
-    return pit_forward(tet, pts, cond, bary, pred, occ, hit_buf, B, T, Q, algo, workspace, workspace_bytes, stream_, tet_order);
+    DEFTET_CHECK_ARG(!query_box_in || query_box_in != query_box_out, "query_box_in and query_box_out must not alias");
+    return pit_forward(tet, pts, cond, bary, pred, occ, hit_buf, B, T, Q, algo, workspace, workspace_bytes, stream_, tet_order,
+                       query_box_in, query_box_out);
 }
 
 // The same operator in two calls: the QUERY side (bounding box + counting sort: depends on pts and on
@@ -2890,8 +3028,21 @@ extern "C" int deftet_point_in_tet_ordered_f32(const float *tet, const float *pt
 // backward is still running — and the TET side consumes it.  One prepare feeds exactly one scan
 // (the scan uses up the result sentinels and counters the prepare resets); both must see the same
 // pts, sizes, algo and workspace.
+static int pit_prepare_entry(const float *pts, int B, int T, int Q, int algo, void *workspace, size_t workspace_bytes, void *stream_,
+                             const float *boxIn, float *boxOut);
 extern "C" int deftet_point_in_tet_prepare_f32(const float *pts, int B, int T, int Q, int algo, void *workspace,
                                                size_t workspace_bytes, void *stream_)
+{
+    return pit_prepare_entry(pts, B, T, Q, algo, workspace, workspace_bytes, stream_, nullptr, nullptr);
+}
+extern "C" int deftet_point_in_tet_prepare_ex_f32(const float *pts, int B, int T, int Q, int algo, const float *query_box_in,
+                                                  float *query_box_out, void *workspace, size_t workspace_bytes, void *stream_)
+{
+    DEFTET_CHECK_ARG(!query_box_in || query_box_in != query_box_out, "query_box_in and query_box_out must not alias");
+    return pit_prepare_entry(pts, B, T, Q, algo, workspace, workspace_bytes, stream_, query_box_in, query_box_out);
+}
+static int pit_prepare_entry(const float *pts, int B, int T, int Q, int algo, void *workspace, size_t workspace_bytes, void *stream_,
+                             const float *boxIn, float *boxOut)
 {
     DEFTET_CHECK_ARG(B >= 0 && T >= 0 && Q >= 0 && B <= 65535, "bad size (B=%d T=%d Q=%d)", B, T, Q);
     DEFTET_CHECK_ARG(algo == DEFTET_PIT_AUTO || algo == DEFTET_PIT_EXACT || algo == DEFTET_PIT_SLAB || algo == DEFTET_PIT_WAVE || algo == DEFTET_PIT_PAIR, "prepare needs a binned algo (got %d)", algo);
@@ -2901,7 +3052,7 @@ extern "C" int deftet_point_in_tet_prepare_f32(const float *pts, int B, int T, i
     DEFTET_CHECK_ARG(workspace && ((uintptr_t)workspace & 255) == 0, "workspace null or not 256-byte aligned");
     Layout L = make_layout(B, T, Q, algo, workspace, workspace_bytes);
     DEFTET_CHECK_ARG(L.bytes <= workspace_bytes, "workspace too small: need %zu bytes, got %zu", L.bytes, workspace_bytes);
-    return pit_prepare(L, pts, B, Q, as_stream(stream_));
+    return pit_prepare(L, pts, B, Q, as_stream(stream_), boxIn, boxOut);
 }
 
 static int pit_scan_entry(const float *tet, const float *pts, float *cond, float *bary, const float *pred, float *occ, int32_t *hit_buf,
@@ -2922,7 +3073,7 @@ extern "C" int deftet_point_in_tet_scan_f32(const float *tet, const float *pts, 
     return pit_scan_entry(tet, pts, cond, bary, pred, occ, hit_buf, B, T, Q, algo, workspace, workspace_bytes, stream_, nullptr);
 }
 
-extern "C" int deftet_point_in_tet_scan_ordered_f32(const float *tet, const float *pts, float *cond, float *bary, const float *pred,
+extern "C" int deftet_point_in_tet_scan_ex_f32(const float *tet, const float *pts, float *cond, float *bary, const float *pred,
                                                     float *occ, int32_t *hit_buf, int B, int T, int Q, int algo,
                                                     const int32_t *tet_order, void *workspace, size_t workspace_bytes, void *stream_)
 {

@@ -48,7 +48,50 @@ class PreparedQueries:
         self.consumed = False
 
 
-def prepare_queries(pts_bxqx3, n_tet, algo=PIT_AUTO):
+# Query boxes tracked from call to call (query_box="track"): per (device, B, Q) two [B,6] tensors used in turns — a call hands the
+# box the PREVIOUS call measured to the library (query_box_in: the grid spans it, the measuring launch is skipped) and receives
+# the box of its own queries for the next one.  A training loop draws its queries from one distribution (dataloader.py:108), so
+# the previous box fits; where it does not, the queries outside it are answered exactly by the side path at brute-force cost
+# each and the NEXT call has the right box again.  DEFTET_PIT_BOX=off switches the tracking off.
+_box_cache = {}
+
+
+def _tracked_boxes(dev, B, Q):
+    """(query_box_in | None, query_box_out) for this call."""
+    import os
+    if os.environ.get("DEFTET_PIT_BOX", "track") == "off":
+        return None, None
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), B, Q)
+    st = _box_cache.get(key)
+    if st is None:
+        st = _box_cache[key] = {"box": [torch.empty(B, 6, device=dev, dtype=torch.float32) for _ in range(2)], "phase": -1}
+    if st["phase"] < 0:                                   # first call: measured box, remembered in box[0]
+        st["phase"] = 0
+        return None, st["box"][0]
+    box_in, box_out = st["box"][st["phase"]], st["box"][1 - st["phase"]]
+    st["phase"] = 1 - st["phase"]
+    return box_in, box_out
+
+
+def clear_query_box_cache():
+    _box_cache.clear()
+
+
+def _resolve_query_box(query_box, dev, B, Q, algo):
+    """query_box argument -> (query_box_in, query_box_out) tensors or Nones."""
+    if query_box is None or algo == PIT_BRUTE or B == 0 or Q == 0:
+        return None, None
+    if isinstance(query_box, str):
+        if query_box != "track":
+            raise RuntimeError("query_box must be None, 'track' or a float32 [B,6] tensor (lo xyz, hi xyz)")
+        return _tracked_boxes(dev, B, Q)
+    _lib.require_gpu(query_box)
+    if query_box.dtype != torch.float32 or query_box.shape != (B, 6) or not query_box.is_contiguous() or query_box.device != dev:
+        raise RuntimeError("query_box must be a contiguous float32 [B,6] tensor (lo xyz, hi xyz) on the queries' device")
+    return query_box, None
+
+
+def prepare_queries(pts_bxqx3, n_tet, algo=PIT_AUTO, query_box=None):
     _lib.require_gpu(pts_bxqx3)
     if algo == PIT_BRUTE:
         raise RuntimeError("prepare_queries needs a binned algo")
@@ -61,8 +104,10 @@ def prepare_queries(pts_bxqx3, n_tet, algo=PIT_AUTO):
     with torch.cuda.device(dev):
         nbytes = max(lib.deftet_point_in_tet_workspace_bytes(B, pq.n_tet, Q, algo), 256)
         pq.workspace = torch.empty(nbytes, device=dev, dtype=torch.uint8)       # private: outlives the cached per-stream workspace
-        _lib.check(lib.deftet_point_in_tet_prepare_f32(_lib.ptr(pts), B, pq.n_tet, Q, algo, _lib.ptr(pq.workspace), nbytes,
-                                                       _lib.current_stream(dev)), "deftet_point_in_tet_prepare_f32")
+        box_in, box_out = _resolve_query_box(query_box, dev, B, Q, algo)
+        _lib.check(lib.deftet_point_in_tet_prepare_ex_f32(_lib.ptr(pts), B, pq.n_tet, Q, algo, _lib.ptr(box_in), _lib.ptr(box_out),
+                                                          _lib.ptr(pq.workspace), nbytes, _lib.current_stream(dev)),
+                   "deftet_point_in_tet_prepare_ex_f32")
         pq.event = torch.cuda.Event()
         pq.event.record(torch.cuda.current_stream(dev))
     return pq
@@ -149,13 +194,16 @@ def clear_tet_order_cache():
         _order_cache.clear()
 
 
-def point_in_tet(tet_bxtx4x3, pts_bxqx3, want_bary=False, algo=PIT_AUTO, pred_bxt=None, want_hits=False, prepared=None, order=None):
+def point_in_tet(tet_bxtx4x3, pts_bxqx3, want_bary=False, algo=PIT_AUTO, pred_bxt=None, want_hits=False, prepared=None, order=None,
+                 query_box=None):
     """cond f32 [B,Q,1] (lowest containing tet index or -1); with want_bary also the barycentric
     weights f32 [B,Q,4] of the hit tet; with pred_bxt also occ f32 [B,Q] = the fused
     DefTet.paste_occ gather pred[b, max(index, 0)].  Returns cond | (cond, bary) | (cond, bary, occ)
     | (cond, occ) depending on what was asked for; want_hits appends the opaque int32 hit-record
     buffer that makes point_in_tet_bwd atomic-free.  order: None (the caller's tet numbering), an int32 [T] permutation from
-    tet_spatial_order, or "auto" (auto_tet_order: decided once per grid size and device); never changes a result."""
+    tet_spatial_order, or "auto" (auto_tet_order: decided once per grid size and device); never changes a result.
+    query_box: None (the grid spans the measured box of this call's queries), a float32 [B,6] hint (lo xyz, hi xyz: e.g. the
+    sampler's box) or "track" (the box the previous call with these sizes measured); never changes a result either."""
     _lib.require_gpu(tet_bxtx4x3, pts_bxqx3, pred_bxt)
     lib = _lib.load()
     tet, pts = _f32c(tet_bxtx4x3), _f32c(pts_bxqx3)
@@ -194,15 +242,17 @@ def point_in_tet(tet_bxtx4x3, pts_bxqx3, want_bary=False, algo=PIT_AUTO, pred_bx
             ws = prepared.workspace
             ws.record_stream(cur)
             prepared.consumed = True
-            _lib.check(lib.deftet_point_in_tet_scan_ordered_f32(_lib.ptr(tet), _lib.ptr(pts), _lib.ptr(cond), _lib.ptr(bary), _lib.ptr(pred),
-                                                                _lib.ptr(occ), _lib.ptr(hits), B, T, Q, algo, _lib.ptr(order), _lib.ptr(ws),
-                                                                ws.numel(), _lib.current_stream(dev)), "deftet_point_in_tet_scan_ordered_f32")
+            _lib.check(lib.deftet_point_in_tet_scan_ex_f32(_lib.ptr(tet), _lib.ptr(pts), _lib.ptr(cond), _lib.ptr(bary), _lib.ptr(pred),
+                                                           _lib.ptr(occ), _lib.ptr(hits), B, T, Q, algo, _lib.ptr(order), _lib.ptr(ws),
+                                                           ws.numel(), _lib.current_stream(dev)), "deftet_point_in_tet_scan_ex_f32")
         else:
             nbytes = lib.deftet_point_in_tet_workspace_bytes(B, T, Q, algo)
             ws = _lib.workspace(dev, nbytes)
-            _lib.check(lib.deftet_point_in_tet_ordered_f32(_lib.ptr(tet), _lib.ptr(pts), _lib.ptr(cond), _lib.ptr(bary), _lib.ptr(pred),
-                                                           _lib.ptr(occ), _lib.ptr(hits), B, T, Q, algo, _lib.ptr(order), _lib.ptr(ws),
-                                                           ws.numel(), _lib.current_stream(dev)), "deftet_point_in_tet_ordered_f32")
+            box_in, box_out = _resolve_query_box(query_box, dev, B, Q, algo)
+            _lib.check(lib.deftet_point_in_tet_ex_f32(_lib.ptr(tet), _lib.ptr(pts), _lib.ptr(cond), _lib.ptr(bary), _lib.ptr(pred),
+                                                      _lib.ptr(occ), _lib.ptr(hits), B, T, Q, algo, _lib.ptr(order), _lib.ptr(box_in),
+                                                      _lib.ptr(box_out), _lib.ptr(ws), ws.numel(), _lib.current_stream(dev)),
+                       "deftet_point_in_tet_ex_f32")
     out = (cond,) + ((bary,) if want_bary else ()) + ((occ,) if pred is not None else ()) + ((hits,) if want_hits else ())
     return out if len(out) > 1 else cond
 

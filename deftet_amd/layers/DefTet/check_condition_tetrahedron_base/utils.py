@@ -21,8 +21,9 @@ class TriRender2D(Function):
     def forward(ctx, tet_bxfx4x3, point_pos_bxnx3):
         # the reference also builds an (unused) [B,T,6] bbox tensor here (utils.py:47);
         # the kernel never read it (check_condition_tet_for.cu:154-164), so it is dropped.
-        # order="auto": the traversal order is decided once per grid (static topology); it never changes the result
-        return hip_ops.point_in_tet(tet_bxfx4x3, point_pos_bxnx3, order="auto")
+        # order="auto": the traversal order is decided once per grid (static topology); query_box="track": the query grid spans the
+        # box the previous call measured (one launch fewer); neither ever changes the result
+        return hip_ops.point_in_tet(tet_bxfx4x3, point_pos_bxnx3, order="auto", query_box="track")
 
     @staticmethod
     def backward(ctx, condition_bxnx1):
@@ -40,7 +41,7 @@ class PointInTetBary(Function):
 
     @staticmethod
     def forward(ctx, tet_bxfx4x3, point_pos_bxnx3):
-        cond, w, hits = hip_ops.point_in_tet(tet_bxfx4x3, point_pos_bxnx3, want_bary=True, want_hits=True, order="auto")
+        cond, w, hits = hip_ops.point_in_tet(tet_bxfx4x3, point_pos_bxnx3, want_bary=True, want_hits=True, order="auto", query_box="track")
         ctx.save_for_backward(tet_bxfx4x3, point_pos_bxnx3, cond, hits)
         ctx.mark_non_differentiable(cond)
         return cond, w
@@ -65,7 +66,7 @@ class PointInTetOcc(Function):
     @staticmethod
     def forward(ctx, tet_bxfx4x3, point_pos_bxnx3, pred_tet_occ):
         cond, w, occ, hits = hip_ops.point_in_tet(tet_bxfx4x3, point_pos_bxnx3, want_bary=True, pred_bxt=pred_tet_occ,
-                                                  want_hits=True, order="auto")
+                                                  want_hits=True, order="auto", query_box="track")
         ctx.save_for_backward(tet_bxfx4x3, point_pos_bxnx3, cond, hits)
         ctx.mark_non_differentiable(cond)
         return cond, w, occ

@@ -102,19 +102,30 @@ int deftet_point_in_tet_scan_f32(const float *tet, const float *pts, float *cond
  * (deftet_tet_spatial_order_f32: tet f32 [T,4,3] -> order int32 [T]; breaks int32 [2] on the device, may be NULL, receives
  * how often the column changes or z jumps inside a group of 64 consecutive tets of the caller's order ([0]) and of the
  * computed one ([1]) — when [0] is not much larger than [1] the list is coherent as it is and NULL should be passed on) and
- * hands it to the *_ordered_* variants below.  Every output (cond, bary, occ, hit_buf) is identical with and without it:
+ * hands it to the *_ex_* variants below.  Every output (cond, bary, occ, hit_buf) is identical with and without it:
  * "lowest tet index" (check_condition_tet_for.cu:176-178) is decided on the original indices. */
 size_t deftet_tet_spatial_order_workspace_bytes(int n_tet);
 int deftet_tet_spatial_order_f32(const float *tet, int n_tet, int32_t *order, int32_t *breaks,
                                  void *workspace, size_t workspace_bytes, void *stream);
-int deftet_point_in_tet_ordered_f32(const float *tet, const float *pts, float *cond, float *bary,
+/* Query box (no reference counterpart either).  The binned algorithms span their cell grid over the box of the call's regular
+ * queries, which a first launch measures.  query_box_in (f32 [B,6] = lo xyz, hi xyz on the device, or NULL) replaces the
+ * measurement: the grid spans that box, enlarged by 1/32 per side, and the launch is not made.  It is a HINT, never a promise:
+ * a query outside it is answered exactly by the side path that serves NaN / Inf / huge queries — at brute-force cost per such
+ * query, so hand in the sampler's box (dataloader.py:108 draws from 1.05 (U - 0.5)) or what an earlier call with the same
+ * distribution measured: query_box_out (f32 [B,6] or NULL; must not alias query_box_in) receives the box of THIS call's regular
+ * queries (lo > hi when there is none).  Every output is identical with and without a box. */
+int deftet_point_in_tet_ex_f32(const float *tet, const float *pts, float *cond, float *bary,
+                               const float *pred, float *occ, int32_t *hit_buf,
+                               int n_batch, int n_tet, int n_query, int algo, const int32_t *tet_order,
+                               const float *query_box_in, float *query_box_out,
+                               void *workspace, size_t workspace_bytes, void *stream);
+int deftet_point_in_tet_prepare_ex_f32(const float *pts, int n_batch, int n_tet, int n_query, int algo,
+                                       const float *query_box_in, float *query_box_out,
+                                       void *workspace, size_t workspace_bytes, void *stream);
+int deftet_point_in_tet_scan_ex_f32(const float *tet, const float *pts, float *cond, float *bary,
                                     const float *pred, float *occ, int32_t *hit_buf,
                                     int n_batch, int n_tet, int n_query, int algo, const int32_t *tet_order,
                                     void *workspace, size_t workspace_bytes, void *stream);
-int deftet_point_in_tet_scan_ordered_f32(const float *tet, const float *pts, float *cond, float *bary,
-                                         const float *pred, float *occ, int32_t *hit_buf,
-                                         int n_batch, int n_tet, int n_query, int algo, const int32_t *tet_order,
-                                         void *workspace, size_t workspace_bytes, void *stream);
 
 /* A1b  backward of the weights (the reference's own backward,
  * check_condition_tetrahedron_base/utils.py:55-58, returns None).

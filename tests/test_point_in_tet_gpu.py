@@ -634,3 +634,66 @@ def test_wave_kernel_clamped_footprints_and_degenerate_axis(cuda, oracle):
         for algo in (1, 2, 3, 4, 5):
             assert np.array_equal(hip_ops.point_in_tet(t, p, algo=algo).cpu().numpy(), want), (case, algo)
         assert (want >= 0).any()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# query box (round 5): a box handed in replaces the measuring launch; it is a hint and must never change a result
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("algo", [0, 2, 3, 4, 5])
+def test_query_box_hint_never_changes_the_result(cuda, oracle, algo):
+    from deftet_amd import hip_ops
+    tet, pts = cases.jittered(12, 5000, 2)
+    pts = pts.copy()
+    pts[0, 7] = np.nan
+    pts[1, 11, 2] = np.inf
+    pts[1, 12] = 3e7
+    want = oracle.point_in_tet(tet, pts)
+    t, p = torch.from_numpy(tet).to(cuda), torch.from_numpy(pts).to(cuda)
+    gw = torch.randn(2, 5000, 4, device=cuda, generator=torch.Generator(device=cuda).manual_seed(1))
+    ref_c, ref_w, ref_h = hip_ops.point_in_tet(t, p, want_bary=True, want_hits=True, algo=algo)
+    assert np.array_equal(ref_c.cpu().numpy(), want)
+    ref_g = hip_ops.point_in_tet_bwd(t, p, ref_c, gw, hits=ref_h)[0]
+    fin = torch.from_numpy(np.nan_to_num(pts, nan=0.0, posinf=0.0, neginf=0.0).clip(-1, 1)).to(cuda)
+    exact = torch.cat([fin.amin(1), fin.amax(1)], 1).contiguous()
+    boxes = {
+        "exact": exact,
+        "half": (exact * 0.5).contiguous(),                                       # most queries outside: the side path answers them
+        "tiny": (exact * 1e-3).contiguous(),
+        "elsewhere": (exact + 5.0).contiguous(),                                  # no query inside
+        "nan": torch.full((2, 6), float("nan"), device=cuda),
+        "inverted": torch.cat([exact[:, 3:], exact[:, :3]], 1).contiguous(),
+        "huge": torch.tensor([[-1e30] * 3 + [1e30] * 3] * 2, device=cuda),
+        "flat": torch.cat([exact[:, :3], exact[:, :2], exact[:, 2:3]], 1).contiguous(),   # zero extent along z
+    }
+    for name, box in boxes.items():
+        c, w, h = hip_ops.point_in_tet(t, p, want_bary=True, want_hits=True, algo=algo, query_box=box)
+        assert np.array_equal(c.cpu().numpy(), want), name
+        assert torch.equal(w.view(torch.int32), ref_w.view(torch.int32)), name     # (bit patterns: the NaN query hits tet 0 with NaN weights)
+        g = hip_ops.point_in_tet_bwd(t, p, c, gw, hits=h)[0]
+        fin_g = torch.isfinite(ref_g)
+        assert torch.equal(fin_g, torch.isfinite(g)), name
+        assert (g - ref_g)[fin_g].abs().max().item() <= 2e-6 * ref_g[fin_g].abs().max().item(), name   # (side-path hits are summed by the list path)
+
+
+def test_query_box_tracking_over_rotating_query_sets(cuda):
+    """query_box="track" as the autograd ops use it: three different query sets in turns (different boxes), every call equal to the
+    brute-force kernel; then a set from a shifted, larger box (the first call after the shift is served by the side path)."""
+    from deftet_amd import grids, hip_ops
+    tet, _, _, _ = grids.make_case(16, 10, 2)
+    t = torch.from_numpy(tet).to(cuda)
+    hip_ops.clear_query_box_cache()
+    rng = np.random.default_rng(0)
+    sets = [torch.from_numpy((1.05 * (rng.random((2, 4000, 3)) - 0.5)).astype(np.float32)).to(cuda) for _ in range(3)]
+    for i in range(7):
+        p = sets[i % 3]
+        got = hip_ops.point_in_tet(t, p, query_box="track")
+        assert torch.equal(got, hip_ops.point_in_tet(t, p, algo=hip_ops.PIT_BRUTE)), i
+    shifted = (sets[0] * 1.6 + 0.1).contiguous()
+    for i in range(3):
+        got = hip_ops.point_in_tet(t, shifted, query_box="track")
+        assert torch.equal(got, hip_ops.point_in_tet(t, shifted, algo=hip_ops.PIT_BRUTE)), i
+    # the two-call form takes the box on the query side
+    pq = hip_ops.prepare_queries(sets[1], t.shape[1], query_box="track")
+    got = hip_ops.point_in_tet(t, sets[1], prepared=pq)
+    assert torch.equal(got, hip_ops.point_in_tet(t, sets[1], algo=hip_ops.PIT_BRUTE))
+    hip_ops.clear_query_box_cache()

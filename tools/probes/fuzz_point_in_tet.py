@@ -55,14 +55,28 @@ while time.time() < t_end:
         pts[:, :k] = float("nan"); pts[:, k:2 * k] = 3e6 * scale
     ref = hip_ops.point_in_tet(tet, pts, algo=1)
     for algo in (0, 2, 3, 4, 5):
-        got = hip_ops.point_in_tet(tet, pts, algo=algo)
+        # a random traversal order and a random query box now and then: neither may change a result
+        order = None
+        if T > 1 and rng.random() < 0.3:
+            order = torch.from_numpy(rng.permutation(T).astype("int32")).to(dev) if rng.random() < 0.5 else hip_ops.tet_spatial_order(tet[0])
+        box = None
+        if rng.random() < 0.4:
+            c0 = (torch.rand(B, 3, device=dev, generator=g) - 0.5) * scale
+            half = torch.rand(B, 3, device=dev, generator=g) * scale * float(rng.choice([0.01, 0.3, 0.7, 2.0]))
+            box = torch.cat([c0 - half, c0 + half], 1).contiguous()
+        got = hip_ops.point_in_tet(tet, pts, algo=algo, order=order, query_box=box)
         if not torch.equal(got, ref):
             bad = (got != ref).nonzero()[0].tolist()
             print("MISMATCH algo=%d B=%d T=%d Q=%d kind=%d scale=%g size=%g at %s: %s vs %s" % (algo, B, T, Q, kind, scale, size, bad, got[tuple(bad)].item(), ref[tuple(bad)].item()), flush=True)
             sys.exit(1)
     pred = torch.rand(B, T, device=dev, generator=g)
     falgo = int(rng.choice([0, 2, 3, 4, 5]))
-    cond, w, occ, hits = hip_ops.point_in_tet(tet, pts, want_bary=True, pred_bxt=pred, want_hits=True, algo=falgo)
+    fbox = None
+    if rng.random() < 0.4:
+        c0 = (torch.rand(B, 3, device=dev, generator=g) - 0.5) * scale
+        half = torch.rand(B, 3, device=dev, generator=g) * scale * float(rng.choice([0.3, 0.7, 2.0]))
+        fbox = torch.cat([c0 - half, c0 + half], 1).contiguous()
+    cond, w, occ, hits = hip_ops.point_in_tet(tet, pts, want_bary=True, pred_bxt=pred, want_hits=True, algo=falgo, query_box=fbox)
     assert torch.equal(cond, ref)
     gw = torch.randn(B, Q, 4, device=dev, generator=g); go = torch.randn(B, Q, device=dev, generator=g)
     a = hip_ops.point_in_tet_bwd(tet, pts, cond, gw, grad_occ=go, hits=hits)
