@@ -91,9 +91,12 @@ __device__ unsigned long long g_phase[kPhaseWaves][16];
         if ((threadIdx.x & 63) == 0) g_phase[ph_w_][i] += (unsigned long long)(ph_n_ - ph_t_); \
         ph_t_ = ph_n_;                                                                 \
     } while (0)
+// (the argument is evaluated by the whole wave BEFORE the lane-0 branch: written inside it, a ballot in `v` saw lane 0 only —
+// the "0.04 ungrouped lanes per wave" of round 4 were 1.9)
 #define PHASE_COUNT(i, v)                                                              \
     do {                                                                               \
-        if ((threadIdx.x & 63) == 0) g_phase[ph_w_][i] += (unsigned long long)(v);     \
+        const unsigned long long pc_ = (unsigned long long)(v);                        \
+        if ((threadIdx.x & 63) == 0) g_phase[ph_w_][i] += pc_;                         \
     } while (0)
 // why lanes end up outside every footprint group (lanes per reason, summed over the waves of all launches)
 __device__ unsigned long long g_reason[8];
@@ -1417,6 +1420,12 @@ constexpr int kWvCapPair = PIT_WVCAP_PAIR, kWvRowsPair = 256;
 #ifndef PIT_DBG_PEND
 #define PIT_DBG_PEND 1
 #endif
+// probe builds only (-DPIT_STOP=n): the traversal ends after stage n (1 setup, 2 groups + radius, 3 row bounds + scan, 4 staging
+// without the candidate loop but with the tail, 5 everything but the publish / record tail) with what it computed kept alive, so that instruction counters can be read per stage
+#ifndef PIT_STOP
+#define PIT_STOP 0
+#endif
+#define PIT_KEEP(x) asm volatile("" ::"v"(x))
 #ifndef PIT_WAVES_PAIR
 #define PIT_WAVES_PAIR 5
 #endif
@@ -1688,6 +1697,13 @@ __device__ __forceinline__ void tet_scan_wave_body(const float *__restrict__ tet
     bool work = works[0];
 #pragma unroll
     for (int k = 1; k < NT; ++k) work = work || works[k];
+    if (PIT_STOP == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { PIT_KEEP(F[0].N[i][0]); PIT_KEEP(F[0].N[i][1]); PIT_KEEP(F[0].N[i][2]); PIT_KEEP(F[0].C[i]); }
+        PIT_KEEP(eabsMax[0]); PIT_KEEP(mrg[0]); PIT_KEEP(wk[0][0]); PIT_KEEP(wk[0][1]); PIT_KEEP(wk[0][2]);
+        PIT_KEEP(cx0); PIT_KEEP(cx1); PIT_KEEP(cy0); PIT_KEEP(cy1); PIT_KEEP(cz0); PIT_KEEP(cz1); PIT_KEEP((int)work);
+        return;
+    }
     const int Gp = table_pitch(G);
     const int *tb = table + (size_t)b * cellStride;
     const float4 *sq = sortedQ + (size_t)b * Q;
@@ -1768,6 +1784,12 @@ __device__ __forceinline__ void tet_scan_wave_body(const float *__restrict__ tet
             for (int i = 0; i < 4; ++i) { F[k].N[i][0] = F[k].N[i][1] = F[k].N[i][2] = 0.f; F[k].C[i] = -INFINITY; }
             F[k].twoEmax = 0.f;
         }
+    }
+    if (PIT_STOP == 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { PIT_KEEP(F[0].N[i][0]); PIT_KEEP(F[0].N[i][1]); PIT_KEEP(F[0].N[i][2]); PIT_KEEP(F[0].C[i]); }
+        PIT_KEEP(F[0].twoEmax); PIT_KEEP(gid); PIT_KEEP(rowsTot); PIT_KEEP(rowOff1); PIT_KEEP(cz0); PIT_KEEP(cz1);
+        return;
     }
     PHASE_MARK(0);                                                       // [0] load + setup + grouping
     int *resb = uniform_ptr(result + (size_t)b * Q);
@@ -1870,6 +1892,12 @@ __device__ __forceinline__ void tet_scan_wave_body(const float *__restrict__ tet
         }
         if (lane == 0) W.rowBase[Rtot] = (unsigned short)N;
         wave_sync();
+        if (PIT_STOP == 3) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { PIT_KEEP(F[0].N[i][0]); PIT_KEEP(F[0].N[i][1]); PIT_KEEP(F[0].N[i][2]); PIT_KEEP(F[0].C[i]); }
+            PIT_KEEP(F[0].twoEmax); PIT_KEEP(gid); PIT_KEEP(N); PIT_KEEP(lb); PIT_KEEP(cz0); PIT_KEEP(cz1);
+            return;
+        }
         PHASE_MARK(4);                                                   // [4] row bounds, scan
         // the lane's rows: the slabs [cz0, cz1] of its group's footprint, all of the footprint's y rows
         const bool mine2 = gid == 1;
@@ -1930,7 +1958,14 @@ __device__ __forceinline__ void tet_scan_wave_body(const float *__restrict__ tet
             // values of a candidate to one lane — was measured: the vector instructions around the matrix ones (dead-slot masks,
             // minima, acceptance bookkeeping, the transposition through LDS) are as many as the 14 it replaces: 94 vs 82 us.)
             const int lo = max(rn, r0), hi = min(re, r1);
-            if (gid >= 0 && lo < hi) {
+#ifdef PIT_PHASE_TIMING
+            {   // candidates of the wave's busiest lane / of all its lanes in this chunk: what the loop's trip count is made of
+                const int nc = (gid >= 0 && lo < hi) ? (int)W.rowBase[hi] - (int)W.rowBase[lo] : 0;
+                const int mx = __builtin_amdgcn_readlane(wave_scan_max(nc), 63), sm = __builtin_amdgcn_readlane(wave_scan_add(nc), 63);
+                if ((threadIdx.x & 63) == 0) { atomicAdd(&g_reason[0], (unsigned long long)mx); atomicAdd(&g_reason[1], (unsigned long long)sm); }
+            }
+#endif
+            if (PIT_STOP != 4 && gid >= 0 && lo < hi) {
                 unsigned c = (unsigned)(W.rowBase[lo] - B0) * 16u;      // byte offsets into W.q
                 const unsigned e = (unsigned)(W.rowBase[hi] - B0) * 16u;
                 PHASE_COUNT(13, (e - c) >> 4);
@@ -2015,6 +2050,7 @@ __device__ __forceinline__ void tet_scan_wave_body(const float *__restrict__ tet
         }
     }
     PHASE_MARK(2);                                                       // [2] global walk
+    if (PIT_STOP == 5) { PIT_KEEP(slotA[0]); PIT_KEEP(pend0); PIT_KEEP(pend1); PIT_KEEP(npend); return; }   // (everything but the publish / record tail)
     if (!valid) return;
     int hcnt[NT];                                                        // accepted (kWvSlots + 1 stands for "more than kWvSlots")
 #pragma unroll

@@ -31,7 +31,7 @@ def per_kernel(d, counter):
         name = re.sub(r"\(.*", "", row["Kernel_Name"]).replace("void ", "")
         tot[name] += float(row["Counter_Value"]) * 1024.0
         cnt[name] += 1
-    return {k: tot[k] / cnt[k] for k in tot}
+    return {k: tot[k] / cnt[k] for k in tot}, dict(cnt)
 
 
 def source_sha1():
@@ -42,7 +42,7 @@ def source_sha1():
 
 
 def main(fetch_dir, write_dir):
-    f, w = per_kernel(fetch_dir, "FETCH_SIZE"), per_kernel(write_dir, "WRITE_SIZE")
+    (f, fc), (w, _) = per_kernel(fetch_dir, "FETCH_SIZE"), per_kernel(write_dir, "WRITE_SIZE")
     out = {"note": __doc__.split("Corrections", 1)[1].strip().replace("\n", " "), "kernel_source_sha1": source_sha1(),
            "commit": os.environ.get("DEFTET_COMMIT", "(fill in: git rev-parse HEAD of the measured tree)"), "per_kernel": {}}
     for k in sorted(set(f) | set(w)):
@@ -53,8 +53,15 @@ def main(fetch_dir, write_dir):
     for k, v in out["per_kernel"].items():                      # "<short kernel name>_hbm_bytes_per_launch" (bench.py reads the dominant kernel's)
         short = re.sub(r"<.*", "", k.split("::")[-1])              # template instances share their kernel's key (k_tet_scan_wave<false>)
         out["%s_hbm_bytes_per_launch" % short] = out.get("%s_hbm_bytes_per_launch" % short, 0) or (v["fetch_bytes_corrected_x2"] + v["WRITE_SIZE_bytes"])
-    step = sum(v["fetch_bytes_corrected_x2"] + v["WRITE_SIZE_bytes"] for v in out["per_kernel"].values())
-    out["whole_step_hbm_bytes"] = step
+    # the step = the kernels launched once per step: everything launched at least half as often as the most frequent kernel
+    # (the one-time launches of a run — the traversal-order choice of the first call, the first call's measured query box —
+    # are in per_kernel but not in the sum)
+    most = max((fc.get(k, 0) for k in out["per_kernel"]), default=0)
+    step_kernels = [k for k in out["per_kernel"] if fc.get(k, 0) * 2 >= most]
+    for k, v in out["per_kernel"].items():
+        v["launches"] = fc.get(k, 0)
+    out["step_kernels"] = [k.split("::")[-1] for k in step_kernels]
+    out["whole_step_hbm_bytes"] = sum(out["per_kernel"][k]["fetch_bytes_corrected_x2"] + out["per_kernel"][k]["WRITE_SIZE_bytes"] for k in step_kernels)
     print(json.dumps(out, indent=1))
 
 
