@@ -80,7 +80,7 @@ __device__ __forceinline__ void note_overflow(int *counters, int nB, int b, int 
 // Diagnostic build only (tools/probes/build_variant.sh … -DPIT_PHASE_TIMING): per-phase wall cycles of the traversal
 // kernel.  Lane 0 of every wave adds its s_memtime deltas to a slot of its own (no atomics: same-address atomics from
 // 32 k waves would dominate what is being measured); deftet_debug_phase_read sums the slots.
-constexpr int kPhaseWaves = 1 << 16;
+constexpr int kPhaseWaves = 1 << 17;
 __device__ unsigned long long g_phase[kPhaseWaves][16];
 #define PHASE_DECL                                                                                      \
     long long ph_t_ = clock64();                                                                        \
@@ -98,6 +98,12 @@ __device__ unsigned long long g_phase[kPhaseWaves][16];
         const unsigned long long pc_ = (unsigned long long)(v);                        \
         if ((threadIdx.x & 63) == 0) g_phase[ph_w_][i] += pc_;                         \
     } while (0)
+// when every wave of the traversal starts and ends (constant-rate wall clock, 100 MHz): the launch's occupancy over time
+__device__ unsigned long long g_span[kPhaseWaves][2];
+#define SPAN_MARK(k)                                                                                                     \
+    do {                                                                                                                 \
+        if ((threadIdx.x & 63) == 0) g_span[ph_w_][k] = wall_clock64();                                                  \
+    } while (0)
 // why lanes end up outside every footprint group (lanes per reason, summed over the waves of all launches)
 __device__ unsigned long long g_reason[8];
 #define REASON_COUNT(i, mask)                                                                                        \
@@ -106,6 +112,7 @@ __device__ unsigned long long g_reason[8];
         if (rm_ != 0ull && (threadIdx.x & 63) == 0) atomicAdd(&g_reason[i], (unsigned long long)__popcll(rm_));     \
     } while (0)
 #else
+#define SPAN_MARK(k)
 #define REASON_COUNT(i, mask)
 #define PHASE_DECL
 #define PHASE_MARK(i)
@@ -1407,6 +1414,11 @@ constexpr int kWvRows = 192;                            // (cz, cy) rows of a st
 #endif
 constexpr int kWvCap = PIT_WVCAP;                       // staged queries per chunk
 constexpr int kWvSlots = 6;                             // accepted queries a lane keeps: record + half a spill record
+#ifndef PIT_WG
+#define PIT_WG 128     // 256: 64.4-64.8 / 144.5-145.8 us at configs[2] / [3]; 128: 63.3 / 142.8; 64: 64.2 / 143.1 (a workgroup frees its slots when its slowest wave ends)
+#endif
+constexpr int kWvThreads = PIT_WG;                      // threads per workgroup of the wave-staged kernels (nothing in them needs more than a wave)
+static_assert(kWvThreads % 64 == 0 && kWvThreads >= 64 && kWvThreads <= 256, "whole waves");
 static_assert(kWvRows % 64 == 0 && kWvSlots >= 4 && kWvSlots <= 8, "whole waves of row ids; the records hold four + four");
 // two tets per lane (k_tet_scan_pair): the wave's footprint holds the rows and queries of 128 tets
 #ifndef PIT_WVCAP_PAIR
@@ -1569,7 +1581,7 @@ __device__ __noinline__ int exact_rescan_slots(const float *__restrict__ tv, int
                     accept(P, q.x, q.y, q.z)) {
                     const int qi = __float_as_int(q.w);
                     atomicMin(&res[qi], t);
-                    slotCol[min(hcnt, kWvSlots) * 256] = qi;
+                    slotCol[min(hcnt, kWvSlots) * kWvThreads] = qi;
                     ++hcnt;
                 }
             }
@@ -1593,8 +1605,8 @@ __device__ __forceinline__ void tet_scan_wave_body(const float *__restrict__ tet
 {
     constexpr int CAP = NT == 1 ? kWvCap : kWvCapPair, ROWS = NT == 1 ? kWvRows : kWvRowsPair;
     typedef WaveStageT<CAP, ROWS> Stage;
-    __shared__ Stage s_w[4];
-    __shared__ int s_hit[NT][kWvSlots + 2][256];                       // [tet of the lane][slot][thread]; the last two rows swallow the overflow
+    __shared__ Stage s_w[kWvThreads / 64];
+    __shared__ int s_hit[NT][kWvSlots + 2][kWvThreads];                // [tet of the lane][slot][thread]; the last two rows swallow the overflow
     if (ucount && blockIdx.x == 0 && __builtin_amdgcn_readfirstlane(threadIdx.x) == 0) {   // per-shape words of the hit buffer
         ucount[blockIdx.y] = 0;                                        // (wave-uniform branch, see k_tet_scan_slab: behind a
         ucount[hpad + blockIdx.y] = 0;                                 // one-thread branch: 80 registers and an 8-byte scratch store
@@ -1615,6 +1627,7 @@ __device__ __forceinline__ void tet_scan_wave_body(const float *__restrict__ tet
     };
     auto tet_exists = [&](int k) -> bool { return valid && (NT == 1 || NT * t + k < T); };
     PHASE_DECL;
+    SPAN_MARK(0);
     const Grid g = load_grid(gparam + b * kGridWords);
     // --- filter-only setup -------------------------------------------------------------------------------------------
     // Everything that does not depend on the lane's group is finished here, so that the vertices and normals are dead
@@ -1799,8 +1812,8 @@ __device__ __forceinline__ void tet_scan_wave_body(const float *__restrict__ tet
     unsigned slot0[NT], slotEnd[NT], slotA[NT];                         // byte offsets into s_hit
 #pragma unroll
     for (int k = 0; k < NT; ++k) {
-        slot0[k] = (unsigned)(k * (kWvSlots + 2) * 256 + tid) * 4u;
-        slotEnd[k] = slot0[k] + (unsigned)(kWvSlots + 1) * 1024u;
+        slot0[k] = (unsigned)(k * (kWvSlots + 2) * kWvThreads + tid) * 4u;
+        slotEnd[k] = slot0[k] + (unsigned)(kWvSlots + 1) * (unsigned)(kWvThreads * 4);
         slotA[k] = slot0[k];
     }
     int pend0 = -1, pend1 = -1, npend = 0;                              // undecided candidates: query id, tet of the lane in bit 30
@@ -1831,7 +1844,7 @@ __device__ __forceinline__ void tet_scan_wave_body(const float *__restrict__ tet
                 // after the loops (an atomic per acceptance here is a vector-memory instruction with one or two live lanes in
                 // most wave-iterations: 28 of them per wave kept the address unit as busy as the round-3 gathers did)
                 *reinterpret_cast<int *>(reinterpret_cast<char *>(&s_hit[0][0][0]) + slotA[k]) = qi;
-                slotA[k] = min(slotA[k] + 1024u, slotEnd[k]);
+                slotA[k] = min(slotA[k] + (unsigned)(kWvThreads * 4), slotEnd[k]);
             }
         bool band = fabsf(av[0]) <= F[0].twoEmax;                       // rare: decided by the reference predicate after the loops
 #pragma unroll
@@ -1958,13 +1971,6 @@ __device__ __forceinline__ void tet_scan_wave_body(const float *__restrict__ tet
             // values of a candidate to one lane — was measured: the vector instructions around the matrix ones (dead-slot masks,
             // minima, acceptance bookkeeping, the transposition through LDS) are as many as the 14 it replaces: 94 vs 82 us.)
             const int lo = max(rn, r0), hi = min(re, r1);
-#ifdef PIT_PHASE_TIMING
-            {   // candidates of the wave's busiest lane / of all its lanes in this chunk: what the loop's trip count is made of
-                const int nc = (gid >= 0 && lo < hi) ? (int)W.rowBase[hi] - (int)W.rowBase[lo] : 0;
-                const int mx = __builtin_amdgcn_readlane(wave_scan_max(nc), 63), sm = __builtin_amdgcn_readlane(wave_scan_add(nc), 63);
-                if ((threadIdx.x & 63) == 0) { atomicAdd(&g_reason[0], (unsigned long long)mx); atomicAdd(&g_reason[1], (unsigned long long)sm); }
-            }
-#endif
             if (PIT_STOP != 4 && gid >= 0 && lo < hi) {
                 unsigned c = (unsigned)(W.rowBase[lo] - B0) * 16u;      // byte offsets into W.q
                 const unsigned e = (unsigned)(W.rowBase[hi] - B0) * 16u;
@@ -2054,7 +2060,7 @@ __device__ __forceinline__ void tet_scan_wave_body(const float *__restrict__ tet
     if (!valid) return;
     int hcnt[NT];                                                        // accepted (kWvSlots + 1 stands for "more than kWvSlots")
 #pragma unroll
-    for (int k = 0; k < NT; ++k) hcnt[k] = (int)((slotA[k] - slot0[k]) >> 10);
+    for (int k = 0; k < NT; ++k) hcnt[k] = (int)((slotA[k] - slot0[k]) / (unsigned)(kWvThreads * 4));
     if (PIT_DBG_PEND && npend > 0) {                                     // undecided candidates (rare)
         atomicAdd(&counters[gridDim.y * 4 + b * 4 + 1], npend);         // statistics: candidates decided exactly
         if (npend > 2) {
@@ -2124,6 +2130,7 @@ __device__ __forceinline__ void tet_scan_wave_body(const float *__restrict__ tet
         irregular_tail(tet, te, b, T, Q, pts, counters, irregQ, result);
     }
     PHASE_MARK(3);                                                       // [3] exact decisions, records
+    SPAN_MARK(1);
 }
 
 #define PIT_SCAN_PARAMS                                                                                                               \
@@ -2132,12 +2139,12 @@ __device__ __forceinline__ void tet_scan_wave_body(const float *__restrict__ tet
         const float *__restrict__ pts, const int *__restrict__ irregQ, int *ucount, int hpad, int4 *spill, const int *__restrict__ order
 #define PIT_SCAN_FWD tet, T, Q, gparam, G, Gx, table, cellStride, sortedQ, result, counters, irregT, hits, pts, irregQ, ucount, hpad, spill, order
 template <bool ORD>
-__global__ __launch_bounds__(256, PIT_WAVES2) void k_tet_scan_wave(PIT_SCAN_PARAMS)
+__global__ __launch_bounds__(kWvThreads, PIT_WAVES2) void k_tet_scan_wave(PIT_SCAN_PARAMS)
 {
     tet_scan_wave_body<ORD, 1>(PIT_SCAN_FWD);
 }
 template <bool ORD>
-__global__ __launch_bounds__(256, PIT_WAVES_PAIR) void k_tet_scan_pair(PIT_SCAN_PARAMS)
+__global__ __launch_bounds__(kWvThreads, PIT_WAVES_PAIR) void k_tet_scan_pair(PIT_SCAN_PARAMS)
 {
     tet_scan_wave_body<ORD, 2>(PIT_SCAN_FWD);
 }
@@ -2989,15 +2996,17 @@ static int pit_scan(const Layout &L, const float *tet, const float *pts, float *
             int4 *spill = hit_buf ? (int4 *)(hit_buf + hit_spill_off(B, T, Q)) : (int4 *)nullptr;
             const int kern = resolve_auto(algo, T, Q);
             const bool slab = kern == DEFTET_PIT_SLAB;
-            const dim3 gp(((((T + 1) / 2 + 255) / 256 + 7) / 8) * 8, B);                  // two tets per lane
+            const dim3 bw(kWvThreads);                                                           // the wave-staged kernels' workgroup
+            const dim3 gw((((T + kWvThreads - 1) / kWvThreads + 7) / 8) * 8, B);
+            const dim3 gp(((((T + 1) / 2 + kWvThreads - 1) / kWvThreads + 7) / 8) * 8, B);       // two tets per lane
 #define PIT_SCAN_ARGS tet, T, Q, L.gparam, L.G, L.Gx, L.table, L.cellStride, L.sortedQ, L.result, L.counters, L.irregT, (int4 *)hit_buf, pts, \
                       L.irregQ, ucount, hit_pad(B), spill, (const int *)order
             if (slab && order) DEFTET_LAUNCH(k_tet_scan_slab<true>, gt, blk, st, PIT_SCAN_ARGS);
             else if (slab) DEFTET_LAUNCH(k_tet_scan_slab<false>, gt, blk, st, PIT_SCAN_ARGS);
-            else if (kern == DEFTET_PIT_PAIR && order) DEFTET_LAUNCH(k_tet_scan_pair<true>, gp, blk, st, PIT_SCAN_ARGS);
-            else if (kern == DEFTET_PIT_PAIR) DEFTET_LAUNCH(k_tet_scan_pair<false>, gp, blk, st, PIT_SCAN_ARGS);
-            else if (order) DEFTET_LAUNCH(k_tet_scan_wave<true>, gt, blk, st, PIT_SCAN_ARGS);
-            else DEFTET_LAUNCH(k_tet_scan_wave<false>, gt, blk, st, PIT_SCAN_ARGS);
+            else if (kern == DEFTET_PIT_PAIR && order) DEFTET_LAUNCH(k_tet_scan_pair<true>, gp, bw, st, PIT_SCAN_ARGS);
+            else if (kern == DEFTET_PIT_PAIR) DEFTET_LAUNCH(k_tet_scan_pair<false>, gp, bw, st, PIT_SCAN_ARGS);
+            else if (order) DEFTET_LAUNCH(k_tet_scan_wave<true>, gw, bw, st, PIT_SCAN_ARGS);
+            else DEFTET_LAUNCH(k_tet_scan_wave<false>, gw, bw, st, PIT_SCAN_ARGS);
 #undef PIT_SCAN_ARGS
         }
     } else if (ucount) {
@@ -3139,6 +3148,27 @@ extern "C" int deftet_point_in_tet_read_stats(const void *workspace, size_t work
 }
 
 #ifdef PIT_PHASE_TIMING
+// probe builds: what the runtime says about the residency of the traversal kernels (workgroups of 256 threads per compute unit)
+extern "C" int deftet_debug_occupancy(int *out8)
+{
+    int n = 0;
+    DEFTET_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)deftet::pit::k_tet_scan_wave<false>, 256, 0)); out8[0] = n;
+    DEFTET_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)deftet::pit::k_tet_scan_pair<false>, 256, 0)); out8[1] = n;
+    DEFTET_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, (const void *)deftet::pit::k_tet_scan_slab<false>, 256, 0)); out8[2] = n;
+    hipFuncAttributes a;
+    DEFTET_HIP(hipFuncGetAttributes(&a, (const void *)deftet::pit::k_tet_scan_wave<false>));
+    out8[3] = (int)a.sharedSizeBytes; out8[4] = a.numRegs; out8[5] = (int)a.maxDynamicSharedSizeBytes;
+    hipDeviceProp_t pr;
+    DEFTET_HIP(hipGetDeviceProperties(&pr, 0));
+    out8[6] = (int)pr.sharedMemPerMultiprocessor; out8[7] = (int)pr.sharedMemPerBlock;
+    return DEFTET_OK;
+}
+extern "C" int deftet_debug_span_read(unsigned long long *out, int n_waves)     // out[2 * n_waves]: start, end per wave id
+{
+    DEFTET_CHECK_ARG(out && n_waves > 0 && n_waves <= deftet::pit::kPhaseWaves, "bad argument");
+    DEFTET_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(deftet::pit::g_span), (size_t)n_waves * 16));
+    return DEFTET_OK;
+}
 extern "C" int deftet_debug_reason_read(unsigned long long *out8, int reset)
 {
     DEFTET_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(deftet::pit::g_reason), 64));

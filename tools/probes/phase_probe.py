@@ -50,5 +50,5 @@ print(json.dumps({"kernel": hip_ops.pit_kernel_name(a.algo, wl.T, wl.Q), "waves_
                   "cycles_per_wave": {k: round(v, 2) for k, v in zip(names, vals)}, "total": round(sum(vals[:7]))}), flush=True)
 if hasattr(raw, "deftet_debug_reason_read"):
     raw.deftet_debug_reason_read(rbuf, 1)
-    print(json.dumps({"ungrouped_lanes_per_launch": dict(zip(["sum_over_waves_of_busiest_lane_candidates", "sum_of_all_lane_candidates", "small_pivot_group(all remaining)", "five_rows", "slabs>64", "rows>cap",
+    print(json.dumps({"ungrouped_lanes_per_launch": dict(zip(["few_left_p0", "few_left_p1", "small_pivot_group(all remaining)", "five_rows", "slabs>64", "rows>cap",
                                                                "left_after_two_groups", "row_longer_than_chunk"], [int(rbuf[i]) // reps for i in range(8)]))}), flush=True)

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Round 5 evidence pass (one box): everything lands in gpurun_out/r05/, the files that are judged are then copied to profiles/.
-#   gpurun -- 'DEFTET_COMMIT=<git rev-parse HEAD> tools/probes/r05_evidence.sh [part ...]'     parts: pmc bench prof ab tol (default: all)
+#   gpurun -- 'DEFTET_COMMIT=<git rev-parse HEAD> tools/probes/r05_evidence.sh [part ...]'     parts: pmc bench prof ab stage tol (default: all)
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
 O=gpurun_out/r05; mkdir -p $O
-parts="${*:-pmc bench prof ab tol}"
+parts="${*:-pmc bench prof ab stage tol}"
 B="python $PWD/bench.py"
 Q="--no-cpu-baseline --no-other-configs --no-bandwidth-probe --no-brute-force"
 has() { case " $parts " in *" $1 "*) return 0;; esac; return 1; }
@@ -38,6 +38,12 @@ if has ab; then
   rm -f $O/r05_step_kernels.jsonl
   for c in 2 1 3; do python tools/probes/sort_probe.py --config $c 2>/dev/null | tail -1 >> $O/r05_step_kernels.jsonl; done
   for c in 2 3; do DEFTET_HIP_LIB=$PWD/tools/probes/bin/libdeftet_phase.so python tools/probes/phase_probe.py --algo 4 --config $c 2>/dev/null | tail -2; done > $O/r05_phase_and_ungrouped_lanes.jsonl
+fi
+if has stage; then
+  STAGES="1 2 3 4 5 0" tools/probes/r05_stage_insts.sh > $O/r05_stage_insts.txt 2>&1
+  rm -f $O/r05_wave_spans.jsonl
+  for c in 2 3; do DEFTET_HIP_LIB=$PWD/tools/probes/bin/libdeftet_phase.so python tools/probes/span_probe.py --config $c 2>/dev/null | tail -1 >> $O/r05_wave_spans.jsonl; done
+  DEFTET_HIP_LIB=$PWD/tools/probes/bin/libdeftet_phase.so python tools/probes/occupancy_probe.py 2>/dev/null | tail -1 > $O/r05_occupancy.txt
 fi
 if has tol; then
   rm -f $O/r05_tolerances.jsonl
