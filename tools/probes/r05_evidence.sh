@@ -26,7 +26,7 @@ if has prof; then
   for spec in "2 r05_bench" "4 r05_raster_step" "5 r05_geometry_step"; do
     set -- $spec
     rm -rf $O/prof_$1
-    (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_$1 -o p -- $B --config $1 --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs --no-brute-force 2>/dev/null | tail -1 > $GRAFT_REPO_ROOT/$O/$2_line_under_rocprof.json)
+    (cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof_$1 -o p -- $B --config $1 --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs --no-brute-force --no-bandwidth-probe 2>/dev/null | tail -1 > $GRAFT_REPO_ROOT/$O/$2_line_under_rocprof.json)
     f=$(find $O/prof_$1 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/$2_kernel_stats.csv
     rm -rf $O/prof_$1
   done
