@@ -29,6 +29,24 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 
 
+# Per-source flags.  -fno-slp-vectorize for point_in_tet.hip: left to itself the compiler packs adjacent scalar fp32 subtractions
+# and products of the per-tet setups into v_pk_add_f32 / v_pk_mul_f32 and pays for it with register shuffles and live ranges —
+# k_bary_bwd_hits needs 94 registers with it and 70 without (five -> six waves per SIMD, 56.0 -> 52.5 us at configs[2]),
+# k_finalize 64 -> 53 (29.4 -> 28.0), the traversal 62.7 -> 61.5; the packed FMAs the traversal loop WANTS are written as vector
+# types and stay.  reduce.hip is the opposite case (k_rowdot_fused 16.9 -> 20.7 us without the packing), so the flag is per file.
+# DEFTET_BUILD_NOSLP=a.hip,b.hip adds files for an experiment.
+# (surface_ops.hip: k_tri_query_coop 0.632 -> 0.616 ms, geometry step 2.49 -> 2.465; raster.hip: slower without, 2.415 -> 2.44 ms;
+# tet_ops / check_sign / vertex_ops: no difference — tools/probes/r05_noslp.sh)
+PER_FILE_FLAGS = {"point_in_tet.hip": ["-fno-slp-vectorize"], "surface_ops.hip": ["-fno-slp-vectorize"]}
+
+
+def _file_flags(src):
+    extra = list(PER_FILE_FLAGS.get(os.path.basename(src), []))
+    if os.path.basename(src) in (os.environ.get("DEFTET_BUILD_NOSLP") or "").split(","):
+        extra.append("-fno-slp-vectorize")
+    return extra
+
+
 def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))
 
@@ -36,6 +54,7 @@ def sources():
 def _headers():
     out = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
     out.append(os.path.join(os.path.dirname(HERE), "include", "deftet_hip.h"))
+    out.append(os.path.abspath(__file__))                   # the flags live here: a change of them rebuilds
     return out
 
 
@@ -88,6 +107,7 @@ def _obj_for(src, flags):
 
 
 def _compile(src, flags, force, verbose):
+    flags = flags + _file_flags(src)
     obj = _obj_for(src, flags)
     newest = max(os.path.getmtime(p) for p in [src] + _headers())
     if not force and os.path.exists(obj) and os.path.getmtime(obj) >= newest:
