@@ -2617,7 +2617,10 @@ __device__ __forceinline__ bool bwd_rescan(const float *__restrict__ tet, const 
     return parked;
 }
 
-__global__ __launch_bounds__(256) void k_bary_bwd_hits(const float *__restrict__ tet, const float *__restrict__ pts,
+#ifndef PIT_BWD_WAVES
+#define PIT_BWD_WAVES 7
+#endif
+__global__ __launch_bounds__(256, PIT_BWD_WAVES) void k_bary_bwd_hits(const float *__restrict__ tet, const float *__restrict__ pts,
                                                        const float *__restrict__ cond, const float *__restrict__ grad_w,
                                                        const int4 *__restrict__ hits, int T, int Q, float *grad_tet,
                                                        float *grad_pts, int accumulate, const float *__restrict__ gocc,
@@ -2627,8 +2630,14 @@ __global__ __launch_bounds__(256) void k_bary_bwd_hits(const float *__restrict__
     __shared__ float wsum[4];
     __shared__ float s_vals[kMissStride];
     __shared__ int s_last;
-    __shared__ float4 s_rows[4][192];
-    __shared__ float s_park[13][256];
+    // One buffer for two uses that never overlap in time: `s_park` (the rare rescan parks its sums there until the record's own
+    // hits have been added) and `s_rows` (the wave's 48-byte rows on their way out).  The rescan only runs when the shape has
+    // uncovered hits (nU > 0, the same for every thread of the workgroup), and then a barrier separates the last read of s_park
+    // from the first write of s_rows; without it the kernel held 25.9 KB per workgroup — six per compute unit where its 70
+    // registers allow seven.
+    __shared__ __attribute__((aligned(16))) float s_buf[13 * 256];
+    float4(*s_rows)[192] = reinterpret_cast<float4(*)[192]>(s_buf);   // [4][192] float4 = 12 KB of the 13 KB
+    float(*s_park)[256] = reinterpret_cast<float(*)[256]>(s_buf);     // [13][256] float
     const int2 sb = shape_block(pin);                                  // shape-per-XCD placement
     const int b = sb.x, bx = sb.y, tid = threadIdx.x, lane = tid & 63;
     const bool side = grad_pred && bx < nMissParts;                // block-uniform
@@ -2722,6 +2731,7 @@ __global__ __launch_bounds__(256) void k_bary_bwd_hits(const float *__restrict__
         for (int k = 0; k < 12; ++k) acc[k] += s_park[k][tid];
         gp += s_park[12][tid];
     }
+    if (nU > 0) __syncthreads();                                   // (workgroup-uniform) s_park is done with before s_rows overwrites it
     if (live) {
         const bool deferred = grad_pred && t == 0;                 // tet 0 of the shape: written by the ticket winner below
         if (grad_pred && !deferred) stream_store(grad_pred + (size_t)b * T + t, accumulate ? grad_pred[(size_t)b * T + t] + gp : gp);
