@@ -45,6 +45,36 @@ def test_ops_fail_loudly_without_gpu_tensors():
     from deftet_amd.layers.DefTet.check_condition_tetrahedron_base.utils import check_condition_f_base
     with pytest.raises(_lib.DefTetHipError):
         check_condition_f_base(torch.zeros(1, 2, 4, 3), torch.zeros(1, 3, 3))
+    # the round-5 entry points too: the traversal order and the query-box hint never run anywhere but on the GPU
+    from deftet_amd import hip_ops
+    with pytest.raises(_lib.DefTetHipError):
+        hip_ops.tet_spatial_order(torch.zeros(10, 4, 3))
+    with pytest.raises(_lib.DefTetHipError):
+        hip_ops.point_in_tet(torch.zeros(1, 2, 4, 3), torch.zeros(1, 3, 3), order="auto", query_box="track")
+    with pytest.raises(ValueError):
+        hip_ops.pit_kernel_name(hip_ops.PIT_AUTO)               # the kernel AUTO runs depends on the sizes: no silent default
+
+
+def test_tracked_query_boxes_alternate_between_two_buffers():
+    """host logic of query_box="track" (no kernel involved): the first call of a (device, B, Q) measures and writes buffer 0, every later
+    call reads what the previous one wrote and writes the other buffer; DEFTET_PIT_BOX=off disables it."""
+    from deftet_amd import hip_ops
+    hip_ops.clear_query_box_cache()
+    dev = torch.device("cpu", 0)                                 # (the helper only allocates and hands out tensors)
+    i0, o0 = hip_ops._tracked_boxes(dev, 2, 100)
+    i1, o1 = hip_ops._tracked_boxes(dev, 2, 100)
+    i2, o2 = hip_ops._tracked_boxes(dev, 2, 100)
+    assert i0 is None and o0.shape == (2, 6)
+    assert i1 is o0 and o1 is not o0
+    assert i2 is o1 and o2 is o0
+    j0, p0 = hip_ops._tracked_boxes(dev, 2, 101)                 # another query count: its own state
+    assert j0 is None and p0 is not o0 and p0 is not o1
+    os.environ["DEFTET_PIT_BOX"] = "off"
+    try:
+        assert hip_ops._tracked_boxes(dev, 2, 100) == (None, None)
+    finally:
+        del os.environ["DEFTET_PIT_BOX"]
+    hip_ops.clear_query_box_cache()
 
 
 @pytest.mark.parametrize("res", [2, 4, 20])
