@@ -627,6 +627,7 @@ __global__ __launch_bounds__(kSortThreads) void k_slab_sort(const float4 *__rest
     const int nb = (cyHi - cyLo) * GxP, R1 = G * kSub;
     const int binLo = cz * kSub + part * kSubPerPart;
     PHASE_DECL;
+    SPAN_MARK(0);
     // runs of this part, one per chunk
     int a[kRunsPer], len[kRunsPer], asum = 0, lsum = 0;
 #pragma unroll
@@ -769,6 +770,7 @@ __global__ __launch_bounds__(kSortThreads) void k_slab_sort(const float4 *__rest
         }
     }
     PHASE_MARK(12);                                                 // [12] table plane
+    SPAN_MARK(1);
     if (keep) return;
     __syncthreads();
     for (int i = tid; i < n; i += kSortThreads) {
