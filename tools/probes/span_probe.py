@@ -23,7 +23,9 @@ n = wl.B * nblk * 4                                  # (the probe numbers its ro
 buf = (ctypes.c_ulonglong * (2 * n))()
 assert raw.deftet_debug_span_read(buf, n) == 0
 sp = np.frombuffer(buf, dtype=np.uint64).reshape(n, 2).astype(np.int64)
+sp = sp[(np.arange(n) % 4) < WG // 64]               # the rows this kernel's waves write (k_slab_sort stamps the same table before it)
 sp = sp[(sp[:, 1] > sp[:, 0])]                      # waves that ran to the end (a block's padding waves return early)
+sp = sp[sp[:, 0] >= np.percentile(sp[:, 0], 1) - 500]   # (rows of padding workgroups still hold k_slab_sort's earlier stamps: > 5 us before the launch)
 t0 = sp[:, 0].min(); sp = (sp - t0) * 10e-3         # 100 MHz ticks -> microseconds
 life = sp[:, 1] - sp[:, 0]
 end = sp[:, 1].max()
