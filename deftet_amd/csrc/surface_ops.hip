@@ -1922,7 +1922,10 @@ constexpr int kTriQueryBlocks = 8192;
 // (Register budget of FOUR waves per SIMD: the allocator takes 145 VGPRs = three waves when left alone; held to 128 it
 // spills nine dwords and the kernel runs 0.76 -> 0.63 ms at 8 x 97 k points — five waves, 96 VGPRs with 176 bytes of
 // scratch, and six are slower again: geometry step 2.80 / 2.68 / 2.85 / 3.24 ms for 3 / 4 / 5 / 6 waves.)
-__attribute__((amdgpu_waves_per_eu(4, 8)))
+#ifndef TRI_WAVES
+#define TRI_WAVES 4
+#endif
+__attribute__((amdgpu_waves_per_eu(TRI_WAVES, 8)))
 __global__ __launch_bounds__(kTriChunkWaves * 64) void k_tri_query_coop(const float *__restrict__ pts, const float *__restrict__ face,
                                                                          const float *__restrict__ nfb, int P, const TGrid *__restrict__ gp,
                                                                          const int *__restrict__ cellStart, const int *__restrict__ list,
