@@ -426,6 +426,7 @@ constexpr int kMaxBin1 = kMaxG * kSub;     // 896
 // the NEXT call: the box of its chunk's regular queries goes to partOut[chunk], k_slab_sort reduces the chunks' boxes into
 // query_box_out.  Queries the grid does not bin (outside the hint, NaN / Inf / huge) are listed per chunk without a global
 // counter (nobody has zeroed one): irregQ[q0 + i], i < irrCnt[chunk]; k_slab_sort compacts the lists and sets the counters.
+// irrCnt[nShapes * kMaxRowBlocks + chunk] counts the chunk's regular queries OUTSIDE the hint on their own (query_box_misses).
 template <bool HINT>
 __global__ __launch_bounds__(256) void k_slab_local(const float *__restrict__ pts, int Q, const float *__restrict__ bboxPart,
                                                     float *gparam, int G, int Gx, int nblk, int nblkPad, int chunkQ,
@@ -434,7 +435,7 @@ __global__ __launch_bounds__(256) void k_slab_local(const float *__restrict__ pt
 {
     __shared__ int hist[kMaxBin1 + 1];
     __shared__ int wtot[4];
-    __shared__ int s_irr;
+    __shared__ int s_irr, s_out;
     __shared__ float s_box[4][6];
     const int b = blockIdx.y, blk = blockIdx.x, R1 = G * kSub, tid = threadIdx.x;
     const int q0 = blk * chunkQ, q1 = min(Q, q0 + chunkQ);
@@ -449,7 +450,7 @@ __global__ __launch_bounds__(256) void k_slab_local(const float *__restrict__ pt
     }
     if (HINT) {
         for (int q = q0 + tid; q < q1; q += 256) result[(size_t)b * Q + q] = kMiss;
-        if (tid == 0) s_irr = 0;
+        if (tid == 0) { s_irr = 0; s_out = 0; }
     }
     const Grid g = HINT ? hint_grid(boxIn + (size_t)b * 6, G, Gx) : reduce_grid(bboxPart + (size_t)b * kBoxBlocks * 6, kBoxBlocks, G, Gx);
     float blo[3] = {INFINITY, INFINITY, INFINITY}, bhi[3] = {-INFINITY, -INFINITY, -INFINITY};   // HINT: box of this chunk's regular queries
@@ -461,9 +462,13 @@ __global__ __launch_bounds__(256) void k_slab_local(const float *__restrict__ pt
     };
     // a query the grid does not bin: with a measured box that is a NaN / Inf / huge one, with a hint also one outside the hint
     auto binned = [&](float x, float y, float z) { return HINT ? query_binned(x, y, z, g) : query_regular(x, y, z); };
-    auto list_irregular = [&](int q) {
-        if (HINT) irregQ[(size_t)b * Q + q0 + atomicAdd(&s_irr, 1)] = q;                      // LDS counter, the chunk's own segment
-        else irregQ[(size_t)b * Q + atomicAdd(&counters[b * 4 + 1], 1)] = q;
+    auto list_irregular = [&](int q, float x, float y, float z) {
+        if (HINT) {
+            irregQ[(size_t)b * Q + q0 + atomicAdd(&s_irr, 1)] = q;                            // LDS counter, the chunk's own segment
+            if (query_regular(x, y, z)) atomicAdd(&s_out, 1);                                 // a miss of the hint, not a NaN / Inf / huge query
+        } else {
+            irregQ[(size_t)b * Q + atomicAdd(&counters[b * 4 + 1], 1)] = q;
+        }
     };
     if (blk == 0 && tid == 0) {                                    // publish for k_slab_sort / the traversal
         float *gp = gparam + b * kGridWords;                       // (constant indices: a dynamic one sends g through LDS — 13 us)
@@ -489,7 +494,7 @@ __global__ __launch_bounds__(256) void k_slab_local(const float *__restrict__ pt
                     kbin[k] = bin_of(kp[k].x, kp[k].y, kp[k].z);
                     krank[k] = atomicAdd(&hist[kbin[k]], 1);                          // LDS
                 } else {                                           // NaN / Inf / huge (/ outside the hint): tested by every tet lane at the end of the traversal
-                    list_irregular(q);
+                    list_irregular(q, kp[k].x, kp[k].y, kp[k].z);
                 }
             }
         }
@@ -499,7 +504,7 @@ __global__ __launch_bounds__(256) void k_slab_local(const float *__restrict__ pt
             const float x = p[0], y = p[1], z = p[2];
             box_add(x, y, z);
             if (binned(x, y, z)) atomicAdd(&hist[bin_of(x, y, z)], 1);
-            else list_irregular(q);
+            else list_irregular(q, x, y, z);
         }
     }
     if (HINT) {                                                    // the chunk's box for the next call's hint
@@ -523,7 +528,10 @@ __global__ __launch_bounds__(256) void k_slab_local(const float *__restrict__ pt
             for (int i = 1; i < 4; ++i) v = tid < 3 ? fminf(v, s_box[i][tid]) : fmaxf(v, s_box[i][tid]);
             partOut[((size_t)b * kMaxRowBlocks + blk) * 6 + tid] = v;
         }
-        if (tid == 0) irrCnt[b * kMaxRowBlocks + blk] = s_irr;
+        if (tid == 0) {
+            irrCnt[b * kMaxRowBlocks + blk] = s_irr;
+            irrCnt[(gridDim.y + b) * kMaxRowBlocks + blk] = s_out;
+        }
     }
     {   // exclusive scan of the R1 counts (<= 4 consecutive bins per thread); hist[R1] = number of regular queries
         constexpr int kPer = (kMaxBin1 + 255) / 256;               // 4
@@ -592,7 +600,8 @@ __global__ __launch_bounds__(kSortThreads) void k_slab_sort(const float4 *__rest
                                                             int G, int Gx, const int *__restrict__ pre, int nblk, int nblkPad,
                                                             int chunkQ, long long cellStride, int *table, float4 *sortedQ, int pin,
                                                             const float *__restrict__ boxPart, int nPart, int partStride, float *boxOut,
-                                                            int hint, const int *__restrict__ irrCnt, int *irregQ, int *counters)
+                                                            int hint, const int *__restrict__ irrCnt, int *irregQ, int *counters,
+                                                            int *missOut)
 {
     if (shape_block(pin).y == 0 && (boxOut || hint)) {               // (block-uniform; before the sort proper: nothing below depends on it)
         const int b0 = shape_block(pin).x, nB = gridDim.y;
@@ -604,16 +613,27 @@ __global__ __launch_bounds__(kSortThreads) void k_slab_sort(const float4 *__rest
                 for (int k = 0; k < 3; ++k) { boxOut[b0 * 6 + k] = lo[k]; boxOut[b0 * 6 + 3 + k] = hi[k]; }   // lo > hi: no regular query
             }
         }
-        if (hint && threadIdx.x == 0) {
-            int n = 0;
+        if (hint && threadIdx.x < 64) {
+            // One wave, 64 entries per step.  A list's place in the compact list never lies behind its own segment (n <= c *
+            // chunkQ) and every step's loads return before its stores leave (the stores carry the loaded values), so the copy
+            // may overlap its source.
+            int n = 0, nOut = 0;
             for (int c = 0; c < nblk; ++c) {
                 const int cnt = irrCnt[b0 * kMaxRowBlocks + c];
+                nOut += irrCnt[(nB + b0) * kMaxRowBlocks + c];
                 const int *src = irregQ + (size_t)b0 * Q + (size_t)c * chunkQ;
-                for (int i = 0; i < cnt; ++i) irregQ[(size_t)b0 * Q + n++] = src[i];
+                for (int i = (int)threadIdx.x; i < cnt; i += 64) {
+                    const int v = src[i];
+                    irregQ[(size_t)b0 * Q + n + i] = v;
+                }
+                n += cnt;
             }
-            counters[b0 * 4 + 0] = 0; counters[b0 * 4 + 1] = n; counters[b0 * 4 + 2] = 0; counters[b0 * 4 + 3] = 0;
+            if (threadIdx.x == 0) {
+                counters[b0 * 4 + 0] = 0; counters[b0 * 4 + 1] = n; counters[b0 * 4 + 2] = 0; counters[b0 * 4 + 3] = 0;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) counters[nB * 4 + b0 * 4 + k] = 0;
+                for (int k = 0; k < 4; ++k) counters[nB * 4 + b0 * 4 + k] = 0;
+                if (missOut) missOut[b0] = nOut;                     // (may be host-mapped memory: one posted store per shape)
+            }
         }
     }
     extern __shared__ __attribute__((aligned(16))) int cnt[];       // [rows of the part][GxP] counts -> starts (-> placement cursors)
@@ -2911,7 +2931,7 @@ static Layout make_layout(int B, int T, int Q, int algo, void *ws, size_t wsByte
         L.chunkQ = ((Q + L.nRowBlk - 1) / L.nRowBlk + 255) / 256 * 256;
         L.bboxPart = A.take<float>((size_t)B * kBoxBlocks * 6);
         L.chunkBox = A.take<float>((size_t)B * kMaxRowBlocks * 6);  // k_slab_local<true>: the chunks' boxes, the chunks' unbinned counts
-        L.irrCnt = A.take<int>((size_t)B * kMaxRowBlocks);
+        L.irrCnt = A.take<int>((size_t)B * kMaxRowBlocks * 2);      // unbinned queries per chunk, then those of them that are regular
         L.counters = A.take<int>((size_t)B * (8 + kOvfCap));  // 4 counters + 4 statistics words per shape, then the overflowed-tet lists
         L.gparam = A.take<float>((size_t)B * kGridWords);
         L.table = A.take<int>((size_t)B * L.cellStride);
@@ -2974,7 +2994,8 @@ static int pit_check(const float *tet, const float *pts, const float *cond, cons
 }
 
 // query side: resets + bounding box + counting sort of the queries into grid cells (depends on pts, B, T, Q only)
-static int pit_prepare(const Layout &L, const float *pts, int B, int Q, hipStream_t st, const float *boxIn = nullptr, float *boxOut = nullptr)
+static int pit_prepare(const Layout &L, const float *pts, int B, int Q, hipStream_t st, const float *boxIn = nullptr, float *boxOut = nullptr,
+                       int32_t *missOut = nullptr)
 {
     const dim3 blk(256);
     if (boxIn) {                                                         // two launches: the grid spans the box handed in
@@ -2989,7 +3010,7 @@ static int pit_prepare(const Layout &L, const float *pts, int B, int Q, hipStrea
     DEFTET_LAUNCH_SHM(k_slab_sort, dim3(L.G * kParts, B), dim3(kSortThreads), shm, st, L.localQ, Q, L.gparam, L.G, L.Gx, L.pre, L.nRowBlk, L.nblkPad,
                       L.chunkQ, L.cellStride, L.table, L.sortedQ, (size_t)Q * 16 <= ((size_t)4 << 20),
                       (const float *)(boxIn ? L.chunkBox : L.bboxPart), boxIn ? L.nRowBlk : kBoxBlocks, boxIn ? kMaxRowBlocks : kBoxBlocks, boxOut,
-                      boxIn ? 1 : 0, (const int *)L.irrCnt, L.irregQ, L.counters);
+                      boxIn ? 1 : 0, (const int *)L.irrCnt, L.irregQ, L.counters, (int *)(boxIn ? missOut : nullptr));
     return DEFTET_OK;
 }
 
@@ -3031,7 +3052,7 @@ static int pit_scan(const Layout &L, const float *tet, const float *pts, float *
 
 static int pit_forward(const float *tet, const float *pts, float *cond, float *bary, const float *pred, float *occ, int32_t *hit_buf,
                        int B, int T, int Q, int algo, void *workspace, size_t workspace_bytes, void *stream_, const int32_t *order,
-                       const float *boxIn = nullptr, float *boxOut = nullptr)
+                       const float *boxIn = nullptr, float *boxOut = nullptr, int32_t *missOut = nullptr)
 {
     int rc = pit_check(tet, pts, cond, bary, pred, occ, hit_buf, B, T, Q, algo, workspace);
     if (rc != DEFTET_OK || B == 0 || Q == 0) return rc;
@@ -3049,7 +3070,7 @@ static int pit_forward(const float *tet, const float *pts, float *cond, float *b
                       (int *)nullptr, (const int *)nullptr, L.irregT, 0, pin_shapes(Q), (const float *)nullptr);
         return DEFTET_OK;
     }
-    rc = pit_prepare(L, pts, B, Q, st, boxIn, boxOut);
+    rc = pit_prepare(L, pts, B, Q, st, boxIn, boxOut, missOut);
     if (rc != DEFTET_OK) return rc;
     return pit_scan(L, tet, pts, cond, bary, pred, occ, hit_buf, B, T, Q, algo, st, order);
 }
@@ -3069,15 +3090,18 @@ extern "C" int deftet_point_in_tet_f32(const float *tet, const float *pts, float
 // a hint: queries outside it are answered exactly by the side path that handles NaN / Inf / huge queries, at brute-force cost
 // each — hand in the sampler's box, or the box an earlier call with the same query distribution measured: query_box_out
 // (f32 [B,6] or NULL, must not alias query_box_in) receives the box of THIS call's regular queries (lo > hi when there is none).
-// The brute-force algorithm ignores both.
+// query_box_misses (int32 [B] or NULL; any memory the device can write, e.g. host-mapped so that the caller can poll it
+// without synchronising) receives, when query_box_in is given, how many regular queries of each shape fell outside it: the
+// feedback a caller that reuses boxes needs to notice that its query distribution moved (hip_ops.point_in_tet's "track"
+// mode goes back to measuring when it sees misses).  The brute-force algorithm ignores all three.
 extern "C" int deftet_point_in_tet_ex_f32(const float *tet, const float *pts, float *cond, float *bary, const float *pred,
                                           float *occ, int32_t *hit_buf, int B, int T, int Q, int algo, const int32_t *tet_order,
-                                          const float *query_box_in, float *query_box_out,
+                                          const float *query_box_in, float *query_box_out, int32_t *query_box_misses,
                                           void *workspace, size_t workspace_bytes, void *stream_)
 {
     DEFTET_CHECK_ARG(!query_box_in || query_box_in != query_box_out, "query_box_in and query_box_out must not alias");
     return pit_forward(tet, pts, cond, bary, pred, occ, hit_buf, B, T, Q, algo, workspace, workspace_bytes, stream_, tet_order,
-                       query_box_in, query_box_out);
+                       query_box_in, query_box_out, query_box_misses);
 }
 
 // The same operator in two calls: the QUERY side (bounding box + counting sort: depends on pts and on
@@ -3086,20 +3110,21 @@ extern "C" int deftet_point_in_tet_ex_f32(const float *tet, const float *pts, fl
 // (the scan uses up the result sentinels and counters the prepare resets); both must see the same
 // pts, sizes, algo and workspace.
 static int pit_prepare_entry(const float *pts, int B, int T, int Q, int algo, void *workspace, size_t workspace_bytes, void *stream_,
-                             const float *boxIn, float *boxOut);
+                             const float *boxIn, float *boxOut, int32_t *missOut);
 extern "C" int deftet_point_in_tet_prepare_f32(const float *pts, int B, int T, int Q, int algo, void *workspace,
                                                size_t workspace_bytes, void *stream_)
 {
-    return pit_prepare_entry(pts, B, T, Q, algo, workspace, workspace_bytes, stream_, nullptr, nullptr);
+    return pit_prepare_entry(pts, B, T, Q, algo, workspace, workspace_bytes, stream_, nullptr, nullptr, nullptr);
 }
 extern "C" int deftet_point_in_tet_prepare_ex_f32(const float *pts, int B, int T, int Q, int algo, const float *query_box_in,
-                                                  float *query_box_out, void *workspace, size_t workspace_bytes, void *stream_)
+                                                  float *query_box_out, int32_t *query_box_misses, void *workspace,
+                                                  size_t workspace_bytes, void *stream_)
 {
     DEFTET_CHECK_ARG(!query_box_in || query_box_in != query_box_out, "query_box_in and query_box_out must not alias");
-    return pit_prepare_entry(pts, B, T, Q, algo, workspace, workspace_bytes, stream_, query_box_in, query_box_out);
+    return pit_prepare_entry(pts, B, T, Q, algo, workspace, workspace_bytes, stream_, query_box_in, query_box_out, query_box_misses);
 }
 static int pit_prepare_entry(const float *pts, int B, int T, int Q, int algo, void *workspace, size_t workspace_bytes, void *stream_,
-                             const float *boxIn, float *boxOut)
+                             const float *boxIn, float *boxOut, int32_t *missOut)
 {
     DEFTET_CHECK_ARG(B >= 0 && T >= 0 && Q >= 0 && B <= 65535, "bad size (B=%d T=%d Q=%d)", B, T, Q);
     DEFTET_CHECK_ARG(algo == DEFTET_PIT_AUTO || algo == DEFTET_PIT_EXACT || algo == DEFTET_PIT_SLAB || algo == DEFTET_PIT_WAVE || algo == DEFTET_PIT_PAIR, "prepare needs a binned algo (got %d)", algo);
@@ -3109,7 +3134,7 @@ static int pit_prepare_entry(const float *pts, int B, int T, int Q, int algo, vo
     DEFTET_CHECK_ARG(workspace && ((uintptr_t)workspace & 255) == 0, "workspace null or not 256-byte aligned");
     Layout L = make_layout(B, T, Q, algo, workspace, workspace_bytes);
     DEFTET_CHECK_ARG(L.bytes <= workspace_bytes, "workspace too small: need %zu bytes, got %zu", L.bytes, workspace_bytes);
-    return pit_prepare(L, pts, B, Q, as_stream(stream_), boxIn, boxOut);
+    return pit_prepare(L, pts, B, Q, as_stream(stream_), boxIn, boxOut, missOut);
 }
 
 static int pit_scan_entry(const float *tet, const float *pts, float *cond, float *bary, const float *pred, float *occ, int32_t *hit_buf,

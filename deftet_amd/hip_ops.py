@@ -51,36 +51,74 @@ class PreparedQueries:
 # Query boxes tracked from call to call (query_box="track"): per (device, B, Q) two [B,6] tensors used in turns — a call hands the
 # box the PREVIOUS call measured to the library (query_box_in: the grid spans it, the measuring launch is skipped) and receives
 # the box of its own queries for the next one.  A training loop draws its queries from one distribution (dataloader.py:108), so
-# the previous box fits; where it does not, the queries outside it are answered exactly by the side path at brute-force cost
-# each and the NEXT call has the right box again.  DEFTET_PIT_BOX=off switches the tracking off.
+# the previous box fits.  Where it does not, the queries outside it are answered exactly by the side path — at brute-force cost
+# each, so the tracker must notice: the library counts them per shape into `misses`, an int32 [B] tensor in pinned host memory
+# that the kernels write directly and the next calls read WITHOUT synchronising (the value seen is a few calls old when the
+# host runs ahead of the GPU).  More than `limit` misses in a shape => the next `backoff` calls measure their own box again
+# (always exact, always at full speed, one launch more), and `backoff` quadruples every time that happens, so a caller that
+# alternates between two query distributions under the same (B, Q) ends up measuring; a long run of clean tracked calls
+# shrinks it again.  DEFTET_PIT_BOX=off switches the tracking off.
 _box_cache = {}
 
 
+class _BoxTracker:
+    def __init__(self, dev, B, Q):
+        self.box = [torch.empty(B, 6, device=dev, dtype=torch.float32) for _ in range(2)]
+        pin = torch.cuda.is_available()
+        self.misses = torch.zeros(max(B, 1), dtype=torch.int32, pin_memory=pin)
+        self._np = self.misses.numpy()                       # the same memory: polling it is a few hundred nanoseconds
+        self.limit = max(4, Q >> 14)                         # misses per shape that are not worth a reaction
+        self.phase, self.hold, self.backoff, self.clean = -1, 0, 1, 0
+        self.counts = {"tracked": 0, "measured": 0, "backoffs": 0}
+
+    def step(self):
+        """(query_box_in | None, query_box_out, query_box_misses | None) for the next call."""
+        if self.phase >= 0 and int(self._np.max()) > self.limit:
+            self._np[:] = 0                                  # (a tracked call still in flight may set it again: one more back-off)
+            self.hold, self.clean = self.backoff, 0
+            self.backoff = min(self.backoff * 4, 1 << 20)
+            self.counts["backoffs"] += 1
+        if self.phase < 0 or self.hold > 0:                  # measured box, remembered in box[0] for the next tracked call
+            self.hold = max(self.hold - 1, 0)
+            self.phase = 0
+            self.counts["measured"] += 1
+            return None, self.box[0], None
+        box_in, box_out = self.box[self.phase], self.box[1 - self.phase]
+        self.phase = 1 - self.phase
+        self.counts["tracked"] += 1
+        self.clean += 1
+        if self.clean >= 64 * self.backoff and self.backoff > 1:
+            self.backoff, self.clean = self.backoff // 4, 0
+        return box_in, box_out, self.misses
+
+
 def _tracked_boxes(dev, B, Q):
-    """(query_box_in | None, query_box_out) for this call."""
+    """(query_box_in | None, query_box_out, query_box_misses | None) for this call."""
     import os
     if os.environ.get("DEFTET_PIT_BOX", "track") == "off":
-        return None, None
+        return None, None, None
     key = (dev.index if dev.index is not None else torch.cuda.current_device(), B, Q)
     st = _box_cache.get(key)
     if st is None:
-        st = _box_cache[key] = {"box": [torch.empty(B, 6, device=dev, dtype=torch.float32) for _ in range(2)], "phase": -1}
-    if st["phase"] < 0:                                   # first call: measured box, remembered in box[0]
-        st["phase"] = 0
-        return None, st["box"][0]
-    box_in, box_out = st["box"][st["phase"]], st["box"][1 - st["phase"]]
-    st["phase"] = 1 - st["phase"]
-    return box_in, box_out
+        st = _box_cache[key] = _BoxTracker(dev, B, Q)
+    return st.step()
 
 
 def clear_query_box_cache():
     _box_cache.clear()
 
 
-def _resolve_query_box(query_box, dev, B, Q, algo):
-    """query_box argument -> (query_box_in, query_box_out) tensors or Nones."""
+def query_box_trackers():
+    """{(device, B, Q): {"tracked", "measured", "backoffs", "hold", "backoff"}} — what query_box="track" has been doing."""
+    return {k: dict(v.counts, hold=v.hold, backoff=v.backoff) for k, v in _box_cache.items()}
+
+
+def _resolve_query_box(query_box, dev, B, Q, algo, misses=None):
+    """query_box argument -> (query_box_in, query_box_out, query_box_misses) tensors or Nones."""
+    if misses is not None and (misses.dtype != torch.int32 or misses.numel() < B or not misses.is_contiguous()):
+        raise RuntimeError("query_box_misses must be a contiguous int32 tensor of at least B entries (device or pinned host memory)")
     if query_box is None or algo == PIT_BRUTE or B == 0 or Q == 0:
-        return None, None
+        return None, None, None
     if isinstance(query_box, str):
         if query_box != "track":
             raise RuntimeError("query_box must be None, 'track' or a float32 [B,6] tensor (lo xyz, hi xyz)")
@@ -88,10 +126,10 @@ def _resolve_query_box(query_box, dev, B, Q, algo):
     _lib.require_gpu(query_box)
     if query_box.dtype != torch.float32 or query_box.shape != (B, 6) or not query_box.is_contiguous() or query_box.device != dev:
         raise RuntimeError("query_box must be a contiguous float32 [B,6] tensor (lo xyz, hi xyz) on the queries' device")
-    return query_box, None
+    return query_box, None, misses
 
 
-def prepare_queries(pts_bxqx3, n_tet, algo=PIT_AUTO, query_box=None):
+def prepare_queries(pts_bxqx3, n_tet, algo=PIT_AUTO, query_box=None, query_box_misses=None):
     _lib.require_gpu(pts_bxqx3)
     if algo == PIT_BRUTE:
         raise RuntimeError("prepare_queries needs a binned algo")
@@ -104,9 +142,9 @@ def prepare_queries(pts_bxqx3, n_tet, algo=PIT_AUTO, query_box=None):
     with torch.cuda.device(dev):
         nbytes = max(lib.deftet_point_in_tet_workspace_bytes(B, pq.n_tet, Q, algo), 256)
         pq.workspace = torch.empty(nbytes, device=dev, dtype=torch.uint8)       # private: outlives the cached per-stream workspace
-        box_in, box_out = _resolve_query_box(query_box, dev, B, Q, algo)
+        box_in, box_out, box_miss = _resolve_query_box(query_box, dev, B, Q, algo, query_box_misses)
         _lib.check(lib.deftet_point_in_tet_prepare_ex_f32(_lib.ptr(pts), B, pq.n_tet, Q, algo, _lib.ptr(box_in), _lib.ptr(box_out),
-                                                          _lib.ptr(pq.workspace), nbytes, _lib.current_stream(dev)),
+                                                          _lib.ptr(box_miss), _lib.ptr(pq.workspace), nbytes, _lib.current_stream(dev)),
                    "deftet_point_in_tet_prepare_ex_f32")
         pq.event = torch.cuda.Event()
         pq.event.record(torch.cuda.current_stream(dev))
@@ -195,7 +233,7 @@ def clear_tet_order_cache():
 
 
 def point_in_tet(tet_bxtx4x3, pts_bxqx3, want_bary=False, algo=PIT_AUTO, pred_bxt=None, want_hits=False, prepared=None, order=None,
-                 query_box=None):
+                 query_box=None, query_box_misses=None):
     """cond f32 [B,Q,1] (lowest containing tet index or -1); with want_bary also the barycentric
     weights f32 [B,Q,4] of the hit tet; with pred_bxt also occ f32 [B,Q] = the fused
     DefTet.paste_occ gather pred[b, max(index, 0)].  Returns cond | (cond, bary) | (cond, bary, occ)
@@ -203,7 +241,9 @@ def point_in_tet(tet_bxtx4x3, pts_bxqx3, want_bary=False, algo=PIT_AUTO, pred_bx
     buffer that makes point_in_tet_bwd atomic-free.  order: None (the caller's tet numbering), an int32 [T] permutation from
     tet_spatial_order, or "auto" (auto_tet_order: decided once per grid size and device); never changes a result.
     query_box: None (the grid spans the measured box of this call's queries), a float32 [B,6] hint (lo xyz, hi xyz: e.g. the
-    sampler's box) or "track" (the box the previous call with these sizes measured); never changes a result either."""
+    sampler's box) or "track" (the box the previous call with these sizes measured, with a fall-back to measuring when the
+    queries stop fitting it); never changes a result either.  query_box_misses: with a [B,6] hint, an int32 [>= B] tensor
+    (device or pinned host memory) that receives the number of regular queries per shape outside the hint."""
     _lib.require_gpu(tet_bxtx4x3, pts_bxqx3, pred_bxt)
     lib = _lib.load()
     tet, pts = _f32c(tet_bxtx4x3), _f32c(pts_bxqx3)
@@ -248,10 +288,11 @@ def point_in_tet(tet_bxtx4x3, pts_bxqx3, want_bary=False, algo=PIT_AUTO, pred_bx
         else:
             nbytes = lib.deftet_point_in_tet_workspace_bytes(B, T, Q, algo)
             ws = _lib.workspace(dev, nbytes)
-            box_in, box_out = _resolve_query_box(query_box, dev, B, Q, algo)
+            box_in, box_out, box_miss = _resolve_query_box(query_box, dev, B, Q, algo, query_box_misses)
             _lib.check(lib.deftet_point_in_tet_ex_f32(_lib.ptr(tet), _lib.ptr(pts), _lib.ptr(cond), _lib.ptr(bary), _lib.ptr(pred),
                                                       _lib.ptr(occ), _lib.ptr(hits), B, T, Q, algo, _lib.ptr(order), _lib.ptr(box_in),
-                                                      _lib.ptr(box_out), _lib.ptr(ws), ws.numel(), _lib.current_stream(dev)),
+                                                      _lib.ptr(box_out), _lib.ptr(box_miss), _lib.ptr(ws), ws.numel(),
+                                                      _lib.current_stream(dev)),
                        "deftet_point_in_tet_ex_f32")
     out = (cond,) + ((bary,) if want_bary else ()) + ((occ,) if pred is not None else ()) + ((hits,) if want_hits else ())
     return out if len(out) > 1 else cond

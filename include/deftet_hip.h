@@ -113,14 +113,18 @@ int deftet_tet_spatial_order_f32(const float *tet, int n_tet, int32_t *order, in
  * a query outside it is answered exactly by the side path that serves NaN / Inf / huge queries — at brute-force cost per such
  * query, so hand in the sampler's box (dataloader.py:108 draws from 1.05 (U - 0.5)) or what an earlier call with the same
  * distribution measured: query_box_out (f32 [B,6] or NULL; must not alias query_box_in) receives the box of THIS call's regular
- * queries (lo > hi when there is none).  Every output is identical with and without a box. */
+ * queries (lo > hi when there is none).  query_box_misses (int32 [B] or NULL; any memory the device can write — host-mapped
+ * memory lets the caller poll it without synchronising) receives, when query_box_in is given, the number of regular queries
+ * of each shape that fell outside it (NaN / Inf / huge queries are not counted): a caller that reuses boxes sees there that its
+ * query distribution moved and measures again (what hip_ops.point_in_tet(query_box="track") does).  Every output is identical
+ * with and without a box. */
 int deftet_point_in_tet_ex_f32(const float *tet, const float *pts, float *cond, float *bary,
                                const float *pred, float *occ, int32_t *hit_buf,
                                int n_batch, int n_tet, int n_query, int algo, const int32_t *tet_order,
-                               const float *query_box_in, float *query_box_out,
+                               const float *query_box_in, float *query_box_out, int32_t *query_box_misses,
                                void *workspace, size_t workspace_bytes, void *stream);
 int deftet_point_in_tet_prepare_ex_f32(const float *pts, int n_batch, int n_tet, int n_query, int algo,
-                                       const float *query_box_in, float *query_box_out,
+                                       const float *query_box_in, float *query_box_out, int32_t *query_box_misses,
                                        void *workspace, size_t workspace_bytes, void *stream);
 int deftet_point_in_tet_scan_ex_f32(const float *tet, const float *pts, float *cond, float *bary,
                                     const float *pred, float *occ, int32_t *hit_buf,

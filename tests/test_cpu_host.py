@@ -61,19 +61,67 @@ def test_tracked_query_boxes_alternate_between_two_buffers():
     from deftet_amd import hip_ops
     hip_ops.clear_query_box_cache()
     dev = torch.device("cpu", 0)                                 # (the helper only allocates and hands out tensors)
-    i0, o0 = hip_ops._tracked_boxes(dev, 2, 100)
-    i1, o1 = hip_ops._tracked_boxes(dev, 2, 100)
-    i2, o2 = hip_ops._tracked_boxes(dev, 2, 100)
-    assert i0 is None and o0.shape == (2, 6)
+    i0, o0, m0 = hip_ops._tracked_boxes(dev, 2, 100)
+    i1, o1, m1 = hip_ops._tracked_boxes(dev, 2, 100)
+    i2, o2, m2 = hip_ops._tracked_boxes(dev, 2, 100)
+    assert i0 is None and o0.shape == (2, 6) and m0 is None     # a measuring call has no hint to miss
     assert i1 is o0 and o1 is not o0
     assert i2 is o1 and o2 is o0
-    j0, p0 = hip_ops._tracked_boxes(dev, 2, 101)                 # another query count: its own state
+    assert m1 is m2 and m1.dtype == torch.int32 and m1.numel() == 2 and m1.device.type == "cpu"   # the mailbox the kernels write
+    j0, p0, _ = hip_ops._tracked_boxes(dev, 2, 101)              # another query count: its own state
     assert j0 is None and p0 is not o0 and p0 is not o1
     os.environ["DEFTET_PIT_BOX"] = "off"
     try:
-        assert hip_ops._tracked_boxes(dev, 2, 100) == (None, None)
+        assert hip_ops._tracked_boxes(dev, 2, 100) == (None, None, None)
     finally:
         del os.environ["DEFTET_PIT_BOX"]
+    hip_ops.clear_query_box_cache()
+
+
+def test_tracked_query_boxes_fall_back_to_measuring_when_queries_miss_the_box():
+    """host logic of the tracker's feedback loop: the kernels report the regular queries that fell outside the hinted box in a
+    pinned int32 mailbox; more than `limit` of them => the next calls measure again, for a number of calls that quadruples with
+    every relapse (two alternating query distributions end up measuring all the time) and shrinks after a long clean run."""
+    from deftet_amd import hip_ops
+    hip_ops.clear_query_box_cache()
+    dev = torch.device("cpu", 0)
+    B, Q = 3, 1 << 17
+
+    def call():
+        return hip_ops._tracked_boxes(dev, B, Q)
+
+    def state():
+        return hip_ops.query_box_trackers()[(0, B, Q)]
+
+    assert call()[0] is None                                     # first call measures
+    box_in, _, miss = call()
+    assert box_in is not None and miss is not None
+    limit = max(4, Q >> 14)
+    miss[1] = limit                                              # a few stragglers: not worth a reaction
+    assert call()[0] is not None and state()["backoffs"] == 0
+    miss[1] = limit + 1                                          # what a tracked call whose box did not fit reports
+    i, o, m = call()
+    assert i is None and m is None and o is not None             # ... the next call measures
+    assert int(miss.max()) == 0 and state()["backoffs"] == 1 and state()["backoff"] == 4
+    i, o2, m = call()                                            # one measuring call (back-off 1), then tracking resumes from its box
+    assert i is o and m is miss
+    miss[0] = 1000                                               # relapse: four measuring calls
+    for _ in range(4):
+        assert call()[0] is None
+    assert call()[0] is not None and state()["backoffs"] == 2 and state()["backoff"] == 16
+    for k in range(2, 6):                                        # a caller that keeps missing: 16, 64, ... measuring calls per tracked one
+        miss[2] = 77
+        n = 0
+        while call()[0] is None:
+            n += 1
+        assert n == 4 ** k
+    tracked = state()["tracked"]
+    assert state()["measured"] > 20 * tracked                    # i.e. it measures practically always
+    # a long clean run earns the short back-off again
+    b0 = state()["backoff"]
+    for _ in range(64 * b0):
+        assert call()[0] is not None
+    assert state()["backoff"] == b0 // 4
     hip_ops.clear_query_box_cache()
 
 

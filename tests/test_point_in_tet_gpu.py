@@ -675,6 +675,74 @@ def test_query_box_hint_never_changes_the_result(cuda, oracle, algo):
         assert (g - ref_g)[fin_g].abs().max().item() <= 2e-6 * ref_g[fin_g].abs().max().item(), name   # (side-path hits are summed by the list path)
 
 
+def test_query_box_misses_are_counted_exactly(cuda):
+    """query_box_misses: the number of REGULAR queries per shape outside the hinted box (enlarged by 1/32 per side, as the grid
+    spans it) — into device memory or into pinned host memory the kernel writes directly (what the tracker polls); NaN / Inf /
+    huge queries are not misses of the box."""
+    from deftet_amd import hip_ops
+    tet, pts = cases.jittered(12, 20000, 3)
+    pts = pts.copy()
+    pts[0, :50] = np.nan
+    pts[1, 100:130, 1] = np.inf
+    pts[2, 7] = 3e7
+    t, p = torch.from_numpy(tet).to(cuda), torch.from_numpy(pts).to(cuda)
+    ref = hip_ops.point_in_tet(t, p)
+    big = 1048576.0
+    regular = (p.abs() <= big).all(-1)
+    fin = torch.where(regular[..., None], p, torch.zeros_like(p))
+    exact = torch.cat([fin.amin(1), fin.amax(1)], 1).contiguous()
+    for name, box in (("exact", exact), ("half", (exact * 0.5).contiguous()), ("shifted", (exact + 0.3).contiguous()),
+                      ("elsewhere", (exact + 5.0).contiguous())):
+        lo, hi = box[:, :3], box[:, 3:]
+        e = (hi - lo) * (1.0 / 32.0)
+        glo, ghi = torch.clamp(lo - e, min=-big), torch.clamp(hi + e, max=big)
+        inside = ((p >= glo[:, None]) & (p <= ghi[:, None])).all(-1)
+        want = (regular & ~inside).sum(1).to(torch.int32)
+        on_dev = torch.full((3,), -1, device=cuda, dtype=torch.int32)
+        on_host = torch.full((3,), -1, dtype=torch.int32).pin_memory()
+        for algo in (0, 3):
+            got = hip_ops.point_in_tet(t, p, algo=algo, query_box=box, query_box_misses=on_dev)
+            assert torch.equal(got, ref), name
+            got = hip_ops.point_in_tet(t, p, algo=algo, query_box=box, query_box_misses=on_host)
+            assert torch.equal(got, ref), name
+        torch.cuda.synchronize()
+        assert torch.equal(on_dev.cpu(), want.cpu()), (name, on_dev.tolist(), want.tolist())
+        assert torch.equal(on_host, want.cpu()), (name, on_host.tolist(), want.tolist())
+        if name == "exact":
+            assert int(want.sum()) == 0
+        else:
+            assert int(want.min()) > 0
+
+
+def test_query_box_tracking_backs_off_when_the_queries_stop_fitting(cuda):
+    """query_box="track" with a caller that alternates between two query distributions under the same (B, Q): every call exact;
+    the tracker sees the misses in its pinned mailbox and goes back to measuring, for longer each time (the side path costs a
+    brute-force scan per query outside the box, so tracking must not go on blindly)."""
+    from deftet_amd import grids, hip_ops
+    tet, _, _, _ = grids.make_case(16, 10, 2)
+    t = torch.from_numpy(tet).to(cuda)
+    hip_ops.clear_query_box_cache()
+    rng = np.random.default_rng(3)
+    near = torch.from_numpy((0.5 * (rng.random((2, 3000, 3)) - 0.5)).astype(np.float32)).to(cuda)
+    wide = torch.from_numpy((1.05 * (rng.random((2, 3000, 3)) - 0.5)).astype(np.float32)).to(cuda)
+    refs = [hip_ops.point_in_tet(t, q, algo=hip_ops.PIT_BRUTE) for q in (near, wide)]
+    key = (cuda.index if cuda.index is not None else torch.cuda.current_device(), 2, 3000)
+    for i in range(40):
+        got = hip_ops.point_in_tet(t, (near, wide)[i % 2], query_box="track")
+        assert torch.equal(got, refs[i % 2]), i
+        torch.cuda.synchronize()                                   # (the mailbox is polled without one: here every call sees the last)
+    st = hip_ops.query_box_trackers()[key]
+    assert st["backoffs"] >= 2 and st["measured"] >= 30 and st["tracked"] <= 8, st
+    # one distribution from now on: tracking resumes and stays
+    before = st["tracked"]
+    for i in range(st["hold"] + 12):
+        assert torch.equal(hip_ops.point_in_tet(t, wide, query_box="track"), refs[1])
+        torch.cuda.synchronize()
+    st = hip_ops.query_box_trackers()[key]
+    assert st["tracked"] >= before + 10 and st["hold"] == 0, st
+    hip_ops.clear_query_box_cache()
+
+
 def test_query_box_tracking_over_rotating_query_sets(cuda):
     """query_box="track" as the autograd ops use it: three different query sets in turns (different boxes), every call equal to the
     brute-force kernel; then a set from a shifted, larger box (the first call after the shift is served by the side path)."""

@@ -64,7 +64,16 @@ while time.time() < t_end:
             c0 = (torch.rand(B, 3, device=dev, generator=g) - 0.5) * scale
             half = torch.rand(B, 3, device=dev, generator=g) * scale * float(rng.choice([0.01, 0.3, 0.7, 2.0]))
             box = torch.cat([c0 - half, c0 + half], 1).contiguous()
-        got = hip_ops.point_in_tet(tet, pts, algo=algo, order=order, query_box=box)
+        miss = torch.full((B,), -1, device=dev, dtype=torch.int32) if box is not None and algo != 1 else None
+        got = hip_ops.point_in_tet(tet, pts, algo=algo, order=order, query_box=box, query_box_misses=miss)
+        if miss is not None:                                 # the miss count the box tracker relies on: regular queries outside the enlarged box
+            lo, hi = box[:, :3], box[:, 3:]
+            e = (hi - lo) * (1.0 / 32.0)
+            glo, ghi = torch.clamp(lo - e, min=-1048576.0), torch.clamp(hi + e, max=1048576.0)
+            want = ((pts.abs() <= 1048576.0).all(-1) & ~((pts >= glo[:, None]) & (pts <= ghi[:, None])).all(-1)).sum(1).to(torch.int32)
+            if not torch.equal(miss, want):
+                print("MISS COUNT algo=%d B=%d T=%d Q=%d kind=%d: %s vs %s" % (algo, B, T, Q, kind, miss.tolist(), want.tolist()), flush=True)
+                sys.exit(1)
         if not torch.equal(got, ref):
             bad = (got != ref).nonzero()[0].tolist()
             print("MISMATCH algo=%d B=%d T=%d Q=%d kind=%d scale=%g size=%g at %s: %s vs %s" % (algo, B, T, Q, kind, scale, size, bad, got[tuple(bad)].item(), ref[tuple(bad)].item()), flush=True)
