@@ -74,6 +74,7 @@ class PitWorkload:
     def __init__(self, cfg, rank, device, world, gather=None, pipeline=PIPELINE, algo=ALGO):
         from deftet_amd import grids
         self.cfg, self.world, self.gather, self.pipeline, self.algo = cfg, world, gather, pipeline, algo
+        self.device = torch.device(device)
         res, Q, B = cfg["res"], cfg["n_query"], cfg["batch"]
         if cfg.get("mesh") == "cube40":                   # the shipped QuarTet grid (probe use: a non-Kuhn tet order)
             g40 = np.load(os.path.join(ROOT, "tests", "golden", "cube40_grid.npz"))
@@ -198,6 +199,11 @@ class PitWorkload:
         if self.world > 1 and self.gather is not None:
             self.gather.flush()                           # the last step's all-gather belongs to the timed region
 
+    def _tracker_counts(self):
+        from deftet_amd import hip_ops
+        st = hip_ops.query_box_trackers().get((self.device.index if self.device.index is not None else torch.cuda.current_device(), self.B, self.Q))
+        return "no tracked call yet" if st is None else "%d tracked, %d measured, %d fall-backs to measuring" % (st["tracked"], st["measured"], st["backoffs"])
+
     def describe(self):
         return {"workload": "%s: T=%d tets, %d uniform queries, %d shapes per GPU, point-in-tet index + weights + paste_occ, "
                             "fwd+bwd, grid build included, %d rotating input sets" % (self.cfg["name"], self.T, self.Q, self.B, len(self.sets)),
@@ -206,7 +212,8 @@ class PitWorkload:
                 "inputs_generated_on": self.generated_on,
                 "tet_order": "%s -> %s" % (self.order_mode, "the caller's numbering" if self.order is None else "computed column order"),
                 "query_box": ("tracked: the grid of a step spans the box the previous step's (different) queries measured; queries outside it "
-                              "take the exact side path" if self.query_box else "measured by every step"),
+                              "take the exact side path and are counted; calls so far: %s" % self._tracker_counts()
+                              if self.query_box else "measured by every step"),
                 "pipelining": ("query sort of step i+1 enqueued on a second stream during step i" if self.pipeline else "none")}
 
 
