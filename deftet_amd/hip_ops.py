@@ -153,7 +153,7 @@ def prepare_queries(pts_bxqx3, n_tet, algo=PIT_AUTO, query_box=None, query_box_m
 
 def tet_spatial_order(tet_tx4x3, want_breaks=False):
     """int32 [T] permutation that walks the tets of ONE shape column by column ((x, y) columns one mean tet extent wide,
-    ascending z inside a column): the traversal order deftet_point_in_tet_ordered_f32 takes.  Static topology => computed once
+    ascending z inside a column): the traversal order the *_ex_* entry points take (tet_order).  Static topology => computed once
     (from any positions of the grid) and reused for every step and every shape of a batch.  want_breaks also returns the
     int32 [2] device tensor (breaks of the caller's order, breaks of the computed one) the C entry point describes."""
     _lib.require_gpu(tet_tx4x3)
