@@ -1040,6 +1040,20 @@ __device__ __forceinline__ void stream_store(float4 *p, const float4 v)
     __builtin_nontemporal_store(x, reinterpret_cast<f32x4 *>(p));
 }
 __device__ __forceinline__ void stream_store(float *p, float v) { __builtin_nontemporal_store(v, p); }
+// probe switches (tools/probes/build_variant.sh): the tet records of a launch are read once — do they belong in the L2s?
+#ifndef PIT_SCAN_TET_NT
+#define PIT_SCAN_TET_NT 0
+#endif
+#ifndef PIT_BWD_TET_NT
+#define PIT_BWD_TET_NT 0
+#endif
+template <bool NT>
+__device__ __forceinline__ float4 load_f4(const float4 *p)
+{
+    if (!NT) return *p;
+    const f32x4 x = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p));
+    return make_float4(x[0], x[1], x[2], x[3]);
+}
 __device__ __forceinline__ int4 stream_load(const int4 *p)
 {
     const i32x4 x = __builtin_nontemporal_load(reinterpret_cast<const i32x4 *>(p));
@@ -1665,7 +1679,7 @@ __device__ __forceinline__ void tet_scan_wave_body(const float *__restrict__ tet
         float v[12];
         {
             const float4 *src = reinterpret_cast<const float4 *>(tet + ((size_t)b * T + tet_id(k)) * 12);
-            float4 a = src[0], bq = src[1], c = src[2];
+            float4 a = load_f4<PIT_SCAN_TET_NT != 0>(src), bq = load_f4<PIT_SCAN_TET_NT != 0>(src + 1), c = load_f4<PIT_SCAN_TET_NT != 0>(src + 2);
             v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
             v[4] = bq.x; v[5] = bq.y; v[6] = bq.z; v[7] = bq.w;
             v[8] = c.x; v[9] = c.y; v[10] = c.z; v[11] = c.w;
@@ -2532,7 +2546,7 @@ struct TetGrad {
 __device__ __forceinline__ void tet_grad_setup(const float *__restrict__ tet, size_t i, TetGrad &g)
 {
     const float4 *src = reinterpret_cast<const float4 *>(tet + i * 12);
-    const float4 t0 = src[0], t1 = src[1], t2 = src[2];
+    const float4 t0 = load_f4<PIT_BWD_TET_NT != 0>(src), t1 = load_f4<PIT_BWD_TET_NT != 0>(src + 1), t2 = load_f4<PIT_BWD_TET_NT != 0>(src + 2);
     const float C[3] = {t1.z, t1.w, t2.x}, D[3] = {t2.y, t2.z, t2.w};
     g.A[0] = t0.x; g.A[1] = t0.y; g.A[2] = t0.z; g.Bv[0] = t0.w; g.Bv[1] = t1.x; g.Bv[2] = t1.y;
     float vab[3], vac[3], vad[3], vbc[3], vbd[3];
