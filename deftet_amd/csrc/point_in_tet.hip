@@ -2609,9 +2609,14 @@ constexpr int kMissStride = 80;    // floats of workspace per shape: kMissParts 
 // One launch for the whole backward:
 //  * every tet lane adds up the (<= 4) hits of its record in ascending query order — no atomics;
 //  * a tet whose record is marked overflowed (or any tet, when the uncovered list holds NaN/Inf/huge queries) gets
-//    its hits from the forward's uncovered list: the WAVE scans the list for the lane (64 entries per step), the
-//    matching lanes evaluate one hit each and a fixed-order butterfly adds them up — no atomics either, so the
-//    whole gradient is bit-reproducible;
+//    its hits from the forward's uncovered list: the WAVE scans the list for the lane (64 entries per step) and adds
+//    the tet's hits up in ASCENDING QUERY ORDER, the order the record path uses — the list itself is in whatever order
+//    k_finalize's workgroups appended to it, so (round 5) the wave takes the smallest query id not yet added, one pass
+//    over the list per hit; no atomics, and the whole gradient is bit-reproducible from run to run.  (Rounds 2-4 let
+//    the matching lanes evaluate one hit each and added the lanes up with a butterfly: fixed tree, but which lane held
+//    which hit followed the list order — the last bits of an overflowed tet's gradient changed from run to run.  A tet
+//    with so many unrecorded hits that (hits) x (list length / 64) exceeds kRescanOrderedSteps still takes that path:
+//    one pass per hit is then too slow.)
 //  * paste_occ sends every miss to tet 0 (deftet.py:133-135), so grad_pred[b,0] also gets the sum of grad_occ over
 //    the misses: the first nMissParts workgroups of a shape each sum a slice of the queries on the side (hidden under
 //    the kernel's own traffic), hand their partial to memory and draw a ticket; the workgroup that draws the last one
@@ -2623,41 +2628,79 @@ constexpr int kMissStride = 80;    // floats of workspace per shape: kMissParts 
 // not add up: 110 -> 96 VGPRs, 4 -> 5 waves per SIMD, 69.5 -> 63.1 us inside the configs[2] step.  (Out of line with
 // the register budget of 6 waves: the same time, its callee-saved spills cost what the occupancy gains; forcing 6
 // waves on the inlined form spills on the main path: 84 us.)  Returns whether this lane's tet was one of them.
+// One pass over the list per hit is affordable while (hits of the tet) x (64-entry steps of the list) stays below this; beyond
+// it (thousands of queries inside one tet) the matching lanes evaluate one hit each and a butterfly adds the lanes up
+constexpr long long kRescanOrderedSteps = 16384;
 __device__ __forceinline__ bool bwd_rescan(const float *__restrict__ tet, const float *__restrict__ pts, const float *__restrict__ cond,
                                         const float *__restrict__ grad_w, const float *__restrict__ gocc, float *grad_pts,
                                         bool want_pred, const int *__restrict__ ulist, int b, int T, int Q, int nU,
                                         unsigned long long need, int t, float (*park)[256])
 {
     const int tid = threadIdx.x, lane = tid & 63;
+    const int *__restrict__ lst = ulist + (size_t)b * Q;
     bool parked = false;
     while (need) {
         const int L = __ffsll((long long)need) - 1;
         need &= need - 1;
         const int tL = __shfl(t, L);
         const float tLf = (float)tL;
+        // smallest listed query > cur that this tet won (a hit recorded by the overflowing tet's own record cannot be in the
+        // list: overflowed records are ignored by the caller); the first call also counts the tet's listed hits
+        int m = 0;
+        auto next_hit = [&](int cur, bool count) {
+            int best = 0x7FFFFFFF;
+            for (int base = 0; base < nU; base += 64) {
+                const int e = base + lane;
+                const int q = e < nU ? lst[e] : -1;
+                const bool mine = q > cur && cond[(size_t)b * Q + q] == tLf;
+                if (mine) best = min(best, q);
+                if (count) m += __popcll(__ballot(mine));
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) best = min(best, __shfl_xor(best, off));
+            return best;
+        };
+        int best = next_hit(-1, true);
+        if (m == 0) continue;                                       // (the usual answer when every lane has to look: irregular queries)
+        const bool ordered = (long long)m * ((nU + 63) >> 6) <= kRescanOrderedSteps;   // wave-uniform
         float part[13];
 #pragma unroll
         for (int k = 0; k < 13; ++k) part[k] = 0.f;
-        for (int base = 0; base < nU; base += 64) {
-            const int e = base + lane;
-            const int q = e < nU ? ulist[(size_t)b * Q + e] : -1;
-            const size_t i = (size_t)b * Q + (q >= 0 ? q : 0);
-            if (q >= 0 && cond[i] == tLf) {
-                // a hit recorded by the overflowing tet's own record cannot be here: overflowed records are ignored by the caller
-                TetGrad g;
-                tet_grad_setup(tet, (size_t)b * T + tL, g);
+        TetGrad g;
+        tet_grad_setup(tet, (size_t)b * T + tL, g);
+        // ONE instance of the evaluation for both modes.  ordered: the whole wave evaluates hit `best` (wave-uniform values: every
+        // lane holds the same sums), then looks for the next; otherwise: every lane evaluates its own entry of the next 64
+        for (int base = 0;;) {
+            int q;
+            bool mine;
+            if (ordered) {
+                if (best == 0x7FFFFFFF) break;
+                q = best;
+                mine = true;
+            } else {
+                if (base >= nU) break;
+                const int e = base + lane;
+                q = e < nU ? lst[e] : -1;
+                mine = q >= 0 && cond[(size_t)b * Q + q] == tLf;
+                base += 64;
+            }
+            if (mine) {
+                const size_t i = (size_t)b * Q + q;
                 float G3[3];
                 tet_grad_add(g, pts + i * 3, reinterpret_cast<const float4 *>(grad_w)[i], part, G3);
                 if (grad_pts) { grad_pts[i * 3] = G3[0]; grad_pts[i * 3 + 1] = G3[1]; grad_pts[i * 3 + 2] = G3[2]; }
                 if (want_pred) part[12] += gocc[i];
             }
+            if (ordered) best = next_hit(best, false);
         }
+        if (!ordered) {
 #pragma unroll
-        for (int k = 0; k < 13; ++k) {
-            float v = part[k];
+            for (int k = 0; k < 13; ++k) {
+                float v = part[k];
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);      // fixed butterfly: same order on every run
-            part[k] = v;
+                for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);  // fixed tree; which lane holds which hit follows the list order
+                part[k] = v;
+            }
         }
         if (lane == L) {                     // parked in LDS until the record's own hits are summed
 #pragma unroll
@@ -2701,7 +2744,9 @@ __global__ __launch_bounds__(256, PIT_BWD_WAVES) void k_bary_bwd_hits(const floa
         for (int off = 32; off > 0; off >>= 1) gm += __shfl_xor(gm, off);
         if (lane == 0) wsum[tid >> 6] = gm;
         __syncthreads();
-        missPartial = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+        // (the same value in every thread of the workgroup: kept in a scalar register — the kernel has not one vector
+        // register to spare at seven waves per SIMD, and a spill here is a scratch store + load in EVERY wave of the launch)
+        missPartial = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((wsum[0] + wsum[1]) + (wsum[2] + wsum[3]))));
     }
     const int t = bx * blockDim.x + tid;
     const bool live = t < T;

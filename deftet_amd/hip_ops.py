@@ -100,7 +100,9 @@ def _tracked_boxes(dev, B, Q):
     key = (dev.index if dev.index is not None else torch.cuda.current_device(), B, Q)
     st = _box_cache.get(key)
     if st is None:
-        st = _box_cache[key] = _BoxTracker(dev, B, Q)
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            return None, None, None                          # no state is born inside a graph capture (its tensors would belong to the
+        st = _box_cache[key] = _BoxTracker(dev, B, Q)        # graph's pool, pinned memory cannot be allocated there): this call measures
     return st.step()
 
 

@@ -765,3 +765,89 @@ def test_query_box_tracking_over_rotating_query_sets(cuda):
     got = hip_ops.point_in_tet(t, sets[1], prepared=pq)
     assert torch.equal(got, hip_ops.point_in_tet(t, sets[1], algo=hip_ops.PIT_BRUTE))
     hip_ops.clear_query_box_cache()
+
+
+def test_step_captured_in_a_hipgraph_replays_on_new_inputs(cuda):
+    """fwd (index, weights, occupancy, hit records) + bwd + loss row dots captured in ONE hipGraph with the hints the autograd ops pass
+    (order="auto", query_box="track") — as the very first call of its (B, Q), so the tracker must not create state inside the
+    capture — then replayed on other inputs copied into the captured tensors: every replay equals the eager operator."""
+    from deftet_amd import grids, hip_ops
+    hip_ops.clear_query_box_cache()
+    B, Q = 2, 3100                                                   # a (B, Q) no other test tracks
+    sets = []
+    for s in range(3):
+        tet, pts, _, _ = grids.make_case(12, Q, B, 0.1 + 0.05 * s)
+        g = torch.Generator(device=cuda).manual_seed(50 + s)
+        t = torch.from_numpy(tet).to(cuda)
+        sets.append(dict(tet=t, pts=torch.from_numpy(pts).to(cuda) * (1.0 + 0.1 * s), pred=torch.rand(B, t.shape[1], device=cuda, generator=g),
+                         gw=torch.randn(B, Q, 4, device=cuda, generator=g), go=torch.randn(B, Q, device=cuda, generator=g)))
+    st = {k: v.clone() for k, v in sets[0].items()}                 # the tensors the graph reads
+
+    def step(d, **hints):
+        cond, w, occ, hits = hip_ops.point_in_tet(d["tet"], d["pts"], want_bary=True, pred_bxt=d["pred"], want_hits=True, **hints)
+        loss = hip_ops.rowdot(w, d["gw"], occ, d["go"])
+        gt, _, gp = hip_ops.point_in_tet_bwd(d["tet"], d["pts"], cond, d["gw"], grad_occ=d["go"], hits=hits)
+        return cond, w, occ, loss, gt, gp
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        step(st)                                                     # workspaces reach their size outside the capture (no hints: no tracker yet)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = step(st, order="auto", query_box="track")
+    key = (cuda.index if cuda.index is not None else torch.cuda.current_device(), B, Q)
+    assert key not in hip_ops.query_box_trackers()                   # the capture measured its box: nothing was allocated for tracking
+    for i in (1, 2, 0, 2):
+        for k in st:
+            st[k].copy_(sets[i][k])
+        graph.replay()
+        torch.cuda.synchronize()
+        want = step(sets[i])
+        assert torch.equal(out[0], hip_ops.point_in_tet(sets[i]["tet"], sets[i]["pts"], algo=hip_ops.PIT_BRUTE)), i
+        for name, a, b in zip(("cond", "w", "occ", "loss", "grad_tet", "grad_pred"), out, want):
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (i, name)
+    # ... and with a tracker that already exists the captured step reads / writes its two boxes
+    for i in range(3):
+        step(sets[i], order="auto", query_box="track")
+    graph2 = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph2):
+        out2 = step(st, order="auto", query_box="track")
+    for i in (2, 1):
+        for k in st:
+            st[k].copy_(sets[i][k])
+        graph2.replay()
+        torch.cuda.synchronize()
+        want = step(sets[i])
+        for name, a, b in zip(("cond", "w", "occ", "loss", "grad_tet", "grad_pred"), out2, want):
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (i, name)
+    del graph, graph2
+    hip_ops.clear_query_box_cache()
+
+
+def test_backward_is_bit_reproducible_with_overflowed_records(cuda):
+    """2.4 queries per tet: several tets accept more queries than their hit record and its spill record hold, so their hits come
+    from the forward's list of unrecorded hits, whose ORDER changes from run to run (workgroups append to it with an atomic).  The
+    backward adds them in ascending query order all the same: every run gives the same bits (rounds 2-4 did not: the lanes of a
+    butterfly held the hits in list order)."""
+    from deftet_amd import grids, hip_ops
+    for res, Q in ((12, 3100), (20, 10000)):
+        tet, pts, _, _ = grids.make_case(res, Q, 2, 0.1)
+        t, p = torch.from_numpy(tet).to(cuda), torch.from_numpy(pts).to(cuda)
+        g = torch.Generator(device=cuda).manual_seed(5)
+        gw, go = torch.randn(2, Q, 4, device=cuda, generator=g), torch.randn(2, Q, device=cuda, generator=g)
+        pred = torch.rand(2, t.shape[1], device=cuda, generator=g)
+        ref = None
+        for it in range(12):
+            cond, w, occ, hits = hip_ops.point_in_tet(t, p, want_bary=True, pred_bxt=pred, want_hits=True)
+            gt, gq, gp = hip_ops.point_in_tet_bwd(t, p, cond, gw, want_grad_pts=True, grad_occ=go, hits=hits)
+            if it == 0:
+                assert hip_ops.point_in_tet_stats(2, t.shape[1], Q, 0, cuda)[:, 6].min() > 0      # overflowed tets in every shape
+                ref = (gt.clone(), gq.clone(), gp.clone())
+                lst = hip_ops.point_in_tet_bwd(t, p, cond, gw, want_grad_pts=True, grad_occ=go)   # the list backward: same sums up to rounding
+                assert (lst[0] - gt).abs().max().item() <= 2e-6 * gt.abs().max().item()
+            else:
+                for name, a, b in zip(("grad_tet", "grad_pts", "grad_pred"), (gt, gq, gp), ref):
+                    assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (res, it, name)
