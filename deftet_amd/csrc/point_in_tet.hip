@@ -3304,6 +3304,7 @@ extern "C" int deftet_debug_phase_read(unsigned long long *out16, int reset)
 }
 #endif
 
+constexpr long long kDenseQueriesPerTet = 2;
 extern "C" size_t deftet_point_in_tet_bwd_workspace_bytes(int B, int T, int Q)
 {
     if (B <= 0 || T < 0 || Q < 0) return 0;
@@ -3334,7 +3335,15 @@ extern "C" int deftet_point_in_tet_bwd_f32(const float *tet, const float *pts, c
     }
     DEFTET_CHECK_ARG(tet && pts && cond && grad_w, "null pointer");
     DEFTET_CHECK_ARG(((uintptr_t)tet & 15) == 0 && ((uintptr_t)grad_w & 15) == 0, "tet/grad_w must be 16-byte aligned");
-    if (hit_buf) {
+    // More than kDenseQueriesPerTet queries per tet: more and more tets accept more queries than a record and its spill record
+    // hold (six to eight), every one of them scans the shape's list of unrecorded hits, and that is quadratic — 111 ms against
+    // 0.055 ms for the per-tet lists at 100,000 queries on 6,000 tets; the crossover is measured (tools/probes/
+    // dense_queries_probe.py --sweep, 8 shapes x 48,000 tets: records 0.024 / 0.028 / 0.035 / 0.058 / 0.189 / 0.501 ms against
+    // lists 0.036 / 0.052 / 0.069 / 0.090 / 0.107 / 0.120 ms at 0.5 / 1.0 / 1.6 / 2.1 / 2.6 / 3.0 queries per tet).  The records
+    // are for the sparse case (BASELINE: 0.4 to 1 query per tet); with a workspace the dense case takes the lists.
+    const bool dense = (long long)Q > kDenseQueriesPerTet * (long long)T && workspace && ((uintptr_t)workspace & 255) == 0 &&
+                       workspace_bytes >= deftet_point_in_tet_bwd_workspace_bytes(B, T, Q);
+    if (hit_buf && !dense) {
         // fastest path: the forward's hit records (needs only kMissParts floats per shape of workspace)
         DEFTET_CHECK_ARG(((uintptr_t)hit_buf & 15) == 0, "hit_buf must be 16-byte aligned");
         float *missPart = nullptr;

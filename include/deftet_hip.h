@@ -140,9 +140,13 @@ int deftet_point_in_tet_scan_ex_f32(const float *tet, const float *pts, float *c
  * grad_occ f32 [B,Q] + grad_pred f32 [B,T] (both or neither): fused backward of the paste_occ
  * gather, grad_pred[b,t] = sum of grad_occ over the queries that pasted from t (misses -> tet 0).
  * hit_buf (from the forward, same tet/pts/cond) selects the fastest path (with grad_pred it
- * also needs 80*n_batch floats of workspace); else workspace
- * (deftet_point_in_tet_bwd_workspace_bytes) enables the linked-list gather path; with neither a
- * float-atomic scatter is used. */
+ * also needs 80*n_batch floats of workspace): every tet adds the queries of its record in ascending query
+ * order — no atomics, the same bits on every run; else workspace
+ * (deftet_point_in_tet_bwd_workspace_bytes) enables the linked-list gather path (per-tet lists threaded with one
+ * atomic exchange per hit, added in arrival order); with neither a float-atomic scatter is used.  The records are for
+ * the sparse case (BASELINE: 0.4 to 1 query per tet): with more than 2 queries per tet (n_query > 2 n_tet) records
+ * overflow by the hundred, the list path is the faster one (measured) and, given a workspace of that size, runs even
+ * when hit_buf is handed in. */
 /* Diagnostics (not on the hot path): 8 int32 per shape left in `workspace` by the last forward — [0] irregular tets,
  * [1] irregular queries, [2] hit-record overflow flag, [5] tets re-scanned exactly, [6] overflowed tets, others unused.
  * Copies to host memory and synchronises the stream.  deftet_point_in_tet_grid_dims reports the cell grid (y/z cells per

@@ -773,7 +773,7 @@ def test_step_captured_in_a_hipgraph_replays_on_new_inputs(cuda):
     capture — then replayed on other inputs copied into the captured tensors: every replay equals the eager operator."""
     from deftet_amd import grids, hip_ops
     hip_ops.clear_query_box_cache()
-    B, Q = 2, 3100                                                   # a (B, Q) no other test tracks
+    B, Q = 2, 2500                                                   # a (B, Q) no other test tracks; <= 2 queries per tet: the backward reads the records
     sets = []
     for s in range(3):
         tet, pts, _, _ = grids.make_case(12, Q, B, 0.1 + 0.05 * s)
@@ -828,13 +828,16 @@ def test_step_captured_in_a_hipgraph_replays_on_new_inputs(cuda):
 
 
 def test_backward_is_bit_reproducible_with_overflowed_records(cuda):
-    """2.4 queries per tet: several tets accept more queries than their hit record and its spill record hold, so their hits come
-    from the forward's list of unrecorded hits, whose ORDER changes from run to run (workgroups append to it with an atomic).  The
-    backward adds them in ascending query order all the same: every run gives the same bits (rounds 2-4 did not: the lanes of a
-    butterfly held the hits in list order)."""
+    """Half of the queries in an eighth of the volume (8 to 9 per tet there, under 2 per tet overall: the backward reads the records):
+    many tets accept more queries than their hit record and its spill record hold, so their hits come from the forward's list of
+    unrecorded hits, whose ORDER changes from run to run (workgroups append to it with an atomic).  The backward adds them in
+    ascending query order all the same: every run gives the same bits (rounds 2-4 did not: the lanes of a butterfly held the hits
+    in list order)."""
     from deftet_amd import grids, hip_ops
-    for res, Q in ((12, 3100), (20, 10000)):
+    for res, Q in ((12, 2500), (20, 11000)):
         tet, pts, _, _ = grids.make_case(res, Q, 2, 0.1)
+        pts = pts.copy()
+        pts[:, : Q // 2] *= 0.5
         t, p = torch.from_numpy(tet).to(cuda), torch.from_numpy(pts).to(cuda)
         g = torch.Generator(device=cuda).manual_seed(5)
         gw, go = torch.randn(2, Q, 4, device=cuda, generator=g), torch.randn(2, Q, device=cuda, generator=g)
@@ -851,3 +854,37 @@ def test_backward_is_bit_reproducible_with_overflowed_records(cuda):
             else:
                 for name, a, b in zip(("grad_tet", "grad_pts", "grad_pred"), (gt, gq, gp), ref):
                     assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (res, it, name)
+
+
+@pytest.mark.parametrize("algo", [0, 3, 4])
+def test_shapes_of_a_batch_do_not_see_each_other(cuda, algo):
+    """A batch is B independent problems (per-shape grids, sorts, records, lists): every shape gives the same bits alone and inside
+    a batch of different shapes — index, weights, occupancy, all gradients — also when one of the others is full of NaN queries,
+    has a query set of another scale, or tets that overflow their records."""
+    from deftet_amd import grids, hip_ops
+    Q = 2500                                                         # (<= 2 queries per tet on average: the backward reads the records)
+    tet, pts, _, _ = grids.make_case(12, Q, 4, 0.15)
+    pts = pts.copy()
+    pts[1, :500] = np.nan
+    pts[2] *= 3.0                                                    # another box: most of these queries miss
+    pts[3] = pts[3] * 0.6                                            # dense: 9 queries per tet in the middle, those records overflow
+    t, p = torch.from_numpy(tet).to(cuda), torch.from_numpy(pts).to(cuda)
+    g = torch.Generator(device=cuda).manual_seed(9)
+    gw, go = torch.randn(4, Q, 4, device=cuda, generator=g), torch.randn(4, Q, device=cuda, generator=g)
+    pred = torch.rand(4, t.shape[1], device=cuda, generator=g)
+
+    def run(sl):
+        cond, w, occ, hits = hip_ops.point_in_tet(t[sl], p[sl], want_bary=True, pred_bxt=pred[sl], want_hits=True, algo=algo)
+        gt, gq, gp = hip_ops.point_in_tet_bwd(t[sl], p[sl], cond, gw[sl], want_grad_pts=True, grad_occ=go[sl], hits=hits)
+        return cond, w, occ, gt, gq, gp
+
+    whole = run(slice(0, 4))
+    assert hip_ops.point_in_tet_stats(4, t.shape[1], Q, algo, cuda)[3, 6] > 0          # shape 3 has overflowed records
+    for b in range(4):
+        alone = run(slice(b, b + 1))
+        for name, x, y in zip(("cond", "w", "occ", "grad_tet", "grad_pts", "grad_pred"), whole, alone):
+            hitq = (whole[0][b, :, 0] >= 0)
+            xa, ya = x[b:b + 1], y
+            if name == "grad_pts":                                   # defined for the hits only (a miss has no tet to differentiate through)
+                xa, ya = xa[0][hitq], ya[0][hitq]
+            assert torch.equal(xa.contiguous().view(torch.int32), ya.contiguous().view(torch.int32)), (b, name)
