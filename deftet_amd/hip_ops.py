@@ -321,6 +321,13 @@ def point_in_tet_stats(B, T, Q, algo, device):
     return out
 
 
+def bwd_uses_records(n_tet, n_query):
+    """Whether point_in_tet_bwd reads the forward's hit records for this size.  They are for the sparse case (BASELINE: 0.4 to 1
+    query per tet); above 2 queries per tet the library takes per-tet lists whatever it is handed (include/deftet_hip.h,
+    deftet_point_in_tet_bwd_f32), so a caller need not ask the forward for records there."""
+    return int(n_query) <= 2 * int(n_tet)
+
+
 def point_in_tet_bwd(tet_bxtx4x3, pts_bxqx3, cond, grad_w, want_grad_pts=False, grad_occ=None, hits=None):
     """(grad_tet [B,T,4,3], grad_pts [B,Q,3] | None) and, when grad_occ [B,Q] is given, also
     grad_pred [B,T] (fused paste_occ backward).  `hits` = the forward's hit-record buffer (same

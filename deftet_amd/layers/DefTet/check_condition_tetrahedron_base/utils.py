@@ -41,7 +41,10 @@ class PointInTetBary(Function):
 
     @staticmethod
     def forward(ctx, tet_bxfx4x3, point_pos_bxnx3):
-        cond, w, hits = hip_ops.point_in_tet(tet_bxfx4x3, point_pos_bxnx3, want_bary=True, want_hits=True, order="auto", query_box="track")
+        # hit records only where the backward reads them (<= 2 queries per tet; beyond, it takes per-tet lists: hip_ops.bwd_uses_records)
+        rec = hip_ops.bwd_uses_records(tet_bxfx4x3.shape[1], point_pos_bxnx3.shape[1])
+        out = hip_ops.point_in_tet(tet_bxfx4x3, point_pos_bxnx3, want_bary=True, want_hits=rec, order="auto", query_box="track")
+        cond, w, hits = out if rec else (out + (None,))
         ctx.save_for_backward(tet_bxfx4x3, point_pos_bxnx3, cond, hits)
         ctx.mark_non_differentiable(cond)
         return cond, w
@@ -65,8 +68,9 @@ class PointInTetOcc(Function):
 
     @staticmethod
     def forward(ctx, tet_bxfx4x3, point_pos_bxnx3, pred_tet_occ):
-        cond, w, occ, hits = hip_ops.point_in_tet(tet_bxfx4x3, point_pos_bxnx3, want_bary=True, pred_bxt=pred_tet_occ,
-                                                  want_hits=True, order="auto", query_box="track")
+        rec = hip_ops.bwd_uses_records(tet_bxfx4x3.shape[1], point_pos_bxnx3.shape[1])
+        out = hip_ops.point_in_tet(tet_bxfx4x3, point_pos_bxnx3, want_bary=True, pred_bxt=pred_tet_occ, want_hits=rec, order="auto", query_box="track")
+        cond, w, occ, hits = out if rec else (out + (None,))
         ctx.save_for_backward(tet_bxfx4x3, point_pos_bxnx3, cond, hits)
         ctx.mark_non_differentiable(cond)
         return cond, w, occ

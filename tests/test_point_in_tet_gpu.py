@@ -888,3 +888,38 @@ def test_shapes_of_a_batch_do_not_see_each_other(cuda, algo):
             if name == "grad_pts":                                   # defined for the hits only (a miss has no tet to differentiate through)
                 xa, ya = xa[0][hitq], ya[0][hitq]
             assert torch.equal(xa.contiguous().view(torch.int32), ya.contiguous().view(torch.int32)), (b, name)
+
+
+def test_autograd_ops_in_the_dense_case(cuda, oracle):
+    """13 queries per tet: the autograd operators do not ask the forward for hit records (hip_ops.bwd_uses_records) and the backward
+    takes the per-tet lists — same index / weights / occupancy as ever, gradients equal to the fp64 autograd of the reference's
+    barycentric formula."""
+    from deftet_amd import hip_ops
+    from deftet_amd.layers.DefTet.check_condition_tetrahedron_base.utils import point_in_tet_occ
+    tet, pts = cases.jittered(8, 5000, 2)
+    assert not hip_ops.bwd_uses_records(tet.shape[1], pts.shape[1]) and hip_ops.bwd_uses_records(257250, 100000)
+    t = torch.from_numpy(tet).to(cuda).requires_grad_(True)
+    p = torch.from_numpy(pts).to(cuda)
+    g = torch.Generator(device=cuda).manual_seed(2)
+    pred = torch.rand(2, tet.shape[1], device=cuda, generator=g).requires_grad_(True)
+    gw, go = torch.randn(2, 5000, 4, device=cuda, generator=g), torch.randn(2, 5000, device=cuda, generator=g)
+    cond, w, occ = point_in_tet_occ(t, p, pred)
+    assert np.array_equal(cond.detach().cpu().numpy(), oracle.point_in_tet(tet, pts))
+    ((w * gw).sum() + (occ * go).sum()).backward()
+    # fp64 reference: the reference's bary_centric_tet on the winning tets, paste_occ with misses aliasing tet 0
+    t64 = torch.from_numpy(tet).double().to(cuda).requires_grad_(True)
+    p64 = pred.detach().double().requires_grad_(True)
+    idx = cond.detach()[..., 0].long()
+    hit = idx >= 0
+    sel = torch.gather(t64, 1, idx.clamp_min(0)[:, :, None, None].expand(-1, -1, 4, 3))
+    a, b, c, d = sel.unbind(2)
+    q = p.double()
+    vol = lambda x, y, z: (x * torch.cross(y, z, dim=-1)).sum(-1)
+    v6 = 1.0 / vol(b - a, c - a, d - a)
+    w64 = torch.stack([vol(q - b, d - b, c - b) * v6, vol(q - a, c - a, d - a) * v6, vol(q - a, d - a, b - a) * v6, vol(q - a, b - a, c - a) * v6], -1)
+    w64 = torch.where(hit[..., None], w64, torch.zeros_like(w64))
+    occ64 = torch.gather(p64, 1, idx.clamp_min(0))
+    ((w64 * gw.double()).sum() + (occ64 * go.double()).sum()).backward()
+    check_close("dense w", w.detach().double(), w64.detach(), 2e-6)
+    check_close("dense grad_tet", t.grad.double(), t64.grad, 4e-6)
+    check_close("dense grad_pred", pred.grad.double(), p64.grad, 2e-6)
