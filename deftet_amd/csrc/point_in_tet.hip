@@ -296,6 +296,21 @@ __device__ __forceinline__ int cell_of(float x, float o, float inv, int G)
     return (int)f;
 }
 
+// A WIDE tet: its cell box holds so large a part of the query grid that its lane would walk thousands of candidates on its own
+// while the rest of the chip has nothing to do — queries packed into a box the size of a tet (or smaller: every tet that
+// touches the box then covers ALL cells) cost 59 ms that way where brute force needs 16 (tools/probes/regime_probe.py).  Such a
+// tet is handed to k_finalize with the irregular ones: every QUERY lane tests it with the reference predicate, n_query tests in
+// parallel instead of a serial walk, and "lowest index" is decided there as for any irregular tet.  The estimate is the cell
+// count times the mean occupancy of a cell (the grid spans the queries' own box); the bound keeps both sides cheap: a lane
+// never walks more than ~max(4096, Q/32) candidates, and at most ~8 x 32 tets of a shape can be that wide.
+// (An axis along which all queries coincide has one occupied cell layer, inv == 0: it does not dilute the occupancy.)
+__device__ __forceinline__ bool wide_tet(int cx0, int cx1, int cy0, int cy1, int cz0, int cz1, int Q, int G, int Gx, const Grid &g)
+{
+    const float cells = (float)(cx1 - cx0 + 1) * (float)((cy1 - cy0 + 1) * (cz1 - cz0 + 1));
+    const float layers = (g.inv[0] > 0.f ? (float)Gx : 1.0f) * (g.inv[1] > 0.f ? (float)G : 1.0f) * (g.inv[2] > 0.f ? (float)G : 1.0f);
+    return cells * ((float)Q / layers) > fmaxf(4096.0f, (float)Q * (1.0f / 32.0f));
+}
+
 __device__ __forceinline__ bool query_regular(float x, float y, float z)
 {
     return fabsf(x) <= kBig && fabsf(y) <= kBig && fabsf(z) <= kBig;   // NaN fails
@@ -911,6 +926,13 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan(const float *__rest
     const int cx0 = cell_of(elo[0], g.o[0], g.inv[0], Gx), cx1 = cell_of(ehi[0], g.o[0], g.inv[0], Gx);
     const int cy0 = cell_of(elo[1], g.o[1], g.inv[1], G), cy1 = cell_of(ehi[1], g.o[1], g.inv[1], G);
     const int cz0 = cell_of(elo[2], g.o[2], g.inv[2], G), cz1 = cell_of(ehi[2], g.o[2], g.inv[2], G);
+    if (wide_tet(cx0, cx1, cy0, cy1, cz0, cz1, Q, G, Gx, g)) {            // k_finalize tests it against every query instead
+        int k = atomicAdd(&counters[b * 4 + 0], 1);
+        irregT[(size_t)b * T + k] = t;
+        if (hits) hits[(size_t)b * T + t] = make_int4(-1, -1, -1, kHitOverflow);
+        irregular_queries_tail(P, t, b, Q, pts, counters, irregQ, result);
+        return;
+    }
     const int Gp = table_pitch(G);
     const int *tb = table + (size_t)b * cellStride;
     const float4 *sq = sortedQ + (size_t)b * Q;
@@ -1251,6 +1273,13 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan_slab(const float *_
     const int cx0 = cell_of(elo[0], g.o[0], g.inv[0], Gx), cx1 = cell_of(ehi[0], g.o[0], g.inv[0], Gx);
     const int cy0 = cell_of(elo[1], g.o[1], g.inv[1], G), cy1 = cell_of(ehi[1], g.o[1], g.inv[1], G);
     const int cz0 = cell_of(elo[2], g.o[2], g.inv[2], G), cz1 = cell_of(ehi[2], g.o[2], g.inv[2], G);
+    if (wide_tet(cx0, cx1, cy0, cy1, cz0, cz1, Q, G, Gx, g)) {            // k_finalize tests it against every query instead
+        int k = atomicAdd(&counters[b * 4 + 0], 1);
+        irregT[(size_t)b * T + k] = t;
+        if (hits) hits[(size_t)b * T + t] = make_int4(-1, -1, -1, kHitOverflow);
+        irregular_tail(tet, t, b, T, Q, pts, counters, irregQ, result);
+        return;
+    }
     const int Gp = table_pitch(G);
     const int *tb = table + (size_t)b * cellStride;
     const float4 *sq = sortedQ + (size_t)b * Q;
@@ -1731,11 +1760,13 @@ __device__ __forceinline__ void tet_scan_wave_body(const float *__restrict__ tet
         }
         // no regular query can lie in the enlarged box -> nothing to traverse
         const bool ingrid = !(ehi[0] < g.lo[0] || elo[0] > g.hi[0] || ehi[1] < g.lo[1] || elo[1] > g.hi[1] || ehi[2] < g.lo[2] || elo[2] > g.hi[2]);
-        works[k] = tet_exists(k) && regular[k] && ingrid;
         {
             const int ax0 = cell_of(elo[0], g.o[0], g.inv[0], Gx), ax1 = cell_of(ehi[0], g.o[0], g.inv[0], Gx);
             const int ay0 = cell_of(elo[1], g.o[1], g.inv[1], G), ay1 = cell_of(ehi[1], g.o[1], g.inv[1], G);
             const int az0 = cell_of(elo[2], g.o[2], g.inv[2], G), az1 = cell_of(ehi[2], g.o[2], g.inv[2], G);
+            // a wide tet (wide_tet above) goes the way of the irregular ones: listed for k_finalize, not traversed, not recorded
+            regular[k] = regular[k] && !(ingrid && wide_tet(ax0, ax1, ay0, ay1, az0, az1, Q, G, Gx, g));
+            works[k] = tet_exists(k) && regular[k] && ingrid;
             if (NT == 1) {
                 cx0 = ax0; cx1 = ax1; cy0 = ay0; cy1 = ay1; cz0 = az0; cz1 = az1;
             } else if (works[k]) {

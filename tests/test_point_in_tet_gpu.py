@@ -923,3 +923,33 @@ def test_autograd_ops_in_the_dense_case(cuda, oracle):
     check_close("dense w", w.detach().double(), w64.detach(), 2e-6)
     check_close("dense grad_tet", t.grad.double(), t64.grad, 4e-6)
     check_close("dense grad_pred", pred.grad.double(), p64.grad, 2e-6)
+
+
+@pytest.mark.parametrize("algo", [0, 2, 3, 4, 5])
+def test_wide_tets_are_tested_by_the_query_lanes(cuda, algo):
+    """All queries inside a box the size of a tet or smaller (or at one point): the grid spans that box, so every tet that touches it
+    covers a large part of the cells and would walk thousands of candidates in one lane.  Such tets are handed to k_finalize like
+    the irregular ones (counters word 0) — same index, weights and gradients as the brute-force kernel / the list backward."""
+    from deftet_amd import grids, hip_ops
+    Q = 20000
+    tet, pts, _, _ = grids.make_case(16, Q, 3, 0.1)
+    pts = pts.copy()
+    pts[0] = pts[0] * 1e-3 + 0.1                                      # a ball far smaller than a tet
+    pts[1] = pts[1] * 0.08 - 0.2                                      # about one tet wide
+    pts[2] = 0.25                                                    # one point: every axis of the grid is degenerate
+    t, p = torch.from_numpy(tet).to(cuda), torch.from_numpy(pts).to(cuda)
+    g = torch.Generator(device=cuda).manual_seed(4)
+    gw = torch.randn(3, Q, 4, device=cuda, generator=g)
+    ref = hip_ops.point_in_tet(t, p, algo=hip_ops.PIT_BRUTE)
+    cond, w, hits = hip_ops.point_in_tet(t, p, want_bary=True, want_hits=True, algo=algo)
+    assert torch.equal(cond, ref)
+    assert (ref >= 0).float().mean().item() > 0.9
+    stats = hip_ops.point_in_tet_stats(3, t.shape[1], Q, algo, cuda)
+    assert (stats[:, 0] > 0).all(), stats[:, 0]                       # tets listed for k_finalize: the wide ones (the mesh has no irregular tet)
+    a = hip_ops.point_in_tet_bwd(t, p, cond, gw, hits=hits)[0]
+    b = hip_ops.point_in_tet_bwd(t, p, cond, gw)[0]
+    check_close("wide tets: hit-record backward vs list backward", a, b, 2e-5)
+    # the uniform case of the same size lists none
+    u = torch.from_numpy(grids.make_case(16, Q, 3, 0.1)[1]).to(cuda)
+    hip_ops.point_in_tet(t, u, algo=algo)
+    assert (hip_ops.point_in_tet_stats(3, t.shape[1], Q, algo, cuda)[:, 0] == 0).all()
