@@ -193,6 +193,7 @@ struct Grid {
     float o[3], inv[3], lo[3], hi[3];
     float pe[3];     // kErrScale * max(|lo|, |hi|): the query-side part of the filter's error radius
     float cs[3];     // upper bound of a cell's edge (1.001 * extent / cells, >= 1e-30): k_tet_scan_wave's candidate-distance bound
+    int wide;        // a tet whose cell box holds more cells than this is WIDE (wide_tet below); set by k_slab_local, which knows Q
 };
 constexpr int kBoxBlocks = 64;
 
@@ -216,6 +217,7 @@ __device__ __forceinline__ Grid make_grid(const float *lo, const float *hi, int 
         // cell_of (<< 0.1 %); with inv == 0 every regular query sits in cell 0 and the box is <= 1e-30 wide
         g.cs[k] = fmaxf(1.001f * ((h - l) / (float)(k == 0 ? Gx : G)), 1e-30f);
     }
+    g.wide = 0x7FFFFFFF;                           // (k_slab_local publishes the real threshold)
     return g;
 }
 
@@ -285,6 +287,7 @@ __device__ __forceinline__ Grid load_grid(const float *__restrict__ gp)
         g.pe[k] = gp[12 + k];
         g.cs[k] = gp[15 + k];
     }
+    g.wide = __float_as_int(gp[18]);
     return g;
 }
 
@@ -304,11 +307,17 @@ __device__ __forceinline__ int cell_of(float x, float o, float inv, int G)
 // count times the mean occupancy of a cell (the grid spans the queries' own box); the bound keeps both sides cheap: a lane
 // never walks more than ~max(4096, Q/32) candidates, and at most ~8 x 32 tets of a shape can be that wide.
 // (An axis along which all queries coincide has one occupied cell layer, inv == 0: it does not dilute the occupancy.)
-__device__ __forceinline__ bool wide_tet(int cx0, int cx1, int cy0, int cy1, int cz0, int cz1, int Q, int G, int Gx, const Grid &g)
+// The threshold is a number of CELLS, worked out once per shape by the thread that publishes the grid (k_slab_local) and read
+// from the grid parameters: the traversal pays two multiplications and a compare per tet.
+__device__ __forceinline__ int wide_cells(const Grid &g, int Q, int G, int Gx)
 {
-    const float cells = (float)(cx1 - cx0 + 1) * (float)((cy1 - cy0 + 1) * (cz1 - cz0 + 1));
     const float layers = (g.inv[0] > 0.f ? (float)Gx : 1.0f) * (g.inv[1] > 0.f ? (float)G : 1.0f) * (g.inv[2] > 0.f ? (float)G : 1.0f);
-    return cells * ((float)Q / layers) > fmaxf(4096.0f, (float)Q * (1.0f / 32.0f));
+    const float cells = fmaxf(4096.0f, (float)Q * (1.0f / 32.0f)) * layers / fmaxf((float)Q, 1.0f);
+    return cells >= 2.0e9f ? 0x7FFFFFFF : (int)cells;                 // (few queries: no tet is wide)
+}
+__device__ __forceinline__ bool wide_tet(int cx0, int cx1, int cy0, int cy1, int cz0, int cz1, const Grid &g)
+{
+    return (cx1 - cx0 + 1) * ((cy1 - cy0 + 1) * (cz1 - cz0 + 1)) > g.wide;   // <= 128 x 64 x 64 cells: no overflow
 }
 
 __device__ __forceinline__ bool query_regular(float x, float y, float z)
@@ -489,6 +498,7 @@ __global__ __launch_bounds__(256) void k_slab_local(const float *__restrict__ pt
         float *gp = gparam + b * kGridWords;                       // (constant indices: a dynamic one sends g through LDS — 13 us)
 #pragma unroll
         for (int k = 0; k < 3; ++k) { gp[k] = g.o[k]; gp[3 + k] = g.inv[k]; gp[6 + k] = g.lo[k]; gp[9 + k] = g.hi[k]; gp[12 + k] = g.pe[k]; gp[15 + k] = g.cs[k]; }
+        gp[18] = __int_as_float(wide_cells(g, Q, G, Gx));
     }
     for (int i = tid; i <= R1; i += 256) hist[i] = 0;
     __syncthreads();
@@ -926,7 +936,7 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan(const float *__rest
     const int cx0 = cell_of(elo[0], g.o[0], g.inv[0], Gx), cx1 = cell_of(ehi[0], g.o[0], g.inv[0], Gx);
     const int cy0 = cell_of(elo[1], g.o[1], g.inv[1], G), cy1 = cell_of(ehi[1], g.o[1], g.inv[1], G);
     const int cz0 = cell_of(elo[2], g.o[2], g.inv[2], G), cz1 = cell_of(ehi[2], g.o[2], g.inv[2], G);
-    if (wide_tet(cx0, cx1, cy0, cy1, cz0, cz1, Q, G, Gx, g)) {            // k_finalize tests it against every query instead
+    if (wide_tet(cx0, cx1, cy0, cy1, cz0, cz1, g)) {            // k_finalize tests it against every query instead
         int k = atomicAdd(&counters[b * 4 + 0], 1);
         irregT[(size_t)b * T + k] = t;
         if (hits) hits[(size_t)b * T + t] = make_int4(-1, -1, -1, kHitOverflow);
@@ -1273,7 +1283,7 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan_slab(const float *_
     const int cx0 = cell_of(elo[0], g.o[0], g.inv[0], Gx), cx1 = cell_of(ehi[0], g.o[0], g.inv[0], Gx);
     const int cy0 = cell_of(elo[1], g.o[1], g.inv[1], G), cy1 = cell_of(ehi[1], g.o[1], g.inv[1], G);
     const int cz0 = cell_of(elo[2], g.o[2], g.inv[2], G), cz1 = cell_of(ehi[2], g.o[2], g.inv[2], G);
-    if (wide_tet(cx0, cx1, cy0, cy1, cz0, cz1, Q, G, Gx, g)) {            // k_finalize tests it against every query instead
+    if (wide_tet(cx0, cx1, cy0, cy1, cz0, cz1, g)) {            // k_finalize tests it against every query instead
         int k = atomicAdd(&counters[b * 4 + 0], 1);
         irregT[(size_t)b * T + k] = t;
         if (hits) hits[(size_t)b * T + t] = make_int4(-1, -1, -1, kHitOverflow);
@@ -1765,7 +1775,7 @@ __device__ __forceinline__ void tet_scan_wave_body(const float *__restrict__ tet
             const int ay0 = cell_of(elo[1], g.o[1], g.inv[1], G), ay1 = cell_of(ehi[1], g.o[1], g.inv[1], G);
             const int az0 = cell_of(elo[2], g.o[2], g.inv[2], G), az1 = cell_of(ehi[2], g.o[2], g.inv[2], G);
             // a wide tet (wide_tet above) goes the way of the irregular ones: listed for k_finalize, not traversed, not recorded
-            regular[k] = regular[k] && !(ingrid && wide_tet(ax0, ax1, ay0, ay1, az0, az1, Q, G, Gx, g));
+            regular[k] = regular[k] && !(ingrid && wide_tet(ax0, ax1, ay0, ay1, az0, az1, g));
             works[k] = tet_exists(k) && regular[k] && ingrid;
             if (NT == 1) {
                 cx0 = ax0; cx1 = ax1; cy0 = ay0; cy1 = ay1; cz0 = az0; cz1 = az1;
