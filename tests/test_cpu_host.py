@@ -438,3 +438,11 @@ def test_bench_self_launch_command(monkeypatch):
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
     # every BASELINE configuration has a workload definition (5 = the full geometry step, not a BASELINE entry)
     assert sorted(bench.CONFIGS) == [1, 2, 3, 4, 5] and bench.CONFIGS[2]["res"] == 70 and bench.CONFIGS[2]["n_query"] == 100_000
+
+
+def test_profiles_readme_quotes_what_the_evidence_files_hold():
+    """profiles/README.md's rows for the evidence pass (bench lines, kernel tables, pmc summaries) are generated from the files: a
+    refreshed pass that is not followed by tools/profiles_readme_rows.py leaves stale figures, and this fails."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "profiles_readme_rows.py"), "--check"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
