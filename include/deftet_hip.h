@@ -42,7 +42,9 @@ extern "C" {
 #define DEFTET_PIT_WAVE 4    /* a wave stages the candidates of its 64 tets in LDS, filter-only per-tet setup (k_tet_scan_wave) */
 #define DEFTET_PIT_PAIR 5    /* the same with two tets per lane: a wave stages once for 128 tets (k_tet_scan_pair; measured slower, never AUTO) */
 
-/* 200: round 4.  (deftet_tet_energies_workspace_bytes(B) is gone: the forward needs ..._bytes2(B, T).  Algorithm ids other
+/* 210: round 5 — the *_ex_* point-in-tet entry points (traversal order, query box with its miss counts),
+ * deftet_tet_spatial_order_f32, DEFTET_PIT_PAIR; the backward takes per-tet lists above 2 queries per tet.
+ * 200: round 4.  (deftet_tet_energies_workspace_bytes(B) is gone: the forward needs ..._bytes2(B, T).  Algorithm ids other
  * than the DEFTET_PIT_* values above — the STAGED / ROWS / ... ids 2-11 of the round-2 library — are rejected with
  * DEFTET_EINVAL, never silently mapped.) */
 int deftet_version(void);
