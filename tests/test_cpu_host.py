@@ -53,6 +53,8 @@ def test_ops_fail_loudly_without_gpu_tensors():
         hip_ops.point_in_tet(torch.zeros(1, 2, 4, 3), torch.zeros(1, 3, 3), order="auto", query_box="track")
     with pytest.raises(ValueError):
         hip_ops.pit_kernel_name(hip_ops.PIT_AUTO)               # the kernel AUTO runs depends on the sizes: no silent default
+    # the backward reads hit records up to 2 queries per tet (include/deftet_hip.h, deftet_point_in_tet_bwd_f32): the autograd ops ask for them only there
+    assert hip_ops.bwd_uses_records(257250, 100000) and hip_ops.bwd_uses_records(48000, 96000) and not hip_ops.bwd_uses_records(48000, 96001)
 
 
 def test_tracked_query_boxes_alternate_between_two_buffers():

@@ -1,7 +1,7 @@
 """Timing of the grid-accelerated operators OUTSIDE the training distribution they were tuned on: clustered, planar, collinear, far and
 duplicated inputs at 100 k points.  A regime that costs 100x the uniform case is a cliff worth knowing.  python tools/probes/regime_probe.py"""
 import os, sys, time
-import numpy as np, torch
+import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from deftet_amd import grids, hip_ops
