@@ -86,7 +86,14 @@ class PitWorkload:
             idx = np.arange(n * n * n * 6).reshape(n, n, n, 6)       # [ix, iy, iz, k] -> current position
             tets = tets[idx.transpose(2, 1, 0, 3).reshape(-1)]       # new position ((iz*n + iy)*n + ix)*6 + k
         if cfg.get("mesh") == "shuffled":                 # probe use: the same grid, its tet list in random order
-            self.shuffle_perm = np.random.default_rng(7).permutation(tets.shape[0])
+            rng7 = np.random.default_rng(7)
+            frac = float(cfg.get("shuffle_frac", 1.0))      # < 1: only that fraction of the positions trade places (probe: the order rule's crossover)
+            if frac >= 1.0:
+                self.shuffle_perm = rng7.permutation(tets.shape[0])
+            else:
+                sel = np.sort(rng7.choice(tets.shape[0], int(frac * tets.shape[0]), replace=False))
+                self.shuffle_perm = np.arange(tets.shape[0])
+                self.shuffle_perm[sel] = sel[rng7.permutation(sel.size)]
             tets = tets[self.shuffle_perm]
         # traversal order handed to the operator: "auto" (what the autograd ops pass: decided once per grid), "native" (none),
         # "sorted" (the computed column order, unconditionally) — DEFTET_BENCH_TET_ORDER / cfg["tet_order"]; never changes a result
@@ -201,7 +208,7 @@ class PitWorkload:
 
     def _tracker_counts(self):
         from deftet_amd import hip_ops
-        st = hip_ops.query_box_trackers().get((self.device.index if self.device.index is not None else torch.cuda.current_device(), self.B, self.Q))
+        st = hip_ops.query_box_trackers().get(hip_ops.query_box_key(self.device, self.B, self.Q))
         return "no tracked call yet" if st is None else "%d tracked, %d measured, %d fall-backs to measuring" % (st["tracked"], st["measured"], st["backoffs"])
 
     def describe(self):
@@ -242,6 +249,10 @@ class RasterWorkload:
         self.last = None
         # saturation policy (include/deftet_hip.h): 0 = NEAREST (the library default), 1 = FIRST; DEFTET_BENCH_RASTER_POLICY
         self.policy = int(os.environ.get("DEFTET_BENCH_RASTER_POLICY", "0"))
+
+    def saturated(self):
+        from deftet_amd.render.deftet_sparse_render import saturated_pixels
+        return saturated_pixels(*[x.detach() for x in self.t], knum=self.k)
 
     def step(self, i):
         from deftet_amd.render import deftet_sparse_render
@@ -737,6 +748,15 @@ def main():
                              "ms_per_step": rec["ms_per_step"], "ms_per_step_median": rec["ms_per_step_median"]}
                     if isinstance(w2, PitWorkload):
                         entry["ms_per_step_hipgraph"] = graph_replay(w2, k2)[0]
+                    if isinstance(w2, RasterWorkload):
+                        # both saturation policies every round (which one Kaolin implements is unknown; this configuration saturates)
+                        entry["policy"] = ["nearest", "first"][w2.policy]
+                        w2.policy = 1 - w2.policy
+                        e3, ps3, _, _ = timed(w2, lib, k2, 3, 1, barrier=False, step_events=True)
+                        entry["ms_per_step_%s" % ["nearest", "first"][w2.policy]] = round(e3 / k2 * 1e3, 4)
+                        w2.policy = 1 - w2.policy
+                        entry["saturated_pixels"] = w2.saturated()
+                        entry["n_pixel"] = w2.P
                     if w2.dominant_bytes > 0:
                         entry["roofline"] = {k: rec["roofline"][k] for k in ("kernel", "achieved", "frac", "avg_launch_ms", "whole_step")}
                         if "valu" in rec["roofline"]:

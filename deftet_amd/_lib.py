@@ -29,6 +29,8 @@ SIGNATURES = {
     "deftet_point_in_tet_scan_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _sz, _vp]),
     "deftet_tet_spatial_order_workspace_bytes": (_sz, [_i]),
     "deftet_tet_spatial_order_f32": (_i, [_vp, _i, _vp, _vp, _vp, _sz, _vp]),
+    "deftet_tet_order_coherence_workspace_bytes": (_sz, [_i]),
+    "deftet_tet_order_coherence_f32": (_i, [_vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "deftet_point_in_tet_ex_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "deftet_point_in_tet_prepare_ex_f32": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "deftet_point_in_tet_scan_ex_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),

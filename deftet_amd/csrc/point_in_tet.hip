@@ -1528,6 +1528,15 @@ constexpr int kWvCapPair = PIT_WVCAP_PAIR, kWvRowsPair = 256;
 #define PIT_STOP 0
 #endif
 #define PIT_KEEP(x) asm volatile("" ::"v"(x))
+#ifndef PIT_PROBE_PREFILL
+#define PIT_PROBE_PREFILL 0
+#endif
+#ifndef PIT_PIN_SHAPES
+#define PIT_PIN_SHAPES 0
+#endif
+#ifndef PIT_PROBE_SCATTER
+#define PIT_PROBE_SCATTER 0   // probe builds only (1 / 2): per-hit scattered stores beside the publish atomics (timing only)
+#endif
 #ifndef PIT_WAVES_PAIR
 #define PIT_WAVES_PAIR 5
 #endif
@@ -1679,6 +1688,35 @@ __device__ __noinline__ int exact_rescan_slots(const float *__restrict__ tv, int
     return hcnt;
 }
 
+// barycentric weights, utils/tet_utils.py:25-45 (same association as the torch expression)
+__device__ __forceinline__ float triple(const float *a, const float *b, const float *c)
+{
+    float x0 = b[1] * c[2] - b[2] * c[1];
+    float x1 = b[2] * c[0] - b[0] * c[2];
+    float x2 = b[0] * c[1] - b[1] * c[0];
+    return (a[0] * x0 + a[1] * x1) + a[2] * x2;
+}
+// the four weights of point p in the tet (t0, t1, t2 = its 48-byte record): utils/tet_utils.py:28-45, operation for operation
+__device__ __forceinline__ float4 bary_weights(const float4 t0, const float4 t1, const float4 t2, float px, float py, float pz)
+{
+    const float A[3] = {t0.x, t0.y, t0.z}, Bv[3] = {t0.w, t1.x, t1.y}, Cv[3] = {t1.z, t1.w, t2.x}, D[3] = {t2.y, t2.z, t2.w};
+    const float pp[3] = {px, py, pz};
+    float vap[3], vbp[3], vab[3], vac[3], vad[3], vbc[3], vbd[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        vap[k] = pp[k] - A[k]; vbp[k] = pp[k] - Bv[k];
+        vab[k] = Bv[k] - A[k]; vac[k] = Cv[k] - A[k]; vad[k] = D[k] - A[k];
+        vbc[k] = Cv[k] - Bv[k]; vbd[k] = D[k] - Bv[k];
+    }
+    const float v6 = 1.0f / triple(vab, vac, vad);
+    float4 wq;
+    wq.x = triple(vbp, vbd, vbc) * v6;
+    wq.y = triple(vap, vac, vad) * v6;
+    wq.z = triple(vap, vad, vab) * v6;
+    wq.w = triple(vap, vab, vac) * v6;
+    return wq;
+}
+
 // NT tets per lane (1: k_tet_scan_wave, 2: k_tet_scan_pair).  With two, the lane owns the tets at positions 2p and 2p + 1 — in a
 // coherent list neighbours, usually with the same candidates — and everything that is done once per WAVE (footprint groups,
 // row bounds, scan, staging: 59 % of the instructions of the one-tet kernel at configs[2]) serves 128 tets instead of 64:
@@ -1697,16 +1735,32 @@ __device__ __forceinline__ void tet_scan_wave_body(const float *__restrict__ tet
     typedef WaveStageT<CAP, ROWS> Stage;
     __shared__ Stage s_w[kWvThreads / 64];
     __shared__ int s_hit[NT][kWvSlots + 2][kWvThreads];                // [tet of the lane][slot][thread]; the last two rows swallow the overflow
-    if (ucount && blockIdx.x == 0 && __builtin_amdgcn_readfirstlane(threadIdx.x) == 0) {   // per-shape words of the hit buffer
-        ucount[blockIdx.y] = 0;                                        // (wave-uniform branch, see k_tet_scan_slab: behind a
-        ucount[hpad + blockIdx.y] = 0;                                 // one-thread branch: 80 registers and an 8-byte scratch store
-        ucount[2 * hpad + blockIdx.y] = 0;                             // per lane = 16 MB of HBM writes per launch; so: 76, none)
+#if PIT_PIN_SHAPES
+    // probe builds: shape-per-XCD placement (shape_block): workgroup L runs on XCD L % 8, so with shape = L % B every XCD walks ONE
+    // shape (B = 8) and the per-query arrays it scatters into live in one L2
+    const int pinL = blockIdx.y * gridDim.x + blockIdx.x, pinB = gridDim.y;
+#define PIT_BLK_B (pinL % pinB)
+#define PIT_BLK_X (pinL / pinB)
+#else
+#define PIT_BLK_B blockIdx.y
+#define PIT_BLK_X blockIdx.x
+#endif
+    if (ucount && PIT_BLK_X == 0 && __builtin_amdgcn_readfirstlane(threadIdx.x) == 0) {   // per-shape words of the hit buffer
+        ucount[PIT_BLK_B] = 0;                                         // (wave-uniform branch, see k_tet_scan_slab: behind a
+        ucount[hpad + PIT_BLK_B] = 0;                                  // one-thread branch: 80 registers and an 8-byte scratch store
+        ucount[2 * hpad + PIT_BLK_B] = 0;                              // per lane = 16 MB of HBM writes per launch; so: 76, none)
     }
-    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const int b = PIT_BLK_B, tid = threadIdx.x, lane = tid & 63;
     Stage &W = s_w[tid >> 6];
     const int nblk = gridDim.x;
+#if PIT_PIN_SHAPES
+    const int vb = PIT_BLK_X;
+#else
     const int per = (nblk + 7) >> 3;
     const int vb = (blockIdx.x & 7) * per + (blockIdx.x >> 3);        // XCD-aware mapping, see k_tet_scan
+#endif
+#undef PIT_BLK_B
+#undef PIT_BLK_X
     const int t = vb * blockDim.x + tid;                                // the lane's position in the launch: tets at NT * t + k
     const bool valid = vb < nblk && t < (T + NT - 1) / NT;
     if (__builtin_amdgcn_ballot_w64(valid) == 0ull) return;           // (every other lane stays: the wave works together)
@@ -2196,7 +2250,30 @@ __device__ __forceinline__ void tet_scan_wave_body(const float *__restrict__ tet
 #pragma unroll 1
         for (int i = 0; i < kWvSlots; ++i) {                             // publish: one atomic instruction per slot level in use
             if (__builtin_amdgcn_ballot_w64(hc > i) == 0ull) break;
+#if PIT_PROBE_SCATTER == 0
             if (hc > i) atomic_smin_off_nh(resb, (unsigned)s_hit[k][i][tid] * 4u, te);
+#else
+            // timing probe only (wrong spill records): what do per-hit scattered output stores cost next to the atomics?
+            if (hc > i && spill) {
+                const int qi = s_hit[k][i][tid];
+                char *pb = reinterpret_cast<char *>(spill);
+                const size_t nq = (size_t)gridDim.y * Q, iq = (size_t)b * Q + qi;
+                bool win = true;
+                if (PIT_PROBE_SCATTER == 1) atomic_smin_off_nh(resb, (unsigned)qi * 4u, te);
+                else win = atomicMin(&result[iq], te) > te;
+                if (win && PIT_PROBE_SCATTER == 3) {
+                    const float4 *src = reinterpret_cast<const float4 *>(tet + ((size_t)b * T + te) * 12);
+                    const float *pp = pts + iq * 3;
+                    *reinterpret_cast<float4 *>(pb + iq * 16) = bary_weights(src[0], src[1], src[2], pp[0], pp[1], pp[2]);
+                    *reinterpret_cast<float *>(pb + nq * 16 + iq * 4) = (float)te;
+                    *reinterpret_cast<float *>(pb + nq * 20 + iq * 4) = (float)qi;
+                } else if (win) {
+                    *reinterpret_cast<float4 *>(pb + iq * 16) = make_float4((float)te, (float)qi, 0.25f, 0.5f);
+                    *reinterpret_cast<float *>(pb + nq * 16 + iq * 4) = (float)te;
+                    *reinterpret_cast<float *>(pb + nq * 20 + iq * 4) = (float)qi;
+                }
+            }
+#endif
         }
         if (hits) {
             // <= 4 accepted: the record; 5..kWvSlots: the record (flagged) + the spill record; more: overflow marker (the hits are
@@ -2207,7 +2284,7 @@ __device__ __forceinline__ void tet_scan_wave_body(const float *__restrict__ tet
 #pragma unroll
             for (int i = 0; i < 4; ++i)
                 if (i < hc) h[i] = s_hit[k][i][tid];
-            const bool spilled = hc > 4 && hc <= kWvSlots && spill != nullptr;
+            const bool spilled = hc > 4 && hc <= kWvSlots && spill != nullptr && PIT_PROBE_SCATTER == 0;   // (probe builds scribble over the spill records)
             const bool over = hc > 4 && !spilled;
             if (spilled) {
 #pragma unroll
@@ -2242,16 +2319,6 @@ __global__ __launch_bounds__(kWvThreads, PIT_WAVES_PAIR) void k_tet_scan_pair(PI
 }
 #undef PIT_SCAN_PARAMS
 #undef PIT_SCAN_FWD
-
-// barycentric weights, utils/tet_utils.py:25-45 (same association as the torch expression)
-__device__ __forceinline__ float triple(const float *a, const float *b, const float *c)
-{
-    float x0 = b[1] * c[2] - b[2] * c[1];
-    float x1 = b[2] * c[0] - b[0] * c[2];
-    float x2 = b[0] * c[1] - b[1] * c[0];
-    return (a[0] * x0 + a[1] * x1) + a[2] * x2;
-}
-
 
 __global__ __launch_bounds__(256) void k_finalize(const float *__restrict__ tet, const float *__restrict__ pts, int T,
                                                   int Q, const int *__restrict__ result, float *cond, float *bary,
@@ -2340,21 +2407,9 @@ __global__ __launch_bounds__(256) void k_finalize(const float *__restrict__ tet,
     float4 wq = make_float4(0.f, 0.f, 0.f, 0.f);
     if (hit) {
         const float4 *src = reinterpret_cast<const float4 *>(tet + ((size_t)b * T + r) * 12);
-        float4 t0 = src[0], t1 = src[1], t2 = src[2];
-        const float A[3] = {t0.x, t0.y, t0.z}, Bv[3] = {t0.w, t1.x, t1.y}, Cv[3] = {t1.z, t1.w, t2.x}, D[3] = {t2.y, t2.z, t2.w};
+        const float4 t0 = src[0], t1 = src[1], t2 = src[2];
         const float *pp = pts + i * 3;
-        float vap[3], vbp[3], vab[3], vac[3], vad[3], vbc[3], vbd[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            vap[k] = pp[k] - A[k]; vbp[k] = pp[k] - Bv[k];
-            vab[k] = Bv[k] - A[k]; vac[k] = Cv[k] - A[k]; vad[k] = D[k] - A[k];
-            vbc[k] = Cv[k] - Bv[k]; vbd[k] = D[k] - Bv[k];
-        }
-        float v6 = 1.0f / triple(vab, vac, vad);
-        wq.x = triple(vbp, vbd, vbc) * v6;
-        wq.y = triple(vap, vac, vad) * v6;
-        wq.z = triple(vap, vad, vab) * v6;
-        wq.w = triple(vap, vab, vac) * v6;
+        wq = bary_weights(t0, t1, t2, pp[0], pp[1], pp[2]);
     }
     stream_store(reinterpret_cast<float4 *>(bary) + i, wq);
 }
@@ -3144,6 +3199,10 @@ static int pit_scan(const Layout &L, const float *tet, const float *pts, float *
             int4 *spill = hit_buf ? (int4 *)(hit_buf + hit_spill_off(B, T, Q)) : (int4 *)nullptr;
             const int kern = resolve_auto(algo, T, Q);
             const bool slab = kern == DEFTET_PIT_SLAB;
+#if PIT_PROBE_SCATTER && PIT_PROBE_PREFILL
+            // probe: the lines the per-hit stores will hit are written in full first (do they then sit in the Infinity Cache?)
+            if (spill) DEFTET_HIP(hipMemsetAsync(spill, 0, (size_t)B * Q * 24, st));
+#endif
             const dim3 bw(kWvThreads);                                                           // the wave-staged kernels' workgroup
             const dim3 gw((((T + kWvThreads - 1) / kWvThreads + 7) / 8) * 8, B);
             const dim3 gp(((((T + 1) / 2 + kWvThreads - 1) / kWvThreads + 7) / 8) * 8, B);       // two tets per lane

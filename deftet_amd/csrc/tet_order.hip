@@ -213,6 +213,57 @@ __global__ __launch_bounds__(256) void k_order_breaks(const unsigned *__restrict
     }
 }
 
+// How coherent a tet numbering is FOR THE TRAVERSAL: far[0] = places inside a group of 64 consecutive tets (of the caller's
+// order, or of `order` when given) where the next tet lies FAR from the one before — the centroids differ by more than
+// kFarExt mean box extents along some axis — and far[1] = the number of places looked at.  (The `breaks` of
+// deftet_tet_spatial_order_f32 count every change of column; the shipped QuarTet grid alternates between NEIGHBOURING columns
+// all the time — 76 % breaks — and is still the faster order as it is: what the wave kernel cares about is whether the 64 tets
+// of a wave share a neighbourhood, not whether they share a column.)  Non-finite tets count as far from everything.
+constexpr float kFarExt = 3.0f;
+constexpr int kFarBlocks = 256;
+
+__global__ __launch_bounds__(256) void k_order_far(const float *__restrict__ tet, int T, const int *__restrict__ order,
+                                                   const float *__restrict__ part, int *blockFar)
+{
+    __shared__ float st[kStatWords];
+    __shared__ int sh[4];
+    reduce_stats(part, st);
+    const float n = fmaxf(st[9], 1.f);
+    const float lim[3] = {kFarExt * st[6] / n, kFarExt * st[7] / n, kFarExt * st[8] / n};
+    int far = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < T; i += gridDim.x * blockDim.x) {
+        if ((i & 63) == 0) continue;
+        float c0[3], c1[3], e[3];
+        const bool ok0 = centroid_of(tet, order ? order[i - 1] : i - 1, c0, e), ok1 = centroid_of(tet, order ? order[i] : i, c1, e);
+        bool f = !(ok0 && ok1);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) f = f || !(fabsf(c1[k] - c0[k]) <= lim[k]);
+        far += f ? 1 : 0;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) far += __shfl_xor(far, off);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = far;
+    __syncthreads();
+    if (threadIdx.x == 0) blockFar[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+// one workgroup adds the partials up and stores the two words with plain stores (`out` may be host-mapped memory)
+__global__ __launch_bounds__(kFarBlocks) void k_order_far_sum(const int *__restrict__ blockFar, int T, int *out)
+{
+    __shared__ int sh[kFarBlocks / 64];
+    int v = blockFar[threadIdx.x];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+        for (int k = 0; k < kFarBlocks / 64; ++k) tot += sh[k];
+        out[0] = tot;
+        out[1] = T - (T + 63) / 64;
+    }
+}
+
 struct Layout {
     float *part;
     unsigned *hist;
@@ -272,5 +323,35 @@ extern "C" int deftet_tet_spatial_order_f32(const float *tet, int n_tet, int32_t
                                                         2 * kColBits + kZBits, L.sortTmp, L.sortBytes, st);
     if (rc != DEFTET_OK) return rc;
     if (breaks) DEFTET_LAUNCH(k_order_breaks, dim3(nblk), dim3(256), st, (const unsigned *)L.key, (const unsigned *)L.skey, n_tet, breaks);
+    return DEFTET_OK;
+}
+
+// Coherence of a tet numbering for the traversal (k_order_far above): out2[0] = far steps inside groups of 64 consecutive tets
+// of `order` (NULL: the caller's own numbering), out2[1] = steps looked at.  out2 is written with two plain 4-byte stores by
+// one thread and may be host-mapped memory (a caller can poll it without synchronising).  Three small launches.
+extern "C" size_t deftet_tet_order_coherence_workspace_bytes(int n_tet)
+{
+    if (n_tet <= 0) return 0;
+    return align_up((size_t)deftet::order::kStatBlocks * deftet::order::kStatWords * 4, 256) + align_up((size_t)deftet::order::kFarBlocks * 4, 256);
+}
+
+extern "C" int deftet_tet_order_coherence_f32(const float *tet, int n_tet, const int32_t *order, int32_t *out2, void *workspace,
+                                              size_t workspace_bytes, void *stream_)
+{
+    using namespace deftet::order;
+    DEFTET_CHECK_ARG(n_tet >= 0 && out2, "negative size or null output");
+    hipStream_t st = as_stream(stream_);
+    if (n_tet == 0) {
+        DEFTET_HIP(hipMemsetAsync(out2, 0, 8, st));
+        return DEFTET_OK;
+    }
+    DEFTET_CHECK_ARG(tet && ((uintptr_t)tet & 15) == 0, "null or misaligned pointer");
+    DEFTET_CHECK_ARG(workspace && ((uintptr_t)workspace & 255) == 0 && workspace_bytes >= deftet_tet_order_coherence_workspace_bytes(n_tet),
+                     "workspace null, misaligned or too small");
+    float *part = static_cast<float *>(workspace);
+    int *blockFar = reinterpret_cast<int *>(static_cast<char *>(workspace) + align_up((size_t)kStatBlocks * kStatWords * 4, 256));
+    DEFTET_LAUNCH(k_order_stats, dim3(kStatBlocks), dim3(256), st, tet, n_tet, part);
+    DEFTET_LAUNCH(k_order_far, dim3(kFarBlocks), dim3(256), st, tet, n_tet, (const int *)order, (const float *)part, blockFar);
+    DEFTET_LAUNCH(k_order_far_sum, dim3(1), dim3(kFarBlocks), st, (const int *)blockFar, n_tet, out2);
     return DEFTET_OK;
 }

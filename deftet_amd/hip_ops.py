@@ -48,17 +48,23 @@ class PreparedQueries:
         self.consumed = False
 
 
-# Query boxes tracked from call to call (query_box="track"): per (device, B, Q) two [B,6] tensors used in turns — a call hands the
-# box the PREVIOUS call measured to the library (query_box_in: the grid spans it, the measuring launch is skipped) and receives
-# the box of its own queries for the next one.  A training loop draws its queries from one distribution (dataloader.py:108), so
-# the previous box fits.  Where it does not, the queries outside it are answered exactly by the side path — at brute-force cost
-# each, so the tracker must notice: the library counts them per shape into `misses`, an int32 [B] tensor in pinned host memory
-# that the kernels write directly and the next calls read WITHOUT synchronising (the value seen is a few calls old when the
-# host runs ahead of the GPU).  More than `limit` misses in a shape => the next `backoff` calls measure their own box again
-# (always exact, always at full speed, one launch more), and `backoff` quadruples every time that happens, so a caller that
-# alternates between two query distributions under the same (B, Q) ends up measuring; a long run of clean tracked calls
-# shrinks it again.  DEFTET_PIT_BOX=off switches the tracking off.
+# Query boxes tracked from call to call (query_box="track"): per (device, STREAM, B, Q) two [B,6] tensors used in turns — a call
+# hands the box the PREVIOUS call measured to the library (query_box_in: the grid spans it, the measuring launch is skipped) and
+# receives the box of its own queries for the next one.  A training loop draws its queries from one distribution
+# (dataloader.py:108), so the previous box fits.  Where it does not, the queries outside it are answered exactly by the side
+# path — at brute-force cost each, so the tracker must notice: the library counts them per shape into `misses`, an int32 [B]
+# tensor in pinned host memory that the kernels write directly and the next calls read WITHOUT synchronising (the value seen
+# is a few calls old when the host runs ahead of the GPU).  More than `limit` misses in a shape => the next `backoff` calls
+# measure their own box again (always exact, always at full speed, one launch more), and `backoff` quadruples every time that
+# happens, so a caller that alternates between two query distributions under the same (B, Q) ends up measuring; a long run of
+# clean tracked calls shrinks it again.  DEFTET_PIT_BOX=off switches the tracking off.
+# The stream is part of the key (round 6): call N+1 reads the box call N's k_slab_sort wrote, and only the
+# order of ONE stream makes that read come after the write — two streams sharing a tracker (bench.py's pipelined path: one
+# prepare on the main stream, the next on a side stream) raced, and a box that changes while k_slab_local runs gives its
+# workgroups different grids.  Calls on different streams now never share a box; inside the library every workgroup takes
+# the grid from the snapshot its own launch sequence published (k_slab_local<true>: see there).
 _box_cache = {}
+_box_lock = __import__("threading").Lock()
 
 
 class _BoxTracker:
@@ -92,27 +98,41 @@ class _BoxTracker:
         return box_in, box_out, self.misses
 
 
+def query_box_key(dev, B, Q):
+    """Key of the tracker a query_box="track" call on `dev`'s CURRENT stream uses (see query_box_trackers)."""
+    dev = torch.device(dev)
+    on_gpu = dev.type == "cuda" and torch.cuda.is_available()
+    idx = dev.index if dev.index is not None else (torch.cuda.current_device() if on_gpu else 0)
+    return (idx, torch.cuda.current_stream(dev).cuda_stream if on_gpu else 0, B, Q)
+
+
 def _tracked_boxes(dev, B, Q):
     """(query_box_in | None, query_box_out, query_box_misses | None) for this call."""
     import os
     if os.environ.get("DEFTET_PIT_BOX", "track") == "off":
         return None, None, None
-    key = (dev.index if dev.index is not None else torch.cuda.current_device(), B, Q)
-    st = _box_cache.get(key)
-    if st is None:
-        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
-            return None, None, None                          # no state is born inside a graph capture (its tensors would belong to the
-        st = _box_cache[key] = _BoxTracker(dev, B, Q)        # graph's pool, pinned memory cannot be allocated there): this call measures
-    return st.step()
+    # A call that is being captured into a graph measures its own box and touches no tracker: a tracked call would bake ONE
+    # (box_in, box_out, misses) triple into the graph — replays would never alternate the buffers nor ever fall back to
+    # measuring (the misses are only polled by eager calls), and the Python phase would no longer describe what the graph does.
+    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        return None, None, None
+    key = query_box_key(dev, B, Q)
+    with _box_lock:
+        st = _box_cache.get(key)
+        if st is None:
+            st = _box_cache[key] = _BoxTracker(dev, B, Q)
+        return st.step()
 
 
 def clear_query_box_cache():
-    _box_cache.clear()
+    with _box_lock:
+        _box_cache.clear()
 
 
 def query_box_trackers():
-    """{(device, B, Q): {"tracked", "measured", "backoffs", "hold", "backoff"}} — what query_box="track" has been doing."""
-    return {k: dict(v.counts, hold=v.hold, backoff=v.backoff) for k, v in _box_cache.items()}
+    """{(device, stream, B, Q): {"tracked", "measured", "backoffs", "hold", "backoff"}} — what query_box="track" has been doing."""
+    with _box_lock:
+        return {k: dict(v.counts, hold=v.hold, backoff=v.backoff) for k, v in _box_cache.items()}
 
 
 def _resolve_query_box(query_box, dev, B, Q, algo, misses=None):
@@ -170,21 +190,130 @@ def tet_spatial_order(tet_tx4x3, want_breaks=False):
         ws = _lib.workspace(dev, max(lib.deftet_tet_spatial_order_workspace_bytes(T), 256))
         _lib.check(lib.deftet_tet_spatial_order_f32(_lib.ptr(tet), T, _lib.ptr(order), _lib.ptr(breaks), _lib.ptr(ws), ws.numel(),
                                                     _lib.current_stream(dev)), "deftet_tet_spatial_order_f32")
+    _orders_checked[_order_id(order, T)] = True                       # a stable sort of 0..T-1: a permutation by construction
     return (order, breaks) if want_breaks else order
 
 
-# Traversal orders chosen automatically, one per (device, number of tets, kernel): decided at the first call by MEASURING the
-# forward on the tensors it was handed — the caller's numbering against the computed column order, a few launches each, ~1 ms
-# once — then reused: the topology of a DefTet grid is static (layers/DefTet/deftet.py:65-68), and the order is a matter of
-# speed only, so a stale or unlucky choice can never change a result.  (A static coherence measure was tried first — the
-# `breaks` counts of deftet_tet_spatial_order_f32 — and chose wrongly for the shipped QuarTet grid, whose own order is the
-# faster one although it looks less regular.)  DEFTET_PIT_ORDER=off|force overrides the decision.
+def tet_order_coherence(tet_tx4x3, order=None, out=None):
+    """int32 [2] = (far steps, steps looked at) of a tet numbering of ONE shape: places inside a group of 64 consecutive tets
+    — of `order` when given, else of the caller's own numbering — where the next tet's centroid lies more than three mean box
+    extents from the one before (include/deftet_hip.h, deftet_tet_order_coherence_f32).  What auto_tet_order decides on.
+    out: an int32 tensor of >= 2 entries to write into (device memory, or pinned host memory a caller polls)."""
+    _lib.require_gpu(tet_tx4x3, order)
+    lib = _lib.load()
+    tet = _f32c(tet_tx4x3)
+    if tet.dim() != 3 or tet.shape[1:] != (4, 3):
+        raise RuntimeError("tet_tx4x3 must be [T,4,3] (one shape), got %s" % (tuple(tet.shape),))
+    T, dev = tet.shape[0], tet.device
+    if order is not None and (order.dtype != torch.int32 or order.shape != (T,) or not order.is_contiguous() or order.device != dev):
+        raise RuntimeError("order must be a contiguous int32 [T] tensor on the tets' device")
+    if out is None:
+        out = torch.empty(2, device=dev, dtype=torch.int32)
+    elif out.dtype != torch.int32 or out.numel() < 2 or not out.is_contiguous():
+        raise RuntimeError("out must be a contiguous int32 tensor of at least 2 entries")
+    with torch.cuda.device(dev):
+        ws = _lib.workspace(dev, max(lib.deftet_tet_order_coherence_workspace_bytes(T), 256))
+        _lib.check(lib.deftet_tet_order_coherence_f32(_lib.ptr(tet), T, _lib.ptr(order), _lib.ptr(out), _lib.ptr(ws), ws.numel(),
+                                                      _lib.current_stream(dev)), "deftet_tet_order_coherence_f32")
+    return out
+
+
+# Traversal orders chosen automatically (order="auto"), one per (device, number of tets, kernel, TOPOLOGY): decided at the first
+# eager call from the numbering's COHERENCE — tet_order_coherence: the fraction of steps inside 64-tet groups that land far
+# from the tet before — never from a stopwatch (round 5 timed both orders inside the operator: eight extra forwards and a
+# verdict that depended on the box's noise).  The computed column order is taken when more than _FAR_LIMIT of the caller's steps
+# are far AND the computed order at least halves that.  Measured (profiles/r06_order_rule.jsonl, tools/probes/order_rule_probe.py,
+# order_breaks_probe.py): ONE displaced tet per wave already sends its lane to the global walk — the Kuhn list with 1 % / 4 % /
+# 100 % of its positions shuffled (far fraction 0.024 / 0.082 / 0.995) runs 79 / 93 / 195 us against 64 / 66 / 98 through the
+# computed order — while the Kuhn grids in any enumeration (0.005-0.007: the column ends) and the shipped QuarTet grid (0.047,
+# which the computed order only brings to 0.027: its numbering walks neighbouring columns in turns) are faster as they are (the
+# QuarTet grid by 13 %: a permutation costs gathers of 48-byte records, profiles/r05_scan_ab_orders.jsonl).  A stale or unlucky
+# choice can never change a result.
+#   topology: what identifies the tet LIST (static during training, layers/DefTet/deftet.py:65-68) — a TetTopology (its serial), any
+# hashable key, or the index tensor itself (fingerprinted once by content).  Callers that only have positions
+# (check_condition_f_base's reference signature) pass None: their entry is keyed by the sizes alone and is WATCHED — every
+# _WATCH_EVERY-th call the coherence of the caller's numbering (and of the permutation in use) is measured asynchronously into
+# pinned host memory and read by a later call without synchronising; when it no longer matches what the decision was made on (a
+# second mesh with the same number of tets and another numbering) the entry is dropped and decided again.
+# DEFTET_PIT_ORDER=off|force overrides the decision.
+_FAR_LIMIT = 0.02
+_WATCH_EVERY = 64
 _order_cache = {}
 _order_lock = __import__("threading").Lock()
+_topology_prints = {}
 
 
-def auto_tet_order(tet_bxtx4x3, pts_bxqx3, algo=PIT_AUTO):
-    """The cached traversal order for this grid, or None when its own numbering is at least as fast (or the grid is tiny)."""
+class _OrderEntry:
+    def __init__(self, choice, fractions):
+        self.choice, self.fractions = choice, fractions      # fractions: (far fraction of the caller's numbering, of the computed order) | None
+        self.calls, self.mail, self.event = 0, None, None
+
+
+def _far_fraction(pair):
+    return float(pair[0]) / max(int(pair[1]), 1)
+
+
+def _decide_order(f_native, f_sorted):
+    """True = traverse in the computed column order; the deterministic rule of auto_tet_order."""
+    return f_native > _FAR_LIMIT and f_sorted <= 0.5 * f_native
+
+
+def _topology_key(topology):
+    if topology is None or isinstance(topology, (int, str, tuple)):
+        return topology
+    serial = getattr(topology, "serial", None)
+    if serial is not None:
+        return ("topology", int(serial))
+    if isinstance(topology, torch.Tensor):
+        k = (topology.data_ptr(), topology._version, tuple(topology.shape), str(topology.dtype), str(topology.device))
+        fp = _topology_prints.get(k)
+        if fp is None:
+            # content fingerprint (one reduction + sync, once per tensor version): two index lists with the same content share
+            # a decision, two numberings of one mesh do not
+            flat = topology.reshape(-1).to(torch.int64)
+            w = (torch.arange(flat.numel(), device=flat.device, dtype=torch.int64) * 2654435761 + 40503) & 0xFFFFFFFF
+            fp = (int(((flat + 1) * w).sum().item()) & ((1 << 62) - 1), int(flat.numel()))
+            if len(_topology_prints) > 64:
+                _topology_prints.clear()
+            _topology_prints[k] = fp
+        return ("tensor",) + fp
+    raise RuntimeError("topology must be None, a hashable key, a TetTopology or the index tensor")
+
+
+def _moved(now, then):
+    return abs(now - then) > max(0.01, 0.5 * then)
+
+
+def _watch_order(entry, key, tet0):
+    """Position-only callers: now and then measure what is being traversed, asynchronously, and compare with what the decision
+    was made on — the far-step fraction of the caller's numbering, and of the permutation in use if there is one.  Both are
+    properties of the tet LIST (a training step deforms the grid by a fraction of a tet: they move in the third digit), so a
+    value that moved means another list is being handed in under the same sizes: the entry is dropped and decided again."""
+    entry.calls += 1
+    if entry.fractions is None or entry.calls % _WATCH_EVERY or torch.cuda.is_current_stream_capturing():
+        return
+    if entry.mail is not None and entry.event is not None:
+        if not entry.event.query():
+            return                                            # the last measurement has not landed yet: look again next time
+        m = entry.mail.tolist()
+        stale = _moved(_far_fraction(m[0:2]), entry.fractions[0]) or (entry.choice is not None and _moved(_far_fraction(m[2:4]), entry.fractions[1]))
+        if stale:
+            with _order_lock:
+                if _order_cache.get(key) is entry:
+                    del _order_cache[key]
+            return
+    if entry.mail is None:
+        entry.mail = torch.zeros(4, dtype=torch.int32, pin_memory=True)
+        entry.mail[1] = entry.mail[3] = 1
+    tet_order_coherence(tet0, None, out=entry.mail[0:2])
+    if entry.choice is not None:
+        tet_order_coherence(tet0, entry.choice, out=entry.mail[2:4])
+    entry.event = torch.cuda.Event()
+    entry.event.record(torch.cuda.current_stream(tet0.device))
+
+
+def auto_tet_order(tet_bxtx4x3, pts_bxqx3, algo=PIT_AUTO, topology=None):
+    """The cached traversal order for this grid, or None when its own numbering is coherent enough (or the grid is tiny)."""
     import os
     mode = os.environ.get("DEFTET_PIT_ORDER", "auto")
     B, T, dev = tet_bxtx4x3.shape[0], tet_bxtx4x3.shape[1], tet_bxtx4x3.device
@@ -194,39 +323,32 @@ def auto_tet_order(tet_bxtx4x3, pts_bxqx3, algo=PIT_AUTO):
     kernel = int(_lib.load().deftet_point_in_tet_resolve_algo(int(algo), T, Q))
     if kernel not in (PIT_SLAB, PIT_WAVE, PIT_PAIR):
         return None
-    key = (dev.index if dev.index is not None else torch.cuda.current_device(), T, kernel)
+    tkey = _topology_key(topology)
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), T, kernel, tkey)
     with _order_lock:
-        if key in _order_cache:
-            return _order_cache[key][0]
-    if torch.cuda.is_current_stream_capturing():                     # no timing inside a graph capture: decide at an eager call
+        entry = _order_cache.get(key)
+    if entry is not None:
+        if tkey is None:
+            _watch_order(entry, key, tet_bxtx4x3[0])
+        return entry.choice
+    if torch.cuda.is_current_stream_capturing():                     # the decision reads two counters back: not inside a graph capture
         return None
     order = tet_spatial_order(tet_bxtx4x3[0])
     if mode == "force":
-        choice, times = order, None
+        choice, fractions = order, None
     else:
-        def run(o, n):
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            best = float("inf")
-            for i in range(n + 1):                                     # (the first run of each candidate is a warm-up)
-                a.record()
-                point_in_tet(tet_bxtx4x3, pts_bxqx3, algo=algo, order=o)
-                b.record()
-                b.synchronize()
-                if i:
-                    best = min(best, a.elapsed_time(b))
-            return best
-        t_native, t_sorted = run(None, 3), run(order, 3)
-        choice = order if t_sorted < 0.92 * t_native else None         # the caller's numbering unless the other is clearly faster
-        times = (t_native, t_sorted)
+        fractions = (_far_fraction(tet_order_coherence(tet_bxtx4x3[0]).tolist()), _far_fraction(tet_order_coherence(tet_bxtx4x3[0], order).tolist()))
+        choice = order if _decide_order(*fractions) else None
     with _order_lock:
-        _order_cache[key] = (choice, times)
+        _order_cache[key] = _OrderEntry(choice, fractions)
     return choice
 
 
 def tet_order_decisions():
-    """{(device, n_tet, kernel id): (chosen "sorted" | "native", (ms native, ms sorted) | None)} — what auto_tet_order decided."""
+    """{(device, n_tet, kernel id, topology key): (chosen "sorted" | "native", (far fraction of the caller's numbering, of the
+    computed order) | None)} — what auto_tet_order decided."""
     with _order_lock:
-        return {k: ("native" if v[0] is None else "sorted", v[1]) for k, v in _order_cache.items()}
+        return {k: ("native" if v.choice is None else "sorted", v.fractions) for k, v in _order_cache.items()}
 
 
 def clear_tet_order_cache():
@@ -234,14 +356,40 @@ def clear_tet_order_cache():
         _order_cache.clear()
 
 
+# Permutations handed in by the caller are checked ONCE per tensor (version): a duplicate silently skips tets, an entry outside
+# [0, T) indexes the tet array and the hit records out of bounds.  The orders this module computes are
+# permutations by construction (a stable sort of 0..T-1) and are registered without the check.
+_orders_checked = {}
+
+
+def _order_id(order, T):
+    return (order.data_ptr(), order._version, int(T), str(order.device))
+
+
+def _check_order(order, T):
+    k = _order_id(order, T)
+    if k in _orders_checked:
+        return
+    if torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("order: a permutation must be validated by an eager call before it is used inside a graph capture")
+    o = order.to(torch.int64)
+    ok = T == 0 or (int(o.min()) >= 0 and int(o.max()) < T and bool((torch.bincount(o, minlength=T) == 1).all()))
+    if not ok:
+        raise RuntimeError("order must be a permutation of 0..T-1 (duplicates would skip tets, entries outside the range index out of bounds)")
+    if len(_orders_checked) > 256:
+        _orders_checked.clear()
+    _orders_checked[k] = True
+
+
 def point_in_tet(tet_bxtx4x3, pts_bxqx3, want_bary=False, algo=PIT_AUTO, pred_bxt=None, want_hits=False, prepared=None, order=None,
-                 query_box=None, query_box_misses=None):
+                 query_box=None, query_box_misses=None, topology=None):
     """cond f32 [B,Q,1] (lowest containing tet index or -1); with want_bary also the barycentric
     weights f32 [B,Q,4] of the hit tet; with pred_bxt also occ f32 [B,Q] = the fused
     DefTet.paste_occ gather pred[b, max(index, 0)].  Returns cond | (cond, bary) | (cond, bary, occ)
     | (cond, occ) depending on what was asked for; want_hits appends the opaque int32 hit-record
     buffer that makes point_in_tet_bwd atomic-free.  order: None (the caller's tet numbering), an int32 [T] permutation from
-    tet_spatial_order, or "auto" (auto_tet_order: decided once per grid size and device); never changes a result.
+    tet_spatial_order (checked once per tensor), or "auto" (auto_tet_order: decided once per grid from the numbering's coherence; `topology` identifies the tet list — a
+    TetTopology, any hashable key or the index tensor; None = keyed by the sizes and re-checked now and then); never changes a result.
     query_box: None (the grid spans the measured box of this call's queries), a float32 [B,6] hint (lo xyz, hi xyz: e.g. the
     sampler's box) or "track" (the box the previous call with these sizes measured, with a fall-back to measuring when the
     queries stop fitting it); never changes a result either.  query_box_misses: with a [B,6] hint, an int32 [>= B] tensor
@@ -267,11 +415,12 @@ def point_in_tet(tet_bxtx4x3, pts_bxqx3, want_bary=False, algo=PIT_AUTO, pred_bx
     if isinstance(order, str):
         if order != "auto":
             raise RuntimeError("order must be None, 'auto' or an int32 [T] permutation")
-        order = auto_tet_order(tet, pts, algo) if algo in (PIT_AUTO, PIT_SLAB, PIT_WAVE, PIT_PAIR) else None
+        order = auto_tet_order(tet, pts, algo, topology) if algo in (PIT_AUTO, PIT_SLAB, PIT_WAVE, PIT_PAIR) else None
     if order is not None:
         _lib.require_gpu(order)
         if order.dtype != torch.int32 or order.shape != (T,) or not order.is_contiguous() or order.device != dev:
             raise RuntimeError("order must be a contiguous int32 [T] tensor on the tets' device")
+        _check_order(order, T)
     with torch.cuda.device(dev):
         if prepared is not None:
             if prepared.consumed or prepared.algo != algo or prepared.n_tet != T or prepared.pts.data_ptr() != pts.data_ptr() \

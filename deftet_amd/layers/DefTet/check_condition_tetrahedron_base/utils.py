@@ -18,19 +18,23 @@ from deftet_amd import hip_ops
 
 class TriRender2D(Function):
     @staticmethod
-    def forward(ctx, tet_bxfx4x3, point_pos_bxnx3):
+    def forward(ctx, tet_bxfx4x3, point_pos_bxnx3, topology=None):
         # the reference also builds an (unused) [B,T,6] bbox tensor here (utils.py:47);
         # the kernel never read it (check_condition_tet_for.cu:154-164), so it is dropped.
-        # order="auto": the traversal order is decided once per grid (static topology); query_box="track": the query grid spans the
-        # box the previous call measured (one launch fewer); neither ever changes the result
-        return hip_ops.point_in_tet(tet_bxfx4x3, point_pos_bxnx3, order="auto", query_box="track")
+        # order="auto": the traversal order is decided once per grid (static topology) from how coherently the list is numbered;
+        # query_box="track": the query grid spans the box the previous call measured (one launch fewer); neither ever changes
+        # the result.  topology (not in the reference's signature, optional): what identifies the tet list — see hip_ops.auto_tet_order
+        return hip_ops.point_in_tet(tet_bxfx4x3, point_pos_bxnx3, order="auto", query_box="track", topology=topology)
 
     @staticmethod
     def backward(ctx, condition_bxnx1):
-        return None, None
+        return None, None, None
 
 
-check_condition_f_base = TriRender2D.apply
+def check_condition_f_base(tet_bxfx4x3, point_pos_bxnx3, topology=None):
+    """condition_bxnx1 (utils.py:38-62).  `topology` is optional and build-defined: a TetTopology / hashable key / index tensor
+    that identifies the tet list, so that the traversal-order decision is cached per topology instead of per size."""
+    return TriRender2D.apply(tet_bxfx4x3, point_pos_bxnx3, topology)
 
 
 class PointInTetBary(Function):

@@ -45,7 +45,10 @@ class TetTopology:
     """Per-topology cache for the vertex<->tet gather: the incidence CSR is built once (the tet
     list is static during training, train_multigpu.py:72-77) and reused by every backward."""
 
+    _serials = __import__("itertools").count(1)
+
     def __init__(self, tet_idx, n_vertex):
+        self.serial = next(TetTopology._serials)              # identifies the tet LIST: hip_ops.auto_tet_order keys its decision on it
         idx = tet_idx.long()
         # The reference hands every shape of a batch the SAME tet list (`tet_fx4.unsqueeze(0).expand(B, -1, -1)`,
         # train_multigpu.py:72-77): keep one copy then — the gather reads 8 MB of indices instead of 66 MB at res 70, B = 8,
@@ -213,7 +216,9 @@ class DefTet(nn.Module):
         center_occ = center_occ.squeeze(-1)
         if inference:
             assert point_pos_bxpx3 is not None, 'point_pos_bxpx3 not given'
-            condition = check_condition_f_base(tet_bxfx4x3, point_pos_bxpx3)
+            # (the traversal order of the query is decided per TOPOLOGY when the index list is at hand; positions only otherwise)
+            topo = _topology_for(tetrahedron_bxfx4, vertice_pos.shape[1]) if tetrahedron_bxfx4 is not None else None
+            condition = check_condition_f_base(tet_bxfx4x3, point_pos_bxpx3, topo)
             pred_surface_face = self.get_boundary_index(face_fx3, face_tet_fx2, (pred_occ > inference_threshold).float())
             return (amips_energy, edge, volume_variance, sum_analytic, sum_normal, center_occ, condition, boundary,
                     pred_surface_face, sum_chamfer)

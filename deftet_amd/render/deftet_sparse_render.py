@@ -65,12 +65,43 @@ class _SparseRender(Function):
         return None, None, None, gxy, gff, None, None, None
 
 
+_warned_saturation = False
+_default_calls = 0
+
+
+def saturated_pixels(pixel_coords, render_ranges, face_vertices_z, face_vertices_image, face_features, knum, eps=1e-8):
+    """Number of pixels that MORE than knum faces cover (where NEAREST and FIRST record different faces): one extra forward with
+    knum + 1 slots.  Diagnostic (bench.py reports it for BASELINE configs[4]); synchronises."""
+    with torch.no_grad():
+        _, face = _SparseRender.apply(pixel_coords, render_ranges, face_vertices_z, face_vertices_image, face_features,
+                                      int(knum) + 1, float(eps), NEAREST)
+    return int((face[..., int(knum)] >= 0).sum().item())
+
+
 def deftet_sparse_render(pixel_coords, render_ranges, face_vertices_z, face_vertices_image, face_features,
-                         knum=300, eps=1e-8, policy=NEAREST):
+                         knum=300, eps=1e-8, policy=None):
     """(pixel_coords [B,P,2], render_ranges [B,P,2] (min,max depth), face_vertices_z [B,F,3],
     face_vertices_image [B,F,3,2], face_features [B,F,3,D]) ->
     (features [B,P,knum,D] sorted nearest-first, face_idx int64 [B,P,knum], -1 = empty).
-    policy: which covering faces a pixel with more than knum of them records — NEAREST (default: the knum nearest) or
-    FIRST (the first knum in face order); the same result whenever no pixel saturates, as at the reference's call site."""
-    return _SparseRender.apply(pixel_coords, render_ranges, face_vertices_z, face_vertices_image, face_features,
-                               int(knum), float(eps), int(policy))
+    policy: which covering faces a pixel with more than knum of them records — NEAREST (the knum nearest) or FIRST (the first knum
+    in face order).  They give the same result whenever no pixel saturates, as at the reference's call site (knum = 300 against
+    ~60 covering faces, deftetrneder.py:97-100); which one Kaolin implements is NOT known here (parity unpinned), so a caller
+    whose knum can saturate should say which it wants: with policy=None the call renders NEAREST and — on its first call and
+    every 256th after it, one small reduction + synchronisation — warns ONCE when pixels came back with all knum slots in use."""
+    global _warned_saturation, _default_calls
+    explicit = policy is not None
+    out = _SparseRender.apply(pixel_coords, render_ranges, face_vertices_z, face_vertices_image, face_features,
+                              int(knum), float(eps), int(policy) if explicit else NEAREST)
+    if not explicit and not _warned_saturation:
+        _default_calls += 1
+        if _default_calls % 256 == 1 and not torch.cuda.is_current_stream_capturing():
+            full = int((out[1][..., int(knum) - 1] >= 0).sum().item()) if knum > 0 and out[1].numel() else 0
+            if full:
+                import warnings
+                _warned_saturation = True
+                warnings.warn("deftet_sparse_render: %d pixels recorded knum=%d faces; if more faces than that cover them the saturation "
+                              "policy decides which are kept (NEAREST here, the default; FIRST is the other candidate) and Kaolin's own "
+                              "behaviour is not pinned in this build — pass policy=NEAREST or policy=FIRST explicitly "
+                              "(deftet_amd.render.deftet_sparse_render.saturated_pixels counts the pixels that really differ)"
+                              % (full, int(knum)), RuntimeWarning, stacklevel=2)
+    return out

@@ -109,6 +109,14 @@ int deftet_point_in_tet_scan_f32(const float *tet, const float *pts, float *cond
 size_t deftet_tet_spatial_order_workspace_bytes(int n_tet);
 int deftet_tet_spatial_order_f32(const float *tet, int n_tet, int32_t *order, int32_t *breaks,
                                  void *workspace, size_t workspace_bytes, void *stream);
+
+/* How coherent a numbering is for the traversal (round 6; what hip_ops.auto_tet_order decides on, no stopwatch):
+ * out2[0] = steps inside groups of 64 consecutive tets of `order` (int32 [T] on the device, or NULL = the caller's own
+ * numbering) where the next tet's centroid lies more than three mean box extents from the one before, out2[1] = steps looked
+ * at.  out2 receives two plain 4-byte stores and may be host-mapped memory.  tet: f32 [T,4,3] of ONE shape. */
+size_t deftet_tet_order_coherence_workspace_bytes(int n_tet);
+int deftet_tet_order_coherence_f32(const float *tet, int n_tet, const int32_t *order, int32_t *out2,
+                                   void *workspace, size_t workspace_bytes, void *stream);
 /* Query box (no reference counterpart either).  The binned algorithms span their cell grid over the box of the call's regular
  * queries, which a first launch measures.  query_box_in (f32 [B,6] = lo xyz, hi xyz on the device, or NULL) replaces the
  * measurement: the grid spans that box, enlarged by 1/32 per side, and the launch is not made.  It is a HINT, never a promise:

@@ -93,7 +93,7 @@ def test_tracked_query_boxes_fall_back_to_measuring_when_queries_miss_the_box():
         return hip_ops._tracked_boxes(dev, B, Q)
 
     def state():
-        return hip_ops.query_box_trackers()[(0, B, Q)]
+        return hip_ops.query_box_trackers()[hip_ops.query_box_key(dev, B, Q)]
 
     assert call()[0] is None                                     # first call measures
     box_in, _, miss = call()

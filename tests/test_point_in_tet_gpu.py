@@ -1,4 +1,6 @@
 """GPU parity tests for A1 / A1b: HIP path (through the C ABI) vs the CPU oracle."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -595,9 +597,9 @@ def test_shuffled_tets_configs2_size_bit_exact_vs_brute(cuda):
     native, srt = breaks.tolist()
     assert native > 4 * srt
     hip_ops.clear_tet_order_cache()
-    assert hip_ops.auto_tet_order(t, p) is not None                    # the measured choice takes the computed order here
-    (choice, times), = hip_ops.tet_order_decisions().values()
-    assert choice == "sorted" and times[1] < times[0]
+    assert hip_ops.auto_tet_order(t, p) is not None                    # the coherence rule takes the computed order here
+    (choice, fractions), = hip_ops.tet_order_decisions().values()
+    assert choice == "sorted" and fractions[0] > 0.9 and fractions[1] < 0.05   # far steps: the caller's list, the computed order
     gw = torch.randn(2, 100_000, 4, device=cuda, generator=torch.Generator(device=cuda).manual_seed(0))
     for algo in (hip_ops.PIT_PAIR, hip_ops.PIT_WAVE, hip_ops.PIT_SLAB):
         ref = None
@@ -609,6 +611,94 @@ def test_shuffled_tets_configs2_size_bit_exact_vs_brute(cuda):
                 ref = (w, g)
             assert torch.equal(w, ref[0]) and torch.equal(g, ref[1])   # recorded hits are summed in ascending query order
     hip_ops.clear_tet_order_cache()
+
+
+def test_auto_order_is_decided_per_topology_from_coherence(cuda):
+    """order="auto" (round 6): a deterministic rule on the numbering's coherence (far steps inside 64-tet groups), cached per
+    TOPOLOGY — two meshes with the same number of tets and different numberings get different decisions, whichever comes first;
+    the shipped QuarTet grid (76 % column changes, yet neighbours all the way) keeps its own numbering; results never change."""
+    from deftet_amd import grids, hip_ops
+    tet, pts, _, _ = grids.make_case(40, 20_000, 2)
+    rng = np.random.default_rng(5)
+    perm = rng.permutation(tet.shape[1])
+    t_coh, t_shuf = torch.from_numpy(tet).to(cuda), torch.from_numpy(np.ascontiguousarray(tet[:, perm])).to(cuda)
+    p = torch.from_numpy(pts).to(cuda)
+    idx_coh = torch.arange(tet.shape[1] * 4, device=cuda).reshape(-1, 4)            # stand-ins for the two index lists
+    idx_shuf = idx_coh[torch.from_numpy(perm).to(cuda)].contiguous()
+    far_coh, far_shuf = hip_ops.tet_order_coherence(t_coh[0]).tolist(), hip_ops.tet_order_coherence(t_shuf[0]).tolist()
+    assert far_coh[1] == far_shuf[1] == tet.shape[1] - (tet.shape[1] + 63) // 64
+    assert far_coh[0] < 0.05 * far_coh[1] and far_shuf[0] > 0.9 * far_shuf[1]
+    srt = hip_ops.tet_spatial_order(t_shuf[0])
+    assert hip_ops.tet_order_coherence(t_shuf[0], srt).tolist()[0] < 0.05 * far_shuf[1]
+    brute = {"coh": hip_ops.point_in_tet(t_coh, p, algo=hip_ops.PIT_BRUTE), "shuf": hip_ops.point_in_tet(t_shuf, p, algo=hip_ops.PIT_BRUTE)}
+    for first in ("coh", "shuf"):
+        hip_ops.clear_tet_order_cache()
+        for name in ((first, "shuf" if first == "coh" else "coh") * 2):
+            tt, topo = (t_coh, idx_coh) if name == "coh" else (t_shuf, idx_shuf)
+            got = hip_ops.point_in_tet(tt, p, order="auto", topology=topo)
+            assert torch.equal(got, brute[name]), (first, name)
+        dec = hip_ops.tet_order_decisions()
+        assert sorted(v[0] for v in dec.values()) == ["native", "sorted"], dec          # same T, same kernel: two entries, two decisions
+        for (_, _, _, tk), (choice, fr) in dec.items():
+            assert tk[0] == "tensor" and (choice == "sorted") == (fr[0] > 0.5)
+    # a TetTopology-like object (serial) and a plain hashable key work as well
+    hip_ops.clear_tet_order_cache()
+
+    class Topo:
+        serial = 12345
+    assert hip_ops.auto_tet_order(t_shuf, p, topology=Topo()) is not None and hip_ops.auto_tet_order(t_coh, p, topology="kuhn40") is None
+    # the shipped QuarTet grid: its numbering changes column at three steps out of four and is still the one to traverse
+    g40 = np.load(os.path.join(os.path.dirname(__file__), "golden", "cube40_grid.npz"))
+    q40 = torch.from_numpy(np.ascontiguousarray(g40["verts"].astype(np.float32)[g40["tets"]])[None]).to(cuda)
+    _, breaks = hip_ops.tet_spatial_order(q40[0], want_breaks=True)
+    far = hip_ops.tet_order_coherence(q40[0]).tolist()
+    assert breaks.tolist()[0] > 0.5 * far[1] and far[0] < 0.10 * far[1], (breaks.tolist(), far)
+    assert hip_ops.auto_tet_order(q40, p[:1], topology="cube40") is None
+    hip_ops.clear_tet_order_cache()
+
+
+def test_auto_order_without_a_topology_notices_another_mesh(cuda):
+    """Callers with positions only (check_condition_f_base's reference signature): the decision is keyed by the sizes and WATCHED —
+    a second mesh with the same number of tets and another numbering is noticed within a few watch periods and decided again;
+    every call along the way returns the brute-force answer."""
+    from deftet_amd import grids, hip_ops
+    tet, pts, _, _ = grids.make_case(40, 20_000, 1)
+    perm = np.random.default_rng(6).permutation(tet.shape[1])
+    t_coh, t_shuf = torch.from_numpy(tet).to(cuda), torch.from_numpy(np.ascontiguousarray(tet[:, perm])).to(cuda)
+    p = torch.from_numpy(pts).to(cuda)
+    brute = {id(t_coh): hip_ops.point_in_tet(t_coh, p, algo=hip_ops.PIT_BRUTE), id(t_shuf): hip_ops.point_in_tet(t_shuf, p, algo=hip_ops.PIT_BRUTE)}
+    hip_ops.clear_tet_order_cache()
+
+    def decision():
+        (choice, _), = hip_ops.tet_order_decisions().values()
+        return choice
+
+    for tt, want in ((t_coh, "native"), (t_shuf, "sorted"), (t_coh, "native")):
+        for i in range(4 * hip_ops._WATCH_EVERY + 2):
+            got = hip_ops.point_in_tet(tt, p, order="auto")
+            if i % 50 == 0:
+                assert torch.equal(got, brute[id(tt)])
+                torch.cuda.synchronize()
+        assert decision() == want, (want, hip_ops.tet_order_decisions())
+    hip_ops.clear_tet_order_cache()
+
+
+def test_order_argument_must_be_a_permutation(cuda):
+    """A caller's `order` is validated once per tensor: duplicates would skip tets, entries outside [0, T) index the
+    tet array and the hit records out of bounds."""
+    from deftet_amd import grids, hip_ops
+    tet, pts, _, _ = grids.make_case(8, 500, 1)
+    t, p = torch.from_numpy(tet).to(cuda), torch.from_numpy(pts).to(cuda)
+    T = tet.shape[1]
+    good = torch.from_numpy(np.random.default_rng(0).permutation(T).astype(np.int32)).to(cuda)
+    assert torch.equal(hip_ops.point_in_tet(t, p, order=good), hip_ops.point_in_tet(t, p))
+    for bad in (good.clone().index_fill_(0, torch.tensor([3], device=cuda), int(good[4])),      # a duplicate
+                good.clone().index_fill_(0, torch.tensor([0], device=cuda), T),                 # past the end
+                good.clone().index_fill_(0, torch.tensor([T - 1], device=cuda), -1)):           # negative
+        with pytest.raises(RuntimeError, match="permutation"):
+            hip_ops.point_in_tet(t, p, order=bad)
+    good[0], good[1] = int(good[1]), int(good[0])                       # modified in place: checked again, still a permutation
+    assert torch.equal(hip_ops.point_in_tet(t, p, order=good), hip_ops.point_in_tet(t, p))
 
 
 def test_wave_kernel_clamped_footprints_and_degenerate_axis(cuda, oracle):
@@ -726,7 +816,7 @@ def test_query_box_tracking_backs_off_when_the_queries_stop_fitting(cuda):
     near = torch.from_numpy((0.5 * (rng.random((2, 3000, 3)) - 0.5)).astype(np.float32)).to(cuda)
     wide = torch.from_numpy((1.05 * (rng.random((2, 3000, 3)) - 0.5)).astype(np.float32)).to(cuda)
     refs = [hip_ops.point_in_tet(t, q, algo=hip_ops.PIT_BRUTE) for q in (near, wide)]
-    key = (cuda.index if cuda.index is not None else torch.cuda.current_device(), 2, 3000)
+    key = hip_ops.query_box_key(cuda, 2, 3000)
     for i in range(40):
         got = hip_ops.point_in_tet(t, (near, wide)[i % 2], query_box="track")
         assert torch.equal(got, refs[i % 2]), i
@@ -798,8 +888,7 @@ def test_step_captured_in_a_hipgraph_replays_on_new_inputs(cuda):
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph):
         out = step(st, order="auto", query_box="track")
-    key = (cuda.index if cuda.index is not None else torch.cuda.current_device(), B, Q)
-    assert key not in hip_ops.query_box_trackers()                   # the capture measured its box: nothing was allocated for tracking
+    assert not any(k[0] == (cuda.index or 0) and k[2:] == (B, Q) for k in hip_ops.query_box_trackers())                   # the capture measured its box: nothing was allocated for tracking
     for i in (1, 2, 0, 2):
         for k in st:
             st[k].copy_(sets[i][k])
@@ -809,12 +898,15 @@ def test_step_captured_in_a_hipgraph_replays_on_new_inputs(cuda):
         assert torch.equal(out[0], hip_ops.point_in_tet(sets[i]["tet"], sets[i]["pts"], algo=hip_ops.PIT_BRUTE)), i
         for name, a, b in zip(("cond", "w", "occ", "loss", "grad_tet", "grad_pred"), out, want):
             assert torch.equal(a.view(torch.int32), b.view(torch.int32)), (i, name)
-    # ... and with a tracker that already exists the captured step reads / writes its two boxes
+    # ... and with a tracker that already exists a captured step still measures its own box and leaves the tracker alone (round 6:
+    # a tracked triple baked into a graph would never alternate its buffers nor ever fall back to measuring)
     for i in range(3):
         step(sets[i], order="auto", query_box="track")
+    before = hip_ops.query_box_trackers()
     graph2 = torch.cuda.CUDAGraph()
     with torch.cuda.graph(graph2):
         out2 = step(st, order="auto", query_box="track")
+    assert hip_ops.query_box_trackers() == before
     for i in (2, 1):
         for k in st:
             st[k].copy_(sets[i][k])

@@ -289,3 +289,36 @@ def test_baseline_config_properties(cuda):
     z = torch.where(vs, z, torch.full_like(z, -1e30))
     assert (z[:, 1:] <= z[:, :-1]).all()
     assert (z[vs] <= 0).all() and (z[vs] >= -1000).all()
+
+
+def test_default_policy_warns_once_when_pixels_fill_up(cuda):
+    """policy=None (round 6): the call renders NEAREST and says ONCE that pixels came back full — which faces a saturated pixel keeps
+    is the one thing Kaolin's absence leaves open; an explicit policy never warns; saturated_pixels counts where the two differ."""
+    import warnings
+    from deftet_amd import grids, hip_ops
+    from deftet_amd.render import deftet_sparse_render as mod
+    from deftet_amd.render.deftet_sparse_render import deftet_sparse_render, saturated_pixels, NEAREST, FIRST
+    verts, tets = grids.kuhn_grid(8)
+    f3 = hip_ops.tet_to_face(tets, verts.shape[0], cuda, with_boundary=True)[0].cpu().numpy()
+    fz, fxy, ff = grids.project_faces(verts, f3, seed=0)
+    pix, rngs = grids.pixel_grid(32)
+    t = [torch.from_numpy(x).to(cuda) for x in (pix, rngs, fz, fxy, ff)]
+    k = 4                                                            # far fewer slots than covering faces
+    mod._warned_saturation, mod._default_calls = False, 0
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        a = deftet_sparse_render(*t, knum=k)
+        b = deftet_sparse_render(*t, knum=k)
+        c = deftet_sparse_render(*t, knum=k, policy=NEAREST)
+        d = deftet_sparse_render(*t, knum=k, policy=FIRST)
+    msgs = [w for w in rec if "saturation" in str(w.message)]
+    assert len(msgs) == 1 and "policy=" in str(msgs[0].message)
+    assert torch.equal(a[1], c[1]) and torch.equal(b[1], c[1])     # the default IS NEAREST
+    n_sat = saturated_pixels(*t, knum=k)
+    differ = int((c[1] != d[1]).any(-1).sum())
+    assert 0 < differ <= n_sat <= int((c[1][..., k - 1] >= 0).sum())
+    mod._warned_saturation, mod._default_calls = False, 0
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        deftet_sparse_render(*t, knum=4000)                          # never fills up: silent
+    assert not [w for w in rec if "saturation" in str(w.message)]
