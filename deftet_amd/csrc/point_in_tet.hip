@@ -499,6 +499,7 @@ __global__ __launch_bounds__(256) void k_slab_local(const float *__restrict__ pt
 #pragma unroll
         for (int k = 0; k < 3; ++k) { gp[k] = g.o[k]; gp[3 + k] = g.inv[k]; gp[6 + k] = g.lo[k]; gp[9 + k] = g.hi[k]; gp[12 + k] = g.pe[k]; gp[15 + k] = g.cs[k]; }
         gp[18] = __int_as_float(wide_cells(g, Q, G, Gx));
+        gp[19] = HINT ? 1.0f : 0.f;                                  // k_finalize: with a measured box every regular query is binned (no test needed)
     }
     for (int i = tid; i <= R1; i += 256) hist[i] = 0;
     __syncthreads();
@@ -2320,6 +2321,16 @@ __global__ __launch_bounds__(kWvThreads, PIT_WAVES_PAIR) void k_tet_scan_pair(PI
 #undef PIT_SCAN_PARAMS
 #undef PIT_SCAN_FWD
 
+// QPT queries per thread (round 6 experiment; 1 is what ships).  A query's work is two memory round trips in a row — its winner,
+// then the winner's 48-byte record and prediction — so two or more chains per thread, every gather issued before the first is
+// used, looked like free memory-level parallelism.  Measured inside the configs[2] step (tools/probes/sort_probe.py, two runs
+// each): QPT 1 / 2 / 3 / 4 = 25.1-25.8 / 26.8-27.5 / 28.6 / 29.8-30.0 us — the kernel is bound by how fast the texture path
+// takes 64 scattered 16-byte requests per instruction, not by how many are in flight; more per thread only adds registers.
+// Query j of the thread is (chunk * QPT + j) * 256 + tid, so every access stays coalesced per j.
+#ifndef PIT_FIN_QPT
+#define PIT_FIN_QPT 1
+#endif
+template <int QPT>
 __global__ __launch_bounds__(256) void k_finalize(const float *__restrict__ tet, const float *__restrict__ pts, int T,
                                                   int Q, const int *__restrict__ result, float *cond, float *bary,
                                                   const float *__restrict__ pred, float *occ, const int4 *__restrict__ hits,
@@ -2329,89 +2340,114 @@ __global__ __launch_bounds__(256) void k_finalize(const float *__restrict__ tet,
     __shared__ int s_cnt[4], s_base;
     const int2 sb = shape_block(pin);                                  // shape-per-XCD placement
     const int b = sb.x;
-    const int q = sb.y * blockDim.x + threadIdx.x;
-    const bool live = q < Q;                                        // (no early return: the append below has barriers)
-    const size_t i = (size_t)b * Q + (live ? q : 0);
-    int r = live ? result[i] : kMiss;
+    int q[QPT], r[QPT];
+    bool live[QPT];                                                 // (no early return: the append below has barriers)
+    size_t i[QPT];
+    float px[QPT], py[QPT], pz[QPT];
+#pragma unroll
+    for (int j = 0; j < QPT; ++j) {
+        q[j] = (sb.y * QPT + j) * (int)blockDim.x + (int)threadIdx.x;
+        live[j] = q[j] < Q;
+        i[j] = (size_t)b * Q + (live[j] ? q[j] : 0);
+        r[j] = live[j] ? result[i[j]] : kMiss;
+    }
+#pragma unroll
+    for (int j = 0; j < QPT; ++j) {
+        const float *p = pts + i[j] * 3;
+        px[j] = p[0]; py[j] = p[1]; pz[j] = p[2];
+    }
     // irregular tets (not certified for the grid filter; normally none) are tested here against
     // every query: query-centric, so no atomics and no extra launch
     const int nIrregT = counters ? counters[b * 4 + 0] : 0;
-    if (nIrregT > 0 && live) {
-        const float *p = pts + i * 3;
-        const float x = p[0], y = p[1], z = p[2];
+    if (nIrregT > 0) {
         for (int k = 0; k < nIrregT; ++k) {
             const int t = irregT[(size_t)b * T + k];
             float v[12];
             const float *src = tet + ((size_t)b * T + t) * 12;
 #pragma unroll
-            for (int j = 0; j < 12; ++j) v[j] = src[j];
+            for (int jj = 0; jj < 12; ++jj) v[jj] = src[jj];
             Planes P;
             make_planes(v, P);
-            if (accept(P, x, y, z)) r = min(r, t);
+#pragma unroll
+            for (int j = 0; j < QPT; ++j)
+                if (live[j] && accept(P, px[j], py[j], pz[j])) r[j] = min(r[j], t);
         }
     }
-    const bool hit = r != kMiss;
-    if (live) {
-        stream_store(cond + i, hit ? (float)r : -1.0f);             // :177, :149
-        if (occ) stream_store(occ + i, pred[(size_t)b * T + (hit ? r : 0)]);   // paste_occ: misses alias tet 0 (deftet.py:133-135)
+    // every gather of the thread leaves here, before anything waits for one of them
+    bool hit[QPT];
+    float4 t0[QPT], t1[QPT], t2[QPT];
+    float pr[QPT];
+#pragma unroll
+    for (int j = 0; j < QPT; ++j) {
+        hit[j] = r[j] != kMiss;
+        const float4 *src = reinterpret_cast<const float4 *>(tet + ((size_t)b * T + (hit[j] ? r[j] : 0)) * 12);
+        if (bary && hit[j]) { t0[j] = src[0]; t1[j] = src[1]; t2[j] = src[2]; }
+        pr[j] = (occ && live[j]) ? pred[(size_t)b * T + (hit[j] ? r[j] : 0)] : 0.f;    // paste_occ: misses alias tet 0 (deftet.py:133-135)
     }
-    bool uncovered = false;
-    if (hits && hit) {
-        // is this hit in its tet's record?  (not if the tet overflowed / is irregular, or if the
-        // query took the irregular-query side path, which records nothing)
-        const float *pq = pts + i * 3;
-        // records are complete unless some tet is irregular or overflowed (wave-uniform test: the
-        // per-hit gather of the record is skipped for ordinary meshes)
-        // (a query the grid did not bin — NaN / Inf / huge, or outside the box the grid was given — took the side path, which
-        // records nothing; with the box measured from the queries themselves the second test is true for every regular query)
-        bool covered = query_regular(pq[0], pq[1], pq[2]);
-        if (gparam) covered = covered && query_binned(pq[0], pq[1], pq[2], load_grid(gparam + b * kGridWords));
-        const bool sidePath = !covered;
-        if (counters) {
-            const int nB = gridDim.y, nOvf = counters[nB * 4 + b * 4 + 2];
-            if (counters[b * 4 + 0] > 0 || nOvf > kOvfCap) {
-                // irregular tets exist, or more overflowed tets than the list holds: read the winning tet's record
-                covered = covered && hits[(size_t)b * T + r].w != kHitOverflow;
-            } else {
-                // the usual case: a handful of overflowed tets per shape, listed; wave-uniform scalar reads, no gather
-                const int *ovf = counters + nB * 8 + b * kOvfCap;
-                for (int k = 0; k < nOvf; ++k) covered = covered && ovf[k] != r;
+#pragma unroll
+    for (int j = 0; j < QPT; ++j) {
+        if (live[j]) {
+            stream_store(cond + i[j], hit[j] ? (float)r[j] : -1.0f);  // :177, :149
+            if (occ) stream_store(occ + i[j], pr[j]);
+        }
+        bool uncovered = false;
+        if (hits && hit[j]) {
+            // is this hit in its tet's record?  (not if the tet overflowed / is irregular, or if the
+            // query took the irregular-query side path, which records nothing)
+            // records are complete unless some tet is irregular or overflowed (wave-uniform test: the
+            // per-hit gather of the record is skipped for ordinary meshes)
+            // (a query the grid did not bin — NaN / Inf / huge, or outside the box the grid was given — took the side path, which
+            // records nothing; with the box measured from the queries themselves the second test is true for every regular query:
+            // gparam[19] says whether the grid came from a hint)
+            bool covered = query_regular(px[j], py[j], pz[j]);
+            if (gparam && gparam[b * kGridWords + 19] != 0.f) covered = covered && query_binned(px[j], py[j], pz[j], load_grid(gparam + b * kGridWords));
+            const bool sidePath = !covered;
+            if (counters) {
+                const int nB = gridDim.y, nOvf = counters[nB * 4 + b * 4 + 2];
+                if (counters[b * 4 + 0] > 0 || nOvf > kOvfCap) {
+                    // irregular tets exist, or more overflowed tets than the list holds: read the winning tet's record
+                    covered = covered && hits[(size_t)b * T + r[j]].w != kHitOverflow;
+                } else {
+                    // the usual case: a handful of overflowed tets per shape, listed; wave-uniform scalar reads, no gather
+                    const int *ovf = counters + nB * 8 + b * kOvfCap;
+                    for (int k = 0; k < nOvf; ++k) covered = covered && ovf[k] != r[j];
+                }
+            }
+            if (!covered) {
+                uncovered = true;
+                if (sidePath) ucount[2 * hpad + b] = 1;              // its tet's record may be complete: every lane must look
             }
         }
-        if (!covered) {
-            uncovered = true;
-            if (sidePath) ucount[2 * hpad + b] = 1;                  // its tet's record may be complete: every lane must look
+        if (hits) {
+            // Append the uncovered hits of this workgroup with ONE atomic: the counter is a single address per shape, and
+            // same-address atomics serialise at the memory side (~50 ns each) — where many tets overflow their four-slot
+            // record (configs[1]: one query per tet on average, ~650 uncovered hits per shape) one atomic per hit made this
+            // kernel 50 us instead of 25.
+            const unsigned long long m = __ballot(uncovered);
+            const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+            if (j > 0) __syncthreads();                              // s_cnt / s_base of the previous query row are done with
+            if (lane == 0) s_cnt[wave] = __popcll(m);
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const int tot = (s_cnt[0] + s_cnt[1]) + (s_cnt[2] + s_cnt[3]);
+                s_base = tot > 0 ? atomicAdd(&ucount[b], tot) : 0;
+            }
+            __syncthreads();
+            if (uncovered) {
+                int off = s_base + __popcll(m & ((1ull << lane) - 1ull));
+                for (int w = 0; w < wave; ++w) off += s_cnt[w];
+                ulist[(size_t)b * Q + off] = q[j];
+            }
         }
     }
-    if (hits) {
-        // Append the uncovered hits of this workgroup with ONE atomic: the counter is a single address per shape, and
-        // same-address atomics serialise at the memory side (~50 ns each) — where many tets overflow their four-slot
-        // record (configs[1]: one query per tet on average, ~650 uncovered hits per shape) one atomic per hit made this
-        // kernel 50 us instead of 25.
-        const unsigned long long m = __ballot(uncovered);
-        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-        if (lane == 0) s_cnt[wave] = __popcll(m);
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const int tot = (s_cnt[0] + s_cnt[1]) + (s_cnt[2] + s_cnt[3]);
-            s_base = tot > 0 ? atomicAdd(&ucount[b], tot) : 0;
-        }
-        __syncthreads();
-        if (uncovered) {
-            int off = s_base + __popcll(m & ((1ull << lane) - 1ull));
-            for (int w = 0; w < wave; ++w) off += s_cnt[w];
-            ulist[(size_t)b * Q + off] = q;
-        }
+    if (!bary) return;
+#pragma unroll
+    for (int j = 0; j < QPT; ++j) {
+        if (!live[j]) continue;
+        float4 wq = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (hit[j]) wq = bary_weights(t0[j], t1[j], t2[j], px[j], py[j], pz[j]);
+        stream_store(reinterpret_cast<float4 *>(bary) + i[j], wq);
     }
-    if (!bary || !live) return;
-    float4 wq = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (hit) {
-        const float4 *src = reinterpret_cast<const float4 *>(tet + ((size_t)b * T + r) * 12);
-        const float4 t0 = src[0], t1 = src[1], t2 = src[2];
-        const float *pp = pts + i * 3;
-        wq = bary_weights(t0, t1, t2, pp[0], pp[1], pp[2]);
-    }
-    stream_store(reinterpret_cast<float4 *>(bary) + i, wq);
 }
 
 // ------------------------------------------------------------------------------------
@@ -3189,7 +3225,7 @@ static int pit_scan(const Layout &L, const float *tet, const float *pts, float *
                     int32_t *hit_buf, int B, int T, int Q, int algo, hipStream_t st, const int32_t *order = nullptr)
 {
     const dim3 blk(256);
-    const dim3 gq((Q + 255) / 256, B), gt((((T + 255) / 256 + 7) / 8) * 8, B);   // gt: multiple of 8 for the XCD mapping
+    const dim3 gf((Q + 256 * PIT_FIN_QPT - 1) / (256 * PIT_FIN_QPT), B), gt((((T + 255) / 256 + 7) / 8) * 8, B);   // gt: multiple of 8 for the XCD mapping
     int *ucount = hit_buf ? hit_buf + hit_cnt_off(B, T) : nullptr;
     if (T > 0) {
         if (algo == DEFTET_PIT_EXACT) {
@@ -3219,7 +3255,7 @@ static int pit_scan(const Layout &L, const float *tet, const float *pts, float *
     } else if (ucount) {
         DEFTET_HIP(hipMemsetAsync(ucount, 0, (size_t)3 * hit_pad(B) * 4, st));
     }
-    DEFTET_LAUNCH(k_finalize, gq, blk, st, tet, pts, T, Q, L.result, cond, bary, pred, occ, (const int4 *)hit_buf, ucount,
+    DEFTET_LAUNCH(k_finalize<PIT_FIN_QPT>, gf, blk, st, tet, pts, T, Q, L.result, cond, bary, pred, occ, (const int4 *)hit_buf, ucount,
                   hit_buf ? hit_buf + hit_list_off(B, T) : nullptr, L.counters, L.irregT, hit_pad(B), pin_shapes(Q), (const float *)L.gparam);
     return DEFTET_OK;
 }
@@ -3240,7 +3276,7 @@ static int pit_forward(const float *tet, const float *pts, float *cond, float *b
             DEFTET_LAUNCH(k_prep_records, dim3((unsigned)((n + 255) / 256)), blk, st, tet, n, L.rec);
         }
         DEFTET_LAUNCH(k_brute, gq, blk, st, L.rec, pts, T, Q, L.result);
-        DEFTET_LAUNCH(k_finalize, gq, blk, st, tet, pts, T, Q, L.result, cond, bary, pred, occ, (const int4 *)nullptr, (int *)nullptr,
+        DEFTET_LAUNCH(k_finalize<PIT_FIN_QPT>, dim3((Q + 256 * PIT_FIN_QPT - 1) / (256 * PIT_FIN_QPT), B), blk, st, tet, pts, T, Q, L.result, cond, bary, pred, occ, (const int4 *)nullptr, (int *)nullptr,
                       (int *)nullptr, (const int *)nullptr, L.irregT, 0, pin_shapes(Q), (const float *)nullptr);
         return DEFTET_OK;
     }
