@@ -147,13 +147,33 @@ __global__ __launch_bounds__(64) void k_pix_grid(const float *__restrict__ part,
 // face classification + tile range.  A face is "regular" iff its six coordinates are finite and
 // <= 2^20, |k3| >= 2^-7 * w^2 (w = largest box extent) and |k3| >= 2^10 * eps: then every pixel
 // the fp32 test can accept lies within w/64 of the face's box (same argument as DESIGN.md A1).
-struct FaceBox { int tx0, tx1, ty0, ty1, mode; };   // mode 0: skip, 1: tiles, 2: wide
+// SLIVER faces (round 6).  A face whose area is small against its extent — |k3| < kTau w^2, an edge-on triangle — used to go to
+// the "wide" list with the truly degenerate ones, and every wave tested every wide face against its 64 pixels: at BASELINE
+// configs[4] one diagonal plane family of the res-70 grid passes within a degree of the camera, 846 of 521,850 faces are such
+// slivers, and 4,096 waves x 846 faces = 3.5 M broadcast tests stood beside the 1.6 M of all tile lists together
+// (profiles/r06_raster_probes.jsonl).  They are not unbounded: with u = 2^-24, W >= every edge component, K1, K2, K3 the exact
+// values of the contract's expressions on the rounded edges and (s, t) = fl(p - a):
+//     (s, t) = alpha (m, pp) + beta (n, q),  alpha = K1 / K3, beta = K2 / K3                          (Cramer)
+//     k_i = K_i + e_i, |e_1|, |e_2| <= 3.01 u W (|s| + |t|), |e_3| <= 6.02 u W^2, den = fl(k3 + eps), |eps| <= |k3| / 1024
+//     covered  =>  k1/den, k2/den >= -2^-150  and  k1/den + k2/den <= 1 + 2.1 u          (correctly rounded /, fl(fl(1 - w1) - w2) >= 0)
+// and |k3| >= 2^-16 w^2 gives rho = 6.02 u W^2 / |k3| <= 0.0236, den / K3 = 1 + theta with |theta| <= 0.0252, and, with
+// S = |alpha| + |beta| and |s| + |t| <= 2 W S:  S <= 1.0252 (1 + 2.2 u) + 2 (rho / (1 - rho)) S  =>  S <= 1.078,
+// alpha, beta >= -0.026, alpha + beta <= 1.078.  So (alpha, beta) lies within L1 distance 0.182 of the triangle's own
+// parameter simplex, i.e. p lies within 0.182 W (1 + 2u) of the face's box along each axis: the box enlarged by kSliverMargin = 1/4
+// of its extent holds every pixel the contract can accept (measured on 400 random slivers x 400,000 pixels along their lines, numpy
+// fp32: at most 0.002 w outside).  The enlarged box must survive its own rounding, so a sliver also needs
+// w >= 2^-16 max|coordinate| (then u |coordinate| <= 2^-8 w).  Such faces stay on the wide list — their boxes span dozens of tiles
+// — but the list now carries a certified box per face (regular faces that are wide by SPAN have theirs too) and a wave skips the
+// faces whose box misses its pixels' box: one scalar 16-byte load and four compares instead of the whole test.
+constexpr float kTauSliver = 1.0f / 65536.0f;      // 2^-16
+constexpr float kSliverMargin = 0.25f;
+struct FaceBox { int tx0, tx1, ty0, ty1, mode; float elx, ehx, ely, ehy; };   // mode 0: skip, 1: tiles, 2: wide; e*: certified box (+-inf: none)
 
 __device__ __forceinline__ FaceBox face_box(const float *__restrict__ xy, int f, const Grid2 &g, float eps)
 {
     const float2 a = reinterpret_cast<const float2 *>(xy)[f * 3], b = reinterpret_cast<const float2 *>(xy)[f * 3 + 1],
                  c = reinterpret_cast<const float2 *>(xy)[f * 3 + 2];
-    FaceBox r{0, 0, 0, 0, 2};
+    FaceBox r{0, 0, 0, 0, 2, -INFINITY, INFINITY, -INFINITY, INFINITY};
     const bool finite = fabsf(a.x) <= kBig && fabsf(a.y) <= kBig && fabsf(b.x) <= kBig && fabsf(b.y) <= kBig &&
                         fabsf(c.x) <= kBig && fabsf(c.y) <= kBig;
     const float m = b.x - a.x, pp = b.y - a.y, n = c.x - a.x, q = c.y - a.y;
@@ -162,13 +182,23 @@ __device__ __forceinline__ FaceBox face_box(const float *__restrict__ xy, int f,
     const float loy = fminf(a.y, fminf(b.y, c.y)), hiy = fmaxf(a.y, fmaxf(b.y, c.y));
     const float w = fmaxf(hix - lox, hiy - loy);
     const bool regular = finite && fabsf(k3) >= kTau * (w * w) && fabsf(k3) >= 1024.0f * fabsf(eps) && w > 0.f;
-    if (!regular) return r;
+    if (!regular) {
+        const float cmax = fmaxf(fmaxf(fabsf(lox), fabsf(hix)), fmaxf(fabsf(loy), fabsf(hiy)));
+        const bool sliver = finite && fabsf(k3) >= kTauSliver * (w * w) && fabsf(k3) >= 1024.0f * fabsf(eps) && w > 0.f && w >= kTauSliver * cmax;
+        if (sliver) {
+            const float mg = w * kSliverMargin;
+            r.elx = lox - mg; r.ehx = hix + mg; r.ely = loy - mg; r.ehy = hiy + mg;
+            if (r.ehx < g.lox || r.elx > g.hix || r.ehy < g.loy || r.ely > g.hiy) r.mode = 0;       // no tame pixel can be covered
+        }
+        return r;
+    }
     const float mg = w * kMargin;
     const float elx = lox - mg, ehx = hix + mg, ely = loy - mg, ehy = hiy + mg;
     if (ehx < g.lox || elx > g.hix || ehy < g.loy || ely > g.hiy) { r.mode = 0; return r; }
     r.tx0 = cell_of(elx, g.ox, g.ix, g.gx); r.tx1 = cell_of(ehx, g.ox, g.ix, g.gx);
     r.ty0 = cell_of(ely, g.oy, g.iy, g.gy); r.ty1 = cell_of(ehy, g.oy, g.iy, g.gy);
     r.mode = ((r.tx1 - r.tx0 + 1) * (r.ty1 - r.ty0 + 1) <= kMaxTiles) ? 1 : 2;
+    r.elx = elx; r.ehx = ehx; r.ely = ely; r.ehy = ehy;
     return r;
 }
 
@@ -215,14 +245,17 @@ __global__ __launch_bounds__(256) void k_face_span(const float *__restrict__ xy,
 __global__ __launch_bounds__(256) void k_face_pairs(const float *__restrict__ xy, int F, const Grid2 *__restrict__ gp, float eps,
                                                     const int *__restrict__ pairOff, const int *__restrict__ wideOff,
                                                     unsigned *key, unsigned *val, int *wide, int *nWide, long long cap,
-                                                    const unsigned *__restrict__ perm)
+                                                    const unsigned *__restrict__ perm, float4 *wideBox)
 {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < F) {
         const int f = perm ? (int)perm[i] : (int)i;                  // pairs come out in binning order: the stable sort by tile keeps it
         const Grid2 g = *gp;
         const FaceBox fb = face_box(xy, f, g, eps);
-        if (fb.mode == 2) wide[wideOff[i]] = f;
+        if (fb.mode == 2) {
+            wide[wideOff[i]] = f;
+            wideBox[wideOff[i]] = make_float4(fb.elx, fb.ehx, fb.ely, fb.ehy);      // certified box of the face, or the whole plane
+        }
         if (fb.mode == 1) {
             int o = pairOff[i];
             for (int ty = fb.ty0; ty <= fb.ty1; ++ty)
@@ -300,8 +333,16 @@ struct Hit { int f; float z, w1, w2; };
 #ifdef RAST_STATS        // probe builds only: where k_pix_raster spends its time under the NEAREST policy
 __device__ unsigned long long g_rast_stats[8];
 #define RAST_STAT(i, v) do { const unsigned long long v_ = (unsigned long long)(v); if (lane == 0) atomicAdd(&g_rast_stats[i], v_); } while (0)
+#define RAST_STAT_MAX(i, v) do { const unsigned long long v_ = (unsigned long long)(v); if (lane == 0) atomicMax(&g_rast_stats[i], v_); } while (0)
 #else
 #define RAST_STAT(i, v)
+#define RAST_STAT_MAX(i, v)
+#endif
+#ifndef RAST_ILP
+#define RAST_ILP 2                 // faces evaluated per trip of the face loop before they are committed in list order
+#endif
+#ifndef RAST_PROBE_NOSTORE
+#define RAST_PROBE_NOSTORE 0      // probe builds only (wrong results): the hit-record store of the NEAREST face loop left out
 #endif
 constexpr int kPendDepth = 4;          // admitted hits a full lane queues before the wave works the queues off (NEAREST)
 
@@ -335,6 +376,7 @@ __device__ __noinline__ Worst rast_work_off(const int4 (*pend)[64], int npend, W
         }
         if (go) out[w.at] = rec;
         unsigned long long need = __ballot(go);
+        RAST_STAT(5, __popcll(need));                                   // [5] records replaced
         // The new worst of a lane that replaced: the WAVE reads that lane's knum records (lane i reads record i: one
         // coalesced request instead of knum dependent ones from a single lane), the record just replaced comes from
         // registers, and a butterfly finds the worst.
@@ -373,7 +415,7 @@ __global__ __launch_bounds__(256) void k_pix_raster(const float *__restrict__ pi
                                                     const int *__restrict__ nWide, int F, int knum, float eps, int4 *hits,
                                                     int *nhit, const unsigned *__restrict__ pixOrder,
                                                     const int *__restrict__ pixStart, const int *__restrict__ chunkStart,
-                                                    const unsigned *__restrict__ zAbsMax)
+                                                    const unsigned *__restrict__ zAbsMax, const float4 *__restrict__ wideBox)
 {
     const int lane = threadIdx.x & 63;
     const int W = blockIdx.x * 4 + (threadIdx.x >> 6);              // chunk id (wave-uniform)
@@ -383,6 +425,10 @@ __global__ __launch_bounds__(256) void k_pix_raster(const float *__restrict__ pi
         const int mid = (lo + hi) >> 1;
         if (chunkStart[mid] <= W) lo = mid; else hi = mid;
     }
+#ifdef RAST_STATS
+    const unsigned long long tStart = __builtin_amdgcn_s_memtime();
+    int nBroadcast = 0;
+#endif
     const int tile = lo;
     const int slot = pixStart[tile] + (W - chunkStart[tile]) * 64 + lane;
     const bool live = slot < pixStart[tile + 1];
@@ -411,31 +457,46 @@ __global__ __launch_bounds__(256) void k_pix_raster(const float *__restrict__ pi
         worstZ = w.z; worstF = w.f; worstAt = w.at;
         npend = 0;
     };
-    auto test = [&](int f, float ax, float ay, float m, float pp, float n, float q, float den, float az, float bz, float cz) __attribute__((always_inline)) {
-        if (!nearest && nh >= knum) return;
+    // One (face, pixel) test in two halves: `eval` is pure arithmetic (the contract's operations, nothing else), `commit` records
+    // the hit.  The face loop below evaluates RAST_ILP faces per trip before it commits them in list order: a wave's trip is one
+    // long dependent chain (eleven lane reads, two IEEE division sequences of ten dependent instructions each, five compares),
+    // there are only four waves per SIMD to interleave (4,096 chunks on 1,024 SIMDs), and by the counters the vector ALU was
+    // "busy" 0.9 k cycles per trip for ~60 instructions — waiting for its own results (round 6: profiles/r06_raster_probes.jsonl;
+    // the hit-record stores, suspected first, are not it: without them the kernel takes 0.87 instead of 0.89 ms).
+    struct Ev { float z, w1, w2; bool ok; };
+    auto eval = [&](float ax, float ay, float m, float pp, float n, float q, float den, float az, float bz, float cz) __attribute__((always_inline)) {
         const float s_ = px - ax, t = py - ay;
         const float k1 = s_ * q - n * t, k2 = m * t - s_ * pp;
-        const float w1 = k1 / den, w2 = k2 / den, w0 = 1 - w1 - w2;
+        Ev e;
+        e.w1 = k1 / den; e.w2 = k2 / den;
+        const float w0 = 1 - e.w1 - e.w2;
+        e.z = (w0 * az + e.w1 * bz) + e.w2 * cz;
+        e.ok = (w0 >= 0 && e.w1 >= 0 && e.w2 >= 0) && (e.z >= zmin && e.z <= zmax);
+        return e;
+    };
+    auto commit = [&](int f, const Ev &e) __attribute__((always_inline)) {
         if (!nearest) {                                               // FIRST: the round-2 body, nothing else
-            if (!(w0 >= 0 && w1 >= 0 && w2 >= 0)) return;
-            const float z = (w0 * az + w1 * bz) + w2 * cz;
-            if (!(z >= zmin && z <= zmax)) return;
-            out[nh] = make_int4(f, __float_as_int(z), __float_as_int(w1), __float_as_int(w2));
-            ++nh;
+            if (e.ok && nh < knum) {
+                out[nh] = make_int4(f, __float_as_int(e.z), __float_as_int(e.w1), __float_as_int(e.w2));
+                ++nh;
+            }
             return;
         }
-        const float z = (w0 * az + w1 * bz) + w2 * cz;
         // (the two counters advance OUTSIDE the branches: written as ++nh / ++npend inside them the compiler merges the two
         // increments into one store through a selected address, which puts both counters into scratch memory — a scratch
         // load, a dependent scratch store and another load with s_waitcnt vmcnt(0) in every iteration of the face loop)
         int dnh = 0, dnp = 0;
-        if ((w0 >= 0 && w1 >= 0 && w2 >= 0) && (z >= zmin && z <= zmax)) {
-            const int4 rec = make_int4(f, __float_as_int(z), __float_as_int(w1), __float_as_int(w2));
+        if (e.ok) {
+            const int4 rec = make_int4(f, __float_as_int(e.z), __float_as_int(e.w1), __float_as_int(e.w2));
             if (nh < knum) {
+#if RAST_PROBE_NOSTORE == 0
                 out[nh] = rec;
-                if (nh == 0 || worse(z, f, worstZ, worstF)) { worstZ = z; worstF = f; worstAt = nh; }
+#elif RAST_PROBE_NOSTORE == 2
+                if (nh == 1000000) out[nh] = rec;                     // timing probe: the store stays in the code, never executes
+#endif
+                if (nh == 0 || worse(e.z, f, worstZ, worstF)) { worstZ = e.z; worstF = f; worstAt = nh; }
                 dnh = 1;
-            } else if (live && knum > 0 && worse(worstZ, worstF, z, f)) {   // full (dead lanes only count as full)
+            } else if (live && knum > 0 && worse(worstZ, worstF, e.z, f)) {   // full (dead lanes only count as full)
                 pend[npend][lane] = rec;
                 dnp = 1;
             }
@@ -443,6 +504,10 @@ __global__ __launch_bounds__(256) void k_pix_raster(const float *__restrict__ pi
         nh += dnh;
         npend += dnp;
         if (nearest && __any(npend == kPendDepth)) work_off();
+    };
+    auto test = [&](int f, float ax, float ay, float m, float pp, float n, float q, float den, float az, float bz, float cz) __attribute__((always_inline)) {
+        if (!nearest && nh >= knum) return;
+        commit(f, eval(ax, ay, m, pp, n, q, den, az, bz, cz));
     };
     auto face_terms = [&](float2 a, float2 b, float2 c, float &m, float &pp, float &n, float &q, float &den) {
         m = b.x - a.x; pp = b.y - a.y; n = c.x - a.x; q = c.y - a.y;
@@ -453,18 +518,6 @@ __global__ __launch_bounds__(256) void k_pix_raster(const float *__restrict__ pi
     const int ib = allFaces ? 0 : tileStart[tile], ie = allFaces ? F : tileStart[tile + 1];
     int j = 0;
     const int je = allFaces ? 0 : *nWide;
-    auto wide_before = [&](int fLimit) __attribute__((always_inline)) {                            // wide faces with index < fLimit (normally none)
-        while (j < je) {
-            const int f = wide[j];
-            if (f >= fLimit) break;
-            const float2 a = reinterpret_cast<const float2 *>(fxy)[f * 3], b = reinterpret_cast<const float2 *>(fxy)[f * 3 + 1],
-                         c = reinterpret_cast<const float2 *>(fxy)[f * 3 + 2];
-            float m, pp, n, q, den;
-            face_terms(a, b, c, m, pp, n, q, den);
-            test(f, a.x, a.y, m, pp, n, q, den, fz[f * 3], fz[f * 3 + 1], fz[f * 3 + 2]);
-            ++j;
-        }
-    };
     // image-space box of this wave's pixels: a listed (regular) face whose enlarged box misses it
     // cannot be accepted by any lane (the certified-box argument of face_box) and is skipped
     float cxl = live ? px : INFINITY, cxh = live ? px : -INFINITY, cyl = live ? py : INFINITY, cyh = live ? py : -INFINITY;
@@ -473,6 +526,22 @@ __global__ __launch_bounds__(256) void k_pix_raster(const float *__restrict__ pi
         cxl = fminf(cxl, __shfl_xor(cxl, off)); cxh = fmaxf(cxh, __shfl_xor(cxh, off));
         cyl = fminf(cyl, __shfl_xor(cyl, off)); cyh = fmaxf(cyh, __shfl_xor(cyh, off));
     }
+    auto wide_before = [&](int fLimit) __attribute__((always_inline)) {                            // wide faces with index < fLimit (normally none)
+        while (j < je) {
+            const int f = wide[j];
+            if (f >= fLimit) break;
+            // (certified box of the face, see face_box: none of this wave's pixels inside => nothing to test; wave-uniform)
+            const float4 wb = wideBox[j];
+            if (wb.y < cxl || wb.x > cxh || wb.w < cyl || wb.z > cyh) { ++j; continue; }
+            const float2 a = reinterpret_cast<const float2 *>(fxy)[f * 3], b = reinterpret_cast<const float2 *>(fxy)[f * 3 + 1],
+                         c = reinterpret_cast<const float2 *>(fxy)[f * 3 + 2];
+            float m, pp, n, q, den;
+            face_terms(a, b, c, m, pp, n, q, den);
+            test(f, a.x, a.y, m, pp, n, q, den, fz[f * 3], fz[f * 3 + 1], fz[f * 3 + 2]);
+            ++j;
+            RAST_STAT(4, 1);                                            // [4] wide faces tested (per wave)
+        }
+    };
     // Software pipeline over the list, 64 entries per stage: while batch k is tested, the face data of batch k+1 (whose
     // list entries arrived during batch k-1) and the list entries of batch k+2 are in flight — the two dependent round
     // trips per batch were exposed with only ~4.5 waves per SIMD.
@@ -537,23 +606,46 @@ __global__ __launch_bounds__(256) void k_pix_raster(const float *__restrict__ pi
         unsigned long long todo = __ballot(cand);
         RAST_STAT(1, 1);                                                // [1] batches of 64 entries
         RAST_STAT(2, __popcll(todo));                                   // [2] faces broadcast
+#ifdef RAST_STATS
+        nBroadcast += __popcll(todo);
+#endif
         int since = 0;
         while (todo) {
-            const int k = __ffsll((long long)todo) - 1;
-            todo &= todo - 1;
-            const int f = __builtin_amdgcn_readlane(fm, k);
-            if (je > 0 && !nearest) wide_before(f);                   // FIRST: wide faces merged in face order
-            test(f, bcast(a.x, k), bcast(a.y, k), bcast(fm_, k), bcast(fpp, k), bcast(fn, k), bcast(fq, k), bcast(fden, k), bcast(az, k),
-                 bcast(bz, k), bcast(cz, k));
-            if (!nearest && (++since & 7) == 0 && __all(nh >= knum)) break;
+            int kk[RAST_ILP], ff[RAST_ILP];
+            Ev ev[RAST_ILP];
+            bool have[RAST_ILP];
+#pragma unroll
+            for (int u = 0; u < RAST_ILP; ++u) {                      // (past the end of the batch: the last face again, not committed)
+                have[u] = todo != 0ull;
+                kk[u] = have[u] ? __ffsll((long long)todo) - 1 : kk[u > 0 ? u - 1 : 0];
+                todo &= todo - 1;
+                ff[u] = __builtin_amdgcn_readlane(fm, kk[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < RAST_ILP; ++u)
+                ev[u] = eval(bcast(a.x, kk[u]), bcast(a.y, kk[u]), bcast(fm_, kk[u]), bcast(fpp, kk[u]), bcast(fn, kk[u]), bcast(fq, kk[u]),
+                             bcast(fden, kk[u]), bcast(az, kk[u]), bcast(bz, kk[u]), bcast(cz, kk[u]));
+            bool stop = false;
+#pragma unroll
+            for (int u = 0; u < RAST_ILP; ++u) {
+                if (!have[u] || stop) continue;                       // (wave-uniform)
+                if (je > 0 && !nearest) wide_before(ff[u]);           // FIRST: wide faces merged in face order
+                commit(ff[u], ev[u]);
+                if (!nearest && (++since & 7) == 0 && __all(nh >= knum)) stop = true;
+            }
+            if (stop) break;
         }
         fmCur = fmNext; cur = nxt; fmNext = fmAfter;
     }
     if (je > 0) wide_before(0x7FFFFFFF);
     if (nearest) work_off();
     RAST_STAT(0, 1);                                                    // [0] wave-chunks
+#ifdef RAST_STATS
+    RAST_STAT_MAX(6, nBroadcast);                                       // [6] most faces broadcast by one wave
+    RAST_STAT_MAX(7, __builtin_amdgcn_s_memtime() - tStart);            // [7] longest wave, shader cycles
+#endif
     RAST_STAT(3, __popcll(__ballot(live)));                             // [3] live lanes
-    if (live) nhit[p] = nh;
+    if (live) nhit[p] = (nearest && RAST_PROBE_NOSTORE) ? 0 : nh;      // (probe builds wrote no records: nothing for k_pix_emit to read)
 }
 
 // one wave per pixel: rank by (z descending, face ascending), write the sorted outputs
@@ -833,6 +925,7 @@ struct Layout {
     int *pixStart, *chunkCount, *chunkStart;
     long long cap;
     int4 *hits;
+    float4 *wideBox;
     void *tmp;
     size_t tmpBytes;
 };
@@ -848,6 +941,7 @@ static Layout make_layout(int P, int F, int knum, void *ws, size_t wsb)
     L.tileStart = A.take<int>((size_t)L.nTiles + 2);
     L.nWide = A.take<int>(4);
     L.wide = A.take<int>((size_t)F + 1);
+    L.wideBox = A.take<float4>((size_t)F + 1);
     L.span = A.take<int>((size_t)F + 1);
     L.isWide = A.take<int>((size_t)F + 1);
     L.pairOff = A.take<int>((size_t)F + 1);
@@ -944,7 +1038,7 @@ extern "C" int deftet_sparse_render_fwd_policy_f32(const float *pix, const float
             RAST_TRY((prims::scan<int, prims::Plus, true>(L.span, L.pairOff, (size_t)F + 1, 0, prims::Plus(), L.tmp, L.tmpBytes, st)));
             RAST_TRY((prims::scan<int, prims::Plus, true>(L.isWide, L.wideOff, (size_t)F + 1, 0, prims::Plus(), L.tmp, L.tmpBytes, st)));
             DEFTET_LAUNCH(k_face_pairs, dim3((unsigned)((L.cap + 255) / 256)), dim3(256), st, xb, F, L.grid, eps, L.pairOff, L.wideOff, L.pkey,
-                          L.pval, L.wide, L.nWide, L.cap, perm);
+                          L.pval, L.wide, L.nWide, L.cap, perm, L.wideBox);
             // stable sort of the (tile, face) pairs by tile — of the pairs really produced (pairOff[F], known on the device
             // only): the workgroups beyond that count find nothing to do (rounds 1-2 sorted the whole F * 16 capacity)
             RAST_TRY((prims::radix_sort<unsigned, unsigned>(L.pkey, L.skey, L.pval, L.list, (size_t)L.cap, 19, L.tmp, L.tmpBytes, st,
@@ -966,11 +1060,11 @@ extern "C" int deftet_sparse_render_fwd_policy_f32(const float *pix, const float
             if (nearest)
                 DEFTET_LAUNCH(k_pix_raster<true>, dim3((unsigned)((maxChunks + 3) / 4)), dim3(256), st, pb, rb, zb, xb, P, L.nTiles, L.tileStart,
                               (const int *)L.list, L.wide, L.nWide, F, knum, eps, L.hits, L.nhit, (const unsigned *)L.pixOrder,
-                              (const int *)L.pixStart, (const int *)L.chunkStart, (const unsigned *)L.zAbsMax);
+                              (const int *)L.pixStart, (const int *)L.chunkStart, (const unsigned *)L.zAbsMax, (const float4 *)L.wideBox);
             else
                 DEFTET_LAUNCH(k_pix_raster<false>, dim3((unsigned)((maxChunks + 3) / 4)), dim3(256), st, pb, rb, zb, xb, P, L.nTiles, L.tileStart,
                               (const int *)L.list, L.wide, L.nWide, F, knum, eps, L.hits, L.nhit, (const unsigned *)L.pixOrder,
-                              (const int *)L.pixStart, (const int *)L.chunkStart, (const unsigned *)L.zAbsMax);
+                              (const int *)L.pixStart, (const int *)L.chunkStart, (const unsigned *)L.zAbsMax, (const float4 *)L.wideBox);
         }
         DEFTET_LAUNCH(k_pix_emit, dim3((P + 3) / 4), dim3(256), st, L.hits, L.nhit, fb, P, D, knum,
                       out_feat + (size_t)b * P * knum * D, (long long *)out_face + (size_t)b * P * knum,

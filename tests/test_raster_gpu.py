@@ -296,7 +296,8 @@ def test_default_policy_warns_once_when_pixels_fill_up(cuda):
     is the one thing Kaolin's absence leaves open; an explicit policy never warns; saturated_pixels counts where the two differ."""
     import warnings
     from deftet_amd import grids, hip_ops
-    from deftet_amd.render import deftet_sparse_render as mod
+    import importlib
+    mod = importlib.import_module("deftet_amd.render.deftet_sparse_render")   # (the package exports the FUNCTION under the same name)
     from deftet_amd.render.deftet_sparse_render import deftet_sparse_render, saturated_pixels, NEAREST, FIRST
     verts, tets = grids.kuhn_grid(8)
     f3 = hip_ops.tet_to_face(tets, verts.shape[0], cuda, with_boundary=True)[0].cpu().numpy()

@@ -16,7 +16,7 @@ from deftet_amd import _lib  # noqa: E402
 from deftet_amd.render import deftet_sparse_render  # noqa: E402
 from tests.test_raster_gpu import pixel_grid, projected_grid  # noqa: E402
 
-NAMES = ["wave_chunks", "batches", "faces_broadcast", "live_lanes", "work_off_calls", "replacements_lanes", "rescan_passes", "-"]
+NAMES = ["wave_chunks", "batches", "faces_broadcast", "live_lanes", "wide_faces_tested", "records_replaced", "max_faces_broadcast_by_a_wave", "longest_wave_cycles"]
 
 
 def main():

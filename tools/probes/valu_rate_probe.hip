@@ -16,6 +16,12 @@ __global__ __launch_bounds__(256) void k_rate(float *out, float seed)
     float a[kChains];
     f32x2 p[kChains];
     const float m = seed * 0.999f, c = seed * 1e-3f;
+    __shared__ float4 s_q[64];
+    float4 q4[2] = {};
+    const unsigned ldsAddr = (unsigned)(size_t)&s_q[(int)seed & 63];
+    if (threadIdx.x < 64) s_q[threadIdx.x] = make_float4(seed, seed, seed, seed);
+    __syncthreads();
+    asm volatile("s_mov_b32 s30, 5" ::: "s30");
 #pragma unroll
     for (int i = 0; i < kChains; ++i) { a[i] = seed + i + threadIdx.x; p[i] = f32x2{a[i], a[i] + 0.5f}; }
     for (int it = 0; it < kIters; ++it) {
@@ -40,11 +46,23 @@ __global__ __launch_bounds__(256) void k_rate(float *out, float seed)
             if (KIND == 16) asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=v"(a[i]) : "v"(m), "v"(c));
             if (KIND == 17) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(a[i]) : "v"(m));
             if (KIND == 18) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(m));
+            // round 6: what the rasterizer's face loop is made of
+            if (KIND == 19) asm volatile("v_readlane_b32 s20, %0, s30" : : "v"(a[i]) : "s20");                       // lane select in an SGPR
+            if (KIND == 20) asm volatile("v_readlane_b32 s20, %1, s30\n\tv_add_f32 %0, s20, %0" : "+v"(a[i]) : "v"(m) : "s20");   // + a VALU reader of the SGPR
+            if (KIND == 21) asm volatile("v_rcp_f32 %0, %0" : "+v"(a[i]));
+            if (KIND == 22) asm volatile("v_div_scale_f32 %0, vcc, %0, %1, %0" : "+v"(a[i]) : "v"(m) : "vcc");
+            if (KIND == 23) asm volatile("v_div_fmas_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(m), "v"(c) : "vcc");
+            if (KIND == 24) asm volatile("v_div_fixup_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(m), "v"(c));
+            if (KIND == 25) asm volatile("v_cmp_le_f32_e64 s[20:21], %0, %1" : : "v"(a[i]), "v"(m) : "s20", "s21");
+            if (KIND == 26) asm volatile("ds_read_b128 %0, %1" : "=v"(q4[i & 1]) : "v"(ldsAddr) : "memory");          // wave-uniform address: LDS broadcast
+            if (KIND == 27) asm volatile("v_readfirstlane_b32 s20, %0" : : "v"(a[i]) : "s20");
+            if (KIND == 28) { a[i] = a[i] / m; }                                                                     // the compiler's IEEE division sequence
         }
     }
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < kChains; ++i) s += a[i] + p[i].x + p[i].y;
+    if (KIND == 26) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); s += q4[0].x + q4[1].y; }
     if (s == 12345.678f) out[0] = s;
 }
 
@@ -97,5 +115,15 @@ int main()
     if (run<15>("v_fmac_f32", out, clk, nCU)) return 1;
     if (run<17>("v_sub_f32", out, clk, nCU)) return 1;
     if (run<18>("v_mul_f32", out, clk, nCU)) return 1;
+    if (run<19>("v_readlane_b32 (sgpr lane)", out, clk, nCU)) return 1;
+    if (run<20>("v_readlane_b32 + v_add_f32 reading it (2 instr)", out, clk, nCU)) return 1;
+    if (run<27>("v_readfirstlane_b32", out, clk, nCU)) return 1;
+    if (run<21>("v_rcp_f32", out, clk, nCU)) return 1;
+    if (run<22>("v_div_scale_f32", out, clk, nCU)) return 1;
+    if (run<23>("v_div_fmas_f32", out, clk, nCU)) return 1;
+    if (run<24>("v_div_fixup_f32", out, clk, nCU)) return 1;
+    if (run<25>("v_cmp_le_f32_e64 (sgpr pair)", out, clk, nCU)) return 1;
+    if (run<26>("ds_read_b128 (uniform address)", out, clk, nCU)) return 1;
+    if (run<28>("a / m (IEEE division sequence)", out, clk, nCU)) return 1;
     return 0;
 }
