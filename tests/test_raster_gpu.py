@@ -323,3 +323,44 @@ def test_default_policy_warns_once_when_pixels_fill_up(cuda):
         warnings.simplefilter("always")
         deftet_sparse_render(*t, knum=4000)                          # never fills up: silent
     assert not [w for w in rec if "saturation" in str(w.message)]
+
+
+def test_sliver_faces_have_certified_boxes(cuda, oracle):
+    """Edge-on faces (area 2^-8 .. 2^-17 of their extent squared) are pruned per pixel chunk by a box enlarged by a quarter of
+    their extent (raster.hip, face_box; round 6).  Pixels are placed where the contract is most likely to accept outside the
+    face's own box — on the faces' lines, beyond their ends, a fraction of their width off — at several coordinate magnitudes;
+    slivers thinner than 2^-16, collinear and tiny ones keep the unbounded path.  Bit-exact against the brute-force oracle."""
+    rng = np.random.default_rng(11)
+    F = 260
+    fxy = np.zeros((1, F, 3, 2), np.float32)
+    lines = []
+    for i in range(F):
+        k = rng.integers(6, 20)                                        # area ratio ~ 2^-k: regular, sliver and degenerate faces
+        off = [0.0, 5.0, 300.0, 20000.0][i % 4]
+        L = rng.uniform(0.05, 40.0) * (1.0 if off < 1e3 else 50.0)
+        th = rng.uniform(0, 2 * np.pi)
+        d, dp = np.array([np.cos(th), np.sin(th)]), np.array([-np.sin(th), np.cos(th)])
+        a = rng.uniform(-1, 1, 2) * off
+        h = L * 2.0 ** (-float(k)) * rng.uniform(0.6, 1.6)
+        fxy[0, i, 0], fxy[0, i, 1], fxy[0, i, 2] = a, a + L * d, a + rng.uniform(0.2, 1.0) * L * d + h * dp
+        lines.append((a, d, dp, L, h))
+    fxy[0, 250] = fxy[0, 3][[0, 0, 2]]                                 # two equal corners
+    fxy[0, 251, 2] = (fxy[0, 251, 0] + fxy[0, 251, 1]) / 2             # collinear
+    fz = rng.uniform(-5, -1, (1, F, 3)).astype(np.float32)
+    ff = rng.random((1, F, 3, 3)).astype(np.float32)
+    pts = []
+    for i in range(F):
+        a, d, dp, L, h = lines[i]
+        lam = rng.uniform(-1.5, 2.5, 24) * L
+        mu = rng.normal(0, 1, 24) * h * rng.choice([0.1, 1.0, 10.0, 100.0], 24)
+        pts.append(a[None] + lam[:, None] * d[None] + mu[:, None] * dp[None])
+        pts.append(fxy[0, i].astype(np.float64))                       # the corners themselves
+    pix = np.concatenate(pts)[None].astype(np.float32)
+    P = pix.shape[1]
+    rngs = np.tile(np.array([-1000.0, 0.0], np.float32), (1, P, 1))
+    for knum, policy in ((6, NEAREST), (6, FIRST), (64, NEAREST)):
+        wf, wface, ww = oracle.sparse_render_fwd(pix, rngs, fz, fxy, ff, knum=knum, policy=policy)
+        feat, face = run(pix, rngs, fz, fxy, ff, knum, cuda, policy=policy)
+        assert np.array_equal(face.cpu().numpy(), wface), (knum, policy)
+        assert np.array_equal(feat.cpu().numpy(), wf, equal_nan=True)
+    assert (wface >= 0).sum() > 2000                                  # the pixels do land on the faces
