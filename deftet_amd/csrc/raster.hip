@@ -339,7 +339,7 @@ __device__ unsigned long long g_rast_stats[8];
 #define RAST_STAT_MAX(i, v)
 #endif
 #ifndef RAST_ILP
-#define RAST_ILP 2                 // faces evaluated per trip of the face loop before they are committed in list order
+#define RAST_ILP 1                 // faces evaluated per trip of the face loop before they are committed in list order (1 / 2 / 4: 352 / 360 / 370 us)
 #endif
 #ifndef RAST_PROBE_NOSTORE
 #define RAST_PROBE_NOSTORE 0      // probe builds only (wrong results): the hit-record store of the NEAREST face loop left out
@@ -516,7 +516,6 @@ __global__ __launch_bounds__(256) void k_pix_raster(const float *__restrict__ pi
     };
     const bool allFaces = tile == nTilesCap;                        // the non-tame pixels: every face, no lists
     const int ib = allFaces ? 0 : tileStart[tile], ie = allFaces ? F : tileStart[tile + 1];
-    int j = 0;
     const int je = allFaces ? 0 : *nWide;
     // image-space box of this wave's pixels: a listed (regular) face whose enlarged box misses it
     // cannot be accepted by any lane (the certified-box argument of face_box) and is skipped
@@ -526,19 +525,34 @@ __global__ __launch_bounds__(256) void k_pix_raster(const float *__restrict__ pi
         cxl = fminf(cxl, __shfl_xor(cxl, off)); cxh = fmaxf(cxh, __shfl_xor(cxh, off));
         cyl = fminf(cyl, __shfl_xor(cyl, off)); cyh = fmaxf(cyh, __shfl_xor(cyh, off));
     }
-    auto wide_before = [&](int fLimit) __attribute__((always_inline)) {                            // wide faces with index < fLimit (normally none)
-        while (j < je) {
-            const int f = wide[j];
-            if (f >= fLimit) break;
-            // (certified box of the face, see face_box: none of this wave's pixels inside => nothing to test; wave-uniform)
-            const float4 wb = wideBox[j];
-            if (wb.y < cxl || wb.x > cxh || wb.w < cyl || wb.z > cyh) { ++j; continue; }
+    // Wide faces: the list is scanned 64 entries at a time — lane l holds the certified box of entry jw + l (face_box; the whole
+    // plane for the truly degenerate ones) and a ballot leaves the entries whose box meets this wave's pixels; only those are
+    // tested, in list order.  (A face that is pruned can be dropped at any time: it records nothing.  One entry per trip through
+    // scalar loads cost a memory latency per entry: 846 entries per wave at configs[4], two of them survivors.)
+    int jw = -64;
+    unsigned long long wmask = 0ull;
+    auto wide_before = [&](int fLimit) __attribute__((always_inline)) {                            // wide faces with index < fLimit
+        for (;;) {
+            while (wmask == 0ull && jw + 64 < je) {
+                jw += 64;
+                const int idx = jw + lane;
+                bool meets = false;
+                if (idx < je) {
+                    const float4 wb = wideBox[idx];
+                    meets = !(wb.y < cxl || wb.x > cxh || wb.w < cyl || wb.z > cyh);
+                }
+                wmask = __ballot(meets);
+            }
+            if (wmask == 0ull) return;
+            const int jj = jw + __ffsll((long long)wmask) - 1;
+            const int f = wide[jj];
+            if (f >= fLimit) return;
+            wmask &= wmask - 1ull;
             const float2 a = reinterpret_cast<const float2 *>(fxy)[f * 3], b = reinterpret_cast<const float2 *>(fxy)[f * 3 + 1],
                          c = reinterpret_cast<const float2 *>(fxy)[f * 3 + 2];
             float m, pp, n, q, den;
             face_terms(a, b, c, m, pp, n, q, den);
             test(f, a.x, a.y, m, pp, n, q, den, fz[f * 3], fz[f * 3 + 1], fz[f * 3 + 2]);
-            ++j;
             RAST_STAT(4, 1);                                            // [4] wide faces tested (per wave)
         }
     };
