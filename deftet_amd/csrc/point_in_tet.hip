@@ -1529,6 +1529,9 @@ constexpr int kWvCapPair = PIT_WVCAP_PAIR, kWvRowsPair = 256;
 #define PIT_STOP 0
 #endif
 #define PIT_KEEP(x) asm volatile("" ::"v"(x))
+#ifndef PIT_PROBE_SKIP
+#define PIT_PROBE_SKIP 0      // probe builds only (wrong results): 1 = no publish atomics, 2 = no hit-record store in k_tet_scan_wave
+#endif
 #ifndef PIT_PROBE_PREFILL
 #define PIT_PROBE_PREFILL 0
 #endif
@@ -2060,8 +2063,9 @@ __device__ __forceinline__ void tet_scan_wave_body(const float *__restrict__ tet
         }
         PHASE_MARK(4);                                                   // [4] row bounds, scan
         // the lane's rows: the slabs [cz0, cz1] of its group's footprint, all of the footprint's y rows
-        const bool mine2 = gid == 1;
-        const int rowOff = mine2 ? rowOff1 : 0, gz = mine2 ? gz0[1] : gz0[0], gs = mine2 ? gsh[1] : gsh[0];
+        // (sel: the SGPR-pair form of the select; written as ?: the compiler emits the VCC form, which gfx950 issues eight times slower)
+        const lanemask_t mine2 = mask_of(gid == 1);
+        const int rowOff = sel(mine2, rowOff1, 0), gz = sel(mine2, gz0[1], gz0[0]), gs = sel(mine2, gsh[1], gsh[0]);
         int rn = rowOff + ((cz0 - gz) << gs);                          // next row to walk
         const int re = rowOff + ((cz1 + 1 - gz) << gs);
         if (!fitsRows) { REASON_COUNT(7, __builtin_amdgcn_ballot_w64(gid >= 0)); gid = -1; }
@@ -2252,7 +2256,7 @@ __device__ __forceinline__ void tet_scan_wave_body(const float *__restrict__ tet
         for (int i = 0; i < kWvSlots; ++i) {                             // publish: one atomic instruction per slot level in use
             if (__builtin_amdgcn_ballot_w64(hc > i) == 0ull) break;
 #if PIT_PROBE_SCATTER == 0
-            if (hc > i) atomic_smin_off_nh(resb, (unsigned)s_hit[k][i][tid] * 4u, te);
+            if (hc > i && !(PIT_PROBE_SKIP & 1)) atomic_smin_off_nh(resb, (unsigned)s_hit[k][i][tid] * 4u, te);   // (PIT_PROBE_SKIP: timing probes)
 #else
             // timing probe only (wrong spill records): what do per-hit scattered output stores cost next to the atomics?
             if (hc > i && spill) {
@@ -2295,7 +2299,7 @@ __device__ __forceinline__ void tet_scan_wave_body(const float *__restrict__ tet
                 h[0] |= kHitSpilled;
             }
             if (over) note_overflow(counters, gridDim.y, b, te);
-            store_rec(hits + (size_t)b * T + te, over ? make_int4(-1, -1, -1, kHitOverflow) : make_int4(h[0], h[1], h[2], h[3]));
+            if (!(PIT_PROBE_SKIP & 2)) store_rec(hits + (size_t)b * T + te, over ? make_int4(-1, -1, -1, kHitOverflow) : make_int4(h[0], h[1], h[2], h[3]));
         }
         irregular_tail(tet, te, b, T, Q, pts, counters, irregQ, result);
     }
