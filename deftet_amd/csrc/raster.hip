@@ -341,6 +341,9 @@ __device__ unsigned long long g_rast_stats[8];
 #ifndef RAST_ILP
 #define RAST_ILP 1                 // faces evaluated per trip of the face loop before they are committed in list order (1 / 2 / 4: 352 / 360 / 370 us)
 #endif
+#ifndef RAST_LDS_BCAST
+#define RAST_LDS_BCAST 1
+#endif
 #ifndef RAST_PROBE_NOSTORE
 #define RAST_PROBE_NOSTORE 0      // probe builds only (wrong results): the hit-record store of the NEAREST face loop left out
 #endif
@@ -448,6 +451,9 @@ __global__ __launch_bounds__(256) void k_pix_raster(const float *__restrict__ pi
     // pending hit in the same pass.  A queued hit is re-tested against the lane's current worst when it is taken out (the
     // threshold only tightens in between).
     __shared__ int4 s_pend[4][kPendDepth][64];
+#if RAST_LDS_BCAST
+    __shared__ float4 s_face[4][64][3];                              // per wave: the batch's faces, 48 bytes each
+#endif
     int4(*pend)[64] = s_pend[threadIdx.x >> 6];
     float worstZ = INFINITY;                                        // the record a better hit would replace
     int worstF = -1, worstAt = 0, npend = 0;
@@ -624,6 +630,37 @@ __global__ __launch_bounds__(256) void k_pix_raster(const float *__restrict__ pi
         nBroadcast += __popcll(todo);
 #endif
         int since = 0;
+#if RAST_LDS_BCAST
+        // The surviving faces are handed to the 64 pixel lanes through LDS: every lane parks the eleven words of ITS face, the
+        // wave reads them back one face at a time with three 16-byte reads at a wave-uniform address (a broadcast: one LDS
+        // cycle each, on the LDS pipe) — the next face's reads are in flight while this one is evaluated.  Eleven v_readlane
+        // per face were 8 cycles of the VECTOR pipe each on this chip (tools/probes/valu_rate_probe.hip), a quarter of a trip.
+        {
+            float4 *mine = &s_face[threadIdx.x >> 6][lane][0];
+            mine[0] = make_float4(a.x, a.y, fm_, fpp);
+            mine[1] = make_float4(fn, fq, fden, az);
+            mine[2] = make_float4(bz, cz, __int_as_float(fm), 0.f);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        auto fetch = [&](int k, float4 &q0, float4 &q1, float4 &q2) __attribute__((always_inline)) {
+            const float4 *src = &s_face[threadIdx.x >> 6][k][0];
+            q0 = src[0]; q1 = src[1]; q2 = src[2];
+        };
+        float4 c0, c1, c2, n0 = {}, n1 = {}, n2 = {};
+        if (todo) fetch(__ffsll((long long)todo) - 1, c0, c1, c2);
+        while (todo) {
+            todo &= todo - 1;
+            if (todo) fetch(__ffsll((long long)todo) - 1, n0, n1, n2);
+            const int f = __float_as_int(c2.z);
+            const Ev e = eval(c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y);
+            if (je > 0 && !nearest) wide_before(f);                   // FIRST: wide faces merged in face order
+            commit(f, e);
+            if (!nearest && (++since & 7) == 0 && __all(nh >= knum)) break;
+            c0 = n0; c1 = n1; c2 = n2;
+        }
+        __builtin_amdgcn_wave_barrier();                               // (the next batch overwrites s_face: DS operations of a wave execute in order)
+#else
         while (todo) {
             int kk[RAST_ILP], ff[RAST_ILP];
             Ev ev[RAST_ILP];
@@ -649,6 +686,7 @@ __global__ __launch_bounds__(256) void k_pix_raster(const float *__restrict__ pi
             }
             if (stop) break;
         }
+#endif
         fmCur = fmNext; cur = nxt; fmNext = fmAfter;
     }
     if (je > 0) wide_before(0x7FFFFFFF);
