@@ -39,7 +39,9 @@ constexpr float kTau = 1.0f / 128.0f;
 constexpr float kMargin = 1.0f / 64.0f;
 
 struct Grid2 { float ox, oy, ix, iy, lox, loy, hix, hiy; int gx, gy; };
-constexpr int kG2Max = 512;            // tiles per axis (upper bound; the actual count is chosen on the device)
+constexpr int kG2Max = 90;             // tiles per axis (upper bound; the actual count is chosen on the device).  90^2 < 2^13: the tile keys of
+                                       // the two sorts below fit 13 (+ 2) bits = two radix passes each (512 per axis, rounds 1-5: 19 / 21 bits = three),
+                                       // and the per-tile tables and the chunk launch shrink from 262 k to 8 k entries.  BASELINE configs[4] picks 32 x 32.
 
 __device__ __forceinline__ int cell_of(float x, float o, float inv, int G)
 {
@@ -205,10 +207,11 @@ __device__ __forceinline__ FaceBox face_box(const float *__restrict__ xy, int f,
 // Tile lists WITHOUT atomics and without a per-tile sort (round-1 history: atomic count + atomic
 // fill + a bitonic sort per tile = 0.58 + 0.59 + 1.71 ms at configs[4]): every face reports how
 // many tiles it overlaps, an exclusive scan turns that into pair offsets, the (tile, face) pairs
-// are written in ascending face order and ONE stable radix sort by tile (prims.hpp, 19 key bits)
+// are written in ascending face order and ONE stable radix sort by tile (prims.hpp, 13 key bits)
 // leaves every tile's faces ascending.  The wide list is a stream compaction (ascending by
 // construction).  Unused pair slots carry the key kPadKey and sort to the end.
-constexpr unsigned kPadKey = 1u << 18;             // > any tile id (kG2Max^2 = 2^18 tiles at most)
+constexpr unsigned kPadKey = 8191u;                // > any tile id (kG2Max^2 = 8,100 tiles at most), 13 bits
+static_assert((unsigned)(kG2Max * kG2Max) <= kPadKey, "the pad key sorts behind every tile");
 
 // NEAREST binning order: faces by descending depth of their nearest corner (zhi = largest corner z; the camera looks
 // down -z), so that every tile list comes out near-first and the walk of k_pix_raster can stop at the first batch that lies
@@ -297,7 +300,7 @@ __global__ __launch_bounds__(256) void k_pix_keys(const float *__restrict__ pix,
     const Grid2 g = *gp;
     const float px = pix[p * 2], py = pix[p * 2 + 1];
     const bool tame = fabsf(px) <= kBig && fabsf(py) <= kBig;
-    unsigned k = kPadKey * 4u;
+    unsigned k = (unsigned)(kG2Max * kG2Max) * 4u;                   // the pseudo-tile nTilesCap of the NaN / Inf / huge pixels
     if (tame) {
         const int tx = cell_of(px, g.ox, g.ix, g.gx), ty = cell_of(py, g.oy, g.iy, g.gy);
         // two more key bits: the quadrant of the tile, so that 64 consecutive pixels form a compact patch
@@ -309,7 +312,7 @@ __global__ __launch_bounds__(256) void k_pix_keys(const float *__restrict__ pix,
 }
 
 // pixStart[t] = first tile-sorted pixel slot whose key is >= t (t in [0, nTilesCap + 1]; the key
-// nTilesCap = kPadKey collects the NaN/Inf/huge pixels), and the number of 64-pixel chunks of tile t
+// nTilesCap = kG2Max^2 collects the NaN/Inf/huge pixels), and the number of 64-pixel chunks of tile t
 __global__ __launch_bounds__(256) void k_pix_chunks(const unsigned *__restrict__ xskey, int P, int nTilesCap, int *pixStart,
                                                     int *chunkCount)
 {
@@ -1093,7 +1096,7 @@ extern "C" int deftet_sparse_render_fwd_policy_f32(const float *pix, const float
                           L.pval, L.wide, L.nWide, L.cap, perm, L.wideBox);
             // stable sort of the (tile, face) pairs by tile — of the pairs really produced (pairOff[F], known on the device
             // only): the workgroups beyond that count find nothing to do (rounds 1-2 sorted the whole F * 16 capacity)
-            RAST_TRY((prims::radix_sort<unsigned, unsigned>(L.pkey, L.skey, L.pval, L.list, (size_t)L.cap, 19, L.tmp, L.tmpBytes, st,
+            RAST_TRY((prims::radix_sort<unsigned, unsigned>(L.pkey, L.skey, L.pval, L.list, (size_t)L.cap, 13, L.tmp, L.tmpBytes, st,
                                                             (const int *)(L.pairOff + F))));
             DEFTET_LAUNCH(k_tile_starts, dim3((L.nTiles + 256) / 256), dim3(256), st, (const unsigned *)L.skey, (const int *)(L.pairOff + F), L.nTiles,
                           L.tileStart);
@@ -1102,7 +1105,7 @@ extern "C" int deftet_sparse_render_fwd_policy_f32(const float *pix, const float
             DEFTET_HIP(hipMemsetAsync(L.nWide, 0, 16, st));
         }
         DEFTET_LAUNCH(k_pix_keys, dim3((P + 255) / 256), dim3(256), st, pb, P, L.grid, L.xkey, L.xval);
-        RAST_TRY((prims::radix_sort<unsigned, unsigned>(L.xkey, L.xskey, L.xval, L.pixOrder, (size_t)P, 21, L.tmp, L.tmpBytes, st)));
+        RAST_TRY((prims::radix_sort<unsigned, unsigned>(L.xkey, L.xskey, L.xval, L.pixOrder, (size_t)P, 15, L.tmp, L.tmpBytes, st)));
         DEFTET_LAUNCH(k_pix_chunks, dim3((L.nTiles + 2 + 255) / 256), dim3(256), st, (const unsigned *)L.xskey, P, L.nTiles, L.pixStart,
                       L.chunkCount);
         RAST_TRY((prims::scan<int, prims::Plus, true>(L.chunkCount, L.chunkStart, (size_t)L.nTiles + 2, 0, prims::Plus(), L.tmp, L.tmpBytes, st)));
