@@ -18,7 +18,7 @@
  *     the rounding level.  The restatement follows the cited kernel text operation by
  *     operation in fp32 with FMA contraction disabled (build with -ffp-contract=off),
  *     and is pinned at the semantic level against the reference's Python
- *     bary_centric_tet (utils/tet_utils.py:28-45) by tests/test_oracle_golden.py.
+ *     bary_centric_tet (utils/tet_utils.py:28-45) by tests/test_cpu_oracle_golden.py.
  *
  * Build: see oracle/Makefile  (gcc -O2 -ffp-contract=off -fopenmp -shared -fPIC).
  */
