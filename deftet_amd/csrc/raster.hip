@@ -712,29 +712,54 @@ __global__ __launch_bounds__(256) void k_pix_emit(const int4 *__restrict__ hits,
                                                   const float *__restrict__ feat, int P, int D, int knum, float *out_feat,
                                                   long long *out_face, float *out_w)
 {
-    // wave-uniform pixel: the inner-loop reads of hits[j] then go through the scalar cache
+    // The (face, z) keys of the pixel's hits are parked in LDS, 64 at a time, and every lane ranks its own hit against them with
+    // wave-uniform 8-byte reads (LDS broadcasts, all in flight together).  Rounds 2-5 read them through the scalar cache with a
+    // wait after every pair of loads: 32 dependent scalar-cache latencies per wave (round 6: 0.30 -> 0.245 ms at configs[4]).
+    __shared__ int2 s_key[4][64];
     const int p = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (p >= P) return;
     const int n = nhit[p];
     const int4 *h = hits + (size_t)p * knum;
-    for (int i = lane; i < knum; i += 64) {
-        if (i < n) {
-            const int4 me = h[i];
-            const float zi = __int_as_float(me.y);
-            int r = 0;
-            for (int j = 0; j < n; ++j) {
-                const int2 o = *reinterpret_cast<const int2 *>(h + j);   // (face, z): wave-uniform address, one scalar-width load
+    for (int i0 = 0; i0 < knum; i0 += 64) {                          // (wave-uniform trip count)
+        const int i = i0 + lane;
+        const bool mine = i < n;
+        int4 me = make_int4(0, 0, 0, 0);
+        if (mine) me = h[i];
+        const float zi = __int_as_float(me.y);
+        int r = 0;
+        for (int j0 = 0; j0 < n; j0 += 64) {                          // the pixel's hits, 64 keys per round
+            __builtin_amdgcn_wave_barrier();
+            const int jl = j0 + lane;
+            if (jl < n) s_key[wv][lane] = (jl >= i0 && jl < i0 + 64) ? make_int2(me.x, me.y) : *reinterpret_cast<const int2 *>(h + jl);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int m = min(64, n - j0);
+            int j = 0;
+            for (; j + 8 <= m; j += 8) {
+                int2 o[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) o[u] = s_key[wv][j + u];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float zj = __int_as_float(o[u].y);
+                    r += (zj > zi || (zj == zi && o[u].x < me.x)) ? 1 : 0;
+                }
+            }
+            for (; j < m; ++j) {
+                const int2 o = s_key[wv][j];
                 const float zj = __int_as_float(o.y);
                 r += (zj > zi || (zj == zi && o.x < me.x)) ? 1 : 0;
             }
+        }
+        if (mine) {
             const size_t o = (size_t)p * knum + r;
             const float w1 = __int_as_float(me.z), w2 = __int_as_float(me.w), w0 = 1 - w1 - w2;
             out_face[o] = me.x;
             if (out_w) { out_w[o * 3] = w0; out_w[o * 3 + 1] = w1; out_w[o * 3 + 2] = w2; }
             const float *ff = feat + (size_t)me.x * 3 * D;
             for (int d = 0; d < D; ++d) out_feat[o * D + d] = (w0 * ff[d] + w1 * ff[D + d]) + w2 * ff[2 * D + d];
-        } else {
+        } else if (i < knum) {
             const size_t o = (size_t)p * knum + i;                 // slots n..knum-1 stay empty
             out_face[o] = -1;
             if (out_w) { out_w[o * 3] = 0.f; out_w[o * 3 + 1] = 0.f; out_w[o * 3 + 2] = 0.f; }
