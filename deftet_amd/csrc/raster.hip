@@ -796,6 +796,17 @@ struct FaceKeyLoad {
 
 constexpr int kDChunk = 4;
 
+// Select with the lane mask in an SGPR pair (v_cndmask_b32_e64).  Written as `c ? a : b` on a per-lane bool the compiler emits the
+// VCC form where it can, and gfx950 issues that form about eight times slower than any other VALU instruction (23 cycles
+// against 3-4.5: tools/probes/valu_rate_probe.hip) — 21 of them were a seventh of a wave's time in k_bwd_sorted.
+typedef unsigned long long lanemask_t;
+__device__ __forceinline__ float sel_f(lanemask_t m, float if_set, float if_clear)
+{
+    float d;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(d) : "v"(if_clear), "v"(if_set), "s"(m));
+    return d;
+}
+
 // Data-parallel-primitive moves (full-rate VALU; ds_bpermute shuffles made this kernel LDS-pipe bound: 1.07 ms):
 // row_shr:n inside the 16-lane rows, then row_bcast:15 (lane 15 of each row to the next row; rows 1 and 3
 // written) and row_bcast:31 (lane 31 to rows 2 and 3).  Lanes without a source receive 0.
@@ -868,10 +879,11 @@ __device__ __forceinline__ void block_carry(float (&v)[N], float (*s_sum)[20], c
         while (u > 0 && s_one[u]) --u;
         fromBefore = u == 0 && s_one[0];
     }
+    const lanemask_t mFirst = __ballot(inFirstRun);
 #pragma unroll
     for (int k = 0; k < N; ++k) {
         const float ck = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(c), k));
-        v[k] += inFirstRun ? ck : 0.f;
+        v[k] += sel_f(mFirst, ck, 0.f);
     }
     ext = inFirstRun && fromBefore;
 }
@@ -929,9 +941,11 @@ __global__ __launch_bounds__(kBwdWaves * 64) void k_bwd_sorted(const float *__re
         const float gm = gk2 * t + gk3 * q, gp_ = -gk2 * s - gk3 * nn, gn = -gk1 * t - gk3 * pp, gq = gk1 * s + gk3 * m;
         const float gs = gk1 * q - gk2 * pp, gt = -gk1 * nn + gk2 * m;
         float v[6] = {-(gm + gn + gs), -(gp_ + gq + gt), gm, gp_, gn, gq};
-        if (!valid)
+        {
+            const lanemask_t mValid = __ballot(valid);
 #pragma unroll
-            for (int k = 0; k < 6; ++k) v[k] = 0.f;
+            for (int k = 0; k < 6; ++k) v[k] = sel_f(mValid, v[k], 0.f);
+        }
         seg_scan(v, same);
         bool ext;
         block_carry(v, s_sum, s_one, e, lane, inFirstRun, ext);
