@@ -42,7 +42,9 @@ extern "C" {
 #define DEFTET_PIT_WAVE 4    /* a wave stages the candidates of its 64 tets in LDS, filter-only per-tet setup (k_tet_scan_wave) */
 #define DEFTET_PIT_PAIR 5    /* the same with two tets per lane: a wave stages once for 128 tets (k_tet_scan_pair; measured slower, never AUTO) */
 
-/* 210: round 5 — the *_ex_* point-in-tet entry points (traversal order, query box with its miss counts),
+/* 220: round 6 — deftet_tet_order_coherence_f32 (what the traversal-order decision is made on); the rasterizer bins into at most
+ *      90 x 90 tiles and gives sliver faces a certified box (no interface change).
+ * 210: round 5 — the *_ex_* point-in-tet entry points (traversal order, query box with its miss counts),
  * deftet_tet_spatial_order_f32, DEFTET_PIT_PAIR; the backward takes per-tet lists above 2 queries per tet.
  * 200: round 4.  (deftet_tet_energies_workspace_bytes(B) is gone: the forward needs ..._bytes2(B, T).  Algorithm ids other
  * than the DEFTET_PIT_* values above — the STAGED / ROWS / ... ids 2-11 of the round-2 library — are rejected with
@@ -122,7 +124,8 @@ int deftet_tet_order_coherence_f32(const float *tet, int n_tet, const int32_t *o
  * measurement: the grid spans that box, enlarged by 1/32 per side, and the launch is not made.  It is a HINT, never a promise:
  * a query outside it is answered exactly by the side path that serves NaN / Inf / huge queries — at brute-force cost per such
  * query, so hand in the sampler's box (dataloader.py:108 draws from 1.05 (U - 0.5)) or what an earlier call with the same
- * distribution measured: query_box_out (f32 [B,6] or NULL; must not alias query_box_in) receives the box of THIS call's regular
+ * distribution measured: query_box_in is read by the call's kernels: like any input it must not be written while they run (hand boxes from call to
+ * call on ONE stream, or order the streams with an event).  query_box_out (f32 [B,6] or NULL; must not alias query_box_in) receives the box of THIS call's regular
  * queries (lo > hi when there is none).  query_box_misses (int32 [B] or NULL; any memory the device can write — host-mapped
  * memory lets the caller poll it without synchronising) receives, when query_box_in is given, the number of regular queries
  * of each shape that fell outside it (NaN / Inf / huge queries are not counted): a caller that reuses boxes sees there that its
