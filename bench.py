@@ -242,7 +242,7 @@ class RasterWorkload:
         self.pairs_per_step = float(self.P) * self.F
         self.unit = "M ray-face tests/s"
         self.dominant = b"k_pix_raster"
-        self.valu_files = ("profiles/r05_pmc_raster.json",)       # (counters of THIS round's kernel only)
+        self.valu_files = ("profiles/r06_pmc_raster.json",)       # (counters of THIS round's kernel only)
         # SURVEY 8(d) A12 fwd: F*(12+24+48) + P*(8+8) + P*k*(16+4)
         self.dominant_bytes = self.F * 84.0 + self.P * 16.0 + self.P * self.k * 20.0
         self.step_bytes = 2.0 * self.dominant_bytes
@@ -291,7 +291,7 @@ class GeometryWorkload:
         self.pairs_per_step = float(B)
         self.unit = "shapes/s"
         self.dominant = b"k_tri_query_coop"
-        self.valu_files = ("profiles/r05_pmc_geometry.json",)
+        self.valu_files = ("profiles/r06_pmc_geometry.json", "profiles/r05_pmc_geometry.json")
         self.dominant_bytes = 0.0
         self.step_bytes = 0.0
         self.last = None
@@ -499,7 +499,7 @@ def traffic_record(kernel):
     tools/pmc_traffic.py collected for the same command.  It is only quoted while the kernel source it was measured on
     (sha1 of deftet_amd/csrc/point_in_tet.hip, stored in the file) is still the one in the tree; otherwise null."""
     import hashlib
-    for rel in ("profiles/r05_pmc_traffic.json", "profiles/r04_pmc_traffic.json", "profiles/r03_pmc_traffic.json"):
+    for rel in ("profiles/r06_pmc_traffic.json", "profiles/r05_pmc_traffic.json", "profiles/r04_pmc_traffic.json", "profiles/r03_pmc_traffic.json"):
         path = os.path.join(ROOT, rel)
         if not os.path.exists(path):
             continue
