@@ -448,3 +448,37 @@ def test_profiles_readme_quotes_what_the_evidence_files_hold():
     import subprocess
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "profiles_readme_rows.py"), "--check"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_order_rule_and_topology_keys_are_pure_functions():
+    """host logic of order="auto" (round 6): a fixed rule on two far-step fractions, and what identifies a tet list."""
+    from deftet_amd import hip_ops
+    d = hip_ops._decide_order
+    # the measured cases the rule was fitted on (profiles/r06_order_rule.jsonl, r06_order_breaks.jsonl)
+    assert not d(0.0047, 0.0047)            # Kuhn grid, any enumeration
+    assert not d(0.047, 0.027)              # the shipped QuarTet grid: the computed order does not even halve its far steps
+    assert d(0.0244, 0.0047)                # 1 % of the positions shuffled: already 25 % slower as it is
+    assert d(0.995, 0.0047)                 # a shuffled list
+    assert not d(0.5, 0.4)                  # nothing to gain from a permutation that is incoherent itself
+    # the watch compares what is traversed now with what the decision was made on
+    assert not hip_ops._moved(0.0050, 0.0047) and not hip_ops._moved(0.052, 0.047)
+    assert hip_ops._moved(0.99, 0.0047) and hip_ops._moved(0.0047, 0.99)
+    k = hip_ops._topology_key
+    assert k(None) is None and k(7) == 7 and k("grid") == "grid" and k((1, 2)) == (1, 2)
+
+    class Topo:
+        serial = 3
+    assert k(Topo()) == ("topology", 3)
+    a = torch.arange(48, dtype=torch.int64).reshape(12, 4)
+    assert k(a) == k(a.clone()) and k(a) != k(a.flip(0).contiguous()) and k(a)[0] == "tensor"
+    assert k(a.to(torch.int32)) == k(a)                                     # content, not dtype
+    with pytest.raises(RuntimeError):
+        k(object())
+
+
+def test_sparse_render_default_policy_is_none():
+    """the rasterizer's saturation policy is an open question (Kaolin absent): the default is NOT a silent choice"""
+    import inspect
+    from deftet_amd.render.deftet_sparse_render import deftet_sparse_render, NEAREST, FIRST
+    assert inspect.signature(deftet_sparse_render).parameters["policy"].default is None
+    assert (NEAREST, FIRST) == (0, 1)
