@@ -1532,6 +1532,9 @@ constexpr int kWvCapPair = PIT_WVCAP_PAIR, kWvRowsPair = 256;
 #ifndef PIT_PROBE_SKIP
 #define PIT_PROBE_SKIP 0      // probe builds only (wrong results): 1 = no publish atomics, 2 = no hit-record store in k_tet_scan_wave
 #endif
+#ifndef PIT_PROBE_REC8
+#define PIT_PROBE_REC8 0      // probe builds only (wrong results for tets with more than two hits): 8-byte hit records, wave kernel + backward
+#endif
 #ifndef PIT_PROBE_PREFILL
 #define PIT_PROBE_PREFILL 0
 #endif
@@ -2299,7 +2302,12 @@ __device__ __forceinline__ void tet_scan_wave_body(const float *__restrict__ tet
                 h[0] |= kHitSpilled;
             }
             if (over) note_overflow(counters, gridDim.y, b, te);
+#if PIT_PROBE_REC8
+            __builtin_nontemporal_store(h[0], reinterpret_cast<int *>(hits) + ((size_t)b * T + te) * 2);          // timing probe: 8-byte records (hits 3+ are lost)
+            __builtin_nontemporal_store(h[1], reinterpret_cast<int *>(hits) + ((size_t)b * T + te) * 2 + 1);
+#else
             if (!(PIT_PROBE_SKIP & 2)) store_rec(hits + (size_t)b * T + te, over ? make_int4(-1, -1, -1, kHitOverflow) : make_int4(h[0], h[1], h[2], h[3]));
+#endif
         }
         irregular_tail(tet, te, b, T, Q, pts, counters, irregQ, result);
     }
@@ -2886,7 +2894,12 @@ __global__ __launch_bounds__(256, PIT_BWD_WAVES) void k_bary_bwd_hits(const floa
     }
     const int t = bx * blockDim.x + tid;
     const bool live = t < T;
+#if PIT_PROBE_REC8
+    int4 h = make_int4(-1, -1, -1, -1);
+    if (live) { const int2 h2 = reinterpret_cast<const int2 *>(hits)[(size_t)b * T + t]; h.x = h2.x & ~kHitSpilled; h.y = h2.y; if (h2.x < 0) h.x = -1; }
+#else
     int4 h = live ? stream_load(hits + (size_t)b * T + t) : make_int4(-1, -1, -1, -1);
+#endif
     const bool spilled = h.w != kHitOverflow && h.x >= 0 && (h.x & kHitSpilled) != 0;   // four more slots in the spill record
     if (spilled) h.x &= ~kHitSpilled;
     bool parked = false;
