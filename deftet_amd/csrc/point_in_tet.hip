@@ -43,28 +43,33 @@ constexpr float kWMin = 9.3132257e-10f;      // 2^-30
 constexpr int kMiss = 0x7F7F7F7F;            // result sentinel (> any tet index)
 constexpr int kMaxG = 112;                   // y/z cells per axis (slab key has 7 bits)
 constexpr int kMaxBins = 15 * 1024;          // (cy, cx) counters of one slab quarter must fit k_slab_sort's LDS (60 KB)
-constexpr int kHitOverflow = -2;            // hits[.].w: this tet has accepted queries that are not recorded
+constexpr int kHitOverflow = -2;            // hits[.].y: this tet has accepted queries that are not recorded
 
 // "hit record" buffer written by the forward and consumed by the backward (int32 words):
-//   [0, 4*B*T)            int4 per tet: the (<= 4) queries the tet accepted, or w == kHitOverflow
-//   [4*B*T, +3*pad)       three words per shape (pad = B rounded up to kHitPad): [0, pad) number of uncovered queries,
+//   [0, 2*B*T)            int2 per tet (round 6; int4 before): the first two queries the tet accepted (-1: none; the slots fill in
+//                         order), or y == kHitOverflow: accepted queries that are not recorded.  kHitSpilled set in .x: up to
+//                         four more are in the spill record.  71 % of the tets of BASELINE configs[2] accept nothing, 24 % one
+//                         query, 4.1 % two, 0.5 % more: 8 bytes per tet instead of 16 take 16.5 MB out of the traversal's writes
+//                         and out of the backward's reads (1.5 + 3.3 us, measured with a probe build before the format changed:
+//                         profiles/r06_traversal_memory_ops.jsonl).
+//   [2*B*T, +3*pad)       three words per shape (pad = B rounded up to kHitPad): [0, pad) number of uncovered queries,
 //                         [pad, 2 pad) ticket of the backward's miss-sum reduction (zero between calls),
 //                         [2 pad, 3 pad) flag: some uncovered entry belongs to a NaN/Inf/huge query
 //   [.., + B*Q)           per shape: uncovered queries = hits that are NOT in their tet's record
 //                         (tet overflowed / irregular tet / NaN-Inf-huge query)
-//   [.., + 4*B*T)         int4 per tet: the SPILL record — a tet that accepts a fifth query writes its first four into
-//                         hits[.] with kHitSpilled set in .x and collects up to four more here; only a ninth acceptance
-//                         makes it "overflowed".  (With four slots only, a dense query set — configs[1]: one query per
-//                         tet on average — overflowed 130 tets per shape, and their ~650 uncovered hits cost k_finalize
-//                         and the backward 20 us each.)  Untouched for tets that never spill.
+//   [.., + 4*B*T)         int4 per tet: the SPILL record — accepted queries three to six (or -1); a seventh acceptance makes
+//                         the tet "overflowed" (its hits are then carried by the uncovered list).  (With four slots in all, a
+//                         dense query set — configs[1]: one query per tet on average — overflowed 130 tets per shape, and their
+//                         ~650 uncovered hits cost k_finalize and the backward 20 us each.)  Untouched for tets that never spill.
 constexpr int kHitPad = 64;
 __host__ __device__ inline int hit_pad(int B) { return (B + kHitPad - 1) / kHitPad * kHitPad; }
-__host__ __device__ inline size_t hit_cnt_off(int B, int T) { return (size_t)B * T * 4; }
-__host__ __device__ inline size_t hit_list_off(int B, int T) { return (size_t)B * T * 4 + (size_t)3 * hit_pad(B); }
-// second record of the tets that accepted five to eight queries (k_tet_scan_slab; int4 per tet, 16-byte aligned)
+__host__ __device__ inline size_t hit_cnt_off(int B, int T) { return (size_t)B * T * 2; }
+__host__ __device__ inline size_t hit_list_off(int B, int T) { return (size_t)B * T * 2 + (size_t)3 * hit_pad(B); }
+// second record of the tets that accepted three to six queries (int4 per tet, 16-byte aligned)
 __host__ __device__ inline size_t hit_spill_off(int B, int T, int Q) { return (hit_list_off(B, T) + (size_t)B * Q + 3) / 4 * 4; }
-constexpr int kHitSpilled = 1 << 30;       // flag in hits[.].x: four more accepted queries (or -1) are in the spill record
-// Tets whose hit record overflowed (> 4 accepted queries; ~1e-4 of the tets at BASELINE configs[2]) are also LISTED, so
+constexpr int kHitSpilled = 1 << 30;       // flag in hits[.].x: up to four more accepted queries (or -1) are in the spill record
+constexpr int kRecSlots = 2, kSpillSlots = 4;   // accepted queries a tet records: 2 + 4
+// Tets whose hit record overflowed (> 6 accepted queries; ~1e-4 of the tets at BASELINE configs[2]) are also LISTED, so
 // that k_finalize can tell "this hit is not in its tet's record" from a short wave-uniform list instead of gathering the
 // winning tet's 16-byte record for every query of the shape.  The list lives behind the counter block:
 //   counters[0, 4B) counters | [4B, 8B) statistics ([.][2] = number of overflowed tets) | [8B, 8B + B*kOvfCap) the lists.
@@ -74,6 +79,20 @@ __device__ __forceinline__ void note_overflow(int *counters, int nB, int b, int 
     counters[b * 4 + 2] = 1;                                           // some record overflowed (benign race: all write 1)
     const int k = atomicAdd(&counters[nB * 4 + b * 4 + 2], 1);
     if (k < kOvfCap) counters[nB * 8 + b * kOvfCap + k] = t;
+}
+
+// The record of a tet from its first n accepted queries hq[0 .. 5] (-1 beyond n); more than the record and its spill record
+// hold: the overflow marker (and the tet is listed).  Plain stores (the traversal kernels have their own, tuned ones).
+__device__ __forceinline__ void put_hit_record(int2 *hits, int4 *spill, size_t idx, const int (&hq)[kRecSlots + kSpillSlots], int n,
+                                               int *counters, int nB, int b, int t)
+{
+    if (n > kRecSlots + kSpillSlots || (n > kRecSlots && !spill)) {
+        hits[idx] = make_int2(-1, kHitOverflow);
+        note_overflow(counters, nB, b, t);
+        return;
+    }
+    if (n > kRecSlots) spill[idx] = make_int4(hq[2], hq[3], hq[4], hq[5]);
+    hits[idx] = make_int2(n > kRecSlots ? (hq[0] | kHitSpilled) : hq[0], hq[1]);
 }
 
 #ifdef PIT_PHASE_TIMING
@@ -873,8 +892,8 @@ struct CellBox {
 __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan(const float *__restrict__ tet, int T, int Q,
                                                   const float *__restrict__ gparam, int G, int Gx, const int *__restrict__ table,
                                                   long long cellStride, const float4 *__restrict__ sortedQ, int *result, int *counters,
-                                                  int *irregT, int4 *hits, const float *__restrict__ pts,
-                                                  const int *__restrict__ irregQ, int *ucount, int hpad)
+                                                  int *irregT, int2 *hits, const float *__restrict__ pts,
+                                                  const int *__restrict__ irregQ, int *ucount, int hpad, int4 *spill)
 {
     // per-shape words of the hit buffer: uncovered-hit counter (k_finalize appends), backward ticket, irregular-query flag.
     // (hpad is an argument: deriving it from gridDim.y here made the compiler fetch the dispatch packet with vector loads:
@@ -908,15 +927,15 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan(const float *__rest
     make_planes(v, P);
     TetBox bx;
     const bool regular = classify(v, P, bx);
-    // hits[b,t] (optional): the queries this tet ACCEPTED (up to 4; w == kHitOverflow marks "more
-    // than fit / not recorded") — the backward filters them by condition == t, so no per-hit
+    // hits[b,t] (optional): the queries this tet ACCEPTED (two in the record, four in the spill record; y == kHitOverflow
+    // marks "more than fit / not recorded") — the backward filters them by condition == t, so no per-hit
     // atomics or linked lists are needed there.
-    int4 hrec = make_int4(-1, -1, -1, -1);
+    int hq[kRecSlots + kSpillSlots] = {-1, -1, -1, -1, -1, -1};
     int hcnt = 0;
     if (!regular) {
         int k = atomicAdd(&counters[b * 4 + 0], 1);
         irregT[(size_t)b * T + k] = t;
-        if (hits) hits[(size_t)b * T + t] = make_int4(-1, -1, -1, kHitOverflow);   // accepted by k_finalize, not recorded
+        if (hits) hits[(size_t)b * T + t] = make_int2(-1, kHitOverflow);   // accepted by k_finalize, not recorded
         irregular_queries_tail(P, t, b, Q, pts, counters, irregQ, result);
         return;
     }
@@ -930,7 +949,7 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan(const float *__rest
     }
     // no regular query can lie in the enlarged box -> nothing to do
     if (ehi[0] < g.lo[0] || elo[0] > g.hi[0] || ehi[1] < g.lo[1] || elo[1] > g.hi[1] || ehi[2] < g.lo[2] || elo[2] > g.hi[2]) {
-        if (hits) hits[(size_t)b * T + t] = hrec;
+        if (hits) hits[(size_t)b * T + t] = make_int2(-1, -1);
         irregular_queries_tail(P, t, b, Q, pts, counters, irregQ, result);
         return;
     }
@@ -940,7 +959,7 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan(const float *__rest
     if (wide_tet(cx0, cx1, cy0, cy1, cz0, cz1, g)) {            // k_finalize tests it against every query instead
         int k = atomicAdd(&counters[b * 4 + 0], 1);
         irregT[(size_t)b * T + k] = t;
-        if (hits) hits[(size_t)b * T + t] = make_int4(-1, -1, -1, kHitOverflow);
+        if (hits) hits[(size_t)b * T + t] = make_int2(-1, kHitOverflow);
         irregular_queries_tail(P, t, b, Q, pts, counters, irregQ, result);
         return;
     }
@@ -957,21 +976,14 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan(const float *__rest
                     accept(P, q.x, q.y, q.z)) {
                     const int qi = __float_as_int(q.w);
                     atomicMin(&res[qi], t);
-                    if (hcnt == 0) hrec.x = qi;
-                    else if (hcnt == 1) hrec.y = qi;
-                    else if (hcnt == 2) hrec.z = qi;
-                    else if (hcnt == 3) hrec.w = qi;
+#pragma unroll
+                    for (int k = 0; k < kRecSlots + kSpillSlots; ++k)
+                        if (hcnt == k) hq[k] = qi;
                     ++hcnt;
                 }
             }
         }
-    if (hits) {
-        if (hcnt > 4) {
-            hrec.w = kHitOverflow;
-            note_overflow(counters, gridDim.y, b, t);
-        }
-        hits[(size_t)b * T + t] = hrec;
-    }
+    if (hits) put_hit_record(hits, spill, (size_t)b * T + t, hq, hcnt, counters, gridDim.y, b, t);
     irregular_queries_tail(P, t, b, Q, pts, counters, irregQ, result);
 }
 
@@ -1064,6 +1076,7 @@ __device__ __forceinline__ T *uniform_ptr(T *p)
     return reinterpret_cast<T *>(((unsigned long long)hi << 32) | lo);
 }
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2s __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 // streaming accesses (each byte touched once per launch): the nt hint keeps them from evicting the per-query arrays the
 // gathers of k_finalize / k_bary_bwd_hits live on in the 4 MiB L2 of each XCD
@@ -1093,19 +1106,19 @@ __device__ __forceinline__ float4 load_f4(const float4 *p)
     const f32x4 x = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p));
     return make_float4(x[0], x[1], x[2], x[3]);
 }
-__device__ __forceinline__ void store_rec(int4 *p, const int4 v)
+__device__ __forceinline__ void store_rec(int2 *p, const int2 v)
 {
     if (PIT_REC_NT) {
-        const i32x4 x = {v.x, v.y, v.z, v.w};
-        __builtin_nontemporal_store(x, reinterpret_cast<i32x4 *>(p));
+        const i32x2s x = {v.x, v.y};
+        __builtin_nontemporal_store(x, reinterpret_cast<i32x2s *>(p));
     } else {
         *p = v;
     }
 }
-__device__ __forceinline__ int4 stream_load(const int4 *p)
+__device__ __forceinline__ int2 stream_load(const int2 *p)
 {
-    const i32x4 x = __builtin_nontemporal_load(reinterpret_cast<const i32x4 *>(p));
-    return make_int4(x.x, x.y, x.z, x.w);
+    const i32x2s x = __builtin_nontemporal_load(reinterpret_cast<const i32x2s *>(p));
+    return make_int2(x.x, x.y);
 }
 __device__ __forceinline__ void store_b128_off(void *base, unsigned byte_off, int x, int y, int z, int w)
 {
@@ -1116,13 +1129,20 @@ __device__ __forceinline__ void store_b128_off(void *base, unsigned byte_off, in
     asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2\n\ts_nop 2" ::"v"(byte_off), "v"(v), "s"(base) : "memory");
 }
 
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void store_b64_off(void *base, unsigned byte_off, int x, int y)
+{
+    const i32x2 v = {x, y};
+    asm volatile("s_nop 4\n\tglobal_store_dwordx2 %0, %1, %2\n\ts_nop 2" ::"v"(byte_off), "v"(v), "s"(base) : "memory");
+}
+
 // Exact re-scan of ONE tet's candidates (box test + reference predicate, as k_tet_scan does), used by k_tet_scan_slab for
 // the very rare tets that met the filter's undecided band more than twice.  Out of line and called
 // AFTER the traversal loop, so that nothing of it is scheduled (or kept in registers) inside the loop.  Publishes every
-// accepted query with atomicMin (idempotent w.r.t. the ones the filter already accepted) and returns the hit record.
-__device__ __noinline__ int4 exact_rescan(const float *__restrict__ tv, int t, const int *__restrict__ tb, const float4 *__restrict__ sq,
+// accepted query with atomicMin (idempotent w.r.t. the ones the filter already accepted) and writes the hit record.
+__device__ __noinline__ void exact_rescan(const float *__restrict__ tv, int t, const int *__restrict__ tb, const float4 *__restrict__ sq,
                                           int *res, int G, int Gx, int cx0, int cx1, int cy0, int cy1, int cz0, int cz1,
-                                          float m, int *counters, int nB, int b)
+                                          float m, int *counters, int nB, int b, int2 *hits, int4 *spill, size_t idx)
 {
     float vv[12];
 #pragma unroll
@@ -1136,7 +1156,7 @@ __device__ __noinline__ int4 exact_rescan(const float *__restrict__ tv, int t, c
         ehi[k] = fmaxf(fmaxf(vv[k], vv[3 + k]), fmaxf(vv[6 + k], vv[9 + k])) + m;
     }
     const int Gp = table_pitch(G);
-    int4 hrec = make_int4(-1, -1, -1, -1);
+    int hq[kRecSlots + kSpillSlots] = {-1, -1, -1, -1, -1, -1};
     int hcnt = 0;
     for (int cz = cz0; cz <= cz1; ++cz)
         for (int cy = cy0; cy <= cy1; ++cy) {
@@ -1147,19 +1167,14 @@ __device__ __noinline__ int4 exact_rescan(const float *__restrict__ tv, int t, c
                     accept(P, q.x, q.y, q.z)) {
                     const int qi = __float_as_int(q.w);
                     atomicMin(&res[qi], t);
-                    if (hcnt == 0) hrec.x = qi;
-                    else if (hcnt == 1) hrec.y = qi;
-                    else if (hcnt == 2) hrec.z = qi;
-                    else if (hcnt == 3) hrec.w = qi;
+#pragma unroll
+                    for (int k = 0; k < kRecSlots + kSpillSlots; ++k)
+                        if (hcnt == k) hq[k] = qi;
                     ++hcnt;
                 }
             }
         }
-    if (hcnt > 4) {
-        hrec.w = kHitOverflow;
-        note_overflow(counters, nB, b, t);
-    }
-    return hrec;
+    if (hits) put_hit_record(hits, spill, idx, hq, hcnt, counters, nB, b, t);
 }
 
 // The reference predicate for ONE (tet, candidate) pair, used by k_tet_scan_slab for the rare candidates inside the
@@ -1208,7 +1223,7 @@ template <bool ORD>
 __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan_slab(const float *__restrict__ tet, int T, int Q,
                                                   const float *__restrict__ gparam, int G, int Gx, const int *__restrict__ table,
                                                   long long cellStride, const float4 *__restrict__ sortedQ, int *result, int *counters,
-                                                  int *irregT, int4 *hits, const float *__restrict__ pts,
+                                                  int *irregT, int2 *hits, const float *__restrict__ pts,
                                                   const int *__restrict__ irregQ, int *ucount, int hpad, int4 *spill,
                                                   const int *__restrict__ order)
 {
@@ -1246,7 +1261,7 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan_slab(const float *_
         if (!classify(v, P, bx)) {
             int k = atomicAdd(&counters[b * 4 + 0], 1);
             irregT[(size_t)b * T + k] = t;
-            if (hits) hits[(size_t)b * T + t] = make_int4(-1, -1, -1, kHitOverflow);
+            if (hits) hits[(size_t)b * T + t] = make_int2(-1, kHitOverflow);
             irregular_queries_tail(P, t, b, Q, pts, counters, irregQ, result);
             return;
         }
@@ -1277,7 +1292,7 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan_slab(const float *_
         ehi[k] = bx.hi[k] + m;
     }
     if (ehi[0] < g.lo[0] || elo[0] > g.hi[0] || ehi[1] < g.lo[1] || elo[1] > g.hi[1] || ehi[2] < g.lo[2] || elo[2] > g.hi[2]) {
-        if (hits) hits[(size_t)b * T + t] = make_int4(-1, -1, -1, -1);
+        if (hits) hits[(size_t)b * T + t] = make_int2(-1, -1);
         irregular_tail(tet, t, b, T, Q, pts, counters, irregQ, result);
         return;
     }
@@ -1287,7 +1302,7 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan_slab(const float *_
     if (wide_tet(cx0, cx1, cy0, cy1, cz0, cz1, g)) {            // k_finalize tests it against every query instead
         int k = atomicAdd(&counters[b * 4 + 0], 1);
         irregT[(size_t)b * T + k] = t;
-        if (hits) hits[(size_t)b * T + t] = make_int4(-1, -1, -1, kHitOverflow);
+        if (hits) hits[(size_t)b * T + t] = make_int2(-1, kHitOverflow);
         irregular_tail(tet, t, b, T, Q, pts, counters, irregQ, result);
         return;
     }
@@ -1305,11 +1320,20 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan_slab(const float *_
     //    into its record (flagged kHitSpilled) and goes on collecting into the spill record, the second time it marks the
     //    tet "overflowed" (its hits are then carried by the uncovered list).
     int h0 = -1, h1 = -1, h2 = -1, h3 = -1, hcnt = 0;
-    int full = 0;                                                      // 0: nothing yet, 1: first four spilled, 2: overflowed
-    auto on_full = [&]() {                                             // the lane holds four PUBLISHED acceptances and gets a fifth
+    int full = 0;                                                      // 0: nothing yet, 1: first batch spilled, 2: overflowed
+    int cap = 4, scnt = 0;                                             // acceptances the register may hold now; spill slots already used
+    auto on_full = [&]() {                                             // the lane holds PUBLISHED acceptances and gets more than fit
         // (scalar base + 32-bit offset, like the record store at the end: a 64-bit per-lane address kept alive across the
         // loop for this rare store was spilt to scratch)
-        if (hits && spill && full == 0) store_b128_off(uniform_ptr(hits + (size_t)b * T), (unsigned)t * 16u, h0 | kHitSpilled, h1, h2, h3);
+        // first time: the first two held go to the record (flagged), the others (if any) to the first slots of the spill record,
+        // and the register goes on collecting what the spill record still has room for (six recorded in all, whatever the
+        // batches the acceptances arrive in); second time: the tet is marked overflowed at the end
+        if (hits && spill && full == 0) {
+            store_b64_off(uniform_ptr(hits + (size_t)b * T), (unsigned)t * 8u, h0 | kHitSpilled, h1);
+            store_b128_off(uniform_ptr(spill + (size_t)b * T), (unsigned)t * 16u, h2, h3, -1, -1);
+            scnt = max(hcnt - kRecSlots, 0);
+            cap = kSpillSlots - scnt;
+        }
         full = (hits && spill) ? min(full + 1, 2) : 2;
         h0 = -1; h1 = -1; h2 = -1; h3 = -1;
         hcnt = 0;
@@ -1395,8 +1419,8 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan_slab(const float *_
                 acc[k] = mask_of(live[k] && av[k] > 0.f);
                 cnew += sel(acc[k], 1, 0);
             }
-            if (__builtin_amdgcn_ballot_w64(cnew > 4) != 0ull) {              // rare: a fifth acceptance
-                if (cnew > 4) {
+            if (__builtin_amdgcn_ballot_w64(cnew > cap) != 0ull) {            // rare: more acceptances than the register holds
+                if (cnew > cap) {
                     int *resb = result + (size_t)b * Q;
                     if (hcnt > 0) atomicMin(&resb[h0], t);
                     if (hcnt > 1) atomicMin(&resb[h1], t);
@@ -1422,8 +1446,7 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan_slab(const float *_
         const float *tv = tet + ((size_t)b * T + t) * 12;
         atomicAdd(&counters[gridDim.y * 4 + b * 4 + 1], npend);              // statistics: candidates decided exactly
         if (npend > 2) {
-            const int4 r = exact_rescan(tv, t, tb, sq, result + (size_t)b * Q, G, Gx, cx0, cx1, cy0, cy1, cz0, cz1, m, counters, gridDim.y, b);
-            if (hits) hits[(size_t)b * T + t] = r;
+            exact_rescan(tv, t, tb, sq, result + (size_t)b * Q, G, Gx, cx0, cx1, cy0, cy1, cz0, cz1, m, counters, gridDim.y, b, hits, spill, (size_t)b * T + t);
             irregular_tail(tet, t, b, T, Q, pts, counters, irregQ, result);
             return;
         }
@@ -1432,9 +1455,11 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan_slab(const float *_
             if (exact_accept(tv, q.x, q.y, q.z) > 0.f) {
                 const int qi = __float_as_int(q.w);
                 atomicMin(&result[(size_t)b * Q + qi], t);
-                if (hcnt == 4) {                                             // (the held four are not published yet)
+                if (hcnt >= cap) {                                           // (the held ones are not published yet)
                     int *resb = result + (size_t)b * Q;
-                    atomicMin(&resb[h0], t); atomicMin(&resb[h1], t); atomicMin(&resb[h2], t); atomicMin(&resb[h3], t);
+                    atomicMin(&resb[h0], t); atomicMin(&resb[h1], t);
+                    if (hcnt > 2) atomicMin(&resb[h2], t);
+                    if (hcnt > 3) atomicMin(&resb[h3], t);
                     on_full();
                 }
                 h3 = h2; h2 = h1; h1 = h0; h0 = qi;                          // (qi itself was published above)
@@ -1447,13 +1472,24 @@ __global__ __launch_bounds__(256, PIT_WAVES) void k_tet_scan_slab(const float *_
     if (hcnt > 1) atomic_smin_off(resb, (unsigned)h1 * 4u, t);
     if (hcnt > 2) atomic_smin_off(resb, (unsigned)h2 * 4u, t);
     if (hcnt > 3) atomic_smin_off(resb, (unsigned)h3 * 4u, t);
+    if (full == 1 && hcnt > cap) full = 2;                             // (the last wave-iteration brought more than the spill record still holds)
     if (full == 2) note_overflow(counters, gridDim.y, b, t);
     if (hits) {
-        // full == 0: the record; 1: the spill record (the first four are in the record already); 2: overflow marker
-        const lanemask_t o = mask_of(full == 2);
-        const int r0 = sel(o, -1, h0), r1 = sel(o, -1, h1), r2 = sel(o, -1, h2), r3 = sel(o, kHitOverflow, h3);
-        if (full != 1) store_b128_off(uniform_ptr(hits + (size_t)b * T), (unsigned)t * 16u, r0, r1, r2, r3);
-        else store_b128_off(uniform_ptr(spill + (size_t)b * T), (unsigned)t * 16u, r0, r1, r2, r3);
+        // full == 0: the record (+ the low half of the spill record when three or four are held); 1: the high half of the spill
+        // record (record and low half were written when the register spilled); 2: overflow marker
+        if (full == 0) {
+            const lanemask_t sp = mask_of(hcnt > 2);
+            store_b64_off(uniform_ptr(hits + (size_t)b * T), (unsigned)t * 8u, sel(sp, h0 | kHitSpilled, h0), h1);
+            if (hcnt > 2) store_b128_off(uniform_ptr(spill + (size_t)b * T), (unsigned)t * 16u, h2, h3, -1, -1);
+        } else if (full == 1) {                                          // (rare: one dword per held acceptance, behind the slots in use)
+            int *sp = reinterpret_cast<int *>(spill + (size_t)b * T + t) + scnt;
+            if (hcnt > 0) sp[0] = h0;
+            if (hcnt > 1) sp[1] = h1;
+            if (hcnt > 2) sp[2] = h2;
+            if (hcnt > 3) sp[3] = h3;
+        } else {
+            store_b64_off(uniform_ptr(hits + (size_t)b * T), (unsigned)t * 8u, -1, kHitOverflow);
+        }
     }
     irregular_tail(tet, t, b, T, Q, pts, counters, irregQ, result);
     PHASE_MARK(2);                                                       // [2] publish (atomics, record store) / re-scan
@@ -1531,9 +1567,6 @@ constexpr int kWvCapPair = PIT_WVCAP_PAIR, kWvRowsPair = 256;
 #define PIT_KEEP(x) asm volatile("" ::"v"(x))
 #ifndef PIT_PROBE_SKIP
 #define PIT_PROBE_SKIP 0      // probe builds only (wrong results): 1 = no publish atomics, 2 = no hit-record store in k_tet_scan_wave
-#endif
-#ifndef PIT_PROBE_REC8
-#define PIT_PROBE_REC8 0      // probe builds only (wrong results for tets with more than two hits): 8-byte hit records, wave kernel + backward
 #endif
 #ifndef PIT_PROBE_PREFILL
 #define PIT_PROBE_PREFILL 0
@@ -1629,11 +1662,11 @@ __device__ __forceinline__ void cross_fma(float ax, float ay, float az, float bx
 
 // irregular tet (flat / needle / non-finite / huge): listed for k_finalize, its hits are not recorded
 __device__ __noinline__ void irregular_tet_slow(const float *__restrict__ tet, int t, int b, int T, int Q, const float *__restrict__ pts,
-                                                int *counters, int *irregT, const int *__restrict__ irregQ, int *result, int4 *hits)
+                                                int *counters, int *irregT, const int *__restrict__ irregQ, int *result, int2 *hits)
 {
     const int k = atomicAdd(&counters[b * 4 + 0], 1);
     irregT[(size_t)b * T + k] = t;
-    if (hits) hits[(size_t)b * T + t] = make_int4(-1, -1, -1, kHitOverflow);
+    if (hits) hits[(size_t)b * T + t] = make_int2(-1, kHitOverflow);
     if (counters[b * 4 + 1] > 0) irregular_tail_slow(tet, t, b, T, Q, pts, counters, irregQ, result);
 }
 
@@ -1734,7 +1767,7 @@ template <bool ORD, int NT>                                             // ORD: 
 __device__ __forceinline__ void tet_scan_wave_body(const float *__restrict__ tet, int T, int Q,
                                                   const float *__restrict__ gparam, int G, int Gx, const int *__restrict__ table,
                                                   long long cellStride, const float4 *__restrict__ sortedQ, int *result, int *counters,
-                                                  int *irregT, int4 *hits, const float *__restrict__ pts,
+                                                  int *irregT, int2 *hits, const float *__restrict__ pts,
                                                   const int *__restrict__ irregQ, int *ucount, int hpad, int4 *spill,
                                                   const int *__restrict__ order)
 {
@@ -2284,30 +2317,25 @@ __device__ __forceinline__ void tet_scan_wave_body(const float *__restrict__ tet
 #endif
         }
         if (hits) {
-            // <= 4 accepted: the record; 5..kWvSlots: the record (flagged) + the spill record; more: overflow marker (the hits are
+            // <= 2 accepted: the record; 3..kWvSlots: the record (flagged) + the spill record; more: overflow marker (the hits are
             // then carried by the uncovered list, see k_finalize)
-            int h[8];
+            int h[kRecSlots + kSpillSlots];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) h[i] = -1;
+            for (int i = 0; i < kRecSlots + kSpillSlots; ++i) h[i] = -1;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < kRecSlots; ++i)
                 if (i < hc) h[i] = s_hit[k][i][tid];
-            const bool spilled = hc > 4 && hc <= kWvSlots && spill != nullptr && PIT_PROBE_SCATTER == 0;   // (probe builds scribble over the spill records)
-            const bool over = hc > 4 && !spilled;
+            const bool spilled = hc > kRecSlots && hc <= kWvSlots && spill != nullptr && PIT_PROBE_SCATTER == 0;   // (probe builds scribble over the spill records)
+            const bool over = hc > kRecSlots && !spilled;
             if (spilled) {
 #pragma unroll
-                for (int i = 4; i < kWvSlots; ++i)
+                for (int i = kRecSlots; i < kWvSlots; ++i)
                     if (i < hc) h[i] = s_hit[k][i][tid];
-                spill[(size_t)b * T + te] = make_int4(h[4], h[5], h[6], h[7]);
+                spill[(size_t)b * T + te] = make_int4(h[2], h[3], h[4], h[5]);
                 h[0] |= kHitSpilled;
             }
             if (over) note_overflow(counters, gridDim.y, b, te);
-#if PIT_PROBE_REC8
-            __builtin_nontemporal_store(h[0], reinterpret_cast<int *>(hits) + ((size_t)b * T + te) * 2);          // timing probe: 8-byte records (hits 3+ are lost)
-            __builtin_nontemporal_store(h[1], reinterpret_cast<int *>(hits) + ((size_t)b * T + te) * 2 + 1);
-#else
-            if (!(PIT_PROBE_SKIP & 2)) store_rec(hits + (size_t)b * T + te, over ? make_int4(-1, -1, -1, kHitOverflow) : make_int4(h[0], h[1], h[2], h[3]));
-#endif
+            if (!(PIT_PROBE_SKIP & 2)) store_rec(hits + (size_t)b * T + te, over ? make_int2(-1, kHitOverflow) : make_int2(h[0], h[1]));
         }
         irregular_tail(tet, te, b, T, Q, pts, counters, irregQ, result);
     }
@@ -2317,7 +2345,7 @@ __device__ __forceinline__ void tet_scan_wave_body(const float *__restrict__ tet
 
 #define PIT_SCAN_PARAMS                                                                                                               \
     const float *__restrict__ tet, int T, int Q, const float *__restrict__ gparam, int G, int Gx, const int *__restrict__ table,      \
-        long long cellStride, const float4 *__restrict__ sortedQ, int *result, int *counters, int *irregT, int4 *hits,                \
+        long long cellStride, const float4 *__restrict__ sortedQ, int *result, int *counters, int *irregT, int2 *hits,                \
         const float *__restrict__ pts, const int *__restrict__ irregQ, int *ucount, int hpad, int4 *spill, const int *__restrict__ order
 #define PIT_SCAN_FWD tet, T, Q, gparam, G, Gx, table, cellStride, sortedQ, result, counters, irregT, hits, pts, irregQ, ucount, hpad, spill, order
 template <bool ORD>
@@ -2345,7 +2373,7 @@ __global__ __launch_bounds__(kWvThreads, PIT_WAVES_PAIR) void k_tet_scan_pair(PI
 template <int QPT>
 __global__ __launch_bounds__(256) void k_finalize(const float *__restrict__ tet, const float *__restrict__ pts, int T,
                                                   int Q, const int *__restrict__ result, float *cond, float *bary,
-                                                  const float *__restrict__ pred, float *occ, const int4 *__restrict__ hits,
+                                                  const float *__restrict__ pred, float *occ, const int2 *__restrict__ hits,
                                                   int *ucount, int *ulist, const int *__restrict__ counters,
                                                   const int *__restrict__ irregT, int hpad, int pin, const float *__restrict__ gparam)
 {
@@ -2418,7 +2446,7 @@ __global__ __launch_bounds__(256) void k_finalize(const float *__restrict__ tet,
                 const int nB = gridDim.y, nOvf = counters[nB * 4 + b * 4 + 2];
                 if (counters[b * 4 + 0] > 0 || nOvf > kOvfCap) {
                     // irregular tets exist, or more overflowed tets than the list holds: read the winning tet's record
-                    covered = covered && hits[(size_t)b * T + r[j]].w != kHitOverflow;
+                    covered = covered && hits[(size_t)b * T + r[j]].y != kHitOverflow;
                 } else {
                     // the usual case: a handful of overflowed tets per shape, listed; wave-uniform scalar reads, no gather
                     const int *ovf = counters + nB * 8 + b * kOvfCap;
@@ -2860,7 +2888,7 @@ __device__ __forceinline__ bool bwd_rescan(const float *__restrict__ tet, const 
 #endif
 __global__ __launch_bounds__(256, PIT_BWD_WAVES) void k_bary_bwd_hits(const float *__restrict__ tet, const float *__restrict__ pts,
                                                        const float *__restrict__ cond, const float *__restrict__ grad_w,
-                                                       const int4 *__restrict__ hits, int T, int Q, float *grad_tet,
+                                                       const int2 *__restrict__ hits, int T, int Q, float *grad_tet,
                                                        float *grad_pts, int accumulate, const float *__restrict__ gocc,
                                                        float *grad_pred, float *missPart, int nMissParts, int *hitWords,
                                                        const int *__restrict__ ulist, int pad, const int4 *__restrict__ spill, int pin)
@@ -2894,33 +2922,28 @@ __global__ __launch_bounds__(256, PIT_BWD_WAVES) void k_bary_bwd_hits(const floa
     }
     const int t = bx * blockDim.x + tid;
     const bool live = t < T;
-#if PIT_PROBE_REC8
-    int4 h = make_int4(-1, -1, -1, -1);
-    if (live) { const int2 h2 = reinterpret_cast<const int2 *>(hits)[(size_t)b * T + t]; h.x = h2.x & ~kHitSpilled; h.y = h2.y; if (h2.x < 0) h.x = -1; }
-#else
-    int4 h = live ? stream_load(hits + (size_t)b * T + t) : make_int4(-1, -1, -1, -1);
-#endif
-    const bool spilled = h.w != kHitOverflow && h.x >= 0 && (h.x & kHitSpilled) != 0;   // four more slots in the spill record
+    int2 h = live ? stream_load(hits + (size_t)b * T + t) : make_int2(-1, -1);
+    const bool spilled = h.y != kHitOverflow && h.x >= 0 && (h.x & kHitSpilled) != 0;   // up to four more in the spill record
     if (spilled) h.x &= ~kHitSpilled;
     bool parked = false;
     // hits that are in no record (overflowed / irregular tets; NaN/Inf/huge queries): the forward listed them
     const int nU = hitWords[b];
     if (nU > 0) {                                                  // wave-uniform (scalar load)
         const bool anyQ = hitWords[2 * pad + b] != 0;              // entries of irregular queries: their tets' records look complete
-        const unsigned long long need = __ballot(live && (h.w == kHitOverflow || anyQ));
+        const unsigned long long need = __ballot(live && (h.y == kHitOverflow || anyQ));
         if (need) parked = bwd_rescan(tet, pts, cond, grad_w, gocc, grad_pts, grad_pred != nullptr, ulist, b, T, Q, nU, need, t, s_park);
     }
     float acc[12];
 #pragma unroll
     for (int k = 0; k < 12; ++k) acc[k] = 0.f;
     float gp = 0.f;
-    if (h.x >= 0 && h.w != kHitOverflow) {                         // slots fill in order: x < 0 means no accepted query
+    if (h.x >= 0 && h.y != kHitOverflow) {                         // slots fill in order: x < 0 means no accepted query
         TetGrad g;
         tet_grad_setup(tet, (size_t)b * T + t, g);
         // the records list the accepted queries in traversal order, which depends on the (arbitrary)
         // order of queries inside a grid cell: sort the ids so that the fp32 sums below are
         // added in the same order on every run (empty slots, -1, go last)
-        unsigned hu[8] = {(unsigned)h.x, (unsigned)h.y, (unsigned)h.z, (unsigned)h.w, ~0u, ~0u, ~0u, ~0u};
+        unsigned hu[8] = {(unsigned)h.x, (unsigned)h.y, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u};
         const float tf = (float)t;
         auto add_hit = [&](int q) {
             if (q < 0) return;
@@ -2941,17 +2964,17 @@ __global__ __launch_bounds__(256, PIT_BWD_WAVES) void k_bary_bwd_hits(const floa
             gp = won ? gp + go : gp;
         };
 #define DEFTET_CSWAP(a, b) { const unsigned lo_ = min(hu[a], hu[b]), hi_ = max(hu[a], hu[b]); hu[a] = lo_; hu[b] = hi_; }
-        if (!__any(spilled)) {                                       // the usual wave: four slots, five comparators
-            DEFTET_CSWAP(0, 1) DEFTET_CSWAP(2, 3) DEFTET_CSWAP(0, 2) DEFTET_CSWAP(1, 3) DEFTET_CSWAP(1, 2)
+        if (!__any(spilled)) {                                       // the usual wave: two slots, one comparator
+            DEFTET_CSWAP(0, 1)
 #pragma unroll 1
-            for (int k = 0; k < 4 && __any(hu[0] != ~0u); ++k) {     // sorted: empty slots are last, most records hold one hit
+            for (int k = 0; k < 2 && __any(hu[0] != ~0u); ++k) {     // sorted: empty slots are last, most records hold one hit
                 add_hit((int)hu[0]);
-                hu[0] = hu[1]; hu[1] = hu[2]; hu[2] = hu[3]; hu[3] = ~0u;
+                hu[0] = hu[1]; hu[1] = ~0u;
             }
         } else {
             if (spilled) {
                 const int4 h2 = spill[(size_t)b * T + t];
-                hu[4] = (unsigned)h2.x; hu[5] = (unsigned)h2.y; hu[6] = (unsigned)h2.z; hu[7] = (unsigned)h2.w;
+                hu[2] = (unsigned)h2.x; hu[3] = (unsigned)h2.y; hu[4] = (unsigned)h2.z; hu[5] = (unsigned)h2.w;
             }
             // 19-comparator sorting network for eight keys (empty slots are 0xFFFFFFFF and end up last)
             DEFTET_CSWAP(0, 1) DEFTET_CSWAP(2, 3) DEFTET_CSWAP(4, 5) DEFTET_CSWAP(6, 7)
@@ -2962,7 +2985,7 @@ __global__ __launch_bounds__(256, PIT_BWD_WAVES) void k_bary_bwd_hits(const floa
             DEFTET_CSWAP(2, 4) DEFTET_CSWAP(3, 5)
             DEFTET_CSWAP(3, 4)
 #pragma unroll 1
-            for (int k = 0; k < 8 && __any(hu[0] != ~0u); ++k) {
+            for (int k = 0; k < 6 && __any(hu[0] != ~0u); ++k) {
                 add_hit((int)hu[0]);
 #pragma unroll
                 for (int j = 0; j < 7; ++j) hu[j] = hu[j + 1];
@@ -3247,7 +3270,7 @@ static int pit_scan(const Layout &L, const float *tet, const float *pts, float *
     if (T > 0) {
         if (algo == DEFTET_PIT_EXACT) {
             DEFTET_LAUNCH(k_tet_scan, gt, blk, st, tet, T, Q, L.gparam, L.G, L.Gx, L.table, L.cellStride, L.sortedQ, L.result,
-                          L.counters, L.irregT, (int4 *)hit_buf, pts, L.irregQ, ucount, hit_pad(B));
+                          L.counters, L.irregT, (int2 *)hit_buf, pts, L.irregQ, ucount, hit_pad(B), hit_buf ? (int4 *)(hit_buf + hit_spill_off(B, T, Q)) : (int4 *)nullptr);
         } else {
             int4 *spill = hit_buf ? (int4 *)(hit_buf + hit_spill_off(B, T, Q)) : (int4 *)nullptr;
             const int kern = resolve_auto(algo, T, Q);
@@ -3259,7 +3282,7 @@ static int pit_scan(const Layout &L, const float *tet, const float *pts, float *
             const dim3 bw(kWvThreads);                                                           // the wave-staged kernels' workgroup
             const dim3 gw((((T + kWvThreads - 1) / kWvThreads + 7) / 8) * 8, B);
             const dim3 gp(((((T + 1) / 2 + kWvThreads - 1) / kWvThreads + 7) / 8) * 8, B);       // two tets per lane
-#define PIT_SCAN_ARGS tet, T, Q, L.gparam, L.G, L.Gx, L.table, L.cellStride, L.sortedQ, L.result, L.counters, L.irregT, (int4 *)hit_buf, pts, \
+#define PIT_SCAN_ARGS tet, T, Q, L.gparam, L.G, L.Gx, L.table, L.cellStride, L.sortedQ, L.result, L.counters, L.irregT, (int2 *)hit_buf, pts, \
                       L.irregQ, ucount, hit_pad(B), spill, (const int *)order
             if (slab && order) DEFTET_LAUNCH(k_tet_scan_slab<true>, gt, blk, st, PIT_SCAN_ARGS);
             else if (slab) DEFTET_LAUNCH(k_tet_scan_slab<false>, gt, blk, st, PIT_SCAN_ARGS);
@@ -3272,7 +3295,7 @@ static int pit_scan(const Layout &L, const float *tet, const float *pts, float *
     } else if (ucount) {
         DEFTET_HIP(hipMemsetAsync(ucount, 0, (size_t)3 * hit_pad(B) * 4, st));
     }
-    DEFTET_LAUNCH(k_finalize<PIT_FIN_QPT>, gf, blk, st, tet, pts, T, Q, L.result, cond, bary, pred, occ, (const int4 *)hit_buf, ucount,
+    DEFTET_LAUNCH(k_finalize<PIT_FIN_QPT>, gf, blk, st, tet, pts, T, Q, L.result, cond, bary, pred, occ, (const int2 *)hit_buf, ucount,
                   hit_buf ? hit_buf + hit_list_off(B, T) : nullptr, L.counters, L.irregT, hit_pad(B), pin_shapes(Q), (const float *)L.gparam);
     return DEFTET_OK;
 }
@@ -3293,7 +3316,7 @@ static int pit_forward(const float *tet, const float *pts, float *cond, float *b
             DEFTET_LAUNCH(k_prep_records, dim3((unsigned)((n + 255) / 256)), blk, st, tet, n, L.rec);
         }
         DEFTET_LAUNCH(k_brute, gq, blk, st, L.rec, pts, T, Q, L.result);
-        DEFTET_LAUNCH(k_finalize<PIT_FIN_QPT>, dim3((Q + 256 * PIT_FIN_QPT - 1) / (256 * PIT_FIN_QPT), B), blk, st, tet, pts, T, Q, L.result, cond, bary, pred, occ, (const int4 *)nullptr, (int *)nullptr,
+        DEFTET_LAUNCH(k_finalize<PIT_FIN_QPT>, dim3((Q + 256 * PIT_FIN_QPT - 1) / (256 * PIT_FIN_QPT), B), blk, st, tet, pts, T, Q, L.result, cond, bary, pred, occ, (const int2 *)nullptr, (int *)nullptr,
                       (int *)nullptr, (const int *)nullptr, L.irregT, 0, pin_shapes(Q), (const float *)nullptr);
         return DEFTET_OK;
     }
@@ -3506,7 +3529,7 @@ extern "C" int deftet_point_in_tet_bwd_f32(const float *tet, const float *pts, c
         }
         const int tblocks = (T + 255) / 256, nMissParts = tblocks < kMissParts ? tblocks : kMissParts;
         int32_t *words = const_cast<int32_t *>(hit_buf) + hit_cnt_off(B, T);    // counters / ticket / flag: the buffer is this library's own
-        DEFTET_LAUNCH(k_bary_bwd_hits, dim3(tblocks, B), dim3(256), st, tet, pts, cond, grad_w, (const int4 *)hit_buf, T, Q,
+        DEFTET_LAUNCH(k_bary_bwd_hits, dim3(tblocks, B), dim3(256), st, tet, pts, cond, grad_w, (const int2 *)hit_buf, T, Q,
                       grad_tet, grad_pts, accumulate, grad_occ, grad_pred, missPart, nMissParts, words,
                       (const int *)(hit_buf + hit_list_off(B, T)), hit_pad(B), (const int4 *)(hit_buf + hit_spill_off(B, T, Q)), pin_shapes(Q));
     } else if (workspace) {

@@ -235,8 +235,8 @@ def test_backward_hit_records_adversarial(cuda, oracle, seed, algo):
     pred = torch.rand(B, T, device=cuda, generator=gen)
     cond, w, occ, hits = hip_ops.point_in_tet(t, p, want_bary=True, pred_bxt=pred, want_hits=True, algo=algo)
     assert np.array_equal(cond.cpu().numpy(), oracle.point_in_tet(tet, pts))
-    h4 = hits[: B * T * 4].view(B, T, 4)
-    assert (h4[..., 3] == -2).any()                                    # some tet overflowed / is irregular
+    h2 = hits[: B * T * 2].view(B, T, 2)                               # the 8-byte records (round 6)
+    assert (h2[..., 1] == -2).any()                                    # some tet overflowed / is irregular
     gw = torch.randn(B, Q, 4, device=cuda, generator=gen)
     go = torch.randn(B, Q, device=cuda, generator=gen)
     a = hip_ops.point_in_tet_bwd(t, p, cond, gw, want_grad_pts=True, grad_occ=go, hits=hits)
@@ -473,18 +473,18 @@ def test_hit_records_equal_between_traversal_kernels(cuda, res, nq):
     SPILLED = 1 << 30
 
     def records(algo):
-        """Per tet: the sorted tuple of recorded queries, or None when the tet is marked overflowed.  The default kernel keeps
-        up to six (record + spill record, flag in slot 0), the round-3 traversal eight, the exact kernel four."""
+        """Per tet: the sorted tuple of recorded queries, or None when the tet is marked overflowed.  Every kernel keeps up to six
+        (two in the 8-byte record, four in the spill record, flag in slot 0; round 6)."""
         cond, hits = hip_ops.point_in_tet(t, p, want_hits=True, algo=algo)
-        rec = hits[:4 * B * T].view(B, T, 4).cpu().numpy()
+        rec = hits[:2 * B * T].view(B, T, 2).cpu().numpy()
         pad = (B + 63) // 64 * 64
-        off = (4 * B * T + 3 * pad + B * Q + 3) // 4 * 4
+        off = (2 * B * T + 3 * pad + B * Q + 3) // 4 * 4
         spill = hits[off:off + 4 * B * T].view(B, T, 4).cpu().numpy()
         out = {}
         for bi in range(B):
             for ti in range(T):
                 r = rec[bi, ti]
-                if r[3] == -2:
+                if r[1] == -2:
                     out[bi, ti] = None
                     continue
                 ids = list(r)
@@ -496,22 +496,20 @@ def test_hit_records_equal_between_traversal_kernels(cuda, res, nq):
 
     cond, rec0 = records(4)
     _, rec2 = records(2)
-    _, rec3 = records(3)                                               # the round-3 traversal: eight slots too, but a batch of
-    for key, ids3 in rec3.items():                                     # three candidates may push it over the edge early
+    _, rec3 = records(3)                                               # the round-3 traversal: six slots too (four, then two), but a
+    for key, ids3 in rec3.items():                                     # batch of three candidates may push it over the edge early
         ids0 = rec0[key]
         if ids3 is not None and ids0 is not None:
             assert ids0 == ids3, (key, ids0, ids3)
         elif ids3 is not None:
-            assert 7 <= len(ids3) <= 8, (key, ids3)                  # the default keeps six (record + half a spill record)
+            assert False, (key, ids3)                                  # the default overflows at seven: so does the slab kernel
         else:
             assert ids0 is None or 5 <= len(ids0) <= 6, (key, ids0)
     n_spilled = 0
     for key, ids2 in rec2.items():
         ids0 = rec0[key]
-        if ids2 is not None:
-            assert ids0 == ids2, (key, ids0, ids2)                    # at most four acceptances: the same set
-        elif ids0 is not None:
-            assert 5 <= len(ids0) <= 6                               # the exact kernel overflows at five, the default at seven
+        assert ids0 == ids2, (key, ids0, ids2)                        # the exact kernel: the same six slots, the same sets
+        if ids0 is not None and len(ids0) > 2:
             n_spilled += 1
     if nq >= 4 * T // 3:
         assert n_spilled > 0                                          # the dense case really exercises the spill record
