@@ -55,6 +55,8 @@ SIGNATURES = {
     "deftet_tet_vertex_csr_workspace_bytes": (_sz, [_i, _i, _i]),
     "deftet_tet_vertex_csr_i32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "deftet_tet_gather_bwd_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "deftet_point_in_tet_bwd_to_vertices_workspace_bytes": (_sz, [_i, _i, _i]),
+    "deftet_point_in_tet_bwd_to_vertices_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "deftet_rowdot_workspace_bytes": (_sz, [_i]),
     "deftet_rowdot_f32": (_i, [_vp, _vp, _vp, _i, _ll, _vp, _sz, _vp]),
     "deftet_rowdot2_f32": (_i, [_vp, _vp, _ll, _vp, _vp, _ll, _vp, _i, _vp, _sz, _vp]),

@@ -85,4 +85,13 @@ constexpr int kWave = 64;  // CDNA4 wavefront
 // (the caller then takes its multi-launch form, which needs no counters).
 int ticket_slot_for_stream(hipStream_t st, int n_slots);
 
+// vertex_ops.hip: grad_pos[b,v] = sum over the (tet, corner) incidences of vertex v of the rows of a [B,T,4,3] gradient, in the
+// incidence CSR's order (k_gather_bwd).  rowMask == nullptr: dense rows.  Otherwise the rows are in the COMPACTED form
+// k_bary_bwd_hits<true> writes (point_in_tet.hip): rowMask[b][t / 64] has bit t % 64 set iff tet t has a row, stored at row
+// (t & ~63) + popcount(mask below the bit); absent rows are zero and are skipped (x + 0 = x: the same sums, bit for bit).
+namespace vtx {
+int gather_bwd_rows(const float *rows, const unsigned long long *rowMask, const int32_t *offsets, const int32_t *slots, float *grad_pos,
+                    int B, int V, int T, int idx_batch, int accumulate, hipStream_t st);
+}
+
 }  // namespace deftet

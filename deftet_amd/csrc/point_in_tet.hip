@@ -2886,12 +2886,19 @@ __device__ __forceinline__ bool bwd_rescan(const float *__restrict__ tet, const 
 #ifndef PIT_BWD_WAVES
 #define PIT_BWD_WAVES 7
 #endif
+// SPARSE (deftet_point_in_tet_bwd_to_vertices_f32): grad_tet is a workspace whose only reader is the vertex gather
+// (vertex_ops.hip: k_gather_bwd_rows).  71 % of the rows are zero at BASELINE configs[2] (0.34 hits per tet), so a wave writes
+// only the rows of the tets that accepted something, COMPACTED to the start of its 64-row block in lane order, and one 64-bit
+// word per wave (rowMask[b][t / 64], the ballot of those lanes) tells the reader which tets they belong to: rank = popcount of
+// the mask below the tet's bit.  29 MB of contiguous stores instead of 99 MB, and the reader fetches a third of the lines.
+template <bool SPARSE>
 __global__ __launch_bounds__(256, PIT_BWD_WAVES) void k_bary_bwd_hits(const float *__restrict__ tet, const float *__restrict__ pts,
                                                        const float *__restrict__ cond, const float *__restrict__ grad_w,
                                                        const int2 *__restrict__ hits, int T, int Q, float *grad_tet,
                                                        float *grad_pts, int accumulate, const float *__restrict__ gocc,
                                                        float *grad_pred, float *missPart, int nMissParts, int *hitWords,
-                                                       const int *__restrict__ ulist, int pad, const int4 *__restrict__ spill, int pin)
+                                                       const int *__restrict__ ulist, int pad, const int4 *__restrict__ spill, int pin,
+                                                       unsigned long long *rowMask)
 {
     __shared__ float wsum[4];
     __shared__ float s_vals[kMissStride];
@@ -3007,19 +3014,26 @@ __global__ __launch_bounds__(256, PIT_BWD_WAVES) void k_bary_bwd_hits(const floa
     {   // the 48-byte rows of a wave go through LDS so that every store instruction writes 1 KB of consecutive addresses
         // (a lane storing its own row wrote 16 bytes every 48: three partial-line streaming stores per line)
         const int w = tid >> 6;
-        s_rows[w][lane * 3] = make_float4(acc[0], acc[1], acc[2], acc[3]);
-        s_rows[w][lane * 3 + 1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
-        s_rows[w][lane * 3 + 2] = make_float4(acc[8], acc[9], acc[10], acc[11]);
-        __syncthreads();
         const int t0 = t - lane;                                    // the wave's first tet
+        // SPARSE: the rows of the tets that accepted a query (the only ones that can be non-zero), in lane order
+        const bool has = live && ((h.x >= 0 && h.y != kHitOverflow) || parked);
+        const unsigned long long hm = SPARSE ? __ballot(has) : 0ull;
+        const int slot = SPARSE ? __popcll(hm & ((1ull << lane) - 1ull)) : lane;
+        if (!SPARSE || has) {
+            s_rows[w][slot * 3] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            s_rows[w][slot * 3 + 1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+            s_rows[w][slot * 3 + 2] = make_float4(acc[8], acc[9], acc[10], acc[11]);
+        }
+        if (SPARSE && lane == 0 && t0 < T) rowMask[(size_t)b * ((T + 63) >> 6) + (t0 >> 6)] = hm;
+        __syncthreads();
         float4 *dst = reinterpret_cast<float4 *>(grad_tet + ((size_t)b * T + t0) * 12);
-        const int nRow = min(64, T - t0) * 3;                       // float4 pieces of the wave's live rows (<= 0: none)
+        const int nRow = (SPARSE ? __popcll(hm) : min(64, T - t0)) * 3;   // float4 pieces of the wave's live rows (<= 0: none)
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const int j = k * 64 + lane;
             if (j < nRow) {
                 float4 o = s_rows[w][j];
-                if (accumulate) { const float4 p = dst[j]; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
+                if (accumulate && !SPARSE) { const float4 p = dst[j]; o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }   // (SPARSE: the rows are a workspace; `accumulate` is about grad_pred)
                 stream_store(dst + j, o);
             }
         }
@@ -3529,9 +3543,10 @@ extern "C" int deftet_point_in_tet_bwd_f32(const float *tet, const float *pts, c
         }
         const int tblocks = (T + 255) / 256, nMissParts = tblocks < kMissParts ? tblocks : kMissParts;
         int32_t *words = const_cast<int32_t *>(hit_buf) + hit_cnt_off(B, T);    // counters / ticket / flag: the buffer is this library's own
-        DEFTET_LAUNCH(k_bary_bwd_hits, dim3(tblocks, B), dim3(256), st, tet, pts, cond, grad_w, (const int2 *)hit_buf, T, Q,
+        DEFTET_LAUNCH(k_bary_bwd_hits<false>, dim3(tblocks, B), dim3(256), st, tet, pts, cond, grad_w, (const int2 *)hit_buf, T, Q,
                       grad_tet, grad_pts, accumulate, grad_occ, grad_pred, missPart, nMissParts, words,
-                      (const int *)(hit_buf + hit_list_off(B, T)), hit_pad(B), (const int4 *)(hit_buf + hit_spill_off(B, T, Q)), pin_shapes(Q));
+                      (const int *)(hit_buf + hit_list_off(B, T)), hit_pad(B), (const int4 *)(hit_buf + hit_spill_off(B, T, Q)), pin_shapes(Q),
+                      (unsigned long long *)nullptr);
     } else if (workspace) {
         const size_t need = deftet_point_in_tet_bwd_workspace_bytes(B, T, Q);
         DEFTET_CHECK_ARG(workspace_bytes >= need && ((uintptr_t)workspace & 255) == 0,
@@ -3557,6 +3572,72 @@ extern "C" int deftet_point_in_tet_bwd_f32(const float *tet, const float *pts, c
         }
     }
     return DEFTET_OK;
+}
+
+// A1b backward fused with the backward of the vertex -> tet gather (N2): dL/dpos [B,V,3] without the dense dL/dtet.
+// The reference's dataflow is vertice_pos -> torch.gather -> tet_bxfx4x3 -> operators (layers/DefTet/deftet.py:65-68), so the
+// gradient of a caller that owns both the gather and the query ends on the vertices; deftet_point_in_tet_bwd_f32 followed by
+// deftet_tet_gather_bwd_f32 writes 48 bytes per tet (71 % of them zeros at 0.34 hits per tet) and reads them back.  Here the
+// per-tet pass keeps only the rows of tets that accepted a query (k_bary_bwd_hits<true>: compacted per wave + one mask word
+// per 64 tets) and the per-vertex pass (vertex_ops.hip, k_gather_bwd<true>) adds them up in the incidence CSR's order: the
+// same additions in the same order as the two-call form, bit for bit, no floating-point atomics.
+extern "C" size_t deftet_point_in_tet_bwd_to_vertices_workspace_bytes(int B, int T, int Q)
+{
+    if (B <= 0 || T < 0 || Q < 0) return 0;
+    return align_up((size_t)B * T * 48, 256) + align_up((size_t)B * ((T + 63) / 64) * 8, 256) +
+           align_up(deftet_point_in_tet_bwd_workspace_bytes(B, T, Q), 256);
+}
+
+extern "C" int deftet_point_in_tet_bwd_to_vertices_f32(const float *tet, const float *pts, const float *cond, const float *grad_w,
+                                                       const float *grad_occ, const int32_t *hit_buf, const int32_t *csr_offsets,
+                                                       const int32_t *csr_slots, int idx_batch, float *grad_pos, float *grad_pts,
+                                                       float *grad_pred, int B, int V, int T, int Q, int accumulate, void *workspace,
+                                                       size_t workspace_bytes, void *stream_)
+{
+    DEFTET_CHECK_ARG(B >= 0 && V >= 0 && T >= 0 && Q >= 0, "negative size");
+    DEFTET_CHECK_ARG(B <= 65535, "n_batch=%d exceeds 65535", B);
+    DEFTET_CHECK_ARG((grad_occ == nullptr) == (grad_pred == nullptr), "grad_occ and grad_pred must be given together");
+    DEFTET_CHECK_ARG(idx_batch == 1 || idx_batch == B, "CSR batch must be 1 or n_batch (got %d)", idx_batch);
+    hipStream_t st = as_stream(stream_);
+    if (B == 0) return DEFTET_OK;
+    DEFTET_CHECK_ARG(V == 0 || grad_pos, "null grad_pos");
+    if (T == 0 || Q == 0 || V == 0) {                                 // no tet or no query: zero gradients
+        if (grad_pts && Q > 0) DEFTET_HIP(hipMemsetAsync(grad_pts, 0, (size_t)B * Q * 12, st));
+        if (!accumulate) {
+            if (V > 0) DEFTET_HIP(hipMemsetAsync(grad_pos, 0, (size_t)B * V * 12, st));
+            if (grad_pred && T > 0) DEFTET_HIP(hipMemsetAsync(grad_pred, 0, (size_t)B * T * 4, st));
+        }
+        return DEFTET_OK;
+    }
+    DEFTET_CHECK_ARG(tet && pts && cond && grad_w && csr_offsets && csr_slots, "null pointer");
+    DEFTET_CHECK_ARG(((uintptr_t)tet & 15) == 0 && ((uintptr_t)grad_w & 15) == 0, "tet/grad_w must be 16-byte aligned");
+    const size_t need = deftet_point_in_tet_bwd_to_vertices_workspace_bytes(B, T, Q);
+    DEFTET_CHECK_ARG(workspace && workspace_bytes >= need && ((uintptr_t)workspace & 255) == 0,
+                     "workspace null, misaligned or too small (%zu < %zu)", workspace_bytes, need);
+    Arena A(workspace, workspace_bytes);
+    float *rows = A.take<float>((size_t)B * T * 12);
+    unsigned long long *rowMask = A.take<unsigned long long>((size_t)B * ((T + 63) / 64));
+    const size_t innerBytes = deftet_point_in_tet_bwd_workspace_bytes(B, T, Q);
+    void *inner = A.take<char>(innerBytes);
+    const bool dense = (long long)Q > kDenseQueriesPerTet * (long long)T;
+    if (hit_buf && !dense) {
+        DEFTET_CHECK_ARG(((uintptr_t)hit_buf & 15) == 0, "hit_buf must be 16-byte aligned");
+        if (grad_pts) DEFTET_HIP(hipMemsetAsync(grad_pts, 0, (size_t)B * Q * 12, st));
+        const int tblocks = (T + 255) / 256, nMissParts = tblocks < kMissParts ? tblocks : kMissParts;
+        int32_t *words = const_cast<int32_t *>(hit_buf) + hit_cnt_off(B, T);
+        DEFTET_LAUNCH(k_bary_bwd_hits<true>, dim3(tblocks, B), dim3(256), st, tet, pts, cond, grad_w, (const int2 *)hit_buf, T, Q,
+                      rows, grad_pts, accumulate, grad_occ, grad_pred, static_cast<float *>(inner), nMissParts, words,
+                      (const int *)(hit_buf + hit_list_off(B, T)), hit_pad(B), (const int4 *)(hit_buf + hit_spill_off(B, T, Q)), pin_shapes(Q),
+                      rowMask);
+        return vtx::gather_bwd_rows(rows, rowMask, csr_offsets, csr_slots, grad_pos, B, V, T, idx_batch, accumulate, st);
+    }
+    // no records (the forward was asked for none), or the dense case where the records are not the fast path: the per-tet lists
+    // into dense rows, then the dense gather
+    if (accumulate) DEFTET_HIP(hipMemsetAsync(rows, 0, (size_t)B * T * 48, st));     // (the inner call's `accumulate` covers grad_pred too)
+    const int rc = deftet_point_in_tet_bwd_f32(tet, pts, cond, grad_w, rows, grad_pts, grad_occ, grad_pred, hit_buf, B, T, Q, accumulate, inner,
+                                               innerBytes, stream_);
+    if (rc != DEFTET_OK) return rc;
+    return vtx::gather_bwd_rows(rows, nullptr, csr_offsets, csr_slots, grad_pos, B, V, T, idx_batch, accumulate, st);
 }
 
 extern "C" int deftet_paste_occ_fwd_f32(const float *pred, float *cond, float *out, int B, int T, int Q,

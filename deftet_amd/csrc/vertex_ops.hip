@@ -69,9 +69,13 @@ __global__ __launch_bounds__(256) void k_csr_offsets(const unsigned *__restrict_
 // one after the other, then the four partial sums are combined as (s0 + s1) + (s2 + s3).  A fixed
 // order (restated by oracle.tet_gather_bwd), four times the memory parallelism of one lane per
 // vertex (a vertex has ~24 incidences: one lane per vertex measured 115 us for 99 MB).
+// MASKED: the rows come compacted from k_bary_bwd_hits<true> (common.hpp: gather_bwd_rows) — a 64-bit word per 64 tets says
+// which tets have one; an absent row is an exact zero and adding it would not change a partial sum, so it is skipped: the
+// same additions in the same order as the dense form.  The words of a shape (32 KB at T = 257,250) live in the L2.
+template <bool MASKED>
 __global__ __launch_bounds__(256) void k_gather_bwd(const float *__restrict__ grad_tet, const int *__restrict__ offsets,
                                                     const int *__restrict__ slots, float *grad_pos, int V, long long slotsPerShape,
-                                                    int idxBatch, int accumulate)
+                                                    int idxBatch, int accumulate, const unsigned long long *__restrict__ rowMask)
 {
     const int b = blockIdx.y;
     // XCD-aware placement (workgroup i runs on XCD i % 8, each XCD has its own L2): every XCD takes one CONTIGUOUS eighth of
@@ -86,15 +90,37 @@ __global__ __launch_bounds__(256) void k_gather_bwd(const float *__restrict__ gr
         const int s0 = offsets[row], s1 = offsets[row + 1];
         const float *g = grad_tet + (size_t)b * slotsPerShape * 3;
         int i = s0 + k;
-        for (; i + 4 < s1; i += 8) {                         // two independent gathers in flight per lane
-            const float *p = g + (size_t)slots[i] * 3, *q = g + (size_t)slots[i + 4] * 3;
-            const float px = p[0], py = p[1], pz = p[2], qx = q[0], qy = q[1], qz = q[2];
-            ax += px; ay += py; az += pz;
-            ax += qx; ay += qy; az += qz;
-        }
-        if (i < s1) {
-            const float *p = g + (size_t)slots[i] * 3;
-            ax += p[0]; ay += p[1]; az += p[2];
+        if (MASKED) {
+            const unsigned long long *mk = rowMask + (size_t)b * (size_t)((slotsPerShape / 4 + 63) >> 6);
+            // slot s = 4 t + corner -> the float offset of the corner in the compacted rows, or -1 when tet t has no row
+            auto where = [&](int s) -> long long {
+                const int t = s >> 2;
+                const unsigned long long w = mk[t >> 6], bit = 1ull << (t & 63);
+                return (w & bit) ? ((long long)((t & ~63) + __popcll(w & (bit - 1ull))) * 4 + (s & 3)) * 3 : -1ll;
+            };
+            for (; i + 4 < s1; i += 8) {                     // two independent gathers in flight per lane
+                const long long op = where(slots[i]), oq = where(slots[i + 4]);
+                float px = 0.f, py = 0.f, pz = 0.f, qx = 0.f, qy = 0.f, qz = 0.f;
+                if (op >= 0) { px = g[op]; py = g[op + 1]; pz = g[op + 2]; }
+                if (oq >= 0) { qx = g[oq]; qy = g[oq + 1]; qz = g[oq + 2]; }
+                if (op >= 0) { ax += px; ay += py; az += pz; }
+                if (oq >= 0) { ax += qx; ay += qy; az += qz; }
+            }
+            if (i < s1) {
+                const long long op = where(slots[i]);
+                if (op >= 0) { ax += g[op]; ay += g[op + 1]; az += g[op + 2]; }
+            }
+        } else {
+            for (; i + 4 < s1; i += 8) {                     // two independent gathers in flight per lane
+                const float *p = g + (size_t)slots[i] * 3, *q = g + (size_t)slots[i + 4] * 3;
+                const float px = p[0], py = p[1], pz = p[2], qx = q[0], qy = q[1], qz = q[2];
+                ax += px; ay += py; az += pz;
+                ax += qx; ay += qy; az += qz;
+            }
+            if (i < s1) {
+                const float *p = g + (size_t)slots[i] * 3;
+                ax += p[0]; ay += p[1]; az += p[2];
+            }
         }
     }
     // (s0 + s1) + (s2 + s3); lanes of one vertex are adjacent, the whole wave takes part
@@ -163,15 +189,22 @@ extern "C" int deftet_tet_vertex_csr_i32(const int64_t *tet_idx, int32_t *offset
     return DEFTET_OK;
 }
 
-extern "C" int deftet_tet_gather_bwd_f32(const float *grad_tet, const int32_t *offsets, const int32_t *slots, float *grad_pos, int B,
-                                         int V, int T, int idx_batch, int accumulate, void *stream_)
+int deftet::vtx::gather_bwd_rows(const float *rows, const unsigned long long *rowMask, const int32_t *offsets, const int32_t *slots,
+                                 float *grad_pos, int B, int V, int T, int idx_batch, int accumulate, hipStream_t st)
 {
     DEFTET_CHECK_ARG(B >= 0 && V >= 0 && T >= 0, "negative size");
     DEFTET_CHECK_ARG(idx_batch == 1 || idx_batch == B, "CSR batch must be 1 or n_batch (got %d)", idx_batch);
     DEFTET_CHECK_ARG(B <= 65535, "n_batch=%d exceeds 65535", B);
     if (B == 0 || V == 0) return DEFTET_OK;
-    DEFTET_CHECK_ARG(offsets && grad_pos && (T == 0 || (grad_tet && slots)), "null pointer");
-    DEFTET_LAUNCH(vtx::k_gather_bwd, dim3((((V + 63) / 64 + 7) / 8) * 8, B), dim3(256), as_stream(stream_), grad_tet, offsets, slots, grad_pos, V,
-                  (long long)T * 4, idx_batch, accumulate);
+    DEFTET_CHECK_ARG(offsets && grad_pos && (T == 0 || (rows && slots)), "null pointer");
+    const dim3 grid((((V + 63) / 64 + 7) / 8) * 8, B);
+    if (rowMask) DEFTET_LAUNCH(vtx::k_gather_bwd<true>, grid, dim3(256), st, rows, offsets, slots, grad_pos, V, (long long)T * 4, idx_batch, accumulate, rowMask);
+    else DEFTET_LAUNCH(vtx::k_gather_bwd<false>, grid, dim3(256), st, rows, offsets, slots, grad_pos, V, (long long)T * 4, idx_batch, accumulate, rowMask);
     return DEFTET_OK;
+}
+
+extern "C" int deftet_tet_gather_bwd_f32(const float *grad_tet, const int32_t *offsets, const int32_t *slots, float *grad_pos, int B,
+                                         int V, int T, int idx_batch, int accumulate, void *stream_)
+{
+    return vtx::gather_bwd_rows(grad_tet, nullptr, offsets, slots, grad_pos, B, V, T, idx_batch, accumulate, as_stream(stream_));
 }

@@ -502,6 +502,40 @@ def point_in_tet_bwd(tet_bxtx4x3, pts_bxqx3, cond, grad_w, want_grad_pts=False, 
     return grad_tet, grad_pts
 
 
+def point_in_tet_bwd_to_vertices(tet_bxtx4x3, pts_bxqx3, cond, grad_w, csr, n_vertex, want_grad_pts=False, grad_occ=None, hits=None,
+                                 out=None):
+    """(grad_pos [B,V,3], grad_pts [B,Q,3] | None[, grad_pred [B,T]]): point_in_tet_bwd followed by tet_gather_bwd in one call
+    that never writes the dense grad_tet — the gradient of a caller that owns both the gather (layers/DefTet/deftet.py:65-68)
+    and the query.  csr = tet_vertex_csr(...) of the topology the tets were gathered with; bit-identical to the two-call form.
+    out: existing [B,V,3] tensor to ADD to."""
+    _lib.require_gpu(tet_bxtx4x3, pts_bxqx3, cond, grad_w, grad_occ)
+    lib = _lib.load()
+    tet, pts, cond, gw = _f32c(tet_bxtx4x3), _f32c(pts_bxqx3), _f32c(cond), _f32c(grad_w)
+    B, T, Q, V = tet.shape[0], tet.shape[1], pts.shape[1], int(n_vertex)
+    offsets, slots, Bi = csr
+    if slots.numel() != Bi * T * 4 or offsets.numel() != Bi * V + 1:
+        raise RuntimeError("point_in_tet_bwd_to_vertices: CSR does not match tet / n_vertex")
+    dev = pts.device
+    acc = out is not None
+    if acc and (out.shape != (B, V, 3) or out.dtype != torch.float32 or not out.is_contiguous()):
+        raise RuntimeError("point_in_tet_bwd_to_vertices: out must be contiguous f32 [B,V,3]")
+    grad_pos = out if acc else torch.empty(B, V, 3, device=dev, dtype=torch.float32)
+    grad_pts = torch.empty_like(pts) if want_grad_pts else None
+    go = _f32c(grad_occ) if grad_occ is not None else None
+    # (`accumulate` of the C entry covers grad_pos AND grad_pred: a fresh grad_pred must then start from zero)
+    grad_pred = (torch.zeros if acc else torch.empty)(B, T, device=dev, dtype=torch.float32) if go is not None else None
+    with torch.cuda.device(dev):
+        ws = _lib.workspace(dev, lib.deftet_point_in_tet_bwd_to_vertices_workspace_bytes(B, T, Q))
+        _lib.check(lib.deftet_point_in_tet_bwd_to_vertices_f32(_lib.ptr(tet), _lib.ptr(pts), _lib.ptr(cond), _lib.ptr(gw), _lib.ptr(go),
+                                                               _lib.ptr(hits), _lib.ptr(offsets), _lib.ptr(slots), Bi, _lib.ptr(grad_pos),
+                                                               _lib.ptr(grad_pts), _lib.ptr(grad_pred), B, V, T, Q, 1 if acc else 0,
+                                                               _lib.ptr(ws), ws.numel(), _lib.current_stream(dev)),
+                   "deftet_point_in_tet_bwd_to_vertices_f32")
+    if go is not None:
+        return grad_pos, grad_pts, grad_pred
+    return grad_pos, grad_pts
+
+
 def paste_occ_fwd(pred_bxt, cond_bxqx1, clamp_inplace=True):
     _lib.require_gpu(pred_bxt, cond_bxqx1)
     lib = _lib.load()

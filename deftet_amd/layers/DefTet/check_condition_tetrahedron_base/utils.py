@@ -90,6 +90,40 @@ class PointInTetOcc(Function):
 point_in_tet_occ = PointInTetOcc.apply
 
 
+class PointInTetOccVertices(Function):
+    """PointInTetOcc for a caller that owns the vertex -> tet gather as well (layers/DefTet/deftet.py:65-68 followed by the query):
+    (vertice_pos [B,V,3], pts [B,Q,3], pred_tet_occ [B,T], topology[, tet_bxfx4x3]) -> (condition, weights, occ).
+
+    `topology` is a deftet_amd.layers.DefTet.deftet.TetTopology (index list + incidence CSR).  tet_bxfx4x3: the positions gathered
+    from `vertice_pos` with that topology, when the caller has them already (their VALUES are used; the gradient goes to
+    vertice_pos).  The backward never writes the dense [B,T,4,3] gradient: deftet_point_in_tet_bwd_to_vertices_f32 keeps the rows
+    of the tets that accepted a query and sums them per vertex in the CSR's order — the same bits as PointInTetOcc's backward
+    followed by the gather's."""
+
+    @staticmethod
+    def forward(ctx, vertice_pos, point_pos_bxnx3, pred_tet_occ, topology, tet_bxfx4x3=None):
+        tet = tet_bxfx4x3.detach() if tet_bxfx4x3 is not None else hip_ops.tet_gather(vertice_pos, topology.tet_idx)
+        rec = hip_ops.bwd_uses_records(tet.shape[1], point_pos_bxnx3.shape[1])
+        out = hip_ops.point_in_tet(tet, point_pos_bxnx3, want_bary=True, pred_bxt=pred_tet_occ, want_hits=rec, order="auto",
+                                   query_box="track", topology=topology)
+        cond, w, occ, hits = out if rec else (out + (None,))
+        ctx.save_for_backward(tet, point_pos_bxnx3, cond, hits)
+        ctx.topology = topology
+        ctx.n_vertex = vertice_pos.shape[1]
+        ctx.mark_non_differentiable(cond)
+        return cond, w, occ
+
+    @staticmethod
+    def backward(ctx, _grad_cond, grad_w, grad_occ):
+        tet, pts, cond, hits = ctx.saved_tensors
+        g_pos, g_pts, g_pred = hip_ops.point_in_tet_bwd_to_vertices(tet, pts, cond, grad_w, ctx.topology.csr, ctx.n_vertex,
+                                                                    want_grad_pts=ctx.needs_input_grad[1], grad_occ=grad_occ, hits=hits)
+        return (g_pos if ctx.needs_input_grad[0] else None), g_pts, (g_pred if ctx.needs_input_grad[2] else None), None, None
+
+
+point_in_tet_occ_vertices = PointInTetOccVertices.apply
+
+
 class PasteOcc(Function):
     """DefTet.paste_occ (layers/DefTet/deftet.py:132-136) as one fused gather with its
     scatter-add backward; `condition` is clamped in place like the reference does."""

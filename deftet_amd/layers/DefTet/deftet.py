@@ -22,7 +22,7 @@ import torch
 import torch.nn as nn
 
 from deftet_amd import hip_ops, surface_losses
-from deftet_amd.layers.DefTet.check_condition_tetrahedron_base.utils import check_condition_f_base, paste_occ
+from deftet_amd.layers.DefTet.check_condition_tetrahedron_base.utils import check_condition_f_base, paste_occ, point_in_tet_occ_vertices
 
 EPS = 1e-10
 
@@ -157,6 +157,14 @@ class DefTet(nn.Module):
 
     def paste_occ(self, pred_tet_occ, condition):
         return paste_occ(pred_tet_occ, condition)
+
+    # --- A1 + A1b + paste_occ for a caller that holds the VERTICES (build-defined, like point_in_tet_occ): the gradient of the
+    #     weights lands on vertice_pos without the dense per-tet gradient in between
+    def occupancy_query(self, vertice_pos, tetrahedron_bxfx4, point_pos_bxpx3, pred_tet_occ, tet_bxfx4x3=None):
+        """(condition [B,Q,1], weights [B,Q,4], occ [B,Q]) of the query points in the mesh (vertice_pos, tetrahedron_bxfx4);
+        tet_bxfx4x3 = self.gather_tet_pos(vertice_pos, tetrahedron_bxfx4) when the caller has it already."""
+        topo = _topology_for(tetrahedron_bxfx4, vertice_pos.shape[1])
+        return point_in_tet_occ_vertices(vertice_pos, point_pos_bxpx3, pred_tet_occ, topo, tet_bxfx4x3)
 
     # --- A11 (each call evaluates the fused kernel and returns its own component)
     def volume_variance(self, tet_bxfx4x3, base_area_mask=None, area_normalize=(20, 20), pow=2, center_occ=None):

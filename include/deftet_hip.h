@@ -355,6 +355,21 @@ int deftet_tet_gather_bwd_f32(const float *grad_tet, const int32_t *offsets, con
                               float *grad_pos, int n_batch, int n_vertex, int n_tet, int idx_batch,
                               int accumulate, void *stream);
 
+/* A1b backward composed with the gather's backward (round 6): the gradient of a caller that owns BOTH the gather
+ * (layers/DefTet/deftet.py:65-68) and the query lands on the vertices, grad_pos f32 [B,V,3] (overwritten, or added to when
+ * accumulate != 0; the flag also covers grad_pred), without the dense grad_tet [B,T,4,3] of deftet_point_in_tet_bwd_f32 +
+ * deftet_tet_gather_bwd_f32: only the rows of tets that accepted a query are written (to `workspace`) and read back.
+ * Same arguments as deftet_point_in_tet_bwd_f32 (grad_pts / grad_occ + grad_pred optional) plus the incidence CSR of
+ * deftet_tet_vertex_csr_i32.  The result equals the two-call form bit for bit (the same additions in the same order); no
+ * floating-point atomics.  Without hit_buf, or beyond two queries per tet, the per-tet lists fill dense rows in the
+ * workspace instead (same result). */
+size_t deftet_point_in_tet_bwd_to_vertices_workspace_bytes(int n_batch, int n_tet, int n_query);
+int deftet_point_in_tet_bwd_to_vertices_f32(const float *tet, const float *pts, const float *cond, const float *grad_w,
+                                            const float *grad_occ, const int32_t *hit_buf, const int32_t *csr_offsets,
+                                            const int32_t *csr_slots, int idx_batch, float *grad_pos, float *grad_pts,
+                                            float *grad_pred, int n_batch, int n_vertex, int n_tet, int n_query,
+                                            int accumulate, void *workspace, size_t workspace_bytes, void *stream);
+
 /* A11 fused per-tet energies, layers/DefTet/deftet.py:239-338: out f32 [B,3] =
  * {volume_variance(pow_v), amips_energy(inv_v f32 [T,3,3]; 0 when NULL), edge_length(pow_e)};
  * stats f64 [B,8] is produced by the forward and consumed by the backward, which writes

@@ -72,6 +72,9 @@ def run_step(m, pos, idx, f3, t2, gt_verts, gt_faces, pts, inv_v, pred, times=No
     return loss, boundary, cond
 
 
+FUSED_QUERY_BWD = os.environ.get("DEFTET_STEP_FUSED_BWD", "1") not in ("", "0")
+
+
 def run_full_step(m, pos, idxB, f3, t2, gt_verts, gt_faces, pts, inv_v, pred, gt_pts):
     """forward_surface_align (training branch) + occupancy query + backward."""
     B = pos.shape[0]
@@ -81,7 +84,10 @@ def run_full_step(m, pos, idxB, f3, t2, gt_verts, gt_faces, pts, inv_v, pred, gt
                                   gt_surface_points=gt_pts, tet_face_bxfx3=f3[None].expand(B, -1, -1),
                                   tet_face_tet_bx4fx2=t2[None].expand(B, -1, -1), tet_bxfx4x3=tet)
     amips, edge, vvar, analytic, normal, center_occ, boundary, chamfer, _ = out
-    cond, w, occ = point_in_tet_occ(tet, pts, pred)
+    if FUSED_QUERY_BWD:     # the query's gradient goes straight to the vertices (no dense per-tet gradient in between)
+        cond, w, occ = m.occupancy_query(pos, idxB, pts, pred, tet_bxfx4x3=tet)
+    else:                   # DEFTET_STEP_FUSED_BWD=0: the two-stage chain (dense dL/dtet, summed with the energies' by autograd, then the gather's backward)
+        cond, w, occ = point_in_tet_occ(tet, pts, pred)
     loss = standin_loss(w, occ, amips, edge, vvar, chamfer, analytic, normal)
     loss.backward()
     return loss, boundary
