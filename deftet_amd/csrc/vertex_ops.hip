@@ -98,17 +98,19 @@ __global__ __launch_bounds__(256) void k_gather_bwd(const float *__restrict__ gr
                 const unsigned long long w = mk[t >> 6], bit = 1ull << (t & 63);
                 return (w & bit) ? ((long long)((t & ~63) + __popcll(w & (bit - 1ull))) * 4 + (s & 3)) * 3 : -1ll;
             };
-            for (; i + 4 < s1; i += 8) {                     // two independent gathers in flight per lane
-                const long long op = where(slots[i]), oq = where(slots[i + 4]);
-                float px = 0.f, py = 0.f, pz = 0.f, qx = 0.f, qy = 0.f, qz = 0.f;
-                if (op >= 0) { px = g[op]; py = g[op + 1]; pz = g[op + 2]; }
-                if (oq >= 0) { qx = g[oq]; qy = g[oq + 1]; qz = g[oq + 2]; }
-                if (op >= 0) { ax += px; ay += py; az += pz; }
-                if (oq >= 0) { ax += qx; ay += qy; az += qz; }
-            }
-            if (i < s1) {
-                const long long op = where(slots[i]);
-                if (op >= 0) { ax += g[op]; ay += g[op + 1]; az += g[op + 2]; }
+            // four incidences in flight per lane (slot -> mask word -> row is a chain of three loads; a vertex of a Kuhn grid has
+            // ~22 incidences, five or six per lane); the additions keep the order of the dense form: i, i + 4, i + 8, ...
+            for (; i < s1; i += 16) {
+                long long o[4];
+                float r[4][3];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = i + 4 * j < s1 ? where(slots[i + 4 * j]) : -1ll;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (o[j] >= 0) { r[j][0] = g[o[j]]; r[j][1] = g[o[j] + 1]; r[j][2] = g[o[j] + 2]; }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (o[j] >= 0) { ax += r[j][0]; ay += r[j][1]; az += r[j][2]; }
             }
         } else {
             for (; i + 4 < s1; i += 8) {                     // two independent gathers in flight per lane
