@@ -55,6 +55,7 @@ SIGNATURES = {
     "deftet_tet_vertex_csr_workspace_bytes": (_sz, [_i, _i, _i]),
     "deftet_tet_vertex_csr_i32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "deftet_tet_gather_bwd_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "deftet_put_host_ints": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
     "deftet_point_in_tet_bwd_to_vertices_workspace_bytes": (_sz, [_i, _i, _i]),
     "deftet_point_in_tet_bwd_to_vertices_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _vp]),
     "deftet_rowdot_workspace_bytes": (_sz, [_i]),
@@ -161,20 +162,63 @@ def require_gpu(*tensors) -> None:
                                  "there is no CPU fallback" % t.device)
 
 
+# Host-side cost of a call matters: a geometry step (bench.py --config 5) makes ~75 library calls between ~70 torch launches and
+# was bound by the Python thread, not by the kernels (tools/probes/geometry_cpu_probe.py: 2.37 ms of host time in a 2.43 ms
+# step; tools/probes/host_call_probe.py: 11-15 us per library call against 4 us per torch elementwise launch).  So: raw stream
+# handles from torch._C (no Stream object), plain integers for pointers (ctypes converts them for c_void_p parameters), the
+# device guard only when the current device is another one, the workspace looked up without the lock when it is large enough.
 def ptr(t):
-    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+    return t.data_ptr() if t is not None else None
+
+
+try:                                                    # (private, but stable since torch 1.x; the public route is ~6x slower)
+    from torch._C import _cuda_getCurrentRawStream as _raw_stream, _cuda_getDevice as _cur_device
+except Exception:                                       # pragma: no cover
+    _raw_stream = _cur_device = None
+
+
+def _dev_index(device):
+    idx = device.index
+    if idx is None:
+        import torch
+        idx = torch.cuda.current_device()
+    return idx
 
 
 def current_stream(device):
+    """raw hipStream_t (int) of torch's current stream on `device`"""
+    if _raw_stream is not None:
+        return _raw_stream(_dev_index(device))
     import torch
-    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+class _NoGuard:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def on_device(device):
+    """`with on_device(dev):` == `with torch.cuda.device(dev):`, for free when dev is the current device already"""
+    if _cur_device is not None and (device.index is None or device.index == _cur_device()):
+        return _NO_GUARD
+    import torch
+    return torch.cuda.device(device)
 
 
 def workspace(device, nbytes: int):
     """uint8 tensor of at least nbytes on `device`, cached per (device, stream)."""
+    key = (_dev_index(device), current_stream(device))
+    buf = _ws.get(key)                                  # (a dict read is atomic; the lock is for the grow path)
+    if buf is not None and buf.numel() >= nbytes:
+        return buf
     import torch
-    key = (device.index if device.index is not None else torch.cuda.current_device(),
-           torch.cuda.current_stream(device).cuda_stream)
     with _ws_lock:
         buf = _ws.get(key)
         if buf is None or buf.numel() < nbytes:

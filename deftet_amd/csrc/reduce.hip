@@ -220,3 +220,40 @@ extern "C" int deftet_sqrt_rowsum_bwd_f32(const float *x, float eps, const float
                   deftet::as_stream(stream_), x, grad_out, grad_x, n_cols, eps);
     return DEFTET_OK;
 }
+
+// A few host integers (per-shape counts, offsets) to device memory WITHOUT a host-to-device copy: the values travel in the
+// kernel's argument block.  A copy from pageable host memory — what torch.tensor(list, device=...) issues — blocks the host
+// until the stream has drained; two of them per geometry step kept the Python thread waiting for the GPU and the GPU waiting
+// for the Python thread (tools/probes/geometry_cpu_probe.py).  Asynchronous, and legal inside a graph capture.
+namespace deftet {
+namespace red {
+constexpr int kHostInts = 64;
+struct HostInts {
+    long long v[kHostInts];
+};
+__global__ void k_put_ints(HostInts h, int n, int *o32, long long *o64, float *of)
+{
+    const int i = threadIdx.x;
+    if (i >= n) return;
+    if (o32) o32[i] = (int)h.v[i];
+    if (o64) o64[i] = h.v[i];
+    if (of) of[i] = (float)h.v[i];
+}
+}  // namespace red
+}  // namespace deftet
+
+extern "C" int deftet_put_host_ints(const long long *host_values, int n, int32_t *out_i32, long long *out_i64, float *out_f32, void *stream_)
+{
+    DEFTET_CHECK_ARG(n >= 0, "negative count");
+    if (n == 0) return DEFTET_OK;
+    DEFTET_CHECK_ARG(host_values && (out_i32 || out_i64 || out_f32), "null pointer");
+    for (int at = 0; at < n; at += deftet::red::kHostInts) {
+        deftet::red::HostInts h;
+        const int m = n - at < deftet::red::kHostInts ? n - at : deftet::red::kHostInts;
+        for (int i = 0; i < m; ++i) h.v[i] = host_values[at + i];
+        for (int i = m; i < deftet::red::kHostInts; ++i) h.v[i] = 0;
+        DEFTET_LAUNCH(deftet::red::k_put_ints, dim3(1), dim3(deftet::red::kHostInts), deftet::as_stream(stream_), h, m, out_i32 ? out_i32 + at : nullptr,
+                      out_i64 ? out_i64 + at : nullptr, out_f32 ? out_f32 + at : nullptr);
+    }
+    return DEFTET_OK;
+}

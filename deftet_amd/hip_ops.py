@@ -103,7 +103,7 @@ def query_box_key(dev, B, Q):
     dev = torch.device(dev)
     on_gpu = dev.type == "cuda" and torch.cuda.is_available()
     idx = dev.index if dev.index is not None else (torch.cuda.current_device() if on_gpu else 0)
-    return (idx, torch.cuda.current_stream(dev).cuda_stream if on_gpu else 0, B, Q)
+    return (idx, _lib.current_stream(dev) if on_gpu else 0, B, Q)
 
 
 def _tracked_boxes(dev, B, Q):
@@ -161,7 +161,7 @@ def prepare_queries(pts_bxqx3, n_tet, algo=PIT_AUTO, query_box=None, query_box_m
         raise RuntimeError("point_pos_bxnx3 must be [B,Q,3], got %s" % (tuple(pts.shape),))
     B, Q, dev = pts.shape[0], pts.shape[1], pts.device
     pq = PreparedQueries(pts, n_tet, algo)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         nbytes = max(lib.deftet_point_in_tet_workspace_bytes(B, pq.n_tet, Q, algo), 256)
         pq.workspace = torch.empty(nbytes, device=dev, dtype=torch.uint8)       # private: outlives the cached per-stream workspace
         box_in, box_out, box_miss = _resolve_query_box(query_box, dev, B, Q, algo, query_box_misses)
@@ -186,7 +186,7 @@ def tet_spatial_order(tet_tx4x3, want_breaks=False):
     T, dev = tet.shape[0], tet.device
     order = torch.empty(T, device=dev, dtype=torch.int32)
     breaks = torch.zeros(2, device=dev, dtype=torch.int32)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         ws = _lib.workspace(dev, max(lib.deftet_tet_spatial_order_workspace_bytes(T), 256))
         _lib.check(lib.deftet_tet_spatial_order_f32(_lib.ptr(tet), T, _lib.ptr(order), _lib.ptr(breaks), _lib.ptr(ws), ws.numel(),
                                                     _lib.current_stream(dev)), "deftet_tet_spatial_order_f32")
@@ -211,7 +211,7 @@ def tet_order_coherence(tet_tx4x3, order=None, out=None):
         out = torch.empty(2, device=dev, dtype=torch.int32)
     elif out.dtype != torch.int32 or out.numel() < 2 or not out.is_contiguous():
         raise RuntimeError("out must be a contiguous int32 tensor of at least 2 entries")
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         ws = _lib.workspace(dev, max(lib.deftet_tet_order_coherence_workspace_bytes(T), 256))
         _lib.check(lib.deftet_tet_order_coherence_f32(_lib.ptr(tet), T, _lib.ptr(order), _lib.ptr(out), _lib.ptr(ws), ws.numel(),
                                                       _lib.current_stream(dev)), "deftet_tet_order_coherence_f32")
@@ -421,7 +421,7 @@ def point_in_tet(tet_bxtx4x3, pts_bxqx3, want_bary=False, algo=PIT_AUTO, pred_bx
         if order.dtype != torch.int32 or order.shape != (T,) or not order.is_contiguous() or order.device != dev:
             raise RuntimeError("order must be a contiguous int32 [T] tensor on the tets' device")
         _check_order(order, T)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         if prepared is not None:
             if prepared.consumed or prepared.algo != algo or prepared.n_tet != T or prepared.pts.data_ptr() != pts.data_ptr() \
                     or prepared.pts.shape != pts.shape:
@@ -463,7 +463,7 @@ def point_in_tet_stats(B, T, Q, algo, device):
     lib = _lib.load()
     dev = torch.device(device)
     out = np.zeros((B, 8), np.int32)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         ws = _lib.workspace(dev, lib.deftet_point_in_tet_workspace_bytes(B, T, Q, algo))
         _lib.check(lib.deftet_point_in_tet_read_stats(_lib.ptr(ws), ws.numel(), B, T, Q, algo, out.ctypes.data, _lib.current_stream(dev)),
                    "deftet_point_in_tet_read_stats")
@@ -490,7 +490,7 @@ def point_in_tet_bwd(tet_bxtx4x3, pts_bxqx3, cond, grad_w, want_grad_pts=False, 
     grad_pts = torch.empty_like(pts) if want_grad_pts else None
     go = _f32c(grad_occ) if grad_occ is not None else None
     grad_pred = torch.empty(B, T, device=dev, dtype=torch.float32) if go is not None else None
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         ws = _lib.workspace(dev, lib.deftet_point_in_tet_bwd_workspace_bytes(B, T, Q))
         _lib.check(lib.deftet_point_in_tet_bwd_f32(_lib.ptr(tet), _lib.ptr(pts), _lib.ptr(cond), _lib.ptr(gw),
                                                    _lib.ptr(grad_tet), _lib.ptr(grad_pts), _lib.ptr(go), _lib.ptr(grad_pred),
@@ -524,7 +524,7 @@ def point_in_tet_bwd_to_vertices(tet_bxtx4x3, pts_bxqx3, cond, grad_w, csr, n_ve
     go = _f32c(grad_occ) if grad_occ is not None else None
     # (`accumulate` of the C entry covers grad_pos AND grad_pred: a fresh grad_pred must then start from zero)
     grad_pred = (torch.zeros if acc else torch.empty)(B, T, device=dev, dtype=torch.float32) if go is not None else None
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         ws = _lib.workspace(dev, lib.deftet_point_in_tet_bwd_to_vertices_workspace_bytes(B, T, Q))
         _lib.check(lib.deftet_point_in_tet_bwd_to_vertices_f32(_lib.ptr(tet), _lib.ptr(pts), _lib.ptr(cond), _lib.ptr(gw), _lib.ptr(go),
                                                                _lib.ptr(hits), _lib.ptr(offsets), _lib.ptr(slots), Bi, _lib.ptr(grad_pos),
@@ -545,7 +545,7 @@ def paste_occ_fwd(pred_bxt, cond_bxqx1, clamp_inplace=True):
     B, T = pred.shape
     Q = cond_bxqx1.shape[1]
     out = torch.empty(B, Q, device=pred.device, dtype=torch.float32)
-    with torch.cuda.device(pred.device):
+    with _lib.on_device(pred.device):
         _lib.check(lib.deftet_paste_occ_fwd_f32(_lib.ptr(pred), _lib.ptr(cond_bxqx1), _lib.ptr(out), B, T, Q,
                                                 int(clamp_inplace), _lib.current_stream(pred.device)),
                    "deftet_paste_occ_fwd_f32")
@@ -558,7 +558,7 @@ def paste_occ_bwd(cond_bxqx1, grad_out_bxq, n_tet):
     cond, go = _f32c(cond_bxqx1), _f32c(grad_out_bxq)
     B, Q = go.shape
     gp = torch.empty(B, n_tet, device=go.device, dtype=torch.float32)
-    with torch.cuda.device(go.device):
+    with _lib.on_device(go.device):
         _lib.check(lib.deftet_paste_occ_bwd_f32(_lib.ptr(cond), _lib.ptr(go), _lib.ptr(gp), B, n_tet, Q, 1,
                                                 _lib.current_stream(go.device)), "deftet_paste_occ_bwd_f32")
     return gp
@@ -584,7 +584,7 @@ def radix_sort(keys, values=None, bits=None, n_valid=None):
         raise RuntimeError("radix_sort: values must have the keys' length and 4- or 8-byte elements")
     ko = torch.empty_like(k)
     vo = torch.empty_like(v) if v is not None else None
-    with torch.cuda.device(k.device):
+    with _lib.on_device(k.device):
         ws = _lib.workspace(k.device, lib.deftet_radix_sort_workspace_bytes(n, kb, vb))
         _lib.check(lib.deftet_radix_sort(_lib.ptr(k), _lib.ptr(ko), _lib.ptr(v), _lib.ptr(vo), n, kb, vb, int(bits or kb * 8),
                                          _lib.ptr(n_valid), _lib.ptr(ws), ws.numel(), _lib.current_stream(k.device)), "deftet_radix_sort")
@@ -599,7 +599,7 @@ def scan(x, kind="exclusive"):
     if t.dtype not in (torch.int32, torch.int64):
         raise RuntimeError("scan: int32 or int64")
     out = torch.empty_like(t)
-    with torch.cuda.device(t.device):
+    with _lib.on_device(t.device):
         ws = _lib.workspace(t.device, lib.deftet_scan_workspace_bytes(t.numel(), t.element_size()))
         _lib.check(lib.deftet_scan(_lib.ptr(t), _lib.ptr(out), t.numel(), t.element_size(), {"exclusive": 0, "inclusive": 1, "max": 2}[kind],
                                    _lib.ptr(ws), ws.numel(), _lib.current_stream(t.device)), "deftet_scan")
@@ -626,7 +626,7 @@ def rowdot(a, b=None, a2=None, b2=None):
     elif b2 is not None:
         raise RuntimeError("rowdot: b2 without a2")
     out = torch.empty(R, device=a.device, dtype=torch.float32)
-    with torch.cuda.device(a.device):
+    with _lib.on_device(a.device):
         ws = _lib.workspace(a.device, lib.deftet_rowdot_workspace_bytes(R))
         _lib.check(lib.deftet_rowdot2_f32(_lib.ptr(a), _lib.ptr(b), a.numel() // max(R, 1), _lib.ptr(a2), _lib.ptr(b2), n2,
                                           _lib.ptr(out), R, _lib.ptr(ws), ws.numel(), _lib.current_stream(a.device)),
@@ -650,7 +650,7 @@ class _SqrtRowSum(torch.autograd.Function):
         if x.numel() == 0:
             return torch.zeros(R, device=x.device, dtype=torch.float32)
         out = torch.empty(R, device=x.device, dtype=torch.float32)
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             ws = _lib.workspace(x.device, lib.deftet_rowdot_workspace_bytes(R))
             _lib.check(lib.deftet_sqrt_rowsum_f32(_lib.ptr(x), float(eps), _lib.ptr(out), R, x.numel() // max(R, 1), _lib.ptr(ws), ws.numel(),
                                                   _lib.current_stream(x.device)), "deftet_sqrt_rowsum_f32")
@@ -665,7 +665,7 @@ class _SqrtRowSum(torch.autograd.Function):
         if x.numel() == 0:
             return gx, None
         R = x.shape[0]
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             _lib.check(lib.deftet_sqrt_rowsum_bwd_f32(_lib.ptr(x), ctx.eps, _lib.ptr(g), _lib.ptr(gx), R, x.numel() // max(R, 1),
                                                       _lib.current_stream(x.device)), "deftet_sqrt_rowsum_bwd_f32")
         return gx, None
@@ -699,7 +699,7 @@ def tet_adj_share(tet_list, n_point, device):
     T = tet.shape[0]
     out = torch.empty(max(T * 8, 1), 3, dtype=torch.int32, device=dev)
     n = torch.zeros(1, dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         ws = _builder_ws(lib, dev, n_point, T)
         _lib.check(lib.deftet_tet_adj_share_i32(_lib.ptr(tet), _lib.ptr(out), _lib.ptr(n), int(n_point), T, _lib.ptr(ws),
                                                 ws.numel(), _lib.current_stream(dev)), "deftet_tet_adj_share_i32")
@@ -714,7 +714,7 @@ def tet_face_adj(tet_list, n_point, device, wrap32=True):
     _lib.require_gpu(tet)
     T = tet.shape[0]
     n = torch.zeros(1, dtype=torch.int64, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         ws = _builder_ws(lib, dev, n_point, T)
         st = _lib.current_stream(dev)
         _lib.check(lib.deftet_tet_face_adj_i32(_lib.ptr(tet), None, 0, _lib.ptr(n), int(n_point), T, int(wrap32),
@@ -735,7 +735,7 @@ def tet_point_adj(tet_list, n_point, device):
     T = tet.shape[0]
     out = torch.empty(max(T * 12, 1), 2, dtype=torch.int32, device=dev)
     n = torch.zeros(1, dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         ws = _builder_ws(lib, dev, n_point, T)
         _lib.check(lib.deftet_tet_point_adj_i32(_lib.ptr(tet), _lib.ptr(out), _lib.ptr(n), int(n_point), T, _lib.ptr(ws),
                                                 ws.numel(), _lib.current_stream(dev)), "deftet_tet_point_adj_i32")
@@ -752,7 +752,7 @@ def colaps_v(points_nx3):
     m = torch.empty(max(N, 1), dtype=torch.int32, device=dev)
     inv = torch.empty(max(N, 1), dtype=torch.int32, device=dev)
     n = torch.zeros(1, dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         ws = _builder_ws(lib, dev, N, 0)
         _lib.check(lib.deftet_colaps_v_f32(_lib.ptr(pts), _lib.ptr(m), _lib.ptr(inv), _lib.ptr(n), N, _lib.ptr(ws), ws.numel(),
                                            _lib.current_stream(dev)), "deftet_colaps_v_f32")
@@ -773,7 +773,7 @@ def tet_to_face(tet_list, n_point, device, with_boundary=False):
     tf2 = torch.empty(cap, 2, dtype=torch.int64, device=dev)
     b3 = torch.empty(cap, 3, dtype=torch.int64, device=dev)
     counts = torch.zeros(3, dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         ws = _builder_ws(lib, dev, n_point, T)
         _lib.check(lib.deftet_tet_to_face_i32(_lib.ptr(tet), _lib.ptr(f3), _lib.ptr(t2), _lib.ptr(tf2), _lib.ptr(b3),
                                               _lib.ptr(counts), int(n_point), T, int(with_boundary), _lib.ptr(ws), ws.numel(),
@@ -795,7 +795,7 @@ def tet_neighbours(tet_list, n_point, device, want_face_owners=False):
     T = int(torch.as_tensor(tet_list).shape[0])
     nbr = torch.empty(T, 4, dtype=torch.int64, device=dev)
     owners = torch.empty(T * 4, 2, dtype=torch.int64, device=dev) if want_face_owners else None
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         ws = _lib.workspace(dev, lib.deftet_tet_neighbours_workspace_bytes(T))
         _lib.check(lib.deftet_tet_neighbours_i64(_lib.ptr(t2), _lib.ptr(tf2), int(t2.shape[0]), T, _lib.ptr(nbr), _lib.ptr(owners),
                                                  _lib.ptr(ws), ws.numel(), _lib.current_stream(dev)), "deftet_tet_neighbours_i64")
@@ -811,12 +811,31 @@ def face_edge_adj(face_fx3x3, n_max_nei=30, brute=False):
     face = _f32c(face_fx3x3)
     F = face.shape[0]
     adj = torch.full((F, n_max_nei), -1.0, device=face.device, dtype=torch.float32)    # utils.py:47
-    with torch.cuda.device(face.device):
+    with _lib.on_device(face.device):
         ws = None if brute else _lib.workspace(face.device, lib.deftet_face_edge_adj_workspace_bytes(F))
         _lib.check(lib.deftet_face_edge_adj_f32(_lib.ptr(face), _lib.ptr(adj), F, n_max_nei, _lib.ptr(ws),
                                                 ws.numel() if ws is not None else 0, _lib.current_stream(face.device)),
                    "deftet_face_edge_adj_f32")
     return adj
+
+
+def host_ints(values, device, i32=False, i64=False, f32=False):
+    """Device tensors holding a few HOST integers (per-shape counts, offsets), one per requested dtype, in the order
+    (int32, int64, float32).  The values travel in a kernel's argument block (deftet_put_host_ints): no copy from pageable
+    host memory — torch.tensor(list, device=...) blocks the Python thread until the stream has drained — and one launch for
+    all dtypes."""
+    import ctypes
+    vals = [int(v) for v in values]
+    n = len(vals)
+    outs = [torch.empty(n, device=device, dtype=dt) if want else None
+            for want, dt in ((i32, torch.int32), (i64, torch.int64), (f32, torch.float32))]
+    if n and any(o is not None for o in outs):
+        lib = _lib.load()
+        with _lib.on_device(torch.device(device)):
+            _lib.check(lib.deftet_put_host_ints((ctypes.c_longlong * n)(*vals), n, _lib.ptr(outs[0]), _lib.ptr(outs[1]), _lib.ptr(outs[2]),
+                                                _lib.current_stream(torch.device(device))), "deftet_put_host_ints")
+    got = tuple(o for o in outs if o is not None)
+    return got[0] if len(got) == 1 else got
 
 
 def _host_counts(counts, B, hi, what):
@@ -836,7 +855,7 @@ def face_edge_adj_ragged(face_bxfx3x3, n_face, n_max_nei=30, brute=False):
     B, F = face.shape[0], face.shape[1]
     cnt = _host_counts(n_face, B, F, "face_edge_adj_ragged")
     adj = torch.full((B, F, n_max_nei), -1.0, device=face.device, dtype=torch.float32)
-    with torch.cuda.device(face.device):
+    with _lib.on_device(face.device):
         ws = None if brute else _lib.workspace(face.device, lib.deftet_face_edge_adj_ragged_workspace_bytes(B, F))
         _lib.check(lib.deftet_face_edge_adj_ragged_f32(_lib.ptr(face), _lib.ptr(adj), B, F, cnt, n_max_nei, _lib.ptr(ws),
                                                        ws.numel() if ws is not None else 0, _lib.current_stream(face.device)),
@@ -852,7 +871,7 @@ def nn_index_ragged(queries_bxnx3, points_bxmx3, n_query, brute=False):
     B, N, M = q.shape[0], q.shape[1], p.shape[1]
     cnt = _host_counts(n_query, B, N, "nn_index_ragged")
     out = torch.zeros(B, N, device=q.device, dtype=torch.int32)
-    with torch.cuda.device(q.device):
+    with _lib.on_device(q.device):
         ws = None if brute else _lib.workspace(q.device, lib.deftet_nn_index_workspace_bytes(B, N, M))
         _lib.check(lib.deftet_nn_index_ragged_f32(_lib.ptr(q), _lib.ptr(p), _lib.ptr(out), B, N, M, cnt, _lib.ptr(ws),
                                                   ws.numel() if ws is not None else 0, _lib.current_stream(q.device)),
@@ -873,13 +892,13 @@ class _ChamferToCloud(torch.autograd.Function):
         r = torch.rand(2, B, F, K, device=dev, generator=generator) if uv is None else _f32c(uv).reshape(2, B, F, K)
         samples = torch.empty(B, F * K, 3, device=dev, dtype=torch.float32)
         st = _lib.current_stream(dev)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             _lib.check(lib.deftet_face_samples_f32(_lib.ptr(tri), _lib.ptr(r), _lib.ptr(samples), B, F, K, st), "deftet_face_samples_f32")
         n_valid = [int(c) * K for c in counts]
         idx = nn_index_ragged(samples, gt, n_valid)
-        nv = torch.tensor(n_valid, device=dev, dtype=torch.int32)
+        nv = host_ints(n_valid, dev, i32=True)                        # (not torch.tensor(..., device=dev): that copy blocks until the stream drains)
         d = torch.empty(B, F * K, device=dev, dtype=torch.float32)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             _lib.check(lib.deftet_chamfer_fwd_f32(_lib.ptr(samples), _lib.ptr(gt), _lib.ptr(idx), _lib.ptr(nv), _lib.ptr(d), B, F * K, M, st),
                        "deftet_chamfer_fwd_f32")
         ctx.save_for_backward(samples, gt, idx, nv, d, r)
@@ -893,7 +912,7 @@ class _ChamferToCloud(torch.autograd.Function):
         lib = _lib.load()
         g = _f32c(grad_sum)
         grad_tri = torch.empty(B, F, 3, 3, device=samples.device, dtype=torch.float32)
-        with torch.cuda.device(samples.device):
+        with _lib.on_device(samples.device):
             _lib.check(lib.deftet_chamfer_bwd_f32(_lib.ptr(samples), _lib.ptr(gt), _lib.ptr(idx), _lib.ptr(nv), _lib.ptr(d), _lib.ptr(r),
                                                   _lib.ptr(g), _lib.ptr(grad_tri), B, F, K, M, _lib.current_stream(samples.device)),
                        "deftet_chamfer_bwd_f32")
@@ -920,7 +939,7 @@ class _NormalConsistency(torch.autograd.Function):
         loss = torch.empty(B, device=tri.device, dtype=torch.float32)
         nrm = torch.empty(B, F, 3, device=tri.device, dtype=torch.float32)
         cnt = torch.empty(B, device=tri.device, dtype=torch.float32)
-        with torch.cuda.device(tri.device):
+        with _lib.on_device(tri.device):
             _lib.check(lib.deftet_normal_consistency_fwd_f32(_lib.ptr(tri), _lib.ptr(adj), _lib.ptr(n_face), _lib.ptr(loss), _lib.ptr(nrm),
                                                              _lib.ptr(cnt), B, F, K, _lib.current_stream(tri.device)),
                        "deftet_normal_consistency_fwd_f32")
@@ -934,7 +953,7 @@ class _NormalConsistency(torch.autograd.Function):
         B, F, K = tri.shape[0], tri.shape[1], adj.shape[2]
         gtri = torch.empty_like(tri)
         acc = torch.empty(B, F, 3, device=tri.device, dtype=torch.float32)
-        with torch.cuda.device(tri.device):
+        with _lib.on_device(tri.device):
             _lib.check(lib.deftet_normal_consistency_bwd_f32(_lib.ptr(tri), _lib.ptr(adj), _lib.ptr(n_face), _lib.ptr(nrm), _lib.ptr(cnt),
                                                              _lib.ptr(_f32c(g)), _lib.ptr(gtri), _lib.ptr(acc), B, F, K,
                                                              _lib.current_stream(tri.device)), "deftet_normal_consistency_bwd_f32")
@@ -962,7 +981,7 @@ def tri_dist_fwd(pts_bxpx3, face_bxfx3x3, n_face_b, brute=False, want_order=Fals
     order = None
     if want_order and not brute and face.shape[1] > 0 and B * P > 0:
         order = torch.empty(B, P, device=pts.device, dtype=torch.int32)
-    with torch.cuda.device(pts.device):
+    with _lib.on_device(pts.device):
         ws = None if brute else _lib.workspace(pts.device, lib.deftet_tri_dist_workspace_bytes(B, P, face.shape[1]))
         _lib.check(lib.deftet_tri_dist_fwd_order_f32(_lib.ptr(pts), _lib.ptr(face), _lib.ptr(nfb), _lib.ptr(d), _lib.ptr(f),
                                                      _lib.ptr(order), B, P, face.shape[1], _lib.ptr(ws),
@@ -979,7 +998,7 @@ def tri_dist_bwd(pts_bxpx3, face_bxfx3x3, closest_f, dl_dd, deterministic=False,
     pts, face, cf, g = _f32c(pts_bxpx3), _f32c(face_bxfx3x3), _f32c(closest_f), _f32c(dl_dd)
     B, P, F = pts.shape[0], pts.shape[1], face.shape[1]
     out = torch.zeros(B, F, 3, 3, device=pts.device, dtype=torch.float32)               # utils.py:65
-    with torch.cuda.device(pts.device):
+    with _lib.on_device(pts.device):
         if order is not None and not deterministic:
             _lib.check(lib.deftet_tri_dist_bwd_order_f32(_lib.ptr(pts), _lib.ptr(face), _lib.ptr(cf), _lib.ptr(g),
                                                          _lib.ptr(order.contiguous()), _lib.ptr(out), B, P, F,
@@ -998,7 +1017,7 @@ def nn_index(queries_bxnx3, points_bxmx3, brute=False):
     q, p = _f32c(queries_bxnx3), _f32c(points_bxmx3)
     B, N, M = q.shape[0], q.shape[1], p.shape[1]
     out = torch.zeros(B, N, device=q.device, dtype=torch.int32)                         # nearest_neighbor.py:32-33
-    with torch.cuda.device(q.device):
+    with _lib.on_device(q.device):
         ws = None if brute else _lib.workspace(q.device, lib.deftet_nn_index_workspace_bytes(B, N, M))
         _lib.check(lib.deftet_nn_index_f32(_lib.ptr(q), _lib.ptr(p), _lib.ptr(out), B, N, M, _lib.ptr(ws),
                                            ws.numel() if ws is not None else 0, _lib.current_stream(q.device)),
@@ -1021,7 +1040,7 @@ def check_sign(verts_bxvx3, faces_fx3, points_bxnx3, brute=False, return_count=F
     cnt = torch.empty(B, N, device=dev, dtype=torch.int32) if return_count else None
     bad = torch.zeros(1, device=dev, dtype=torch.int32)
     algo = 1 if brute else 0
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         ws = _lib.workspace(dev, lib.deftet_check_sign_workspace_bytes(B, F, algo))
         _lib.check(lib.deftet_check_sign_f32(_lib.ptr(v), _lib.ptr(f), _lib.ptr(p), _lib.ptr(out), _lib.ptr(cnt), _lib.ptr(bad), B, V, F, N,
                                              algo, _lib.ptr(ws), ws.numel(), _lib.current_stream(dev)), "deftet_check_sign_f32")
@@ -1051,7 +1070,7 @@ def check_sign_ragged(verts_list, faces_list, points_bxnx3, brute=False, return_
     bad = torch.zeros(1, device=dev, dtype=torch.int32)
     algo = 1 if brute else 0
     ftot, fmax = int(sum(f_cnt)), int(max(f_cnt) if f_cnt else 0)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         ws = _lib.workspace(dev, lib.deftet_check_sign_ragged_workspace_bytes(B, ftot, fmax, algo))
         _lib.check(lib.deftet_check_sign_ragged_f32(_lib.ptr(v_cat), _lib.ptr(v_off), _lib.ptr(f_cat), _lib.ptr(f_off), _lib.ptr(p),
                                                     _lib.ptr(out), _lib.ptr(cnt), _lib.ptr(bad), B, ftot, fmax, N, algo, _lib.ptr(ws),
@@ -1080,7 +1099,7 @@ def tet_edges(tet_tx4, n_point):
     edges = torch.empty(max(6 * T, 1), 2, device=dev, dtype=torch.int64)
     tet_edge = torch.empty(T, 6, device=dev, dtype=torch.int64)
     cnt = torch.zeros(2, device=dev, dtype=torch.int32)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         ws = _builder_ws(lib, dev, n_point, T)
         _lib.check(lib.deftet_tet_edges_i64(_lib.ptr(tet), _lib.ptr(edges), _lib.ptr(tet_edge), _lib.ptr(cnt), _lib.ptr(cnt[1:]),
                                             int(n_point), T, _lib.ptr(ws), ws.numel(), _lib.current_stream(dev)), "deftet_tet_edges_i64")
@@ -1109,7 +1128,7 @@ def subdivide(tet_tx4, points_px3, feat_pxk, subdiv_sig=None):
     fn = torch.empty(P + E, K, device=dev, dtype=torch.float32)
     tn = torch.empty(max(8 * T, 1), 4, device=dev, dtype=torch.int64)
     cnt = torch.zeros(1, device=dev, dtype=torch.int32)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         ws = _builder_ws(lib, dev, P, T)
         _lib.check(lib.deftet_subdivide_f32(_lib.ptr(tet), _lib.ptr(tet_edge), _lib.ptr(edges), _lib.ptr(pts), _lib.ptr(feat), _lib.ptr(sig),
                                             _lib.ptr(pn), _lib.ptr(fn), _lib.ptr(tn), _lib.ptr(cnt), P, T, E, K,
@@ -1127,7 +1146,7 @@ def point_adj_idx(n_point, tet_tx4):
     n = pairs.shape[0]
     adjsum = torch.zeros(P, 1, device=dev, dtype=torch.float32)
     mx = torch.zeros(1, device=dev, dtype=torch.int32)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         ws = _lib.workspace(dev, (P + 1) * 4 + 256)
         args = (_lib.ptr(pairs), n, P)
         _lib.check(lib.deftet_point_adj_table_i64(*args, None, 0, _lib.ptr(adjsum), _lib.ptr(mx), _lib.ptr(ws), ws.numel(),
@@ -1150,7 +1169,7 @@ def delete_tet(tet_tx4, tet_weights_txk, thres=0.01):
         raise RuntimeError("delete_tet: weights [T,k] expected")
     out = torch.empty(max(T, 1), 4, device=dev, dtype=torch.int64)
     cnt = torch.zeros(1, device=dev, dtype=torch.int32)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         ws = _builder_ws(lib, dev, 0, T)
         _lib.check(lib.deftet_delete_tet_i64(_lib.ptr(tet), _lib.ptr(w), float(np.float32(thres)), _lib.ptr(out), _lib.ptr(cnt), T, w.shape[1],
                                              _lib.ptr(ws), ws.numel(), _lib.current_stream(dev)), "deftet_delete_tet_i64")
@@ -1166,7 +1185,7 @@ def tet_neighbour_weights(tet_weights_txk, tet_neighbour_idx_tx4, neilevel=1):
     T = w.shape[0]
     if nei.shape != (T, 4):
         raise RuntimeError("tet_neighbour_weights: neighbour index [T,4] expected")
-    with torch.cuda.device(w.device):
+    with _lib.on_device(w.device):
         for _ in range(int(neilevel)):
             K = w.shape[1]
             out = torch.empty(T, 4 * K, device=w.device, dtype=torch.float32)
@@ -1197,7 +1216,7 @@ def tet_gather(pos_bxvx3, tet_idx, check=False):
         raise RuntimeError("tet_gather: pos [B,V,3] and tet_idx [T,4] or [B,T,4] expected")
     out = torch.empty(B, T, 4, 3, device=pos.device, dtype=torch.float32)
     bad = torch.zeros(1, device=pos.device, dtype=torch.int32) if check else None
-    with torch.cuda.device(pos.device):
+    with _lib.on_device(pos.device):
         _lib.check(lib.deftet_tet_gather_fwd_f32(_lib.ptr(pos), _lib.ptr(idx), _lib.ptr(out), _lib.ptr(bad), B, V, T, idx.shape[0],
                                                  _lib.current_stream(pos.device)), "deftet_tet_gather_fwd_f32")
     if check and int(bad.item()):
@@ -1216,7 +1235,7 @@ def tet_vertex_csr(tet_idx, n_vertex):
     offsets = torch.empty(Bi * V + 1, device=dev, dtype=torch.int32)
     slots = torch.empty(Bi * T * 4, device=dev, dtype=torch.int32)
     bad = torch.zeros(1, device=dev, dtype=torch.int32)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         ws = _lib.workspace(dev, lib.deftet_tet_vertex_csr_workspace_bytes(Bi, V, T))
         _lib.check(lib.deftet_tet_vertex_csr_i32(_lib.ptr(idx), _lib.ptr(offsets), _lib.ptr(slots), _lib.ptr(bad), Bi, V, T,
                                                  _lib.ptr(ws), ws.numel(), _lib.current_stream(dev)), "deftet_tet_vertex_csr_i32")
@@ -1239,7 +1258,7 @@ def tet_gather_bwd(grad_tet_bxtx4x3, csr, n_vertex, out=None):
     if acc and (out.shape != (B, V, 3) or out.dtype != torch.float32 or not out.is_contiguous()):
         raise RuntimeError("tet_gather_bwd: out must be contiguous f32 [B,V,3]")
     gp = out if acc else torch.empty(B, V, 3, device=g.device, dtype=torch.float32)
-    with torch.cuda.device(g.device):
+    with _lib.on_device(g.device):
         _lib.check(lib.deftet_tet_gather_bwd_f32(_lib.ptr(g), _lib.ptr(offsets), _lib.ptr(slots), _lib.ptr(gp), B, V, T, Bi,
                                                  1 if acc else 0, _lib.current_stream(g.device)), "deftet_tet_gather_bwd_f32")
     return gp
@@ -1259,7 +1278,7 @@ def boundary_index(tet_face_fx3, tet_idx_fx2, occ_bxn, mode=1):
     dev = occ.device
     out = torch.empty(max(B * Fi, 1), 3, dtype=torch.int64, device=dev)
     offs = torch.zeros(B + 1, dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         ws = _lib.workspace(dev, lib.deftet_boundary_index_workspace_bytes(B, Fi))
         _lib.check(lib.deftet_boundary_index_i64(_lib.ptr(face), _lib.ptr(tidx), _lib.ptr(occ), _lib.ptr(out), _lib.ptr(offs),
                                                  B, T, Fi, mode, _lib.ptr(ws), ws.numel(), _lib.current_stream(dev)),
@@ -1279,7 +1298,7 @@ class _TetEnergies(torch.autograd.Function):
         dev = tet.device
         out = torch.empty(B, 3, device=dev, dtype=torch.float32)
         stats = torch.empty(B, 8, device=dev, dtype=torch.float64)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             ws = _lib.workspace(dev, lib.deftet_tet_energies_workspace_bytes2(B, T))
             _lib.check(lib.deftet_tet_energies_fwd_f32(_lib.ptr(tet), _lib.ptr(inv), _lib.ptr(out), _lib.ptr(stats), B, T,
                                                        int(pow_v), int(pow_e), float(scale), _lib.ptr(ws), ws.numel(),
@@ -1296,7 +1315,7 @@ class _TetEnergies(torch.autograd.Function):
         g = _f32c(grad_out)
         B, T = tet.shape[0], tet.shape[1]
         grad_tet = torch.empty_like(tet)
-        with torch.cuda.device(tet.device):
+        with _lib.on_device(tet.device):
             _lib.check(lib.deftet_tet_energies_bwd_f32(_lib.ptr(tet), _lib.ptr(inv) if has_inv else None, _lib.ptr(stats),
                                                        _lib.ptr(g), _lib.ptr(grad_tet), B, T, pow_v, pow_e, scale,
                                                        _lib.current_stream(tet.device)), "deftet_tet_energies_bwd_f32")

@@ -35,7 +35,7 @@ class _SparseRender(Function):
         dev = pix.device
         feat = torch.empty(B, P, knum, D, device=dev, dtype=torch.float32)
         face = torch.empty(B, P, knum, device=dev, dtype=torch.int64)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             ws = _lib.workspace(dev, lib.deftet_sparse_render_workspace_bytes(B, P, F, knum))
             _lib.check(lib.deftet_sparse_render_fwd_policy_f32(_lib.ptr(pix), _lib.ptr(rng), _lib.ptr(fz), _lib.ptr(fxy), _lib.ptr(ff),
                                                                _lib.ptr(feat), _lib.ptr(face), _lib.ptr(None), B, P, F, D, knum, eps,
@@ -61,7 +61,7 @@ class _SparseRender(Function):
         gxy = torch.empty_like(fxy)
         gff = torch.empty_like(ff)
         dev = pix.device
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             ws = _lib.workspace(dev, lib.deftet_sparse_render_bwd_workspace_bytes(B, P, F, knum))
             _lib.check(lib.deftet_sparse_render_bwd_f32(_lib.ptr(pix), _lib.ptr(fxy), _lib.ptr(ff), _lib.ptr(face), _lib.ptr(None),
                                                         _lib.ptr(g), _lib.ptr(gxy), _lib.ptr(gff), B, P, F, D, knum, ctx.eps,

@@ -116,13 +116,17 @@ def surface_terms_batched(vertices_bxnx3, boundary_list, gt_points_bxmx3, per_fa
     the reference drew (sqrt-warp on uv[0], mesh_utils.py:296-298) the sample points are the reference's."""
     B, dev = vertices_bxnx3.shape[0], vertices_bxnx3.device
     counts = [int(f.shape[0]) for f in boundary_list]
-    one = torch.ones(B, device=dev)
     f_max = max(counts) if counts else 0
     if f_max == 0:
-        return torch.ones(3, B, device=dev) if stacked else (one, one.clone(), one.clone())
+        return torch.ones(3, B, device=dev) if stacked else tuple(torch.ones(B, device=dev) for _ in range(3))
     faces = torch.nn.utils.rnn.pad_sequence([f.long() for f in boundary_list], batch_first=True)      # [B,F_max,3], zeros beyond F_b
-    n_face = torch.tensor(counts, device=dev)
-    empty = n_face == 0
+    # The per-shape counts (and the sample counts of the chamfer mean) reach the device through a kernel's argument block,
+    # not through torch.tensor(counts, device=dev): that is a copy from pageable host memory, which blocks the Python thread
+    # until the stream has drained — it made this function a synchronisation point twice per step.
+    n_i32, n_f32 = hip_ops.host_ints(counts + [max(c * per_face, 1) for c in counts], dev, i32=True, f32=True)
+    n_face, n_face_f, n_sample_f = n_i32[:B], n_f32[:B], n_f32[B:]
+    any_empty = min(counts) == 0                                                                       # (host-side: no synchronisation)
+    empty = n_face == 0 if any_empty else None
     tri = corners(vertices_bxnx3, faces)
     # normal consistency (A8 table + one fused launch per direction)
     with torch.no_grad():
@@ -132,13 +136,14 @@ def surface_terms_batched(vertices_bxnx3, boundary_list, gt_points_bxmx3, per_fa
     gt = gt_points_bxmx3.reshape(B, -1, 3)
     # (sample placement, distance to the nearest cloud point and the gradient back to the corners: three HIP launches
     # around the A10 search instead of ~45 elementwise ones)
-    chamfer = hip_ops.chamfer_to_cloud(tri, gt, counts, per_face, generator, uv) / (n_face * per_face).clamp(min=1)
+    chamfer = hip_ops.chamfer_to_cloud(tri, gt, counts, per_face, generator, uv) / n_sample_f
     # analytic: ground-truth cloud -> predicted surface (A9)
-    d2, _ = tet_analytic_distance_f_batch(gt, tri, n_face.float())
-    if min(counts) == 0:                                                                               # (host-side: no synchronisation)
+    d2, _ = tet_analytic_distance_f_batch(gt, tri, n_face_f)
+    if any_empty:
         d2 = torch.where(empty[:, None, None], torch.zeros_like(d2), d2)
     # sqrt(d^2 + 1e-10) and the mean over the points in one launch (one more for the backward) instead of six + six
     analytic = hip_ops.sqrt_rowsum(d2, SQRT_EPS) / max(d2[0].numel(), 1)
     terms = torch.stack((chamfer, analytic, normal))                                                   # [3,B]
-    terms = torch.where(empty[None, :], torch.ones_like(terms), terms)
+    if any_empty:
+        terms = torch.where(empty[None, :], torch.ones_like(terms), terms)
     return terms if stacked else (terms[0], terms[1], terms[2])

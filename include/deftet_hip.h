@@ -203,6 +203,10 @@ int deftet_sqrt_rowsum_f32(const float *x, float eps, float *out, int n_rows, lo
                            size_t workspace_bytes, void *stream);
 int deftet_sqrt_rowsum_bwd_f32(const float *x, float eps, const float *grad_out, float *grad_x, int n_rows,
                                long long n_cols, void *stream);
+/* n HOST integers (per-shape counts, offsets) written to device arrays (any of out_i32 / out_i64 / out_f32, each [n] or NULL)
+ * by a kernel that carries them in its argument block: asynchronous — unlike a copy from pageable host memory, which blocks
+ * the host until the stream has drained — and legal inside a graph capture. */
+int deftet_put_host_ints(const long long *host_values, int n, int32_t *out_i32, long long *out_i64, float *out_f32, void *stream);
 
 /* ---------------------------------------------------------------------------------
  * A2-A6  adjacency builders.  Device variants take device pointers and a caller

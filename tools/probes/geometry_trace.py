@@ -40,8 +40,7 @@ boundary = stage("get_boundary_index", lambda: m.get_boundary_index(f3, t2, occ_
 en = stage("energies", lambda: m.energies(tet, inv_v))
 terms = stage("surface_terms_batched", lambda: surface_losses.surface_terms_batched(pos, boundary, gt, per_face=20, stacked=True))
 tm = stage("terms.mean + tuple", lambda: terms.mean(1, keepdim=True))
-tet2 = stage("gather_tet_pos (2)", lambda: m.gather_tet_pos(pos, idxB))
-cwo = stage("point_in_tet_occ", lambda: point_in_tet_occ(tet2, pts, pred))
+cwo = stage("occupancy_query", lambda: m.occupancy_query(pos, idxB, pts, pred, tet_bxfx4x3=tet))     # as step_demo.run_full_step
 cond, w, occ = cwo
 vvar, amips, edge = en
 sc, sa, sn = tm
