@@ -7,7 +7,7 @@ out=$1; shift
 cd "$(dirname "$0")/../.."
 args=()
 for a in "$@"; do
-    if [ "$a" = "--pit-only" ]; then args+=(--only point_in_tet.hip,common.cpp,reduce.hip,probe.hip,tet_order.hip)    # small library: point-in-tet + row dots only
+    if [ "$a" = "--pit-only" ]; then args+=(--only point_in_tet.hip,common.cpp,reduce.hip,probe.hip,tet_order.hip,vertex_ops.hip,prims.hip)    # small library: point-in-tet + row dots only
     else args+=("$a"); fi
 done
 python -m deftet_amd.build --out "$out" "${args[@]}" | tail -1
