@@ -124,7 +124,7 @@ extern "C" int deftet_profile_read(double *total_ms, long long *count)
     return DEFTET_OK;
 }
 
-extern "C" int deftet_version(void) { return 220; }   // 220: round 6 (deftet_tet_order_coherence_f32); 210: round 5 (the *_ex_* entry points, tet order, query box + misses)
+extern "C" int deftet_version(void) { return 221; }   // 221: round 6, second half (8-byte hit records, deftet_point_in_tet_bwd_to_vertices_f32, deftet_put_host_ints); 220: round 6 (deftet_tet_order_coherence_f32); 210: round 5 (the *_ex_* entry points, tet order, query box + misses)
 
 extern "C" const char *deftet_last_error(void) { return deftet::err_buf(); }
 

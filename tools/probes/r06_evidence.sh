@@ -1,9 +1,9 @@
 #!/bin/bash
 # Round 6 evidence pass (one box, once): everything lands in gpurun_out/r06/, the files that are judged are then copied to profiles/.
-#   gpurun -- 'DEFTET_COMMIT=<git rev-parse HEAD> tools/probes/r06_evidence.sh [part ...]'     parts: pmc bench prof ab tol (default: all)
+#   gpurun -- 'DEFTET_COMMIT=<git rev-parse HEAD> tools/probes/r06_evidence.sh [part ...]'     parts: pmc bench prof ab host tol (default: all)
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
 O=gpurun_out/r06; mkdir -p $O
-parts="${*:-pmc bench prof ab tol}"
+parts="${*:-pmc bench prof ab host tol}"
 B="python $PWD/bench.py"
 Q="--no-cpu-baseline --no-other-configs --no-bandwidth-probe --no-brute-force"
 has() { case " $parts " in *" $1 "*) return 0;; esac; return 1; }
@@ -41,6 +41,12 @@ if has ab; then
   for c in 2 1 3; do python tools/probes/sort_probe.py --config $c 2>/dev/null | tail -1 >> $O/r06_step_kernels.jsonl; done
   rm -f $O/r06_raster_kernels.jsonl
   for p in 0 1; do python tools/probes/raster_kernels_probe.py $p 2>/dev/null | tail -1 >> $O/r06_raster_kernels.jsonl; done
+fi
+if has host; then
+  python tools/probes/bwd_to_vertices_probe.py 2>/dev/null | grep '^{' > $O/r06_bwd_to_vertices.jsonl
+  python tools/probes/geometry_cpu_probe.py 2>/dev/null | grep '^{' > $O/r06_geometry_host_time.json
+  python tools/probes/host_call_probe.py 2>/dev/null | grep '^{' > $O/r06_host_call_cost.json
+  DEFTET_STEP_FUSED_BWD=0 $B --config 5 --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs --no-bandwidth-probe 2>/dev/null | tail -1 > $O/r06_geometry_line_two_stage_bwd.json
 fi
 if has tol; then
   rm -f $O/r06_tolerances.jsonl
