@@ -12,6 +12,7 @@ rng = np.random.default_rng(int(os.environ.get("FUZZ_SEED", "1")))
 g = torch.Generator(device=dev).manual_seed(7)
 t_end = time.time() + budget
 n = 0
+csr_cache = {}
 while time.time() < t_end:
     B = int(rng.integers(1, 5)); T = int(rng.choice([1, 2, 5, 63, 64, 65, 300, 1000, 3000, 20000])); Q = int(rng.choice([1, 2, 63, 64, 65, 255, 256, 257, 2047, 2048, 2049, 6000, 30000]))
     kind = rng.integers(0, 8)
@@ -97,10 +98,10 @@ while time.time() < t_end:
             if err > 2e-3 * max(ref_mag, 1e-30):
                 d = torch.where(f, (x - y).abs(), torch.zeros_like(x))
                 at = [int(v) for v in torch.unravel_index(d.argmax(), d.shape)]
-                words = hits[4 * B * T:4 * B * T + 3 * ((B + 63) // 64 * 64)].view(3, -1)[:, :B].tolist()
+                words = hits[2 * B * T:2 * B * T + 3 * ((B + 63) // 64 * 64)].view(3, -1)[:, :B].tolist()
                 qs = (cond[at[0], :, 0] == at[1]).nonzero().flatten().tolist()
                 nU = words[0][at[0]]
-                l0 = 4 * B * T + 3 * ((B + 63) // 64 * 64)
+                l0 = 2 * B * T + 3 * ((B + 63) // 64 * 64)
                 ul = hits[l0:l0 + B * Q].view(B, Q)[at[0], :nU].tolist()
                 print("queries won by that tet: %s (coordinates %s); in the uncovered list: %s" % (
                     qs, pts[at[0], qs].tolist(), [q in ul for q in qs]), flush=True)
@@ -108,7 +109,24 @@ while time.time() < t_end:
                 print("BACKWARD MISMATCH %s B=%d T=%d Q=%d kind=%d: err %g of %g at %s: hits-path %g vs list-path %g; "
                       "uncovered/ticket/irregular-query words %s; record of that tet %s" % (
                           name, B, T, Q, kind, err, ref_mag, at, x[tuple(at)].item(), y[tuple(at)].item(), words,
-                          hits[:4 * B * T].view(B, T, 4)[at[0], at[1]].tolist()), flush=True)
+                          hits[:2 * B * T].view(B, T, 2)[at[0], at[1]].tolist()), flush=True)
                 sys.exit(1)
+    # the fused backward onto the vertices (compacted rows + mask words, masked gather) with every tet owning its four vertices:
+    # grad_pos is then grad_tet itself — bit for bit on the record path, to round-off where the per-tet lists take over
+    csr = csr_cache.get(T)
+    if csr is None:
+        csr = csr_cache[T] = hip_ops.tet_vertex_csr(torch.arange(4 * T, device=dev, dtype=torch.int64).view(T, 4), 4 * T)
+    fv = hip_ops.point_in_tet_bwd_to_vertices(tet, pts, cond, gw, csr, 4 * T, grad_occ=go, hits=hits)
+    x, y = fv[0].view(B, T, 4, 3), a[0]
+    f = torch.isfinite(x) & torch.isfinite(y)
+    ok = bool((torch.isfinite(x) == torch.isfinite(y)).all())
+    if ok and f.any():
+        ok = bool((x[f] == y[f]).all()) if Q <= 2 * T else ((x - y)[f]).abs().max().item() <= 2e-3 * max(y[f].abs().max().item(), 1e-30)
+    if ok and Q <= 2 * T:
+        fp = torch.isfinite(fv[2]) & torch.isfinite(a[2])
+        ok = bool((fv[2][fp] == a[2][fp]).all())
+    if not ok:
+        print("TO-VERTICES MISMATCH B=%d T=%d Q=%d kind=%d falgo=%d scale=%g size=%g" % (B, T, Q, kind, falgo, scale, size), flush=True)
+        sys.exit(1)
     n += 1
 print("fuzz ok: %d random cases" % n, flush=True)
