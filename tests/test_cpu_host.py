@@ -446,8 +446,9 @@ def test_profiles_readme_quotes_what_the_evidence_files_hold():
     """profiles/README.md's rows for the evidence pass (bench lines, kernel tables, pmc summaries) are generated from the files: a
     refreshed pass that is not followed by tools/profiles_readme_rows.py leaves stale figures, and this fails."""
     import subprocess
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "profiles_readme_rows.py"), "--check"], capture_output=True, text=True, timeout=120)
-    assert r.returncode == 0, r.stdout + r.stderr
+    for script in ("profiles_readme_rows.py", "profiles_readme_r06.py"):       # round 5's rows; the round-6 section
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", script), "--check"], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, script + ": " + r.stdout + r.stderr
 
 
 def test_order_rule_and_topology_keys_are_pure_functions():
