@@ -154,6 +154,33 @@ def test_bwd_to_vertices_equals_two_call_form(cuda, res, n_query, batch, with_hi
     assert (acc[2] - ref[2]).abs().max() <= (0.0 if records else 1e-5 * ref[2].abs().max().item())
 
 
+def test_bwd_to_vertices_per_shape_index_lists(cuda):
+    """the reference hands every shape its own tetrahedron_bxfx4 (layers/DefTet/deftet.py:65-68): a CSR per shape (idx_batch == B),
+    each shape's list in another order — the masked gather walks per-shape incidence lists and per-shape mask words"""
+    from deftet_amd import hip_ops
+    res, batch, n_query = 8, 3, 700
+    verts, tets = grids.kuhn_grid(res)
+    pos = grids.jittered_positions(verts, res, batch, 0.1).astype(np.float32)
+    V, T = pos.shape[1], len(tets)
+    rng = np.random.default_rng(3)
+    idx_np = np.stack([tets[rng.permutation(T)] for _ in range(batch)]).astype(np.int64)
+    p, idx = torch.from_numpy(pos).to(cuda), torch.from_numpy(idx_np).to(cuda)
+    q = torch.from_numpy(grids.random_queries(batch, n_query)).to(cuda)
+    t = hip_ops.tet_gather(p, idx)
+    csr = hip_ops.tet_vertex_csr(idx, V)
+    assert csr[2] == batch
+    gen = torch.Generator(device=cuda).manual_seed(12)
+    pred = torch.rand(batch, T, device=cuda, generator=gen)
+    cond, w, occ, hits = hip_ops.point_in_tet(t, q, want_bary=True, pred_bxt=pred, want_hits=True)
+    gw = torch.randn(batch, n_query, 4, device=cuda, generator=gen)
+    go = torch.randn(batch, n_query, device=cuda, generator=gen)
+    want = _two_call(hip_ops, t, q, cond, gw, go, hits, csr, V, True)
+    got = hip_ops.point_in_tet_bwd_to_vertices(t, q, cond, gw, csr, V, want_grad_pts=True, grad_occ=go, hits=hits)
+    for a, b in zip(got, want):
+        assert bool((a == b).all())
+    assert want[0].abs().max() > 0
+
+
 def test_bwd_to_vertices_adversarial_and_empty(cuda):
     """overflowing / irregular tets (records marked, hits carried by the uncovered list), per-shape index lists, and the empty
     cases: the fused call still equals the two-call form"""
