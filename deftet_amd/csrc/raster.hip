@@ -24,6 +24,7 @@
 // accumulates its gradients in registers.
 #pragma clang fp contract(off)
 #include <cstring>
+#include <stdlib.h>
 
 #include "common.hpp"
 
@@ -996,6 +997,198 @@ __global__ __launch_bounds__(kBwdWaves * 64) void k_bwd_sorted(const float *__re
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// k_bwd_runs (round 6, D = 4): the same reduction by face over the sorted hits with FOUR CONSECUTIVE hits per lane.  k_bwd_sorted
+// spends two thirds of its time issuing vector instructions (181 M per launch at configs[4], 690 per wave: counters in
+// profiles/r06_pmc_bwd_sorted.json), and half of those are the segmented scan — eighteen values through six DPP steps for every
+// hit.  Here a lane first adds up its own four hits in registers (a run has ~30 hits: 87 % of the lanes hold one run only) and the
+// wave scans ONE value set per lane, a quarter of the scans per hit.  What a lane holds:
+//   * its TAIL — the hits at its end that share the lane's last key kl (all four when the lane is "uniform"); the tails are what
+//     the wave's segmented scan runs over, with kl as the segment key (sorted keys: equal kl <=> same run, and a lane that is not
+//     uniform has kl > the key before it, so its tail starts a segment by itself);
+//   * its HEAD — when the lane is not uniform, the leading hits with the lane's first key kf: that run ENDS inside the lane, its
+//     total is the head plus the scanned tail of the lane before (when that lane's kl == kf) and is written by this lane;
+//   * runs that begin and end inside the lane (faces with one or two hits): written at once.
+// Runs that cross wave boundaries are carried through LDS, runs that cross block boundaries add their parts atomically into the
+// cleared output — as in k_bwd_sorted.  Every order of additions is fixed: bit-reproducible from run to run.
+constexpr int kRunHPL = 4, kRunWaves = 4, kRunBlock = kRunWaves * 64 * kRunHPL;   // 1,024 sorted hits per block
+
+// the value of the lane below (wave_shr:1: across the 16-lane rows too; lane 0 receives 0)
+__device__ __forceinline__ float lane_below(float x)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ int lane_below(int x) { return __builtin_amdgcn_update_dpp(0, x, 0x138, 0xf, 0xf, false); }
+
+__global__ __launch_bounds__(kRunWaves * 64) void k_bwd_runs(const float *__restrict__ pix, const float *__restrict__ fxy,
+                                                             const float *__restrict__ feat, const float *__restrict__ gout,
+                                                             const unsigned *__restrict__ skey, const unsigned *__restrict__ sval,
+                                                             long long n, int F, int knum, float eps, float *gxy, float *gfeat)
+{
+    constexpr int D = 4, NV = 6 + 3 * D;                            // values per run: dL/dxy (6) and dL/dfeat (3 x 4)
+    __shared__ float s_sum[kRunWaves][NV];
+    __shared__ int s_one[kRunWaves];
+    const long long i0 = (long long)blockIdx.x * kRunBlock;
+    if (skey[i0] >= (unsigned)F) return;                            // the padding tail (keys are sorted): whole block idle
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const long long base = i0 + (long long)tid * kRunHPL;
+    unsigned k[kRunHPL], h[kRunHPL];
+    if (base + kRunHPL <= n) {                                      // (n is a multiple of nothing in particular: the last lanes load one by one)
+        const uint4 K = *reinterpret_cast<const uint4 *>(skey + base), H = *reinterpret_cast<const uint4 *>(sval + base);
+        k[0] = K.x; k[1] = K.y; k[2] = K.z; k[3] = K.w;
+        h[0] = H.x; h[1] = H.y; h[2] = H.z; h[3] = H.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < kRunHPL; ++j) {
+            k[j] = base + j < n ? skey[base + j] : (unsigned)F;
+            h[j] = base + j < n ? sval[base + j] : 0u;
+        }
+    }
+    const unsigned kprev = base > 0 ? skey[base - 1] : 0xFFFFFFFFu;                    // the key before the lane's first hit
+    const unsigned knext = base + kRunHPL < n ? skey[base + kRunHPL] : 0xFFFFFFFFu;    // the key after its last
+    // ---- the lane's four hits, added up run by run ------------------------------------------------------------------------
+    float acc[NV], A[NV];
+#pragma unroll
+    for (int q = 0; q < NV; ++q) A[q] = 0.f;
+    bool uniform = true;
+    unsigned kcur = k[0];
+#pragma unroll
+    for (int j = 0; j < kRunHPL; ++j) {
+        const bool valid = k[j] < (unsigned)F;
+        const int f = valid ? (int)k[j] : 0;
+        const unsigned hh = valid ? h[j] : 0u;
+        const int p = (int)(hh / (unsigned)knum);
+        const float2 px = reinterpret_cast<const float2 *>(pix)[p];
+        const float2 a = reinterpret_cast<const float2 *>(fxy)[f * 3], b = reinterpret_cast<const float2 *>(fxy)[f * 3 + 1],
+                     c = reinterpret_cast<const float2 *>(fxy)[f * 3 + 2];
+        const float4 g = reinterpret_cast<const float4 *>(gout)[hh];
+        const float4 f0 = reinterpret_cast<const float4 *>(feat)[f * 3], f1 = reinterpret_cast<const float4 *>(feat)[f * 3 + 1],
+                     f2 = reinterpret_cast<const float4 *>(feat)[f * 3 + 2];
+        const float m = b.x - a.x, pp = b.y - a.y, nn = c.x - a.x, q = c.y - a.y, s = px.x - a.x, t = px.y - a.y;
+        const float k1 = s * q - nn * t, k2 = m * t - s * pp, k3 = m * q - nn * pp;
+        const float den = k3 + eps;
+        const float w1 = k1 / den, w2 = k2 / den, w0 = 1 - w1 - w2;     // the forward's expressions, bit for bit
+        float gw1 = 0.f, gw2 = 0.f;                                  // dL/dw1, dL/dw2 (w0 = 1 - w1 - w2); channel order as k_bwd_sorted
+        gw1 += g.x * (f1.x - f0.x); gw2 += g.x * (f2.x - f0.x);
+        gw1 += g.y * (f1.y - f0.y); gw2 += g.y * (f2.y - f0.y);
+        gw1 += g.z * (f1.z - f0.z); gw2 += g.z * (f2.z - f0.z);
+        gw1 += g.w * (f1.w - f0.w); gw2 += g.w * (f2.w - f0.w);
+        const float gk1 = gw1 / den, gk2 = gw2 / den, gk3 = -(gw1 * w1 + gw2 * w2) / den;
+        const float gm = gk2 * t + gk3 * q, gp_ = -gk2 * s - gk3 * nn, gn = -gk1 * t - gk3 * pp, gq = gk1 * s + gk3 * m;
+        const float gs = gk1 * q - gk2 * pp, gt = -gk1 * nn + gk2 * m;
+        float cv[NV] = {-(gm + gn + gs), -(gp_ + gq + gt), gm, gp_, gn, gq,
+                        w0 * g.x, w0 * g.y, w0 * g.z, w0 * g.w, w1 * g.x, w1 * g.y, w1 * g.z, w1 * g.w, w2 * g.x, w2 * g.y, w2 * g.z, w2 * g.w};
+        if (!valid) {
+#pragma unroll
+            for (int q2 = 0; q2 < NV; ++q2) cv[q2] = 0.f;
+        }
+        if (j == 0) {
+#pragma unroll
+            for (int q2 = 0; q2 < NV; ++q2) acc[q2] = cv[q2];
+        } else {
+            const bool same = k[j] == kcur;
+            if (!same && !uniform && kcur < (unsigned)F) {          // rare: a run that began AND ended inside the lane (a face with <= 2 hits)
+                float *o = gxy + (size_t)kcur * 6, *of = gfeat + (size_t)kcur * 3 * D;
+#pragma unroll
+                for (int q2 = 0; q2 < 3; ++q2) reinterpret_cast<float2 *>(o)[q2] = make_float2(acc[2 * q2], acc[2 * q2 + 1]);
+#pragma unroll
+                for (int v3 = 0; v3 < 3; ++v3) reinterpret_cast<float4 *>(of)[v3] = make_float4(acc[6 + v3 * 4], acc[7 + v3 * 4], acc[8 + v3 * 4], acc[9 + v3 * 4]);
+            }
+            const bool firstEnds = !same && uniform;               // the lane's first run ends here: its sum waits for the carry
+#pragma unroll
+            for (int q2 = 0; q2 < NV; ++q2) {
+                A[q2] = firstEnds ? acc[q2] : A[q2];
+                acc[q2] = same ? acc[q2] + cv[q2] : cv[q2];
+            }
+            uniform = uniform && same;
+            kcur = k[j];
+        }
+    }
+    const unsigned kf = k[0], kl = kcur;
+    const bool tailValid = kl < (unsigned)F;
+    // ---- the tails: segmented scan over the wave, carry across the block's waves ------------------------------------------------
+    const SegFlags same = seg_flags(kl, lane);
+    const unsigned long long heads = __ballot(kprev != kl);         // a tail segment starts at this lane (kprev: the key before the lane)
+    const bool inFirstRun = (heads & ((2ull << lane) - 1ull)) == 0ull;
+    const bool contL = (heads & 1ull) == 0ull;                       // lane 0's tail continues the run of the wave before
+    const bool contR = (__ballot(knext == kl) >> 63) != 0ull;        // lane 63's tail goes on in the next wave
+    if (lane == 0) s_one[w] = (contL && heads == 0ull && contR) ? 1 : 0;
+    // the first HIT of the wave continues a run of the wave before (lane 0's head when it is not uniform, else = contL)
+    const bool contAny = __builtin_amdgcn_readfirstlane((int)(kf == kprev)) != 0;
+    seg_scan(acc, same);                                            // acc: inclusive sums of the tails inside the wave
+    __syncthreads();
+    if (lane == 63)
+#pragma unroll
+        for (int q = 0; q < NV; ++q) s_sum[w][q] = acc[q];
+    __syncthreads();
+    // what the waves before hold of the run that enters this wave (fixed order: nearest wave first, as k_bwd_sorted)
+    float cin = 0.f;
+    bool fromBefore = contAny && w == 0;
+    if (contAny && w > 0) {
+        if (lane < NV) {
+            for (int u = w - 1; u >= 0; --u) {
+                cin += s_sum[u][lane];
+                if (!s_one[u]) break;
+            }
+        }
+        int u = w - 1;
+        while (u > 0 && s_one[u]) --u;
+        fromBefore = u == 0 && s_one[0];
+    }
+    const lanemask_t mFirst = __ballot(inFirstRun && contL);
+    float cinv[NV];
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        cinv[q] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cin), q));
+        acc[q] += sel_f(mFirst, cinv[q], 0.f);
+    }
+    const bool tailExt = inFirstRun && contL && fromBefore;          // the tail's run began in an earlier block
+    // ---- the heads of the lanes that are not uniform: head + what the lanes before hold of that run ----------------------------
+    const bool headCont = kf == kprev;                               // the head continues the run of the lane (or wave) before
+    const int belowExt = lane_below((int)tailExt);
+    const bool headExt = lane == 0 ? (headCont && fromBefore) : (headCont && belowExt != 0);
+    const lanemask_t mHead = __ballot(!uniform);
+    if (mHead != 0ull) {                                            // (wave-uniform: most waves of large faces have none)
+        const lanemask_t mCarry = __ballot(!uniform && headCont), mLane0 = __ballot(lane == 0);
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            const float below = sel_f(mLane0, cinv[q], lane_below(acc[q]));   // lane 0: the carry of the waves before
+            A[q] += sel_f(mCarry, below, 0.f);
+        }
+        if (!uniform && kf < (unsigned)F) {
+            float *o = gxy + (size_t)kf * 6, *of = gfeat + (size_t)kf * 3 * D;
+            if (!headExt) {
+#pragma unroll
+                for (int q = 0; q < 3; ++q) reinterpret_cast<float2 *>(o)[q] = make_float2(A[2 * q], A[2 * q + 1]);
+#pragma unroll
+                for (int v3 = 0; v3 < 3; ++v3) reinterpret_cast<float4 *>(of)[v3] = make_float4(A[6 + v3 * 4], A[7 + v3 * 4], A[8 + v3 * 4], A[9 + v3 * 4]);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 6; ++q) unsafeAtomicAdd(o + q, A[q]);
+#pragma unroll
+                for (int q = 0; q < 3 * D; ++q) unsafeAtomicAdd(of + q, A[6 + q]);
+            }
+        }
+    }
+    // ---- the tails that end with their lane; the block's last lane hands an unfinished run to the next block -------------------
+    const bool ends = tailValid && knext != kl;
+    const bool spill = tid == kRunWaves * 64 - 1 && tailValid && knext == kl;
+    if (ends || spill) {
+        float *o = gxy + (size_t)kl * 6, *of = gfeat + (size_t)kl * 3 * D;
+        if (ends && !tailExt) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) reinterpret_cast<float2 *>(o)[q] = make_float2(acc[2 * q], acc[2 * q + 1]);
+#pragma unroll
+            for (int v3 = 0; v3 < 3; ++v3) reinterpret_cast<float4 *>(of)[v3] = make_float4(acc[6 + v3 * 4], acc[7 + v3 * 4], acc[8 + v3 * 4], acc[9 + v3 * 4]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 6; ++q) unsafeAtomicAdd(o + q, acc[q]);
+#pragma unroll
+            for (int q = 0; q < 3 * D; ++q) unsafeAtomicAdd(of + q, acc[6 + q]);
+        }
+    }
+}
+
 struct BwdLayout {
     size_t bytes, tmpBytes;
     unsigned *skey, *sval;
@@ -1219,7 +1412,14 @@ extern "C" int deftet_sparse_render_bwd_f32(const float *pix, const float *fxy, 
     DEFTET_LAUNCH(k_bwd_sorted<DT>, dim3((unsigned)((n + kBwdWaves * 64 - 1) / (kBwdWaves * 64))), dim3(kBwdWaves * 64), st, pix + (size_t)b * P * 2, fxy + (size_t)b * F * 6, \
                   feat + (size_t)b * F * 3 * D, gout + (size_t)b * n * D, (const unsigned *)L.skey, (const unsigned *)L.sval, n, F, D,   \
                   knum, eps, gxy + (size_t)b * F * 6, gfeat + (size_t)b * F * 3 * D)
-        if (D == 4 && (((uintptr_t)feat | (uintptr_t)gout | (uintptr_t)gfeat) & 15) == 0) RAST_BWD(4);
+        // DEFTET_RAST_BWD=sorted: the round-5 kernel for D = 4 as well (A/B runs)
+        static const bool runs = [] { const char *e = getenv("DEFTET_RAST_BWD"); return !(e && e[0] == 's'); }();
+        const bool d4 = D == 4 && (((uintptr_t)feat | (uintptr_t)gout | (uintptr_t)gfeat) & 15) == 0;
+        if (d4 && runs)
+            DEFTET_LAUNCH(k_bwd_runs, dim3((unsigned)((n + kRunBlock - 1) / kRunBlock)), dim3(kRunWaves * 64), st, pix + (size_t)b * P * 2,
+                          fxy + (size_t)b * F * 6, feat + (size_t)b * F * 3 * D, gout + (size_t)b * n * D, (const unsigned *)L.skey,
+                          (const unsigned *)L.sval, n, F, knum, eps, gxy + (size_t)b * F * 6, gfeat + (size_t)b * F * 3 * D);
+        else if (d4) RAST_BWD(4);
         else RAST_BWD(0);
 #undef RAST_BWD
     }

@@ -35,7 +35,7 @@ def main():
     step()
     torch.cuda.synchronize()
     out = {"lib": os.path.basename(os.environ.get("DEFTET_HIP_LIB", "product")), "policy": ["nearest", "first"][policy]}
-    for k in ("k_pix_raster", "k_pix_emit", "k_bwd_sorted"):
+    for k in ("k_pix_raster", "k_pix_emit", "k_bwd_sorted", "k_bwd_runs"):      # (the backward runs ONE of the last two: the other reads 0)
         lib.deftet_profile_select(k.encode())
         for _ in range(reps):
             step()
