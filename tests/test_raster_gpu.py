@@ -184,6 +184,72 @@ def test_backward_other_feature_widths_and_batches(cuda, oracle, D, B):
     assert (face >= 0).sum().item() > 1000 * B
 
 
+@pytest.mark.parametrize("npix,knum", [(23, 3), (37, 5), (25, 1), (31, 64)])
+def test_backward_four_hits_per_lane_kernel_on_odd_sizes(cuda, oracle, npix, knum):
+    """k_bwd_runs (D = 4: four consecutive sorted hits per lane): hit counts that are no multiple of four (the last lanes load one by
+    one), k = 1 (runs of one or two hits: heads, tails and whole runs inside a lane), against fp64 autograd and against the round-5
+    kernel (DEFTET_RAST_BWD=sorted is read once per process: the comparison runs in a child process)"""
+    from deftet_amd.render import deftet_sparse_render
+    fz, fxy, ff = projected_grid(6)
+    pix, rngs = pixel_grid(npix)
+    pix = pix * 0.6
+    tp, tr, tz = (torch.from_numpy(x).to(cuda) for x in (pix, rngs, fz))
+    txy = torch.from_numpy(fxy).to(cuda).requires_grad_(True)
+    tff = torch.from_numpy(ff).to(cuda).requires_grad_(True)
+    feat, face = deftet_sparse_render(tp, tr, tz, txy, tff, knum=knum)
+    assert (pix.shape[1] * knum) % 4 != 0 or knum == 64
+    go = torch.rand(feat.shape, device=cuda, generator=torch.Generator(device=cuda).manual_seed(7))
+    gxy, gff = torch.autograd.grad(feat, (txy, tff), go)
+    xy64 = txy.detach().double().requires_grad_(True)
+    ff64 = tff.detach().double().requires_grad_(True)
+    feat64 = oracle.sparse_render_torch(tp.double(), xy64, ff64, face)
+    wxy, wff = torch.autograd.grad(feat64, (xy64, ff64), go.double())
+    from tests.tol import check_close
+    for nm, got, want in (("xy", gxy, wxy), ("feat", gff, wff)):
+        assert want.abs().max().item() > 0
+        check_close("A12 grad_%s (k_bwd_runs), %dx%d pixels k=%d vs fp64 autograd" % (nm, npix, npix, knum), got, want, 6e-7, elem_rel=3e-5)
+    # twice the same bits
+    gxy2, gff2 = torch.autograd.grad(deftet_sparse_render(tp, tr, tz, txy, tff, knum=knum)[0], (txy, tff), go)
+    assert torch.equal(gxy, gxy2) and torch.equal(gff, gff2)
+
+
+def test_backward_kernels_agree_in_a_child_process(cuda):
+    """DEFTET_RAST_BWD=sorted (the round-5 reduction, one hit per lane) and the default (k_bwd_runs) on the same inputs: the same
+    gradients up to the order of the fp32 additions"""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "from tests.test_raster_gpu import projected_grid, pixel_grid\n"
+        "from deftet_amd.render import deftet_sparse_render\n"
+        "dev = torch.device('cuda:0')\n"
+        "fz, fxy, ff = projected_grid(8)\n"
+        "pix, rngs = pixel_grid(61)\n"
+        "t = [torch.from_numpy(x).to(dev) for x in (pix * 0.6, rngs, fz, fxy, ff)]\n"
+        "t[3].requires_grad_(True); t[4].requires_grad_(True)\n"
+        "feat, face = deftet_sparse_render(*t, knum=33)\n"
+        "go = torch.rand(feat.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(1))\n"
+        "g = torch.autograd.grad(feat, (t[3], t[4]), go)\n"
+        "np.savez(sys.argv[1], gxy=g[0].cpu().numpy(), gff=g[1].cpu().numpy())\n" % root)
+    outs = []
+    with tempfile.TemporaryDirectory() as d:
+        for mode in ("sorted", "runs"):
+            f = os.path.join(d, mode + ".npz")
+            env = dict(os.environ, DEFTET_RAST_BWD=mode)
+            r = subprocess.run([sys.executable, "-c", code, f], env=env, capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stdout + r.stderr
+            outs.append(dict(np.load(f)))
+    for k in ("gxy", "gff"):
+        a, b = outs[0][k], outs[1][k]
+        assert np.abs(b).max() > 0
+        assert np.abs(a - b).max() <= 2e-6 * np.abs(a).max(), (k, np.abs(a - b).max(), np.abs(a).max())
+        assert ((a == 0) == (b == 0)).all()                             # faces without hits: exactly zero in both
+
+
 def test_backward_face_with_thousands_of_hits(cuda, oracle):
     """two big triangles covering a 96 x 96 pixel grid: 9,216 hits per face, i.e. runs of sorted hits that span nine
     blocks of the backward kernel (partial sums meet through float atomics), next to small faces"""
