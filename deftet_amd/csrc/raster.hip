@@ -1044,7 +1044,7 @@ __global__ __launch_bounds__(kRunWaves * 64) void k_bwd_runs(const float *__rest
             h[j] = base + j < n ? sval[base + j] : 0u;
         }
     }
-    const unsigned kprev = base > 0 ? skey[base - 1] : 0xFFFFFFFFu;                    // the key before the lane's first hit
+    const unsigned kprev = base == 0 ? 0xFFFFFFFFu : base - 1 < n ? skey[base - 1] : (unsigned)F;   // the key before the lane's first hit (past the end: padding)
     const unsigned knext = base + kRunHPL < n ? skey[base + kRunHPL] : 0xFFFFFFFFu;    // the key after its last
     // ---- the lane's four hits, added up run by run ------------------------------------------------------------------------
     float acc[NV], A[NV];

@@ -52,5 +52,6 @@ if has tol; then
   rm -f $O/r06_tolerances.jsonl
   DEFTET_TOLERANCE_REPORT=$PWD/$O/r06_tolerances.jsonl timeout 1500 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1
   grep -v amdgpu.ids $O/pytest_gpu.log | tail -3
+  grep -E '[0-9]+ passed' $O/pytest_gpu.log | tail -1 > $O/r06_pytest_gpu.txt
 fi
 ls -la $O
