@@ -727,6 +727,7 @@ __global__ __launch_bounds__(256) void k_pix_emit(const int4 *__restrict__ hits,
     if (p >= P) return;
     const int n = nhit[p];
     const int4 *h = hits + (size_t)p * knum;
+    const bool vec4 = D == 4 && (((uintptr_t)feat | (uintptr_t)out_feat) & 15) == 0;   // (launch-uniform)
     for (int i0 = 0; i0 < knum; i0 += 64) {                          // (wave-uniform trip count)
         const int i = i0 + lane;
         const bool mine = i < n;
@@ -764,12 +765,19 @@ __global__ __launch_bounds__(256) void k_pix_emit(const int4 *__restrict__ hits,
             out_face[o] = me.x;
             if (out_w) { out_w[o * 3] = w0; out_w[o * 3 + 1] = w1; out_w[o * 3 + 2] = w2; }
             const float *ff = feat + (size_t)me.x * 3 * D;
-            for (int d = 0; d < D; ++d) out_feat[o * D + d] = (w0 * ff[d] + w1 * ff[D + d]) + w2 * ff[2 * D + d];
+            if (vec4) {                                            // D = 4, 16-byte aligned: three 16-byte gathers, one 16-byte store (same expression per channel)
+                const float4 f0 = reinterpret_cast<const float4 *>(ff)[0], f1 = reinterpret_cast<const float4 *>(ff)[1], f2 = reinterpret_cast<const float4 *>(ff)[2];
+                reinterpret_cast<float4 *>(out_feat)[o] = make_float4((w0 * f0.x + w1 * f1.x) + w2 * f2.x, (w0 * f0.y + w1 * f1.y) + w2 * f2.y,
+                                                                       (w0 * f0.z + w1 * f1.z) + w2 * f2.z, (w0 * f0.w + w1 * f1.w) + w2 * f2.w);
+            } else {
+                for (int d = 0; d < D; ++d) out_feat[o * D + d] = (w0 * ff[d] + w1 * ff[D + d]) + w2 * ff[2 * D + d];
+            }
         } else if (i < knum) {
             const size_t o = (size_t)p * knum + i;                 // slots n..knum-1 stay empty
             out_face[o] = -1;
             if (out_w) { out_w[o * 3] = 0.f; out_w[o * 3 + 1] = 0.f; out_w[o * 3 + 2] = 0.f; }
-            for (int d = 0; d < D; ++d) out_feat[o * D + d] = 0.f;
+            if (vec4) reinterpret_cast<float4 *>(out_feat)[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+            else for (int d = 0; d < D; ++d) out_feat[o * D + d] = 0.f;
         }
     }
 }
