@@ -227,14 +227,17 @@ def test_backward_kernels_agree_in_a_child_process(cuda):
         "from tests.test_raster_gpu import projected_grid, pixel_grid\n"
         "from deftet_amd.render import deftet_sparse_render\n"
         "dev = torch.device('cuda:0')\n"
-        "fz, fxy, ff = projected_grid(8)\n"
-        "pix, rngs = pixel_grid(61)\n"
-        "t = [torch.from_numpy(x).to(dev) for x in (pix * 0.6, rngs, fz, fxy, ff)]\n"
-        "t[3].requires_grad_(True); t[4].requires_grad_(True)\n"
-        "feat, face = deftet_sparse_render(*t, knum=33)\n"
-        "go = torch.rand(feat.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(1))\n"
-        "g = torch.autograd.grad(feat, (t[3], t[4]), go)\n"
-        "np.savez(sys.argv[1], gxy=g[0].cpu().numpy(), gff=g[1].cpu().numpy())\n" % root)
+        "out = {}\n"
+        "for case, (res, npix, knum, zoom) in enumerate([(8, 61, 33, 0.6), (4, 97, 7, 0.5), (10, 40, 64, 0.25), (6, 128, 2, 0.7), (12, 50, 16, 0.9)]):\n"
+        "    fz, fxy, ff = projected_grid(res)\n"
+        "    pix, rngs = pixel_grid(npix)\n"
+        "    t = [torch.from_numpy(x).to(dev) for x in (pix * zoom, rngs, fz, fxy, ff)]\n"
+        "    t[3].requires_grad_(True); t[4].requires_grad_(True)\n"
+        "    feat, face = deftet_sparse_render(*t, knum=knum)\n"
+        "    go = torch.rand(feat.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(case))\n"
+        "    g = torch.autograd.grad(feat, (t[3], t[4]), go)\n"
+        "    out['gxy%%d' %% case] = g[0].cpu().numpy(); out['gff%%d' %% case] = g[1].cpu().numpy()\n"
+        "np.savez(sys.argv[1], **out)\n" % root)
     outs = []
     with tempfile.TemporaryDirectory() as d:
         for mode in ("sorted", "runs"):
@@ -243,7 +246,8 @@ def test_backward_kernels_agree_in_a_child_process(cuda):
             r = subprocess.run([sys.executable, "-c", code, f], env=env, capture_output=True, text=True, timeout=600)
             assert r.returncode == 0, r.stdout + r.stderr
             outs.append(dict(np.load(f)))
-    for k in ("gxy", "gff"):
+    assert len(outs[0]) == 10
+    for k in sorted(outs[0]):                                           # five scenes (coarse / fine faces, k from 2 to 64, zoomed in and out)
         a, b = outs[0][k], outs[1][k]
         assert np.abs(b).max() > 0
         assert np.abs(a - b).max() <= 2e-6 * np.abs(a).max(), (k, np.abs(a - b).max(), np.abs(a).max())
